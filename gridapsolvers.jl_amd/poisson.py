@@ -1,0 +1,356 @@
+"""Structured-grid Poisson hierarchy generator (driver-side input synthesis).
+
+Stands in for the Gridap setup the reference's tests run before they reach the
+hot path (test/LinearSolvers/GMGTests.jl:204-224 `gmg_poisson_driver`,
+src/MultilevelTools/FESpaceHierarchies.jl:151-174 `compute_hierarchy_matrices`,
+src/MultilevelTools/GridTransferOperators.jl:391-401 prolongation semantics):
+
+  * domain (0,1)^d, uniform Cartesian cells, Lagrangian Q1 / Q2,
+    Dirichlet on the whole boundary ("boundary" tag, GMGTests.jl:213);
+  * bilinear form  a(u,v) = int grad(v).grad(u)   (GMGTests.jl:208);
+  * per-level re-discretised matrices (not Galerkin RAP; they coincide here);
+  * prolongation P_ij = Phi_j^H(x_i^h) on free dofs (dv_H = 0 in :residual
+    mode, GridTransferOperators.jl:226,230), restriction R = P^T
+    (GridTransferOperators.jl:202-209,536-547 on nested meshes);
+  * vertex-star patches (PatchTopology(ReferenceFE{0},model), assembly=:star,
+    GMGTests.jl:18-36).
+
+Everything is tensor-product: A = K(x)M(x)M + M(x)K(x)M + M(x)M(x)K with 1-D
+stiffness K and mass M.  Free dofs are numbered lexicographically, x fastest.
+The *structural* pattern is kept (3-D Q1: 27 entries/row including the six
+exact-zero face couplings), which is what a finite-element assembler stores.
+
+This module is host-side numpy only; nothing in it is on the timed path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = [
+    "CSR", "poisson_matrix", "prolongation", "dirichlet_lift_rhs", "nodal_values",
+    "l2_error_sq", "vertex_star_patches", "build_hierarchy", "random_rhs", "level_sizes",
+]
+
+
+class CSR:
+    """Plain CSR container: int64 row pointers, int32 columns, fp64 values (0-based)."""
+
+    def __init__(self, shape, ptr, idx, val):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+        self.idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self.val = np.ascontiguousarray(val, dtype=np.float64)
+
+    @property
+    def nnz(self):
+        return int(self.ptr[-1])
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.val, self.idx, self.ptr), shape=self.shape)
+
+    def transpose(self):
+        t = self.to_scipy().T.tocsr()
+        t.sort_indices()
+        return CSR(t.shape, t.indptr, t.indices, t.data)
+
+    def matvec(self, x):
+        return self.to_scipy() @ x
+
+
+# --------------------------------------------------------------------------
+# 1-D building blocks
+# --------------------------------------------------------------------------
+def _elem_1d(order, h):
+    if order == 1:
+        K = np.array([[1.0, -1.0], [-1.0, 1.0]]) / h
+        M = np.array([[2.0, 1.0], [1.0, 2.0]]) * (h / 6.0)
+    elif order == 2:  # local nodes: left, mid, right
+        K = np.array([[7.0, -8.0, 1.0], [-8.0, 16.0, -8.0], [1.0, -8.0, 7.0]]) / (3.0 * h)
+        M = np.array([[4.0, 2.0, -1.0], [2.0, 16.0, 2.0], [-1.0, 2.0, 4.0]]) * (h / 30.0)
+    else:
+        raise ValueError("order must be 1 or 2")
+    return K, M
+
+
+def _assemble_1d(n, order):
+    """Dense 1-D stiffness / mass on all order*n+1 nodes, and the element pattern."""
+    h = 1.0 / n
+    nn = order * n + 1
+    Ke, Me = _elem_1d(order, h)
+    K = np.zeros((nn, nn))
+    M = np.zeros((nn, nn))
+    S = np.zeros((nn, nn), dtype=bool)
+    for e in range(n):
+        sl = slice(order * e, order * e + order + 1)
+        K[sl, sl] += Ke
+        M[sl, sl] += Me
+        S[sl, sl] = True
+    return K, M, S
+
+
+def _padded_rows(S, mats, rows, col_map):
+    """Rows `rows` of the 1-D operators as fixed-width padded tables.
+
+    Returns cols[nr,W] (mapped through col_map, -1 = absent / non-free) and a
+    list of vals[nr,W] (one per matrix in mats)."""
+    nr = len(rows)
+    W = int(S[rows].sum(axis=1).max()) if nr else 1
+    cols = -np.ones((nr, W), dtype=np.int64)
+    vals = [np.zeros((nr, W)) for _ in mats]
+    for a, r in enumerate(rows):
+        cc = np.nonzero(S[r])[0]
+        k = 0
+        for c in cc:
+            if col_map[c] < 0:
+                continue
+            cols[a, k] = col_map[c]
+            for t, Mx in enumerate(mats):
+                vals[t][a, k] = Mx[r, c]
+            k += 1
+    return cols, vals
+
+
+def _axis_tables(n, order, dim_active):
+    """(ncols_free, cols[nr,W], Kvals, Mvals) for one axis; a collapsed axis
+    (2-D problems) is the 1x1 identity for M and zero for K."""
+    if not dim_active:
+        return 1, np.zeros((1, 1), dtype=np.int64), np.zeros((1, 1)), np.ones((1, 1))
+    K, M, S = _assemble_1d(n, order)
+    nn = order * n + 1
+    free = np.arange(1, nn - 1)
+    col_map = -np.ones(nn, dtype=np.int64)
+    col_map[free] = np.arange(len(free))
+    cols, (kv, mv) = _padded_rows(S, [K, M], free, col_map)
+    return len(free), cols, kv, mv
+
+
+def _tensor_csr(axes, terms, ncols_axes):
+    """CSR of sum_t  Z_t (x) Y_t (x) X_t  (x fastest) from padded 1-D row tables.
+
+    axes  = [(cols_x, ...), (cols_y, ...), (cols_z, ...)] padded col tables
+    terms = list of (vx, vy, vz) padded value tables
+    Rows are emitted in lexicographic order with sorted columns, so no global
+    sort is needed.  Processed in slabs over z rows to bound memory."""
+    cx, cy, cz = axes
+    nx, ny, nz = cx.shape[0], cy.shape[0], cz.shape[0]
+    ncx, ncy, ncz = ncols_axes
+    Wx, Wy, Wz = cx.shape[1], cy.shape[1], cz.shape[1]
+    mx, my, mz = cx >= 0, cy >= 0, cz >= 0
+    cntx, cnty, cntz = mx.sum(1), my.sum(1), mz.sum(1)
+    row_nnz = (cntz[:, None, None] * cnty[None, :, None] * cntx[None, None, :]).reshape(-1)
+    ptr = np.zeros(nx * ny * nz + 1, dtype=np.int64)
+    np.cumsum(row_nnz, out=ptr[1:])
+    nnz = int(ptr[-1])
+    idx = np.empty(nnz, dtype=np.int32)
+    val = np.empty(nnz, dtype=np.float64)
+    per_z = ny * nx * Wz * Wy * Wx
+    zchunk = max(1, int(2.0e7 // max(per_z, 1)))
+    for z0 in range(0, nz, zchunk):
+        z1 = min(nz, z0 + zchunk)
+        # layout [z, y, x, wz, wy, wx]
+        mask = (mz[z0:z1, None, None, :, None, None] & my[None, :, None, None, :, None]
+                & mx[None, None, :, None, None, :])
+        col = (cz[z0:z1, None, None, :, None, None] * (ncy * ncx)
+               + cy[None, :, None, None, :, None] * ncx
+               + cx[None, None, :, None, None, :])
+        v = None
+        for (vx, vy, vz) in terms:
+            t = (vz[z0:z1, None, None, :, None, None] * vy[None, :, None, None, :, None]
+                 * vx[None, None, :, None, None, :])
+            v = t if v is None else v + t
+        lo, hi = ptr[z0 * ny * nx], ptr[z1 * ny * nx]
+        idx[lo:hi] = col[mask]
+        val[lo:hi] = v[mask]
+    return CSR((nx * ny * nz, ncx * ncy * ncz), ptr, idx, val)
+
+
+def _dims(ncells):
+    nc = tuple(int(c) for c in ncells)
+    if len(nc) not in (2, 3):
+        raise ValueError("2-D or 3-D only")
+    return nc + (1,) * (3 - len(nc)), len(nc)
+
+
+def level_sizes(ncells, order):
+    """Number of free dofs (order*n-1 per active direction)."""
+    nc, d = _dims(ncells)
+    return int(np.prod([order * nc[k] - 1 for k in range(d)]))
+
+
+def poisson_matrix(ncells, order=1) -> CSR:
+    """Free-free block of the Q`order` stiffness matrix of -Laplace on (0,1)^d."""
+    nc, d = _dims(ncells)
+    tabs = [_axis_tables(nc[k], order, k < d) for k in range(3)]
+    ncols = [t[0] for t in tabs]
+    cols = [t[1] for t in tabs]
+    K = [t[2] for t in tabs]
+    M = [t[3] for t in tabs]
+    terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
+    if d == 3:
+        terms.append((M[0], M[1], K[2]))
+    return _tensor_csr(cols, terms, ncols)
+
+
+def _interp_1d(nc_coarse, order):
+    """Dense 1-D interpolation, fine nodes (2*nc cells) x coarse nodes."""
+    nH = order * nc_coarse + 1
+    nh = order * 2 * nc_coarse + 1
+    P = np.zeros((nh, nH))
+    S = np.zeros((nh, nH), dtype=bool)
+    for E in range(nc_coarse):
+        for a in range(2 * order + 1):           # fine nodes inside coarse cell E
+            xi = a / (2.0 * order)
+            if order == 1:
+                phi = [1.0 - xi, xi]
+            else:
+                phi = [2.0 * (xi - 0.5) * (xi - 1.0), 4.0 * xi * (1.0 - xi), 2.0 * xi * (xi - 0.5)]
+            i = 2 * order * E + a
+            for b, w in enumerate(phi):
+                if w != 0.0:
+                    P[i, order * E + b] = w
+                    S[i, order * E + b] = True
+    return P, S
+
+
+def prolongation(ncells_coarse, order=1) -> CSR:
+    """P : coarse free dofs -> fine free dofs (fine mesh = coarse refined x2).
+
+    y = P x  <=>  interpolate!(uH, fv_h, Uh) with zero Dirichlet values
+    (GridTransferOperators.jl:391-401, :226,230)."""
+    nc, d = _dims(ncells_coarse)
+    cols, vals, ncols = [], [], []
+    for k in range(3):
+        if k >= d:
+            cols.append(np.zeros((1, 1), dtype=np.int64)); vals.append(np.ones((1, 1))); ncols.append(1)
+            continue
+        P, S = _interp_1d(nc[k], order)
+        nh, nH = P.shape
+        free_h = np.arange(1, nh - 1)
+        col_map = -np.ones(nH, dtype=np.int64)
+        col_map[1:nH - 1] = np.arange(nH - 2)
+        c, (v,) = _padded_rows(S, [P], free_h, col_map)
+        cols.append(c); vals.append(v); ncols.append(nH - 2)
+    return _tensor_csr(cols, [tuple(vals)], ncols)
+
+
+def _apply_axes(G, mats):
+    """(Mz (x) My (x) Mx) applied to G[z,y,x]."""
+    out = G
+    out = np.tensordot(out, mats[0].T, axes=([2], [0]))                # x
+    out = np.moveaxis(np.tensordot(out, mats[1].T, axes=([1], [0])), 2, 1)  # y
+    out = np.moveaxis(np.tensordot(out, mats[2].T, axes=([0], [0])), 2, 0)  # z
+    return out
+
+
+def _full_1d(nc, order, d):
+    Ks, Ms, nn = [], [], []
+    for k in range(3):
+        if k < d:
+            K, M, _ = _assemble_1d(nc[k], order)
+        else:
+            K, M = np.zeros((1, 1)), np.ones((1, 1))
+        Ks.append(K); Ms.append(M); nn.append(K.shape[0])
+    return Ks, Ms, nn
+
+
+def _node_coords(nc, order, d):
+    xs = [np.linspace(0.0, 1.0, order * nc[k] + 1) if k < d else np.zeros(1) for k in range(3)]
+    Z, Y, X = np.meshgrid(xs[2], xs[1], xs[0], indexing="ij")
+    return X, Y, Z
+
+
+def _interior(nn, d):
+    return tuple(slice(1, nn[k] - 1) if k < d else slice(0, 1) for k in (2, 1, 0))
+
+
+def dirichlet_lift_rhs(ncells, order=1, u=None):
+    """b = -A_fd u_d for f = 0: the rhs of the reference's test problem
+    u = x1 + x2 (GMGTests.jl:204-206: f = -Laplace(u) = 0)."""
+    nc, d = _dims(ncells)
+    if u is None:
+        u = lambda X, Y, Z: X + Y
+    Ks, Ms, nn = _full_1d(nc, order, d)
+    X, Y, Z = _node_coords(nc, order, d)
+    G = u(X, Y, Z).astype(np.float64)
+    G[_interior(nn, d)] = 0.0                                  # keep only Dirichlet values
+    AG = _apply_axes(G, [Ks[0], Ms[1], Ms[2]]) + _apply_axes(G, [Ms[0], Ks[1], Ms[2]])
+    if d == 3:
+        AG = AG + _apply_axes(G, [Ms[0], Ms[1], Ks[2]])
+    return np.ascontiguousarray(-AG[_interior(nn, d)].reshape(-1))
+
+
+def nodal_values(ncells, order=1, u=None):
+    """Nodal interpolant of u on the free dofs (exact discrete solution for u in the FE space)."""
+    nc, d = _dims(ncells)
+    if u is None:
+        u = lambda X, Y, Z: X + Y
+    nn = [order * nc[k] + 1 if k < d else 1 for k in range(3)]
+    X, Y, Z = _node_coords(nc, order, d)
+    return np.ascontiguousarray(u(X, Y, Z)[_interior(nn, d)].reshape(-1).astype(np.float64))
+
+
+def l2_error_sq(ncells, order, x, u=None):
+    """E = int (u_h - u)^2 = e^T M e for u in the FE space -- the quantity the
+    reference tests print / assert (SmoothersTests.jl:36-43, GMGTests.jl:134-142)."""
+    nc, d = _dims(ncells)
+    Ks, Ms, nn = _full_1d(nc, order, d)
+    e = np.zeros((nn[2], nn[1], nn[0]))
+    e[_interior(nn, d)] = (np.asarray(x) - nodal_values(ncells, order, u)).reshape(e[_interior(nn, d)].shape)
+    return float(np.sum(e * _apply_axes(e, Ms)))
+
+
+def random_rhs(n, seed=20240601):
+    """Problem P-rand: b ~ U(-1,1) (deterministic)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    return rng.uniform(-1.0, 1.0, size=n)
+
+
+def vertex_star_patches(ncells, order=1):
+    """One patch per mesh vertex: the free dofs strictly inside the union of
+    the cells touching that vertex (Q1: the vertex dof; Q2: up to 3^d dofs).
+    Returns (patch_ptr int64, patch_dofs int32), patches in lexicographic
+    vertex order, dofs sorted ascending inside each patch."""
+    nc, d = _dims(ncells)
+    nf = [order * nc[k] - 1 if k < d else 1 for k in range(3)]
+
+    def axis_lists(k):
+        if k >= d:
+            return [np.zeros(1, dtype=np.int64)]
+        out = []
+        for v in range(nc[k] + 1):
+            node = order * v
+            lo, hi = node - (order - 1), node + (order - 1)
+            nodes = np.arange(max(lo, 1), min(hi, order * nc[k] - 1) + 1)
+            out.append(nodes - 1)                        # free numbering
+        return out
+
+    ax, ay, az = axis_lists(0), axis_lists(1), axis_lists(2)
+    ptr = [0]
+    dofs = []
+    for lz in az:
+        for ly in ay:
+            for lx in ax:
+                if len(lx) == 0 or len(ly) == 0 or len(lz) == 0:
+                    ptr.append(ptr[-1]); continue
+                g = (lz[:, None, None] * (nf[1] * nf[0]) + ly[None, :, None] * nf[0] + lx[None, None, :]).reshape(-1)
+                dofs.append(g)
+                ptr.append(ptr[-1] + g.size)
+    dofs = np.concatenate(dofs) if dofs else np.zeros(0, dtype=np.int64)
+    return np.asarray(ptr, dtype=np.int64), dofs.astype(np.int32)
+
+
+def build_hierarchy(ncells_fine, nlevels, order=1):
+    """Level 1 = finest (reference convention, ModelHierarchies.jl:80-111).
+
+    Returns dict(mats=[A_1..A_L], prolongations=[P_1..P_{L-1}] (P_l: level l+1 -> l),
+    restrictions=[R_l = P_l^T], ncells=[...], order=order)."""
+    nc = tuple(int(c) for c in ncells_fine)
+    cells = [tuple(c // (2 ** l) for c in nc) for l in range(nlevels)]
+    for l in range(nlevels):
+        if any(cells[l][k] * 2 ** l != nc[k] or cells[l][k] < 2 for k in range(len(nc))):
+            raise ValueError("ncells must be divisible by 2^(nlevels-1) with >=2 coarsest cells")
+    mats = [poisson_matrix(c, order) for c in cells]
+    Ps = [prolongation(cells[l + 1], order) for l in range(nlevels - 1)]
+    Rs = [P.transpose() for P in Ps]
+    return dict(mats=mats, prolongations=Ps, restrictions=Rs, ncells=cells, order=order)
