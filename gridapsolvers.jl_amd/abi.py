@@ -1,0 +1,95 @@
+"""ctypes binding of include/gmg_amd.h (libgmgamd.so).  Thin: no logic here."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_STATE, ERR_ALLOC, ERR_COMM, ERR_UNSUPPORTED, ERR_SINGULAR = 1, 2, 3, 4, 5, 6, 7
+CSR, CSC = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+MODE_PRECONDITIONER, MODE_SOLVER = 0, 1
+V_CYCLE, W_CYCLE, F_CYCLE = 0, 1, 2
+CONVERGED_ATOL, CONVERGED_RTOL, DIVERGED_MAXITER, DIVERGED_BREAKDOWN = 0, 1, 2, 3
+PRE, POST, PRE_AND_POST = 0, 1, 2
+PATCH_LU, PATCH_NOPIVOT = 0, 1
+OP_A, OP_P, OP_R = 0, 1, 2
+
+
+class Result(C.Structure):
+    _fields_ = [("niters", C.c_int32), ("flag", C.c_int32), ("res0", C.c_double), ("res", C.c_double)]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("alg_bytes", C.c_double),
+                ("rows", C.c_int64), ("nnz", C.c_int64)]
+
+
+# every symbol include/gmg_amd.h declares (tests check the library exports all of them)
+SYMBOLS = {
+    "gmg_create": [C.POINTER(C.c_void_p), C.c_int, C.c_int],
+    "gmg_destroy": [C.c_void_p],
+    "gmg_last_error": [C.c_void_p],
+    "gmg_version": [],
+    "gmg_set_matrix": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                       C.c_int, C.c_int, C.c_int],
+    "gmg_update_values": [C.c_void_p, C.c_int, C.c_void_p],
+    "gmg_set_prolongation": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_int, C.c_int, C.c_int],
+    "gmg_set_restriction": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_int, C.c_int, C.c_int],
+    "gmg_set_smoother_jacobi": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double],
+    "gmg_set_smoother_patch": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_void_p,
+                               C.c_void_p, C.c_int, C.c_int],
+    "gmg_set_options": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double],
+    "gmg_setup": [C.c_void_p],
+    "gmg_apply": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Result), C.c_void_p, C.c_int],
+    "gmg_cg_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                     C.POINTER(Result), C.c_void_p, C.c_int],
+    "gmg_fgmres_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                         C.c_double, C.c_double, C.c_int, C.POINTER(Result), C.c_void_p, C.c_int],
+    "gmg_op_apply": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
+    "gmg_smooth": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
+    "gmg_precond_apply": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
+    "gmg_coarse_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
+    "gmg_dot": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)],
+    "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
+    "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],
+    "gmg_model_bytes": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "gmg_device_bytes": [C.c_void_p, C.POINTER(C.c_int64)],
+}
+
+_LIB = None
+
+
+class GmgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgmgamd status {code}: {msg}")
+        self.code = code
+
+
+def load(path=None):
+    """dlopen libgmgamd.so.  Fails loudly when the HIP extension is missing:
+    there is no CPU fallback in the product."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = path or _build.lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not built: run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(path)
+    for name, args in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_char_p if name == "gmg_last_error" else C.c_int
+    _LIB = lib
+    return lib
+
+
+def check(handle, status):
+    if status != OK:
+        msg = load().gmg_last_error(handle)
+        raise GmgError(status, msg.decode() if msg else "")
+    return status

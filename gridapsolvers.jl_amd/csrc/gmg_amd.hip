@@ -1,0 +1,1386 @@
+// gmg_amd.hip -- host side of libgmgamd.so: the C ABI declared in include/gmg_amd.h.
+//
+// Owns, per handle, the device-resident multigrid hierarchy (CSR A_l, D^-1_l,
+// explicit P_l and R_l = P_l^T, patch inverse blocks, dense coarse inverse,
+// work vectors) and drives the gfx950 kernels of kernels.hpp on ONE HIP stream.
+// Host code only orchestrates: every fp64 operation on vectors / matrices of the
+// hot path runs on the GPU.  There is no CPU fallback: without a HIP device
+// gmg_create fails with GMG_ERR_HIP.
+//
+// Reference call structure reproduced (GridapSolvers.jl v0.7.1, src/LinearSolvers):
+//   gmg_apply        = solve!(x,::GMGNumericalSetup,b)        GMGLinearSolvers.jl:612-645
+//   Solver::cycle    = gmg_v_cycle!/gmg_w_cycle!/gmg_f_cycle!  GMGLinearSolvers.jl:468-610
+//   Solver::smooth   = solve!(x,::RichardsonSmootherNS,r)      RichardsonSmoothers.jl:84-98
+//   gmg_cg_solve     = solve!(x,::CGNumericalSetup,b)          Krylov/CGSolvers.jl:73-120
+//   gmg_fgmres_solve = solve!(x,::FGMRESNumericalSetup,b)      Krylov/FGMRESSolvers.jl:130-199
+//   ConvLog          = ConvergenceLog / SolverTolerances       SolverInterfaces/ConvergenceLogs.jl:101-150,
+//                                                              SolverTolerances.jl:97-128
+#include "../../include/gmg_amd.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace gmg;
+
+namespace {
+
+std::string g_last_error;
+
+struct GmgError {
+  int code;
+  std::string msg;
+};
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      throw GmgError{GMG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)};         \
+  } while (0)
+
+#define REQUIRE(cond, code, text)                  \
+  do {                                             \
+    if (!(cond)) throw GmgError{(code), (text)};   \
+  } while (0)
+
+// ----------------------------------------------------------------------------
+// host-side sparse containers and input conversion
+// ----------------------------------------------------------------------------
+struct HostCSR {
+  int64_t nrows = 0, ncols = 0;
+  std::vector<int64_t> ptr;
+  std::vector<int32_t> col;
+  std::vector<double> val;
+  int64_t nnz() const { return ptr.empty() ? 0 : ptr.back(); }
+};
+
+int64_t read_index(const void *p, int64_t i, int bytes)
+{
+  return bytes == 8 ? reinterpret_cast<const int64_t *>(p)[i] : (int64_t) reinterpret_cast<const int32_t *>(p)[i];
+}
+
+// Accepts {CSR|CSC} x {0|1}-based x {int32|int64} (SparseMatrixCSC{Float64,Int}: CSC,1,8;
+// SparseMatrixCSR{1,Float64,Int32}: CSR,1,4 ...) and produces 0-based CSR.
+HostCSR convert_input(int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr, const void *idx,
+                      const double *val, int layout, int base, int bytes)
+{
+  REQUIRE(ptr && idx && val, GMG_ERR_INVALID, "null matrix array");
+  REQUIRE(nrows >= 0 && ncols >= 0 && nnz >= 0, GMG_ERR_INVALID, "negative matrix size");
+  REQUIRE(bytes == 4 || bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
+  REQUIRE(base == 0 || base == 1, GMG_ERR_INVALID, "index_base must be 0 or 1");
+  REQUIRE(layout == GMG_CSR || layout == GMG_CSC, GMG_ERR_INVALID, "layout must be GMG_CSR or GMG_CSC");
+  REQUIRE(ncols < (int64_t)INT32_MAX && nrows < (int64_t)INT32_MAX, GMG_ERR_UNSUPPORTED,
+          "more than 2^31-1 rows/cols per device");
+  const int64_t nmajor = layout == GMG_CSR ? nrows : ncols;
+  const int64_t nminor = layout == GMG_CSR ? ncols : nrows;
+  REQUIRE(read_index(ptr, 0, bytes) == base, GMG_ERR_INVALID, "pointer array does not start at index_base");
+  REQUIRE(read_index(ptr, nmajor, bytes) - base == nnz, GMG_ERR_INVALID, "pointer array end != nnz");
+  HostCSR out;
+  out.nrows = nrows;
+  out.ncols = ncols;
+  out.ptr.assign(nrows + 1, 0);
+  out.col.resize(nnz);
+  out.val.resize(nnz);
+  if (layout == GMG_CSR) {
+    for (int64_t i = 0; i <= nrows; ++i) out.ptr[i] = read_index(ptr, i, bytes) - base;
+    for (int64_t i = 0; i < nrows; ++i) REQUIRE(out.ptr[i] <= out.ptr[i + 1], GMG_ERR_INVALID, "row pointers not monotone");
+    for (int64_t k = 0; k < nnz; ++k) {
+      const int64_t c = read_index(idx, k, bytes) - base;
+      REQUIRE(c >= 0 && c < nminor, GMG_ERR_INVALID, "column index out of range");
+      out.col[k] = (int32_t)c;
+    }
+    std::memcpy(out.val.data(), val, sizeof(double) * (size_t)nnz);
+  } else {
+    // transpose CSC -> CSR by counting sort (keeps columns sorted within a row)
+    for (int64_t k = 0; k < nnz; ++k) {
+      const int64_t r = read_index(idx, k, bytes) - base;
+      REQUIRE(r >= 0 && r < nminor, GMG_ERR_INVALID, "row index out of range");
+      out.ptr[r + 1]++;
+    }
+    for (int64_t i = 0; i < nrows; ++i) out.ptr[i + 1] += out.ptr[i];
+    std::vector<int64_t> fill(out.ptr.begin(), out.ptr.end() - 1);
+    for (int64_t c = 0; c < ncols; ++c) {
+      const int64_t k0 = read_index(ptr, c, bytes) - base, k1 = read_index(ptr, c + 1, bytes) - base;
+      REQUIRE(k0 <= k1, GMG_ERR_INVALID, "column pointers not monotone");
+      for (int64_t k = k0; k < k1; ++k) {
+        const int64_t r = read_index(idx, k, bytes) - base;
+        const int64_t q = fill[r]++;
+        out.col[q] = (int32_t)c;
+        out.val[q] = val[k];
+      }
+    }
+  }
+  return out;
+}
+
+HostCSR transpose(const HostCSR &A)
+{
+  HostCSR T;
+  T.nrows = A.ncols;
+  T.ncols = A.nrows;
+  T.ptr.assign(T.nrows + 1, 0);
+  const int64_t nnz = A.nnz();
+  T.col.resize(nnz);
+  T.val.resize(nnz);
+  for (int64_t k = 0; k < nnz; ++k) T.ptr[A.col[k] + 1]++;
+  for (int64_t i = 0; i < T.nrows; ++i) T.ptr[i + 1] += T.ptr[i];
+  std::vector<int64_t> fill(T.ptr.begin(), T.ptr.end() - 1);
+  for (int64_t i = 0; i < A.nrows; ++i)
+    for (int64_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+      const int64_t q = fill[A.col[k]]++;
+      T.col[q] = (int32_t)i;
+      T.val[q] = A.val[k];
+    }
+  return T;
+}
+
+// ----------------------------------------------------------------------------
+// device containers
+// ----------------------------------------------------------------------------
+struct DevCSR {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  bool ptr64 = false;
+  void *rowptr = nullptr;
+  int32_t *col = nullptr;
+  double *val = nullptr;
+  int32_t *blk_row = nullptr;
+  int nblocks = 0;
+  int lanes_log2 = 0;
+  bool present() const { return rowptr != nullptr; }
+};
+
+enum SmootherKind { SM_JACOBI = 0, SM_PATCH = 1 };
+
+struct Smoother {
+  int kind = SM_JACOBI;
+  int niter = 10;             // GMGLinearSolvers.jl:52 default RichardsonSmoother(Jacobi,10)
+  double omega = 1.0;         // RichardsonSmoothers.jl:28 default
+  // patch data (host copy kept until setup)
+  int patch_kind = GMG_PATCH_LU;
+  std::vector<int64_t> h_pptr;
+  std::vector<int32_t> h_pdofs;
+  // device
+  int64_t npatch = 0;
+  int max_np = 0;
+  int64_t *d_pptr = nullptr;
+  int32_t *d_pdofs = nullptr;
+  int64_t *d_boff = nullptr;
+  double *d_binv = nullptr;
+  int64_t *d_iptr = nullptr, *d_inc = nullptr;
+  double *d_contrib = nullptr;
+  bool built = false;
+};
+
+struct Level {
+  HostCSR hA, hP, hR;
+  bool hasA = false, hasP = false, hasR = false;
+  DevCSR A, P, R;
+  double *dinv = nullptr;
+  Smoother pre, post;
+  bool post_shares_pre = true;
+  int64_t n = 0;
+  double *x = nullptr;            // correction at this level (levels > 0)
+  double *rbuf[2] = {nullptr, nullptr};
+  double *dx = nullptr;
+  double *rcur = nullptr;         // buffer holding the current residual after a cycle
+};
+
+// ConvergenceLog + SolverTolerances (ConvergenceLogs.jl:42-150, SolverTolerances.jl:97-128)
+struct ConvLog {
+  int maxiter = 0;
+  double atol = 0, rtol = 0;
+  int num_iters = 0;
+  std::vector<double> residuals;
+  void configure(int mi, double a, double r)
+  {
+    maxiter = mi; atol = a; rtol = r;
+    residuals.assign((size_t)std::max(mi, 0) + 1, 0.0);
+  }
+  bool finished(int niter, double e_a, double e_r) const
+  {
+    return (niter >= maxiter) || (e_r < rtol) || (e_a < atol); // strict <, SolverTolerances.jl:126-128
+  }
+  bool init(double r0)
+  {
+    num_iters = 0;
+    std::fill(residuals.begin(), residuals.end(), 0.0);
+    residuals[0] = r0;
+    return finished(num_iters, r0, 1.0);
+  }
+  bool update(double r)
+  {
+    num_iters += 1;
+    if ((size_t)num_iters < residuals.size()) residuals[num_iters] = r;
+    return finished(num_iters, r, r / residuals[0]);
+  }
+  int finalize(double r) const
+  {
+    const double r_rel = r / residuals[0];
+    if (r_rel < rtol) return GMG_CONVERGED_RTOL;
+    if (r < atol) return GMG_CONVERGED_ATOL;
+    if (num_iters >= maxiter) return GMG_DIVERGED_MAXITER;
+    return GMG_DIVERGED_BREAKDOWN;
+  }
+  void export_to(gmg_result *res, double *hist, int cap, double last) const
+  {
+    if (res) {
+      res->niters = num_iters;
+      res->flag = finalize(last);
+      res->res0 = residuals[0];
+      res->res = last;
+    }
+    if (hist)
+      for (int i = 0; i <= num_iters && i < cap; ++i) hist[i] = residuals[i];
+  }
+};
+
+constexpr int kScalarSlots = 4096;
+
+int env_int(const char *name, int dflt)
+{
+  const char *s = std::getenv(name);
+  return s && *s ? std::atoi(s) : dflt;
+}
+
+} // namespace
+
+// ----------------------------------------------------------------------------
+// the solver object behind gmg_handle_t
+// ----------------------------------------------------------------------------
+struct gmg_solver {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int nlev = 0;
+  std::vector<Level> lev;
+  std::string err;
+  bool setup_done = false;
+  int64_t dev_bytes = 0;
+  std::vector<void *> allocs;
+
+  // GMGLinearSolver kwargs (GMGLinearSolvers.jl:56-58)
+  int mode = GMG_MODE_PRECONDITIONER, cycle_type = GMG_V_CYCLE;
+  ConvLog log;
+
+  // coarse solver
+  double *d_Ainv = nullptr;
+
+  // reductions
+  double *d_partials = nullptr;
+  double *d_scalars = nullptr;
+  double *h_scalars = nullptr; // pinned
+
+  // Krylov work vectors (CGSolvers.jl:42-48 ; FGMRESSolvers.jl:58-70)
+  double *cg_w = nullptr, *cg_p = nullptr, *cg_z = nullptr, *cg_r = nullptr;
+  std::vector<double *> fg_V, fg_Z;
+  // staging buffers for host-memory callers
+  double *st_b = nullptr, *st_x = nullptr;
+  std::vector<double *> st_extra;
+
+  // tuning
+  int xcd_remap = 1;
+  int lanes_override = -1;
+
+  // profiling of the fused sweep
+  int prof_level = -1;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
+  double prof_ms = 0.0;
+  int64_t prof_launches = 0;
+
+  // ---- memory -------------------------------------------------------------
+  template <typename T>
+  T *dalloc(size_t count)
+  {
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 64; // slack for vector loads
+    HIP_CHECK(hipMalloc(&p, bytes));
+    allocs.push_back(p);
+    dev_bytes += (int64_t)bytes;
+    return reinterpret_cast<T *>(p);
+  }
+  template <typename T>
+  T *upload(const std::vector<T> &v)
+  {
+    T *p = dalloc<T>(v.size());
+    // blocking copy: callers pass temporaries (setup path, not timed)
+    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+  }
+  double *dvec(int64_t n)
+  {
+    double *p = dalloc<double>((size_t)n);
+    HIP_CHECK(hipMemsetAsync(p, 0, sizeof(double) * (size_t)std::max<int64_t>(n, 1), stream));
+    return p;
+  }
+  void free_all()
+  {
+    for (void *p : allocs) (void)hipFree(p);
+    allocs.clear();
+    dev_bytes = 0;
+    for (auto &L : lev) {
+      L.A = DevCSR(); L.P = DevCSR(); L.R = DevCSR();
+      L.dinv = L.x = L.dx = L.rcur = nullptr;
+      L.rbuf[0] = L.rbuf[1] = nullptr;
+      L.pre.built = L.post.built = false;
+    }
+    d_Ainv = d_partials = d_scalars = nullptr;
+    cg_w = cg_p = cg_z = cg_r = st_b = st_x = nullptr;
+    fg_V.clear(); fg_Z.clear(); st_extra.clear();
+    setup_done = false;
+  }
+
+  // ---- uploads --------------------------------------------------------------
+  DevCSR upload_csr(const HostCSR &H)
+  {
+    DevCSR D;
+    D.nrows = H.nrows; D.ncols = H.ncols; D.nnz = H.nnz();
+    D.ptr64 = D.nnz >= (int64_t)INT32_MAX;
+    if (D.ptr64) D.rowptr = upload(H.ptr);
+    else {
+      std::vector<int32_t> p32(H.ptr.begin(), H.ptr.end());
+      D.rowptr = upload(p32);
+    }
+    D.col = upload(H.col);
+    D.val = upload(H.val);
+    // workgroup row ranges: greedy fill of the kTile-nnz LDS tile
+    std::vector<int32_t> blk;
+    blk.push_back(0);
+    int64_t r = 0;
+    int64_t maxlen = 0;
+    while (r < H.nrows) {
+      int64_t e = r;
+      const int64_t base = H.ptr[r];
+      while (e < H.nrows && H.ptr[e + 1] - base <= kTile && (e - r) < 4096) ++e;
+      if (e == r) e = r + 1; // single long row
+      maxlen = std::max(maxlen, H.ptr[e] - base);
+      blk.push_back((int32_t)e);
+      r = e;
+    }
+    D.nblocks = (int)blk.size() - 1;
+    D.blk_row = upload(blk);
+    // lanes per row in the reduce phase: ~ (avg nnz/row)/8, power of two in [1,64]
+    const double avg = H.nrows ? (double)D.nnz / (double)H.nrows : 1.0;
+    int lg = 0;
+    while (lg < 6 && (double)(1 << (lg + 1)) * 6.0 <= avg) ++lg;
+    if (lanes_override >= 0) lg = std::min(lanes_override, 6);
+    D.lanes_log2 = lg;
+    return D;
+  }
+
+  // ---- kernel launchers ------------------------------------------------------
+  static int grid_for(int64_t n, int block = 256)
+  {
+    const int64_t g = (n + block - 1) / block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, 256 * 8));
+  }
+
+  template <int EPI>
+  void launch_stream(const DevCSR &M, const StreamArgs &a)
+  {
+    if (M.nblocks == 0) return;
+    if (M.ptr64) hipLaunchKernelGGL((csr_stream_kernel<EPI, int64_t>), dim3(M.nblocks), dim3(kBlock), 0, stream, a);
+    else hipLaunchKernelGGL((csr_stream_kernel<EPI, int32_t>), dim3(M.nblocks), dim3(kBlock), 0, stream, a);
+    HIP_CHECK(hipGetLastError());
+  }
+  StreamArgs base_args(const DevCSR &M) const
+  {
+    StreamArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rowptr = M.rowptr; a.col = M.col; a.val = M.val; a.blk_row = M.blk_row;
+    a.nblocks = M.nblocks; a.lanes_log2 = M.lanes_log2; a.xcd_remap = xcd_remap;
+    return a;
+  }
+  // y = M x
+  void spmv_set(const DevCSR &M, const double *x, double *y)
+  {
+    StreamArgs a = base_args(M); a.x = x; a.y = y;
+    launch_stream<EPI_SET>(M, a);
+  }
+  // y -= M x
+  void spmv_sub(const DevCSR &M, const double *x, double *y)
+  {
+    StreamArgs a = base_args(M); a.x = x; a.y = y;
+    launch_stream<EPI_SUB>(M, a);
+  }
+  // y = b - M x
+  void spmv_resid(const DevCSR &M, const double *x, const double *b, double *y)
+  {
+    StreamArgs a = base_args(M); a.x = x; a.y = y; a.b = b;
+    launch_stream<EPI_RESID>(M, a);
+  }
+  // y = M x ; x2 += y
+  void spmv_addto(const DevCSR &M, const double *x, double *y, double *x2)
+  {
+    StreamArgs a = base_args(M); a.x = x; a.y = y; a.x2 = x2;
+    launch_stream<EPI_ADDTO>(M, a);
+  }
+  // fused Richardson-Jacobi sweep: x += w*Dinv*r_old ; r_new = r_old - A*(w*Dinv*r_old)
+  void sweep(int l, const Smoother &S, double *x, const double *r_old, double *r_new, bool x_zero)
+  {
+    Level &L = lev[l];
+    StreamArgs a = base_args(L.A);
+    a.x = r_old; a.b = r_old; a.dinv = L.dinv; a.omega = S.omega; a.y = r_new; a.x2 = x; a.x_zero = x_zero ? 1 : 0;
+    const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();
+    if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
+    launch_stream<EPI_SWEEP>(L.A, a);
+    if (prof) {
+      HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
+      prof_used += 2;
+    }
+  }
+
+  void copy(double *dst, const double *src, int64_t n)
+  {
+    if (n > 0 && dst != src) HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+  }
+  void zero(double *dst, int64_t n)
+  {
+    if (n > 0) HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)n, stream));
+  }
+
+  // dot -> device scalar slot (no host sync)
+  void dot_async(int64_t n, const double *a, const double *b, int slot, bool take_sqrt)
+  {
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n / 2 + kBlock - 1) / kBlock));
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, n, a, b, d_partials, aligned ? 1 : 0);
+    HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, stream, nb, d_partials, d_scalars + slot, take_sqrt ? 1 : 0);
+    HIP_CHECK(hipGetLastError());
+  }
+  double fetch_scalar(int slot)
+  {
+    HIP_CHECK(hipMemcpyAsync(h_scalars + slot, d_scalars + slot, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return h_scalars[slot];
+  }
+  double dot(int64_t n, const double *a, const double *b)
+  {
+    dot_async(n, a, b, 0, false);
+    return fetch_scalar(0);
+  }
+  double norm(int64_t n, const double *a)
+  {
+    dot_async(n, a, a, 0, true);
+    return fetch_scalar(0);
+  }
+
+  // ---- smoother ---------------------------------------------------------------
+  void build_patch(Level &L, Smoother &S);
+  void patch_precond(Level &L, Smoother &S, const double *r, double omega, bool relax, double *dx, double *x);
+
+  // solve!(x,ns::RichardsonSmootherNumericalSetup,r), RichardsonSmoothers.jl:84-98.
+  // r_in may be a caller-owned read-only vector; returns the buffer holding the
+  // updated residual (one of L.rbuf[]).
+  double *smooth(int l, Smoother &S, double *x, const double *r_in, bool x_zero)
+  {
+    Level &L = lev[l];
+    const int64_t n = L.n;
+    const bool r_internal = (r_in == L.rbuf[0] || r_in == L.rbuf[1]);
+    if (S.niter <= 0) {
+      if (x_zero) zero(x, n);
+      if (!r_internal) { copy(L.rbuf[0], r_in, n); return L.rbuf[0]; }
+      return const_cast<double *>(r_in);
+    }
+    if (S.kind == SM_JACOBI) {
+      const double *cur = r_in;
+      double *out = nullptr;
+      for (int it = 0; it < S.niter; ++it) {              // :90 while iter <= niter
+        out = (cur == L.rbuf[0]) ? L.rbuf[1] : L.rbuf[0];
+        sweep(l, S, x, cur, out, x_zero && it == 0);       // :91-95 fused
+        cur = out;
+      }
+      return out;
+    }
+    // patch smoother: r updated in place
+    double *r = nullptr;
+    if (r_internal) r = const_cast<double *>(r_in);
+    else { r = L.rbuf[0]; copy(r, r_in, n); }
+    if (x_zero) zero(x, n);
+    for (int it = 0; it < S.niter; ++it) {
+      patch_precond(L, S, r, S.omega, true, L.dx, x);      // :91-93
+      spmv_sub(L.A, L.dx, r);                              // :94-95
+    }
+    return r;
+  }
+
+  void coarse_solve(const double *r, double *x)
+  {
+    const int n = (int)lev[nlev - 1].n;
+    const int waves_per_block = kBlock / 64;
+    const int grid = (n + waves_per_block - 1) / waves_per_block;
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, stream, n, d_Ainv, r, x);
+    HIP_CHECK(hipGetLastError());
+  }
+
+  // gmg_v_cycle! / gmg_w_cycle! / gmg_f_cycle!, GMGLinearSolvers.jl:468-610
+  void cycle(int l, double *x, const double *r_in, bool x_zero, int ctype)
+  {
+    Level &L = lev[l];
+    if (l == nlev - 1) {                                   // :472-474
+      coarse_solve(r_in, x);
+      return;
+    }
+    Level &C = lev[l + 1];
+    double *r = smooth(l, L.pre, x, r_in, x_zero);         // :481
+    const int passes = (ctype == GMG_V_CYCLE) ? 1 : 2;
+    for (int pass = 0; pass < passes; ++pass) {
+      if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
+      spmv_set(L.R, r, C.rbuf[0]);                         // :484 rH = R rh
+      // :487 fill!(dxH,0) is implicit: the first sweep below / the coarse solve write dxH
+      const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
+      cycle(l + 1, C.x, C.rbuf[0], true, child);           // :488
+      spmv_addto(L.P, C.x, L.dx, x);                       // :491,494 dxh = P dxH ; xh += dxh
+      spmv_sub(L.A, L.dx, r);                              // :495-496 rh -= Ah dxh
+    }
+    r = smooth(l, L.post, x, r, false);                    // :499
+    L.rcur = r;
+  }
+
+  // solve!(x,ns::GMGNumericalSetup,b), GMGLinearSolvers.jl:612-645 (device pointers).
+  // known_res0 >= 0: the caller already holds norm(b) (outer CG's `res`), which
+  // removes the only host round trip of the preconditioner application.
+  double gmg_solve_dev(double *x, const double *b, double known_res0)
+  {
+    Level &L0 = lev[0];
+    const int64_t n = L0.n;
+    const double *r_in;
+    bool x_zero;
+    if (mode == GMG_MODE_PRECONDITIONER) {                 // :618-620
+      x_zero = true;  // fill!(x,0) folded into the first sweep
+      r_in = b;       // copy!(rh,b) folded: the first sweep reads b, writes rh
+    } else {                                               // :621-625
+      spmv_resid(L0.A, x, b, L0.rbuf[0]);
+      r_in = L0.rbuf[0];
+      x_zero = false;
+    }
+    double res = known_res0;
+    if (!(res >= 0.0)) res = norm(n, r_in);                // :627
+    bool done = log.init(res);                             // :628
+    if (done && x_zero) zero(x, n);
+    const bool single = (log.maxiter == 1);
+    while (!done) {
+      cycle(0, x, r_in, x_zero, cycle_type);               // :630-637
+      r_in = L0.rcur;
+      x_zero = false;
+      if (single && known_res0 >= 0.0) {
+        // maxiter == 1: update! returns true whatever the norm is (:640); the
+        // post-cycle norm is a logging-only quantity here and is not fetched.
+        log.num_iters = 1;
+        res = NAN;
+        done = true;
+      } else {
+        res = norm(n, r_in);                               // :639
+        done = log.update(res);                            // :640
+      }
+    }
+    return res;
+  }
+
+  // Krylov preconditioner dispatch: 0 = nothing (z .= r, CGSolvers.jl:91), 1 = this GMG,
+  // 2 = JacobiLinearSolver() on the finest matrix (JacobiLinearSolvers.jl:43-47)
+  void krylov_precond(int kind, double *z, const double *r, double known_res0)
+  {
+    const int64_t n = lev[0].n;
+    if (kind == 1) gmg_solve_dev(z, r, known_res0);
+    else if (kind == 2) {
+      hipLaunchKernelGGL(jacobi_apply_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, lev[0].dinv, r, z);
+      HIP_CHECK(hipGetLastError());
+    } else copy(z, r, n);
+  }
+
+  // ---- staging for host-memory callers -----------------------------------------
+  const double *in_vec(const double *p, int64_t n, int memspace, double *stage)
+  {
+    if (memspace == GMG_MEM_DEVICE) return p;
+    HIP_CHECK(hipMemcpyAsync(stage, p, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
+    return stage;
+  }
+  void out_vec(double *user, const double *dev, int64_t n, int memspace)
+  {
+    if (memspace == GMG_MEM_DEVICE) {
+      if (user != dev) copy(user, dev, n);
+    } else {
+      HIP_CHECK(hipMemcpyAsync(user, dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  double *scratch_vec(size_t i, int64_t n)
+  {
+    while (st_extra.size() <= i) st_extra.push_back(nullptr);
+    if (!st_extra[i]) st_extra[i] = dvec(n);
+    return st_extra[i];
+  }
+
+  void setup();
+  void build_coarse();
+};
+
+// ----------------------------------------------------------------------------
+// patch smoother: setup + application
+// ----------------------------------------------------------------------------
+void gmg_solver::build_patch(Level &L, Smoother &S)
+{
+  const int64_t npatch = (int64_t)S.h_pptr.size() - 1;
+  REQUIRE(npatch >= 0, GMG_ERR_INVALID, "patch_ptr missing");
+  S.npatch = npatch;
+  std::vector<int64_t> boff((size_t)npatch + 1, 0);
+  int max_np = 0;
+  for (int64_t p = 0; p < npatch; ++p) {
+    const int64_t np = S.h_pptr[p + 1] - S.h_pptr[p];
+    REQUIRE(np >= 0, GMG_ERR_INVALID, "patch_ptr not monotone");
+    boff[p + 1] = boff[p] + np * np;
+    max_np = std::max<int>(max_np, (int)np);
+  }
+  const int64_t ndof_entries = S.h_pptr[npatch];
+  for (int64_t q = 0; q < ndof_entries; ++q)
+    REQUIRE(S.h_pdofs[q] >= 0 && S.h_pdofs[q] < L.n, GMG_ERR_INVALID, "patch dof out of range");
+  S.max_np = max_np;
+  S.d_pptr = upload(S.h_pptr);
+  S.d_pdofs = upload(S.h_pdofs);
+  S.d_boff = upload(boff);
+  S.d_binv = dalloc<double>((size_t)boff[npatch]);
+  S.d_contrib = dvec(ndof_entries);
+  // dof -> contribution slots, ascending patch order (= reference loop order PatchSolvers.jl:288)
+  std::vector<int64_t> iptr((size_t)L.n + 1, 0), inc((size_t)ndof_entries);
+  for (int64_t q = 0; q < ndof_entries; ++q) iptr[S.h_pdofs[q] + 1]++;
+  for (int64_t i = 0; i < L.n; ++i) iptr[i + 1] += iptr[i];
+  {
+    std::vector<int64_t> fill(iptr.begin(), iptr.end() - 1);
+    for (int64_t q = 0; q < ndof_entries; ++q) inc[fill[S.h_pdofs[q]]++] = q;
+  }
+  S.d_iptr = upload(iptr);
+  S.d_inc = upload(inc);
+  // factorise in chunks so the scratch stays bounded
+  if (npatch > 0 && max_np > 0) {
+    const size_t per = (size_t)max_np * max_np;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(npatch, (int64_t)((256u << 20) / (per * sizeof(double)))));
+    double *scratch = nullptr;
+    HIP_CHECK(hipMalloc((void **)&scratch, per * sizeof(double) * (size_t)chunk));
+    int *d_nsing = dalloc<int>(1);
+    HIP_CHECK(hipMemsetAsync(d_nsing, 0, sizeof(int), stream));
+    const int pivoting = (S.patch_kind == GMG_PATCH_LU) ? 1 : 0;
+    for (int64_t p0 = 0; p0 < npatch; p0 += chunk) {
+      const int64_t cnt = std::min(chunk, npatch - p0);
+      const int grid = (int)((cnt + 63) / 64);
+      // shift the patch tables instead of the patch id: pptr/boff are absolute
+      if (L.A.ptr64)
+        hipLaunchKernelGGL((patch_factor_kernel<int64_t>), dim3(grid), dim3(64), 0, stream, cnt, S.d_pptr + p0, S.d_pdofs,
+                           S.d_boff + p0, (const int64_t *)L.A.rowptr, L.A.col, L.A.val, S.d_binv, scratch, max_np, pivoting, d_nsing);
+      else
+        hipLaunchKernelGGL((patch_factor_kernel<int32_t>), dim3(grid), dim3(64), 0, stream, cnt, S.d_pptr + p0, S.d_pdofs,
+                           S.d_boff + p0, (const int32_t *)L.A.rowptr, L.A.col, L.A.val, S.d_binv, scratch, max_np, pivoting, d_nsing);
+      HIP_CHECK(hipGetLastError());
+    }
+    int nsing = 0;
+    HIP_CHECK(hipMemcpyAsync(&nsing, d_nsing, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    (void)hipFree(scratch);
+    REQUIRE(nsing == 0, GMG_ERR_SINGULAR, "singular patch block (BlockJacobiSolvers.jl:163 'Factorization failed')");
+  }
+  S.built = true;
+}
+
+// dx = (omega *) sum_p scatter(inv(A_pp) r_p) ; relax: x += dx
+void gmg_solver::patch_precond(Level &L, Smoother &S, const double *r, double omega, bool relax, double *dx, double *x)
+{
+  if (S.npatch > 0) {
+    if (S.max_np <= 64) {
+      const int grid = (int)((S.npatch + 3) / 4);
+      hipLaunchKernelGGL(patch_apply_kernel, dim3(grid), dim3(kBlock), 0, stream, S.npatch, S.d_pptr, S.d_pdofs, S.d_boff,
+                         S.d_binv, r, S.d_contrib);
+    } else {
+      hipLaunchKernelGGL(patch_apply_big_kernel, dim3((int)S.npatch), dim3(kBlock), 0, stream, S.npatch, S.d_pptr, S.d_pdofs,
+                         S.d_boff, S.d_binv, r, S.d_contrib);
+    }
+    HIP_CHECK(hipGetLastError());
+  }
+  const int grid = (int)((L.n + 255) / 256);
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(std::max(grid, 1)), dim3(256), 0, stream, L.n, S.d_iptr, S.d_inc, S.d_contrib,
+                     omega, relax ? 1 : 0, dx, x);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------
+// coarse solver: coarsest_solver = LUSolver() (GMGLinearSolvers.jl:54,423-434).
+// The exact factorisation is done once on the host (banded LU with partial
+// pivoting) and turned into a dense inverse so that the per-cycle solve is a
+// single bandwidth-bound GEMV on the device.
+// ----------------------------------------------------------------------------
+namespace {
+struct BandLU {
+  int n = 0, kl = 0, ku = 0, ld = 0;
+  std::vector<double> ab;
+  std::vector<int> piv;
+  double &at(int i, int j) { return ab[(size_t)(kl + ku + i - j) + (size_t)j * ld]; }
+  double get(int i, int j) const { return ab[(size_t)(kl + ku + i - j) + (size_t)j * ld]; }
+
+  bool factor(const HostCSR &A)
+  {
+    n = (int)A.nrows;
+    for (int i = 0; i < n; ++i)
+      for (int64_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) {
+        kl = std::max(kl, i - A.col[k]);
+        ku = std::max(ku, A.col[k] - i);
+      }
+    ld = 2 * kl + ku + 1;
+    ab.assign((size_t)ld * n, 0.0);
+    piv.assign(n, 0);
+    for (int i = 0; i < n; ++i)
+      for (int64_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) at(i, A.col[k]) += A.val[k];
+    int ju = 0;
+    for (int j = 0; j < n; ++j) {
+      const int km = std::min(kl, n - 1 - j);
+      int p = j;
+      double best = std::fabs(get(j, j));
+      for (int i = j + 1; i <= j + km; ++i)
+        if (std::fabs(get(i, j)) > best) { best = std::fabs(get(i, j)); p = i; }
+      if (best == 0.0) return false;
+      piv[j] = p;
+      ju = std::max(ju, std::min(p + ku, n - 1));
+      ju = std::max(ju, j);
+      if (p != j)
+        for (int c = j; c <= ju; ++c) std::swap(at(j, c), at(p, c));
+      const double inv = 1.0 / get(j, j);
+      for (int i = j + 1; i <= j + km; ++i) at(i, j) *= inv;
+      for (int c = j + 1; c <= ju; ++c) {
+        const double f = get(j, c);
+        if (f != 0.0)
+          for (int i = j + 1; i <= j + km; ++i) at(i, c) -= get(i, j) * f;
+      }
+    }
+    return true;
+  }
+  void solve(double *x) const
+  {
+    for (int j = 0; j < n; ++j) {
+      const int km = std::min(kl, n - 1 - j);
+      if (piv[j] != j) std::swap(x[j], x[piv[j]]);
+      const double xj = x[j];
+      if (xj != 0.0)
+        for (int i = j + 1; i <= j + km; ++i) x[i] -= get(i, j) * xj;
+    }
+    const int kv = kl + ku;
+    for (int j = n - 1; j >= 0; --j) {
+      x[j] /= get(j, j);
+      const double xj = x[j];
+      for (int i = std::max(0, j - kv); i < j; ++i) x[i] -= get(i, j) * xj;
+    }
+  }
+};
+} // namespace
+
+void gmg_solver::build_coarse()
+{
+  const HostCSR &A = lev[nlev - 1].hA;
+  const int n = (int)A.nrows;
+  REQUIRE((double)n * n * 8.0 < 64e9, GMG_ERR_UNSUPPORTED, "coarsest level too large for a dense inverse; add levels");
+  BandLU lu;
+  REQUIRE(lu.factor(A), GMG_ERR_SINGULAR, "coarsest-level matrix is singular");
+  std::vector<double> inv((size_t)n * n);
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nthreads = (int)std::min<unsigned>(hw, (unsigned)std::max(1, n / 16));
+  auto work = [&](int t) {
+    std::vector<double> e(n);
+    for (int c = t; c < n; c += nthreads) {
+      std::fill(e.begin(), e.end(), 0.0);
+      e[c] = 1.0;
+      lu.solve(e.data());
+      for (int i = 0; i < n; ++i) inv[(size_t)i * n + c] = e[i]; // row-major inverse
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &t : th) t.join();
+  d_Ainv = upload(inv);
+  HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// numerical_setup(ss::GMGSymbolicSetup,mat): GMGLinearSolvers.jl:183-210
+void gmg_solver::setup()
+{
+  HIP_CHECK(hipSetDevice(device));
+  free_all();
+  xcd_remap = env_int("GMG_XCD_REMAP", 1);
+  lanes_override = env_int("GMG_LANES_LOG2", -1);
+  for (int l = 0; l < nlev; ++l) {
+    Level &L = lev[l];
+    REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));
+    REQUIRE(L.hA.nrows == L.hA.ncols, GMG_ERR_INVALID, "level matrix must be square");
+    L.n = L.hA.nrows;
+    if (l < nlev - 1) {
+      REQUIRE(L.hasP, GMG_ERR_STATE, "gmg_set_prolongation missing for level " + std::to_string(l));
+      REQUIRE(lev[l + 1].hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l + 1));
+      REQUIRE(L.hP.nrows == L.hA.nrows && L.hP.ncols == lev[l + 1].hA.nrows, GMG_ERR_INVALID,
+              "prolongation shape does not match level sizes (GMGLinearSolvers.jl:59-61)");
+      if (L.hasR)
+        REQUIRE(L.hR.nrows == L.hP.ncols && L.hR.ncols == L.hP.nrows, GMG_ERR_INVALID, "restriction shape mismatch");
+    }
+  }
+  d_partials = dvec(kRedBlocks);
+  d_scalars = dvec(kScalarSlots);
+  if (!h_scalars) HIP_CHECK(hipHostMalloc((void **)&h_scalars, kScalarSlots * sizeof(double)));
+  for (int l = 0; l < nlev; ++l) {
+    Level &L = lev[l];
+    L.A = upload_csr(L.hA);                                 // :185 gmg_compute_matrices
+    L.rbuf[0] = dvec(L.n);                                  // :187,188 rh / rH
+    if (l > 0) L.x = dvec(L.n);                             // :188 dxH
+    if (l < nlev - 1) {
+      L.rbuf[1] = dvec(L.n);
+      L.dx = dvec(L.n);                                     // :188 dxh (Adxh is fused away)
+      L.P = upload_csr(L.hP);
+      if (L.hasR) L.R = upload_csr(L.hR);
+      else {
+        HostCSR Rt = transpose(L.hP);                       // R = P^T, GridTransferOperators.jl:536-547
+        L.R = upload_csr(Rt);
+      }
+      // :189-190 smoother caches: inv_diag = 1 ./ diag(A) (JacobiLinearSolvers.jl:20-23)
+      L.dinv = dalloc<double>((size_t)L.n);
+      int *d_nzero = dalloc<int>(1);
+      HIP_CHECK(hipMemsetAsync(d_nzero, 0, sizeof(int), stream));
+      const int grid = (int)std::max<int64_t>(1, (L.n + 255) / 256);
+      if (L.A.ptr64)
+        hipLaunchKernelGGL((inv_diag_kernel<int64_t>), dim3(grid), dim3(256), 0, stream, L.n, (const int64_t *)L.A.rowptr, L.A.col, L.A.val, L.dinv, d_nzero);
+      else
+        hipLaunchKernelGGL((inv_diag_kernel<int32_t>), dim3(grid), dim3(256), 0, stream, L.n, (const int32_t *)L.A.rowptr, L.A.col, L.A.val, L.dinv, d_nzero);
+      HIP_CHECK(hipGetLastError());
+      int nzero = 0;
+      HIP_CHECK(hipMemcpyAsync(&nzero, d_nzero, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      const bool need_diag = (L.pre.kind == SM_JACOBI) || (L.post.kind == SM_JACOBI);
+      REQUIRE(!(need_diag && nzero > 0), GMG_ERR_SINGULAR, "zero diagonal entry on level " + std::to_string(l));
+      if (L.pre.kind == SM_PATCH) build_patch(L, L.pre);
+      if (L.post_shares_pre) L.post = L.pre;
+      else if (L.post.kind == SM_PATCH) build_patch(L, L.post);
+    }
+  }
+  build_coarse();                                           // :195 gmg_coarse_solver_caches
+  const int64_t n0 = lev[0].n;
+  cg_w = dvec(n0); cg_p = dvec(n0); cg_z = dvec(n0); cg_r = dvec(n0);
+  st_b = dvec(n0); st_x = dvec(n0);
+  HIP_CHECK(hipStreamSynchronize(stream));
+  setup_done = true;
+}
+
+// ----------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------
+namespace {
+template <typename F>
+int guarded(gmg_handle_t h, F &&f)
+{
+  try {
+    if (h) HIP_CHECK(hipSetDevice(h->device));
+    f();
+    return GMG_OK;
+  } catch (const GmgError &e) {
+    if (h) h->err = e.msg;
+    g_last_error = e.msg;
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    if (h) h->err = "host allocation failed";
+    g_last_error = "host allocation failed";
+    return GMG_ERR_ALLOC;
+  } catch (const std::exception &e) {
+    if (h) h->err = e.what();
+    g_last_error = e.what();
+    return GMG_ERR_INVALID;
+  }
+}
+void check_level(gmg_handle_t h, int lev, bool not_coarsest)
+{
+  REQUIRE(h, GMG_ERR_INVALID, "null handle");
+  REQUIRE(lev >= 0 && lev < h->nlev, GMG_ERR_INVALID, "level out of range");
+  if (not_coarsest) REQUIRE(lev < h->nlev - 1, GMG_ERR_INVALID, "level must not be the coarsest");
+}
+void check_ready(gmg_handle_t h)
+{
+  REQUIRE(h, GMG_ERR_INVALID, "null handle");
+  REQUIRE(h->setup_done, GMG_ERR_STATE, "gmg_setup has not been called (numerical_setup missing)");
+}
+} // namespace
+
+extern "C" {
+
+int gmg_version(void) { return 100; }
+
+const char *gmg_last_error(gmg_handle_t h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int gmg_create(gmg_handle_t *out, int nlevels, int device_id)
+{
+  return guarded(nullptr, [&] {
+    REQUIRE(out, GMG_ERR_INVALID, "null handle pointer");
+    *out = nullptr;
+    REQUIRE(nlevels >= 2, GMG_ERR_INVALID, "at least two levels required");
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    REQUIRE(ndev > 0, GMG_ERR_HIP, "no HIP device visible: libgmgamd has no CPU path");
+    REQUIRE(device_id >= 0 && device_id < ndev, GMG_ERR_INVALID, "device_id out of range");
+    HIP_CHECK(hipSetDevice(device_id));
+    gmg_solver *s = new gmg_solver();
+    s->device = device_id;
+    s->nlev = nlevels;
+    s->lev.resize(nlevels);
+    s->log.configure(100, 1.0e-14, 1.0e-8); // GMGLinearSolvers.jl:58 defaults
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete s;
+      throw GmgError{GMG_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)};
+    }
+    *out = s;
+  });
+}
+
+int gmg_destroy(gmg_handle_t h)
+{
+  if (!h) return GMG_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->free_all();
+  for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
+  if (h->h_scalars) (void)hipHostFree(h->h_scalars);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return GMG_OK;
+}
+
+int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr,
+                   const void *idx, const double *val, int layout, int index_base, int index_bytes)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, false);
+    REQUIRE(nrows == ncols, GMG_ERR_INVALID, "level matrix must be square");
+    h->lev[lev].hA = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    h->lev[lev].hasA = true;
+    h->setup_done = false;
+  });
+}
+
+int gmg_update_values(gmg_handle_t h, int lev, const double *val)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, false);
+    Level &L = h->lev[lev];
+    REQUIRE(L.hasA, GMG_ERR_STATE, "no matrix set on this level");
+    REQUIRE(val, GMG_ERR_INVALID, "null values");
+    // values are given in the 0-based CSR order held by the handle
+    std::memcpy(L.hA.val.data(), val, sizeof(double) * (size_t)L.hA.nnz());
+    h->setup_done = false;
+  });
+}
+
+int gmg_set_prolongation(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr,
+                         const void *idx, const double *val, int layout, int index_base, int index_bytes)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    h->lev[lev].hP = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    h->lev[lev].hasP = true;
+    h->setup_done = false;
+  });
+}
+
+int gmg_set_restriction(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr,
+                        const void *idx, const double *val, int layout, int index_base, int index_bytes)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    h->lev[lev].hR = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    h->lev[lev].hasR = true;
+    h->setup_done = false;
+  });
+}
+
+static void assign_smoother(gmg_handle_t h, int lev, int which, const Smoother &S)
+{
+  Level &L = h->lev[lev];
+  REQUIRE(which == GMG_PRE || which == GMG_POST || which == GMG_PRE_AND_POST, GMG_ERR_INVALID, "bad `which`");
+  if (which == GMG_PRE_AND_POST) { L.pre = S; L.post_shares_pre = true; }
+  else if (which == GMG_PRE) { L.pre = S; if (L.post_shares_pre) { L.post_shares_pre = false; } }
+  else { L.post = S; L.post_shares_pre = false; }
+  h->setup_done = false;
+}
+
+int gmg_set_smoother_jacobi(gmg_handle_t h, int lev, int which, int niter, double omega)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    REQUIRE(niter >= 0, GMG_ERR_INVALID, "niter < 0");
+    Smoother S;
+    S.kind = SM_JACOBI; S.niter = niter; S.omega = omega;
+    assign_smoother(h, lev, which, S);
+  });
+}
+
+int gmg_set_smoother_patch(gmg_handle_t h, int lev, int which, int niter, double omega, int kind, int64_t npatch,
+                           const void *patch_ptr, const void *patch_dofs, int index_base, int index_bytes)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    REQUIRE(niter >= 0 && npatch >= 0, GMG_ERR_INVALID, "negative niter / npatch");
+    REQUIRE(patch_ptr && (patch_dofs || npatch == 0), GMG_ERR_INVALID, "null patch arrays");
+    REQUIRE(index_bytes == 4 || index_bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
+    REQUIRE(kind == GMG_PATCH_LU || kind == GMG_PATCH_NOPIVOT, GMG_ERR_INVALID, "bad patch kind");
+    Smoother S;
+    S.kind = SM_PATCH; S.niter = niter; S.omega = omega; S.patch_kind = kind;
+    S.h_pptr.resize((size_t)npatch + 1);
+    for (int64_t p = 0; p <= npatch; ++p) S.h_pptr[p] = read_index(patch_ptr, p, index_bytes) - index_base;
+    REQUIRE(S.h_pptr[0] == 0, GMG_ERR_INVALID, "patch_ptr does not start at index_base");
+    const int64_t tot = S.h_pptr[npatch];
+    S.h_pdofs.resize((size_t)tot);
+    for (int64_t q = 0; q < tot; ++q) S.h_pdofs[q] = (int32_t)(read_index(patch_dofs, q, index_bytes) - index_base);
+    assign_smoother(h, lev, which, S);
+  });
+}
+
+int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, double atol, double rtol)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    REQUIRE(mode == GMG_MODE_PRECONDITIONER || mode == GMG_MODE_SOLVER, GMG_ERR_INVALID,
+            "mode must be :preconditioner or :solver (GMGLinearSolvers.jl:60)");
+    REQUIRE(cycle == GMG_V_CYCLE || cycle == GMG_W_CYCLE || cycle == GMG_F_CYCLE, GMG_ERR_INVALID,
+            "cycle_type must be :v_cycle, :w_cycle or :f_cycle (GMGLinearSolvers.jl:61)");
+    REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
+    h->mode = mode; h->cycle_type = cycle;
+    h->log.configure(maxiter, atol, rtol);
+  });
+}
+
+int gmg_setup(gmg_handle_t h)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    h->setup();
+  });
+}
+
+int gmg_apply(gmg_handle_t h, const double *b, double *x, int memspace, gmg_result *res, double *hist, int hist_cap)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
+    const int64_t n = h->lev[0].n;
+    const double *db = h->in_vec(b, n, memspace, h->st_b);
+    double *dx = (memspace == GMG_MEM_DEVICE) ? x : h->st_x;
+    if (memspace == GMG_MEM_HOST && h->mode == GMG_MODE_SOLVER)
+      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    const double last = h->gmg_solve_dev(dx, db, -1.0);
+    h->out_vec(x, dx, n, memspace);
+    h->log.export_to(res, hist, hist_cap, last);
+  });
+}
+
+int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int maxiter, double atol, double rtol,
+                 int flexible, int use_precond, gmg_result *res, double *hist, int hist_cap)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
+    REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
+    REQUIRE(use_precond >= 0 && use_precond <= 2, GMG_ERR_INVALID, "use_precond must be 0, 1 or 2");
+    gmg_solver &S = *h;
+    Level &L0 = S.lev[0];
+    const int64_t n = L0.n;
+    const double *db = S.in_vec(b, n, memspace, S.st_b);
+    double *dx = (memspace == GMG_MEM_DEVICE) ? x : S.st_x;
+    if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+    double *w = S.cg_w, *p = S.cg_p, *z = S.cg_z, *r = S.cg_r;
+    ConvLog log;
+    log.configure(maxiter, atol, rtol);
+
+    S.spmv_resid(L0.A, dx, db, r);                         // CGSolvers.jl:79  w = A x ; r = b - w
+    S.zero(p, n);                                          // :80
+    S.zero(z, n);                                          // :81
+    double gamma = 1.0, beta = 0.0, alpha = 0.0;           // :82
+    double resn = S.norm(n, r);                            // :85
+    bool done = log.init(resn);                            // :86
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kBlock - 1) / kBlock));
+    while (!done) {
+      if (!use_precond) {                                  // :90-92
+        S.copy(z, r, n);
+        beta = gamma; gamma = S.dot(n, r, r); beta = gamma / beta;
+      } else if (!flexible) {                              // :93-95
+        S.krylov_precond(use_precond, z, r, resn);
+        beta = gamma; gamma = S.dot(n, z, r); beta = gamma / beta;
+      } else {                                             // :96-99
+        const double delta = S.dot(n, z, r);
+        S.krylov_precond(use_precond, z, r, resn);
+        beta = gamma; gamma = S.dot(n, z, r); beta = (gamma - delta) / beta;
+      }
+      hipLaunchKernelGGL(xpby_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, S.stream, n, z, beta, p); // :101
+      HIP_CHECK(hipGetLastError());
+      S.spmv_set(L0.A, p, w);                              // :104
+      alpha = gamma / S.dot(n, p, w);                      // :105
+      hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, alpha, p, w, dx, r, S.d_partials); // :108-109
+      HIP_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, S.stream, nb, S.d_partials, S.d_scalars, 1);
+      HIP_CHECK(hipGetLastError());
+      resn = S.fetch_scalar(0);                            // :111
+      done = log.update(resn);                             // :112
+    }
+    S.out_vec(x, dx, n, memspace);
+    log.export_to(res, hist, hist_cap, resn);              // :118
+  });
+}
+
+int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m0, int restart, int m_add,
+                     int maxiter, double atol, double rtol, int use_precond, gmg_result *res, double *hist, int hist_cap)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
+    REQUIRE(m0 >= 1 && m_add >= 1 && maxiter >= 0, GMG_ERR_INVALID, "bad FGMRES sizes");
+    REQUIRE(use_precond >= 0 && use_precond <= 2, GMG_ERR_INVALID, "use_precond must be 0, 1 or 2");
+    gmg_solver &S = *h;
+    Level &L0 = S.lev[0];
+    const int64_t n = L0.n;
+    const double *db = S.in_vec(b, n, memspace, S.st_b);
+    double *dx = (memspace == GMG_MEM_DEVICE) ? x : S.st_x;
+    if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+    // caches FGMRESSolvers.jl:58-70
+    int m = std::max<int>(m0, (int)S.fg_Z.size());
+    while ((int)S.fg_V.size() < m + 1) S.fg_V.push_back(S.dvec(n));
+    while ((int)S.fg_Z.size() < m) S.fg_Z.push_back(S.dvec(n));
+    m = (int)S.fg_Z.size();
+    auto &V = S.fg_V;
+    auto &Z = S.fg_Z;
+    // Hessenberg / rotations sized for the largest basis reachable in maxiter steps
+    const int hcap = std::max(m, maxiter + 1) + 1;
+    const int ldh = hcap + 1;
+    REQUIRE(hcap + 2 < kScalarSlots, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer");
+    std::vector<double> H((size_t)ldh * hcap, 0.0), g((size_t)hcap + 1, 0.0), c((size_t)hcap, 0.0), s((size_t)hcap, 0.0);
+    auto Hm = [&](int i, int j) -> double & { return H[(size_t)(i - 1) + (size_t)(j - 1) * ldh]; };
+    ConvLog log;
+    log.configure(maxiter, atol, rtol);
+    const int grid = gmg_solver::grid_for(n);
+
+    // krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 ; FGMRESSolvers.jl:136-140
+    S.spmv_resid(L0.A, dx, db, V[0]);
+    double beta = S.norm(n, V[0]);                         // :141
+    bool done = log.init(beta);                            // :142
+    while (!done) {
+      int j = 1;                                           // :145
+      hipLaunchKernelGGL(div_kernel, dim3(grid), dim3(256), 0, S.stream, n, beta, V[0]); // :146
+      HIP_CHECK(hipGetLastError());
+      std::fill(H.begin(), H.end(), 0.0);                  // :147
+      std::fill(g.begin(), g.end(), 0.0); g[0] = beta;     // :148
+      while (!done && !(restart && j > m0)) {              // :149
+        if (j > m) {                                       // :151-154
+          for (int q = 0; q < m_add; ++q) { V.push_back(S.dvec(n)); Z.push_back(S.dvec(n)); }
+          m += m_add;
+        }
+        double *Vn = V[j], *Zj = Z[j - 1];
+        // krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25
+        S.krylov_precond(use_precond, Zj, V[j - 1], -1.0);
+        S.spmv_set(L0.A, Zj, Vn);                          // :159
+        for (int i = 1; i <= j; ++i) {                     // :160-163 modified Gram-Schmidt
+          S.dot_async(n, Vn, V[i - 1], i, false);
+          hipLaunchKernelGGL(axmy_dev_kernel, dim3(grid), dim3(256), 0, S.stream, n, S.d_scalars + i, V[i - 1], Vn);
+          HIP_CHECK(hipGetLastError());
+        }
+        S.dot_async(n, Vn, Vn, j + 1, true);               // :164
+        hipLaunchKernelGGL(div_dev_kernel, dim3(grid), dim3(256), 0, S.stream, n, S.d_scalars + (j + 1), Vn); // :165
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(S.h_scalars + 1, S.d_scalars + 1, sizeof(double) * (size_t)(j + 1), hipMemcpyDeviceToHost, S.stream));
+        HIP_CHECK(hipStreamSynchronize(S.stream));
+        for (int i = 1; i <= j + 1; ++i) Hm(i, j) = S.h_scalars[i];
+        for (int i = 1; i <= j - 1; ++i) {                 // :168-172
+          const double gm = c[i - 1] * Hm(i, j) + s[i - 1] * Hm(i + 1, j);
+          Hm(i + 1, j) = -s[i - 1] * Hm(i, j) + c[i - 1] * Hm(i + 1, j);
+          Hm(i, j) = gm;
+        }
+        { // LinearAlgebra.givensAlgorithm (:175), normal-range branch + LAPACK sign rule
+          const double f = Hm(j, j), gg = Hm(j + 1, j);
+          double cs, sn;
+          if (gg == 0.0) { cs = 1.0; sn = 0.0; }
+          else if (f == 0.0) { cs = 0.0; sn = 1.0; }
+          else {
+            const double safmn2 = std::ldexp(1.0, -485), safmx2 = 1.0 / safmn2;
+            double f1 = f, g1 = gg, scale = std::max(std::fabs(f1), std::fabs(g1));
+            while (scale >= safmx2) { f1 *= safmn2; g1 *= safmn2; scale = std::max(std::fabs(f1), std::fabs(g1)); }
+            while (scale <= safmn2) { f1 *= safmx2; g1 *= safmx2; scale = std::max(std::fabs(f1), std::fabs(g1)); }
+            const double rr = std::sqrt(f1 * f1 + g1 * g1);
+            cs = f1 / rr; sn = g1 / rr;
+            if (std::fabs(f) > std::fabs(gg) && cs < 0.0) { cs = -cs; sn = -sn; }
+          }
+          c[j - 1] = cs; s[j - 1] = sn;
+        }
+        Hm(j, j) = c[j - 1] * Hm(j, j) + s[j - 1] * Hm(j + 1, j); Hm(j + 1, j) = 0.0; // :176
+        g[j] = -s[j - 1] * g[j - 1]; g[j - 1] = c[j - 1] * g[j - 1];                  // :177
+        beta = std::fabs(g[j]);                            // :179
+        j += 1;                                            // :180
+        done = log.update(beta);                           // :181
+      }
+      j = j - 1;                                           // :183
+      for (int i = j; i >= 1; --i) {                       // :186-188
+        double acc = 0.0;
+        for (int k = i + 1; k <= j; ++k) acc += Hm(i, k) * g[k - 1];
+        g[i - 1] = (g[i - 1] - acc) / Hm(i, i);
+      }
+      for (int i = 1; i <= j; ++i) {                       // :191-193
+        hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, g[i - 1], Z[i - 1], dx);
+        HIP_CHECK(hipGetLastError());
+      }
+      S.spmv_resid(L0.A, dx, db, V[0]);                    // :194
+    }
+    S.out_vec(x, dx, n, memspace);
+    log.export_to(res, hist, hist_cap, beta);              // :197
+  });
+}
+
+int gmg_op_apply(gmg_handle_t h, int lev, int op, const double *x, double *y, int memspace)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    check_level(h, lev, op != GMG_OP_A);
+    REQUIRE(x && y, GMG_ERR_INVALID, "null vector");
+    Level &L = h->lev[lev];
+    const DevCSR *M = op == GMG_OP_A ? &L.A : op == GMG_OP_P ? &L.P : op == GMG_OP_R ? &L.R : nullptr;
+    REQUIRE(M, GMG_ERR_INVALID, "unknown operator");
+    const double *dxv = h->in_vec(x, M->ncols, memspace, h->scratch_vec(0, h->lev[0].n));
+    double *dy = memspace == GMG_MEM_DEVICE ? y : h->scratch_vec(1, h->lev[0].n);
+    h->spmv_set(*M, dxv, dy);
+    h->out_vec(y, dy, M->nrows, memspace);
+  });
+}
+
+int gmg_smooth(gmg_handle_t h, int lev, int which, double *x, double *r, int memspace)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    check_level(h, lev, true);
+    REQUIRE(x && r, GMG_ERR_INVALID, "null vector");
+    REQUIRE(which == GMG_PRE || which == GMG_POST, GMG_ERR_INVALID, "which must be GMG_PRE or GMG_POST");
+    Level &L = h->lev[lev];
+    double *dx = memspace == GMG_MEM_DEVICE ? x : h->scratch_vec(0, h->lev[0].n);
+    if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)L.n, hipMemcpyHostToDevice, h->stream));
+    const double *dr = h->in_vec(r, L.n, memspace, h->scratch_vec(1, h->lev[0].n));
+    double *rout = h->smooth(lev, which == GMG_PRE ? L.pre : L.post, dx, dr, false);
+    h->out_vec(r, rout, L.n, memspace);
+    h->out_vec(x, dx, L.n, memspace);
+  });
+}
+
+int gmg_precond_apply(gmg_handle_t h, int lev, int which, const double *r, double *dx, int memspace)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    check_level(h, lev, true);
+    REQUIRE(r && dx, GMG_ERR_INVALID, "null vector");
+    Level &L = h->lev[lev];
+    Smoother &S = which == GMG_POST ? L.post : L.pre;
+    const double *dr = h->in_vec(r, L.n, memspace, h->scratch_vec(1, h->lev[0].n));
+    double *out = memspace == GMG_MEM_DEVICE ? dx : h->scratch_vec(0, h->lev[0].n);
+    if (S.kind == SM_JACOBI) {
+      hipLaunchKernelGGL(jacobi_apply_kernel, dim3(gmg_solver::grid_for(L.n)), dim3(256), 0, h->stream, L.n, L.dinv, dr, out);
+      HIP_CHECK(hipGetLastError());
+    } else {
+      h->patch_precond(L, S, dr, 1.0, false, out, nullptr);
+    }
+    h->out_vec(dx, out, L.n, memspace);
+  });
+}
+
+int gmg_coarse_solve(gmg_handle_t h, const double *r, double *x, int memspace)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    REQUIRE(r && x, GMG_ERR_INVALID, "null vector");
+    const int64_t n = h->lev[h->nlev - 1].n;
+    const double *dr = h->in_vec(r, n, memspace, h->scratch_vec(1, h->lev[0].n));
+    double *out = memspace == GMG_MEM_DEVICE ? x : h->scratch_vec(0, h->lev[0].n);
+    h->coarse_solve(dr, out);
+    h->out_vec(x, out, n, memspace);
+  });
+}
+
+int gmg_dot(gmg_handle_t h, int64_t n, const double *a, const double *b, int memspace, double *out)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    REQUIRE(a && b && out && n >= 0, GMG_ERR_INVALID, "bad arguments");
+    if (memspace == GMG_MEM_HOST) REQUIRE(n <= h->lev[0].n, GMG_ERR_INVALID, "host vectors longer than the finest level");
+    const double *da = h->in_vec(a, n, memspace, h->scratch_vec(0, h->lev[0].n));
+    const double *db = (a == b) ? da : h->in_vec(b, n, memspace, h->scratch_vec(1, h->lev[0].n));
+    *out = h->dot(n, da, db);
+  });
+}
+
+int gmg_profile_enable(gmg_handle_t h, int lev, int enable)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    if (!enable) { h->prof_level = -1; return; }
+    check_level(h, lev, true);
+    if (h->prof_ev.empty()) {
+      h->prof_ev.resize(2 * 8192);
+      for (auto &ev : h->prof_ev) HIP_CHECK(hipEventCreate(&ev));
+    }
+    h->prof_level = lev;
+    h->prof_used = 0;
+    h->prof_ms = 0.0;
+    h->prof_launches = 0;
+  });
+}
+
+int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    REQUIRE(out, GMG_ERR_INVALID, "null output");
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+      h->prof_ms += ms;
+      h->prof_launches += 1;
+    }
+    h->prof_used = 0;
+    const int l = h->prof_level >= 0 ? h->prof_level : 0;
+    const Level &L = h->lev[l];
+    out->launches = h->prof_launches;
+    out->total_ms = h->prof_ms;
+    out->rows = L.n;
+    out->nnz = L.A.nnz;
+    // B_sweep = 12 Z + 68 N  (fp64 value + int32 column per nnz; row pointer,
+    // r, D^-1, x, dx read / dx, x, Adx, r written as in RichardsonSmoothers.jl:91-95)
+    out->alg_bytes = 12.0 * (double)L.A.nnz + 68.0 * (double)L.n;
+  });
+}
+
+int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    double BV = 0.0;
+    for (int l = 0; l < h->nlev - 1; ++l) {
+      const Level &L = h->lev[l];
+      const double Z = (double)L.A.nnz, N = (double)L.n, ZP = (double)L.P.nnz, NH = (double)h->lev[l + 1].n;
+      const double nu2 = (double)(L.pre.niter + L.post.niter);
+      BV += nu2 * (12.0 * Z + 68.0 * N) + (12.0 * Z + 28.0 * N) + 24.0 * ZP + 36.0 * N + 28.0 * NH;
+    }
+    const double NL = (double)h->lev[h->nlev - 1].n;
+    BV += 8.0 * NL * NL + 16.0 * NL;
+    if (vcycle_bytes) *vcycle_bytes = BV;
+    if (cg_iter_bytes) *cg_iter_bytes = BV + 12.0 * (double)h->lev[0].A.nnz + 132.0 * (double)h->lev[0].n;
+  });
+}
+
+int gmg_device_bytes(gmg_handle_t h, int64_t *bytes)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && bytes, GMG_ERR_INVALID, "null argument");
+    *bytes = h->dev_bytes;
+  });
+}
+
+} // extern "C"

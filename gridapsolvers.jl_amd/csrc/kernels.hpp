@@ -1,0 +1,460 @@
+// kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the GMG hot path.
+//
+// All kernels are HBM-bandwidth bound (~0.16 flop/byte): no MFMA.  Design rules
+// (cdna_hip_programming.md / MI355X_MICROARCH.md):
+//   * matrix streams (12 B/nnz) are read with perfectly coalesced, block-wide
+//     loads into registers, multiplied with the gathered vector entry and the
+//     products staged in LDS ("CSR-stream"); rows are then reduced by G lanes
+//     each with a wave64 shuffle (__shfl_xor) tail;
+//   * the gathered vectors (x, r, D^-1) live in L2 / Infinity Cache; the
+//     blockIdx -> row-range map is XCD-aware so that each XCD's private L2 sees
+//     one contiguous window of them;
+//   * element-wise work of the reference's Richardson sweep is fused into the
+//     SpMV epilogue / gather (see csr_stream_kernel EPI_SWEEP).
+//
+// Reference operations realised here (GridapSolvers.jl v0.7.1, src/):
+//   K1 mul!(y,A,x)            LinearSolvers/RichardsonSmoothers.jl:94, GMGLinearSolvers.jl:495, CGSolvers.jl:79,104
+//   K2 dx=w*Dinv*r; x+=dx     RichardsonSmoothers.jl:91-93, JacobiLinearSolvers.jl:43-47
+//   K3 r -= A dx              RichardsonSmoothers.jl:95, GMGLinearSolvers.jl:496
+//   K4 rH = R rh              GMGLinearSolvers.jl:484
+//   K5 dxh = P dxH; xh += dxh GMGLinearSolvers.jl:491,494
+//   K6 coarse solve           GMGLinearSolvers.jl:474
+//   K7 dot / norm             CGSolvers.jl:85,95,105,111 ; FGMRESSolvers.jl:141,161,164
+//   K8 axpy-class             CGSolvers.jl:101,108-109 ; FGMRESSolvers.jl:146,162,165,192
+//   K9/K10 patch solves       PatchBasedSmoothers/PatchSolvers.jl:279-300, BlockJacobiSolvers.jl:141-170
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmg {
+
+constexpr int kBlock = 256;   // 4 waves of 64
+constexpr int kTile = 2048;   // nnz staged per workgroup (16 KiB of fp64 products in LDS)
+
+enum Epi : int {
+  EPI_SET = 0,     // y = A x
+  EPI_SUB = 1,     // y = y - A x                  (K3)
+  EPI_RESID = 2,   // y = b - A x                  (CGSolvers.jl:79, GMGLinearSolvers.jl:623-624)
+  EPI_SWEEP = 3,   // one Richardson-Jacobi sweep  (K2+K1+K3 fused, see below)
+  EPI_ADDTO = 4    // y = A x ; x2 += y            (K5)
+};
+
+struct StreamArgs {
+  const void *rowptr;     // int32 or int64 [nrows+1]
+  const int32_t *col;     // [nnz]
+  const double *val;      // [nnz]
+  const int32_t *blk_row; // [nblocks+1] first row of each workgroup's row range
+  int nblocks;
+  int lanes_log2;         // G = 1<<lanes_log2 lanes cooperate on one row in the reduce phase
+  int xcd_remap;          // 1: contiguous block ranges per XCD
+  const double *x;        // gather source
+  const double *dinv;     // EPI_SWEEP: D^-1
+  double omega;           // EPI_SWEEP
+  double *y;              // output
+  const double *b;        // EPI_RESID: b ; EPI_SWEEP: r_old (row-wise read)
+  double *x2;             // EPI_SWEEP: x (updated in place) ; EPI_ADDTO: x
+  int x_zero;             // EPI_SWEEP: x is known to be zero on entry (skip the read)
+};
+
+__device__ __forceinline__ int remap_block(int b, int nb, int on)
+{
+  // Observed dispatch: workgroup b runs on XCD b % 8 (performance only, never
+  // correctness).  Give XCD k the contiguous chunk [k*nb/8, (k+1)*nb/8).
+  if (!on || nb < 64) return b;
+  const int per = nb >> 3, rem = nb & 7;
+  const int xcd = b & 7, slot = b >> 3;
+  // XCDs < rem own (per+1) blocks
+  const int base = xcd * per + (xcd < rem ? xcd : rem);
+  return base + slot;
+}
+
+// One workgroup = one contiguous row range whose nnz fit the LDS tile.
+//
+// EPI_SWEEP fuses a whole sweep of RichardsonSmoothers.jl:90-97 with M = Jacobi:
+//     dx = omega .* (inv_diag .* r) ; x .= x .+ dx ; r .= r .- A*dx
+// dx is never materialised: the gather computes dx_j = omega*(dinv_j*r_old_j) on
+// the fly (same two roundings as the reference) and the new residual goes to a
+// second buffer (ping-pong), so one pass over A does the job of the reference's
+// five passes.
+template <int EPI, typename PtrT>
+__global__ __launch_bounds__(kBlock) void csr_stream_kernel(StreamArgs a)
+{
+  __shared__ double prod[kTile];
+  const int tid = threadIdx.x;
+  const int blk = remap_block(blockIdx.x, a.nblocks, a.xcd_remap);
+  const PtrT *__restrict__ rowptr = reinterpret_cast<const PtrT *>(a.rowptr);
+  const int r0 = a.blk_row[blk];
+  const int r1 = a.blk_row[blk + 1];
+  const PtrT nz0 = rowptr[r0];
+  const PtrT nz1 = rowptr[r1];
+  const int64_t cnt = (int64_t)(nz1 - nz0);
+  const int32_t *__restrict__ col = a.col;
+  const double *__restrict__ val = a.val;
+  const double *__restrict__ xg = a.x;
+
+  if (cnt <= kTile) {
+    // ---- phase 1: coalesced stream of (col,val), gather, products -> LDS ----
+    constexpr int U = kTile / kBlock; // 8 independent loads in flight per lane
+    int32_t c[U];
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = tid + u * kBlock;
+      const bool ok = k < cnt;
+      c[u] = ok ? __builtin_nontemporal_load(col + nz0 + k) : -1;
+      v[u] = ok ? __builtin_nontemporal_load(val + nz0 + k) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = tid + u * kBlock;
+      if (c[u] >= 0) {
+        double xv;
+        if (EPI == EPI_SWEEP) xv = a.omega * (a.dinv[c[u]] * xg[c[u]]);
+        else xv = xg[c[u]];
+        prod[k] = v[u] * xv;
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: G lanes per row, strided LDS reads + shuffle tail ----
+    const int G = 1 << a.lanes_log2;
+    const int rows_per_pass = kBlock >> a.lanes_log2;
+    const int sub = tid & (G - 1);
+    for (int rbase = r0; rbase < r1; rbase += rows_per_pass) {
+      const int row = rbase + (tid >> a.lanes_log2);
+      double s = 0.0;
+      if (row < r1) {
+        const int k0 = (int)(rowptr[row] - nz0), k1 = (int)(rowptr[row + 1] - nz0);
+        for (int k = k0 + sub; k < k1; k += G) s += prod[k];
+      }
+      for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (row < r1 && sub == 0) {
+        if (EPI == EPI_SET) a.y[row] = s;
+        else if (EPI == EPI_SUB) a.y[row] = a.y[row] - s;
+        else if (EPI == EPI_RESID) a.y[row] = a.b[row] - s;
+        else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = a.x2[row] + s; }
+        else { // EPI_SWEEP
+          const double ro = a.b[row];
+          const double dxi = a.omega * (a.dinv[row] * ro);
+          const double xo = a.x_zero ? 0.0 : a.x2[row];
+          a.x2[row] = xo + dxi;
+          a.y[row] = ro - s;
+        }
+      }
+    }
+  } else {
+    // ---- long row: the range is a single row; whole workgroup strides it ----
+    double s = 0.0;
+    for (int64_t k = tid; k < cnt; k += kBlock) {
+      const int32_t cc = col[nz0 + k];
+      double xv;
+      if (EPI == EPI_SWEEP) xv = a.omega * (a.dinv[cc] * xg[cc]);
+      else xv = xg[cc];
+      s += val[nz0 + k] * xv;
+    }
+    prod[tid] = s;
+    __syncthreads();
+    for (int w = kBlock >> 1; w > 0; w >>= 1) {
+      if (tid < w) prod[tid] += prod[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int row = r0;
+      s = prod[0];
+      if (EPI == EPI_SET) a.y[row] = s;
+      else if (EPI == EPI_SUB) a.y[row] = a.y[row] - s;
+      else if (EPI == EPI_RESID) a.y[row] = a.b[row] - s;
+      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = a.x2[row] + s; }
+      else {
+        const double ro = a.b[row];
+        const double dxi = a.omega * (a.dinv[row] * ro);
+        const double xo = a.x_zero ? 0.0 : a.x2[row];
+        a.x2[row] = xo + dxi;
+        a.y[row] = ro - s;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// inv_diag = 1.0 ./ diag(A)   (JacobiLinearSolvers.jl:20-23)
+// ---------------------------------------------------------------------------
+template <typename PtrT>
+__global__ void inv_diag_kernel(int64_t n, const PtrT *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                const double *__restrict__ val, double *__restrict__ dinv, int *__restrict__ nzero)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double d = 0.0;
+  for (PtrT k = rowptr[i]; k < rowptr[i + 1]; ++k)
+    if (col[k] == (int32_t)i) d += val[k];
+  if (d == 0.0) atomicAdd(nzero, 1);
+  dinv[i] = 1.0 / d;
+}
+
+// ---------------------------------------------------------------------------
+// K7: deterministic two-stage fp64 reductions.  Stage 1 writes one partial per
+// workgroup (fixed grid => fixed summation tree => bit-reproducible run to
+// run); stage 2 is a single workgroup.
+// ---------------------------------------------------------------------------
+constexpr int kRedBlocks = 1024;
+
+__device__ __forceinline__ double wave_sum(double s)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  return s;
+}
+
+__device__ __forceinline__ double block_sum(double s, double *sh /*[4]*/)
+{
+  s = wave_sum(s);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = s;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  return t; // valid on thread 0
+}
+
+__global__ __launch_bounds__(kBlock) void dot_partial_kernel(int64_t n, const double *__restrict__ a,
+                                                             const double *__restrict__ b,
+                                                             double *__restrict__ partials, int vec)
+{
+  __shared__ double sh[4];
+  double s = 0.0;
+  if (vec) { // both pointers 16-byte aligned: 16 B/lane loads
+    const int64_t n2 = n >> 1;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a);
+    const double2 *b2 = reinterpret_cast<const double2 *>(b);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kBlock) {
+      const double2 u = a2[i], v = b2[i];
+      s += u.x * v.x;
+      s += u.y * v.y;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) s += a[n - 1] * b[n - 1];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) s += a[i] * b[i];
+  }
+  const double t = block_sum(s, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// out[slot] = (take_sqrt ? sqrt : id)(sum partials)
+__global__ __launch_bounds__(kBlock) void reduce_final_kernel(int nparts, const double *__restrict__ partials,
+                                                              double *__restrict__ out, int take_sqrt)
+{
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) s += partials[i];
+  const double t = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = take_sqrt ? sqrt(t) : t;
+}
+
+// ---------------------------------------------------------------------------
+// K8: axpy-class kernels
+// ---------------------------------------------------------------------------
+// p = z + beta*p                     (CGSolvers.jl:101)
+__global__ void xpby_kernel(int64_t n, const double *__restrict__ z, double beta, double *__restrict__ p)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = z[i] + beta * p[i];
+}
+// x += alpha*p ; r -= alpha*w ; partial ||r||^2   (CGSolvers.jl:108-111)
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double alpha, const double *__restrict__ p,
+                                                           const double *__restrict__ w, double *__restrict__ x,
+                                                           double *__restrict__ r, double *__restrict__ partials)
+{
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    x[i] += alpha * p[i];
+    const double rn = r[i] - alpha * w[i];
+    r[i] = rn;
+    s += rn * rn;
+  }
+  const double t = block_sum(s, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+// y += alpha*x                        (FGMRESSolvers.jl:162,192)
+__global__ void axpy_kernel(int64_t n, double alpha, const double *__restrict__ x, double *__restrict__ y)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = y[i] + alpha * x[i];
+}
+// y = y - alpha*x  with alpha read from device memory (MGS step without a host round trip)
+__global__ void axmy_dev_kernel(int64_t n, const double *__restrict__ alpha, const double *__restrict__ x,
+                                double *__restrict__ y)
+{
+  const double al = alpha[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = y[i] - al * x[i];
+}
+// x ./= s                             (FGMRESSolvers.jl:146,165) -- true division as the reference
+__global__ void div_kernel(int64_t n, double s, double *__restrict__ x)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = x[i] / s;
+}
+__global__ void div_dev_kernel(int64_t n, const double *__restrict__ s, double *__restrict__ x)
+{
+  const double d = s[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = x[i] / d;
+}
+// dx = omega*(dinv.*r) ; optionally x += dx     (unfused Jacobi apply, gmg_precond_apply)
+__global__ void jacobi_apply_kernel(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r,
+                                    double *__restrict__ dx)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dx[i] = dinv[i] * r[i];
+}
+
+// ---------------------------------------------------------------------------
+// K6: coarsest solve x = Ainv * r, Ainv dense row-major n x n.  One wave per
+// row, 16 B/lane loads, wave64 shuffle reduction.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int n, const double *__restrict__ Ainv,
+                                                            const double *__restrict__ r, double *__restrict__ x)
+{
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const double *row = Ainv + (size_t)wave * n;
+  double s = 0.0;
+  for (int j = lane; j < n; j += 64) s += row[j] * r[j];
+  s = wave_sum(s);
+  if (lane == 0) x[wave] = s;
+}
+
+// ---------------------------------------------------------------------------
+// K9/K10: patch smoother.
+//  setup : extract A[p,p] (BlockJacobiSolvers.jl:160), factorise (LU with partial
+//          pivoting = PatchSolvers.jl:176 lu!, or NoPivot = BlockJacobiSolvers.jl:162)
+//          and store the explicit inverse block (n_p x n_p, row-major).
+//  apply : per patch  xp = inv(A_pp) * b[rows_p]  -> contribution buffer;
+//          per dof    dx_i = omega * sum_{p contains i, ascending p} xp ; x_i += dx_i
+//          (same accumulation order as the reference's sequential patch loop
+//           PatchSolvers.jl:288-297 => deterministic, no atomics).
+// ---------------------------------------------------------------------------
+// One thread per patch builds the inverse by Gauss-Jordan on an identity-augmented
+// copy held in global scratch (setup only, not on the timed path).
+template <typename PtrT>
+__global__ void patch_factor_kernel(int64_t npatch, const int64_t *__restrict__ pptr, const int32_t *__restrict__ pdofs,
+                                    const int64_t *__restrict__ boff, const PtrT *__restrict__ rowptr,
+                                    const int32_t *__restrict__ col, const double *__restrict__ val,
+                                    double *__restrict__ binv, double *__restrict__ scratch, int max_np,
+                                    int pivoting, int *__restrict__ nsing)
+{
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npatch) return;
+  const int np = (int)(pptr[p + 1] - pptr[p]);
+  if (np == 0) return;
+  const int32_t *dofs = pdofs + pptr[p];
+  double *M = scratch + (size_t)p * max_np * max_np; // row-major np x np copy of A[p,p]
+  double *X = binv + boff[p];                        // row-major np x np, becomes the inverse
+  for (int r = 0; r < np; ++r) {
+    for (int c = 0; c < np; ++c) { M[r * np + c] = 0.0; X[r * np + c] = (r == c) ? 1.0 : 0.0; }
+    const int32_t gr = dofs[r];
+    for (PtrT k = rowptr[gr]; k < rowptr[gr + 1]; ++k) {
+      const int32_t gc = col[k];
+      for (int c = 0; c < np; ++c)
+        if (dofs[c] == gc) M[r * np + c] += val[k];
+    }
+  }
+  // LU-ordered elimination (forward), then back-substitution on all columns of X
+  for (int j = 0; j < np; ++j) {
+    int piv = j;
+    if (pivoting) {
+      double mx = fabs(M[j * np + j]);
+      for (int i = j + 1; i < np; ++i) {
+        const double v = fabs(M[i * np + j]);
+        if (v > mx) { mx = v; piv = i; }
+      }
+    }
+    if (piv != j)
+      for (int c = 0; c < np; ++c) {
+        double t = M[j * np + c]; M[j * np + c] = M[piv * np + c]; M[piv * np + c] = t;
+        t = X[j * np + c]; X[j * np + c] = X[piv * np + c]; X[piv * np + c] = t;
+      }
+    const double d = M[j * np + j];
+    if (d == 0.0) { atomicAdd(nsing, 1); return; }
+    for (int i = j + 1; i < np; ++i) {
+      const double l = M[i * np + j] / d;
+      if (l != 0.0) {
+        for (int c = j + 1; c < np; ++c) M[i * np + c] -= l * M[j * np + c];
+        for (int c = 0; c < np; ++c) X[i * np + c] -= l * X[j * np + c];
+      }
+      M[i * np + j] = 0.0;
+    }
+  }
+  for (int j = np - 1; j >= 0; --j) {
+    const double d = M[j * np + j];
+    for (int c = 0; c < np; ++c) {
+      double s = X[j * np + c];
+      for (int k = j + 1; k < np; ++k) s -= M[j * np + k] * X[k * np + c];
+      X[j * np + c] = s / d;
+    }
+  }
+}
+
+// One wave per patch: lanes = rows of the block (n_p <= 64), b_p staged in LDS.
+__global__ __launch_bounds__(kBlock) void patch_apply_kernel(int64_t npatch, const int64_t *__restrict__ pptr,
+                                                             const int32_t *__restrict__ pdofs,
+                                                             const int64_t *__restrict__ boff,
+                                                             const double *__restrict__ binv,
+                                                             const double *__restrict__ b,
+                                                             double *__restrict__ contrib)
+{
+  __shared__ double sb[4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + w;
+  if (p >= npatch) return;
+  const int64_t q0 = pptr[p];
+  const int np = (int)(pptr[p + 1] - q0);
+  if (np == 0) return;
+  if (lane < np) sb[w][lane] = b[pdofs[q0 + lane]];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < np) {
+    const double *row = binv + boff[p] + (size_t)lane * np;
+    double s = 0.0;
+    for (int k = 0; k < np; ++k) s += row[k] * sb[w][k];
+    contrib[q0 + lane] = s;
+  }
+}
+
+// Generic fallback for patches with n_p > 64: one workgroup per patch.
+__global__ __launch_bounds__(kBlock) void patch_apply_big_kernel(int64_t npatch, const int64_t *__restrict__ pptr,
+                                                                 const int32_t *__restrict__ pdofs,
+                                                                 const int64_t *__restrict__ boff,
+                                                                 const double *__restrict__ binv,
+                                                                 const double *__restrict__ b,
+                                                                 double *__restrict__ contrib)
+{
+  const int64_t p = blockIdx.x;
+  const int64_t q0 = pptr[p];
+  const int np = (int)(pptr[p + 1] - q0);
+  for (int r = threadIdx.x; r < np; r += kBlock) {
+    const double *row = binv + boff[p] + (size_t)r * np;
+    double s = 0.0;
+    for (int k = 0; k < np; ++k) s += row[k] * b[pdofs[q0 + k]];
+    contrib[q0 + r] = s;
+  }
+}
+
+// dof-centric gather: dx_i = omega * sum contrib[inc[k]] ; optionally x_i += dx_i
+__global__ void patch_gather_kernel(int64_t n, const int64_t *__restrict__ iptr, const int64_t *__restrict__ inc,
+                                    const double *__restrict__ contrib, double omega, int relax,
+                                    double *__restrict__ dx, double *__restrict__ x)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int64_t k = iptr[i]; k < iptr[i + 1]; ++k) s += contrib[inc[k]];
+  if (relax) {
+    s = omega * s;
+    x[i] = x[i] + s;
+  }
+  dx[i] = s;
+}
+
+} // namespace gmg

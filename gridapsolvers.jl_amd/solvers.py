@@ -1,0 +1,450 @@
+"""Host-side mirror of the reference's Gridap.Algebra surface for the GMG path.
+
+The reference's host language (Julia) is not available in this image, so the
+layer a GridapSolvers user touches is mirrored here in Python with the same
+names, argument meaning, defaults and error behaviour, on top of the C ABI
+(include/gmg_amd.h).  The Julia binding of the same ABI lives in
+julia/GridapSolversAMD.jl.
+
+    reference (src/LinearSolvers)                      here
+    ------------------------------------------------   ---------------------------
+    JacobiLinearSolver()            JacobiLinearSolvers.jl:6        JacobiLinearSolver
+    RichardsonSmoother(M,niter,w)   RichardsonSmoothers.jl:21-30    RichardsonSmoother
+    PatchSolver / BlockJacobiSolver PatchBasedSmoothers/*.jl        PatchSolver / BlockJacobiSolver
+    GMGLinearSolver(mats,P,R;...)   GMGLinearSolvers.jl:48-69       GMGLinearSolver
+    CGSolver(Pl;...)                Krylov/CGSolvers.jl:19          CGSolver
+    FGMRESSolver(m,Pr;...)          Krylov/FGMRESSolvers.jl:26      FGMRESSolver
+    symbolic_setup / numerical_setup / numerical_setup! / solve!    same names (solve_ = solve!)
+    ConvergenceLog                  SolverInterfaces/ConvergenceLogs.jl:42   ConvergenceLog
+
+All arithmetic happens in libgmgamd.so on the GPU.  Vectors may be numpy arrays
+(host memory, copied in/out per call) or CUDA/HIP torch tensors (used in place).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+__all__ = [
+    "JacobiLinearSolver", "RichardsonSmoother", "PatchSolver", "BlockJacobiSolver", "LUSolver",
+    "GMGLinearSolver", "CGSolver", "FGMRESSolver", "ConvergenceLog",
+    "symbolic_setup", "numerical_setup", "numerical_setup_", "solve_", "mul_",
+    "SOLVER_CONVERGED_ATOL", "SOLVER_CONVERGED_RTOL", "SOLVER_DIVERGED_MAXITER", "SOLVER_DIVERGED_BREAKDOWN",
+]
+
+SOLVER_CONVERGED_ATOL, SOLVER_CONVERGED_RTOL, SOLVER_DIVERGED_MAXITER, SOLVER_DIVERGED_BREAKDOWN = 0, 1, 2, 3
+
+
+# ----------------------------------------------------------------------------
+# small solver description objects (constructors only hold parameters)
+# ----------------------------------------------------------------------------
+class JacobiLinearSolver:
+    """struct JacobiLinearSolver <: LinearSolver (JacobiLinearSolvers.jl:6)."""
+
+
+class LUSolver:
+    """Gridap.Algebra.LUSolver(): the default coarsest_solver (GMGLinearSolvers.jl:54)."""
+
+
+class PatchSolver:
+    """PatchBasedSmoothers.PatchSolver restricted to what reaches solve!: the
+    patch dof tables (patch_rows == patch_cols for :star assembly) -- PatchSolvers.jl:18-54."""
+    kind = abi.PATCH_LU
+
+    def __init__(self, patch_ptr, patch_dofs):
+        self.patch_ptr = np.ascontiguousarray(patch_ptr, dtype=np.int64)
+        self.patch_dofs = np.ascontiguousarray(patch_dofs, dtype=np.int32)
+        if self.patch_ptr.ndim != 1 or self.patch_ptr.size < 1:
+            raise ValueError("patch_ptr must have npatch+1 entries")
+
+
+class BlockJacobiSolver(PatchSolver):
+    """BlockJacobiSolver(patch_rows, patch_cols) -- BlockJacobiSolvers.jl:2-16 (NoPivot LU, :162)."""
+    kind = abi.PATCH_NOPIVOT
+
+
+class RichardsonSmoother:
+    """RichardsonSmoother(M, niter=1, omega=1.0) -- RichardsonSmoothers.jl:21-30."""
+
+    def __init__(self, M, niter=1, omega=1.0):
+        if not isinstance(M, (JacobiLinearSolver, PatchSolver)):
+            raise TypeError("RichardsonSmoother: M must be JacobiLinearSolver, PatchSolver or BlockJacobiSolver")
+        self.M, self.niter, self.omega = M, int(niter), float(omega)
+
+
+class ConvergenceLog:
+    """ConvergenceLog{Float64}: name, tols, num_iters, residuals (ConvergenceLogs.jl:42-60)."""
+
+    def __init__(self, name, maxiter, atol, rtol):
+        self.name, self.maxiter, self.atol, self.rtol = name, int(maxiter), float(atol), float(rtol)
+        self.num_iters = 0
+        self.residuals = np.zeros(self.maxiter + 1)
+        self.flag = None
+
+    def _fill(self, res, hist):
+        self.num_iters = int(res.niters)
+        self.residuals[:] = 0.0
+        self.residuals[: self.num_iters + 1] = hist[: self.num_iters + 1]
+        self.flag = int(res.flag)
+
+    def summary(self):
+        r = self.residuals[self.num_iters]
+        return (f"Convergence[{self.name}]: conv_flag={self.flag}, niter={self.num_iters}, "
+                f"r_abs={r}, r_rel={r / self.residuals[0] if self.residuals[0] else float('nan')}")
+
+
+_MODES = {"preconditioner": abi.MODE_PRECONDITIONER, "solver": abi.MODE_SOLVER}
+_CYCLES = {"v_cycle": abi.V_CYCLE, "w_cycle": abi.W_CYCLE, "f_cycle": abi.F_CYCLE}
+
+
+class GMGLinearSolver:
+    """GMGLinearSolver(smatrices, interp, restrict; pre_smoothers, post_smoothers,
+    coarsest_solver, mode, cycle_type, maxiter, atol, rtol) -- GMGLinearSolvers.jl:48-69.
+
+    smatrices / interp / restrict are sequences of CSR-like objects with fields
+    (shape, ptr, idx, val), 0-based (e.g. poisson.CSR or scipy.sparse.csr_matrix
+    via `from_scipy`).  restrict=None means R = P^T (the :residual-mode transfer of
+    GridTransferOperators.jl:202-209 on nested meshes)."""
+
+    def __init__(self, smatrices, interp, restrict=None, pre_smoothers=None, post_smoothers=None,
+                 coarsest_solver=None, mode="preconditioner", cycle_type="v_cycle",
+                 maxiter=100, atol=1.0e-14, rtol=1.0e-8, verbose=False):
+        nlev = len(smatrices)
+        if pre_smoothers is None:  # Fill(RichardsonSmoother(JacobiLinearSolver(),10),nlev-1)
+            pre_smoothers = [RichardsonSmoother(JacobiLinearSolver(), 10) for _ in range(nlev - 1)]
+        if post_smoothers is None:
+            post_smoothers = pre_smoothers
+        if restrict is None:
+            restrict = [None] * (nlev - 1)
+        # @check length(smatrices)-1 == length(interp) == ... (GMGLinearSolvers.jl:59)
+        if not (nlev - 1 == len(interp) == len(restrict) == len(pre_smoothers) == len(post_smoothers)):
+            raise ValueError("length(smatrices)-1 must equal the number of transfer operators and smoothers")
+        if mode not in _MODES:          # :60
+            raise ValueError("mode must be 'preconditioner' or 'solver'")
+        if cycle_type not in _CYCLES:   # :61
+            raise ValueError("cycle_type must be 'v_cycle', 'w_cycle' or 'f_cycle'")
+        if coarsest_solver is not None and not isinstance(coarsest_solver, LUSolver):
+            raise NotImplementedError("only coarsest_solver=LUSolver() is provided on the device")
+        self.smatrices, self.interp, self.restrict = list(smatrices), list(interp), list(restrict)
+        self.pre_smoothers, self.post_smoothers = list(pre_smoothers), list(post_smoothers)
+        self.mode, self.cycle_type = mode, cycle_type
+        self.log = ConvergenceLog("GMG", maxiter, atol, rtol)
+
+    def num_levels(self):
+        return len(self.smatrices)
+
+
+class CGSolver:
+    """CGSolver(Pl; maxiter=1000, atol=1e-12, rtol=1e-6, flexible=false) -- CGSolvers.jl:19."""
+
+    def __init__(self, Pl=None, maxiter=1000, atol=1e-12, rtol=1.0e-6, flexible=False, verbose=0, name="CG"):
+        self.Pl, self.flexible = Pl, bool(flexible)
+        self.log = ConvergenceLog(name, maxiter, atol, rtol)
+
+
+class FGMRESSolver:
+    """FGMRESSolver(m, Pr; Pl=nothing, restart=false, m_add=1, maxiter=100, atol=1e-12,
+    rtol=1e-6) -- FGMRESSolvers.jl:26."""
+
+    def __init__(self, m, Pr, Pl=None, restart=False, m_add=1, maxiter=100, atol=1e-12, rtol=1.0e-6,
+                 verbose=False, name="FGMRES"):
+        if Pl is not None:
+            raise NotImplementedError("left preconditioner of FGMRES is not on the device path")
+        self.m, self.Pr, self.restart, self.m_add = int(m), Pr, bool(restart), int(m_add)
+        self.log = ConvergenceLog(name, maxiter, atol, rtol)
+
+
+# ----------------------------------------------------------------------------
+# vector / matrix marshalling
+# ----------------------------------------------------------------------------
+def _is_device(v):
+    return hasattr(v, "data_ptr") and getattr(v, "is_cuda", False)
+
+
+def _vec(v, n=None, writable=False):
+    """-> (pointer, memspace, keepalive)."""
+    if _is_device(v):
+        import torch
+        if v.dtype != torch.float64 or not v.is_contiguous():
+            raise TypeError("device vectors must be contiguous float64 tensors")
+        if n is not None and v.numel() != n:
+            raise ValueError(f"vector length {v.numel()} != {n}")
+        return C.c_void_p(v.data_ptr()), abi.MEM_DEVICE, v
+    if not isinstance(v, np.ndarray) or v.dtype != np.float64 or not v.flags.c_contiguous:
+        if writable:
+            raise TypeError("output vectors must be contiguous float64 numpy arrays (or CUDA tensors)")
+        v = np.ascontiguousarray(v, dtype=np.float64)
+    if n is not None and v.size != n:
+        raise ValueError(f"vector length {v.size} != {n}")
+    return C.c_void_p(v.ctypes.data), abi.MEM_HOST, v
+
+
+def _csr_fields(M):
+    """Accept poisson.CSR, scipy.sparse CSR/CSC, or any object with shape/ptr/idx/val."""
+    if hasattr(M, "indptr"):  # scipy
+        layout = abi.CSC if M.format == "csc" else abi.CSR
+        if M.format not in ("csr", "csc"):
+            M = M.tocsr(); layout = abi.CSR
+        return M.shape, np.ascontiguousarray(M.indptr), np.ascontiguousarray(M.indices), \
+            np.ascontiguousarray(M.data, dtype=np.float64), layout, 0
+    base = getattr(M, "index_base", 0)
+    layout = getattr(M, "layout", abi.CSR)
+    return M.shape, np.ascontiguousarray(M.ptr), np.ascontiguousarray(M.idx), \
+        np.ascontiguousarray(M.val, dtype=np.float64), layout, base
+
+
+def _set_op(fn, h, lev, M):
+    shape, ptr, idx, val, layout, base = _csr_fields(M)
+    if ptr.dtype != idx.dtype:
+        ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
+    if ptr.dtype not in (np.int32, np.int64):
+        raise TypeError("index arrays must be int32 or int64")
+    nnz = int(val.size)
+    abi.check(h, fn(h, lev, shape[0], shape[1], nnz, C.c_void_p(ptr.ctypes.data), C.c_void_p(idx.ctypes.data),
+                    C.c_void_p(val.ctypes.data), layout, base, ptr.dtype.itemsize))
+
+
+# ----------------------------------------------------------------------------
+# setups
+# ----------------------------------------------------------------------------
+class GMGSymbolicSetup:
+    """GMGLinearSolvers.jl:160-170: no work."""
+
+    def __init__(self, solver):
+        self.solver = solver
+
+
+class GMGNumericalSetup:
+    """GMGNumericalSetup (GMGLinearSolvers.jl:172-210) backed by a native handle;
+    released by a finalizer like ext/PardisoExt.jl:54-61."""
+
+    def __init__(self, solver, mat, device_id=None):
+        lib = abi.load()
+        self.solver = solver
+        self._lib = lib
+        if device_id is None:
+            device_id = 0
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    device_id = torch.cuda.current_device()
+            except Exception:
+                pass
+        h = C.c_void_p()
+        abi.check(None, lib.gmg_create(C.byref(h), solver.num_levels(), device_id))
+        self.h = h
+        try:
+            self._upload(mat)
+        except Exception:
+            self.close()
+            raise
+
+    def _upload(self, mat):
+        lib, h, s = self._lib, self.h, self.solver
+        nlev = s.num_levels()
+        mats = list(s.smatrices)
+        if mat is not None:
+            mats[0] = mat  # smatrices[1] = mat, GMGLinearSolvers.jl:338
+        for l, A in enumerate(mats):
+            _set_op(lib.gmg_set_matrix, h, l, A)
+        for l in range(nlev - 1):
+            _set_op(lib.gmg_set_prolongation, h, l, s.interp[l])
+            if s.restrict[l] is not None:
+                _set_op(lib.gmg_set_restriction, h, l, s.restrict[l])
+            pre, post = s.pre_smoothers[l], s.post_smoothers[l]
+            if post is pre:
+                self._set_smoother(l, abi.PRE_AND_POST, pre)
+            else:
+                self._set_smoother(l, abi.PRE, pre)
+                self._set_smoother(l, abi.POST, post)
+        abi.check(h, lib.gmg_set_options(h, _MODES[s.mode], _CYCLES[s.cycle_type], s.log.maxiter, s.log.atol, s.log.rtol))
+        abi.check(h, lib.gmg_setup(h))
+        self.n = int(_csr_fields(mats[0])[0][0])
+        self.sizes = [int(_csr_fields(A)[0][0]) for A in mats]
+
+    def _set_smoother(self, l, which, sm):
+        lib, h = self._lib, self.h
+        if not isinstance(sm, RichardsonSmoother):
+            raise TypeError("smoothers must be RichardsonSmoother objects")
+        if isinstance(sm.M, JacobiLinearSolver):
+            abi.check(h, lib.gmg_set_smoother_jacobi(h, l, which, sm.niter, sm.omega))
+        else:
+            pp, pd = sm.M.patch_ptr, sm.M.patch_dofs.astype(np.int64)
+            abi.check(h, lib.gmg_set_smoother_patch(h, l, which, sm.niter, sm.omega, sm.M.kind, pp.size - 1,
+                                                    C.c_void_p(pp.ctypes.data), C.c_void_p(pd.ctypes.data), 0, 8))
+
+    # -- numerical_setup!(ns, A): FromMatrices variant is unsupported in the reference
+    #    (GMGLinearSolvers.jl:249-258 logs @error); here new values on the same pattern are accepted.
+    def update(self, mat):
+        shape, ptr, idx, val, layout, base = _csr_fields(mat)
+        if layout != abi.CSR:
+            raise NotImplementedError("numerical_setup! needs CSR values in the handle's order")
+        abi.check(self.h, self._lib.gmg_update_values(self.h, 0, C.c_void_p(val.ctypes.data)))
+        abi.check(self.h, self._lib.gmg_setup(self.h))
+        return self
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.gmg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- operator-level helpers (duck-typed mul! / smoother solve!)
+    def op_apply(self, lev, op, x, y):
+        px, ms, _k1 = _vec(x)
+        py, ms2, _k2 = _vec(y, writable=True)
+        if ms != ms2:
+            raise TypeError("x and y must live in the same memory space")
+        abi.check(self.h, self._lib.gmg_op_apply(self.h, lev, op, px, py, ms))
+        return y
+
+    def smooth(self, lev, x, r, which=abi.PRE):
+        px, ms, _k1 = _vec(x, self.sizes[lev], writable=True)
+        pr, ms2, _k2 = _vec(r, self.sizes[lev], writable=True)
+        if ms != ms2:
+            raise TypeError("x and r must live in the same memory space")
+        abi.check(self.h, self._lib.gmg_smooth(self.h, lev, which, px, pr, ms))
+        return x, r
+
+    def precond(self, lev, r, dx, which=abi.PRE):
+        pr, ms, _k1 = _vec(r, self.sizes[lev])
+        pd, ms2, _k2 = _vec(dx, self.sizes[lev], writable=True)
+        if ms != ms2:
+            raise TypeError("r and dx must live in the same memory space")
+        abi.check(self.h, self._lib.gmg_precond_apply(self.h, lev, which, pr, pd, ms))
+        return dx
+
+    def coarse_solve(self, r, x):
+        pr, ms, _k1 = _vec(r, self.sizes[-1])
+        px, ms2, _k2 = _vec(x, self.sizes[-1], writable=True)
+        if ms != ms2:
+            raise TypeError("r and x must live in the same memory space")
+        abi.check(self.h, self._lib.gmg_coarse_solve(self.h, pr, px, ms))
+        return x
+
+    def dot(self, a, b):
+        pa, ms, _k1 = _vec(a)
+        pb, ms2, _k2 = _vec(b)
+        out = C.c_double(0.0)
+        n = a.numel() if _is_device(a) else _k1.size
+        abi.check(self.h, self._lib.gmg_dot(self.h, n, pa, pb, ms, C.byref(out)))
+        return out.value
+
+    def profile(self, lev=0, enable=True):
+        abi.check(self.h, self._lib.gmg_profile_enable(self.h, lev, 1 if enable else 0))
+
+    def kernel_stats(self):
+        st = abi.KernelStats()
+        abi.check(self.h, self._lib.gmg_get_kernel_stats(self.h, C.byref(st)))
+        return dict(launches=st.launches, total_ms=st.total_ms, alg_bytes=st.alg_bytes, rows=st.rows, nnz=st.nnz)
+
+    def model_bytes(self):
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        abi.check(self.h, self._lib.gmg_model_bytes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def device_bytes(self):
+        v = C.c_int64(0)
+        abi.check(self.h, self._lib.gmg_device_bytes(self.h, C.byref(v)))
+        return v.value
+
+
+class _KrylovSymbolicSetup:
+    def __init__(self, solver):
+        self.solver = solver
+
+
+class _KrylovNumericalSetup:
+    """CGNumericalSetup / FGMRESNumericalSetup: holds the preconditioner's numerical
+    setup (CGSolvers.jl:50-55, FGMRESSolvers.jl:96-102)."""
+
+    def __init__(self, solver, A, device_id=None):
+        self.solver = solver
+        P = solver.Pl if isinstance(solver, CGSolver) else solver.Pr
+        if isinstance(P, GMGLinearSolver):
+            self.pc_kind, gmg = 1, P
+        elif isinstance(P, tuple) and len(P) == 2 and isinstance(P[1], GMGLinearSolver) and \
+                (P[0] is None or isinstance(P[0], JacobiLinearSolver)):
+            # (None | JacobiLinearSolver(), gmg): Krylov on the handle's finest matrix with Pl = nothing / Jacobi
+            self.pc_kind, gmg = (0 if P[0] is None else 2), P[1]
+        else:
+            raise NotImplementedError("the device Krylov solvers take a GMGLinearSolver preconditioner "
+                                      "(or (None|JacobiLinearSolver(), gmg) to reuse its finest matrix)")
+        self.P_ns = GMGNumericalSetup(gmg, A, device_id)   # numerical_setup(symbolic_setup(Pl,A),A)
+        self.n = self.P_ns.n
+
+
+def symbolic_setup(solver, A=None):
+    """Gridap.Algebra.symbolic_setup(solver, A)."""
+    if isinstance(solver, GMGLinearSolver):
+        return GMGSymbolicSetup(solver)
+    if isinstance(solver, (CGSolver, FGMRESSolver)):
+        return _KrylovSymbolicSetup(solver)
+    raise TypeError(f"no symbolic_setup for {type(solver).__name__}")
+
+
+def numerical_setup(ss, A=None, device_id=None):
+    """Gridap.Algebra.numerical_setup(ss, A)."""
+    if isinstance(ss, GMGSymbolicSetup):
+        return GMGNumericalSetup(ss.solver, A, device_id)
+    if isinstance(ss, _KrylovSymbolicSetup):
+        return _KrylovNumericalSetup(ss.solver, A, device_id)
+    raise TypeError(f"no numerical_setup for {type(ss).__name__}")
+
+
+def numerical_setup_(ns, A):
+    """Gridap.Algebra.numerical_setup!(ns, A)."""
+    if isinstance(ns, GMGNumericalSetup):
+        return ns.update(A)
+    if isinstance(ns, _KrylovNumericalSetup):
+        ns.P_ns.update(A)
+        return ns
+    raise TypeError(f"no numerical_setup! for {type(ns).__name__}")
+
+
+def solve_(x, ns, b):
+    """Gridap.Algebra.solve!(x, ns, b): in place on x, returns x."""
+    if isinstance(ns, GMGNumericalSetup):
+        log = ns.solver.log
+        pb, ms, _kb = _vec(b, ns.n)
+        px, ms2, _kx = _vec(x, ns.n, writable=True)
+        if ms != ms2:
+            raise TypeError("x and b must live in the same memory space")
+        res = abi.Result()
+        hist = np.zeros(log.maxiter + 1)
+        abi.check(ns.h, ns._lib.gmg_apply(ns.h, pb, px, ms, C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
+        log._fill(res, hist)
+        return x
+    if isinstance(ns, _KrylovNumericalSetup):
+        s, g = ns.solver, ns.P_ns
+        log = s.log
+        pb, ms, _kb = _vec(b, ns.n)
+        px, ms2, _kx = _vec(x, ns.n, writable=True)
+        if ms != ms2:
+            raise TypeError("x and b must live in the same memory space")
+        res = abi.Result()
+        hist = np.zeros(log.maxiter + 1)
+        if isinstance(s, CGSolver):
+            abi.check(g.h, g._lib.gmg_cg_solve(g.h, pb, px, ms, log.maxiter, log.atol, log.rtol, int(s.flexible), ns.pc_kind,
+                                               C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
+        else:
+            abi.check(g.h, g._lib.gmg_fgmres_solve(g.h, pb, px, ms, s.m, int(s.restart), s.m_add, log.maxiter,
+                                                   log.atol, log.rtol, ns.pc_kind, C.byref(res),
+                                                   C.c_void_p(hist.ctypes.data), hist.size))
+        log._fill(res, hist)
+        return x
+    raise TypeError(f"no solve! for {type(ns).__name__}")
+
+
+def mul_(y, op, x):
+    """LinearAlgebra.mul!(y, op, x) for op = (ns, lev, 'A'|'P'|'R')."""
+    ns, lev, which = op
+    return ns.op_apply(lev, {"A": abi.OP_A, "P": abi.OP_P, "R": abi.OP_R}[which], x, y)

@@ -1,0 +1,173 @@
+/*
+ * gmg_amd.h -- C ABI of libgmgamd.so, the MI355X (gfx950) geometric-multigrid
+ * V-cycle / CG / FGMRES hot path for GridapSolvers.jl.
+ *
+ * The reference (GridapSolvers.jl v0.7.1) is pure Julia and has no FFI for this
+ * path; its drop-in boundary is the Gridap.Algebra interface
+ *     LinearSolver -> symbolic_setup -> numerical_setup(!) -> solve!
+ * Each entry point below names the reference method(s) (file:line) whose work
+ * it takes over; the Julia wrapper that binds them with `ccall` is in
+ * gridapsolvers.jl_amd/julia/GridapSolversAMD.jl and INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns an int status (GMG_OK == 0); nothing throws or
+ *     longjmps across the boundary; gmg_last_error() gives the message.
+ *   - all pointers passed to setters are HOST pointers borrowed for the call
+ *     only.  Vector arguments of the solve / operator calls are host or device
+ *     pointers according to `memspace`.
+ *   - one handle = one HIP device + one HIP stream; not thread-safe per handle.
+ *   - levels are numbered 0 .. nlevels-1, level 0 = finest (reference: 1 = finest).
+ *   - fp64 values; integer indices int32 or int64, 0- or 1-based, CSR or CSC.
+ */
+#ifndef GMG_AMD_H
+#define GMG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMG_API __attribute__((visibility("default")))
+
+typedef struct gmg_solver *gmg_handle_t;
+
+enum gmg_status {
+  GMG_OK = 0,
+  GMG_ERR_INVALID = 1,     /* bad argument / inconsistent sizes (reference: @check failures) */
+  GMG_ERR_HIP = 2,         /* a HIP runtime call failed */
+  GMG_ERR_STATE = 3,       /* call order violated (e.g. solve before setup) */
+  GMG_ERR_ALLOC = 4,
+  GMG_ERR_COMM = 5,        /* RCCL failure */
+  GMG_ERR_UNSUPPORTED = 6,
+  GMG_ERR_SINGULAR = 7     /* zero pivot / zero diagonal */
+};
+
+enum gmg_layout { GMG_CSR = 0, GMG_CSC = 1 };
+enum gmg_memspace { GMG_MEM_HOST = 0, GMG_MEM_DEVICE = 1 };
+/* GMGLinearSolvers.jl:56 mode ; :57 cycle_type */
+enum gmg_mode { GMG_MODE_PRECONDITIONER = 0, GMG_MODE_SOLVER = 1 };
+enum gmg_cycle { GMG_V_CYCLE = 0, GMG_W_CYCLE = 1, GMG_F_CYCLE = 2 };
+/* SolverInterfaces/SolverTolerances.jl:11-16 SolverConvergenceFlag */
+enum gmg_conv_flag {
+  GMG_CONVERGED_ATOL = 0,
+  GMG_CONVERGED_RTOL = 1,
+  GMG_DIVERGED_MAXITER = 2,
+  GMG_DIVERGED_BREAKDOWN = 3
+};
+enum gmg_which { GMG_PRE = 0, GMG_POST = 1, GMG_PRE_AND_POST = 2 };
+enum gmg_patch_kind {
+  GMG_PATCH_LU = 0,        /* PatchSolver: lu!(A[p,p]) with partial pivoting, PatchSolvers.jl:176 */
+  GMG_PATCH_NOPIVOT = 1    /* BlockJacobiSolver: lu!(A[p,p],NoPivot()), BlockJacobiSolvers.jl:162 */
+};
+enum gmg_op { GMG_OP_A = 0, GMG_OP_P = 1, GMG_OP_R = 2 };
+
+/* Result of an iterative solve: mirrors ConvergenceLog (ConvergenceLogs.jl:42-60). */
+typedef struct {
+  int32_t niters;          /* log.num_iters */
+  int32_t flag;            /* finalize!(log,res) -> gmg_conv_flag */
+  double res0;             /* log.residuals[1] */
+  double res;              /* last residual */
+} gmg_result;
+
+/* Timing / traffic statistics of the profiled kernel class (gmg_profile_enable). */
+typedef struct {
+  int64_t launches;        /* launches measured */
+  double total_ms;         /* sum of HIP-event durations on the handle's stream */
+  double alg_bytes;        /* algorithmic bytes of ONE launch (SURVEY 8d byte model) */
+  int64_t rows, nnz;       /* shape of the operator the kernel streams */
+} gmg_kernel_stats;
+
+/* ---- lifetime ------------------------------------------------------------- */
+/* GMGLinearSolver(...) constructor, GMGLinearSolvers.jl:48-69 (allocates nothing on device yet). */
+GMG_API int gmg_create(gmg_handle_t *h, int nlevels, int device_id);
+/* finalizer of the numerical setup (pattern: ext/PardisoExt.jl:54-61). */
+GMG_API int gmg_destroy(gmg_handle_t h);
+GMG_API const char *gmg_last_error(gmg_handle_t h); /* h may be NULL: last global error */
+GMG_API int gmg_version(void);
+
+/* ---- operators (numerical_setup inputs) ------------------------------------ */
+/* smatrices[lev+1], GMGLinearSolvers.jl:183-185,336-340.  Square. */
+GMG_API int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_t nnz,
+                           const void *ptr, const void *idx, const double *val,
+                           int layout, int index_base, int index_bytes);
+/* numerical_setup!(ns,A): same pattern, new values (GMGLinearSolvers.jl:249-297;
+ * JacobiLinearSolvers.jl:25-27).  Requires gmg_setup to be called again. */
+GMG_API int gmg_update_values(gmg_handle_t h, int lev, const double *val);
+/* interp[lev+1] : level lev+1 -> lev, `mul!(dxh,interp,dxH)` GMGLinearSolvers.jl:491
+ * (y = P x, GridTransferOperators.jl:391-401).  nrows = n(lev), ncols = n(lev+1). */
+GMG_API int gmg_set_prolongation(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_t nnz,
+                                 const void *ptr, const void *idx, const double *val,
+                                 int layout, int index_base, int index_bytes);
+/* restrict[lev+1] : level lev -> lev+1, `mul!(rH,restrict,rh)` :484.  Optional:
+ * when absent R = P^T is built (GridTransferOperators.jl:202-209,536-547). */
+GMG_API int gmg_set_restriction(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_t nnz,
+                                const void *ptr, const void *idx, const double *val,
+                                int layout, int index_base, int index_bytes);
+
+/* ---- smoothers ------------------------------------------------------------- */
+/* RichardsonSmoother(JacobiLinearSolver(),niter,omega): RichardsonSmoothers.jl:84-98,
+ * JacobiLinearSolvers.jl:20-23,43-47. */
+GMG_API int gmg_set_smoother_jacobi(gmg_handle_t h, int lev, int which, int niter, double omega);
+/* RichardsonSmoother(PatchSolver|BlockJacobiSolver,niter,omega): PatchSolvers.jl:279-300,
+ * BlockJacobiSolvers.jl:141-170.  patch_ptr has npatch+1 entries; patch_dofs lists
+ * the rows(=cols) of each patch; blocks A[p,p] are extracted and factorised on the device. */
+GMG_API int gmg_set_smoother_patch(gmg_handle_t h, int lev, int which, int niter, double omega,
+                                   int kind, int64_t npatch, const void *patch_ptr,
+                                   const void *patch_dofs, int index_base, int index_bytes);
+
+/* ---- solver options --------------------------------------------------------- */
+/* kwargs of GMGLinearSolver: mode, cycle_type, maxiter, atol, rtol (GMGLinearSolvers.jl:56-58). */
+GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, double atol, double rtol);
+
+/* numerical_setup(ss,A): GMGLinearSolvers.jl:183-210 -- uploads operators, builds
+ * D^-1, R = P^T, patch factors, work vectors and the coarse solver
+ * (coarsest_solver = LUSolver(), :54,423-434 -> dense inverse on the device). */
+GMG_API int gmg_setup(gmg_handle_t h);
+
+/* ---- hot path ---------------------------------------------------------------- */
+/* solve!(x,ns::GMGNumericalSetup,b) / ldiv!: GMGLinearSolvers.jl:612-649.
+ * hist (may be NULL) receives niters+1 residual norms; hist_cap = its capacity. */
+GMG_API int gmg_apply(gmg_handle_t h, const double *b, double *x, int memspace,
+                      gmg_result *res, double *hist, int hist_cap);
+/* solve!(x,ns::CGNumericalSetup,b) with Pl = this GMG: Krylov/CGSolvers.jl:73-120.
+ * use_precond: 0 = Pl nothing, 1 = this GMG, 2 = JacobiLinearSolver() on the finest
+ * matrix (the reference's CGSolver(JacobiLinearSolver())).  x = initial guess on entry. */
+GMG_API int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace,
+                         int maxiter, double atol, double rtol, int flexible, int use_precond,
+                         gmg_result *res, double *hist, int hist_cap);
+/* solve!(x,ns::FGMRESNumericalSetup,b) with Pr = this GMG, Pl = nothing:
+ * Krylov/FGMRESSolvers.jl:130-199, KrylovUtils.jl:17-54. */
+GMG_API int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace,
+                             int m, int restart, int m_add, int maxiter, double atol, double rtol,
+                             int use_precond, gmg_result *res, double *hist, int hist_cap);
+
+/* ---- operator-level entry points (duck-typed `mul!` / smoother `solve!`) ------ */
+/* mul!(y,op,x) for op in {A_lev, P_lev, R_lev}: RichardsonSmoothers.jl:94,
+ * GMGLinearSolvers.jl:484,491,495. */
+GMG_API int gmg_op_apply(gmg_handle_t h, int lev, int op, const double *x, double *y, int memspace);
+/* solve!(x,ns::RichardsonSmootherNumericalSetup,r): updates x AND r in place
+ * (RichardsonSmoothers.jl:84-98). which = GMG_PRE or GMG_POST. */
+GMG_API int gmg_smooth(gmg_handle_t h, int lev, int which, double *x, double *r, int memspace);
+/* solve!(dx,Mns,r) of the smoother's inner solver (Jacobi / patch), no relaxation:
+ * JacobiLinearSolvers.jl:43-47, PatchSolvers.jl:238-241, BlockJacobiSolvers.jl:119-123. */
+GMG_API int gmg_precond_apply(gmg_handle_t h, int lev, int which, const double *r, double *dx, int memspace);
+/* coarsest solve!(xh,coarsest_solver_cache,rh): GMGLinearSolvers.jl:474. */
+GMG_API int gmg_coarse_solve(gmg_handle_t h, const double *r, double *x, int memspace);
+/* dot / norm as used by the Krylov solvers (CGSolvers.jl:85,95,105). */
+GMG_API int gmg_dot(gmg_handle_t h, int64_t n, const double *a, const double *b, int memspace, double *out);
+
+/* ---- measurement --------------------------------------------------------------- */
+/* Bracket every launch of the fused Richardson-Jacobi sweep on `lev` with HIP
+ * events on the handle's stream (enable=0 stops).  Read with gmg_get_kernel_stats. */
+GMG_API int gmg_profile_enable(gmg_handle_t h, int lev, int enable);
+GMG_API int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out);
+/* Algorithmic bytes (SURVEY 8d byte model) of one V-cycle / one CG iteration. */
+GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes);
+/* Device memory held by the handle, bytes. */
+GMG_API int gmg_device_bytes(gmg_handle_t h, int64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMG_AMD_H */

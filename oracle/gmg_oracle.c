@@ -469,7 +469,7 @@ ORC_API void orc_gmg_setup(orc_gmg *g, int mode, int cycle, int maxiter, double 
 {
   g->mode = mode; g->cycle = cycle;
   g->log.maxiter = maxiter; g->log.atol = atol; g->log.rtol = rtol;
-  g->log.residuals = (double *)calloc((size_t)maxiter + 1, sizeof(double));
+  g->log.residuals = (double *)calloc((size_t)(maxiter > 0 ? maxiter : 0) + 1, sizeof(double));
   g->rh = dalloc(g->lev[0].A.n);
   for (int l = 0; l < g->nlev - 1; ++l) {
     orc_level *L = &g->lev[l];
@@ -594,18 +594,26 @@ ORC_API void orc_gmg_destroy(orc_gmg *g)
   free(g->rh); free(g->log.residuals); free(g->lev); free(g);
 }
 
-/* preconditioner dispatch for the Krylov solvers: pc == NULL -> isnothing(Pl) */
-static void pc_solve(orc_gmg *pc, double *z, const double *r) { orc_gmg_solve(pc, z, r, NULL, NULL); }
+/* preconditioner dispatch for the Krylov solvers.
+ * kind 0: nothing ; 1: GMG (pc = orc_gmg*) ; 2: JacobiLinearSolver (pc = inv_diag,
+ * JacobiLinearSolvers.jl:43-47) */
+enum { ORC_PC_NONE = 0, ORC_PC_GMG = 1, ORC_PC_JACOBI = 2 };
+static void pc_solve(int kind, void *pc, i64 n, double *z, const double *r)
+{
+  if (kind == ORC_PC_GMG) orc_gmg_solve((orc_gmg *)pc, z, r, NULL, NULL);
+  else if (kind == ORC_PC_JACOBI) { const double *d = (const double *)pc; for (i64 i = 0; i < n; ++i) z[i] = d[i] * r[i]; }
+  else memcpy(z, r, (size_t)n * sizeof(double));
+}
 
 /* ------------------------------------------------------------------ */
 /* A7: solve!(x,ns::CGNumericalSetup,b): Krylov/CGSolvers.jl:73-120    */
 /* ------------------------------------------------------------------ */
-ORC_API int orc_cg_solve(i64 n, const i64 *ptr, const i32 *idx, const double *val, orc_gmg *Pl,
+ORC_API int orc_cg_solve(i64 n, const i64 *ptr, const i32 *idx, const double *val, int pc_kind, void *Pl,
                          double *x, const double *b, int maxiter, double atol, double rtol,
                          int flexible, int *niters, double *hist)
 {
   double *w = dalloc(n), *p = dalloc(n), *z = dalloc(n), *r = dalloc(n); /* :42-48 */
-  orc_log log = { maxiter, atol, rtol, 0, (double *)calloc((size_t)maxiter + 1, sizeof(double)) };
+  orc_log log = { maxiter, atol, rtol, 0, (double *)calloc((size_t)(maxiter > 0 ? maxiter : 0) + 1, sizeof(double)) };
   orc_spmv(n, ptr, idx, val, x, w);                         /* :79 */
   for (i64 i = 0; i < n; ++i) r[i] = b[i] - w[i];
   for (i64 i = 0; i < n; ++i) p[i] = 0.0;                   /* :80 */
@@ -614,15 +622,15 @@ ORC_API int orc_cg_solve(i64 n, const i64 *ptr, const i32 *idx, const double *va
   double res = orc_norm(n, r);                              /* :85 */
   int done = log_init(&log, res);                           /* :86 */
   while (!done) {
-    if (!Pl) {                                              /* :90-92 */
+    if (pc_kind == ORC_PC_NONE) {                           /* :90-92 */
       for (i64 i = 0; i < n; ++i) z[i] = r[i];
       beta = gamma; gamma = orc_dot(n, r, r); beta = gamma / beta;
     } else if (!flexible) {                                 /* :93-95 */
-      pc_solve(Pl, z, r);
+      pc_solve(pc_kind, Pl, n, z, r);
       beta = gamma; gamma = orc_dot(n, z, r); beta = gamma / beta;
     } else {                                                /* :96-99 */
       double delta = orc_dot(n, z, r);
-      pc_solve(Pl, z, r);
+      pc_solve(pc_kind, Pl, n, z, r);
       beta = gamma; gamma = orc_dot(n, z, r); beta = (gamma - delta) / beta;
     }
     for (i64 i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];  /* :101 */
@@ -674,7 +682,7 @@ ORC_API void orc_givens(double f, double g, double *out3) { givens_algorithm(f, 
 /* A8: solve!(x,ns::FGMRESNumericalSetup,b): FGMRESSolvers.jl:130-199  */
 /* Pl = nothing ; Pr = GMG (or NULL = identity: solve!(wr,Pr,x) ~ copy) */
 /* ------------------------------------------------------------------ */
-ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double *val, orc_gmg *Pr,
+ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double *val, int pc_kind, void *Pr,
                              double *x, const double *b, int m0, int restart, int m_add,
                              int maxiter, double atol, double rtol, int *niters, double *hist)
 {
@@ -692,7 +700,7 @@ ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double
   double *c = (double *)calloc((size_t)mcap, sizeof(double));
   double *s = (double *)calloc((size_t)mcap, sizeof(double));
 #define HH(i, j) H[(size_t)((i)-1) + (size_t)((j)-1) * ldh] /* 1-based like the reference */
-  orc_log log = { maxiter, atol, rtol, 0, (double *)calloc((size_t)maxiter + 1, sizeof(double)) };
+  orc_log log = { maxiter, atol, rtol, 0, (double *)calloc((size_t)(maxiter > 0 ? maxiter : 0) + 1, sizeof(double)) };
 
   for (i64 i = 0; i < n; ++i) V[0][i] = 0.0;                /* :136 */
   /* krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 */
@@ -718,8 +726,7 @@ ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double
       for (i64 i = 0; i < n; ++i) Vn[i] = 0.0;              /* :157 */
       for (i64 i = 0; i < n; ++i) Zj[i] = 0.0;              /* :158 */
       /* krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25 */
-      if (Pr) pc_solve(Pr, Zj, V[j - 1]);
-      else memcpy(Zj, V[j - 1], (size_t)n * sizeof(double));
+      pc_solve(pc_kind, Pr, n, Zj, V[j - 1]);
       orc_spmv(n, ptr, idx, val, Zj, Vn);                   /* :159 */
       for (int i = 1; i <= j; ++i) {                        /* :160-163 MGS */
         double h = orc_dot(n, Vn, V[i - 1]);
@@ -778,7 +785,7 @@ ORC_API int orc_cg_smoother_solve(i64 n, const i64 *ptr, const i32 *idx, const d
   smoother_setup(&S, &A);
   double *w = dalloc(n), *p = dalloc(n), *z = dalloc(n), *r = dalloc(n);
   double *aux = dalloc(n), *dx = dalloc(n), *Adx = dalloc(n);
-  orc_log log = { maxiter, atol, rtol, 0, (double *)calloc((size_t)maxiter + 1, sizeof(double)) };
+  orc_log log = { maxiter, atol, rtol, 0, (double *)calloc((size_t)(maxiter > 0 ? maxiter : 0) + 1, sizeof(double)) };
   orc_spmv(n, ptr, idx, val, x, w);
   for (i64 i = 0; i < n; ++i) r[i] = b[i] - w[i];
   double gamma = 1.0, beta, alpha;

@@ -187,6 +187,18 @@ class GMG:
             pass
 
 
+def _pc(A, P):
+    """Preconditioner dispatch: None | GMG | "jacobi" (JacobiLinearSolver())."""
+    if P is None:
+        return 0, None, None
+    if isinstance(P, GMG):
+        return 1, P.h, P
+    if P == "jacobi":
+        d = jacobi_inv_diag(A)
+        return 2, C.cast(_d(d), C.c_void_p), d
+    raise TypeError("unknown preconditioner")
+
+
 def cg_solve(A, b, Pl=None, x0=None, maxiter=1000, atol=1e-12, rtol=1e-6, flexible=False):
     """solve!(x, CGNumericalSetup, b) -- returns (x, niters, flag, hist)."""
     n = A.shape[0]
@@ -194,7 +206,8 @@ def cg_solve(A, b, Pl=None, x0=None, maxiter=1000, atol=1e-12, rtol=1e-6, flexib
     b = np.ascontiguousarray(b, dtype=np.float64)
     hist = np.zeros(maxiter + 1)
     nit = C.c_int(0)
-    flag = lib().orc_cg_solve(C.c_int64(n), _p64(A.ptr), _p32(A.idx), _d(A.val), Pl.h if Pl is not None else None,
+    kind, pc, _keep = _pc(A, Pl)
+    flag = lib().orc_cg_solve(C.c_int64(n), _p64(A.ptr), _p32(A.idx), _d(A.val), C.c_int(kind), pc,
                               _d(x), _d(b), C.c_int(maxiter), C.c_double(atol), C.c_double(rtol),
                               C.c_int(int(flexible)), C.byref(nit), _d(hist))
     return x, nit.value, flag, hist[: nit.value + 1].copy()
@@ -207,8 +220,9 @@ def fgmres_solve(A, b, Pr=None, x0=None, m=5, restart=False, m_add=1, maxiter=10
     b = np.ascontiguousarray(b, dtype=np.float64)
     hist = np.zeros(maxiter + 1)
     nit = C.c_int(0)
+    kind, pc, _keep = _pc(A, Pr)
     flag = lib().orc_fgmres_solve(C.c_int64(n), _p64(A.ptr), _p32(A.idx), _d(A.val),
-                                  Pr.h if Pr is not None else None, _d(x), _d(b), C.c_int(m),
+                                  C.c_int(kind), pc, _d(x), _d(b), C.c_int(m),
                                   C.c_int(int(restart)), C.c_int(m_add), C.c_int(maxiter), C.c_double(atol),
                                   C.c_double(rtol), C.byref(nit), _d(hist))
     return x, nit.value, flag, hist[: nit.value + 1].copy()

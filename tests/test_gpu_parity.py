@@ -1,0 +1,406 @@
+"""GPU parity tests: the HIP path (through the C ABI / host mirror) against the CPU
+oracle on the same seeded inputs, against the committed fixtures, and -- at full
+BASELINE size -- through size-independent properties.
+
+Tolerances (fp64): per-kernel max|y-y_ref|/max|y_ref| <= 1e-13;
+V-cycle output <= 1e-11 relative 2-norm; residual histories <= 1e-8 relative per
+entry; iteration counts identical."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import max_rel, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_KERNEL, TOL_VCYCLE, TOL_HIST = 1e-13, 1e-11, 1e-8
+
+
+def seeded(n, seed):
+    return np.random.Generator(np.random.MT19937(seed)).uniform(-1.0, 1.0, size=n)
+
+
+def jac(S, nlev, niter=10, omega=2.0 / 3.0):
+    sm = S.RichardsonSmoother(S.JacobiLinearSolver(), niter, omega)
+    return [sm] * (nlev - 1)
+
+
+def make_gmg(S, H, **kw):
+    nlev = len(H["mats"])
+    kw.setdefault("pre_smoothers", jac(S, nlev))
+    kw.setdefault("post_smoothers", kw["pre_smoothers"])
+    kw.setdefault("maxiter", 1)
+    return S.GMGLinearSolver(H["mats"], H["prolongations"], kw.pop("restrict", H["restrictions"]), **kw)
+
+
+def setup(S, solver, A):
+    return S.numerical_setup(S.symbolic_setup(solver, A), A)
+
+
+# ---------------------------------------------------------------- per-kernel parity
+@pytest.mark.parametrize("nc,nlev,order", [((64, 64), 3, 1), ((16, 16, 16), 3, 1), ((12, 20, 8), 2, 1), ((8, 8, 8), 2, 2)])
+def test_operator_apply_parity(S, orc, hierarchy, nc, nlev, order):
+    """K1/K4/K5: mul!(y,A,x), mul!(rH,R,rh), mul!(dxh,P,dxH) on every level."""
+    H = hierarchy(nc, nlev, order)
+    ns = setup(S, make_gmg(S, H), H["mats"][0])
+    from gridapsolvers_jl_amd import abi
+    for l in range(nlev):
+        A = H["mats"][l]
+        x = seeded(A.shape[0], 100 + l)
+        y = np.zeros(A.shape[0])
+        ns.op_apply(l, abi.OP_A, x, y)
+        assert max_rel(y, orc.spmv(A, x)) <= TOL_KERNEL
+        if l < nlev - 1:
+            P, R = H["prolongations"][l], H["restrictions"][l]
+            xc = seeded(P.shape[1], 200 + l)
+            yp = np.zeros(P.shape[0]); ns.op_apply(l, abi.OP_P, xc, yp)
+            assert max_rel(yp, orc.spmv(P, xc)) <= TOL_KERNEL
+            yr = np.zeros(R.shape[0]); ns.op_apply(l, abi.OP_R, x, yr)
+            assert max_rel(yr, orc.spmv(R, x)) <= TOL_KERNEL
+
+
+@pytest.mark.parametrize("niter,omega", [(1, 1.0), (3, 0.5), (10, 2.0 / 3.0)])
+def test_richardson_jacobi_sweeps_parity(S, orc, hierarchy, niter, omega):
+    """K2+K1+K3 fused sweep vs RichardsonSmoothers.jl:84-98 executed literally by the oracle (odd and even niter)."""
+    nc, nlev = (16, 16, 16), 3
+    H = hierarchy(nc, nlev)
+    ns = setup(S, make_gmg(S, H, pre_smoothers=jac(S, nlev, niter, omega)), H["mats"][0])
+    go = orc.GMG(H["mats"], H["prolongations"], pre_smoothers=[orc.Smoother(orc.JACOBI, niter, omega)] * (nlev - 1), maxiter=1)
+    for l in range(nlev - 1):
+        n = H["mats"][l].shape[0]
+        x0, r0 = seeded(n, 1 + l), seeded(n, 50 + l)
+        x, r = x0.copy(), r0.copy()
+        ns.smooth(l, x, r)
+        xo, ro = go.smooth(l, x0, r0)
+        assert max_rel(x, xo) <= TOL_KERNEL and max_rel(r, ro) <= TOL_KERNEL
+
+
+def test_jacobi_precond_coarse_solve_and_dot(S, orc, hierarchy):
+    nc, nlev = (16, 16, 16), 3
+    H = hierarchy(nc, nlev)
+    ns = setup(S, make_gmg(S, H), H["mats"][0])
+    go = orc.GMG(H["mats"], H["prolongations"], maxiter=1)
+    n = H["mats"][0].shape[0]
+    r = seeded(n, 3)
+    dx = np.zeros(n); ns.precond(0, r, dx)
+    assert max_rel(dx, go.precond(0, r)) <= 1e-15          # inv_diag .* r: bitwise-level
+    nL = H["mats"][-1].shape[0]
+    rc = seeded(nL, 4); xc = np.zeros(nL)
+    ns.coarse_solve(rc, xc)
+    assert max_rel(xc, go.coarse_solve(rc)) <= 1e-12        # dense inverse GEMV vs banded LU (kappa ~ 1e1)
+    a, b = seeded(n, 5), seeded(n, 6)
+    assert abs(ns.dot(a, b) - orc.dot(a, b)) <= 1e-13 * np.sqrt(n)
+    assert abs(ns.dot(a[:-1], b[:-1]) - orc.dot(a[:-1].copy(), b[:-1].copy())) <= 1e-13 * np.sqrt(n)   # odd length
+
+
+# ---------------------------------------------------------------- V / W / F cycles, solver mode
+def test_vcycle_golden_config1(S, hierarchy):
+    gold = np.load(os.path.join(GOLD, "config1_q1_64x64.npz"))
+    H = hierarchy((64, 64), 3)
+    gmg = make_gmg(S, H)
+    ns = setup(S, gmg, H["mats"][0])
+    n = H["mats"][0].shape[0]
+    r = seeded(n, 7)
+    z = np.full(n, 123.0)                                    # must be overwritten (fill!(x,0), GMGLinearSolvers.jl:619)
+    S.solve_(z, ns, r)
+    assert rel_err(z, gold["vcycle_z"]) <= TOL_VCYCLE
+    assert gmg.log.num_iters == 1
+    np.testing.assert_allclose(gmg.log.residuals[:2], gold["vcycle_hist"], rtol=TOL_HIST)
+    x, rr = np.zeros(n), r.copy()
+    ns.smooth(0, x, rr)
+    assert max_rel(x, gold["smooth_x"]) <= TOL_KERNEL and max_rel(rr, gold["smooth_r"]) <= TOL_KERNEL
+
+
+@pytest.mark.parametrize("cyc", ["v", "w", "f"])
+def test_cycle_types_golden(S, hierarchy, cyc):
+    """gmg_v_cycle!/gmg_w_cycle!/gmg_f_cycle! (GMGLinearSolvers.jl:468-610)."""
+    gold = np.load(os.path.join(GOLD, "q1_16cubed.npz"))
+    H = hierarchy((16, 16, 16), 3)
+    gmg = make_gmg(S, H, cycle_type=f"{cyc}_cycle")
+    ns = setup(S, gmg, H["mats"][0])
+    r = seeded(H["mats"][0].shape[0], 11)
+    z = np.zeros_like(r)
+    S.solve_(z, ns, r)
+    assert rel_err(z, gold[f"z_{cyc}"]) <= TOL_VCYCLE
+    np.testing.assert_allclose(gmg.log.residuals[:2], gold[f"h_{cyc}"], rtol=TOL_HIST)
+
+
+def test_solver_mode_golden(S, po, hierarchy):
+    """mode=:solver (GMGLinearSolvers.jl:621-625) iterated to rtol 1e-8."""
+    gold = np.load(os.path.join(GOLD, "q1_16cubed.npz"))
+    nc = (16, 16, 16)
+    H = hierarchy(nc, 3)
+    gmg = make_gmg(S, H, mode="solver", maxiter=6, atol=1e-14, rtol=1e-8)
+    ns = setup(S, gmg, H["mats"][0])
+    b = po.dirichlet_lift_rhs(nc, 1)
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    assert gmg.log.num_iters == int(gold["solver_niters"]) and gmg.log.flag == int(gold["solver_flag"])
+    np.testing.assert_allclose(gmg.log.residuals[: gmg.log.num_iters + 1], gold["solver_hist"], rtol=TOL_HIST)
+    assert rel_err(x, gold["solver_x"]) <= 1e-10
+    assert po.l2_error_sq(nc, 1, x) < 1e-8
+
+
+# ---------------------------------------------------------------- outer Krylov solvers
+@pytest.mark.parametrize("nc,nlev", [((64, 64), 3), ((32, 32, 32), 3), ((16, 24, 8), 2)])
+def test_cg_gmg_matches_oracle(S, po, orc, hierarchy, nc, nlev):
+    """BASELINE configs 1/2 shape: CG(maxiter=20,atol=1e-14,rtol=1e-6) + GMG V-cycle preconditioner."""
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    solver = S.CGSolver(make_gmg(S, H), maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = setup(S, solver, H["mats"][0])
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=g, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert solver.log.num_iters == nit and solver.log.flag == flag
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=TOL_HIST)
+    assert rel_err(x, xo) <= 1e-10
+    assert po.l2_error_sq(nc, 1, x) < 1e-8                   # the reference tests' own criterion
+
+
+def test_cg_golden_config1_and_device_tensors(S, po, hierarchy):
+    import torch
+    gold = np.load(os.path.join(GOLD, "config1_q1_64x64.npz"))
+    nc = (64, 64)
+    H = hierarchy(nc, 3)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    solver = S.CGSolver(make_gmg(S, H), maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = setup(S, solver, H["mats"][0])
+    xd = torch.zeros(b.size, dtype=torch.float64, device="cuda")
+    bd = torch.from_numpy(b).cuda()
+    torch.cuda.synchronize()
+    S.solve_(xd, ns, bd)
+    assert solver.log.num_iters == int(gold["niters"]) == 3
+    np.testing.assert_allclose(solver.log.residuals[:4], gold["hist"], rtol=TOL_HIST)
+    assert rel_err(xd.cpu().numpy(), gold["x"]) <= 1e-10
+    assert torch.equal(bd.cpu(), torch.from_numpy(b))        # b untouched
+    # run-to-run determinism (fixed reduction trees, no atomics)
+    xd2 = torch.zeros_like(xd)
+    S.solve_(xd2, ns, bd)
+    assert torch.equal(xd, xd2)
+
+
+@pytest.mark.parametrize("flexible", [False, True])
+@pytest.mark.parametrize("pc", ["none", "jacobi"])
+def test_cg_variants_reference_krylov_tests(S, po, orc, hierarchy, flexible, pc):
+    """KrylovTests.jl:77-90: CGSolver(), CGSolver(Jacobi), flexible CG; criterion E < 1e-6."""
+    nc = (8, 8, 8)
+    H = hierarchy(nc, 2)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    gmg = make_gmg(S, H)
+    P = (None, gmg) if pc == "none" else (S.JacobiLinearSolver(), gmg)
+    solver = S.CGSolver(P, rtol=1e-8, flexible=flexible)
+    ns = setup(S, solver, H["mats"][0])
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=None if pc == "none" else "jacobi", rtol=1e-8, flexible=flexible)
+    assert solver.log.num_iters == nit and solver.log.flag == flag
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6)
+    assert po.l2_error_sq(nc, 1, x) < 1e-6
+
+
+@pytest.mark.parametrize("m,restart", [(5, False), (2, True), (2, False)])
+def test_fgmres_gmg_matches_oracle(S, po, orc, hierarchy, m, restart):
+    """FGMRESSolvers.jl:130-199 incl. restart and basis growth (m_add)."""
+    nc, nlev = (32, 32), 3
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    solver = S.FGMRESSolver(m, make_gmg(S, H, cycle_type="w_cycle"), restart=restart, maxiter=20, atol=1e-14, rtol=1e-9)
+    ns = setup(S, solver, H["mats"][0])
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], cycle=orc.W_CYCLE, maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=g, m=m, restart=restart, maxiter=20, atol=1e-14, rtol=1e-9)
+    assert solver.log.num_iters == nit and solver.log.flag == flag
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6)
+    assert rel_err(x, xo) <= 1e-9
+
+
+# ---------------------------------------------------------------- patch smoother (config 3 shape)
+@pytest.mark.parametrize("kind", ["patch", "block"])
+def test_q2_patch_smoother_parity(S, po, orc, hierarchy, kind):
+    """Richardson(PatchSolver|BlockJacobiSolver,10,0.2) on Q2 (GMGTests.jl:18-47) + FGMRES(5)."""
+    gold = np.load(os.path.join(GOLD, "q2_16x16_patch.npz"))
+    nc, nlev, order = (16, 16), 2, 2
+    H = hierarchy(nc, nlev, order)
+    pp, pd = po.vertex_star_patches(nc, order)
+    M = S.PatchSolver(pp, pd) if kind == "patch" else S.BlockJacobiSolver(pp, pd)
+    sm = [S.RichardsonSmoother(M, 10, 0.2)]
+    solver = S.FGMRESSolver(5, make_gmg(S, H, pre_smoothers=sm), maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = setup(S, solver, H["mats"][0])
+    b = po.dirichlet_lift_rhs(nc, order)
+    r = seeded(b.size, 13)
+    dx = np.zeros_like(r)
+    ns.P_ns.precond(0, r, dx)
+    assert max_rel(dx, gold["patch_dx"]) <= 1e-12
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    assert solver.log.num_iters == int(gold["niters"])
+    np.testing.assert_allclose(solver.log.residuals[: solver.log.num_iters + 1], gold["hist"], rtol=1e-6)
+    assert rel_err(x, gold["x"]) <= 1e-9
+    assert po.l2_error_sq(nc, order, x) < 1e-8
+
+
+def test_q2_3d_patch_smoother_vs_oracle(S, po, orc, hierarchy):
+    nc, nlev, order = (8, 8, 8), 2, 2
+    H = hierarchy(nc, nlev, order)
+    pp, pd = po.vertex_star_patches(nc, order)
+    assert (pp[1:] - pp[:-1]).max() == 27                    # n_p = 27 in 3-D
+    gmg = make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2)])
+    ns = setup(S, gmg, H["mats"][0])
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd)], maxiter=1)
+    r = seeded(H["mats"][0].shape[0], 17)
+    z = np.zeros_like(r)
+    S.solve_(z, ns, r)
+    zo, _, _, ho = go.solve(r)
+    assert rel_err(z, zo) <= TOL_VCYCLE
+    np.testing.assert_allclose(gmg.log.residuals[:2], ho, rtol=TOL_HIST)
+
+
+# ---------------------------------------------------------------- input formats & edge cases
+def test_input_formats_csc_one_based_int64(S, po, orc, hierarchy, pkg):
+    """The ABI accepts {CSR|CSC} x {0|1}-based x {Int32|Int64} (Julia SparseMatrixCSC{Float64,Int64} is CSC/1/8)."""
+    from gridapsolvers_jl_amd import abi
+    nc, nlev = (12, 10, 6), 2
+    H = hierarchy(nc, nlev)
+
+    class Mat:
+        pass
+
+    def julia_csc(M):
+        csc = M.to_scipy().tocsc(); csc.sort_indices()
+        o = Mat(); o.shape = csc.shape; o.ptr = csc.indptr.astype(np.int64) + 1; o.idx = csc.indices.astype(np.int64) + 1
+        o.val = csc.data.copy(); o.layout = abi.CSC; o.index_base = 1
+        return o
+
+    Hj = dict(mats=[julia_csc(A) for A in H["mats"]], prolongations=[julia_csc(P) for P in H["prolongations"]],
+              restrictions=[None] * (nlev - 1))                  # R = P^T built by the library
+    r = seeded(H["mats"][0].shape[0], 23)
+    z1, z2 = np.zeros_like(r), np.zeros_like(r)
+    S.solve_(z1, setup(S, make_gmg(S, H), H["mats"][0]), r)
+    S.solve_(z2, setup(S, make_gmg(S, Hj), Hj["mats"][0]), r)
+    assert rel_err(z2, z1) <= 1e-14
+    zo = orc.GMG(H["mats"], H["prolongations"], maxiter=1).solve(r)[0]
+    assert rel_err(z1, zo) <= TOL_VCYCLE
+
+
+def test_ragged_empty_and_long_rows(S, orc, po, pkg):
+    """CSR edge cases of the stream kernel: empty rows, rows longer than the LDS tile (2048 nnz), 1-nnz rows."""
+    from gridapsolvers_jl_amd import abi
+    rng = np.random.default_rng(99)
+    n = 5000
+    lens = rng.integers(0, 40, size=n)
+    lens[10] = 0; lens[11] = 0; lens[n - 1] = 0
+    lens[100] = 3000; lens[101] = 2048; lens[102] = 2049; lens[4000] = 4999
+    ptr = np.zeros(n + 1, dtype=np.int64); np.cumsum(lens, out=ptr[1:])
+    idx = np.concatenate([np.sort(rng.choice(n, size=l, replace=False)) for l in lens]).astype(np.int32)
+    val = rng.uniform(-1, 1, size=idx.size)
+    # make it usable as a "level matrix": add a dominant diagonal through a second matrix A = B + D
+    import scipy.sparse as sp
+    B = sp.csr_matrix((val, idx, ptr), shape=(n, n))
+    A = po.CSR((n, n), ptr, idx, val)
+    Asq = (B + sp.diags(np.full(n, 100.0))).tocsr(); Asq.sort_indices()
+    Afull = po.CSR((n, n), Asq.indptr, Asq.indices, Asq.data)
+    nH = 50
+    Pm = sp.csr_matrix((np.ones(n), (np.arange(n), np.arange(n) % nH)), shape=(n, nH)); Pm.sort_indices()
+    P = po.CSR((n, nH), Pm.indptr, Pm.indices, Pm.data)
+    AH = (Pm.T @ Asq @ Pm).tocsr(); AH.sort_indices()
+    H = dict(mats=[Afull, po.CSR((nH, nH), AH.indptr, AH.indices, AH.data)], prolongations=[P], restrictions=[P.transpose()])
+    ns = setup(S, make_gmg(S, H), Afull)
+    x = seeded(n, 1)
+    y = np.zeros(n)
+    ns.op_apply(0, abi.OP_A, x, y)
+    assert max_rel(y, orc.spmv(Afull, x)) <= TOL_KERNEL
+    yr = np.zeros(nH); ns.op_apply(0, abi.OP_R, x, yr)        # R rows have n/nH = 100 nnz
+    assert max_rel(yr, orc.spmv(H["restrictions"][0], x)) <= TOL_KERNEL
+    xs, rs = np.zeros(n), x.copy()
+    ns.smooth(0, xs, rs)
+    xo, ro = orc.GMG(H["mats"], H["prolongations"], maxiter=1).smooth(0, np.zeros(n), x)
+    assert max_rel(xs, xo) <= TOL_KERNEL and max_rel(rs, ro) <= TOL_KERNEL
+    del A
+
+
+def test_error_behaviour_on_device(S, po, hierarchy, pkg):
+    from gridapsolvers_jl_amd import abi
+    H = hierarchy((8, 8), 2)
+    gmg = make_gmg(S, H)
+    ns = setup(S, gmg, H["mats"][0])
+    with pytest.raises(ValueError):
+        S.solve_(np.zeros(3), ns, np.zeros(3))                   # wrong length
+    lib = abi.load()
+    h = C.c_void_p()
+    assert lib.gmg_create(C.byref(h), 2, 0) == abi.OK
+    n = 49
+    x = np.zeros(n)
+    assert lib.gmg_apply(h, x.ctypes.data, x.ctypes.data, abi.MEM_HOST, None, None, 0) == abi.ERR_STATE   # before setup
+    assert b"gmg_setup" in lib.gmg_last_error(h)
+    assert lib.gmg_setup(h) == abi.ERR_STATE                     # matrices missing
+    # singular coarse matrix -> GMG_ERR_SINGULAR
+    Z = po.CSR((4, 4), np.arange(5), np.arange(4), np.zeros(4))
+    bad = dict(mats=[H["mats"][0], H["mats"][1]], prolongations=H["prolongations"], restrictions=H["restrictions"])
+    bad["mats"][1] = po.CSR(H["mats"][1].shape, H["mats"][1].ptr, H["mats"][1].idx, np.zeros_like(H["mats"][1].val))
+    with pytest.raises(abi.GmgError) as ei:
+        setup(S, make_gmg(S, bad), bad["mats"][0])
+    assert ei.value.code == abi.ERR_SINGULAR
+    lib.gmg_destroy(h)
+    del Z
+
+
+def test_maxiter_and_tolerance_flags(S, po, hierarchy):
+    """SolverTolerances.jl:97-128 through the device CG."""
+    nc = (16, 16)
+    H = hierarchy(nc, 3)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    s1 = S.CGSolver(make_gmg(S, H), maxiter=2, atol=0.0, rtol=1e-30)
+    x = np.zeros_like(b); S.solve_(x, setup(S, s1, H["mats"][0]), b)
+    assert s1.log.num_iters == 2 and s1.log.flag == S.SOLVER_DIVERGED_MAXITER
+    s2 = S.CGSolver(make_gmg(S, H), maxiter=50, atol=1e-12, rtol=1e-6)
+    x = np.ones_like(b); S.solve_(x, setup(S, s2, H["mats"][0]), np.zeros_like(b))   # b = 0, x0 != 0
+    assert s2.log.flag in (S.SOLVER_CONVERGED_ATOL, S.SOLVER_CONVERGED_RTOL) and np.linalg.norm(x) < 1e-10
+    s3 = S.CGSolver(make_gmg(S, H), maxiter=50, atol=1e-12, rtol=1e-6)
+    x = np.zeros_like(b); S.solve_(x, setup(S, s3, H["mats"][0]), np.zeros_like(b))  # zero rhs: atol at init
+    assert s3.log.num_iters == 0 and s3.log.flag == S.SOLVER_CONVERGED_ATOL and np.all(x == 0)
+
+
+# ---------------------------------------------------------------- BASELINE config 2 at full size: properties
+def test_config2_full_size_properties(S, po, hierarchy):
+    """3-D Q1 128^3, 4 levels (2 048 383 dofs, 54.4 M nnz): size-independent checks --
+    analytic solution reached within the reference's criterion, iteration count equal to the
+    oracle's count at every smaller size (3), residual history within 5% of BASELINE.md's
+    survey-time values, linearity of the V-cycle, and an exact-residual check."""
+    import torch
+    nc, nlev = (128, 128, 128), 4
+    H = hierarchy(nc, nlev)
+    A = H["mats"][0]
+    assert A.shape[0] == 2048383 and A.nnz == 54439939
+    b = po.dirichlet_lift_rhs(nc, 1)
+    gmg = make_gmg(S, H)
+    solver = S.CGSolver(gmg, maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = setup(S, solver, A)
+    xd = torch.zeros(b.size, dtype=torch.float64, device="cuda")
+    bd = torch.from_numpy(b).cuda()
+    torch.cuda.synchronize()
+    S.solve_(xd, ns, bd)
+    assert solver.log.num_iters == 3 and solver.log.flag == S.SOLVER_CONVERGED_RTOL
+    h = solver.log.residuals[:4] / solver.log.residuals[0]
+    np.testing.assert_allclose(h, [1, 7.4e-3, 3.2e-5, 1.9e-7], rtol=0.05)
+    x = xd.cpu().numpy()
+    assert po.l2_error_sq(nc, 1, x) < 1e-8
+    # true residual agrees with the recurrence residual CG reports
+    r_true = np.linalg.norm(b - A.matvec(x))
+    assert abs(r_true - solver.log.residuals[3]) <= 1e-6 * solver.log.residuals[0]
+    # V-cycle is a linear operator: M(a r1 + r2) == a M r1 + M r2
+    g = ns.P_ns
+    r1, r2 = torch.from_numpy(seeded(b.size, 1)).cuda(), torch.from_numpy(seeded(b.size, 2)).cuda()
+    z1, z2, z3 = torch.zeros_like(r1), torch.zeros_like(r1), torch.zeros_like(r1)
+    torch.cuda.synchronize()
+    S.solve_(z1, g, r1); S.solve_(z2, g, r2)
+    r3 = (0.75 * r1 + r2).contiguous(); torch.cuda.synchronize()
+    S.solve_(z3, g, r3)
+    assert (torch.linalg.norm(z3 - (0.75 * z1 + z2)) / torch.linalg.norm(z3)).item() < 1e-12
+    # symmetry of the preconditioner (needed by CG): <M r1, r2> == <r1, M r2>
+    a12, a21 = torch.dot(z1, r2).item(), torch.dot(r1, z2).item()
+    assert abs(a12 - a21) <= 1e-10 * max(abs(a12), abs(a21))

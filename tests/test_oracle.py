@@ -1,0 +1,228 @@
+"""CPU tests that pin the oracle (oracle/gmg_oracle.c).
+
+The reference (GridapSolvers.jl, Julia) cannot run here and holds no golden
+vectors for this path ("parity unpinned" for V-cycle vectors).  What it does hold
+are analytic known-answer tests; the oracle is checked against every one of them
+that touches the hot path, against an independent numpy/scipy restatement, and
+against the committed fixtures."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from conftest import max_rel, rel_err
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- reference known-answer tests ------------------------------------------------
+@pytest.mark.parametrize("nc", [(8, 8), (8, 8, 8)])
+def test_reference_smoothers_test(po, orc, nc):
+    """test/LinearSolvers/SmoothersTests.jl:13-43,58-74: CG(rtol=1e-8) preconditioned by
+    LinearSolverFromSmoother(RichardsonSmoother(Jacobi,5,2/3)), u = x1+x2, @test E < 1e-8."""
+    A = po.poisson_matrix(nc, 1)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    x, nit, flag, hist = orc.cg_smoother_solve(A, b, 5, 2.0 / 3.0, maxiter=1000, atol=1e-12, rtol=1e-8)
+    assert flag in (0, 1)
+    assert po.l2_error_sq(nc, 1, x) < 1.0e-8
+
+
+@pytest.mark.parametrize("nc", [(8, 8), (8, 8, 8)])
+@pytest.mark.parametrize("which", ["fgmres", "fgmres_restart", "cg", "pcg", "fpcg"])
+def test_reference_krylov_tests(po, orc, nc, which):
+    """test/LinearSolvers/KrylovTests.jl:12-25,77-90: P = JacobiLinearSolver(), rtol 1e-8, @test E < 1e-6."""
+    A = po.poisson_matrix(nc, 1)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    if which == "fgmres":
+        x, *_ = orc.fgmres_solve(A, b, Pr="jacobi", m=10, rtol=1e-8)
+    elif which == "fgmres_restart":
+        x, *_ = orc.fgmres_solve(A, b, Pr="jacobi", m=10, restart=True, rtol=1e-8)
+    elif which == "cg":
+        x, *_ = orc.cg_solve(A, b, rtol=1e-8)
+    elif which == "pcg":
+        x, *_ = orc.cg_solve(A, b, Pl="jacobi", rtol=1e-8)
+    else:
+        x, *_ = orc.cg_solve(A, b, Pl="jacobi", flexible=True, rtol=1e-8)
+    assert po.l2_error_sq(nc, 1, x) < 1.0e-6
+
+
+@pytest.mark.parametrize("nc,nlev", [((16, 16), 3), ((8, 8, 4), 2), ((64, 64), 3), ((32, 32, 32), 3)])
+def test_reference_gmg_tests_configuration(po, orc, hierarchy, nc, nlev):
+    """test/LinearSolvers/GMGTests.jl:52,109-124,204-213: CG(maxiter=20,atol=1e-14,rtol=1e-6) +
+    GMG(maxiter=1,:preconditioner,:v_cycle, Richardson(Jacobi,10,2/3)); the test only prints the
+    L2 error -- here it must be tiny and CG must converge by rtol."""
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    x, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=g, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert flag == 1 and nit <= 5
+    assert po.l2_error_sq(nc, 1, x) < 1.0e-10
+    # survey-time expectation: 3 iterations on the larger meshes
+    if nc in [(64, 64), (32, 32, 32)]:
+        assert nit == 3
+
+
+def test_baseline_md_histories(po, orc, hierarchy):
+    """BASELINE.md section 2 relative residual histories of the independent survey-time restatement."""
+    expect = {((64, 64), 3): [1, 6.8e-3, 2.8e-5, 1.6e-7], ((32, 32, 32), 3): [1, 5.1e-3, 1.7e-5, 5.5e-8]}
+    for (nc, nlev), h in expect.items():
+        H = hierarchy(nc, nlev)
+        g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+        _, nit, _, hist = orc.cg_solve(H["mats"][0], po.dirichlet_lift_rhs(nc, 1), Pl=g, maxiter=20, atol=1e-14, rtol=1e-6)
+        assert nit == 3
+        np.testing.assert_allclose(hist / hist[0], h, rtol=0.05)
+
+
+# ---- independent numpy/scipy twin --------------------------------------------------
+def _np_vcycle(mats, Ps, lev, x, r, niter=10, omega=2.0 / 3.0):
+    A = mats[lev].to_scipy()
+    if lev == len(mats) - 1:
+        x[:] = spla.spsolve(A.tocsc(), r)
+        return
+    dinv = 1.0 / A.diagonal()
+
+    def smooth():
+        for _ in range(niter):
+            dx = omega * (dinv * r)
+            x[:] = x + dx
+            r[:] = r - A @ dx
+    P = Ps[lev].to_scipy()
+    smooth()
+    rH = P.T @ r
+    dxH = np.zeros(P.shape[1])
+    _np_vcycle(mats, Ps, lev + 1, dxH, rH, niter, omega)
+    dx = P @ dxH
+    x[:] = x + dx
+    r[:] = r - A @ dx
+    smooth()
+
+
+@pytest.mark.parametrize("nc,nlev", [((32, 32), 3), ((8, 8, 8), 2)])
+def test_oracle_vs_numpy_twin(po, orc, hierarchy, nc, nlev):
+    H = hierarchy(nc, nlev)
+    n = H["mats"][0].shape[0]
+    r0 = np.random.default_rng(3).uniform(-1, 1, n)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    z, nit, _, hist = g.solve(r0)
+    z2 = np.zeros(n); r2 = r0.copy()
+    _np_vcycle(H["mats"], H["prolongations"], 0, z2, r2)
+    assert nit == 1
+    assert rel_err(z, z2) < 1e-12
+    assert abs(hist[1] - np.linalg.norm(r2)) / hist[1] < 1e-10
+
+
+# ---- operator identities (SURVEY 8c fixture 3) ---------------------------------------
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("nc", [(4, 4), (4, 2, 2)])
+def test_operator_identities(po, nc, order):
+    fine = tuple(2 * c for c in nc)
+    P = po.prolongation(nc, order)
+    Ah, AH = po.poisson_matrix(fine, order), po.poisson_matrix(nc, order)
+    Ps, As, AHs = P.to_scipy(), Ah.to_scipy(), AH.to_scipy()
+    assert abs((Ps.T @ As @ Ps - AHs).toarray()).max() < 1e-13          # A_H == P^T A_h P
+    R = P.transpose().to_scipy()
+    assert abs((R - Ps.T).toarray()).max() == 0.0                        # R == P^T
+    assert abs(As - As.T).max() < 1e-14                                  # symmetric
+    # constants are reproduced by P away from the Dirichlet boundary: interior rows sum to 1
+    rows = np.asarray(Ps.sum(axis=1)).ravel()
+    assert np.isclose(rows, 1.0).any()
+    if order == 1:
+        assert np.isclose(rows.max(), 1.0)
+    # u = x1+x2 is in the FE space: A u_free = b (rhs is the Dirichlet lift)
+    assert max_rel(Ah.matvec(po.nodal_values(fine, order)), po.dirichlet_lift_rhs(fine, order)) < 1e-12
+
+
+def test_structural_pattern_sizes(po):
+    """SURVEY 8 size table: N=(n-1)^d, Z=(3(n-1)-2)^d, Z_P=(3 n_c-3)^d for Q1; Q2: N=(2n-1)^d, Z=(8n-9)^d."""
+    A = po.poisson_matrix((16, 16, 16), 1)
+    assert A.shape[0] == 15 ** 3 and A.nnz == (3 * 15 - 2) ** 3
+    P = po.prolongation((8, 8, 8), 1)
+    assert P.nnz == (3 * 8 - 3) ** 3
+    A2 = po.poisson_matrix((4, 4, 4), 2)
+    assert A2.shape[0] == 7 ** 3 and A2.nnz == (8 * 4 - 9) ** 3
+    A1 = po.poisson_matrix((64, 64), 1)
+    assert (A1.shape[0], A1.nnz) == (3969, 34969)
+
+
+# ---- smoothers / patches ----------------------------------------------------------------
+def test_q1_patch_smoother_is_jacobi(po, orc, hierarchy):
+    """SURVEY 8c fixture 4: for Q1 a vertex-star patch holds the vertex dof only => PatchSolver == Jacobi."""
+    nc = (8, 8, 8)
+    H = hierarchy(nc, 2)
+    pp, pd = po.vertex_star_patches(nc, 1)
+    r = np.random.default_rng(5).uniform(-1, 1, H["mats"][0].shape[0])
+    gj = orc.GMG(H["mats"], H["prolongations"], maxiter=1)
+    for kind in (orc.PATCH, orc.BLOCKJACOBI):
+        gp = orc.GMG(H["mats"], H["prolongations"], pre_smoothers=[orc.Smoother(kind, 10, 2.0 / 3.0, pp, pd)], maxiter=1)
+        assert max_rel(gp.precond(0, r), gj.precond(0, r)) < 1e-15
+        assert rel_err(gp.solve(r)[0], gj.solve(r)[0]) < 1e-13
+
+
+def test_q2_patch_solve_vs_numpy(po, orc, hierarchy):
+    nc, order = (8, 8), 2
+    H = hierarchy(nc, 2, order)
+    A = H["mats"][0].to_scipy().toarray()
+    pp, pd = po.vertex_star_patches(nc, order)
+    r = np.random.default_rng(6).uniform(-1, 1, A.shape[0])
+    ref = np.zeros_like(r)
+    for p in range(len(pp) - 1):
+        d = pd[pp[p]:pp[p + 1]]
+        if d.size:
+            ref[d] += np.linalg.solve(A[np.ix_(d, d)], r[d])
+    assert max((pp[1:] - pp[:-1])) == 9                     # interior vertex: 3^2 dofs
+    for kind in (orc.PATCH, orc.BLOCKJACOBI):
+        g = orc.GMG(H["mats"], H["prolongations"], pre_smoothers=[orc.Smoother(kind, 10, 0.2, pp, pd)], maxiter=1)
+        assert max_rel(g.precond(0, r), ref) < 1e-13
+
+
+def test_direct_solver_and_givens(po, orc):
+    A = po.poisson_matrix((8, 8, 8), 1)
+    b = np.random.default_rng(1).uniform(-1, 1, A.shape[0])
+    x = orc.direct_solve(A, b)
+    assert max_rel(A.matvec(x), b) < 1e-12
+    for f, g in [(3.0, 4.0), (-3.0, 4.0), (5.0, -1.0), (0.0, 2.0), (2.0, 0.0), (1e-300, 1e-300), (1e200, -1e200)]:
+        c, s, r = orc.givens(f, g)
+        assert abs(c * c + s * s - 1.0) < 1e-14
+        assert abs(-s * f + c * g) <= 1e-14 * max(abs(f), abs(g), 1e-300) * 4
+        assert np.isclose(c * f + s * g, r, rtol=1e-14)
+
+
+def test_stopping_rule_semantics(po, orc, hierarchy):
+    """SolverTolerances.jl:117-128: strict '<'; maxiter caps; init! evaluates with e_r = 1."""
+    H = hierarchy((16, 16), 3)
+    A = H["mats"][0]
+    b = po.dirichlet_lift_rhs((16, 16), 1)
+    x, nit, flag, hist = orc.cg_solve(A, b, maxiter=2, rtol=1e-30, atol=0.0)
+    assert nit == 2 and flag == 2 and hist.size == 3                # SOLVER_DIVERGED_MAXITER
+    x, nit, flag, hist = orc.cg_solve(A, b, maxiter=50, rtol=2.0, atol=0.0)
+    assert nit == 0 and flag == 1                                    # e_r = 1 < rtol at init
+    x, nit, flag, hist = orc.cg_solve(A, np.zeros_like(b), maxiter=50, rtol=1e-6, atol=1e-12)
+    assert nit == 0 and flag == 0 and np.all(x == 0)                 # zero rhs: atol at init
+
+
+# ---- committed fixtures ------------------------------------------------------------------
+def test_golden_config1(po, orc, hierarchy):
+    gold = np.load(os.path.join(GOLD, "config1_q1_64x64.npz"))
+    nc, nlev = (64, 64), 3
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    x, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=g, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert nit == int(gold["niters"]) == 3
+    np.testing.assert_allclose(hist, gold["hist"], rtol=1e-12)
+    assert rel_err(x, gold["x"]) < 1e-13
+    assert po.l2_error_sq(nc, 1, gold["x"]) < 1e-8                   # reference criterion
+    xf, nitf, _, histf = orc.fgmres_solve(H["mats"][0], b, Pr=g, m=5, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert nitf == int(gold["fgmres_niters"])
+    np.testing.assert_allclose(histf, gold["fgmres_hist"], rtol=1e-10)
+
+
+def test_w_and_f_cycles_converge_faster_than_v(po, orc, hierarchy):
+    H = hierarchy((16, 16, 16), 3)
+    r = np.random.default_rng(2).uniform(-1, 1, H["mats"][0].shape[0])
+    out = {}
+    for name, cyc in (("v", orc.V_CYCLE), ("w", orc.W_CYCLE), ("f", orc.F_CYCLE)):
+        g = orc.GMG(H["mats"], H["prolongations"], cycle=cyc, maxiter=1)
+        out[name] = g.solve(r)[3][1]
+    assert out["w"] <= out["f"] <= out["v"]
