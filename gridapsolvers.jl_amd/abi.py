@@ -77,6 +77,14 @@ def load(path=None):
     if _LIB is not None:
         return _LIB
     path = path or _build.lib_path()
+    # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in one
+    # process do not both see the GPU, and device pointers must be shared with torch tensors,
+    # so when torch is importable let it load its runtime FIRST; libgmgamd's NEEDED
+    # libamdhip64.so.7 then binds to the copy already in the process.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(path):
         raise ImportError(f"{path} not built: run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950)")
     lib = C.CDLL(path)
