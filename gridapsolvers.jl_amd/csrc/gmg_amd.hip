@@ -151,8 +151,10 @@ struct DevCSR {
   int32_t *col = nullptr;
   double *val = nullptr;
   int32_t *blk_row = nullptr;
+  int64_t *blk_nz = nullptr;
   int nblocks = 0;
   int lanes_log2 = 0;
+  int tile = kTile;
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -188,6 +190,7 @@ struct Level {
   int64_t n = 0;
   double *x = nullptr;            // correction at this level (levels > 0)
   double *rbuf[2] = {nullptr, nullptr};
+  double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
   double *dx = nullptr;
   double *rcur = nullptr;         // buffer holding the current residual after a cycle
 };
@@ -284,8 +287,12 @@ struct gmg_solver {
   std::vector<double *> st_extra;
 
   // tuning
-  int xcd_remap = 1;
+  int xcd_remap = 0;
   int lanes_override = -1;
+  int tpb = 4;          // GMG_TPB: tiles per workgroup of the pipelined kernel
+  int nt_loads = 1;     // GMG_NT: non-temporal matrix stream
+  int variant = 2;      // GMG_VARIANT: 0 multi-pass kernel, 1/3 single-pass (tile 2048/4096), 2/4 + one-gather sweep
+  int tile = kTile;
 
   // profiling of the fused sweep
   int prof_level = -1;
@@ -313,6 +320,14 @@ struct gmg_solver {
     if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return p;
   }
+  template <typename T>
+  T *upload_padded(const std::vector<T> &v, size_t pad)
+  {
+    T *p = dalloc<T>(v.size() + pad);
+    if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(p + v.size(), 0, pad * sizeof(T)));
+    return p;
+  }
   double *dvec(int64_t n)
   {
     double *p = dalloc<double>((size_t)n);
@@ -328,6 +343,7 @@ struct gmg_solver {
       L.A = DevCSR(); L.P = DevCSR(); L.R = DevCSR();
       L.dinv = L.x = L.dx = L.rcur = nullptr;
       L.rbuf[0] = L.rbuf[1] = nullptr;
+      L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pre.built = L.post.built = false;
     }
     d_Ainv = d_partials = d_scalars = nullptr;
@@ -347,29 +363,37 @@ struct gmg_solver {
       std::vector<int32_t> p32(H.ptr.begin(), H.ptr.end());
       D.rowptr = upload(p32);
     }
-    D.col = upload(H.col);
-    D.val = upload(H.val);
-    // workgroup row ranges: greedy fill of the kTile-nnz LDS tile
-    std::vector<int32_t> blk;
-    blk.push_back(0);
-    int64_t r = 0;
-    int64_t maxlen = 0;
-    while (r < H.nrows) {
-      int64_t e = r;
-      const int64_t base = H.ptr[r];
-      while (e < H.nrows && H.ptr[e + 1] - base <= kTile && (e - r) < 4096) ++e;
-      if (e == r) e = r + 1; // single long row
-      maxlen = std::max(maxlen, H.ptr[e] - base);
-      blk.push_back((int32_t)e);
-      r = e;
-    }
-    D.nblocks = (int)blk.size() - 1;
-    D.blk_row = upload(blk);
+    // + one tile of slack: the stream kernels load whole tiles unconditionally
+    D.col = upload_padded(H.col, 4096);
+    D.val = upload_padded(H.val, 4096);
     // lanes per row in the reduce phase: ~ (avg nnz/row)/8, power of two in [1,64]
     const double avg = H.nrows ? (double)D.nnz / (double)H.nrows : 1.0;
     int lg = 0;
     while (lg < 6 && (double)(1 << (lg + 1)) * 6.0 <= avg) ++lg;
     if (lanes_override >= 0) lg = std::min(lanes_override, 6);
+    D.tile = tile;
+    // workgroup row ranges: greedy fill of the LDS tile, at most 256>>lg rows so that every
+    // row owns its G lanes for the whole kernel (single-pass reduce)
+    const int64_t max_rows = kBlock >> lg;
+    std::vector<int32_t> blk;
+    blk.push_back(0);
+    int64_t r = 0;
+    while (r < H.nrows) {
+      int64_t e = r;
+      const int64_t base = H.ptr[r];
+      while (e < H.nrows && H.ptr[e + 1] - base <= D.tile && (e - r) < max_rows) ++e;
+      if (e == r) e = r + 1; // single long row
+      blk.push_back((int32_t)e);
+      r = e;
+    }
+    D.nblocks = (int)blk.size() - 1;
+    D.blk_row = upload(blk);
+    {
+      std::vector<int64_t> bnz(blk.size() + 1);
+      for (size_t i = 0; i < blk.size(); ++i) bnz[i] = H.ptr[blk[i]];
+      bnz[blk.size()] = bnz[blk.size() - 1];
+      D.blk_nz = upload(bnz);
+    }
     D.lanes_log2 = lg;
     return D;
   }
@@ -389,6 +413,39 @@ struct gmg_solver {
     else hipLaunchKernelGGL((csr_stream_kernel<EPI, int32_t>), dim3(M.nblocks), dim3(kBlock), 0, stream, a);
     HIP_CHECK(hipGetLastError());
   }
+  template <int EPI, bool ONEG, bool EMIT_S>
+  void launch_stream1(const DevCSR &M, const StreamArgs2 &a)
+  {
+    if (M.nblocks == 0) return;
+    const dim3 g(M.nblocks), b(kBlock);
+    if (M.tile == 4096) {
+      if (M.ptr64) hipLaunchKernelGGL((csr_stream1_kernel<EPI, int64_t, 4096, ONEG, EMIT_S>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((csr_stream1_kernel<EPI, int32_t, 4096, ONEG, EMIT_S>), g, b, 0, stream, a);
+    } else {
+      if (M.ptr64) hipLaunchKernelGGL((csr_stream1_kernel<EPI, int64_t, 2048, ONEG, EMIT_S>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((csr_stream1_kernel<EPI, int32_t, 2048, ONEG, EMIT_S>), g, b, 0, stream, a);
+    }
+    HIP_CHECK(hipGetLastError());
+  }
+  template <int EPI, bool ONEG>
+  void launch_pipe(const DevCSR &M, const StreamArgs2 &a2)
+  {
+    if (M.nblocks == 0) return;
+    StreamArgs3 a;
+    std::memset(&a, 0, sizeof(a));
+    a.rowptr = a2.rowptr; a.col = a2.col; a.val = a2.val; a.blk_row = a2.blk_row; a.blk_nz = M.blk_nz;
+    a.nblocks = M.nblocks; a.tpb = tpb; a.lanes_log2 = a2.lanes_log2; a.x_zero = a2.x_zero;
+    a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
+    const dim3 g((M.nblocks + tpb - 1) / tpb), b(kBlock);
+    if (nt_loads) {
+      if (M.ptr64) hipLaunchKernelGGL((csr_stream_pipe_kernel<EPI, int64_t, ONEG, true>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((csr_stream_pipe_kernel<EPI, int32_t, ONEG, true>), g, b, 0, stream, a);
+    } else {
+      if (M.ptr64) hipLaunchKernelGGL((csr_stream_pipe_kernel<EPI, int64_t, ONEG, false>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((csr_stream_pipe_kernel<EPI, int32_t, ONEG, false>), g, b, 0, stream, a);
+    }
+    HIP_CHECK(hipGetLastError());
+  }
   StreamArgs base_args(const DevCSR &M) const
   {
     StreamArgs a;
@@ -397,39 +454,65 @@ struct gmg_solver {
     a.nblocks = M.nblocks; a.lanes_log2 = M.lanes_log2; a.xcd_remap = xcd_remap;
     return a;
   }
+  StreamArgs2 base_args1(const DevCSR &M) const
+  {
+    StreamArgs2 a;
+    std::memset(&a, 0, sizeof(a));
+    a.rowptr = M.rowptr; a.col = M.col; a.val = M.val; a.blk_row = M.blk_row;
+    a.nblocks = M.nblocks; a.lanes_log2 = M.lanes_log2; a.xcd_remap = xcd_remap;
+    return a;
+  }
   // y = M x
   void spmv_set(const DevCSR &M, const double *x, double *y)
   {
-    StreamArgs a = base_args(M); a.x = x; a.y = y;
-    launch_stream<EPI_SET>(M, a);
+    if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; launch_stream<EPI_SET>(M, a); return; }
+    StreamArgs2 a = base_args1(M); a.x = x; a.y = y;
+    if (variant >= 5) launch_pipe<EPI_SET, false>(M, a); else
+    launch_stream1<EPI_SET, false, false>(M, a);
   }
   // y -= M x
   void spmv_sub(const DevCSR &M, const double *x, double *y)
   {
-    StreamArgs a = base_args(M); a.x = x; a.y = y;
-    launch_stream<EPI_SUB>(M, a);
+    if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; launch_stream<EPI_SUB>(M, a); return; }
+    StreamArgs2 a = base_args1(M); a.x = x; a.y = y;
+    if (variant >= 5) launch_pipe<EPI_SUB, false>(M, a); else
+    launch_stream1<EPI_SUB, false, false>(M, a);
   }
   // y = b - M x
   void spmv_resid(const DevCSR &M, const double *x, const double *b, double *y)
   {
-    StreamArgs a = base_args(M); a.x = x; a.y = y; a.b = b;
-    launch_stream<EPI_RESID>(M, a);
+    if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; a.b = b; launch_stream<EPI_RESID>(M, a); return; }
+    StreamArgs2 a = base_args1(M); a.x = x; a.y = y; a.b = b;
+    if (variant >= 5) launch_pipe<EPI_RESID, false>(M, a); else
+    launch_stream1<EPI_RESID, false, false>(M, a);
   }
   // y = M x ; x2 += y
   void spmv_addto(const DevCSR &M, const double *x, double *y, double *x2)
   {
-    StreamArgs a = base_args(M); a.x = x; a.y = y; a.x2 = x2;
-    launch_stream<EPI_ADDTO>(M, a);
+    if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; a.x2 = x2; launch_stream<EPI_ADDTO>(M, a); return; }
+    StreamArgs2 a = base_args1(M); a.x = x; a.y = y; a.x2 = x2;
+    if (variant >= 5) launch_pipe<EPI_ADDTO, false>(M, a); else
+    launch_stream1<EPI_ADDTO, false, false>(M, a);
   }
+  bool one_gather() const { return variant == 2 || variant == 4 || variant == 6; }
   // fused Richardson-Jacobi sweep: x += w*Dinv*r_old ; r_new = r_old - A*(w*Dinv*r_old)
-  void sweep(int l, const Smoother &S, double *x, const double *r_old, double *r_new, bool x_zero)
+  // one-gather form: s_old = w*Dinv*r_old is an input, s_new = w*Dinv*r_new an output.
+  void sweep(int l, const Smoother &S, double *x, const double *r_old, double *r_new, bool x_zero,
+             const double *s_old = nullptr, double *s_new = nullptr)
   {
     Level &L = lev[l];
-    StreamArgs a = base_args(L.A);
-    a.x = r_old; a.b = r_old; a.dinv = L.dinv; a.omega = S.omega; a.y = r_new; a.x2 = x; a.x_zero = x_zero ? 1 : 0;
     const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();
     if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
-    launch_stream<EPI_SWEEP>(L.A, a);
+    if (variant == 0) {
+      StreamArgs a = base_args(L.A);
+      a.x = r_old; a.b = r_old; a.dinv = L.dinv; a.omega = S.omega; a.y = r_new; a.x2 = x; a.x_zero = x_zero ? 1 : 0;
+      launch_stream<EPI_SWEEP>(L.A, a);
+    } else {
+      StreamArgs2 a = base_args1(L.A);
+      a.b = r_old; a.dinv = L.dinv; a.omega = S.omega; a.y = r_new; a.x2 = x; a.x_zero = x_zero ? 1 : 0;
+      if (s_old) { a.x = s_old; a.s_out = s_new; if (variant >= 5) launch_pipe<EPI_SWEEP, true>(L.A, a); else launch_stream1<EPI_SWEEP, true, false>(L.A, a); }
+      else { a.x = r_old; if (variant >= 5) launch_pipe<EPI_SWEEP, false>(L.A, a); else launch_stream1<EPI_SWEEP, false, false>(L.A, a); }
+    }
     if (prof) {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
       prof_used += 2;
@@ -488,6 +571,19 @@ struct gmg_solver {
       if (x_zero) zero(x, n);
       if (!r_internal) { copy(L.rbuf[0], r_in, n); return L.rbuf[0]; }
       return const_cast<double *>(r_in);
+    }
+    if (S.kind == SM_JACOBI && one_gather()) {
+      // s_0 = w*Dinv*r_in ; then each sweep: x += s_k ; r -= A s_k (in place after the
+      // first sweep) ; s_{k+1} = w*Dinv*r
+      hipLaunchKernelGGL(scaled_jacobi_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, S.omega, L.dinv, r_in, L.sbuf[0]);
+      HIP_CHECK(hipGetLastError());
+      const double *cur = r_in;
+      double *out = r_internal ? const_cast<double *>(r_in) : L.rbuf[0];
+      for (int it = 0; it < S.niter; ++it) {
+        sweep(l, S, x, cur, out, x_zero && it == 0, L.sbuf[it & 1], L.sbuf[(it + 1) & 1]);
+        cur = out;
+      }
+      return out;
     }
     if (S.kind == SM_JACOBI) {
       const double *cur = r_in;
@@ -809,8 +905,12 @@ void gmg_solver::setup()
 {
   HIP_CHECK(hipSetDevice(device));
   free_all();
-  xcd_remap = env_int("GMG_XCD_REMAP", 1);
+  xcd_remap = env_int("GMG_XCD_REMAP", 0);   // measured: no gain from XCD-contiguous ranges (profiles/r01_tuning.md)
   lanes_override = env_int("GMG_LANES_LOG2", -1);
+  variant = env_int("GMG_VARIANT", 2);
+  tpb = std::max(1, env_int("GMG_TPB", 4));
+  nt_loads = env_int("GMG_NT", 1);
+  tile = (variant == 3 || variant == 4) ? 4096 : kTile;
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));
@@ -835,7 +935,8 @@ void gmg_solver::setup()
     if (l > 0) L.x = dvec(L.n);                             // :188 dxH
     if (l < nlev - 1) {
       L.rbuf[1] = dvec(L.n);
-      L.dx = dvec(L.n);                                     // :188 dxh (Adxh is fused away)
+      L.dx = dvec(L.n);
+      if (one_gather()) { L.sbuf[0] = dvec(L.n); L.sbuf[1] = dvec(L.n); }                                     // :188 dxh (Adxh is fused away)
       L.P = upload_csr(L.hP);
       if (L.hasR) L.R = upload_csr(L.hR);
       else {

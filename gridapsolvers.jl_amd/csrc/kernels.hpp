@@ -176,6 +176,370 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(StreamArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Single-pass CSR-stream kernel (the production path).
+//
+// The host partitions the rows so that every workgroup owns <= (256 >> lanes_log2)
+// rows and <= TILE nnz (a row longer than TILE is a workgroup of its own).  Every
+// row then has its G = 1<<lanes_log2 lanes for the whole kernel, which lets the
+// row pointers and all row-wise epilogue operands be fetched BEFORE the stream
+// phase: after the barrier the kernel touches only LDS and issues its stores.
+//
+// EPI_SWEEP has two forms:
+//   ONEG = false : two gathers per nnz (dinv_j, r_j), r ping-pong, 12Z+44N bytes;
+//   ONEG = true  : one gather per nnz from s = omega*(dinv.*r), which the previous
+//                  sweep's epilogue produced (s ping-pong, r in place), 12Z+60N bytes.
+// Both give bit-identical dx_j = omega*(dinv_j*r_j) (same two roundings as
+// RichardsonSmoothers.jl:91-92 / JacobiLinearSolvers.jl:45).
+// ---------------------------------------------------------------------------
+struct StreamArgs2 {
+  const void *rowptr;
+  const int32_t *col;
+  const double *val;
+  const int32_t *blk_row;
+  int nblocks;
+  int lanes_log2;
+  int xcd_remap;
+  int x_zero;
+  const double *x;     // gather source (ONEG sweep: s_old)
+  const double *dinv;
+  double omega;
+  double *y;           // output (sweep: r_new; ONEG: r in place)
+  const double *b;     // RESID: b ; sweep: r_old (row-wise)
+  double *x2;          // sweep / ADDTO: x
+  double *s_out;       // ONEG sweep and *_S epilogues: s_new = omega*(dinv.*r_new)
+};
+
+template <int EPI, typename PtrT, int TILE, bool ONEG, bool EMIT_S>
+__global__ __launch_bounds__(kBlock) void csr_stream1_kernel(StreamArgs2 a)
+{
+  __shared__ double prod[TILE];
+  const int tid = threadIdx.x;
+  const int blk = remap_block(blockIdx.x, a.nblocks, a.xcd_remap);
+  const PtrT *__restrict__ rowptr = reinterpret_cast<const PtrT *>(a.rowptr);
+  const int r0 = a.blk_row[blk];
+  const int r1 = a.blk_row[blk + 1];
+  const PtrT nz0 = rowptr[r0];
+  const PtrT nz1 = rowptr[r1];
+  const int64_t cnt = (int64_t)(nz1 - nz0);
+  const int32_t *__restrict__ col = a.col;
+  const double *__restrict__ val = a.val;
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+
+  if (cnt <= TILE) {
+    // ---- row-owner prefetch (independent of the stream phase) ----
+    const int lg = a.lanes_log2;
+    const int G = 1 << lg;
+    const int sub = tid & (G - 1);
+    const int row = r0 + (tid >> lg);
+    const bool active = row < r1;
+    const bool owner = active && sub == 0;
+    int k0 = 0, k1 = 0;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0; // epilogue operands
+    if (active) {
+      k0 = (int)(rowptr[row] - nz0);
+      k1 = (int)(rowptr[row + 1] - nz0);
+    }
+    if (owner) {
+      if (EPI == EPI_SUB) e0 = a.y[row];
+      else if (EPI == EPI_RESID) e0 = a.b[row];
+      else if (EPI == EPI_ADDTO) e0 = a.x2[row];
+      else if (EPI == EPI_SWEEP) {
+        e0 = a.b[row];                               // r_old
+        e1 = ONEG ? xg[row] : dinv[row];             // s_old | dinv
+        e2 = a.x_zero ? 0.0 : a.x2[row];             // x
+        if (ONEG) e0 = a.b[row];
+      }
+      if ((EMIT_S || (EPI == EPI_SWEEP && ONEG)) && !(EPI == EPI_SWEEP && !ONEG)) { /* dinv needed for s_new */ }
+    }
+    double dinv_row = 0.0;
+    if (owner && (EMIT_S || (EPI == EPI_SWEEP && ONEG))) dinv_row = dinv[row];
+
+    // ---- phase 1: coalesced stream, gather, products -> LDS ----
+    constexpr int U = TILE / kBlock;
+    int32_t c[U];
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = tid + u * kBlock;
+      const bool ok = k < cnt;
+      c[u] = ok ? __builtin_nontemporal_load(col + nz0 + k) : -1;
+      v[u] = ok ? __builtin_nontemporal_load(val + nz0 + k) : 0.0;
+    }
+    double g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cc = c[u] >= 0 ? c[u] : 0;
+      if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (dinv[cc] * xg[cc]);
+      else g[u] = xg[cc];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = tid + u * kBlock;
+      if (c[u] >= 0) prod[k] = v[u] * g[u];
+    }
+    __syncthreads();
+    // ---- phase 2: G lanes per row, LDS only ----
+    double s = 0.0;
+    for (int k = k0 + sub; k < k1; k += G) s += prod[k];
+    for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (owner) {
+      double rn = 0.0;
+      if (EPI == EPI_SET) { rn = s; a.y[row] = rn; }
+      else if (EPI == EPI_SUB) { rn = e0 - s; a.y[row] = rn; }
+      else if (EPI == EPI_RESID) { rn = e0 - s; a.y[row] = rn; }
+      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+      else { // EPI_SWEEP
+        const double dxi = ONEG ? e1 : omega * (e1 * e0);
+        a.x2[row] = e2 + dxi;
+        rn = e0 - s;
+        a.y[row] = rn;
+      }
+      if (EMIT_S || (EPI == EPI_SWEEP && ONEG)) a.s_out[row] = omega * (dinv_row * rn);
+    }
+  } else {
+    // ---- long row: the range is a single row; whole workgroup strides it ----
+    double s = 0.0;
+    for (int64_t k = tid; k < cnt; k += kBlock) {
+      const int32_t cc = col[nz0 + k];
+      double xv;
+      if (EPI == EPI_SWEEP && !ONEG) xv = omega * (dinv[cc] * xg[cc]);
+      else xv = xg[cc];
+      s += val[nz0 + k] * xv;
+    }
+    prod[tid] = s;
+    __syncthreads();
+    for (int w = kBlock >> 1; w > 0; w >>= 1) {
+      if (tid < w) prod[tid] += prod[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int row = r0;
+      s = prod[0];
+      double rn = 0.0;
+      if (EPI == EPI_SET) { rn = s; a.y[row] = rn; }
+      else if (EPI == EPI_SUB) { rn = a.y[row] - s; a.y[row] = rn; }
+      else if (EPI == EPI_RESID) { rn = a.b[row] - s; a.y[row] = rn; }
+      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = a.x2[row] + s; }
+      else {
+        const double ro = a.b[row];
+        const double dxi = ONEG ? xg[row] : omega * (dinv[row] * ro);
+        const double xo = a.x_zero ? 0.0 : a.x2[row];
+        a.x2[row] = xo + dxi;
+        rn = ro - s;
+        a.y[row] = rn;
+      }
+      if (EMIT_S || (EPI == EPI_SWEEP && ONEG)) a.s_out[row] = omega * (dinv[row] * rn);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Software-pipelined CSR-stream kernel: one workgroup walks `tpb` consecutive tiles
+// and issues the coalesced (col,val) loads of tile t+1 right after the gathers of
+// tile t, so HBM requests stay in flight during the gather wait, the LDS reduce and
+// the epilogue of tile t (the single-tile kernel has nothing in flight then).
+// vmcnt accounting is in-order, hence the order: row-owner loads(t), gathers(t),
+// stream loads(t+1); the compiler can then wait for the gathers with vmcnt(#prefetch).
+// ---------------------------------------------------------------------------
+struct StreamArgs3 {
+  const void *rowptr;
+  const int32_t *col;
+  const double *val;
+  const int32_t *blk_row;
+  const int64_t *blk_nz;   // first nnz of every tile (cuts the blk_row -> rowptr dependency)
+  int nblocks;             // number of tiles
+  int tpb;                 // tiles per workgroup
+  int lanes_log2;
+  int x_zero;
+  const double *x;
+  const double *dinv;
+  double omega;
+  double *y;
+  const double *b;
+  double *x2;
+  double *s_out;
+};
+
+template <int EPI, typename PtrT, bool ONEG, bool NT>
+__global__ __launch_bounds__(kBlock) void csr_stream_pipe_kernel(StreamArgs3 a)
+{
+  constexpr int TILE = kTile;
+  constexpr int U = TILE / kBlock;
+  __shared__ double prod[TILE];
+  const int tid = threadIdx.x;
+  const PtrT *__restrict__ rowptr = reinterpret_cast<const PtrT *>(a.rowptr);
+  const int32_t *__restrict__ col = a.col;
+  const double *__restrict__ val = a.val;
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  const int lg = a.lanes_log2;
+  const int G = 1 << lg;
+  const int sub = tid & (G - 1);
+  const int slot = tid >> lg;
+
+  const int t_begin = blockIdx.x * a.tpb;
+  const int t_end = min(t_begin + a.tpb, a.nblocks);
+  if (t_begin >= t_end) return;
+
+  int32_t c[U];
+  double v[U];
+  int64_t nz0 = a.blk_nz[t_begin];
+  int64_t cnt = a.blk_nz[t_begin + 1] - nz0;
+  // prologue: stream loads of the first tile
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = tid + u * kBlock;
+    const bool ok = (k < cnt) && (cnt <= TILE);
+    if (NT) {
+      c[u] = ok ? __builtin_nontemporal_load(col + nz0 + k) : -1;
+      v[u] = ok ? __builtin_nontemporal_load(val + nz0 + k) : 0.0;
+    } else {
+      c[u] = ok ? col[nz0 + k] : -1;
+      v[u] = ok ? val[nz0 + k] : 0.0;
+    }
+  }
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int r0 = a.blk_row[t];
+    const int r1 = a.blk_row[t + 1];
+    // next tile's extent (uniform, scalar loads)
+    int64_t nz0n = 0, cntn = 0;
+    if (t + 1 < t_end) {
+      nz0n = a.blk_nz[t + 1];
+      cntn = a.blk_nz[t + 2] - nz0n;
+    }
+    if (cnt <= TILE) {
+      // ---- row-owner loads for tile t ----
+      const int row = r0 + slot;
+      const bool active = row < r1;
+      const bool owner = active && sub == 0;
+      int k0 = 0, k1 = 0;
+      double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+      if (active) {
+        k0 = (int)((int64_t)rowptr[row] - nz0);
+        k1 = (int)((int64_t)rowptr[row + 1] - nz0);
+      }
+      if (owner) {
+        if (EPI == EPI_SUB) e0 = a.y[row];
+        else if (EPI == EPI_RESID) e0 = a.b[row];
+        else if (EPI == EPI_ADDTO) e0 = a.x2[row];
+        else if (EPI == EPI_SWEEP) {
+          e0 = a.b[row];                       // r_old
+          e1 = ONEG ? xg[row] : dinv[row];     // s_old | dinv
+          e2 = a.x_zero ? 0.0 : a.x2[row];     // x
+          if (ONEG) dinv_row = dinv[row];
+        }
+      }
+      // ---- gathers for tile t ----
+      double g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cc = c[u] >= 0 ? c[u] : 0;
+        if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (dinv[cc] * xg[cc]);
+        else g[u] = xg[cc];
+      }
+      // ---- stream loads for tile t+1 (stay in flight across the barrier) ----
+      int32_t cn[U];
+      double vn[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = tid + u * kBlock;
+        const bool ok = (k < cntn) && (cntn <= TILE);
+        if (NT) {
+          cn[u] = ok ? __builtin_nontemporal_load(col + nz0n + k) : -1;
+          vn[u] = ok ? __builtin_nontemporal_load(val + nz0n + k) : 0.0;
+        } else {
+          cn[u] = ok ? col[nz0n + k] : -1;
+          vn[u] = ok ? val[nz0n + k] : 0.0;
+        }
+      }
+      // ---- products -> LDS ----
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = tid + u * kBlock;
+        if (c[u] >= 0) prod[k] = v[u] * g[u];
+      }
+      __syncthreads();
+      double s = 0.0;
+      for (int k = k0 + sub; k < k1; k += G) s += prod[k];
+      for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+      if (owner) {
+        double rn = 0.0;
+        if (EPI == EPI_SET) { a.y[row] = s; }
+        else if (EPI == EPI_SUB) { a.y[row] = e0 - s; }
+        else if (EPI == EPI_RESID) { a.y[row] = e0 - s; }
+        else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+        else {
+          const double dxi = ONEG ? e1 : omega * (e1 * e0);
+          a.x2[row] = e2 + dxi;
+          rn = e0 - s;
+          a.y[row] = rn;
+          if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+        }
+      }
+      __syncthreads(); // prod[] is rewritten by the next tile
+#pragma unroll
+      for (int u = 0; u < U; ++u) { c[u] = cn[u]; v[u] = vn[u]; }
+    } else {
+      // ---- long row (a tile of its own): whole workgroup strides it, no prefetch ----
+      double s = 0.0;
+      for (int64_t k = tid; k < cnt; k += kBlock) {
+        const int32_t cc = col[nz0 + k];
+        double xv;
+        if (EPI == EPI_SWEEP && !ONEG) xv = omega * (dinv[cc] * xg[cc]);
+        else xv = xg[cc];
+        s += val[nz0 + k] * xv;
+      }
+      prod[tid] = s;
+      __syncthreads();
+      for (int w = kBlock >> 1; w > 0; w >>= 1) {
+        if (tid < w) prod[tid] += prod[tid + w];
+        __syncthreads();
+      }
+      if (tid == 0) {
+        const int row = r0;
+        s = prod[0];
+        if (EPI == EPI_SET) { a.y[row] = s; }
+        else if (EPI == EPI_SUB) { a.y[row] = a.y[row] - s; }
+        else if (EPI == EPI_RESID) { a.y[row] = a.b[row] - s; }
+        else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = a.x2[row] + s; }
+        else {
+          const double ro = a.b[row];
+          const double dxi = ONEG ? xg[row] : omega * (dinv[row] * ro);
+          const double xo = a.x_zero ? 0.0 : a.x2[row];
+          a.x2[row] = xo + dxi;
+          const double rn = ro - s;
+          a.y[row] = rn;
+          if (ONEG) a.s_out[row] = omega * (dinv[row] * rn);
+        }
+      }
+      __syncthreads();
+      // stream loads of the next tile (not prefetched across a long row)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = tid + u * kBlock;
+        const bool ok = (k < cntn) && (cntn <= TILE);
+        c[u] = ok ? col[nz0n + k] : -1;
+        v[u] = ok ? val[nz0n + k] : 0.0;
+      }
+    }
+    nz0 = nz0n;
+    cnt = cntn;
+  }
+}
+
+// s = omega*(dinv.*r)  (first sweep of a ONEG smoothing pass)
+__global__ void scaled_jacobi_kernel(int64_t n, double omega, const double *__restrict__ dinv,
+                                     const double *__restrict__ r, double *__restrict__ s)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    s[i] = omega * (dinv[i] * r[i]);
+}
+
+// ---------------------------------------------------------------------------
 // inv_diag = 1.0 ./ diag(A)   (JacobiLinearSolvers.jl:20-23)
 // ---------------------------------------------------------------------------
 template <typename PtrT>
