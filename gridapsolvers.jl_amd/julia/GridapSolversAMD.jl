@@ -1,0 +1,330 @@
+# GridapSolversAMD.jl -- Julia binding of libgmgamd.so (include/gmg_amd.h).
+#
+# Host code stays Julia: this module keeps the Gridap.Algebra surface
+#     LinearSolver -> symbolic_setup -> numerical_setup / numerical_setup! -> solve!
+# of GridapSolvers' GMGLinearSolver (src/LinearSolvers/GMGLinearSolvers.jl:48-69,164-210,
+# 612-649), CGSolver (Krylov/CGSolvers.jl:19-120) and FGMRESSolver
+# (Krylov/FGMRESSolvers.jl:26-199) and forwards the work to the MI355X through `ccall`.
+#
+# NOTE: Julia is not installed in the build image, so this file cannot be executed
+# there.  It is deliberately thin and mechanical: every `ccall` below binds one symbol
+# of include/gmg_amd.h with the argument order of that header (a CPU test checks that
+# only declared symbols are referenced), and the same ABI is exercised end-to-end by
+# the Python mirror (gridapsolvers.jl_amd/solvers.py) in the GPU test-suite.
+#
+# Usage (drop-in for the reference's test/LinearSolvers/GMGTests.jl:109-124):
+#
+#     using GridapSolversAMD
+#     smatrices, A, b = compute_hierarchy_matrices(trials,tests,biform,liform,qdegree)
+#     Ps  = explicit_prolongations(tests)          # SparseMatrixCSC per level (see INTEGRATION.md)
+#     gmg = HipGMGLinearSolver(smatrices, Ps;
+#             pre_smoothers  = Fill(RichardsonSmoother(JacobiLinearSolver(),10,2.0/3.0),nlev-1),
+#             maxiter=1, mode=:preconditioner, cycle_type=:v_cycle)
+#     solver = HipCGSolver(gmg; maxiter=20, atol=1e-14, rtol=1e-6)
+#     ns = numerical_setup(symbolic_setup(solver,A),A)
+#     x  = zeros(size(A,2)); solve!(x,ns,b)
+module GridapSolversAMD
+
+using LinearAlgebra
+using SparseArrays
+using Gridap
+using Gridap.Algebra
+using GridapSolvers
+using GridapSolvers.SolverInterfaces: ConvergenceLog, SolverTolerances
+using GridapSolvers.LinearSolvers: RichardsonSmoother, JacobiLinearSolver
+
+export HipGMGLinearSolver, HipCGSolver, HipFGMRESSolver, PatchTable
+
+const libgmgamd = get(ENV, "LIBGMGAMD", joinpath(@__DIR__, "..", "libgmgamd.so"))
+
+# enums of gmg_amd.h
+const GMG_CSR, GMG_CSC = Cint(0), Cint(1)
+const GMG_MEM_HOST, GMG_MEM_DEVICE = Cint(0), Cint(1)
+const GMG_PRE, GMG_POST, GMG_PRE_AND_POST = Cint(0), Cint(1), Cint(2)
+const GMG_PATCH_LU, GMG_PATCH_NOPIVOT = Cint(0), Cint(1)
+
+struct GmgResult
+  niters::Int32
+  flag::Int32
+  res0::Float64
+  res::Float64
+end
+
+function check(h::Ptr{Cvoid}, status::Cint)
+  if status != 0
+    msg = unsafe_string(ccall((:gmg_last_error, libgmgamd), Cstring, (Ptr{Cvoid},), h))
+    error("libgmgamd status $status: $msg")   # reference behaviour: @check / @assert -> exception
+  end
+  return nothing
+end
+
+# ---------------------------------------------------------------------------------
+# smoother descriptions.  RichardsonSmoother / JacobiLinearSolver are the reference's
+# own types; patch smoothers are passed as the dof tables that reach solve!
+# (PatchSolvers.jl:279-300 patch_cols, BlockJacobiSolvers.jl:141-170).
+# ---------------------------------------------------------------------------------
+struct PatchTable
+  patch_ptr  :: Vector{Int64}   # npatch+1, 1-based like Gridap's Table.ptrs
+  patch_dofs :: Vector{Int64}   # 1-based dof ids
+  pivoting   :: Bool            # true: PatchSolver (lu!) ; false: BlockJacobiSolver (NoPivot)
+end
+PatchTable(t::Gridap.Arrays.Table; pivoting=true) = PatchTable(Int64.(t.ptrs), Int64.(t.data), pivoting)
+
+struct HipGMGLinearSolver{A,B,C,D,E} <: Gridap.Algebra.LinearSolver
+  smatrices      :: A
+  interp         :: B           # explicit sparse prolongations, level l+1 -> l
+  restrict       :: C           # explicit sparse restrictions or nothing (=> P^T on the device)
+  pre_smoothers  :: D
+  post_smoothers :: E
+  mode           :: Symbol
+  cycle_type     :: Symbol
+  log            :: ConvergenceLog{Float64}
+  device         :: Int
+end
+
+# Same keyword surface as GMGLinearSolver(smatrices,interp,restrict;...) GMGLinearSolvers.jl:48-69
+function HipGMGLinearSolver(
+  smatrices::AbstractArray{<:AbstractMatrix}, interp::AbstractArray, restrict = nothing;
+  pre_smoothers  = fill(RichardsonSmoother(JacobiLinearSolver(),10),length(smatrices)-1),
+  post_smoothers = pre_smoothers,
+  mode = :preconditioner, cycle_type = :v_cycle,
+  maxiter = 100, atol = 1.0e-14, rtol = 1.0e-08, verbose = false, device = 0,
+)
+  nlev = length(smatrices)
+  @assert nlev-1 == length(interp) == length(pre_smoothers) == length(post_smoothers)
+  @assert isnothing(restrict) || length(restrict) == nlev-1
+  @assert mode ∈ [:preconditioner,:solver]
+  @assert cycle_type ∈ [:v_cycle,:w_cycle,:f_cycle]
+  tols = SolverTolerances{Float64}(;maxiter=maxiter,atol=atol,rtol=rtol)
+  log  = ConvergenceLog("GMG-MI355X",tols;verbose=verbose)
+  return HipGMGLinearSolver(smatrices,interp,restrict,pre_smoothers,post_smoothers,mode,cycle_type,log,device)
+end
+
+struct HipGMGSymbolicSetup{A} <: Gridap.Algebra.SymbolicSetup
+  solver :: A
+end
+Gridap.Algebra.symbolic_setup(s::HipGMGLinearSolver,::AbstractMatrix) = HipGMGSymbolicSetup(s)
+
+mutable struct HipGMGNumericalSetup{A} <: Gridap.Algebra.NumericalSetup
+  solver :: A
+  handle :: Ptr{Cvoid}
+  n      :: Int
+end
+
+# --- operator upload: SparseMatrixCSC{Float64,Ti} is CSC / 1-based / sizeof(Ti) bytes ----
+function _set_op(sym::Symbol, h, lev, M::SparseMatrixCSC{Float64,Ti}) where Ti
+  nb = Cint(sizeof(Ti))
+  GC.@preserve M begin
+    if sym === :matrix
+      st = ccall((:gmg_set_matrix, libgmgamd), Cint,
+        (Ptr{Cvoid},Cint,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+        h, lev, size(M,1), size(M,2), nnz(M), M.colptr, M.rowval, M.nzval, GMG_CSC, 1, nb)
+    elseif sym === :prolongation
+      st = ccall((:gmg_set_prolongation, libgmgamd), Cint,
+        (Ptr{Cvoid},Cint,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+        h, lev, size(M,1), size(M,2), nnz(M), M.colptr, M.rowval, M.nzval, GMG_CSC, 1, nb)
+    else
+      st = ccall((:gmg_set_restriction, libgmgamd), Cint,
+        (Ptr{Cvoid},Cint,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+        h, lev, size(M,1), size(M,2), nnz(M), M.colptr, M.rowval, M.nzval, GMG_CSC, 1, nb)
+    end
+  end
+  check(h, st)
+end
+# SparseMatricesCSR.SparseMatrixCSR{Bi,Float64,Ti}: fields rowptr, colval, nzval (PAExtras.jl:147-159)
+function _set_op(sym::Symbol, h, lev, M::AbstractMatrix)
+  if hasproperty(M,:rowptr) && hasproperty(M,:colval)
+    Ti = eltype(M.rowptr); Bi = Int(first(M.rowptr))          # index base = first row pointer
+    f = sym === :matrix ? :gmg_set_matrix : (sym === :prolongation ? :gmg_set_prolongation : :gmg_set_restriction)
+    GC.@preserve M begin
+      st = if f === :gmg_set_matrix
+        ccall((:gmg_set_matrix, libgmgamd), Cint,
+          (Ptr{Cvoid},Cint,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+          h, lev, size(M,1), size(M,2), length(M.nzval), M.rowptr, M.colval, M.nzval, GMG_CSR, Bi, sizeof(Ti))
+      elseif f === :gmg_set_prolongation
+        ccall((:gmg_set_prolongation, libgmgamd), Cint,
+          (Ptr{Cvoid},Cint,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+          h, lev, size(M,1), size(M,2), length(M.nzval), M.rowptr, M.colval, M.nzval, GMG_CSR, Bi, sizeof(Ti))
+      else
+        ccall((:gmg_set_restriction, libgmgamd), Cint,
+          (Ptr{Cvoid},Cint,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+          h, lev, size(M,1), size(M,2), length(M.nzval), M.rowptr, M.colval, M.nzval, GMG_CSR, Bi, sizeof(Ti))
+      end
+    end
+    check(h, st)
+  else
+    _set_op(sym, h, lev, SparseMatrixCSC{Float64,Int64}(sparse(M)))
+  end
+end
+
+function _set_smoother(h, lev, which, sm::RichardsonSmoother)
+  M = sm.M
+  if M isa JacobiLinearSolver
+    check(h, ccall((:gmg_set_smoother_jacobi, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Cint,Float64),
+                   h, lev, which, sm.niter, sm.ω))
+  elseif M isa PatchTable
+    GC.@preserve M begin
+      check(h, ccall((:gmg_set_smoother_patch, libgmgamd), Cint,
+        (Ptr{Cvoid},Cint,Cint,Cint,Float64,Cint,Int64,Ptr{Cvoid},Ptr{Cvoid},Cint,Cint),
+        h, lev, which, sm.niter, sm.ω, M.pivoting ? GMG_PATCH_LU : GMG_PATCH_NOPIVOT,
+        length(M.patch_ptr)-1, M.patch_ptr, M.patch_dofs, 1, 8))
+    end
+  else
+    error("HipGMGLinearSolver: smoother inner solver $(typeof(M)) is not available on the device")
+  end
+end
+
+# numerical_setup(ss,A): GMGLinearSolvers.jl:183-210
+function Gridap.Algebra.numerical_setup(ss::HipGMGSymbolicSetup, mat::AbstractMatrix)
+  s = ss.solver
+  nlev = length(s.smatrices)
+  href = Ref{Ptr{Cvoid}}(C_NULL)
+  check(C_NULL, ccall((:gmg_create, libgmgamd), Cint, (Ref{Ptr{Cvoid}},Cint,Cint), href, nlev, s.device))
+  h = href[]
+  ns = HipGMGNumericalSetup(s, h, size(mat,1))
+  finalizer(x -> (x.handle != C_NULL && ccall((:gmg_destroy, libgmgamd), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), ns)
+  for l in 1:nlev
+    _set_op(:matrix, h, l-1, l == 1 ? mat : s.smatrices[l])       # smatrices[1] = mat (:338)
+  end
+  for l in 1:nlev-1
+    _set_op(:prolongation, h, l-1, s.interp[l])
+    !isnothing(s.restrict) && _set_op(:restriction, h, l-1, s.restrict[l])
+    if s.post_smoothers[l] === s.pre_smoothers[l]
+      _set_smoother(h, l-1, GMG_PRE_AND_POST, s.pre_smoothers[l])
+    else
+      _set_smoother(h, l-1, GMG_PRE,  s.pre_smoothers[l])
+      _set_smoother(h, l-1, GMG_POST, s.post_smoothers[l])
+    end
+  end
+  tols = s.log.tols
+  mode  = s.mode == :preconditioner ? 0 : 1
+  cycle = s.cycle_type == :v_cycle ? 0 : (s.cycle_type == :w_cycle ? 1 : 2)
+  check(h, ccall((:gmg_set_options, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Cint,Float64,Float64),
+                 h, mode, cycle, tols.maxiter, tols.atol, tols.rtol))
+  check(h, ccall((:gmg_setup, libgmgamd), Cint, (Ptr{Cvoid},), h))
+  return ns
+end
+
+# numerical_setup!(ns,A): new values on the same pattern (the reference's FromMatrices
+# variant only logs an @error, GMGLinearSolvers.jl:249-258; the weak-form variant :260-297
+# re-assembles every level -- pass the re-assembled finest matrix here).
+function Gridap.Algebra.numerical_setup!(ns::HipGMGNumericalSetup, mat::AbstractMatrix)
+  At = SparseMatrixCSC{Float64,Int64}(sparse(transpose(mat)))    # CSR value order of `mat`
+  GC.@preserve At begin
+    check(ns.handle, ccall((:gmg_update_values, libgmgamd), Cint, (Ptr{Cvoid},Cint,Ptr{Float64}), ns.handle, 0, At.nzval))
+  end
+  check(ns.handle, ccall((:gmg_setup, libgmgamd), Cint, (Ptr{Cvoid},), ns.handle))
+  return ns
+end
+
+function _fill_log!(log::ConvergenceLog, res::GmgResult, hist::Vector{Float64})
+  log.num_iters = res.niters
+  fill!(log.residuals, 0.0)
+  log.residuals[1:res.niters+1] .= hist[1:res.niters+1]
+  return log
+end
+
+# solve!(x,ns,b): GMGLinearSolvers.jl:612-645 ; b untouched, x overwritten (zeroed first in
+# :preconditioner mode), returns x.
+function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipGMGNumericalSetup, b::Vector{Float64})
+  @assert length(x) == length(b) == ns.n
+  log  = ns.solver.log
+  res  = Ref(GmgResult(0,0,0.0,0.0))
+  hist = zeros(log.tols.maxiter+1)
+  GC.@preserve x b hist begin
+    check(ns.handle, ccall((:gmg_apply, libgmgamd), Cint,
+      (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Ref{GmgResult},Ptr{Float64},Cint),
+      ns.handle, b, x, GMG_MEM_HOST, res, hist, length(hist)))
+  end
+  _fill_log!(log, res[], hist)
+  return x
+end
+LinearAlgebra.ldiv!(x::AbstractVector, ns::HipGMGNumericalSetup, b::AbstractVector) = solve!(x,ns,b)   # :647-649
+
+# duck-typed `mul!` for the transfer operators of a set-up hierarchy (GMGLinearSolvers.jl:484,491)
+struct HipLevelOperator
+  ns  :: HipGMGNumericalSetup
+  lev :: Int      # 1-based
+  op  :: Cint     # 0 = A, 1 = P, 2 = R
+end
+function LinearAlgebra.mul!(y::Vector{Float64}, o::HipLevelOperator, x::Vector{Float64})
+  GC.@preserve x y begin
+    check(o.ns.handle, ccall((:gmg_op_apply, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Ptr{Float64},Ptr{Float64},Cint),
+                             o.ns.handle, o.lev-1, o.op, x, y, GMG_MEM_HOST))
+  end
+  return y
+end
+
+# ---------------------------------------------------------------------------------
+# Outer Krylov solvers that keep the whole iteration on the device
+# ---------------------------------------------------------------------------------
+struct HipCGSolver{A} <: Gridap.Algebra.LinearSolver
+  Pl       :: A
+  log      :: ConvergenceLog{Float64}
+  flexible :: Bool
+end
+function HipCGSolver(Pl::HipGMGLinearSolver; maxiter=1000, atol=1e-12, rtol=1.e-6, flexible=false, verbose=0, name="CG-MI355X")
+  tols = SolverTolerances{Float64}(;maxiter=maxiter,atol=atol,rtol=rtol)     # CGSolvers.jl:19-23
+  return HipCGSolver(Pl, ConvergenceLog(name,tols;verbose=verbose), flexible)
+end
+
+struct HipFGMRESSolver{A} <: Gridap.Algebra.LinearSolver
+  m       :: Int
+  restart :: Bool
+  m_add   :: Int
+  Pr      :: A
+  log     :: ConvergenceLog{Float64}
+end
+function HipFGMRESSolver(m, Pr::HipGMGLinearSolver; restart=false, m_add=1, maxiter=100, atol=1e-12, rtol=1.e-6, verbose=false, name="FGMRES-MI355X")
+  tols = SolverTolerances{Float64}(maxiter=maxiter,atol=atol,rtol=rtol)      # FGMRESSolvers.jl:26-30
+  return HipFGMRESSolver(m, restart, m_add, Pr, ConvergenceLog(name,tols,verbose=verbose))
+end
+
+struct HipKrylovSymbolicSetup{A} <: Gridap.Algebra.SymbolicSetup
+  solver :: A
+end
+Gridap.Algebra.symbolic_setup(s::Union{HipCGSolver,HipFGMRESSolver}, ::AbstractMatrix) = HipKrylovSymbolicSetup(s)
+
+mutable struct HipKrylovNumericalSetup{A,B} <: Gridap.Algebra.NumericalSetup
+  solver :: A
+  P_ns   :: B
+end
+function Gridap.Algebra.numerical_setup(ss::HipKrylovSymbolicSetup, A::AbstractMatrix)
+  P = ss.solver isa HipCGSolver ? ss.solver.Pl : ss.solver.Pr
+  P_ns = numerical_setup(symbolic_setup(P,A),A)                              # CGSolvers.jl:52
+  return HipKrylovNumericalSetup(ss.solver, P_ns)
+end
+function Gridap.Algebra.numerical_setup!(ns::HipKrylovNumericalSetup, A::AbstractMatrix)
+  numerical_setup!(ns.P_ns, A)
+  return ns
+end
+
+function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<:HipCGSolver}, b::Vector{Float64})
+  s, h = ns.solver, ns.P_ns.handle
+  tols = s.log.tols
+  res  = Ref(GmgResult(0,0,0.0,0.0))
+  hist = zeros(tols.maxiter+1)
+  GC.@preserve x b hist begin
+    check(h, ccall((:gmg_cg_solve, libgmgamd), Cint,
+      (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Cint,Float64,Float64,Cint,Cint,Ref{GmgResult},Ptr{Float64},Cint),
+      h, b, x, GMG_MEM_HOST, tols.maxiter, tols.atol, tols.rtol, s.flexible ? 1 : 0, 1, res, hist, length(hist)))
+  end
+  _fill_log!(s.log, res[], hist)
+  return x
+end
+
+function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<:HipFGMRESSolver}, b::Vector{Float64})
+  s, h = ns.solver, ns.P_ns.handle
+  tols = s.log.tols
+  res  = Ref(GmgResult(0,0,0.0,0.0))
+  hist = zeros(tols.maxiter+1)
+  GC.@preserve x b hist begin
+    check(h, ccall((:gmg_fgmres_solve, libgmgamd), Cint,
+      (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Cint,Cint,Cint,Cint,Float64,Float64,Cint,Ref{GmgResult},Ptr{Float64},Cint),
+      h, b, x, GMG_MEM_HOST, s.m, s.restart ? 1 : 0, s.m_add, tols.maxiter, tols.atol, tols.rtol, 1, res, hist, length(hist)))
+  end
+  _fill_log!(s.log, res[], hist)
+  return x
+end
+
+end # module
