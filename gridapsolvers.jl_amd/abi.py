@@ -55,11 +55,23 @@ SYMBOLS = {
     "gmg_precond_apply": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
     "gmg_coarse_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
     "gmg_dot": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)],
+    "gmg_comm_unique_id": [C.c_char_p, C.c_char_p],
+    "gmg_comm_init_rccl": [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int],
+    "gmg_comm_selftest": [C.c_void_p, C.POINTER(C.c_double)],
+    "gmg_comm_init_host": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "gmg_set_partition": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_void_p],
+    "gmg_set_coarse_global": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                              C.c_int, C.c_void_p, C.c_int64],
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
     "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],
     "gmg_model_bytes": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gmg_device_bytes": [C.c_void_p, C.POINTER(C.c_int64)],
 }
+
+HOST_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                               C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64))
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 
 _LIB = None
 

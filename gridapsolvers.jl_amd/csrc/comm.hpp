@@ -1,0 +1,129 @@
+// comm.hpp -- inter-GPU transport of the row-partitioned hierarchy.
+//
+// The reference gets its communication from PartitionedArrays over MPI:
+//   consistent!(v)  owner -> ghost copy      (PatchSolvers.jl:231,256; inside mul!(::PVector,::PSparseMatrix,::PVector))
+//   dot / norm      sum over parts           (CGSolvers.jl:85,95,105,111)
+// Here one process drives one GPU and the two primitives are
+//   halo exchange : pack kernel -> grouped ncclSend/ncclRecv over xGMI, received straight
+//                   into the ghost segment of the vector (ghosts are ordered by owner rank)
+//   all-reduce    : ncclAllReduce(sum) of a few doubles on the handle's stream.
+// RCCL is bound with dlopen so that the library a host process already uses (e.g. the
+// librccl.so bundled with PyTorch-ROCm, or /opt/rocm/lib/librccl.so.1 for a Julia host)
+// is the one that gets loaded; the communicator is created from a caller-supplied
+// ncclUniqueId (broadcast by the host language: MPI.bcast / torch.distributed).
+//
+// A second transport ("host") stages through pinned host memory and calls back into the
+// host language (MPI in Julia, gloo in the Python tests).  It exists so that the whole
+// distributed algorithm can be run and tested where RCCL cannot (several ranks sharing
+// one GPU); it is not meant for production throughput.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace gmg {
+
+// minimal RCCL ABI (rccl.h: ncclUniqueId is 128 opaque bytes, ncclDouble = 8, ncclSum = 0)
+struct NcclUniqueId { char internal[128]; };
+typedef void *NcclComm;
+
+struct RcclApi {
+  void *dl = nullptr;
+  int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+  int (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+
+  bool load(const char *path, std::string &err)
+  {
+    if (dl) return true;
+    const char *cands[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *c : cands) {
+      if (!c || !*c) continue;
+      dl = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+      if (dl) break;
+    }
+    if (!dl) { err = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
+    auto sym = [&](const char *n) { void *p = dlsym(dl, n); if (!p) err = std::string("missing RCCL symbol ") + n; return p; };
+    GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    Send = (decltype(Send))sym("ncclSend");
+    Recv = (decltype(Recv))sym("ncclRecv");
+    GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+    AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    return GetUniqueId && CommInitRank && CommDestroy && Send && Recv && GroupStart && GroupEnd && AllReduce;
+  }
+};
+
+constexpr int kNcclDouble = 8;
+constexpr int kNcclSum = 0;
+
+enum CommKind { COMM_NONE = 0, COMM_RCCL = 1, COMM_HOST = 2 };
+
+typedef void (*HostExchangeFn)(void *ctx, int nnbr, const int32_t *nbr_rank, const double *sendbuf,
+                               const int64_t *snd_ptr, double *recvbuf, const int64_t *rcv_ptr);
+typedef void (*HostAllreduceFn)(void *ctx, double *vals, int n);
+
+struct Comm {
+  int kind = COMM_NONE;
+  int rank = 0, nranks = 1;
+  RcclApi api;
+  NcclComm comm = nullptr;
+  HostExchangeFn xfn = nullptr;
+  HostAllreduceFn rfn = nullptr;
+  void *ctx = nullptr;
+};
+
+// Per-level exchange plan (PartitionedArrays: assembly_neighbors + local indices)
+struct HaloPlan {
+  bool present = false;
+  int64_t n_own = 0, n_ghost = 0;
+  std::vector<int32_t> nbr;
+  std::vector<int64_t> snd_ptr, rcv_ptr, h_snd_idx;
+  int64_t *d_snd_idx = nullptr;
+  double *d_sendbuf = nullptr;
+  double *h_send = nullptr, *h_recv = nullptr; // pinned, host transport only
+  int64_t nsend() const { return snd_ptr.empty() ? 0 : snd_ptr.back(); }
+};
+
+// sendbuf[i] = v[idx[i]]
+__global__ void halo_pack_kernel(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ v,
+                                 double *__restrict__ sendbuf)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sendbuf[i] = v[idx[i]];
+}
+// full[gid[i]] = r[i]  (coarse-level gather into the replicated vector)
+__global__ void scatter_gid_kernel(int64_t n, const int64_t *__restrict__ gid, const double *__restrict__ r,
+                                   double *__restrict__ full)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) full[gid[i]] = r[i];
+}
+// rectangular dense GEMV: x[i] = sum_j M[i*ncols+j] r[j], one wave per row
+__global__ __launch_bounds__(256) void dense_gemv_rect_kernel(int nrows, int ncols, const double *__restrict__ M,
+                                                              const double *__restrict__ r, double *__restrict__ x)
+{
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= nrows) return;
+  const double *row = M + (size_t)wave * ncols;
+  double s = 0.0;
+  for (int j = lane; j < ncols; j += 64) s += row[j] * r[j];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) x[wave] = s;
+}
+__global__ void sqrt_inplace_kernel(double *v) { v[0] = sqrt(v[0]); }
+
+} // namespace gmg

@@ -17,6 +17,7 @@
 //                                                              SolverTolerances.jl:97-128
 #include "../../include/gmg_amd.h"
 #include "kernels.hpp"
+#include "comm.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -187,7 +188,9 @@ struct Level {
   double *dinv = nullptr;
   Smoother pre, post;
   bool post_shares_pre = true;
-  int64_t n = 0;
+  int64_t n = 0;                  // owned rows
+  int64_t nvec = 0;               // vector length = owned + ghost
+  HaloPlan halo;                  // neighbour exchange plan (multi-GPU)
   double *x = nullptr;            // correction at this level (levels > 0)
   double *rbuf[2] = {nullptr, nullptr};
   double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
@@ -273,6 +276,18 @@ struct gmg_solver {
 
   // coarse solver
   double *d_Ainv = nullptr;
+  // distributed coarse solve: replicated rhs + own rows of the global inverse
+  HostCSR h_coarse_global;
+  std::vector<int64_t> h_coarse_gid;
+  bool has_coarse_global = false;
+  int64_t n_coarse_global = 0;
+  int64_t *d_coarse_gid = nullptr;
+  double *d_coarse_full = nullptr;
+  double *h_coarse_full = nullptr;
+
+  // inter-GPU transport
+  Comm comm;
+  double *cg_x = nullptr;       // solution with ghost space (distributed runs)
 
   // reductions
   double *d_partials = nullptr;
@@ -347,6 +362,8 @@ struct gmg_solver {
       L.pre.built = L.post.built = false;
     }
     d_Ainv = d_partials = d_scalars = nullptr;
+    d_coarse_gid = nullptr; d_coarse_full = nullptr; cg_x = nullptr;
+    for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; }
     cg_w = cg_p = cg_z = cg_r = st_b = st_x = nullptr;
     fg_V.clear(); fg_Z.clear(); st_extra.clear();
     setup_done = false;
@@ -501,6 +518,7 @@ struct gmg_solver {
              const double *s_old = nullptr, double *s_new = nullptr)
   {
     Level &L = lev[l];
+    if (comm.nranks > 1) exchange(l, const_cast<double *>(s_old ? s_old : r_old));
     const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();
     if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
     if (variant == 0) {
@@ -535,8 +553,61 @@ struct gmg_solver {
     const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, n, a, b, d_partials, aligned ? 1 : 0);
     HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, stream, nb, d_partials, d_scalars + slot, take_sqrt ? 1 : 0);
+    finish_reduction(nb, slot, take_sqrt);
+  }
+  // partials -> d_scalars[slot] = (sqrt of) the GLOBAL sum.  Single GPU: one kernel.  Several
+  // ranks: local sum, all-reduce over the parts (the reduction PartitionedArrays performs
+  // inside dot/norm on a PVector), then the square root.
+  void finish_reduction(int nb, int slot, bool take_sqrt)
+  {
+    const bool dist = comm.nranks > 1;
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, stream, nb, d_partials, d_scalars + slot,
+                       (take_sqrt && !dist) ? 1 : 0);
     HIP_CHECK(hipGetLastError());
+    if (!dist) return;
+    if (comm.kind == COMM_RCCL) {
+      const int rc = comm.api.AllReduce(d_scalars + slot, d_scalars + slot, 1, kNcclDouble, kNcclSum, comm.comm, stream);
+      REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclAllReduce: ") + comm.api.GetErrorString(rc));
+      if (take_sqrt) {
+        hipLaunchKernelGGL(sqrt_inplace_kernel, dim3(1), dim3(1), 0, stream, d_scalars + slot);
+        HIP_CHECK(hipGetLastError());
+      }
+    } else {
+      HIP_CHECK(hipMemcpyAsync(h_scalars + slot, d_scalars + slot, sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      double v = h_scalars[slot];
+      comm.rfn(comm.ctx, &v, 1);
+      h_scalars[slot] = take_sqrt ? std::sqrt(v) : v;
+      HIP_CHECK(hipMemcpyAsync(d_scalars + slot, h_scalars + slot, sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+  }
+  // consistent!(v): owner -> ghost copy of the level-l vector `v` (length nvec)
+  void exchange(int l, double *v)
+  {
+    HaloPlan &H = lev[l].halo;
+    if (comm.nranks <= 1 || !H.present || H.nbr.empty()) return;
+    const int64_t ns = H.nsend();
+    if (ns > 0) {
+      hipLaunchKernelGGL(halo_pack_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ns, H.d_snd_idx, v, H.d_sendbuf);
+      HIP_CHECK(hipGetLastError());
+    }
+    double *ghost = v + H.n_own;
+    if (comm.kind == COMM_RCCL) {
+      int rc = comm.api.GroupStart();
+      for (size_t k = 0; k < H.nbr.size() && rc == 0; ++k) {
+        const int64_t sc = H.snd_ptr[k + 1] - H.snd_ptr[k], rcn = H.rcv_ptr[k + 1] - H.rcv_ptr[k];
+        if (sc > 0) rc = comm.api.Send(H.d_sendbuf + H.snd_ptr[k], (size_t)sc, kNcclDouble, H.nbr[k], comm.comm, stream);
+        if (rc == 0 && rcn > 0) rc = comm.api.Recv(ghost + H.rcv_ptr[k], (size_t)rcn, kNcclDouble, H.nbr[k], comm.comm, stream);
+      }
+      const int rc2 = comm.api.GroupEnd();
+      REQUIRE(rc == 0 && rc2 == 0, GMG_ERR_COMM, std::string("RCCL halo exchange: ") + comm.api.GetErrorString(rc ? rc : rc2));
+    } else {
+      if (ns > 0) HIP_CHECK(hipMemcpyAsync(H.h_send, H.d_sendbuf, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      comm.xfn(comm.ctx, (int)H.nbr.size(), H.nbr.data(), H.h_send, H.snd_ptr.data(), H.h_recv, H.rcv_ptr.data());
+      if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(ghost, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, stream));
+    }
   }
   double fetch_scalar(int slot)
   {
@@ -602,6 +673,7 @@ struct gmg_solver {
     if (x_zero) zero(x, n);
     for (int it = 0; it < S.niter; ++it) {
       patch_precond(L, S, r, S.omega, true, L.dx, x);      // :91-93
+      exchange(l, L.dx);
       spmv_sub(L.A, L.dx, r);                              // :94-95
     }
     return r;
@@ -611,6 +683,32 @@ struct gmg_solver {
   {
     const int n = (int)lev[nlev - 1].n;
     const int waves_per_block = kBlock / 64;
+    if (comm.nranks > 1) {
+      // replicate the coarse rhs (sum of disjoint contributions), then apply this rank's rows
+      // of the global inverse.  Reference analogue: the coarsest level lives on one (sub)communicator,
+      // GridTransferOperators.jl:447-532.
+      const int ng = (int)n_coarse_global;
+      zero(d_coarse_full, ng);
+      if (n > 0) {
+        hipLaunchKernelGGL(scatter_gid_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (int64_t)n, d_coarse_gid, r, d_coarse_full);
+        HIP_CHECK(hipGetLastError());
+      }
+      if (comm.kind == COMM_RCCL) {
+        const int rc = comm.api.AllReduce(d_coarse_full, d_coarse_full, (size_t)ng, kNcclDouble, kNcclSum, comm.comm, stream);
+        REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclAllReduce(coarse): ") + comm.api.GetErrorString(rc));
+      } else {
+        HIP_CHECK(hipMemcpyAsync(h_coarse_full, d_coarse_full, sizeof(double) * (size_t)ng, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        comm.rfn(comm.ctx, h_coarse_full, ng);
+        HIP_CHECK(hipMemcpyAsync(d_coarse_full, h_coarse_full, sizeof(double) * (size_t)ng, hipMemcpyHostToDevice, stream));
+      }
+      if (n > 0) {
+        const int grid = (n + waves_per_block - 1) / waves_per_block;
+        hipLaunchKernelGGL(dense_gemv_rect_kernel, dim3(grid), dim3(kBlock), 0, stream, n, ng, d_Ainv, d_coarse_full, x);
+        HIP_CHECK(hipGetLastError());
+      }
+      return;
+    }
     const int grid = (n + waves_per_block - 1) / waves_per_block;
     hipLaunchKernelGGL(dense_gemv_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, stream, n, d_Ainv, r, x);
     HIP_CHECK(hipGetLastError());
@@ -629,11 +727,14 @@ struct gmg_solver {
     const int passes = (ctype == GMG_V_CYCLE) ? 1 : 2;
     for (int pass = 0; pass < passes; ++pass) {
       if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
+      exchange(l, r);
       spmv_set(L.R, r, C.rbuf[0]);                         // :484 rH = R rh
       // :487 fill!(dxH,0) is implicit: the first sweep below / the coarse solve write dxH
       const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
       cycle(l + 1, C.x, C.rbuf[0], true, child);           // :488
+      exchange(l + 1, C.x);
       spmv_addto(L.P, C.x, L.dx, x);                       // :491,494 dxh = P dxH ; xh += dxh
+      exchange(l, L.dx);
       spmv_sub(L.A, L.dx, r);                              // :495-496 rh -= Ah dxh
     }
     r = smooth(l, L.post, x, r, false);                    // :499
@@ -653,6 +754,7 @@ struct gmg_solver {
       x_zero = true;  // fill!(x,0) folded into the first sweep
       r_in = b;       // copy!(rh,b) folded: the first sweep reads b, writes rh
     } else {                                               // :621-625
+      exchange(0, x);                                      // callers pass x with ghost space when distributed
       spmv_resid(L0.A, x, b, L0.rbuf[0]);
       r_in = L0.rbuf[0];
       x_zero = false;
@@ -875,7 +977,8 @@ struct BandLU {
 
 void gmg_solver::build_coarse()
 {
-  const HostCSR &A = lev[nlev - 1].hA;
+  const bool dist = comm.nranks > 1;
+  const HostCSR &A = dist ? h_coarse_global : lev[nlev - 1].hA;
   const int n = (int)A.nrows;
   REQUIRE((double)n * n * 8.0 < 64e9, GMG_ERR_UNSUPPORTED, "coarsest level too large for a dense inverse; add levels");
   BandLU lu;
@@ -896,7 +999,23 @@ void gmg_solver::build_coarse()
   for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
   work(0);
   for (auto &t : th) t.join();
-  d_Ainv = upload(inv);
+  if (!dist) d_Ainv = upload(inv);
+  else {
+    // keep this rank's rows of the global inverse (n_own x n_global, row-major)
+    const int64_t nown = lev[nlev - 1].n;
+    REQUIRE((int64_t)h_coarse_gid.size() == nown, GMG_ERR_INVALID, "own_global_ids length != coarse n_own");
+    std::vector<double> rows((size_t)std::max<int64_t>(nown, 1) * n);
+    for (int64_t i = 0; i < nown; ++i) {
+      const int64_t g = h_coarse_gid[i];
+      REQUIRE(g >= 0 && g < n, GMG_ERR_INVALID, "coarse global id out of range");
+      std::memcpy(&rows[(size_t)i * n], &inv[(size_t)g * n], sizeof(double) * (size_t)n);
+    }
+    d_Ainv = upload(rows);
+    d_coarse_gid = upload(h_coarse_gid);
+    d_coarse_full = dvec(n);
+    n_coarse_global = n;
+    if (comm.kind == COMM_HOST && !h_coarse_full) HIP_CHECK(hipHostMalloc((void **)&h_coarse_full, sizeof(double) * (size_t)n));
+  }
   HIP_CHECK(hipStreamSynchronize(stream));
 }
 
@@ -914,16 +1033,33 @@ void gmg_solver::setup()
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));
-    REQUIRE(L.hA.nrows == L.hA.ncols, GMG_ERR_INVALID, "level matrix must be square");
     L.n = L.hA.nrows;
-    if (l < nlev - 1) {
-      REQUIRE(L.hasP, GMG_ERR_STATE, "gmg_set_prolongation missing for level " + std::to_string(l));
-      REQUIRE(lev[l + 1].hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l + 1));
-      REQUIRE(L.hP.nrows == L.hA.nrows && L.hP.ncols == lev[l + 1].hA.nrows, GMG_ERR_INVALID,
-              "prolongation shape does not match level sizes (GMGLinearSolvers.jl:59-61)");
-      if (L.hasR)
-        REQUIRE(L.hR.nrows == L.hP.ncols && L.hR.ncols == L.hP.nrows, GMG_ERR_INVALID, "restriction shape mismatch");
+    L.nvec = L.hA.ncols;
+    if (L.halo.present) {
+      REQUIRE(comm.nranks > 1, GMG_ERR_STATE, "gmg_set_partition needs gmg_comm_init_* first");
+      REQUIRE(L.halo.n_own == L.hA.nrows && L.halo.n_own + L.halo.n_ghost == L.hA.ncols, GMG_ERR_INVALID,
+              "local matrix must be n_own x (n_own+n_ghost) on level " + std::to_string(l));
+    } else {
+      REQUIRE(comm.nranks == 1, GMG_ERR_STATE, "gmg_set_partition missing on level " + std::to_string(l));
+      REQUIRE(L.hA.nrows == L.hA.ncols, GMG_ERR_INVALID, "level matrix must be square");
     }
+  }
+  for (int l = 0; l < nlev - 1; ++l) {
+    Level &L = lev[l];
+    REQUIRE(L.hasP, GMG_ERR_STATE, "gmg_set_prolongation missing for level " + std::to_string(l));
+    REQUIRE(L.hP.nrows == L.n && L.hP.ncols == lev[l + 1].nvec, GMG_ERR_INVALID,
+            "prolongation shape does not match level sizes (GMGLinearSolvers.jl:59-61)");
+    if (comm.nranks > 1)
+      REQUIRE(L.hasR, GMG_ERR_STATE, "distributed runs need the local rows of R (gmg_set_restriction): a local P^T misses off-rank rows");
+    if (L.hasR)
+      REQUIRE(L.hR.nrows == lev[l + 1].n && L.hR.ncols == L.nvec, GMG_ERR_INVALID, "restriction shape mismatch");
+    if (comm.nranks > 1)
+      REQUIRE(L.pre.kind == SM_JACOBI && L.post.kind == SM_JACOBI, GMG_ERR_UNSUPPORTED,
+              "patch smoothers are single-GPU in this round (need assemble! of ghost rows, PatchSolvers.jl:254)");
+  }
+  if (comm.nranks > 1) {
+    REQUIRE(has_coarse_global, GMG_ERR_STATE, "gmg_set_coarse_global missing (distributed coarse solve)");
+    variant = 2; tile = kTile;   // the one-gather sweep needs only s-ghosts
   }
   d_partials = dvec(kRedBlocks);
   d_scalars = dvec(kScalarSlots);
@@ -931,12 +1067,21 @@ void gmg_solver::setup()
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     L.A = upload_csr(L.hA);                                 // :185 gmg_compute_matrices
-    L.rbuf[0] = dvec(L.n);                                  // :187,188 rh / rH
-    if (l > 0) L.x = dvec(L.n);                             // :188 dxH
+    L.rbuf[0] = dvec(L.nvec);                               // :187,188 rh / rH
+    if (l > 0) L.x = dvec(L.nvec);                          // :188 dxH
+    if (L.halo.present) {
+      HaloPlan &H = L.halo;
+      H.d_snd_idx = upload(H.h_snd_idx);
+      H.d_sendbuf = dvec(H.nsend());
+      if (comm.kind == COMM_HOST) {
+        if (!H.h_send) HIP_CHECK(hipHostMalloc((void **)&H.h_send, sizeof(double) * (size_t)std::max<int64_t>(1, H.nsend())));
+        if (!H.h_recv) HIP_CHECK(hipHostMalloc((void **)&H.h_recv, sizeof(double) * (size_t)std::max<int64_t>(1, H.n_ghost)));
+      }
+    }
     if (l < nlev - 1) {
-      L.rbuf[1] = dvec(L.n);
-      L.dx = dvec(L.n);
-      if (one_gather()) { L.sbuf[0] = dvec(L.n); L.sbuf[1] = dvec(L.n); }                                     // :188 dxh (Adxh is fused away)
+      L.rbuf[1] = dvec(L.nvec);
+      L.dx = dvec(L.nvec);
+      if (one_gather()) { L.sbuf[0] = dvec(L.nvec); L.sbuf[1] = dvec(L.nvec); }                                     // :188 dxh (Adxh is fused away)
       L.P = upload_csr(L.hP);
       if (L.hasR) L.R = upload_csr(L.hR);
       else {
@@ -964,9 +1109,10 @@ void gmg_solver::setup()
     }
   }
   build_coarse();                                           // :195 gmg_coarse_solver_caches
-  const int64_t n0 = lev[0].n;
+  const int64_t n0 = lev[0].nvec;
   cg_w = dvec(n0); cg_p = dvec(n0); cg_z = dvec(n0); cg_r = dvec(n0);
   st_b = dvec(n0); st_x = dvec(n0);
+  if (comm.nranks > 1) cg_x = dvec(n0);
   HIP_CHECK(hipStreamSynchronize(stream));
   setup_done = true;
 }
@@ -1046,6 +1192,12 @@ int gmg_destroy(gmg_handle_t h)
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->free_all();
+  for (auto &L : h->lev) {
+    if (L.halo.h_send) (void)hipHostFree(L.halo.h_send);
+    if (L.halo.h_recv) (void)hipHostFree(L.halo.h_recv);
+  }
+  if (h->h_coarse_full) (void)hipHostFree(h->h_coarse_full);
+  if (h->comm.kind == COMM_RCCL && h->comm.comm) (void)h->comm.api.CommDestroy(h->comm.comm);
   for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
   if (h->h_scalars) (void)hipHostFree(h->h_scalars);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1058,7 +1210,7 @@ int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_
 {
   return guarded(h, [&] {
     check_level(h, lev, false);
-    REQUIRE(nrows == ncols, GMG_ERR_INVALID, "level matrix must be square");
+    REQUIRE(nrows == ncols || h->comm.nranks > 1, GMG_ERR_INVALID, "level matrix must be square");
     h->lev[lev].hA = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
     h->lev[lev].hasA = true;
     h->setup_done = false;
@@ -1171,9 +1323,10 @@ int gmg_apply(gmg_handle_t h, const double *b, double *x, int memspace, gmg_resu
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     const int64_t n = h->lev[0].n;
     const double *db = h->in_vec(b, n, memspace, h->st_b);
-    double *dx = (memspace == GMG_MEM_DEVICE) ? x : h->st_x;
-    if (memspace == GMG_MEM_HOST && h->mode == GMG_MODE_SOLVER)
-      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    const bool dist = h->comm.nranks > 1;
+    double *dx = dist ? h->cg_x : ((memspace == GMG_MEM_DEVICE) ? x : h->st_x);
+    if (h->mode == GMG_MODE_SOLVER && (memspace == GMG_MEM_HOST || dist))
+      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
     const double last = h->gmg_solve_dev(dx, db, -1.0);
     h->out_vec(x, dx, n, memspace);
     h->log.export_to(res, hist, hist_cap, last);
@@ -1192,12 +1345,15 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
     Level &L0 = S.lev[0];
     const int64_t n = L0.n;
     const double *db = S.in_vec(b, n, memspace, S.st_b);
-    double *dx = (memspace == GMG_MEM_DEVICE) ? x : S.st_x;
-    if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+    const bool dist = S.comm.nranks > 1;
+    double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
+    if (memspace == GMG_MEM_HOST || dist)
+      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
     double *w = S.cg_w, *p = S.cg_p, *z = S.cg_z, *r = S.cg_r;
     ConvLog log;
     log.configure(maxiter, atol, rtol);
 
+    S.exchange(0, dx);
     S.spmv_resid(L0.A, dx, db, r);                         // CGSolvers.jl:79  w = A x ; r = b - w
     S.zero(p, n);                                          // :80
     S.zero(z, n);                                          // :81
@@ -1219,12 +1375,12 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
       }
       hipLaunchKernelGGL(xpby_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, S.stream, n, z, beta, p); // :101
       HIP_CHECK(hipGetLastError());
+      S.exchange(0, p);
       S.spmv_set(L0.A, p, w);                              // :104
       alpha = gamma / S.dot(n, p, w);                      // :105
       hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, alpha, p, w, dx, r, S.d_partials); // :108-109
       HIP_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, S.stream, nb, S.d_partials, S.d_scalars, 1);
-      HIP_CHECK(hipGetLastError());
+      S.finish_reduction(nb, 0, true);
       resn = S.fetch_scalar(0);                            // :111
       done = log.update(resn);                             // :112
     }
@@ -1245,12 +1401,15 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
     Level &L0 = S.lev[0];
     const int64_t n = L0.n;
     const double *db = S.in_vec(b, n, memspace, S.st_b);
-    double *dx = (memspace == GMG_MEM_DEVICE) ? x : S.st_x;
-    if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, S.stream));
+    const bool dist = S.comm.nranks > 1;
+    const int64_t nv = L0.nvec;
+    double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
+    if (memspace == GMG_MEM_HOST || dist)
+      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
     // caches FGMRESSolvers.jl:58-70
     int m = std::max<int>(m0, (int)S.fg_Z.size());
-    while ((int)S.fg_V.size() < m + 1) S.fg_V.push_back(S.dvec(n));
-    while ((int)S.fg_Z.size() < m) S.fg_Z.push_back(S.dvec(n));
+    while ((int)S.fg_V.size() < m + 1) S.fg_V.push_back(S.dvec(nv));
+    while ((int)S.fg_Z.size() < m) S.fg_Z.push_back(S.dvec(nv));
     m = (int)S.fg_Z.size();
     auto &V = S.fg_V;
     auto &Z = S.fg_Z;
@@ -1265,6 +1424,7 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
     const int grid = gmg_solver::grid_for(n);
 
     // krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 ; FGMRESSolvers.jl:136-140
+    S.exchange(0, dx);
     S.spmv_resid(L0.A, dx, db, V[0]);
     double beta = S.norm(n, V[0]);                         // :141
     bool done = log.init(beta);                            // :142
@@ -1276,12 +1436,13 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
       std::fill(g.begin(), g.end(), 0.0); g[0] = beta;     // :148
       while (!done && !(restart && j > m0)) {              // :149
         if (j > m) {                                       // :151-154
-          for (int q = 0; q < m_add; ++q) { V.push_back(S.dvec(n)); Z.push_back(S.dvec(n)); }
+          for (int q = 0; q < m_add; ++q) { V.push_back(S.dvec(nv)); Z.push_back(S.dvec(nv)); }
           m += m_add;
         }
         double *Vn = V[j], *Zj = Z[j - 1];
         // krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25
         S.krylov_precond(use_precond, Zj, V[j - 1], -1.0);
+        S.exchange(0, Zj);
         S.spmv_set(L0.A, Zj, Vn);                          // :159
         for (int i = 1; i <= j; ++i) {                     // :160-163 modified Gram-Schmidt
           S.dot_async(n, Vn, V[i - 1], i, false);
@@ -1331,6 +1492,7 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
         hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, g[i - 1], Z[i - 1], dx);
         HIP_CHECK(hipGetLastError());
       }
+      S.exchange(0, dx);
       S.spmv_resid(L0.A, dx, db, V[0]);                    // :194
     }
     S.out_vec(x, dx, n, memspace);
@@ -1347,8 +1509,18 @@ int gmg_op_apply(gmg_handle_t h, int lev, int op, const double *x, double *y, in
     Level &L = h->lev[lev];
     const DevCSR *M = op == GMG_OP_A ? &L.A : op == GMG_OP_P ? &L.P : op == GMG_OP_R ? &L.R : nullptr;
     REQUIRE(M, GMG_ERR_INVALID, "unknown operator");
-    const double *dxv = h->in_vec(x, M->ncols, memspace, h->scratch_vec(0, h->lev[0].n));
-    double *dy = memspace == GMG_MEM_DEVICE ? y : h->scratch_vec(1, h->lev[0].n);
+    const int src = (op == GMG_OP_P) ? lev + 1 : lev;     // level the gathered vector lives on
+    const double *dxv;
+    if (h->comm.nranks > 1) {
+      double *sx = h->scratch_vec(0, h->lev[0].nvec);
+      HIP_CHECK(hipMemcpyAsync(sx, x, sizeof(double) * (size_t)h->lev[src].n,
+                               memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
+      h->exchange(src, sx);
+      dxv = sx;
+    } else {
+      dxv = h->in_vec(x, M->ncols, memspace, h->scratch_vec(0, h->lev[0].nvec));
+    }
+    double *dy = memspace == GMG_MEM_DEVICE ? y : h->scratch_vec(1, h->lev[0].nvec);
     h->spmv_set(*M, dxv, dy);
     h->out_vec(y, dy, M->nrows, memspace);
   });
@@ -1362,9 +1534,9 @@ int gmg_smooth(gmg_handle_t h, int lev, int which, double *x, double *r, int mem
     REQUIRE(x && r, GMG_ERR_INVALID, "null vector");
     REQUIRE(which == GMG_PRE || which == GMG_POST, GMG_ERR_INVALID, "which must be GMG_PRE or GMG_POST");
     Level &L = h->lev[lev];
-    double *dx = memspace == GMG_MEM_DEVICE ? x : h->scratch_vec(0, h->lev[0].n);
+    double *dx = memspace == GMG_MEM_DEVICE ? x : h->scratch_vec(0, h->lev[0].nvec);
     if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)L.n, hipMemcpyHostToDevice, h->stream));
-    const double *dr = h->in_vec(r, L.n, memspace, h->scratch_vec(1, h->lev[0].n));
+    const double *dr = h->in_vec(r, L.n, memspace, h->scratch_vec(1, h->lev[0].nvec));
     double *rout = h->smooth(lev, which == GMG_PRE ? L.pre : L.post, dx, dr, false);
     h->out_vec(r, rout, L.n, memspace);
     h->out_vec(x, dx, L.n, memspace);
@@ -1379,8 +1551,8 @@ int gmg_precond_apply(gmg_handle_t h, int lev, int which, const double *r, doubl
     REQUIRE(r && dx, GMG_ERR_INVALID, "null vector");
     Level &L = h->lev[lev];
     Smoother &S = which == GMG_POST ? L.post : L.pre;
-    const double *dr = h->in_vec(r, L.n, memspace, h->scratch_vec(1, h->lev[0].n));
-    double *out = memspace == GMG_MEM_DEVICE ? dx : h->scratch_vec(0, h->lev[0].n);
+    const double *dr = h->in_vec(r, L.n, memspace, h->scratch_vec(1, h->lev[0].nvec));
+    double *out = memspace == GMG_MEM_DEVICE ? dx : h->scratch_vec(0, h->lev[0].nvec);
     if (S.kind == SM_JACOBI) {
       hipLaunchKernelGGL(jacobi_apply_kernel, dim3(gmg_solver::grid_for(L.n)), dim3(256), 0, h->stream, L.n, L.dinv, dr, out);
       HIP_CHECK(hipGetLastError());
@@ -1397,8 +1569,8 @@ int gmg_coarse_solve(gmg_handle_t h, const double *r, double *x, int memspace)
     check_ready(h);
     REQUIRE(r && x, GMG_ERR_INVALID, "null vector");
     const int64_t n = h->lev[h->nlev - 1].n;
-    const double *dr = h->in_vec(r, n, memspace, h->scratch_vec(1, h->lev[0].n));
-    double *out = memspace == GMG_MEM_DEVICE ? x : h->scratch_vec(0, h->lev[0].n);
+    const double *dr = h->in_vec(r, n, memspace, h->scratch_vec(1, h->lev[0].nvec));
+    double *out = memspace == GMG_MEM_DEVICE ? x : h->scratch_vec(0, h->lev[0].nvec);
     h->coarse_solve(dr, out);
     h->out_vec(x, out, n, memspace);
   });
@@ -1410,9 +1582,120 @@ int gmg_dot(gmg_handle_t h, int64_t n, const double *a, const double *b, int mem
     check_ready(h);
     REQUIRE(a && b && out && n >= 0, GMG_ERR_INVALID, "bad arguments");
     if (memspace == GMG_MEM_HOST) REQUIRE(n <= h->lev[0].n, GMG_ERR_INVALID, "host vectors longer than the finest level");
-    const double *da = h->in_vec(a, n, memspace, h->scratch_vec(0, h->lev[0].n));
-    const double *db = (a == b) ? da : h->in_vec(b, n, memspace, h->scratch_vec(1, h->lev[0].n));
+    const double *da = h->in_vec(a, n, memspace, h->scratch_vec(0, h->lev[0].nvec));
+    const double *db = (a == b) ? da : h->in_vec(b, n, memspace, h->scratch_vec(1, h->lev[0].nvec));
     *out = h->dot(n, da, db);
+  });
+}
+
+// ---- multi-GPU ------------------------------------------------------------------
+int gmg_comm_unique_id(const char *rccl_path, char *id_out128)
+{
+  return guarded(nullptr, [&] {
+    REQUIRE(id_out128, GMG_ERR_INVALID, "null id buffer");
+    RcclApi api;
+    std::string err;
+    REQUIRE(api.load(rccl_path, err), GMG_ERR_COMM, err);
+    NcclUniqueId id;
+    const int rc = api.GetUniqueId(&id);
+    REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclGetUniqueId: ") + api.GetErrorString(rc));
+    std::memcpy(id_out128, id.internal, 128);
+  });
+}
+
+int gmg_comm_init_rccl(gmg_handle_t h, const char *rccl_path, const char *unique_id128, int rank, int nranks)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && unique_id128, GMG_ERR_INVALID, "null argument");
+    REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, GMG_ERR_INVALID, "bad rank / nranks");
+    REQUIRE(h->comm.kind == COMM_NONE, GMG_ERR_STATE, "communicator already initialised");
+    std::string err;
+    REQUIRE(h->comm.api.load(rccl_path, err), GMG_ERR_COMM, err);
+    NcclUniqueId id;
+    std::memcpy(id.internal, unique_id128, 128);
+    const int rc = h->comm.api.CommInitRank(&h->comm.comm, nranks, id, rank);
+    REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclCommInitRank: ") + h->comm.api.GetErrorString(rc));
+    h->comm.kind = COMM_RCCL; h->comm.rank = rank; h->comm.nranks = nranks;
+    h->setup_done = false;
+  });
+}
+
+// Diagnostic: one all-reduce and one grouped self send/recv through the RCCL binding
+// (valid on a 1-rank communicator) -- proves the dlopen'ed signatures and enum values.
+int gmg_comm_selftest(gmg_handle_t h, double *out2)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && out2, GMG_ERR_INVALID, "null argument");
+    REQUIRE(h->comm.kind == COMM_RCCL, GMG_ERR_STATE, "RCCL communicator not initialised");
+    double *d = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d, 4 * sizeof(double)));
+    const double init[4] = {1.5, 42.0, 0.0, 0.0};
+    HIP_CHECK(hipMemcpy(d, init, sizeof(init), hipMemcpyHostToDevice));
+    int rc = h->comm.api.AllReduce(d, d, 1, kNcclDouble, kNcclSum, h->comm.comm, h->stream);
+    REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclAllReduce: ") + h->comm.api.GetErrorString(rc));
+    rc = h->comm.api.GroupStart();
+    if (rc == 0) rc = h->comm.api.Send(d + 1, 1, kNcclDouble, h->comm.rank, h->comm.comm, h->stream);
+    if (rc == 0) rc = h->comm.api.Recv(d + 2, 1, kNcclDouble, h->comm.rank, h->comm.comm, h->stream);
+    const int rc2 = h->comm.api.GroupEnd();
+    REQUIRE(rc == 0 && rc2 == 0, GMG_ERR_COMM, std::string("self send/recv: ") + h->comm.api.GetErrorString(rc ? rc : rc2));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    double back[4];
+    HIP_CHECK(hipMemcpy(back, d, sizeof(back), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    out2[0] = back[0];   // = nranks * 1.5
+    out2[1] = back[2];   // = 42.0
+  });
+}
+
+int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_fn xfn, gmg_host_allreduce_fn rfn, void *ctx)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && xfn && rfn, GMG_ERR_INVALID, "null argument");
+    REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, GMG_ERR_INVALID, "bad rank / nranks");
+    REQUIRE(h->comm.kind == COMM_NONE, GMG_ERR_STATE, "communicator already initialised");
+    h->comm.kind = COMM_HOST; h->comm.rank = rank; h->comm.nranks = nranks;
+    h->comm.xfn = xfn; h->comm.rfn = rfn; h->comm.ctx = ctx;
+    h->setup_done = false;
+  });
+}
+
+int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
+                      const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, false);
+    REQUIRE(n_own >= 0 && n_ghost >= 0 && nnbr >= 0, GMG_ERR_INVALID, "negative sizes");
+    REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
+    HaloPlan &H = h->lev[lev].halo;
+    H = HaloPlan();
+    H.present = true; H.n_own = n_own; H.n_ghost = n_ghost;
+    H.nbr.assign(nbr_rank, nbr_rank + nnbr);
+    H.snd_ptr.assign(1, 0); H.rcv_ptr.assign(1, 0);
+    if (nnbr > 0) { H.snd_ptr.assign(snd_ptr, snd_ptr + nnbr + 1); H.rcv_ptr.assign(rcv_ptr, rcv_ptr + nnbr + 1); }
+    REQUIRE(H.snd_ptr[0] == 0 && H.rcv_ptr[0] == 0, GMG_ERR_INVALID, "snd_ptr / rcv_ptr must start at 0");
+    for (int k = 0; k < nnbr; ++k) {
+      REQUIRE(H.snd_ptr[k] <= H.snd_ptr[k + 1] && H.rcv_ptr[k] <= H.rcv_ptr[k + 1], GMG_ERR_INVALID, "pointers not monotone");
+      REQUIRE(nbr_rank[k] >= 0 && nbr_rank[k] < h->comm.nranks && nbr_rank[k] != h->comm.rank, GMG_ERR_INVALID, "bad neighbour rank");
+    }
+    REQUIRE(H.rcv_ptr.back() == n_ghost, GMG_ERR_INVALID, "rcv_ptr must cover exactly the ghost segment");
+    const int64_t ns = H.snd_ptr.back();
+    REQUIRE(ns == 0 || snd_idx, GMG_ERR_INVALID, "null snd_idx");
+    H.h_snd_idx.assign(snd_idx, snd_idx + ns);
+    for (int64_t i = 0; i < ns; ++i) REQUIRE(snd_idx[i] >= 0 && snd_idx[i] < n_own, GMG_ERR_INVALID, "snd_idx must address owned entries");
+    h->setup_done = false;
+  });
+}
+
+int gmg_set_coarse_global(gmg_handle_t h, int64_t n_global, int64_t nnz, const void *ptr, const void *idx, const double *val,
+                          int layout, int index_base, int index_bytes, const int64_t *own_global_ids, int64_t n_own)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    REQUIRE(n_own == 0 || own_global_ids, GMG_ERR_INVALID, "null own_global_ids");
+    h->h_coarse_global = convert_input(n_global, n_global, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    h->h_coarse_gid.assign(own_global_ids, own_global_ids + n_own);
+    h->has_coarse_global = true;
+    h->setup_done = false;
   });
 }
 

@@ -1,0 +1,255 @@
+"""Box row-partition of the structured Poisson hierarchy (multi-GPU).
+
+Mirrors what PartitionedArrays / GridapDistributed give the reference: per rank and
+per level a local matrix whose rows are the OWNED dofs and whose columns are numbered
+own-first-then-ghost (`own_values`/`partition` convention, JacobiLinearSolvers.jl:29-56),
+plus the neighbour lists a `consistent!` (owner -> ghost copy, PatchSolvers.jl:231) needs.
+
+Ranks form a px x py x pz grid; rank r owns the nodes  c0 < i <= c1  of its cell box in
+every direction, on every level (coarse node I coincides with fine node 2I, so ownership
+nests and restriction / prolongation need only the one-layer halo of the 27-point
+operator).  Ghosts are ordered by (owner rank, global lexicographic id); send lists are
+sorted by global id, so both sides of an exchange agree without negotiation.
+
+Host-side numpy only; nothing here is on the timed path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import poisson as po
+
+__all__ = ["rank_grid", "LocalLevel", "build_local_hierarchy", "global_cells"]
+
+
+def rank_grid(nranks, dim=3):
+    """1x1x1, 2x1x1, 2x2x1, 2x2x2 for 1/2/4/8 GPUs; generic power-of-two otherwise."""
+    g = [1, 1, 1]
+    k = 0
+    n = int(nranks)
+    if n < 1 or (n & (n - 1)):
+        raise ValueError("number of ranks must be a power of two")
+    while n > 1:
+        g[k % dim] *= 2
+        n //= 2
+        k += 1
+    return tuple(g)
+
+
+def global_cells(cells_per_rank, grid):
+    return tuple(int(c) * int(g) for c, g in zip(cells_per_rank, grid))
+
+
+def _coords(rank, grid):
+    px, py, pz = grid
+    return rank % px, (rank // px) % py, rank // (px * py)
+
+
+def _rank_of(cx, cy, cz, grid):
+    return cx + grid[0] * (cy + grid[1] * cz)
+
+
+class LocalLevel:
+    """One level on one rank: local operators in [own | ghost] column numbering + exchange plan."""
+
+    def __init__(self):
+        self.A = self.P = self.R = None
+        self.n_own = self.n_ghost = 0
+        self.nbr_rank = np.zeros(0, np.int32)
+        self.snd_ptr = np.zeros(1, np.int64)
+        self.snd_idx = np.zeros(0, np.int64)
+        self.rcv_ptr = np.zeros(1, np.int64)
+        self.own_gid = None      # global lexicographic free-dof id of every owned dof
+        self.ghost_gid = None
+
+
+def _axis_ranges(ncell_global, order, nparts, coord):
+    """Owned node range (lo, hi] -> free nodes lo+1..hi (clipped), and the extended range."""
+    per = ncell_global // nparts
+    c0, c1 = coord * per, (coord + 1) * per
+    nlast = order * ncell_global - 1                  # last free node
+    lo, hi = order * c0 + 1, min(order * c1, nlast)   # owned free nodes lo..hi inclusive
+    elo, ehi = max(lo - 1, 1), min(hi + 1, nlast)     # one-layer halo of the 27-pt operator
+    # for order 2 the operator couples nodes up to distance 2 inside a cell
+    if order == 2:
+        elo, ehi = max(lo - 2, 1), min(hi + 2, nlast)
+    return lo, hi, elo, ehi
+
+
+def _axis_tables_local(ncell_global, order, lo, hi, elo, ehi, active):
+    """1-D padded row tables for owned rows lo..hi with columns in extended-box numbering."""
+    if not active:
+        return 1, np.zeros((1, 1), dtype=np.int64), np.zeros((1, 1)), np.ones((1, 1))
+    K, M, S = po._assemble_1d(ncell_global, order)
+    nn = order * ncell_global + 1
+    col_map = -np.ones(nn, dtype=np.int64)
+    col_map[elo:ehi + 1] = np.arange(ehi - elo + 1)
+    rows = np.arange(lo, hi + 1)
+    cols, (kv, mv) = po._padded_rows(S, [K, M], rows, col_map)
+    return ehi - elo + 1, cols, kv, mv
+
+
+def _interp_tables_local(nc_coarse_global, order, flo, fhi, celo, cehi, active):
+    """1-D prolongation rows for fine owned nodes flo..fhi, columns = coarse extended numbering."""
+    if not active:
+        return 1, np.zeros((1, 1), dtype=np.int64), np.ones((1, 1))
+    P, S = po._interp_1d(nc_coarse_global, order)
+    nH = P.shape[1]
+    col_map = -np.ones(nH, dtype=np.int64)
+    col_map[celo:cehi + 1] = np.arange(cehi - celo + 1)
+    col_map[0] = -1
+    col_map[nH - 1] = -1
+    c, (v,) = po._padded_rows(S, [P], np.arange(flo, fhi + 1), col_map)
+    return cehi - celo + 1, c, v
+
+
+def _restr_tables_local(nc_coarse_global, order, clo, chi, felo, fehi, active):
+    """1-D restriction (= interpolation transposed) rows for coarse owned nodes, fine extended columns."""
+    if not active:
+        return 1, np.zeros((1, 1), dtype=np.int64), np.ones((1, 1))
+    P, S = po._interp_1d(nc_coarse_global, order)
+    R, SR = P.T.copy(), S.T.copy()
+    nh = P.shape[0]
+    col_map = -np.ones(nh, dtype=np.int64)
+    col_map[felo:fehi + 1] = np.arange(fehi - felo + 1)
+    col_map[0] = -1
+    col_map[nh - 1] = -1
+    c, (v,) = po._padded_rows(SR, [R], np.arange(clo, chi + 1), col_map)
+    return fehi - felo + 1, c, v
+
+
+class _LevelGeom:
+    """Index bookkeeping of one level on one rank."""
+
+    def __init__(self, cells_global, order, grid, rank, d):
+        self.cells, self.order, self.grid, self.rank, self.d = cells_global, order, grid, rank, d
+        co = _coords(rank, grid)
+        self.rng = []
+        for k in range(3):
+            if k < d:
+                self.rng.append(_axis_ranges(cells_global[k], order, grid[k], co[k]))
+            else:
+                self.rng.append((0, 0, 0, 0))
+        self.nfree = [order * cells_global[k] - 1 if k < d else 1 for k in range(3)]
+        own = [r[1] - r[0] + 1 for r in self.rng]
+        ext = [r[3] - r[2] + 1 for r in self.rng]
+        self.own_shape, self.ext_shape = own, ext
+        # global node coordinates of the extended box (z,y,x order arrays)
+        ex = [np.arange(r[2], r[3] + 1) for r in self.rng]
+        Z, Y, X = np.meshgrid(ex[2], ex[1], ex[0], indexing="ij")
+        is_own = ((X >= self.rng[0][0]) & (X <= self.rng[0][1]) & (Y >= self.rng[1][0]) & (Y <= self.rng[1][1])
+                  & (Z >= self.rng[2][0]) & (Z <= self.rng[2][1]))
+        # owner rank of every extended node
+        def owner_1d(i, k):
+            if k >= d:
+                return np.zeros_like(i)
+            per = order * (cells_global[k] // grid[k])
+            return np.minimum((i - 1) // per, grid[k] - 1)
+        owner = _rank_of(owner_1d(X, 0), owner_1d(Y, 1), owner_1d(Z, 2), grid)
+        off = [1 if k < d else 0 for k in range(3)]
+        gid = (X - off[0]) + self.nfree[0] * ((Y - off[1]) + self.nfree[1] * (Z - off[2]))
+        self.is_own = is_own.reshape(-1)
+        self.owner = owner.reshape(-1).astype(np.int64)
+        self.gid = gid.reshape(-1).astype(np.int64)
+        n_ext = self.is_own.size
+        own_ext = np.nonzero(self.is_own)[0]                       # lexicographic inside the box
+        gh_ext = np.nonzero(~self.is_own)[0]
+        order_g = np.lexsort((self.gid[gh_ext], self.owner[gh_ext]))   # by owner, then global id
+        gh_ext = gh_ext[order_g]
+        self.n_own, self.n_ghost = own_ext.size, gh_ext.size
+        self.ext2loc = np.empty(n_ext, dtype=np.int64)
+        self.ext2loc[own_ext] = np.arange(self.n_own)
+        self.ext2loc[gh_ext] = self.n_own + np.arange(self.n_ghost)
+        self.own_gid = self.gid[own_ext]
+        self.ghost_gid = self.gid[gh_ext]
+        self.ghost_owner = self.owner[gh_ext]
+
+    def remap(self, M):
+        """Columns from extended-box numbering to [own | ghost]."""
+        return po.CSR((M.shape[0], self.n_own + self.n_ghost), M.ptr, self.ext2loc[M.idx], M.val)
+
+
+def _exchange_plan(me):
+    """snd/rcv lists of one rank on one level, computed analytically: what I send to rank q is
+    the part of my owned box inside q's extended box, enumerated lexicographically (= ascending
+    global id, the order in which q stores its ghosts owned by me)."""
+    grid, d = me.grid, me.d
+    co = _coords(me.rank, grid)
+    nb = []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx == dy == dz == 0:
+                    continue
+                q = (co[0] + dx, co[1] + dy, co[2] + dz)
+                if all(0 <= q[k] < grid[k] for k in range(3)):
+                    nb.append(_rank_of(*q, grid))
+    nb = sorted(set(nb))
+    snd_ptr, rcv_ptr, snd_idx, nbr = [0], [0], [], []
+    for q in nb:
+        qc = _coords(q, grid)
+        sub = []
+        for k in range(3):
+            if k >= d:
+                sub.append(np.zeros(1, dtype=np.int64)); continue
+            _, _, qelo, qehi = _axis_ranges(me.cells[k], me.order, grid[k], qc[k])
+            lo, hi = me.rng[k][0], me.rng[k][1]
+            a, b = max(lo, qelo), min(hi, qehi)
+            sub.append(np.arange(a, b + 1, dtype=np.int64) - lo if b >= a else np.zeros(0, dtype=np.int64))
+        ox, oy = me.own_shape[0], me.own_shape[1]
+        s = (sub[2][:, None, None] * (oy * ox) + sub[1][None, :, None] * ox + sub[0][None, None, :]).reshape(-1)
+        nrecv = int(np.count_nonzero(me.ghost_owner == q))
+        if s.size == 0 and nrecv == 0:
+            continue
+        nbr.append(q)
+        snd_idx.append(s)
+        snd_ptr.append(snd_ptr[-1] + s.size)
+        rcv_ptr.append(rcv_ptr[-1] + nrecv)
+    assert rcv_ptr[-1] == me.n_ghost, "every ghost must be received from exactly one neighbour"
+    return (np.asarray(nbr, dtype=np.int32), np.asarray(snd_ptr, dtype=np.int64),
+            np.concatenate(snd_idx).astype(np.int64) if snd_idx else np.zeros(0, np.int64),
+            np.asarray(rcv_ptr, dtype=np.int64))
+
+
+def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1):
+    """Local operators of `rank` for every level.  Returns dict(levels=[LocalLevel...],
+    coarse_global=CSR (global coarsest matrix), cells=[...], grid=grid)."""
+    nc = tuple(int(c) for c in cells_global_fine)
+    d = len(nc)
+    nc3 = nc + (1,) * (3 - d)
+    grid = tuple(grid) + (1,) * (3 - len(grid))
+    nranks = int(np.prod(grid))
+    cells = [tuple(c // (2 ** l) for c in nc3[:d]) + (1,) * (3 - d) for l in range(nlevels)]
+    for l in range(nlevels):
+        for k in range(d):
+            if cells[l][k] * 2 ** l != nc3[k] or cells[l][k] % grid[k] or cells[l][k] // grid[k] < 2:
+                raise ValueError("cells per rank must be divisible by 2^(nlevels-1) with >= 2 coarsest cells per rank")
+    levels = []
+    geoms = [_LevelGeom(cells[l], order, grid, rank, d) for l in range(nlevels)]
+    for l in range(nlevels):
+        g = geoms[l]
+        L = LocalLevel()
+        tabs = [_axis_tables_local(cells[l][k], order, *g.rng[k], k < d) for k in range(3)]
+        ncols = [t[0] for t in tabs]
+        cols = [t[1] for t in tabs]
+        K = [t[2] for t in tabs]
+        M = [t[3] for t in tabs]
+        terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
+        if d == 3:
+            terms.append((M[0], M[1], K[2]))
+        L.A = g.remap(po._tensor_csr(cols, terms, ncols))
+        L.n_own, L.n_ghost = g.n_own, g.n_ghost
+        L.own_gid, L.ghost_gid = g.own_gid, g.ghost_gid
+        L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr = _exchange_plan(g)
+        levels.append(L)
+    for l in range(nlevels - 1):
+        gf, gc = geoms[l], geoms[l + 1]
+        pt = [_interp_tables_local(cells[l + 1][k], order, gf.rng[k][0], gf.rng[k][1], gc.rng[k][2], gc.rng[k][3], k < d)
+              for k in range(3)]
+        levels[l].P = gc.remap(po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt]))
+        rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], gf.rng[k][2], gf.rng[k][3], k < d)
+              for k in range(3)]
+        levels[l].R = gf.remap(po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt]))
+    coarse_global = po.poisson_matrix(cells[-1][:d], order)
+    return dict(levels=levels, coarse_global=coarse_global, cells=[c[:d] for c in cells], grid=grid[:d] + (1,) * 0,
+                order=order, rank=rank, nranks=nranks)

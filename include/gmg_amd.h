@@ -157,6 +157,41 @@ GMG_API int gmg_coarse_solve(gmg_handle_t h, const double *r, double *x, int mem
 /* dot / norm as used by the Krylov solvers (CGSolvers.jl:85,95,105). */
 GMG_API int gmg_dot(gmg_handle_t h, int64_t n, const double *a, const double *b, int memspace, double *out);
 
+/* ---- multi-GPU: one handle per rank/GPU ---------------------------------
+ * The reference row-partitions every level with PartitionedArrays (own-then-ghost local
+ * numbering, JacobiLinearSolvers.jl:29-56) and communicates through `consistent!`
+ * (owner->ghost, PatchSolvers.jl:231,256 and inside mul!(::PVector,::PSparseMatrix,::PVector))
+ * and the reductions inside dot/norm.  Call order: gmg_create, gmg_comm_init_*,
+ * gmg_set_partition + gmg_set_matrix/prolongation/restriction with LOCAL operators
+ * (rows = owned dofs, columns = [own | ghost]), gmg_set_coarse_global, gmg_setup.
+ * Vectors passed to the solve calls hold the OWNED entries only. */
+typedef void (*gmg_host_exchange_fn)(void *ctx, int nnbr, const int32_t *nbr_rank, const double *sendbuf,
+                                     const int64_t *snd_ptr, double *recvbuf, const int64_t *rcv_ptr);
+typedef void (*gmg_host_allreduce_fn)(void *ctx, double *vals, int n);
+/* ncclGetUniqueId through the RCCL library at rccl_path (NULL: librccl.so.1); 128 bytes out.
+ * Rank 0 calls it and the host language broadcasts the blob (MPI.bcast / torch.distributed). */
+GMG_API int gmg_comm_unique_id(const char *rccl_path, char *id_out128);
+/* RCCL over xGMI: grouped ncclSend/ncclRecv halos + ncclAllReduce on the handle's stream. */
+GMG_API int gmg_comm_init_rccl(gmg_handle_t h, const char *rccl_path, const char *unique_id128, int rank, int nranks);
+/* Diagnostic: all-reduce of 1.5 (-> out2[0] = 1.5*nranks) and a grouped self send/recv of
+ * 42.0 (-> out2[1]) through the RCCL binding; valid on a 1-rank communicator. */
+GMG_API int gmg_comm_selftest(gmg_handle_t h, double *out2);
+/* Host-staged transport through callbacks of the host language (MPI in Julia, gloo in the
+ * Python tests); lets several ranks share one GPU.  Functional, not fast. */
+GMG_API int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_fn exchange,
+                               gmg_host_allreduce_fn allreduce, void *ctx);
+/* Exchange plan of level lev: neighbours, local ids of owned entries to send (0-based),
+ * and the ghost sub-ranges received from each neighbour (ghosts ordered by owner). */
+GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, int nnbr,
+                              const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
+                              const int64_t *rcv_ptr);
+/* Global coarsest matrix (replicated) + global row id of each owned coarse dof: the coarse
+ * rhs is all-reduced and every rank applies its rows of the global inverse
+ * (reference analogue: coarsest level on a 1-rank sub-communicator, GridTransferOperators.jl:447-532). */
+GMG_API int gmg_set_coarse_global(gmg_handle_t h, int64_t n_global, int64_t nnz, const void *ptr, const void *idx,
+                                  const double *val, int layout, int index_base, int index_bytes,
+                                  const int64_t *own_global_ids, int64_t n_own);
+
 /* ---- measurement --------------------------------------------------------------- */
 /* Bracket every launch of the fused Richardson-Jacobi sweep on `lev` with HIP
  * events on the handle's stream (enable=0 stops).  Read with gmg_get_kernel_stats. */

@@ -1,0 +1,165 @@
+"""Worker of the multi-process tests (launched once per rank by test_distributed_*.py).
+
+mode "numpy": CPU-only emulation of the distributed CG+GMG on this rank's LOCAL operators
+              (partition.py) with gloo halo exchanges / all-reduces -- validates the
+              partition, the exchange plans and the distributed algorithm without a GPU.
+mode "gpu"  : the real thing through libgmgamd with the host-staged transport (several
+              ranks may share one GPU), or RCCL when every rank has its own GPU.
+Rank 0 compares the gathered solution with the serial CPU oracle and writes a JSON verdict."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+
+def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, rtol, niter=10, omega=2.0 / 3.0):
+    import scipy.sparse.linalg as spla
+    levels = local["levels"]
+    nlev = len(levels)
+    A = [L.A.to_scipy() for L in levels]
+    P = [L.P.to_scipy() for L in levels[:-1]]
+    R = [L.R.to_scipy() for L in levels[:-1]]
+    dinv = [1.0 / A[l].diagonal()[: levels[l].n_own] for l in range(nlev - 1)]   # own x own diagonal
+    Gc = local["coarse_global"].to_scipy().tocsc()
+
+    def exchange(l, v):
+        L = levels[l]
+        ops, keep = [], []
+        for k, q in enumerate(L.nbr_rank):
+            r0, r1 = L.rcv_ptr[k], L.rcv_ptr[k + 1]
+            if r1 > r0:
+                t = torch.zeros(int(r1 - r0), dtype=torch.float64); keep.append((t, r0, r1))
+                ops.append(dist.P2POp(dist.irecv, t, int(q)))
+            s = L.snd_idx[L.snd_ptr[k]:L.snd_ptr[k + 1]]
+            if s.size:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(v[s].copy()), int(q)))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, r0, r1 in keep:
+            v[L.n_own + r0: L.n_own + r1] = t.numpy()
+
+    def gdot(a, c):
+        t = torch.tensor([float(np.dot(a, c))], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item())
+
+    def vec(l):
+        return np.zeros(levels[l].n_own + levels[l].n_ghost)
+
+    def smooth(l, x, r):
+        n = levels[l].n_own
+        for _ in range(niter):
+            dx = vec(l)
+            dx[:n] = omega * (dinv[l] * r[:n])
+            x[:n] += dx[:n]
+            exchange(l, dx)
+            r[:n] -= A[l] @ dx
+
+    def cycle(l, x, r):
+        n = levels[l].n_own
+        if l == nlev - 1:
+            full = torch.zeros(Gc.shape[0], dtype=torch.float64)
+            full[torch.from_numpy(levels[l].own_gid)] = torch.from_numpy(r[:n].copy())
+            dist.all_reduce(full)
+            x[:n] = spla.spsolve(Gc, full.numpy())[levels[l].own_gid]
+            return
+        smooth(l, x, r)
+        exchange(l, r)
+        rH = vec(l + 1); rH[: levels[l + 1].n_own] = R[l] @ r
+        dxH = vec(l + 1)
+        cycle(l + 1, dxH, rH)
+        exchange(l + 1, dxH)
+        dx = vec(l); dx[:n] = P[l] @ dxH
+        x[:n] += dx[:n]
+        exchange(l, dx)
+        r[:n] -= A[l] @ dx
+        smooth(l, x, r)
+
+    n = levels[0].n_own
+    x, p, z = vec(0), vec(0), vec(0)
+    r = vec(0); r[:n] = b_own                      # x0 = 0
+    gamma = 1.0
+    res = np.sqrt(gdot(r[:n], r[:n])); hist = [res]
+    it = 0
+    done = (it >= maxiter) or (1.0 < rtol) or (res < atol)
+    while not done:
+        z[:] = 0.0
+        rr = r.copy()
+        cycle(0, z, rr)
+        beta = gamma; gamma = gdot(z[:n], r[:n]); beta = gamma / beta
+        p[:n] = z[:n] + beta * p[:n]
+        exchange(0, p)
+        w = A[0] @ p
+        alpha = gamma / gdot(p[:n], w)
+        x[:n] += alpha * p[:n]
+        r[:n] -= alpha * w
+        res = np.sqrt(gdot(r[:n], r[:n])); hist.append(res); it += 1
+        done = (it >= maxiter) or (res / hist[0] < rtol) or (res < atol)
+    return x[:n].copy(), it, np.array(hist)
+
+
+def main():
+    mode, cells, nlev, out = sys.argv[1], tuple(int(c) for c in sys.argv[2].split("x")), int(sys.argv[3]), sys.argv[4]
+    transport = sys.argv[5] if len(sys.argv) > 5 else "host"
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = entry.import_package()
+    from gridapsolvers_jl_amd import partition as pa, multigpu
+    po = pkg.poisson
+    d = len(cells)
+    grid = pa.rank_grid(world, d)
+    cg = pa.global_cells(cells, grid)
+    maxiter, atol, rtol = 20, 1e-14, 1e-6
+    verdict = {}
+    if mode == "numpy":
+        local = pa.build_local_hierarchy(cg, nlev, grid, rank, 1)
+        b = po.dirichlet_lift_rhs(cg, 1)[local["levels"][0].own_gid]
+        x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol)
+        gid = local["levels"][0].own_gid
+    else:
+        ndev = torch.cuda.device_count()
+        dev = rank % max(ndev, 1)
+        torch.cuda.set_device(dev)
+        g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None)
+        b = g.rhs_lin()
+        x = np.zeros(g.n_own)
+        log = g.cg_solve(b, x, maxiter, atol, rtol)
+        nit, hist = log.num_iters, log.residuals[: log.num_iters + 1].copy()
+        # also exercise device-pointer vectors + FGMRES
+        xd = torch.zeros(g.n_own, dtype=torch.float64, device="cuda"); bd = torch.from_numpy(b).cuda(); torch.cuda.synchronize()
+        log2 = g.fgmres_solve(bd, xd, m=5, maxiter=maxiter, atol=atol, rtol=rtol)
+        verdict["fgmres_iters"] = int(log2.num_iters)
+        verdict["fgmres_vs_cg"] = float(np.max(np.abs(xd.cpu().numpy() - x)))
+        gid = g.local["levels"][0].own_gid
+        g.close()
+    # gather solution on rank 0
+    parts = [None] * world
+    dist.all_gather_object(parts, (gid, x, int(nit), hist.tolist()))
+    if rank == 0:
+        orc = entry.import_oracle()
+        H = po.build_hierarchy(cg, nlev, 1)
+        bg = po.dirichlet_lift_rhs(cg, 1)
+        go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+        xo, nit_o, flag, hist_o = orc.cg_solve(H["mats"][0], bg, Pl=go, maxiter=maxiter, atol=atol, rtol=rtol)
+        xg = np.zeros_like(xo)
+        for gidq, xq, _, _ in parts:
+            xg[gidq] = xq
+        verdict.update(iters=int(nit), iters_oracle=int(nit_o), iters_all_equal=all(p[2] == nit for p in parts),
+                       rel_err=float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)),
+                       hist_dev=float(np.max(np.abs(np.array(hist) - hist_o) / hist_o)) if len(hist) == len(hist_o) else 1.0,
+                       l2_error_sq=float(po.l2_error_sq(cg, 1, xg)), world=world, grid=list(grid), mode=mode)
+        json.dump(verdict, open(out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
