@@ -74,7 +74,7 @@ class DistributedGMG:
 
     def __init__(self, cells_per_rank, nlevels, rank, world, device_id=0, transport="rccl", group=None,
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
-                 gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None):
+                 gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None):
         import torch.distributed as dist
         lib = abi.load()
         self._lib, self.rank, self.world = lib, rank, world
@@ -82,7 +82,10 @@ class DistributedGMG:
         self.grid = pa.rank_grid(world, d)
         self.cells_global = pa.global_cells(cells_per_rank, self.grid)
         t0 = time.perf_counter()
-        self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order)
+        # `lengths` = domain extents; the weak-scaling bench uses (px,py,pz) so that cells stay cubes
+        # (an anisotropic mesh would change the iteration count with the rank grid)
+        self.lengths = lengths
+        self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order, lengths)
         self.t_assembly = time.perf_counter() - t0
         self.order = order
         h = C.c_void_p()
@@ -145,11 +148,11 @@ class DistributedGMG:
     # -- right-hand sides ------------------------------------------------------------------
     def rhs_lin(self):
         """Owned part of the Dirichlet-lift rhs of u = x1 + x2 (reference test problem)."""
-        b = po.dirichlet_lift_rhs(self.cells_global, self.order)
+        b = po.dirichlet_lift_rhs(self.cells_global, self.order, None, self.lengths)
         return np.ascontiguousarray(b[self.local["levels"][0].own_gid])
 
     def exact_own(self):
-        return np.ascontiguousarray(po.nodal_values(self.cells_global, self.order)[self.local["levels"][0].own_gid])
+        return np.ascontiguousarray(po.nodal_values(self.cells_global, self.order, None, self.lengths)[self.local["levels"][0].own_gid])
 
     # -- solves ----------------------------------------------------------------------------
     def cg_solve(self, b, x, maxiter=20, atol=1e-14, rtol=1e-6, flexible=False):
@@ -213,16 +216,17 @@ def run_bench(args, rank, world, local_rank):
     nc = (args.cells,) * 3
     transport = os.environ.get("GMG_TRANSPORT", "rccl")
     group = None
+    lengths = tuple(float(v) for v in pa.rank_grid(world, 3))      # cubic cells at every GPU count
     try:
         if transport == "host":
             raise RuntimeError("host transport requested")
-        g = DistributedGMG(nc, args.levels, rank, world, device_id=local_rank, transport="rccl")
+        g = DistributedGMG(nc, args.levels, rank, world, device_id=local_rank, transport="rccl", lengths=lengths)
     except Exception as e:  # RCCL path unavailable: fall back to the host-staged transport (reported)
         if rank == 0 and transport != "host":
             print(f"[bench] RCCL transport failed ({e}); falling back to host-staged transport", flush=True)
-        group = dist.new_group(backend="gloo")
+        group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
         transport = "host"
-        g = DistributedGMG(nc, args.levels, rank, world, device_id=local_rank, transport="host", group=group)
+        g = DistributedGMG(nc, args.levels, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths)
     b = g.rhs_lin()
     bd = torch.from_numpy(b).cuda()
     xd = torch.zeros(g.n_own, dtype=torch.float64, device="cuda")
@@ -245,10 +249,11 @@ def run_bench(args, rank, world, local_rank):
     dist.barrier()
     dt = time.perf_counter() - t0
     st = g.kernel_stats()
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    err = torch.tensor([float(np.max(np.abs(xd.cpu().numpy() - g.exact_own())))], dtype=torch.float64, device="cuda")
+    err = torch.tensor([float(np.max(np.abs(xd.cpu().numpy() - g.exact_own())))], dtype=torch.float64, device=rdev)
     dist.all_reduce(err, op=dist.ReduceOp.MAX)
     avg_ms = st["total_ms"] / max(st["launches"], 1)
     achieved = st["alg_bytes"] / (avg_ms * 1e-3) / 1e9 if st["launches"] else None
@@ -260,7 +265,7 @@ def run_bench(args, rank, world, local_rank):
         "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"3D Poisson Q1, {args.cells}^3 cells per GPU on a {'x'.join(map(str, g.grid))} GPU grid "
-                        f"(global {'x'.join(map(str, g.cells_global))}), {args.levels}-level GMG V-cycle, "
+                        f"(global {'x'.join(map(str, g.cells_global))} cells on (0,{'x'.join(str(int(v)) for v in lengths)}): cubic cells), {args.levels}-level GMG V-cycle, "
                         f"Richardson(Jacobi,10,2/3), CG rtol={rtol:g}, rhs = u=x1+x2 Dirichlet lift; row partition + "
                         f"halo exchange + scalar all-reduce ({transport})",
             "dofs": n, "dofs_per_gpu": g.n_own, "levels": args.levels, "cg_iterations": int(log.num_iters),

@@ -76,11 +76,11 @@ def _axis_ranges(ncell_global, order, nparts, coord):
     return lo, hi, elo, ehi
 
 
-def _axis_tables_local(ncell_global, order, lo, hi, elo, ehi, active):
+def _axis_tables_local(ncell_global, order, lo, hi, elo, ehi, active, length=1.0):
     """1-D padded row tables for owned rows lo..hi with columns in extended-box numbering."""
     if not active:
         return 1, np.zeros((1, 1), dtype=np.int64), np.zeros((1, 1)), np.ones((1, 1))
-    K, M, S = po._assemble_1d(ncell_global, order)
+    K, M, S = po._assemble_1d(ncell_global, order, length)
     nn = order * ncell_global + 1
     col_map = -np.ones(nn, dtype=np.int64)
     col_map[elo:ehi + 1] = np.arange(ehi - elo + 1)
@@ -211,7 +211,7 @@ def _exchange_plan(me):
             np.asarray(rcv_ptr, dtype=np.int64))
 
 
-def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1):
+def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None):
     """Local operators of `rank` for every level.  Returns dict(levels=[LocalLevel...],
     coarse_global=CSR (global coarsest matrix), cells=[...], grid=grid)."""
     nc = tuple(int(c) for c in cells_global_fine)
@@ -229,7 +229,8 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1):
     for l in range(nlevels):
         g = geoms[l]
         L = LocalLevel()
-        tabs = [_axis_tables_local(cells[l][k], order, *g.rng[k], k < d) for k in range(3)]
+        Ls = po._lengths(lengths, d)
+        tabs = [_axis_tables_local(cells[l][k], order, *g.rng[k], k < d, Ls[k]) for k in range(3)]
         ncols = [t[0] for t in tabs]
         cols = [t[1] for t in tabs]
         K = [t[2] for t in tabs]
@@ -250,6 +251,6 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1):
         rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], gf.rng[k][2], gf.rng[k][3], k < d)
               for k in range(3)]
         levels[l].R = gf.remap(po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt]))
-    coarse_global = po.poisson_matrix(cells[-1][:d], order)
+    coarse_global = po.poisson_matrix(cells[-1][:d], order, lengths)
     return dict(levels=levels, coarse_global=coarse_global, cells=[c[:d] for c in cells], grid=grid[:d] + (1,) * 0,
                 order=order, rank=rank, nranks=nranks)

@@ -73,9 +73,9 @@ def _elem_1d(order, h):
     return K, M
 
 
-def _assemble_1d(n, order):
-    """Dense 1-D stiffness / mass on all order*n+1 nodes, and the element pattern."""
-    h = 1.0 / n
+def _assemble_1d(n, order, length=1.0):
+    """Dense 1-D stiffness / mass on all order*n+1 nodes of (0,length), and the element pattern."""
+    h = float(length) / n
     nn = order * n + 1
     Ke, Me = _elem_1d(order, h)
     K = np.zeros((nn, nn))
@@ -111,12 +111,20 @@ def _padded_rows(S, mats, rows, col_map):
     return cols, vals
 
 
-def _axis_tables(n, order, dim_active):
+def _lengths(lengths, d):
+    """Domain is (0,L1)x..x(0,Ld); default the unit box of the reference tests."""
+    if lengths is None:
+        return (1.0,) * 3
+    L = tuple(float(v) for v in lengths)
+    return L + (1.0,) * (3 - len(L))
+
+
+def _axis_tables(n, order, dim_active, length=1.0):
     """(ncols_free, cols[nr,W], Kvals, Mvals) for one axis; a collapsed axis
     (2-D problems) is the 1x1 identity for M and zero for K."""
     if not dim_active:
         return 1, np.zeros((1, 1), dtype=np.int64), np.zeros((1, 1)), np.ones((1, 1))
-    K, M, S = _assemble_1d(n, order)
+    K, M, S = _assemble_1d(n, order, length)
     nn = order * n + 1
     free = np.arange(1, nn - 1)
     col_map = -np.ones(nn, dtype=np.int64)
@@ -178,10 +186,11 @@ def level_sizes(ncells, order):
     return int(np.prod([order * nc[k] - 1 for k in range(d)]))
 
 
-def poisson_matrix(ncells, order=1) -> CSR:
-    """Free-free block of the Q`order` stiffness matrix of -Laplace on (0,1)^d."""
+def poisson_matrix(ncells, order=1, lengths=None) -> CSR:
+    """Free-free block of the Q`order` stiffness matrix of -Laplace on (0,1)^d (or (0,L_k) per axis)."""
     nc, d = _dims(ncells)
-    tabs = [_axis_tables(nc[k], order, k < d) for k in range(3)]
+    Ls = _lengths(lengths, d)
+    tabs = [_axis_tables(nc[k], order, k < d, Ls[k]) for k in range(3)]
     ncols = [t[0] for t in tabs]
     cols = [t[1] for t in tabs]
     K = [t[2] for t in tabs]
@@ -243,19 +252,21 @@ def _apply_axes(G, mats):
     return out
 
 
-def _full_1d(nc, order, d):
+def _full_1d(nc, order, d, lengths=None):
     Ks, Ms, nn = [], [], []
+    Ls = _lengths(lengths, d)
     for k in range(3):
         if k < d:
-            K, M, _ = _assemble_1d(nc[k], order)
+            K, M, _ = _assemble_1d(nc[k], order, Ls[k])
         else:
             K, M = np.zeros((1, 1)), np.ones((1, 1))
         Ks.append(K); Ms.append(M); nn.append(K.shape[0])
     return Ks, Ms, nn
 
 
-def _node_coords(nc, order, d):
-    xs = [np.linspace(0.0, 1.0, order * nc[k] + 1) if k < d else np.zeros(1) for k in range(3)]
+def _node_coords(nc, order, d, lengths=None):
+    Ls = _lengths(lengths, d)
+    xs = [np.linspace(0.0, Ls[k], order * nc[k] + 1) if k < d else np.zeros(1) for k in range(3)]
     Z, Y, X = np.meshgrid(xs[2], xs[1], xs[0], indexing="ij")
     return X, Y, Z
 
@@ -264,14 +275,14 @@ def _interior(nn, d):
     return tuple(slice(1, nn[k] - 1) if k < d else slice(0, 1) for k in (2, 1, 0))
 
 
-def dirichlet_lift_rhs(ncells, order=1, u=None):
+def dirichlet_lift_rhs(ncells, order=1, u=None, lengths=None):
     """b = -A_fd u_d for f = 0: the rhs of the reference's test problem
     u = x1 + x2 (GMGTests.jl:204-206: f = -Laplace(u) = 0)."""
     nc, d = _dims(ncells)
     if u is None:
         u = lambda X, Y, Z: X + Y
-    Ks, Ms, nn = _full_1d(nc, order, d)
-    X, Y, Z = _node_coords(nc, order, d)
+    Ks, Ms, nn = _full_1d(nc, order, d, lengths)
+    X, Y, Z = _node_coords(nc, order, d, lengths)
     G = u(X, Y, Z).astype(np.float64)
     G[_interior(nn, d)] = 0.0                                  # keep only Dirichlet values
     AG = _apply_axes(G, [Ks[0], Ms[1], Ms[2]]) + _apply_axes(G, [Ms[0], Ks[1], Ms[2]])
@@ -280,23 +291,23 @@ def dirichlet_lift_rhs(ncells, order=1, u=None):
     return np.ascontiguousarray(-AG[_interior(nn, d)].reshape(-1))
 
 
-def nodal_values(ncells, order=1, u=None):
+def nodal_values(ncells, order=1, u=None, lengths=None):
     """Nodal interpolant of u on the free dofs (exact discrete solution for u in the FE space)."""
     nc, d = _dims(ncells)
     if u is None:
         u = lambda X, Y, Z: X + Y
     nn = [order * nc[k] + 1 if k < d else 1 for k in range(3)]
-    X, Y, Z = _node_coords(nc, order, d)
+    X, Y, Z = _node_coords(nc, order, d, lengths)
     return np.ascontiguousarray(u(X, Y, Z)[_interior(nn, d)].reshape(-1).astype(np.float64))
 
 
-def l2_error_sq(ncells, order, x, u=None):
+def l2_error_sq(ncells, order, x, u=None, lengths=None):
     """E = int (u_h - u)^2 = e^T M e for u in the FE space -- the quantity the
     reference tests print / assert (SmoothersTests.jl:36-43, GMGTests.jl:134-142)."""
     nc, d = _dims(ncells)
-    Ks, Ms, nn = _full_1d(nc, order, d)
+    Ks, Ms, nn = _full_1d(nc, order, d, lengths)
     e = np.zeros((nn[2], nn[1], nn[0]))
-    e[_interior(nn, d)] = (np.asarray(x) - nodal_values(ncells, order, u)).reshape(e[_interior(nn, d)].shape)
+    e[_interior(nn, d)] = (np.asarray(x) - nodal_values(ncells, order, u, lengths)).reshape(e[_interior(nn, d)].shape)
     return float(np.sum(e * _apply_axes(e, Ms)))
 
 
@@ -340,7 +351,7 @@ def vertex_star_patches(ncells, order=1):
     return np.asarray(ptr, dtype=np.int64), dofs.astype(np.int32)
 
 
-def build_hierarchy(ncells_fine, nlevels, order=1):
+def build_hierarchy(ncells_fine, nlevels, order=1, lengths=None):
     """Level 1 = finest (reference convention, ModelHierarchies.jl:80-111).
 
     Returns dict(mats=[A_1..A_L], prolongations=[P_1..P_{L-1}] (P_l: level l+1 -> l),
@@ -350,7 +361,7 @@ def build_hierarchy(ncells_fine, nlevels, order=1):
     for l in range(nlevels):
         if any(cells[l][k] * 2 ** l != nc[k] or cells[l][k] < 2 for k in range(len(nc))):
             raise ValueError("ncells must be divisible by 2^(nlevels-1) with >=2 coarsest cells")
-    mats = [poisson_matrix(c, order) for c in cells]
+    mats = [poisson_matrix(c, order, lengths) for c in cells]
     Ps = [prolongation(cells[l + 1], order) for l in range(nlevels - 1)]
     Rs = [P.transpose() for P in Ps]
     return dict(mats=mats, prolongations=Ps, restrictions=Rs, ncells=cells, order=order)
