@@ -156,6 +156,14 @@ struct DevCSR {
   int nblocks = 0;
   int lanes_log2 = 0;
   int tile = kTile;
+  // SELL-64 copy (built when the padding is small): see kernels.hpp sell_kernel
+  bool sell = false;
+  int64_t *soff = nullptr;
+  int32_t *scol = nullptr;
+  double *sval = nullptr;
+  int32_t *rowlen = nullptr;
+  int nslices = 0;
+  int64_t zpad = 0;
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -304,6 +312,10 @@ struct gmg_solver {
   // tuning
   int xcd_remap = 0;
   int lanes_override = -1;
+  int use_sell = 1;     // GMG_SELL: SELL-64 layout for matrices with padding <= sell_maxpad
+  double sell_maxpad = 1.25;
+  int sell_block = 0;   // GMG_SELL_BLOCK: 0 = auto (256 threads on big levels, 64 on small ones)
+  int sell_un = 6;      // GMG_SELL_UN: independent (col,val,gather) triples in flight per lane
   int tpb = 4;          // GMG_TPB: tiles per workgroup of the pipelined kernel
   int nt_loads = 1;     // GMG_NT: non-temporal matrix stream
   int variant = 2;      // GMG_VARIANT: 0 multi-pass kernel, 1/3 single-pass (tile 2048/4096), 2/4 + one-gather sweep
@@ -411,8 +423,67 @@ struct gmg_solver {
       bnz[blk.size()] = bnz[blk.size() - 1];
       D.blk_nz = upload(bnz);
     }
+    build_sell(H, D);
     D.lanes_log2 = lg;
     return D;
+  }
+
+  // SELL-64 conversion (setup): slices of 64 rows, width = longest row of the slice.
+  void build_sell(const HostCSR &H, DevCSR &D)
+  {
+    if (!use_sell || variant == 0 || H.nrows == 0 || D.nnz == 0) return;
+    const int64_t ns = (H.nrows + 63) / 64;
+    std::vector<int64_t> soff((size_t)ns + 1, 0);
+    for (int64_t sl = 0; sl < ns; ++sl) {
+      int64_t w = 0;
+      for (int64_t i = sl * 64; i < std::min<int64_t>(H.nrows, sl * 64 + 64); ++i) w = std::max(w, H.ptr[i + 1] - H.ptr[i]);
+      soff[sl + 1] = soff[sl] + w * 64;
+    }
+    const int64_t zp = soff[ns];
+    if ((double)zp > sell_maxpad * (double)D.nnz) return;   // ragged matrix: keep the CSR-stream kernel
+    std::vector<int32_t> scol((size_t)zp), rowlen((size_t)H.nrows);
+    std::vector<double> sval((size_t)zp, 0.0);
+    for (int64_t sl = 0; sl < ns; ++sl) {
+      const int64_t w = (soff[sl + 1] - soff[sl]) / 64;
+      for (int l = 0; l < 64; ++l) {
+        const int64_t i = sl * 64 + l;
+        const int64_t len = i < H.nrows ? H.ptr[i + 1] - H.ptr[i] : 0;
+        if (i < H.nrows) rowlen[i] = (int32_t)len;
+        const int32_t padcol = len > 0 ? H.col[H.ptr[i]] : 0;   // any valid column
+        for (int64_t j = 0; j < w; ++j) {
+          const int64_t q = soff[sl] + j * 64 + l;
+          if (j < len) { scol[q] = H.col[H.ptr[i] + j]; sval[q] = H.val[H.ptr[i] + j]; }
+          else { scol[q] = padcol; sval[q] = 0.0; }
+        }
+      }
+    }
+    D.soff = upload(soff); D.scol = upload(scol); D.sval = upload(sval); D.rowlen = upload(rowlen);
+    D.nslices = (int)ns; D.zpad = zp; D.sell = true;
+  }
+  template <int EPI, bool ONEG>
+  void launch_sell(const DevCSR &M, const StreamArgs2 &a2)
+  {
+    SellArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.soff = M.soff; a.scol = M.scol; a.sval = M.sval; a.rowlen = M.rowlen; a.nrows = M.nrows; a.nslices = M.nslices;
+    a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
+    // one wave per slice; small levels get single-wave workgroups so that they spread over all CUs
+    const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
+    const dim3 g((M.nslices + wpb - 1) / wpb), b(64 * wpb);
+    const bool nt = nt_loads && (12.0 * (double)M.zpad > 192.0e6);   // keep cache-resident levels cacheable
+#define GMG_SELL_LAUNCH(UNV)                                                                          \
+    do {                                                                                                \
+      if (nt) hipLaunchKernelGGL((sell_kernel<EPI, ONEG, UNV, true>), g, b, 0, stream, a);               \
+      else hipLaunchKernelGGL((sell_kernel<EPI, ONEG, UNV, false>), g, b, 0, stream, a);                 \
+    } while (0)
+    if (sell_un >= 27) GMG_SELL_LAUNCH(27);
+    else if (sell_un >= 9) GMG_SELL_LAUNCH(9);
+    else if (sell_un >= 6) GMG_SELL_LAUNCH(6);
+    else if (sell_un >= 4) GMG_SELL_LAUNCH(4);
+    else if (sell_un >= 3) GMG_SELL_LAUNCH(3);
+    else GMG_SELL_LAUNCH(2);
+#undef GMG_SELL_LAUNCH
+    HIP_CHECK(hipGetLastError());
   }
 
   // ---- kernel launchers ------------------------------------------------------
@@ -484,6 +555,7 @@ struct gmg_solver {
   {
     if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; launch_stream<EPI_SET>(M, a); return; }
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y;
+    if (M.sell) { launch_sell<EPI_SET, false>(M, a); return; }
     if (variant >= 5) launch_pipe<EPI_SET, false>(M, a); else
     launch_stream1<EPI_SET, false, false>(M, a);
   }
@@ -492,6 +564,7 @@ struct gmg_solver {
   {
     if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; launch_stream<EPI_SUB>(M, a); return; }
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y;
+    if (M.sell) { launch_sell<EPI_SUB, false>(M, a); return; }
     if (variant >= 5) launch_pipe<EPI_SUB, false>(M, a); else
     launch_stream1<EPI_SUB, false, false>(M, a);
   }
@@ -500,6 +573,7 @@ struct gmg_solver {
   {
     if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; a.b = b; launch_stream<EPI_RESID>(M, a); return; }
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y; a.b = b;
+    if (M.sell) { launch_sell<EPI_RESID, false>(M, a); return; }
     if (variant >= 5) launch_pipe<EPI_RESID, false>(M, a); else
     launch_stream1<EPI_RESID, false, false>(M, a);
   }
@@ -508,6 +582,7 @@ struct gmg_solver {
   {
     if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; a.x2 = x2; launch_stream<EPI_ADDTO>(M, a); return; }
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y; a.x2 = x2;
+    if (M.sell) { launch_sell<EPI_ADDTO, false>(M, a); return; }
     if (variant >= 5) launch_pipe<EPI_ADDTO, false>(M, a); else
     launch_stream1<EPI_ADDTO, false, false>(M, a);
   }
@@ -528,6 +603,10 @@ struct gmg_solver {
     } else {
       StreamArgs2 a = base_args1(L.A);
       a.b = r_old; a.dinv = L.dinv; a.omega = S.omega; a.y = r_new; a.x2 = x; a.x_zero = x_zero ? 1 : 0;
+      if (L.A.sell) {
+        if (s_old) { a.x = s_old; a.s_out = s_new; launch_sell<EPI_SWEEP, true>(L.A, a); }
+        else { a.x = r_old; launch_sell<EPI_SWEEP, false>(L.A, a); }
+      } else
       if (s_old) { a.x = s_old; a.s_out = s_new; if (variant >= 5) launch_pipe<EPI_SWEEP, true>(L.A, a); else launch_stream1<EPI_SWEEP, true, false>(L.A, a); }
       else { a.x = r_old; if (variant >= 5) launch_pipe<EPI_SWEEP, false>(L.A, a); else launch_stream1<EPI_SWEEP, false, false>(L.A, a); }
     }
@@ -1028,6 +1107,10 @@ void gmg_solver::setup()
   lanes_override = env_int("GMG_LANES_LOG2", -1);
   variant = env_int("GMG_VARIANT", 2);
   tpb = std::max(1, env_int("GMG_TPB", 4));
+  use_sell = env_int("GMG_SELL", 1);
+  sell_un = env_int("GMG_SELL_UN", 6);
+  sell_block = std::min(256, env_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
+  if (const char *mp = std::getenv("GMG_SELL_MAXPAD")) sell_maxpad = std::atof(mp);
   nt_loads = env_int("GMG_NT", 1);
   tile = (variant == 3 || variant == 4) ? 4096 : kTile;
   for (int l = 0; l < nlev; ++l) {

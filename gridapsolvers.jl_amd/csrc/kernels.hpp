@@ -531,6 +531,109 @@ __global__ __launch_bounds__(kBlock) void csr_stream_pipe_kernel(StreamArgs3 a)
   }
 }
 
+// ---------------------------------------------------------------------------
+// SELL-64 kernels (sliced ELLPACK, slice height = one wave64, column-major inside a
+// slice, built at setup from the caller's CSR when the padding it needs is small).
+//
+// lane == row: the j-th stored entries of 64 consecutive rows are contiguous, so the
+// (col,val) stream AND all row-wise epilogue operands are perfectly coalesced, the
+// gather x[col] is contiguous across lanes for banded/stencil matrices, and there is
+// no LDS staging, barrier or shuffle at all.  Each row is summed left to right in
+// its original CSR order -- the same order as a sequential CPU SpMV (bit-identical
+// to the oracle's mul!).  Memory-level parallelism comes from UN independent
+// (col,val) loads + UN gathers in flight per lane and many waves per CU.
+// ---------------------------------------------------------------------------
+struct SellArgs {
+  const int64_t *soff;     // [nslices+1] offsets into scol/sval (multiples of 64)
+  const int32_t *scol;     // padded, column-major per slice; padding points at a valid column
+  const double *sval;      // padding = 0.0 (masked out by rowlen, never added)
+  const int32_t *rowlen;   // [nrows]
+  int64_t nrows;
+  int nslices;
+  int x_zero;
+  const double *x;         // gather source (ONEG sweep: s_old)
+  const double *dinv;
+  double omega;
+  double *y;
+  const double *b;         // RESID: b ; sweep: r_old
+  double *x2;              // sweep / ADDTO: x
+  double *s_out;           // ONEG sweep: s_new
+};
+
+template <int EPI, bool ONEG, int UN, bool NT>
+__global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // any block size that is a multiple of 64
+  if (slice >= a.nslices) return;
+  const int64_t base = a.soff[slice];
+  const int w = (int)((a.soff[slice + 1] - base) >> 6);
+  const int64_t row = (int64_t)slice * 64 + lane;
+  const bool valid = row < a.nrows;
+  const int len = valid ? a.rowlen[row] : 0;
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  // row-wise epilogue operands (coalesced), issued before the stream
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+  if (valid) {
+    if (EPI == EPI_SUB) e0 = a.y[row];
+    else if (EPI == EPI_RESID) e0 = a.b[row];
+    else if (EPI == EPI_ADDTO) e0 = a.x2[row];
+    else if (EPI == EPI_SWEEP) {
+      e0 = a.b[row];
+      e1 = ONEG ? xg[row] : dinv[row];
+      e2 = a.x_zero ? 0.0 : a.x2[row];
+      if (ONEG) dinv_row = dinv[row];
+    }
+  }
+  const int32_t *cp = a.scol + base + lane;
+  const double *vp = a.sval + base + lane;
+  double s = 0.0;
+  int j = 0;
+  for (; j + UN <= w; j += UN) {
+    int32_t c[UN];
+    double v[UN], g[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (NT) { c[u] = __builtin_nontemporal_load(cp + (int64_t)(j + u) * 64); v[u] = __builtin_nontemporal_load(vp + (int64_t)(j + u) * 64); }
+      else { c[u] = cp[(int64_t)(j + u) * 64]; v[u] = vp[(int64_t)(j + u) * 64]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {    // unconditional gathers: padding points at a valid column
+      if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (dinv[c[u]] * xg[c[u]]);
+      else g[u] = xg[c[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const double pr = v[u] * g[u];
+      s = (j + u < len) ? s + pr : s;   // masked: padding is never added
+    }
+  }
+  for (; j < w; ++j) {
+    const int32_t c = cp[(int64_t)j * 64];
+    const double v = vp[(int64_t)j * 64];
+    double g;
+    if (EPI == EPI_SWEEP && !ONEG) g = omega * (dinv[c] * xg[c]);
+    else g = xg[c];
+    const double pr = v * g;
+    s = (j < len) ? s + pr : s;
+  }
+  if (valid) {
+    if (EPI == EPI_SET) a.y[row] = s;
+    else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+    else if (EPI == EPI_RESID) a.y[row] = e0 - s;
+    else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+    else {
+      const double dxi = ONEG ? e1 : omega * (e1 * e0);
+      a.x2[row] = e2 + dxi;
+      const double rn = e0 - s;
+      a.y[row] = rn;
+      if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+    }
+  }
+}
+
 // s = omega*(dinv.*r)  (first sweep of a ONEG smoothing pass)
 __global__ void scaled_jacobi_kernel(int64_t n, double omega, const double *__restrict__ dinv,
                                      const double *__restrict__ r, double *__restrict__ s)

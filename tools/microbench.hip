@@ -76,6 +76,55 @@ __global__ __launch_bounds__(kBlock) void stream_kernel(const int *__restrict__ 
 }
 
 
+// ---- LDS-window variant: 16-bit tile-local column indices + gathered vector staged in LDS ----
+// per tile: segments (start,len) of the distinct columns; window = concatenation of the segments.
+template <int ALIAS>
+__global__ __launch_bounds__(kBlock) void stream_win_kernel(const int *__restrict__ rowptr, const unsigned short *__restrict__ idx16,
+                                                            const double *__restrict__ val, const int *__restrict__ blk_row,
+                                                            const int *__restrict__ seg_ptr, const int *__restrict__ seg_start,
+                                                            const int *__restrict__ seg_woff,
+                                                            const double *__restrict__ x, double *__restrict__ y, int lg)
+{
+  __shared__ double prod[TILE];
+  __shared__ double win[ALIAS ? 1 : 1536];
+  double *w = ALIAS ? prod : win;
+  const int tid = threadIdx.x;
+  const int blk = blockIdx.x;
+  const int r0 = blk_row[blk], r1 = blk_row[blk + 1];
+  const int nz0 = rowptr[r0], cnt = rowptr[r1] - nz0;
+  const int G = 1 << lg, sub = tid & (G - 1), row = r0 + (tid >> lg);
+  int k0 = 0, k1 = 0;
+  if (row < r1) { k0 = rowptr[row] - nz0; k1 = rowptr[row + 1] - nz0; }
+  // stream loads
+  unsigned short c[U]; double v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = tid + u * kBlock;
+    const bool ok = k < cnt;
+    c[u] = ok ? __builtin_nontemporal_load(idx16 + nz0 + k) : (unsigned short)0;
+    v[u] = ok ? __builtin_nontemporal_load(val + nz0 + k) : 0.0;
+  }
+  // window fill: wave j takes segments j, j+4, ...
+  const int s0 = seg_ptr[blk], s1 = seg_ptr[blk + 1] - 1; // last entry = sentinel (total window)
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int sgi = s0 + wave; sgi < s1; sgi += 4) {
+    const int st = seg_start[sgi], wo = seg_woff[sgi], len = seg_woff[sgi + 1] - wo;
+    for (int i = lane; i < len; i += 64) w[wo + i] = x[st + i];
+  }
+  __syncthreads();
+  double g[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) g[u] = w[c[u]];
+  if (ALIAS) __syncthreads();
+#pragma unroll
+  for (int u = 0; u < U; ++u) { const int k = tid + u * kBlock; if (k < cnt) prod[k] = v[u] * g[u]; }
+  __syncthreads();
+  double s = 0.0;
+  for (int k = k0 + sub; k < k1; k += G) s += prod[k];
+  for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (row < r1 && sub == 0) y[row] = s;
+}
+
 // SELL-64 (sliced ELLPACK, slice = one wave of 64 rows, column-major inside the slice):
 // lane == row, every load coalesced, no LDS, sequential left-to-right row sums.
 // MODE bit0: gather x[col]; bit3: second gather; bit2: nt loads; bit4: fused sweep epilogue (reads s,r,x,dinv; writes x,r,s)
@@ -105,14 +154,14 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(int nslices, const long *_
       if (MODE & 4) { c[u] = __builtin_nontemporal_load(cp + (j + u) * 64); v[u] = __builtin_nontemporal_load(vp + (j + u) * 64); }
       else { c[u] = cp[(j + u) * 64]; v[u] = vp[(j + u) * 64]; }
     }
+    double g[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      if (j + u < len) {
-        double g = (MODE & 1) ? x[c[u]] : (double)c[u];
-        if (MODE & 8) g *= x2[c[u]];
-        s += v[u] * g;
-      }
+    for (int u = 0; u < UN; ++u) {   // unconditional gathers (padded entries point at a valid column)
+      g[u] = (MODE & 1) ? x[c[u]] : (double)c[u];
+      if (MODE & 8) g[u] *= x2[c[u]];
     }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) { const double pr = v[u] * g[u]; s = (j + u < len) ? s + pr : s; }
   }
   for (; j < w; ++j) {
     const int c = cp[j * 64]; const double v = vp[j * 64];
@@ -186,38 +235,69 @@ int main(int argc, char **argv)
   RUN(15, "stream nt + 2 gathers + LDS reduce");
   RUN(3, "stream + 1 gather + LDS reduce");
 
-  // ---- SELL-64 ----
+
+  // ---- LDS window ----
   {
-    const int nsl = (int)((N + 63) / 64);
-    std::vector<long> soff(nsl + 1, 0); std::vector<int> rowlen(N);
-    for (int64_t i = 0; i < N; ++i) rowlen[i] = ptr[i + 1] - ptr[i];
-    for (int sidx = 0; sidx < nsl; ++sidx) { int w = 0; for (int64_t i = (int64_t)sidx * 64; i < std::min<int64_t>(N, (int64_t)sidx * 64 + 64); ++i) w = std::max(w, rowlen[i]); soff[sidx + 1] = soff[sidx] + (long)w * 64; }
-    const long ZP = soff[nsl];
-    std::vector<int> scol(ZP); std::vector<double> sval(ZP, 0.0);
-    for (int sidx = 0; sidx < nsl; ++sidx) { const int w = (int)((soff[sidx + 1] - soff[sidx]) / 64);
-      for (int l = 0; l < 64; ++l) { const int64_t i = (int64_t)sidx * 64 + l;
-        for (int j = 0; j < w; ++j) { const long q = soff[sidx] + (long)j * 64 + l;
-          if (i < N && j < rowlen[i]) { scol[q] = col[ptr[i] + j]; sval[q] = val[ptr[i] + j]; } else { scol[q] = i < N ? (int)i : 0; sval[q] = 0.0; } } } }
-    printf("SELL-64: padded nnz %ld (%.2f%% padding)\n", ZP, 100.0 * (ZP - Z) / Z);
-    long *d_soff; int *d_rl, *d_sc; double *d_sv, *d_y2, *d_y3;
-    CK(hipMalloc(&d_soff, (nsl + 1) * 8)); CK(hipMalloc(&d_rl, N * 4)); CK(hipMalloc(&d_sc, ZP * 4)); CK(hipMalloc(&d_sv, ZP * 8)); CK(hipMalloc(&d_y2, N * 8)); CK(hipMalloc(&d_y3, N * 8));
-    CK(hipMemcpy(d_soff, soff.data(), (nsl + 1) * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_rl, rowlen.data(), N * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_sc, scol.data(), ZP * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_sv, sval.data(), ZP * 8, hipMemcpyHostToDevice));
-    CK(hipMemset(d_y2, 0, N * 8)); CK(hipMemset(d_y3, 0, N * 8));
-    const int grid = (nsl + 3) / 4;
-#define RUNS(MODE, UN, label) \
-    t = time_it([&] { hipLaunchKernelGGL((sell_kernel<MODE, UN>), dim3(grid), dim3(kBlock), 0, 0, nsl, d_soff, d_rl, d_sc, d_sv, d_x, d_x2, d_y, d_y2, d_y3, (long)N); }); \
-    printf("%-44s %8.1f us  %7.1f GB/s of CSR matrix bytes\n", label, t * 1e3, mat_bytes / t / 1e6);
-    RUNS(4, 4, "sell stream only nt (un4)");
-    RUNS(5, 4, "sell nt + 1 gather (un4)");
-    RUNS(5, 8, "sell nt + 1 gather (un8)");
-    RUNS(5, 9, "sell nt + 1 gather (un9)");
-    RUNS(5, 3, "sell nt + 1 gather (un3)");
-    RUNS(1, 8, "sell + 1 gather (un8)");
-    RUNS(13, 8, "sell nt + 2 gathers (un8)");
-    RUNS(21, 8, "sell nt + 1 gather + sweep epilogue (un8)");
-    RUNS(21, 9, "sell nt + 1 gather + sweep epilogue (un9)");
-    RUNS(21, 4, "sell nt + 1 gather + sweep epilogue (un4)");
+    std::vector<unsigned short> idx16(Z);
+    std::vector<int> seg_ptr(nb + 1, 0), seg_start, seg_woff;
+    int maxW = 0, maxseg = 0; long totW = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int a0 = ptr[blk[b]], a1 = ptr[blk[b + 1]];
+      std::vector<int> u(col.begin() + a0, col.begin() + a1);
+      std::sort(u.begin(), u.end()); u.erase(std::unique(u.begin(), u.end()), u.end());
+      // segments with gap <= 4
+      std::vector<int> st, en;
+      for (size_t i = 0; i < u.size(); ++i) {
+        if (st.empty() || u[i] - en.back() > 4) { st.push_back(u[i]); en.push_back(u[i] + 1); } else en.back() = u[i] + 1;
+      }
+      int wo = 0;
+      for (size_t k = 0; k < st.size(); ++k) { seg_start.push_back(st[k]); seg_woff.push_back(wo); wo += en[k] - st[k]; }
+      seg_ptr[b + 1] = (int)seg_start.size();
+      maxW = std::max(maxW, wo); maxseg = std::max<int>(maxseg, st.size()); totW += wo;
+      // local indices
+      for (int k = a0; k < a1; ++k) {
+        const int cc = col[k];
+        size_t j = std::upper_bound(st.begin(), st.end(), cc) - st.begin() - 1;
+        int base = 0; for (size_t q = 0; q < j; ++q) base += en[q] - st[q];
+        idx16[k] = (unsigned short)(base + cc - st[j]);
+      }
+    }
+    seg_woff.push_back(0);
+    // make seg_woff[sgi+1]-seg_woff[sgi] valid at tile ends: store lengths via an extra array trick -> rebuild as absolute with sentinel per tile
+    // simpler: recompute woff array with per-tile sentinel
+    std::vector<int> woff2; std::vector<int> start2; std::vector<int> ptr2(nb + 1, 0);
+    for (int b = 0; b < nb; ++b) {
+      int wo = 0;
+      for (int sgi = seg_ptr[b]; sgi < seg_ptr[b + 1]; ++sgi) {
+        start2.push_back(seg_start[sgi]); woff2.push_back(seg_woff[sgi]);
+        (void)wo;
+      }
+      // sentinel: total window of the tile
+      int a0 = seg_ptr[b], a1 = seg_ptr[b + 1];
+      int tot = 0; { const int q0 = ptr[blk[b]], q1 = ptr[blk[b + 1]]; for (int k = q0; k < q1; ++k) tot = std::max<int>(tot, idx16[k] + 1); }
+      start2.push_back(0); woff2.push_back(tot);
+      ptr2[b + 1] = (int)start2.size();
+      (void)a0; (void)a1;
+    }
+    printf("LDS window: max W %d doubles, max segments %d, avg W %.1f per tile (x%.2f of tile nnz)\n", maxW, maxseg, (double)totW / nb, (double)totW / Z);
+    unsigned short *d_i16; int *d_sp, *d_ss, *d_sw;
+    CK(hipMalloc(&d_i16, Z * 2 + 64)); CK(hipMalloc(&d_sp, (nb + 1) * 4)); CK(hipMalloc(&d_ss, start2.size() * 4)); CK(hipMalloc(&d_sw, woff2.size() * 4));
+    // seg_ptr for kernel: segments of tile b are ptr2[b] .. ptr2[b+1]-1 (excluding sentinel)
+    std::vector<int> kptr(nb + 1); for (int b = 0; b <= nb; ++b) kptr[b] = ptr2[b];
+    CK(hipMemcpy(d_i16, idx16.data(), Z * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ss, start2.data(), start2.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_sw, woff2.data(), woff2.size() * 4, hipMemcpyHostToDevice));
+    // kernel loops sgi in [s0, s1): use s1 = ptr2[b+1]-1 -> pass adjusted array
+    std::vector<int> kend(nb + 1); // trick: kernel reads seg_ptr[blk], seg_ptr[blk+1]; we need end excluding sentinel, so build interleaved array
+    std::vector<int> sp2(nb + 1);
+    for (int b = 0; b < nb; ++b) sp2[b] = ptr2[b];
+    sp2[nb] = ptr2[nb];
+    CK(hipMemcpy(d_sp, sp2.data(), (nb + 1) * 4, hipMemcpyHostToDevice));
+    if (maxW <= 1536) {
+      t = time_it([&] { hipLaunchKernelGGL((stream_win_kernel<0>), dim3(nb), dim3(kBlock), 0, 0, d_ptr, d_i16, d_val, d_blk, d_sp, d_ss, d_sw, d_x, d_y, lg); });
+      printf("%-44s %8.1f us  %7.1f GB/s of CSR(12B) matrix bytes\n", "win: val+idx16, LDS window, separate prod", t * 1e3, mat_bytes / t / 1e6);
+    }
+    t = time_it([&] { hipLaunchKernelGGL((stream_win_kernel<1>), dim3(nb), dim3(kBlock), 0, 0, d_ptr, d_i16, d_val, d_blk, d_sp, d_ss, d_sw, d_x, d_y, lg); });
+    printf("%-44s %8.1f us  %7.1f GB/s of CSR(12B) matrix bytes\n", "win: val+idx16, LDS window aliased w/ prod", t * 1e3, mat_bytes / t / 1e6);
   }
   // ---- SELL-64 ----
   {
@@ -241,16 +321,18 @@ int main(int argc, char **argv)
 #define RUNS(MODE, UN, label) \
     t = time_it([&] { hipLaunchKernelGGL((sell_kernel<MODE, UN>), dim3(grid), dim3(kBlock), 0, 0, nsl, d_soff, d_rl, d_sc, d_sv, d_x, d_x2, d_y, d_y2, d_y3, (long)N); }); \
     printf("%-44s %8.1f us  %7.1f GB/s of CSR matrix bytes\n", label, t * 1e3, mat_bytes / t / 1e6);
-    RUNS(4, 4, "sell stream only nt (un4)");
+    RUNS(4, 9, "sell stream only nt (un9)");
+    RUNS(4, 27, "sell stream only nt (un27)");
     RUNS(5, 4, "sell nt + 1 gather (un4)");
-    RUNS(5, 8, "sell nt + 1 gather (un8)");
     RUNS(5, 9, "sell nt + 1 gather (un9)");
-    RUNS(5, 3, "sell nt + 1 gather (un3)");
-    RUNS(1, 8, "sell + 1 gather (un8)");
-    RUNS(13, 8, "sell nt + 2 gathers (un8)");
-    RUNS(21, 8, "sell nt + 1 gather + sweep epilogue (un8)");
+    RUNS(5, 14, "sell nt + 1 gather (un14)");
+    RUNS(5, 27, "sell nt + 1 gather (un27)");
+    RUNS(13, 9, "sell nt + 2 gathers (un9)");
+    RUNS(13, 27, "sell nt + 2 gathers (un27)");
     RUNS(21, 9, "sell nt + 1 gather + sweep epilogue (un9)");
-    RUNS(21, 4, "sell nt + 1 gather + sweep epilogue (un4)");
+    RUNS(21, 14, "sell nt + 1 gather + sweep epilogue (un14)");
+    RUNS(21, 27, "sell nt + 1 gather + sweep epilogue (un27)");
+    RUNS(29, 27, "sell nt + 2 gathers + sweep epilogue (un27)");
   }
   return 0;
 }
