@@ -39,8 +39,9 @@ def main():
     print("\n".join(lines[:14]))
 
     # dominant kernel = the sweep with the largest grid
-    dom = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%csr_stream_kernel<3%' "
-                      "group by grid_x order by grid_x desc limit 1").fetchone()
+    # dominant kernel = the (kernel, grid) pair with the largest total time
+    dom = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels "
+                      "group by name, grid_x order by sum(end-start) desc limit 1").fetchone()
     res = {"kernel": dom[0], "grid_x": dom[1], "avg_us_kernel_trace": dom[2], "launches": dom[3]}
     tl = [f"# dominant kernel: {dom[0]} grid_x={dom[1]} avg {dom[2]:.2f} us over {dom[3]} launches (kernel-trace pass)"]
     for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
@@ -48,8 +49,8 @@ def main():
         if c is None:
             continue
         r = c.execute("select avg(value), min(value), max(value), count(*), avg(end-start)/1e3 from counters_collection "
-                      "where counter_name=? and kernel_name like '%csr_stream_kernel<3%' and grid_size_x=?",
-                      (cname, dom[1])).fetchone()
+                      "where counter_name=? and kernel_name=? and grid_size_x=?",
+                      (cname, dom[0], dom[1])).fetchone()
         if r and r[3]:
             res[cname + "_KiB_avg"] = r[0]
             res[cname + "_launches"] = r[3]
