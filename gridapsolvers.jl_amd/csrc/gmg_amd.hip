@@ -164,6 +164,16 @@ struct DevCSR {
   int32_t *rowlen = nullptr;
   int nslices = 0;
   int64_t zpad = 0;
+  // compressed stream (SELL-C): 16-bit column offsets per slice column, 8-bit value codes
+  bool comp_idx = false, vdict = false;
+  int64_t *poff = nullptr;
+  uint16_t *pidx = nullptr;
+  uint8_t *pcode = nullptr;
+  int32_t *pbase = nullptr;
+  uint8_t *smode = nullptr;
+  double *dict = nullptr;
+  int64_t zpack = 0;
+  double stream_bytes_per_nnz = 12.0;
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -314,6 +324,8 @@ struct gmg_solver {
   int lanes_override = -1;
   int use_sell = 1;     // GMG_SELL: SELL-64 layout for matrices with padding <= sell_maxpad
   double sell_maxpad = 1.25;
+  int use_idx16 = 1;    // GMG_IDX16: 16-bit column offsets where a slice column spans < 65536
+  int use_vdict = 1;    // GMG_VDICT: 8-bit value dictionary when the matrix has <= 256 distinct values
   int sell_block = 0;   // GMG_SELL_BLOCK: 0 = auto (256 threads on big levels, 64 on small ones)
   int sell_un = 6;      // GMG_SELL_UN: independent (col,val,gather) triples in flight per lane
   int tpb = 4;          // GMG_TPB: tiles per workgroup of the pipelined kernel
@@ -459,10 +471,121 @@ struct gmg_solver {
     }
     D.soff = upload(soff); D.scol = upload(scol); D.sval = upload(sval); D.rowlen = upload(rowlen);
     D.nslices = (int)ns; D.zpad = zp; D.sell = true;
+    // ---- lossless compression of the stream (see sellc_kernel) ----
+    std::vector<int64_t> poff((size_t)ns + 1, 0);
+    for (int64_t sl = 0; sl < ns; ++sl) {
+      const int64_t w = (soff[sl + 1] - soff[sl]) / 64;
+      poff[sl + 1] = poff[sl] + ((w + 3) / 4) * 4 * 64;
+    }
+    const int64_t zpp = poff[ns];
+    std::vector<uint8_t> smode((size_t)ns, 0);
+    std::vector<uint16_t> pidx;
+    std::vector<int32_t> pbase;
+    int64_t n16 = 0;
+    if (use_idx16) {
+      pidx.assign((size_t)zpp, 0);
+      pbase.assign((size_t)(zpp / 64), 0);
+      for (int64_t sl = 0; sl < ns; ++sl) {
+        const int64_t w = (soff[sl + 1] - soff[sl]) / 64;
+        const int64_t w4 = (poff[sl + 1] - poff[sl]) / 64;
+        bool ok = w > 0;
+        for (int64_t j = 0; j < w && ok; ++j) {
+          int32_t lo = INT32_MAX, hi = INT32_MIN;
+          for (int l = 0; l < 64; ++l) {
+            const int64_t i = sl * 64 + l;
+            if (i < H.nrows && j < rowlen[i]) { const int32_t c = scol[soff[sl] + j * 64 + l]; lo = std::min(lo, c); hi = std::max(hi, c); }
+          }
+          if (lo == INT32_MAX) lo = hi = scol[soff[sl] + j * 64];   // all-padding column
+          if ((int64_t)hi - lo > 65535) ok = false;
+          pbase[poff[sl] / 64 + j] = lo;
+        }
+        if (!ok) continue;
+        smode[sl] = 1; ++n16;
+        for (int64_t j = w; j < w4; ++j) pbase[poff[sl] / 64 + j] = pbase[poff[sl] / 64 + w - 1];
+        for (int64_t j = 0; j < w4; ++j)
+          for (int l = 0; l < 64; ++l) {
+            const int64_t i = sl * 64 + l;
+            const bool real = j < w && i < H.nrows && j < rowlen[i];
+            const int32_t bj = pbase[poff[sl] / 64 + j];
+            const int32_t c = real ? scol[soff[sl] + j * 64 + l] : bj;      // padding decodes to the (valid) base column
+            pidx[poff[sl] + (j / 4) * 256 + l * 4 + (j % 4)] = (uint16_t)(c - bj);
+          }
+      }
+    }
+    std::vector<uint8_t> pcode;
+    std::vector<double> dict;
+    if (use_vdict) {
+      std::vector<uint64_t> keys;   // distinct bit patterns, sorted
+      keys.reserve(257);
+      bool fits = true;
+      for (int64_t k = 0; k < (int64_t)H.val.size() && fits; ++k) {
+        uint64_t bits;
+        std::memcpy(&bits, &H.val[k], 8);
+        auto it = std::lower_bound(keys.begin(), keys.end(), bits);
+        if (it == keys.end() || *it != bits) {
+          if (keys.size() == 256) fits = false;
+          else keys.insert(it, bits);
+        }
+      }
+      if (fits) {
+        dict.assign(256, 0.0);
+        for (size_t q = 0; q < keys.size(); ++q) std::memcpy(&dict[q], &keys[q], 8);
+        pcode.assign((size_t)zpp, 0);
+        for (int64_t sl = 0; sl < ns; ++sl) {
+          const int64_t w = (soff[sl + 1] - soff[sl]) / 64;
+          for (int64_t j = 0; j < w; ++j)
+            for (int l = 0; l < 64; ++l) {
+              const int64_t i = sl * 64 + l;
+              if (i < H.nrows && j < rowlen[i]) {
+                uint64_t bits;
+                std::memcpy(&bits, &H.val[H.ptr[i] + j], 8);
+                const size_t code = std::lower_bound(keys.begin(), keys.end(), bits) - keys.begin();
+                pcode[poff[sl] + (j / 4) * 256 + l * 4 + (j % 4)] = (uint8_t)code;
+              }
+            }
+        }
+      }
+    }
+    // 16-bit offsets pay off only together with the value dictionary (measured: with 8-byte
+    // values the packed decode costs more than the 2 B/nnz it saves, profiles/r01_tuning.md)
+    D.vdict = !pcode.empty();
+    D.comp_idx = n16 > 0 && (D.vdict || use_idx16 > 1);
+    if (!D.comp_idx) { std::fill(smode.begin(), smode.end(), 0); n16 = 0; }
+    if (D.comp_idx || D.vdict) {
+      D.poff = upload(poff); D.smode = upload(smode); D.zpack = zpp;
+      if (pidx.empty()) pidx.assign(64, 0);
+      if (pbase.empty()) pbase.assign((size_t)(zpp / 64) + 1, 0);
+      if (pcode.empty()) pcode.assign(64, 0);
+      if (dict.empty()) dict.assign(256, 0.0);
+      D.pidx = upload_padded(pidx, 512); D.pbase = upload_padded(pbase, 64); D.pcode = upload_padded(pcode, 512); D.dict = upload(dict);
+      const double frac16 = (double)n16 / (double)ns;
+      D.stream_bytes_per_nnz = (D.vdict ? 1.0 : 8.0) + (2.0 * frac16 + 4.0 * (1.0 - frac16));
+    }
+  }
+  template <int EPI, bool ONEG>
+  void launch_sellc(const DevCSR &M, const StreamArgs2 &a2)
+  {
+    SellCArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.soff = M.soff; a.poff = M.poff; a.scol = M.scol; a.sval = M.sval; a.pidx = M.pidx; a.pcode = M.pcode; a.pbase = M.pbase;
+    a.smode = M.smode; a.dict = M.dict; a.rowlen = M.rowlen; a.nrows = M.nrows; a.nslices = M.nslices;
+    a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
+    const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
+    const dim3 g((M.nslices + wpb - 1) / wpb), b(64 * wpb);
+    const bool nt = nt_loads && (M.stream_bytes_per_nnz * (double)M.zpad > 192.0e6);
+    if (M.vdict) {
+      if (nt) hipLaunchKernelGGL((sellc_kernel<EPI, ONEG, true, true>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((sellc_kernel<EPI, ONEG, true, false>), g, b, 0, stream, a);
+    } else {
+      if (nt) hipLaunchKernelGGL((sellc_kernel<EPI, ONEG, false, true>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((sellc_kernel<EPI, ONEG, false, false>), g, b, 0, stream, a);
+    }
+    HIP_CHECK(hipGetLastError());
   }
   template <int EPI, bool ONEG>
   void launch_sell(const DevCSR &M, const StreamArgs2 &a2)
   {
+    if (M.comp_idx || M.vdict) { launch_sellc<EPI, ONEG>(M, a2); return; }
     SellArgs a;
     std::memset(&a, 0, sizeof(a));
     a.soff = M.soff; a.scol = M.scol; a.sval = M.sval; a.rowlen = M.rowlen; a.nrows = M.nrows; a.nslices = M.nslices;
@@ -1108,6 +1231,8 @@ void gmg_solver::setup()
   variant = env_int("GMG_VARIANT", 2);
   tpb = std::max(1, env_int("GMG_TPB", 4));
   use_sell = env_int("GMG_SELL", 1);
+  use_idx16 = env_int("GMG_IDX16", 1);
+  use_vdict = env_int("GMG_VDICT", 1);
   sell_un = env_int("GMG_SELL_UN", 6);
   sell_block = std::min(256, env_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
   if (const char *mp = std::getenv("GMG_SELL_MAXPAD")) sell_maxpad = std::atof(mp);
@@ -1839,6 +1964,20 @@ int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes)
     BV += 8.0 * NL * NL + 16.0 * NL;
     if (vcycle_bytes) *vcycle_bytes = BV;
     if (cg_iter_bytes) *cg_iter_bytes = BV + 12.0 * (double)h->lev[0].A.nnz + 132.0 * (double)h->lev[0].n;
+  });
+}
+
+int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16, double *stream_bytes_per_nnz, double *padding)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    check_level(h, lev, false);
+    const DevCSR &A = h->lev[lev].A;
+    if (sell) *sell = A.sell ? 1 : 0;
+    if (vdict) *vdict = A.vdict ? 1 : 0;
+    if (idx16) *idx16 = A.comp_idx ? 1 : 0;
+    if (stream_bytes_per_nnz) *stream_bytes_per_nnz = (A.sell && (A.vdict || A.comp_idx)) ? A.stream_bytes_per_nnz : 12.0;
+    if (padding) *padding = A.sell && A.nnz > 0 ? (double)A.zpad / (double)A.nnz : 1.0;
   });
 }
 

@@ -634,6 +634,154 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------
+// Compressed SELL-64 ("SELL-C"): the same lane-per-row kernel fed by a losslessly
+// compressed matrix stream.  Two independent, automatically detected compressions:
+//   IDX16 : per slice column (64 entries) a base column + 16-bit offsets, when the 64
+//           columns span < 65536 (true for banded / stencil matrices); decided per
+//           slice, slices that do not fit keep their 32-bit columns.     4 -> 2 B/nnz
+//   VDICT : when the whole matrix holds <= 256 distinct fp64 values (constant-
+//           coefficient operators on uniform meshes) an 8-bit code into a dictionary
+//           kept in LDS.                                                   8 -> 1 B/nnz
+// Both are exact: the decoded (col,val) pairs are bit-identical to the CSR input, and
+// rows are still summed left to right.  Packed layout: entry (j,lane) of a slice sits at
+// poff + (j/4)*256 + lane*4 + (j%4), so one lane fetches four consecutive entries of
+// its row with a single 4-byte (codes) / 8-byte (offsets) load and a wave reads 256 /
+// 512 contiguous bytes.
+// ---------------------------------------------------------------------------
+struct SellCArgs {
+  const int64_t *soff;      // column-major offsets (scol / sval), width w
+  const int64_t *poff;      // packed offsets (pidx / pcode), width rounded up to 4
+  const int32_t *scol;
+  const double *sval;
+  const uint16_t *pidx;
+  const uint8_t *pcode;
+  const int32_t *pbase;     // [poff/64 + j] base column of slice column j
+  const uint8_t *smode;     // per slice: bit0 = 16-bit offsets valid
+  const double *dict;       // [256]
+  const int32_t *rowlen;
+  int64_t nrows;
+  int nslices;
+  int x_zero;
+  const double *x;
+  const double *dinv;
+  double omega;
+  double *y;
+  const double *b;
+  double *x2;
+  double *s_out;
+};
+
+template <int EPI, bool ONEG, bool VDICT, bool NT>
+__global__ __launch_bounds__(kBlock) void sellc_kernel(SellCArgs a)
+{
+  __shared__ double sdict[VDICT ? 256 : 1];
+  if (VDICT) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) sdict[i] = a.dict[i];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  // wave-uniform by construction; readfirstlane makes it provably so (scalar loads, SGPR loop bounds)
+  const int slice = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  if (slice >= a.nslices) return;
+  const int64_t base = a.soff[slice];
+  const int w = (int)((a.soff[slice + 1] - base) >> 6);
+  const int64_t pb = a.poff[slice];
+  const int npack = (w + 3) >> 2;
+  const bool i16 = (a.smode[slice] & 1) != 0;
+  const int64_t row = (int64_t)slice * 64 + lane;
+  const bool valid = row < a.nrows;
+  const int len = valid ? a.rowlen[row] : 0;
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+  if (valid) {
+    if (EPI == EPI_SUB) e0 = a.y[row];
+    else if (EPI == EPI_RESID) e0 = a.b[row];
+    else if (EPI == EPI_ADDTO) e0 = a.x2[row];
+    else if (EPI == EPI_SWEEP) {
+      e0 = a.b[row];
+      e1 = ONEG ? xg[row] : dinv[row];
+      e2 = a.x_zero ? 0.0 : a.x2[row];
+      if (ONEG) dinv_row = dinv[row];
+    }
+  }
+  // base column of slice column j lives in lane j (w <= 64 is the common case; wider slices reload)
+  const int32_t *pbp = a.pbase + (pb >> 6);
+  int32_t mybase = (i16 && lane < 4 * npack) ? pbp[lane] : 0;
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 *ip = reinterpret_cast<const u32x2 *>(a.pidx + pb) + lane;      // 4 x uint16 per lane per pack
+  const uint32_t *kp = reinterpret_cast<const uint32_t *>(a.pcode + pb) + lane; // 4 x uint8  per lane per pack
+  const int32_t *cp = a.scol + base + lane;
+  const double *vp = a.sval + base + lane;
+  double s = 0.0;
+  constexpr int PK = 2; // packs per iteration: 8 entries in flight per lane
+  for (int p0 = 0; p0 < npack; p0 += PK) {
+    int32_t c[4 * PK];
+    double v[4 * PK], g[4 * PK];
+    u32x2 iw[PK];
+    uint32_t kw[PK];
+#pragma unroll
+    for (int q = 0; q < PK; ++q) {
+      const int pk = (p0 + q < npack) ? p0 + q : npack - 1;   // clamp (masked below)
+      if (i16) iw[q] = NT ? __builtin_nontemporal_load(ip + (int64_t)pk * 64) : ip[(int64_t)pk * 64];
+      if (VDICT) kw[q] = NT ? __builtin_nontemporal_load(kp + (int64_t)pk * 64) : kp[(int64_t)pk * 64];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = 4 * pk + u;
+        const int jc = j < w ? j : w - 1;
+        if (!i16) c[4 * q + u] = NT ? __builtin_nontemporal_load(cp + (int64_t)jc * 64) : cp[(int64_t)jc * 64];
+        if (!VDICT) v[4 * q + u] = NT ? __builtin_nontemporal_load(vp + (int64_t)jc * 64) : vp[(int64_t)jc * 64];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PK; ++q) {
+      const int pk = (p0 + q < npack) ? p0 + q : npack - 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = 4 * pk + u;
+        if (i16) {
+          const uint32_t word = (u < 2) ? iw[q].x : iw[q].y;
+          const int32_t off = (int32_t)((u & 1) ? (word >> 16) : (word & 0xffffu));
+          int32_t bj;
+          if (j < 64) bj = __builtin_amdgcn_readlane(mybase, j);
+          else bj = pbp[j];
+          c[4 * q + u] = bj + off;
+        }
+        if (VDICT) v[4 * q + u] = sdict[(kw[q] >> (8 * u)) & 0xffu];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4 * PK; ++e) {
+      if (EPI == EPI_SWEEP && !ONEG) g[e] = omega * (dinv[c[e]] * xg[c[e]]);
+      else g[e] = xg[c[e]];
+    }
+#pragma unroll
+    for (int q = 0; q < PK; ++q) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = 4 * (p0 + q) + u;
+        const double pr = v[4 * q + u] * g[4 * q + u];
+        s = (p0 + q < npack && j < len) ? s + pr : s;
+      }
+    }
+  }
+  if (valid) {
+    if (EPI == EPI_SET) a.y[row] = s;
+    else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+    else if (EPI == EPI_RESID) a.y[row] = e0 - s;
+    else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+    else {
+      const double dxi = ONEG ? e1 : omega * (e1 * e0);
+      a.x2[row] = e2 + dxi;
+      const double rn = e0 - s;
+      a.y[row] = rn;
+      if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+    }
+  }
+}
+
 // s = omega*(dinv.*r)  (first sweep of a ONEG smoothing pass)
 __global__ void scaled_jacobi_kernel(int64_t n, double omega, const double *__restrict__ dinv,
                                      const double *__restrict__ r, double *__restrict__ s)

@@ -199,6 +199,10 @@ GMG_API int gmg_profile_enable(gmg_handle_t h, int lev, int enable);
 GMG_API int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out);
 /* Algorithmic bytes (SURVEY 8d byte model) of one V-cycle / one CG iteration. */
 GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes);
+/* Storage chosen for A_lev at setup: SELL-64 (vs CSR-stream), 8-bit value dictionary,
+ * 16-bit column offsets, bytes streamed per stored nonzero, padding factor. */
+GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
+                             double *stream_bytes_per_nnz, double *padding);
 /* Device memory held by the handle, bytes. */
 GMG_API int gmg_device_bytes(gmg_handle_t h, int64_t *bytes);
 

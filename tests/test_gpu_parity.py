@@ -406,3 +406,58 @@ def test_config2_full_size_properties(S, po, hierarchy):
     # symmetry of the preconditioner (needed by CG): <M r1, r2> == <r1, M r2>
     a12, a21 = torch.dot(z1, r2).item(), torch.dot(r1, z2).item()
     assert abs(a12 - a21) <= 1e-10 * max(abs(a12), abs(a21))
+
+
+# ---------------------------------------------------------------- storage formats of the operator stream
+def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
+    """CSR-stream, SELL-64 and compressed SELL-C (16-bit column offsets + 8-bit value dictionary) are
+    different LAYOUTS of the same operator.  SELL and SELL-C sum every row left to right over the
+    bit-identical decoded (col,val) pairs, so their results must agree to the last bit; the CSR-stream
+    kernel reduces with a lane tree and agrees to rounding.  All must match the oracle."""
+    nc, nlev = (24, 20, 16), 3
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    r = seeded(b.size, 41)
+    out = {}
+    for name, env in {"csr": dict(GMG_SELL="0"), "sell": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="0"),
+                      "sellc": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="1"),
+                      "sell_idx16": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="2"),
+                      "sell_dict": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="0")}.items():
+        for k in ("GMG_SELL", "GMG_VDICT", "GMG_IDX16"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        solver = S.CGSolver(make_gmg(S, H), maxiter=20, atol=1e-14, rtol=1e-6)
+        ns = setup(S, solver, H["mats"][0])
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        z = np.zeros_like(r)
+        S.solve_(z, ns.P_ns, r)
+        out[name] = (x, z, solver.log.num_iters, solver.log.residuals[: solver.log.num_iters + 1].copy())
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
+    zo = go.solve(r)[0]
+    for name, (x, z, it, h) in out.items():
+        assert it == nit, name
+        assert rel_err(x, xo) <= 1e-10 and rel_err(z, zo) <= TOL_VCYCLE, name
+        np.testing.assert_allclose(h, hist, rtol=TOL_HIST)
+    for name in ("sellc", "sell_idx16", "sell_dict"):
+        assert np.array_equal(out[name][0], out["sell"][0]) and np.array_equal(out[name][1], out["sell"][1]), name
+
+
+def test_value_dictionary_falls_back_on_many_distinct_values(S, po, orc, hierarchy, monkeypatch):
+    """A matrix with > 256 distinct values must take the uncompressed path and still be exact."""
+    from gridapsolvers_jl_amd import abi
+    nc, nlev = (12, 12, 12), 2
+    H = hierarchy(nc, nlev)
+    A = H["mats"][0]
+    rng = np.random.default_rng(8)
+    D = rng.uniform(0.5, 2.0, A.shape[0])                       # symmetric diagonal scaling: all values distinct
+    As = A.to_scipy().multiply(D[:, None]).multiply(D[None, :]).tocsr(); As.sort_indices()
+    A2 = po.CSR(A.shape, As.indptr, As.indices, As.data)
+    H2 = dict(mats=[A2, H["mats"][1]], prolongations=H["prolongations"], restrictions=H["restrictions"])
+    ns = setup(S, make_gmg(S, H2), A2)
+    x = seeded(A.shape[0], 3)
+    y = np.zeros_like(x)
+    ns.op_apply(0, abi.OP_A, x, y)
+    assert max_rel(y, orc.spmv(A2, x)) <= 1e-15                 # sequential row sums: bit-level agreement
