@@ -461,3 +461,22 @@ def test_value_dictionary_falls_back_on_many_distinct_values(S, po, orc, hierarc
     y = np.zeros_like(x)
     ns.op_apply(0, abi.OP_A, x, y)
     assert max_rel(y, orc.spmv(A2, x)) <= 1e-15                 # sequential row sums: bit-level agreement
+
+
+def test_numerical_setup_bang_updates_values(S, po, orc, hierarchy):
+    """numerical_setup!(ns, A) (CGSolvers.jl:57-63 -> GMGLinearSolvers.jl:249-297): same pattern, new values.
+    Scaling the finest operator by 2 must halve the solution of A x = b."""
+    nc, nlev = (16, 16), 3
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    solver = S.CGSolver(make_gmg(S, H), maxiter=30, atol=1e-14, rtol=1e-10)
+    ns = setup(S, solver, H["mats"][0])
+    x1 = np.zeros_like(b); S.solve_(x1, ns, b)
+    A2 = po.CSR(H["mats"][0].shape, H["mats"][0].ptr, H["mats"][0].idx, 2.0 * H["mats"][0].val)
+    S.numerical_setup_(ns, A2)
+    x2 = np.zeros_like(b); S.solve_(x2, ns, b)
+    assert rel_err(2.0 * x2, x1) < 1e-8
+    H2 = dict(mats=[A2] + H["mats"][1:], prolongations=H["prolongations"], restrictions=H["restrictions"])
+    go = orc.GMG(H2["mats"], H2["prolongations"], H2["restrictions"], maxiter=1)
+    xo, nit, _, _ = orc.cg_solve(A2, b, Pl=go, maxiter=30, atol=1e-14, rtol=1e-10)
+    assert solver.log.num_iters == nit and rel_err(x2, xo) < 1e-10
