@@ -1182,7 +1182,10 @@ void gmg_solver::build_coarse()
   const bool dist = comm.nranks > 1;
   const HostCSR &A = dist ? h_coarse_global : lev[nlev - 1].hA;
   const int n = (int)A.nrows;
-  REQUIRE((double)n * n * 8.0 < 64e9, GMG_ERR_UNSUPPORTED, "coarsest level too large for a dense inverse; add levels");
+  // the exact factorisation + inversion runs on the host (setup only): O(n^2 * bandwidth)
+  REQUIRE(n <= env_int("GMG_MAX_COARSE", 12000), GMG_ERR_UNSUPPORTED,
+          "coarsest level has " + std::to_string(n) + " dofs: too large for the dense-inverse coarse solver; "
+          "add multigrid levels (or raise GMG_MAX_COARSE and accept a long setup)");
   BandLU lu;
   REQUIRE(lu.factor(A), GMG_ERR_SINGULAR, "coarsest-level matrix is singular");
   std::vector<double> inv((size_t)n * n);

@@ -217,16 +217,19 @@ def run_bench(args, rank, world, local_rank):
     transport = os.environ.get("GMG_TRANSPORT", "rccl")
     group = None
     lengths = tuple(float(v) for v in pa.rank_grid(world, 3))      # cubic cells at every GPU count
+    # one more level than the single-GPU hierarchy: the GLOBAL coarsest level (dense inverse,
+    # replicated) then stays at <= 15^3 dofs instead of growing with the GPU grid
+    nlev = args.levels + 1
     try:
         if transport == "host":
             raise RuntimeError("host transport requested")
-        g = DistributedGMG(nc, args.levels, rank, world, device_id=local_rank, transport="rccl", lengths=lengths)
+        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths)
     except Exception as e:  # RCCL path unavailable: fall back to the host-staged transport (reported)
         if rank == 0 and transport != "host":
             print(f"[bench] RCCL transport failed ({e}); falling back to host-staged transport", flush=True)
         group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
         transport = "host"
-        g = DistributedGMG(nc, args.levels, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths)
+        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths)
     b = g.rhs_lin()
     bd = torch.from_numpy(b).cuda()
     xd = torch.zeros(g.n_own, dtype=torch.float64, device="cuda")
@@ -265,10 +268,10 @@ def run_bench(args, rank, world, local_rank):
         "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"3D Poisson Q1, {args.cells}^3 cells per GPU on a {'x'.join(map(str, g.grid))} GPU grid "
-                        f"(global {'x'.join(map(str, g.cells_global))} cells on (0,{'x'.join(str(int(v)) for v in lengths)}): cubic cells), {args.levels}-level GMG V-cycle, "
+                        f"(global {'x'.join(map(str, g.cells_global))} cells on (0,{'x'.join(str(int(v)) for v in lengths)}): cubic cells), {nlev}-level GMG V-cycle, "
                         f"Richardson(Jacobi,10,2/3), CG rtol={rtol:g}, rhs = u=x1+x2 Dirichlet lift; row partition + "
                         f"halo exchange + scalar all-reduce ({transport})",
-            "dofs": n, "dofs_per_gpu": g.n_own, "levels": args.levels, "cg_iterations": int(log.num_iters),
+            "dofs": n, "dofs_per_gpu": g.n_own, "levels": nlev, "cg_iterations": int(log.num_iters),
             "transport": transport, "max_abs_error_vs_exact": float(err.item()),
             "setup_s": g.t_setup, "assembly_s": g.t_assembly,
         },
