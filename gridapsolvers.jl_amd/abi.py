@@ -61,8 +61,7 @@ SYMBOLS = {
     "gmg_comm_init_host": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "gmg_set_partition": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_void_p],
-    "gmg_set_coarse_global": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                              C.c_int, C.c_void_p, C.c_int64],
+    "gmg_set_replication": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64],
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
     "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],
     "gmg_model_bytes": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)],

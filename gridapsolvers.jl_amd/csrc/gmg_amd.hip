@@ -294,14 +294,14 @@ struct gmg_solver {
 
   // coarse solver
   double *d_Ainv = nullptr;
-  // distributed coarse solve: replicated rhs + own rows of the global inverse
-  HostCSR h_coarse_global;
-  std::vector<int64_t> h_coarse_gid;
-  bool has_coarse_global = false;
-  int64_t n_coarse_global = 0;
-  int64_t *d_coarse_gid = nullptr;
-  double *d_coarse_full = nullptr;
-  double *h_coarse_full = nullptr;
+  // distributed runs: levels >= rep_from are REPLICATED (every rank holds the global operators and
+  // computes them redundantly, no halo traffic on small levels).  The restricted residual of the last
+  // distributed level is assembled with one all-reduce (own rows scattered by global id).
+  int rep_from = -1;
+  std::vector<int64_t> h_rep_gid;     // global row id (level rep_from) of every row this rank's R produces
+  int64_t *d_rep_gid = nullptr;
+  double *d_rep_tmp = nullptr;
+  double *h_rep_full = nullptr;       // pinned, host transport only
 
   // inter-GPU transport
   Comm comm;
@@ -386,7 +386,7 @@ struct gmg_solver {
       L.pre.built = L.post.built = false;
     }
     d_Ainv = d_partials = d_scalars = nullptr;
-    d_coarse_gid = nullptr; d_coarse_full = nullptr; cg_x = nullptr;
+    d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr;
     for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; }
     cg_w = cg_p = cg_z = cg_r = st_b = st_x = nullptr;
     fg_V.clear(); fg_Z.clear(); st_extra.clear();
@@ -881,36 +881,34 @@ struct gmg_solver {
     return r;
   }
 
+  // rH = R rh across the distributed -> replicated boundary: own coarse rows, scattered into the
+  // global vector by global id, summed over ranks (disjoint contributions).
+  void restrict_replicate(int l, const double *r, double *rH_global)
+  {
+    Level &L = lev[l];
+    const int64_t nrows = L.R.nrows, ng = lev[l + 1].n;
+    spmv_set(L.R, r, d_rep_tmp);
+    zero(rH_global, ng);
+    if (nrows > 0) {
+      hipLaunchKernelGGL(scatter_gid_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, nrows, d_rep_gid, d_rep_tmp, rH_global);
+      HIP_CHECK(hipGetLastError());
+    }
+    if (comm.kind == COMM_RCCL) {
+      const int rc = comm.api.AllReduce(rH_global, rH_global, (size_t)ng, kNcclDouble, kNcclSum, comm.comm, stream);
+      REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclAllReduce(restriction): ") + comm.api.GetErrorString(rc));
+    } else {
+      HIP_CHECK(hipMemcpyAsync(h_rep_full, rH_global, sizeof(double) * (size_t)ng, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      comm.rfn(comm.ctx, h_rep_full, (int)ng);
+      HIP_CHECK(hipMemcpyAsync(rH_global, h_rep_full, sizeof(double) * (size_t)ng, hipMemcpyHostToDevice, stream));
+    }
+  }
+
   void coarse_solve(const double *r, double *x)
   {
     const int n = (int)lev[nlev - 1].n;
     const int waves_per_block = kBlock / 64;
-    if (comm.nranks > 1) {
-      // replicate the coarse rhs (sum of disjoint contributions), then apply this rank's rows
-      // of the global inverse.  Reference analogue: the coarsest level lives on one (sub)communicator,
-      // GridTransferOperators.jl:447-532.
-      const int ng = (int)n_coarse_global;
-      zero(d_coarse_full, ng);
-      if (n > 0) {
-        hipLaunchKernelGGL(scatter_gid_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (int64_t)n, d_coarse_gid, r, d_coarse_full);
-        HIP_CHECK(hipGetLastError());
-      }
-      if (comm.kind == COMM_RCCL) {
-        const int rc = comm.api.AllReduce(d_coarse_full, d_coarse_full, (size_t)ng, kNcclDouble, kNcclSum, comm.comm, stream);
-        REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclAllReduce(coarse): ") + comm.api.GetErrorString(rc));
-      } else {
-        HIP_CHECK(hipMemcpyAsync(h_coarse_full, d_coarse_full, sizeof(double) * (size_t)ng, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        comm.rfn(comm.ctx, h_coarse_full, ng);
-        HIP_CHECK(hipMemcpyAsync(d_coarse_full, h_coarse_full, sizeof(double) * (size_t)ng, hipMemcpyHostToDevice, stream));
-      }
-      if (n > 0) {
-        const int grid = (n + waves_per_block - 1) / waves_per_block;
-        hipLaunchKernelGGL(dense_gemv_rect_kernel, dim3(grid), dim3(kBlock), 0, stream, n, ng, d_Ainv, d_coarse_full, x);
-        HIP_CHECK(hipGetLastError());
-      }
-      return;
-    }
+    // (in distributed runs the coarsest level is replicated: same kernel, global matrix)
     const int grid = (n + waves_per_block - 1) / waves_per_block;
     hipLaunchKernelGGL(dense_gemv_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, stream, n, d_Ainv, r, x);
     HIP_CHECK(hipGetLastError());
@@ -930,6 +928,8 @@ struct gmg_solver {
     for (int pass = 0; pass < passes; ++pass) {
       if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
       exchange(l, r);
+      if (comm.nranks > 1 && l + 1 == rep_from) restrict_replicate(l, r, C.rbuf[0]);
+      else
       spmv_set(L.R, r, C.rbuf[0]);                         // :484 rH = R rh
       // :487 fill!(dxH,0) is implicit: the first sweep below / the coarse solve write dxH
       const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
@@ -1179,8 +1179,7 @@ struct BandLU {
 
 void gmg_solver::build_coarse()
 {
-  const bool dist = comm.nranks > 1;
-  const HostCSR &A = dist ? h_coarse_global : lev[nlev - 1].hA;
+  const HostCSR &A = lev[nlev - 1].hA;
   const int n = (int)A.nrows;
   // the exact factorisation + inversion runs on the host (setup only): O(n^2 * bandwidth)
   REQUIRE(n <= env_int("GMG_MAX_COARSE", 12000), GMG_ERR_UNSUPPORTED,
@@ -1204,23 +1203,7 @@ void gmg_solver::build_coarse()
   for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
   work(0);
   for (auto &t : th) t.join();
-  if (!dist) d_Ainv = upload(inv);
-  else {
-    // keep this rank's rows of the global inverse (n_own x n_global, row-major)
-    const int64_t nown = lev[nlev - 1].n;
-    REQUIRE((int64_t)h_coarse_gid.size() == nown, GMG_ERR_INVALID, "own_global_ids length != coarse n_own");
-    std::vector<double> rows((size_t)std::max<int64_t>(nown, 1) * n);
-    for (int64_t i = 0; i < nown; ++i) {
-      const int64_t g = h_coarse_gid[i];
-      REQUIRE(g >= 0 && g < n, GMG_ERR_INVALID, "coarse global id out of range");
-      std::memcpy(&rows[(size_t)i * n], &inv[(size_t)g * n], sizeof(double) * (size_t)n);
-    }
-    d_Ainv = upload(rows);
-    d_coarse_gid = upload(h_coarse_gid);
-    d_coarse_full = dvec(n);
-    n_coarse_global = n;
-    if (comm.kind == COMM_HOST && !h_coarse_full) HIP_CHECK(hipHostMalloc((void **)&h_coarse_full, sizeof(double) * (size_t)n));
-  }
+  d_Ainv = upload(inv);
   HIP_CHECK(hipStreamSynchronize(stream));
 }
 
@@ -1246,15 +1229,20 @@ void gmg_solver::setup()
     REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));
     L.n = L.hA.nrows;
     L.nvec = L.hA.ncols;
+    const bool replicated = comm.nranks > 1 && rep_from >= 0 && l >= rep_from;
     if (L.halo.present) {
       REQUIRE(comm.nranks > 1, GMG_ERR_STATE, "gmg_set_partition needs gmg_comm_init_* first");
+      REQUIRE(!replicated, GMG_ERR_INVALID, "replicated levels take global operators, not a partition");
       REQUIRE(L.halo.n_own == L.hA.nrows && L.halo.n_own + L.halo.n_ghost == L.hA.ncols, GMG_ERR_INVALID,
               "local matrix must be n_own x (n_own+n_ghost) on level " + std::to_string(l));
     } else {
-      REQUIRE(comm.nranks == 1, GMG_ERR_STATE, "gmg_set_partition missing on level " + std::to_string(l));
+      REQUIRE(comm.nranks == 1 || replicated, GMG_ERR_STATE, "gmg_set_partition missing on level " + std::to_string(l));
       REQUIRE(L.hA.nrows == L.hA.ncols, GMG_ERR_INVALID, "level matrix must be square");
     }
   }
+  if (comm.nranks > 1)
+    REQUIRE(rep_from >= 1 && rep_from <= nlev - 1, GMG_ERR_STATE,
+            "distributed runs need gmg_set_replication: at least the coarsest level must be replicated");
   for (int l = 0; l < nlev - 1; ++l) {
     Level &L = lev[l];
     REQUIRE(L.hasP, GMG_ERR_STATE, "gmg_set_prolongation missing for level " + std::to_string(l));
@@ -1262,15 +1250,18 @@ void gmg_solver::setup()
             "prolongation shape does not match level sizes (GMGLinearSolvers.jl:59-61)");
     if (comm.nranks > 1)
       REQUIRE(L.hasR, GMG_ERR_STATE, "distributed runs need the local rows of R (gmg_set_restriction): a local P^T misses off-rank rows");
-    if (L.hasR)
-      REQUIRE(L.hR.nrows == lev[l + 1].n && L.hR.ncols == L.nvec, GMG_ERR_INVALID, "restriction shape mismatch");
+    if (L.hasR) {
+      const bool boundary = comm.nranks > 1 && l + 1 == rep_from;   // R yields this rank's rows of the replicated level
+      REQUIRE((boundary ? L.hR.nrows == (int64_t)h_rep_gid.size() : L.hR.nrows == lev[l + 1].n) && L.hR.ncols == L.nvec,
+              GMG_ERR_INVALID, "restriction shape mismatch");
+    }
     if (comm.nranks > 1)
       REQUIRE(L.pre.kind == SM_JACOBI && L.post.kind == SM_JACOBI, GMG_ERR_UNSUPPORTED,
               "patch smoothers are single-GPU in this round (need assemble! of ghost rows, PatchSolvers.jl:254)");
   }
   if (comm.nranks > 1) {
-    REQUIRE(has_coarse_global, GMG_ERR_STATE, "gmg_set_coarse_global missing (distributed coarse solve)");
     variant = 2; tile = kTile;   // the one-gather sweep needs only s-ghosts
+    for (int64_t g : h_rep_gid) REQUIRE(g >= 0 && g < lev[rep_from].n, GMG_ERR_INVALID, "replication: global id out of range");
   }
   d_partials = dvec(kRedBlocks);
   d_scalars = dvec(kScalarSlots);
@@ -1323,7 +1314,13 @@ void gmg_solver::setup()
   const int64_t n0 = lev[0].nvec;
   cg_w = dvec(n0); cg_p = dvec(n0); cg_z = dvec(n0); cg_r = dvec(n0);
   st_b = dvec(n0); st_x = dvec(n0);
-  if (comm.nranks > 1) cg_x = dvec(n0);
+  if (comm.nranks > 1) {
+    cg_x = dvec(n0);
+    d_rep_gid = upload(h_rep_gid);
+    d_rep_tmp = dvec((int64_t)h_rep_gid.size());
+    if (comm.kind == COMM_HOST && !h_rep_full)
+      HIP_CHECK(hipHostMalloc((void **)&h_rep_full, sizeof(double) * (size_t)std::max<int64_t>(1, lev[rep_from].n)));
+  }
   HIP_CHECK(hipStreamSynchronize(stream));
   setup_done = true;
 }
@@ -1407,7 +1404,7 @@ int gmg_destroy(gmg_handle_t h)
     if (L.halo.h_send) (void)hipHostFree(L.halo.h_send);
     if (L.halo.h_recv) (void)hipHostFree(L.halo.h_recv);
   }
-  if (h->h_coarse_full) (void)hipHostFree(h->h_coarse_full);
+  if (h->h_rep_full) (void)hipHostFree(h->h_rep_full);
   if (h->comm.kind == COMM_RCCL && h->comm.comm) (void)h->comm.api.CommDestroy(h->comm.comm);
   for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
   if (h->h_scalars) (void)hipHostFree(h->h_scalars);
@@ -1897,15 +1894,14 @@ int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, i
   });
 }
 
-int gmg_set_coarse_global(gmg_handle_t h, int64_t n_global, int64_t nnz, const void *ptr, const void *idx, const double *val,
-                          int layout, int index_base, int index_bytes, const int64_t *own_global_ids, int64_t n_own)
+int gmg_set_replication(gmg_handle_t h, int lev, const int64_t *own_global_ids, int64_t n_own)
 {
   return guarded(h, [&] {
-    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    check_level(h, lev, false);
+    REQUIRE(lev >= 1, GMG_ERR_INVALID, "the finest level cannot be replicated");
     REQUIRE(n_own == 0 || own_global_ids, GMG_ERR_INVALID, "null own_global_ids");
-    h->h_coarse_global = convert_input(n_global, n_global, nnz, ptr, idx, val, layout, index_base, index_bytes);
-    h->h_coarse_gid.assign(own_global_ids, own_global_ids + n_own);
-    h->has_coarse_global = true;
+    h->rep_from = lev;
+    h->h_rep_gid.assign(own_global_ids, own_global_ids + n_own);
     h->setup_done = false;
   });
 }

@@ -74,7 +74,7 @@ class DistributedGMG:
 
     def __init__(self, cells_per_rank, nlevels, rank, world, device_id=0, transport="rccl", group=None,
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
-                 gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None):
+                 gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None):
         import torch.distributed as dist
         lib = abi.load()
         self._lib, self.rank, self.world = lib, rank, world
@@ -85,7 +85,7 @@ class DistributedGMG:
         # `lengths` = domain extents; the weak-scaling bench uses (px,py,pz) so that cells stay cubes
         # (an anisotropic mesh would change the iteration count with the rank grid)
         self.lengths = lengths
-        self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order, lengths)
+        self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order, lengths, rep_from)
         self.t_assembly = time.perf_counter() - t0
         self.order = order
         h = C.c_void_p()
@@ -110,7 +110,7 @@ class DistributedGMG:
                 raise ValueError("transport must be 'rccl' or 'host'")
         levels = self.local["levels"]
         for l, L in enumerate(levels):
-            if world > 1:
+            if world > 1 and not L.replicated:
                 nbr = np.ascontiguousarray(L.nbr_rank, dtype=np.int32)
                 sp, si, rp = (np.ascontiguousarray(a, dtype=np.int64) for a in (L.snd_ptr, L.snd_idx, L.rcv_ptr))
                 self._keep += [nbr, sp, si, rp]
@@ -123,13 +123,9 @@ class DistributedGMG:
                 self._set(lib.gmg_set_restriction, l, L.R)
                 abi.check(h, lib.gmg_set_smoother_jacobi(h, l, abi.PRE_AND_POST, niter, omega))
         if world > 1:
-            G = self.local["coarse_global"]
-            gid = np.ascontiguousarray(levels[-1].own_gid, dtype=np.int64)
-            gidx = G.idx.astype(np.int64)          # keep alive across the call
-            abi.check(h, lib.gmg_set_coarse_global(h, G.shape[0], G.nnz, C.c_void_p(G.ptr.ctypes.data),
-                                                   C.c_void_p(gidx.ctypes.data),
-                                                   C.c_void_p(G.val.ctypes.data), abi.CSR, 0, 8,
-                                                   C.c_void_p(gid.ctypes.data), gid.size))
+            gid = self.local["rep_gid"]
+            self._keep.append(gid)
+            abi.check(h, lib.gmg_set_replication(h, self.local["rep_from"], C.c_void_p(gid.ctypes.data), gid.size))
         modes = {"preconditioner": abi.MODE_PRECONDITIONER, "solver": abi.MODE_SOLVER}
         cycles = {"v_cycle": abi.V_CYCLE, "w_cycle": abi.W_CYCLE, "f_cycle": abi.F_CYCLE}
         abi.check(h, lib.gmg_set_options(h, modes[mode], cycles[cycle_type], gmg_maxiter, gmg_atol, gmg_rtol))
@@ -220,16 +216,24 @@ def run_bench(args, rank, world, local_rank):
     # one more level than the single-GPU hierarchy: the GLOBAL coarsest level (dense inverse,
     # replicated) then stays at <= 15^3 dofs instead of growing with the GPU grid
     nlev = args.levels + 1
+    # replicate every level whose GLOBAL size is small (<= 3e5 dofs): those levels are latency bound and a
+    # halo exchange per sweep would cost more than computing them redundantly on every GPU
+    grid3 = pa.rank_grid(world, 3)
+    rep_from = nlev - 1
+    for l in range(1, nlev):
+        if po.level_sizes(tuple(args.cells * g // 2 ** l for g in grid3), 1) <= 300000:
+            rep_from = l
+            break
     try:
         if transport == "host":
             raise RuntimeError("host transport requested")
-        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths)
+        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from)
     except Exception as e:  # RCCL path unavailable: fall back to the host-staged transport (reported)
         if rank == 0 and transport != "host":
             print(f"[bench] RCCL transport failed ({e}); falling back to host-staged transport", flush=True)
         group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
         transport = "host"
-        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths)
+        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths, rep_from=rep_from)
     b = g.rhs_lin()
     bd = torch.from_numpy(b).cuda()
     xd = torch.zeros(g.n_own, dtype=torch.float64, device="cuda")
@@ -272,7 +276,7 @@ def run_bench(args, rank, world, local_rank):
                         f"Richardson(Jacobi,10,2/3), CG rtol={rtol:g}, rhs = u=x1+x2 Dirichlet lift; row partition + "
                         f"halo exchange + scalar all-reduce ({transport})",
             "dofs": n, "dofs_per_gpu": g.n_own, "levels": nlev, "cg_iterations": int(log.num_iters),
-            "transport": transport, "max_abs_error_vs_exact": float(err.item()),
+            "transport": transport, "replicated_from_level": int(g.local["rep_from"]), "max_abs_error_vs_exact": float(err.item()),
             "setup_s": g.t_setup, "assembly_s": g.t_assembly,
         },
         "roofline": {"bound": "hbm", "kernel": "sell_kernel<EPI_SWEEP,ONEG> (rank 0, finest level)",

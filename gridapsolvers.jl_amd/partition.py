@@ -61,6 +61,7 @@ class LocalLevel:
         self.rcv_ptr = np.zeros(1, np.int64)
         self.own_gid = None      # global lexicographic free-dof id of every owned dof
         self.ghost_gid = None
+        self.replicated = False
 
 
 def _axis_ranges(ncell_global, order, nparts, coord):
@@ -211,46 +212,77 @@ def _exchange_plan(me):
             np.asarray(rcv_ptr, dtype=np.int64))
 
 
-def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None):
-    """Local operators of `rank` for every level.  Returns dict(levels=[LocalLevel...],
-    coarse_global=CSR (global coarsest matrix), cells=[...], grid=grid)."""
+def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None, rep_from=None):
+    """Local operators of `rank` for every level.
+
+    Levels >= rep_from are REPLICATED (global operators on every rank, no halo); by default only the
+    coarsest level is.  Returns dict(levels=[LocalLevel...], rep_from, rep_gid (global ids, in level
+    rep_from numbering, of the rows this rank's boundary restriction produces), cells, grid)."""
     nc = tuple(int(c) for c in cells_global_fine)
     d = len(nc)
     nc3 = nc + (1,) * (3 - d)
     grid = tuple(grid) + (1,) * (3 - len(grid))
     nranks = int(np.prod(grid))
+    if rep_from is None:
+        rep_from = nlevels - 1
+    if nranks == 1:
+        rep_from = nlevels          # nothing to replicate
+    if not (1 <= rep_from <= nlevels):
+        raise ValueError("rep_from must be in 1..nlevels")
     cells = [tuple(c // (2 ** l) for c in nc3[:d]) + (1,) * (3 - d) for l in range(nlevels)]
     for l in range(nlevels):
         for k in range(d):
-            if cells[l][k] * 2 ** l != nc3[k] or cells[l][k] % grid[k] or cells[l][k] // grid[k] < 2:
-                raise ValueError("cells per rank must be divisible by 2^(nlevels-1) with >= 2 coarsest cells per rank")
+            if cells[l][k] * 2 ** l != nc3[k] or cells[l][k] < 2:
+                raise ValueError("cells must be divisible by 2^(nlevels-1) with >= 2 coarsest cells")
+            if l < min(rep_from + 1, nlevels) and (cells[l][k] % grid[k] or cells[l][k] // grid[k] < 2):
+                raise ValueError("partitioned levels need >= 2 cells per rank and direction")
+    Ls = po._lengths(lengths, d)
+    ngeom = min(rep_from + 1, nlevels)
+    geoms = [_LevelGeom(cells[l], order, grid, rank, d) for l in range(ngeom)]
     levels = []
-    geoms = [_LevelGeom(cells[l], order, grid, rank, d) for l in range(nlevels)]
     for l in range(nlevels):
-        g = geoms[l]
         L = LocalLevel()
-        Ls = po._lengths(lengths, d)
-        tabs = [_axis_tables_local(cells[l][k], order, *g.rng[k], k < d, Ls[k]) for k in range(3)]
-        ncols = [t[0] for t in tabs]
-        cols = [t[1] for t in tabs]
-        K = [t[2] for t in tabs]
-        M = [t[3] for t in tabs]
-        terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
-        if d == 3:
-            terms.append((M[0], M[1], K[2]))
-        L.A = g.remap(po._tensor_csr(cols, terms, ncols))
-        L.n_own, L.n_ghost = g.n_own, g.n_ghost
-        L.own_gid, L.ghost_gid = g.own_gid, g.ghost_gid
-        L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr = _exchange_plan(g)
+        if l < rep_from:
+            g = geoms[l]
+            tabs = [_axis_tables_local(cells[l][k], order, *g.rng[k], k < d, Ls[k]) for k in range(3)]
+            ncols = [t[0] for t in tabs]
+            cols = [t[1] for t in tabs]
+            K = [t[2] for t in tabs]
+            M = [t[3] for t in tabs]
+            terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
+            if d == 3:
+                terms.append((M[0], M[1], K[2]))
+            L.A = g.remap(po._tensor_csr(cols, terms, ncols))
+            L.n_own, L.n_ghost = g.n_own, g.n_ghost
+            L.own_gid, L.ghost_gid = g.own_gid, g.ghost_gid
+            L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr = _exchange_plan(g)
+        else:
+            L.A = po.poisson_matrix(cells[l][:d], order, lengths)
+            L.n_own, L.n_ghost = L.A.shape[0], 0
+            L.own_gid, L.ghost_gid = np.arange(L.n_own, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        L.replicated = l >= rep_from
         levels.append(L)
+    rep_gid = np.zeros(0, dtype=np.int64)
     for l in range(nlevels - 1):
-        gf, gc = geoms[l], geoms[l + 1]
-        pt = [_interp_tables_local(cells[l + 1][k], order, gf.rng[k][0], gf.rng[k][1], gc.rng[k][2], gc.rng[k][3], k < d)
-              for k in range(3)]
-        levels[l].P = gc.remap(po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt]))
-        rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], gf.rng[k][2], gf.rng[k][3], k < d)
-              for k in range(3)]
-        levels[l].R = gf.remap(po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt]))
-    coarse_global = po.poisson_matrix(cells[-1][:d], order, lengths)
-    return dict(levels=levels, coarse_global=coarse_global, cells=[c[:d] for c in cells], grid=grid[:d] + (1,) * 0,
-                order=order, rank=rank, nranks=nranks)
+        if l + 1 < rep_from:                      # both levels partitioned
+            gf, gc = geoms[l], geoms[l + 1]
+            pt = [_interp_tables_local(cells[l + 1][k], order, gf.rng[k][0], gf.rng[k][1], gc.rng[k][2], gc.rng[k][3], k < d)
+                  for k in range(3)]
+            levels[l].P = gc.remap(po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt]))
+            rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], gf.rng[k][2], gf.rng[k][3], k < d)
+                  for k in range(3)]
+            levels[l].R = gf.remap(po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt]))
+        elif l + 1 == rep_from:                   # boundary: fine partitioned, coarse replicated
+            gf, gc = geoms[l], geoms[l + 1]
+            last = [order * cells[l + 1][k] - 1 for k in range(3)]
+            pt = [_interp_tables_local(cells[l + 1][k], order, gf.rng[k][0], gf.rng[k][1], 1, last[k], k < d) for k in range(3)]
+            levels[l].P = po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt])   # global coarse columns
+            rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], gf.rng[k][2], gf.rng[k][3], k < d)
+                  for k in range(3)]
+            levels[l].R = gf.remap(po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt]))
+            rep_gid = gc.own_gid
+        else:                                     # both replicated: global transfer operators
+            levels[l].P = po.prolongation(cells[l + 1][:d], order)
+            levels[l].R = levels[l].P.transpose()
+    return dict(levels=levels, rep_from=rep_from, rep_gid=np.ascontiguousarray(rep_gid, dtype=np.int64),
+                cells=[c[:d] for c in cells], grid=grid[:d], order=order, rank=rank, nranks=nranks)

@@ -163,7 +163,7 @@ GMG_API int gmg_dot(gmg_handle_t h, int64_t n, const double *a, const double *b,
  * (owner->ghost, PatchSolvers.jl:231,256 and inside mul!(::PVector,::PSparseMatrix,::PVector))
  * and the reductions inside dot/norm.  Call order: gmg_create, gmg_comm_init_*,
  * gmg_set_partition + gmg_set_matrix/prolongation/restriction with LOCAL operators
- * (rows = owned dofs, columns = [own | ghost]), gmg_set_coarse_global, gmg_setup.
+ * (rows = owned dofs, columns = [own | ghost]), gmg_set_replication, gmg_setup.
  * Vectors passed to the solve calls hold the OWNED entries only. */
 typedef void (*gmg_host_exchange_fn)(void *ctx, int nnbr, const int32_t *nbr_rank, const double *sendbuf,
                                      const int64_t *snd_ptr, double *recvbuf, const int64_t *rcv_ptr);
@@ -185,12 +185,15 @@ GMG_API int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_ex
 GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, int nnbr,
                               const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
                               const int64_t *rcv_ptr);
-/* Global coarsest matrix (replicated) + global row id of each owned coarse dof: the coarse
- * rhs is all-reduced and every rank applies its rows of the global inverse
- * (reference analogue: coarsest level on a 1-rank sub-communicator, GridTransferOperators.jl:447-532). */
-GMG_API int gmg_set_coarse_global(gmg_handle_t h, int64_t n_global, int64_t nnz, const void *ptr, const void *idx,
-                                  const double *val, int layout, int index_base, int index_bytes,
-                                  const int64_t *own_global_ids, int64_t n_own);
+/* Levels >= lev are REPLICATED: every rank passes the GLOBAL operators of those levels
+ * (gmg_set_matrix / _prolongation / _restriction, no gmg_set_partition) and computes them
+ * redundantly -- no halo traffic where the level is tiny.  Across the boundary, P_{lev-1} has
+ * this rank's fine rows and GLOBAL coarse columns; R_{lev-1} yields the rows listed in
+ * own_global_ids (global numbering of level lev), which are summed into the replicated
+ * residual with one all-reduce.  At least the coarsest level must be replicated.
+ * Reference analogue: coarse levels living on fewer ranks (np_per_level, ModelHierarchies.jl:80-148)
+ * with redistribute! at the boundary (GridTransferOperators.jl:447-532). */
+GMG_API int gmg_set_replication(gmg_handle_t h, int lev, const int64_t *own_global_ids, int64_t n_own);
 
 /* ---- measurement --------------------------------------------------------------- */
 /* Bracket every launch of the fused Richardson-Jacobi sweep on `lev` with HIP

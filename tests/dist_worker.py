@@ -25,7 +25,8 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
     P = [L.P.to_scipy() for L in levels[:-1]]
     R = [L.R.to_scipy() for L in levels[:-1]]
     dinv = [1.0 / A[l].diagonal()[: levels[l].n_own] for l in range(nlev - 1)]   # own x own diagonal
-    Gc = local["coarse_global"].to_scipy().tocsc()
+    rep_from, rep_gid = local["rep_from"], local["rep_gid"]
+    Gc = A[nlev - 1].tocsc()                    # coarsest level is always replicated (global matrix)
 
     def exchange(l, v):
         L = levels[l]
@@ -64,14 +65,18 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
     def cycle(l, x, r):
         n = levels[l].n_own
         if l == nlev - 1:
-            full = torch.zeros(Gc.shape[0], dtype=torch.float64)
-            full[torch.from_numpy(levels[l].own_gid)] = torch.from_numpy(r[:n].copy())
-            dist.all_reduce(full)
-            x[:n] = spla.spsolve(Gc, full.numpy())[levels[l].own_gid]
+            x[:n] = spla.spsolve(Gc, r[:n])
             return
         smooth(l, x, r)
         exchange(l, r)
-        rH = vec(l + 1); rH[: levels[l + 1].n_own] = R[l] @ r
+        rH = vec(l + 1)
+        if l + 1 == rep_from:                    # distributed -> replicated boundary: assemble by all-reduce
+            full = torch.zeros(levels[l + 1].n_own, dtype=torch.float64)
+            full[torch.from_numpy(rep_gid)] = torch.from_numpy(R[l] @ r)
+            dist.all_reduce(full)
+            rH[:] = full.numpy()
+        else:
+            rH[: levels[l + 1].n_own] = R[l] @ r
         dxH = vec(l + 1)
         cycle(l + 1, dxH, rH)
         exchange(l + 1, dxH)
@@ -107,6 +112,7 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
 def main():
     mode, cells, nlev, out = sys.argv[1], tuple(int(c) for c in sys.argv[2].split("x")), int(sys.argv[3]), sys.argv[4]
     transport = sys.argv[5] if len(sys.argv) > 5 else "host"
+    rep_from = int(sys.argv[6]) if len(sys.argv) > 6 and int(sys.argv[6]) > 0 else None
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -120,7 +126,7 @@ def main():
     maxiter, atol, rtol = 20, 1e-14, 1e-6
     verdict = {}
     if mode == "numpy":
-        local = pa.build_local_hierarchy(cg, nlev, grid, rank, 1)
+        local = pa.build_local_hierarchy(cg, nlev, grid, rank, 1, None, rep_from)
         b = po.dirichlet_lift_rhs(cg, 1)[local["levels"][0].own_gid]
         x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol)
         gid = local["levels"][0].own_gid
@@ -128,7 +134,7 @@ def main():
         ndev = torch.cuda.device_count()
         dev = rank % max(ndev, 1)
         torch.cuda.set_device(dev)
-        g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None)
+        g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=rep_from)
         b = g.rhs_lin()
         x = np.zeros(g.n_own)
         log = g.cg_solve(b, x, maxiter, atol, rtol)

@@ -19,7 +19,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(mode, world, cells, nlev, tmp_path, transport="host", timeout=600):
+def _launch(mode, world, cells, nlev, tmp_path, transport="host", timeout=600, rep_from=0):
     out = os.path.join(str(tmp_path), f"verdict_{mode}_{world}.json")
     port = _free_port()
     procs = []
@@ -27,7 +27,7 @@ def _launch(mode, world, cells, nlev, tmp_path, transport="host", timeout=600):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode,
-                                       "x".join(map(str, cells)), str(nlev), out, transport], env=env,
+                                       "x".join(map(str, cells)), str(nlev), out, transport, str(rep_from)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     try:
@@ -48,9 +48,10 @@ def _check(v):
     assert v["l2_error_sq"] < 1e-8, v
 
 
-@pytest.mark.parametrize("world,cells,nlev", [(2, (8, 8, 8), 2), (4, (8, 8), 2), (8, (4, 4, 4), 2)])
-def test_partitioned_cg_gmg_numpy_gloo(world, cells, nlev, tmp_path):
-    _check(_launch("numpy", world, cells, nlev, tmp_path))
+@pytest.mark.parametrize("world,cells,nlev,rep", [(2, (8, 8, 8), 2, 0), (4, (8, 8), 2, 0), (8, (4, 4, 4), 2, 0), (8, (8, 8, 8), 3, 1)])
+def test_partitioned_cg_gmg_numpy_gloo(world, cells, nlev, rep, tmp_path):
+    """rep = first replicated level (0: only the coarsest)."""
+    _check(_launch("numpy", world, cells, nlev, tmp_path, rep_from=rep))
 
 
 def test_partition_operators_match_global(po, pkg):
@@ -59,7 +60,7 @@ def test_partition_operators_match_global(po, pkg):
     for nc, nlev, nranks in [((8, 8, 8), 2, 8), ((16, 8, 8), 2, 2), ((16, 16), 3, 4)]:
         grid = pa.rank_grid(nranks, len(nc))
         Hg = po.build_hierarchy(nc, nlev, 1)
-        locs = [pa.build_local_hierarchy(nc, nlev, grid, r, 1) for r in range(nranks)]
+        locs = [pa.build_local_hierarchy(nc, nlev, grid, r, 1, None, nlev) for r in range(nranks)]   # nothing replicated
         for l in range(nlev):
             N = Hg["mats"][l].shape[0]
             x = np.random.default_rng(l).uniform(-1, 1, N)
@@ -83,9 +84,9 @@ def test_partition_operators_match_global(po, pkg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,cells,nlev", [(2, (16, 16, 16), 3), (8, (8, 8, 8), 2), (4, (16, 16), 3)])
-def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, tmp_path):
-    v = _launch("gpu", world, cells, nlev, tmp_path, transport="host")
+@pytest.mark.parametrize("world,cells,nlev,rep", [(2, (16, 16, 16), 3, 0), (8, (8, 8, 8), 2, 0), (4, (16, 16), 3, 0), (2, (16, 16, 16), 4, 2), (8, (8, 8, 8), 3, 1)])
+def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_path):
+    v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep)
     _check(v)
     assert v["fgmres_iters"] <= v["iters"] + 1 and v["fgmres_vs_cg"] < 1e-5
 
