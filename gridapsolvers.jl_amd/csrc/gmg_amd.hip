@@ -328,9 +328,8 @@ struct gmg_solver {
   int use_vdict = 1;    // GMG_VDICT: 8-bit value dictionary when the matrix has <= 256 distinct values
   int sell_block = 0;   // GMG_SELL_BLOCK: 0 = auto (256 threads on big levels, 64 on small ones)
   int sell_un = 6;      // GMG_SELL_UN: independent (col,val,gather) triples in flight per lane
-  int tpb = 4;          // GMG_TPB: tiles per workgroup of the pipelined kernel
   int nt_loads = 1;     // GMG_NT: non-temporal matrix stream
-  int variant = 2;      // GMG_VARIANT: 0 multi-pass kernel, 1/3 single-pass (tile 2048/4096), 2/4 + one-gather sweep
+  int one_gather_sweep = 1;   // GMG_ONE_GATHER: sweep gathers s = w*Dinv*r (1) or r and Dinv (0)
   int tile = kTile;
 
   // profiling of the fused sweep
@@ -443,7 +442,7 @@ struct gmg_solver {
   // SELL-64 conversion (setup): slices of 64 rows, width = longest row of the slice.
   void build_sell(const HostCSR &H, DevCSR &D)
   {
-    if (!use_sell || variant == 0 || H.nrows == 0 || D.nnz == 0) return;
+    if (!use_sell || H.nrows == 0 || D.nnz == 0) return;
     const int64_t ns = (H.nrows + 63) / 64;
     std::vector<int64_t> soff((size_t)ns + 1, 0);
     for (int64_t sl = 0; sl < ns; ++sl) {
@@ -616,54 +615,14 @@ struct gmg_solver {
     return (int)std::max<int64_t>(1, std::min<int64_t>(g, 256 * 8));
   }
 
-  template <int EPI>
-  void launch_stream(const DevCSR &M, const StreamArgs &a)
-  {
-    if (M.nblocks == 0) return;
-    if (M.ptr64) hipLaunchKernelGGL((csr_stream_kernel<EPI, int64_t>), dim3(M.nblocks), dim3(kBlock), 0, stream, a);
-    else hipLaunchKernelGGL((csr_stream_kernel<EPI, int32_t>), dim3(M.nblocks), dim3(kBlock), 0, stream, a);
-    HIP_CHECK(hipGetLastError());
-  }
   template <int EPI, bool ONEG, bool EMIT_S>
   void launch_stream1(const DevCSR &M, const StreamArgs2 &a)
   {
     if (M.nblocks == 0) return;
     const dim3 g(M.nblocks), b(kBlock);
-    if (M.tile == 4096) {
-      if (M.ptr64) hipLaunchKernelGGL((csr_stream1_kernel<EPI, int64_t, 4096, ONEG, EMIT_S>), g, b, 0, stream, a);
-      else hipLaunchKernelGGL((csr_stream1_kernel<EPI, int32_t, 4096, ONEG, EMIT_S>), g, b, 0, stream, a);
-    } else {
-      if (M.ptr64) hipLaunchKernelGGL((csr_stream1_kernel<EPI, int64_t, 2048, ONEG, EMIT_S>), g, b, 0, stream, a);
-      else hipLaunchKernelGGL((csr_stream1_kernel<EPI, int32_t, 2048, ONEG, EMIT_S>), g, b, 0, stream, a);
-    }
+    if (M.ptr64) hipLaunchKernelGGL((csr_stream1_kernel<EPI, int64_t, 2048, ONEG, EMIT_S>), g, b, 0, stream, a);
+    else hipLaunchKernelGGL((csr_stream1_kernel<EPI, int32_t, 2048, ONEG, EMIT_S>), g, b, 0, stream, a);
     HIP_CHECK(hipGetLastError());
-  }
-  template <int EPI, bool ONEG>
-  void launch_pipe(const DevCSR &M, const StreamArgs2 &a2)
-  {
-    if (M.nblocks == 0) return;
-    StreamArgs3 a;
-    std::memset(&a, 0, sizeof(a));
-    a.rowptr = a2.rowptr; a.col = a2.col; a.val = a2.val; a.blk_row = a2.blk_row; a.blk_nz = M.blk_nz;
-    a.nblocks = M.nblocks; a.tpb = tpb; a.lanes_log2 = a2.lanes_log2; a.x_zero = a2.x_zero;
-    a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
-    const dim3 g((M.nblocks + tpb - 1) / tpb), b(kBlock);
-    if (nt_loads) {
-      if (M.ptr64) hipLaunchKernelGGL((csr_stream_pipe_kernel<EPI, int64_t, ONEG, true>), g, b, 0, stream, a);
-      else hipLaunchKernelGGL((csr_stream_pipe_kernel<EPI, int32_t, ONEG, true>), g, b, 0, stream, a);
-    } else {
-      if (M.ptr64) hipLaunchKernelGGL((csr_stream_pipe_kernel<EPI, int64_t, ONEG, false>), g, b, 0, stream, a);
-      else hipLaunchKernelGGL((csr_stream_pipe_kernel<EPI, int32_t, ONEG, false>), g, b, 0, stream, a);
-    }
-    HIP_CHECK(hipGetLastError());
-  }
-  StreamArgs base_args(const DevCSR &M) const
-  {
-    StreamArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.rowptr = M.rowptr; a.col = M.col; a.val = M.val; a.blk_row = M.blk_row;
-    a.nblocks = M.nblocks; a.lanes_log2 = M.lanes_log2; a.xcd_remap = xcd_remap;
-    return a;
   }
   StreamArgs2 base_args1(const DevCSR &M) const
   {
@@ -676,40 +635,32 @@ struct gmg_solver {
   // y = M x
   void spmv_set(const DevCSR &M, const double *x, double *y)
   {
-    if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; launch_stream<EPI_SET>(M, a); return; }
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y;
     if (M.sell) { launch_sell<EPI_SET, false>(M, a); return; }
-    if (variant >= 5) launch_pipe<EPI_SET, false>(M, a); else
     launch_stream1<EPI_SET, false, false>(M, a);
   }
   // y -= M x
   void spmv_sub(const DevCSR &M, const double *x, double *y)
   {
-    if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; launch_stream<EPI_SUB>(M, a); return; }
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y;
     if (M.sell) { launch_sell<EPI_SUB, false>(M, a); return; }
-    if (variant >= 5) launch_pipe<EPI_SUB, false>(M, a); else
     launch_stream1<EPI_SUB, false, false>(M, a);
   }
   // y = b - M x
   void spmv_resid(const DevCSR &M, const double *x, const double *b, double *y)
   {
-    if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; a.b = b; launch_stream<EPI_RESID>(M, a); return; }
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y; a.b = b;
     if (M.sell) { launch_sell<EPI_RESID, false>(M, a); return; }
-    if (variant >= 5) launch_pipe<EPI_RESID, false>(M, a); else
     launch_stream1<EPI_RESID, false, false>(M, a);
   }
   // y = M x ; x2 += y
   void spmv_addto(const DevCSR &M, const double *x, double *y, double *x2)
   {
-    if (variant == 0) { StreamArgs a = base_args(M); a.x = x; a.y = y; a.x2 = x2; launch_stream<EPI_ADDTO>(M, a); return; }
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y; a.x2 = x2;
     if (M.sell) { launch_sell<EPI_ADDTO, false>(M, a); return; }
-    if (variant >= 5) launch_pipe<EPI_ADDTO, false>(M, a); else
     launch_stream1<EPI_ADDTO, false, false>(M, a);
   }
-  bool one_gather() const { return variant == 2 || variant == 4 || variant == 6; }
+  bool one_gather() const { return one_gather_sweep != 0; }
   // fused Richardson-Jacobi sweep: x += w*Dinv*r_old ; r_new = r_old - A*(w*Dinv*r_old)
   // one-gather form: s_old = w*Dinv*r_old is an input, s_new = w*Dinv*r_new an output.
   void sweep(int l, const Smoother &S, double *x, const double *r_old, double *r_new, bool x_zero,
@@ -719,19 +670,15 @@ struct gmg_solver {
     if (comm.nranks > 1) exchange(l, const_cast<double *>(s_old ? s_old : r_old));
     const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();
     if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
-    if (variant == 0) {
-      StreamArgs a = base_args(L.A);
-      a.x = r_old; a.b = r_old; a.dinv = L.dinv; a.omega = S.omega; a.y = r_new; a.x2 = x; a.x_zero = x_zero ? 1 : 0;
-      launch_stream<EPI_SWEEP>(L.A, a);
-    } else {
+    {
       StreamArgs2 a = base_args1(L.A);
       a.b = r_old; a.dinv = L.dinv; a.omega = S.omega; a.y = r_new; a.x2 = x; a.x_zero = x_zero ? 1 : 0;
       if (L.A.sell) {
         if (s_old) { a.x = s_old; a.s_out = s_new; launch_sell<EPI_SWEEP, true>(L.A, a); }
         else { a.x = r_old; launch_sell<EPI_SWEEP, false>(L.A, a); }
       } else
-      if (s_old) { a.x = s_old; a.s_out = s_new; if (variant >= 5) launch_pipe<EPI_SWEEP, true>(L.A, a); else launch_stream1<EPI_SWEEP, true, false>(L.A, a); }
-      else { a.x = r_old; if (variant >= 5) launch_pipe<EPI_SWEEP, false>(L.A, a); else launch_stream1<EPI_SWEEP, false, false>(L.A, a); }
+      if (s_old) { a.x = s_old; a.s_out = s_new; launch_stream1<EPI_SWEEP, true, false>(L.A, a); }
+      else { a.x = r_old; launch_stream1<EPI_SWEEP, false, false>(L.A, a); }
     }
     if (prof) {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
@@ -1214,8 +1161,7 @@ void gmg_solver::setup()
   free_all();
   xcd_remap = env_int("GMG_XCD_REMAP", 0);   // measured: no gain from XCD-contiguous ranges (profiles/r01_tuning.md)
   lanes_override = env_int("GMG_LANES_LOG2", -1);
-  variant = env_int("GMG_VARIANT", 2);
-  tpb = std::max(1, env_int("GMG_TPB", 4));
+  one_gather_sweep = env_int("GMG_ONE_GATHER", 1);
   use_sell = env_int("GMG_SELL", 1);
   use_idx16 = env_int("GMG_IDX16", 1);
   use_vdict = env_int("GMG_VDICT", 1);
@@ -1223,7 +1169,7 @@ void gmg_solver::setup()
   sell_block = std::min(256, env_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
   if (const char *mp = std::getenv("GMG_SELL_MAXPAD")) sell_maxpad = std::atof(mp);
   nt_loads = env_int("GMG_NT", 1);
-  tile = (variant == 3 || variant == 4) ? 4096 : kTile;
+  tile = kTile;
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));
@@ -1260,7 +1206,7 @@ void gmg_solver::setup()
               "patch smoothers are single-GPU in this round (need assemble! of ghost rows, PatchSolvers.jl:254)");
   }
   if (comm.nranks > 1) {
-    variant = 2; tile = kTile;   // the one-gather sweep needs only s-ghosts
+    one_gather_sweep = 1;   // the one-gather sweep needs only s-ghosts
     for (int64_t g : h_rep_gid) REQUIRE(g >= 0 && g < lev[rep_from].n, GMG_ERR_INVALID, "replication: global id out of range");
   }
   d_partials = dvec(kRedBlocks);

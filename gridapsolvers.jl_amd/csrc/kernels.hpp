@@ -39,23 +39,6 @@ enum Epi : int {
   EPI_ADDTO = 4    // y = A x ; x2 += y            (K5)
 };
 
-struct StreamArgs {
-  const void *rowptr;     // int32 or int64 [nrows+1]
-  const int32_t *col;     // [nnz]
-  const double *val;      // [nnz]
-  const int32_t *blk_row; // [nblocks+1] first row of each workgroup's row range
-  int nblocks;
-  int lanes_log2;         // G = 1<<lanes_log2 lanes cooperate on one row in the reduce phase
-  int xcd_remap;          // 1: contiguous block ranges per XCD
-  const double *x;        // gather source
-  const double *dinv;     // EPI_SWEEP: D^-1
-  double omega;           // EPI_SWEEP
-  double *y;              // output
-  const double *b;        // EPI_RESID: b ; EPI_SWEEP: r_old (row-wise read)
-  double *x2;             // EPI_SWEEP: x (updated in place) ; EPI_ADDTO: x
-  int x_zero;             // EPI_SWEEP: x is known to be zero on entry (skip the read)
-};
-
 __device__ __forceinline__ int remap_block(int b, int nb, int on)
 {
   // Observed dispatch: workgroup b runs on XCD b % 8 (performance only, never
@@ -68,115 +51,8 @@ __device__ __forceinline__ int remap_block(int b, int nb, int on)
   return base + slot;
 }
 
-// One workgroup = one contiguous row range whose nnz fit the LDS tile.
-//
-// EPI_SWEEP fuses a whole sweep of RichardsonSmoothers.jl:90-97 with M = Jacobi:
-//     dx = omega .* (inv_diag .* r) ; x .= x .+ dx ; r .= r .- A*dx
-// dx is never materialised: the gather computes dx_j = omega*(dinv_j*r_old_j) on
-// the fly (same two roundings as the reference) and the new residual goes to a
-// second buffer (ping-pong), so one pass over A does the job of the reference's
-// five passes.
-template <int EPI, typename PtrT>
-__global__ __launch_bounds__(kBlock) void csr_stream_kernel(StreamArgs a)
-{
-  __shared__ double prod[kTile];
-  const int tid = threadIdx.x;
-  const int blk = remap_block(blockIdx.x, a.nblocks, a.xcd_remap);
-  const PtrT *__restrict__ rowptr = reinterpret_cast<const PtrT *>(a.rowptr);
-  const int r0 = a.blk_row[blk];
-  const int r1 = a.blk_row[blk + 1];
-  const PtrT nz0 = rowptr[r0];
-  const PtrT nz1 = rowptr[r1];
-  const int64_t cnt = (int64_t)(nz1 - nz0);
-  const int32_t *__restrict__ col = a.col;
-  const double *__restrict__ val = a.val;
-  const double *__restrict__ xg = a.x;
-
-  if (cnt <= kTile) {
-    // ---- phase 1: coalesced stream of (col,val), gather, products -> LDS ----
-    constexpr int U = kTile / kBlock; // 8 independent loads in flight per lane
-    int32_t c[U];
-    double v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = tid + u * kBlock;
-      const bool ok = k < cnt;
-      c[u] = ok ? __builtin_nontemporal_load(col + nz0 + k) : -1;
-      v[u] = ok ? __builtin_nontemporal_load(val + nz0 + k) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = tid + u * kBlock;
-      if (c[u] >= 0) {
-        double xv;
-        if (EPI == EPI_SWEEP) xv = a.omega * (a.dinv[c[u]] * xg[c[u]]);
-        else xv = xg[c[u]];
-        prod[k] = v[u] * xv;
-      }
-    }
-    __syncthreads();
-    // ---- phase 2: G lanes per row, strided LDS reads + shuffle tail ----
-    const int G = 1 << a.lanes_log2;
-    const int rows_per_pass = kBlock >> a.lanes_log2;
-    const int sub = tid & (G - 1);
-    for (int rbase = r0; rbase < r1; rbase += rows_per_pass) {
-      const int row = rbase + (tid >> a.lanes_log2);
-      double s = 0.0;
-      if (row < r1) {
-        const int k0 = (int)(rowptr[row] - nz0), k1 = (int)(rowptr[row + 1] - nz0);
-        for (int k = k0 + sub; k < k1; k += G) s += prod[k];
-      }
-      for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (row < r1 && sub == 0) {
-        if (EPI == EPI_SET) a.y[row] = s;
-        else if (EPI == EPI_SUB) a.y[row] = a.y[row] - s;
-        else if (EPI == EPI_RESID) a.y[row] = a.b[row] - s;
-        else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = a.x2[row] + s; }
-        else { // EPI_SWEEP
-          const double ro = a.b[row];
-          const double dxi = a.omega * (a.dinv[row] * ro);
-          const double xo = a.x_zero ? 0.0 : a.x2[row];
-          a.x2[row] = xo + dxi;
-          a.y[row] = ro - s;
-        }
-      }
-    }
-  } else {
-    // ---- long row: the range is a single row; whole workgroup strides it ----
-    double s = 0.0;
-    for (int64_t k = tid; k < cnt; k += kBlock) {
-      const int32_t cc = col[nz0 + k];
-      double xv;
-      if (EPI == EPI_SWEEP) xv = a.omega * (a.dinv[cc] * xg[cc]);
-      else xv = xg[cc];
-      s += val[nz0 + k] * xv;
-    }
-    prod[tid] = s;
-    __syncthreads();
-    for (int w = kBlock >> 1; w > 0; w >>= 1) {
-      if (tid < w) prod[tid] += prod[tid + w];
-      __syncthreads();
-    }
-    if (tid == 0) {
-      const int row = r0;
-      s = prod[0];
-      if (EPI == EPI_SET) a.y[row] = s;
-      else if (EPI == EPI_SUB) a.y[row] = a.y[row] - s;
-      else if (EPI == EPI_RESID) a.y[row] = a.b[row] - s;
-      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = a.x2[row] + s; }
-      else {
-        const double ro = a.b[row];
-        const double dxi = a.omega * (a.dinv[row] * ro);
-        const double xo = a.x_zero ? 0.0 : a.x2[row];
-        a.x2[row] = xo + dxi;
-        a.y[row] = ro - s;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
-// Single-pass CSR-stream kernel (the production path).
+// CSR-stream kernel: the generic path (ragged matrices such as P, rows longer than a tile).
 //
 // The host partitions the rows so that every workgroup owns <= (256 >> lanes_log2)
 // rows and <= TILE nnz (a row longer than TILE is a workgroup of its own).  Every
@@ -332,202 +208,6 @@ __global__ __launch_bounds__(kBlock) void csr_stream1_kernel(StreamArgs2 a)
       }
       if (EMIT_S || (EPI == EPI_SWEEP && ONEG)) a.s_out[row] = omega * (dinv[row] * rn);
     }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Software-pipelined CSR-stream kernel: one workgroup walks `tpb` consecutive tiles
-// and issues the coalesced (col,val) loads of tile t+1 right after the gathers of
-// tile t, so HBM requests stay in flight during the gather wait, the LDS reduce and
-// the epilogue of tile t (the single-tile kernel has nothing in flight then).
-// vmcnt accounting is in-order, hence the order: row-owner loads(t), gathers(t),
-// stream loads(t+1); the compiler can then wait for the gathers with vmcnt(#prefetch).
-// ---------------------------------------------------------------------------
-struct StreamArgs3 {
-  const void *rowptr;
-  const int32_t *col;
-  const double *val;
-  const int32_t *blk_row;
-  const int64_t *blk_nz;   // first nnz of every tile (cuts the blk_row -> rowptr dependency)
-  int nblocks;             // number of tiles
-  int tpb;                 // tiles per workgroup
-  int lanes_log2;
-  int x_zero;
-  const double *x;
-  const double *dinv;
-  double omega;
-  double *y;
-  const double *b;
-  double *x2;
-  double *s_out;
-};
-
-template <int EPI, typename PtrT, bool ONEG, bool NT>
-__global__ __launch_bounds__(kBlock) void csr_stream_pipe_kernel(StreamArgs3 a)
-{
-  constexpr int TILE = kTile;
-  constexpr int U = TILE / kBlock;
-  __shared__ double prod[TILE];
-  const int tid = threadIdx.x;
-  const PtrT *__restrict__ rowptr = reinterpret_cast<const PtrT *>(a.rowptr);
-  const int32_t *__restrict__ col = a.col;
-  const double *__restrict__ val = a.val;
-  const double *__restrict__ xg = a.x;
-  const double *__restrict__ dinv = a.dinv;
-  const double omega = a.omega;
-  const int lg = a.lanes_log2;
-  const int G = 1 << lg;
-  const int sub = tid & (G - 1);
-  const int slot = tid >> lg;
-
-  const int t_begin = blockIdx.x * a.tpb;
-  const int t_end = min(t_begin + a.tpb, a.nblocks);
-  if (t_begin >= t_end) return;
-
-  int32_t c[U];
-  double v[U];
-  int64_t nz0 = a.blk_nz[t_begin];
-  int64_t cnt = a.blk_nz[t_begin + 1] - nz0;
-  // prologue: stream loads of the first tile
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int k = tid + u * kBlock;
-    const bool ok = (k < cnt) && (cnt <= TILE);
-    if (NT) {
-      c[u] = ok ? __builtin_nontemporal_load(col + nz0 + k) : -1;
-      v[u] = ok ? __builtin_nontemporal_load(val + nz0 + k) : 0.0;
-    } else {
-      c[u] = ok ? col[nz0 + k] : -1;
-      v[u] = ok ? val[nz0 + k] : 0.0;
-    }
-  }
-
-  for (int t = t_begin; t < t_end; ++t) {
-    const int r0 = a.blk_row[t];
-    const int r1 = a.blk_row[t + 1];
-    // next tile's extent (uniform, scalar loads)
-    int64_t nz0n = 0, cntn = 0;
-    if (t + 1 < t_end) {
-      nz0n = a.blk_nz[t + 1];
-      cntn = a.blk_nz[t + 2] - nz0n;
-    }
-    if (cnt <= TILE) {
-      // ---- row-owner loads for tile t ----
-      const int row = r0 + slot;
-      const bool active = row < r1;
-      const bool owner = active && sub == 0;
-      int k0 = 0, k1 = 0;
-      double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
-      if (active) {
-        k0 = (int)((int64_t)rowptr[row] - nz0);
-        k1 = (int)((int64_t)rowptr[row + 1] - nz0);
-      }
-      if (owner) {
-        if (EPI == EPI_SUB) e0 = a.y[row];
-        else if (EPI == EPI_RESID) e0 = a.b[row];
-        else if (EPI == EPI_ADDTO) e0 = a.x2[row];
-        else if (EPI == EPI_SWEEP) {
-          e0 = a.b[row];                       // r_old
-          e1 = ONEG ? xg[row] : dinv[row];     // s_old | dinv
-          e2 = a.x_zero ? 0.0 : a.x2[row];     // x
-          if (ONEG) dinv_row = dinv[row];
-        }
-      }
-      // ---- gathers for tile t ----
-      double g[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int cc = c[u] >= 0 ? c[u] : 0;
-        if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (dinv[cc] * xg[cc]);
-        else g[u] = xg[cc];
-      }
-      // ---- stream loads for tile t+1 (stay in flight across the barrier) ----
-      int32_t cn[U];
-      double vn[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = tid + u * kBlock;
-        const bool ok = (k < cntn) && (cntn <= TILE);
-        if (NT) {
-          cn[u] = ok ? __builtin_nontemporal_load(col + nz0n + k) : -1;
-          vn[u] = ok ? __builtin_nontemporal_load(val + nz0n + k) : 0.0;
-        } else {
-          cn[u] = ok ? col[nz0n + k] : -1;
-          vn[u] = ok ? val[nz0n + k] : 0.0;
-        }
-      }
-      // ---- products -> LDS ----
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = tid + u * kBlock;
-        if (c[u] >= 0) prod[k] = v[u] * g[u];
-      }
-      __syncthreads();
-      double s = 0.0;
-      for (int k = k0 + sub; k < k1; k += G) s += prod[k];
-      for (int off = G >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
-      if (owner) {
-        double rn = 0.0;
-        if (EPI == EPI_SET) { a.y[row] = s; }
-        else if (EPI == EPI_SUB) { a.y[row] = e0 - s; }
-        else if (EPI == EPI_RESID) { a.y[row] = e0 - s; }
-        else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
-        else {
-          const double dxi = ONEG ? e1 : omega * (e1 * e0);
-          a.x2[row] = e2 + dxi;
-          rn = e0 - s;
-          a.y[row] = rn;
-          if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
-        }
-      }
-      __syncthreads(); // prod[] is rewritten by the next tile
-#pragma unroll
-      for (int u = 0; u < U; ++u) { c[u] = cn[u]; v[u] = vn[u]; }
-    } else {
-      // ---- long row (a tile of its own): whole workgroup strides it, no prefetch ----
-      double s = 0.0;
-      for (int64_t k = tid; k < cnt; k += kBlock) {
-        const int32_t cc = col[nz0 + k];
-        double xv;
-        if (EPI == EPI_SWEEP && !ONEG) xv = omega * (dinv[cc] * xg[cc]);
-        else xv = xg[cc];
-        s += val[nz0 + k] * xv;
-      }
-      prod[tid] = s;
-      __syncthreads();
-      for (int w = kBlock >> 1; w > 0; w >>= 1) {
-        if (tid < w) prod[tid] += prod[tid + w];
-        __syncthreads();
-      }
-      if (tid == 0) {
-        const int row = r0;
-        s = prod[0];
-        if (EPI == EPI_SET) { a.y[row] = s; }
-        else if (EPI == EPI_SUB) { a.y[row] = a.y[row] - s; }
-        else if (EPI == EPI_RESID) { a.y[row] = a.b[row] - s; }
-        else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = a.x2[row] + s; }
-        else {
-          const double ro = a.b[row];
-          const double dxi = ONEG ? xg[row] : omega * (dinv[row] * ro);
-          const double xo = a.x_zero ? 0.0 : a.x2[row];
-          a.x2[row] = xo + dxi;
-          const double rn = ro - s;
-          a.y[row] = rn;
-          if (ONEG) a.s_out[row] = omega * (dinv[row] * rn);
-        }
-      }
-      __syncthreads();
-      // stream loads of the next tile (not prefetched across a long row)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = tid + u * kBlock;
-        const bool ok = (k < cntn) && (cntn <= TILE);
-        c[u] = ok ? col[nz0n + k] : -1;
-        v[u] = ok ? val[nz0n + k] : 0.0;
-      }
-    }
-    nz0 = nz0n;
-    cnt = cntn;
   }
 }
 
@@ -716,54 +396,60 @@ __global__ __launch_bounds__(kBlock) void sellc_kernel(SellCArgs a)
   const int32_t *cp = a.scol + base + lane;
   const double *vp = a.sval + base + lane;
   double s = 0.0;
-  constexpr int PK = 2; // packs per iteration: 8 entries in flight per lane
-  for (int p0 = 0; p0 < npack; p0 += PK) {
-    int32_t c[4 * PK];
-    double v[4 * PK], g[4 * PK];
-    u32x2 iw[PK];
-    uint32_t kw[PK];
+  // The compressed stream is so small (12 B per 4 entries) that a lane can afford to request
+  // the packs of its WHOLE row at once (PB packs = 32 entries per round, 3 VGPRs per pack); the
+  // gathers then run in sub-batches of 8 behind a single HBM latency instead of one per batch.
+  constexpr int PB = 8;   // packs requested per round
+  constexpr int PK = 2;   // packs per gather batch (8 gathers in flight)
+  for (int r0 = 0; r0 < npack; r0 += PB) {
+    u32x2 iw[PB];
+    uint32_t kw[PB];
 #pragma unroll
-    for (int q = 0; q < PK; ++q) {
-      const int pk = (p0 + q < npack) ? p0 + q : npack - 1;   // clamp (masked below)
+    for (int q = 0; q < PB; ++q) {
+      const int pk = (r0 + q < npack) ? r0 + q : npack - 1;   // clamp (masked below)
       if (i16) iw[q] = NT ? __builtin_nontemporal_load(ip + (int64_t)pk * 64) : ip[(int64_t)pk * 64];
       if (VDICT) kw[q] = NT ? __builtin_nontemporal_load(kp + (int64_t)pk * 64) : kp[(int64_t)pk * 64];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = 4 * pk + u;
-        const int jc = j < w ? j : w - 1;
-        if (!i16) c[4 * q + u] = NT ? __builtin_nontemporal_load(cp + (int64_t)jc * 64) : cp[(int64_t)jc * 64];
-        if (!VDICT) v[4 * q + u] = NT ? __builtin_nontemporal_load(vp + (int64_t)jc * 64) : vp[(int64_t)jc * 64];
-      }
     }
 #pragma unroll
-    for (int q = 0; q < PK; ++q) {
-      const int pk = (p0 + q < npack) ? p0 + q : npack - 1;
+    for (int b0 = 0; b0 < PB; b0 += PK) {
+      if (r0 + b0 < npack) {   // wave-uniform
+        int32_t c[4 * PK];
+        double v[4 * PK], g[4 * PK];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = 4 * pk + u;
-        if (i16) {
-          const uint32_t word = (u < 2) ? iw[q].x : iw[q].y;
-          const int32_t off = (int32_t)((u & 1) ? (word >> 16) : (word & 0xffffu));
-          int32_t bj;
-          if (j < 64) bj = __builtin_amdgcn_readlane(mybase, j);
-          else bj = pbp[j];
-          c[4 * q + u] = bj + off;
+        for (int q = 0; q < PK; ++q) {
+          const int pk = (r0 + b0 + q < npack) ? r0 + b0 + q : npack - 1;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = 4 * pk + u;
+            const int jc = j < w ? j : w - 1;
+            if (i16) {
+              const uint32_t word = (u < 2) ? iw[b0 + q].x : iw[b0 + q].y;
+              const int32_t off = (int32_t)((u & 1) ? (word >> 16) : (word & 0xffffu));
+              int32_t bj;
+              if (j < 64) bj = __builtin_amdgcn_readlane(mybase, j);
+              else bj = pbp[j];
+              c[4 * q + u] = bj + off;
+            } else {
+              c[4 * q + u] = NT ? __builtin_nontemporal_load(cp + (int64_t)jc * 64) : cp[(int64_t)jc * 64];
+            }
+            if (VDICT) v[4 * q + u] = sdict[(kw[b0 + q] >> (8 * u)) & 0xffu];
+            else v[4 * q + u] = NT ? __builtin_nontemporal_load(vp + (int64_t)jc * 64) : vp[(int64_t)jc * 64];
+          }
         }
-        if (VDICT) v[4 * q + u] = sdict[(kw[q] >> (8 * u)) & 0xffu];
-      }
-    }
 #pragma unroll
-    for (int e = 0; e < 4 * PK; ++e) {
-      if (EPI == EPI_SWEEP && !ONEG) g[e] = omega * (dinv[c[e]] * xg[c[e]]);
-      else g[e] = xg[c[e]];
-    }
+        for (int e = 0; e < 4 * PK; ++e) {
+          if (EPI == EPI_SWEEP && !ONEG) g[e] = omega * (dinv[c[e]] * xg[c[e]]);
+          else g[e] = xg[c[e]];
+        }
 #pragma unroll
-    for (int q = 0; q < PK; ++q) {
+        for (int q = 0; q < PK; ++q) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = 4 * (p0 + q) + u;
-        const double pr = v[4 * q + u] * g[4 * q + u];
-        s = (p0 + q < npack && j < len) ? s + pr : s;
+          for (int u = 0; u < 4; ++u) {
+            const int j = 4 * (r0 + b0 + q) + u;
+            const double pr = v[4 * q + u] * g[4 * q + u];
+            s = (r0 + b0 + q < npack && j < len) ? s + pr : s;
+          }
+        }
       }
     }
   }

@@ -1,7 +1,7 @@
 """Kernel-variant timing harness (GPU box): python tools_tune.py  -> one line per variant."""
 import json, os, subprocess, sys
-VARIANTS = json.loads(os.environ.get("TUNE_VARIANTS", "[]")) or [dict(GMG_VARIANT=2, GMG_XCD_REMAP=0)]
-KEYS = ("GMG_VARIANT", "GMG_XCD_REMAP", "GMG_LANES_LOG2", "GMG_TPB", "GMG_NT")
+VARIANTS = json.loads(os.environ.get("TUNE_VARIANTS", "[]")) or [dict()]
+KEYS = ("GMG_ONE_GATHER", "GMG_XCD_REMAP", "GMG_LANES_LOG2", "GMG_NT", "GMG_SELL", "GMG_SELL_UN", "GMG_SELL_BLOCK", "GMG_SELL_MAXPAD", "GMG_VDICT", "GMG_IDX16")
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import numpy as np, torch
