@@ -126,4 +126,31 @@ __global__ __launch_bounds__(256) void dense_gemv_rect_kernel(int nrows, int nco
 }
 __global__ void sqrt_inplace_kernel(double *v) { v[0] = sqrt(v[0]); }
 
+// Rows that reference ghost columns ("boundary rows") finish their mat-vec after the halo has
+// arrived: g = sum_k val[k] * v[col[k]] over the row's ghost entries, then
+//   MODE 0: y[row] += g                         (y = A x)
+//   MODE 1: y[row] -= g                         (y -= A x ; y = b - A x)
+//   MODE 2: y[row] -= g ; s[row] = omega*(dinv[row]*y[row])   (fused sweep: r and s = w*Dinv*r)
+// The owned-column part ran while the exchange was in flight (own x own / own x ghost split of
+// the local matrix, the standard PartitionedArrays-style overlap).
+template <int MODE>
+__global__ void ghost_fix_kernel(int64_t nb, const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
+                                 const int32_t *__restrict__ col, const double *__restrict__ val,
+                                 const double *__restrict__ v, double *__restrict__ y, const double *__restrict__ dinv,
+                                 double omega, double *__restrict__ s_out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  double g = 0.0;
+  for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) g += val[k] * v[col[k]];
+  const int32_t row = rows[i];
+  if (MODE == 0) y[row] = y[row] + g;
+  else if (MODE == 1) y[row] = y[row] - g;
+  else {
+    const double rn = y[row] - g;
+    y[row] = rn;
+    s_out[row] = omega * (dinv[row] * rn);
+  }
+}
+
 } // namespace gmg

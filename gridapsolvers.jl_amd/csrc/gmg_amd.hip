@@ -165,6 +165,7 @@ struct DevCSR {
   int nslices = 0;
   int64_t zpad = 0;
   // compressed stream (SELL-C): 16-bit column offsets per slice column, 8-bit value codes
+  int64_t nnz_model = -1;   // nnz of the caller's operator when A was split (byte model)
   bool comp_idx = false, vdict = false;
   int64_t *poff = nullptr;
   uint16_t *pidx = nullptr;
@@ -209,6 +210,13 @@ struct Level {
   int64_t n = 0;                  // owned rows
   int64_t nvec = 0;               // vector length = owned + ghost
   HaloPlan halo;                  // neighbour exchange plan (multi-GPU)
+  // own x ghost part of A on the rows that have ghost columns (A itself then holds own x own only)
+  bool split = false;
+  int64_t nbnd = 0;
+  int32_t *gh_rows = nullptr;
+  int64_t *gh_ptr = nullptr;
+  int32_t *gh_col = nullptr;
+  double *gh_val = nullptr;
   double *x = nullptr;            // correction at this level (levels > 0)
   double *rbuf[2] = {nullptr, nullptr};
   double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
@@ -305,6 +313,9 @@ struct gmg_solver {
 
   // inter-GPU transport
   Comm comm;
+  hipStream_t comm_stream = nullptr;   // halo traffic overlapping the own x own mat-vec (RCCL only)
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  int overlap = 1;                     // GMG_OVERLAP
   double *cg_x = nullptr;       // solution with ghost space (distributed runs)
 
   // reductions
@@ -381,6 +392,7 @@ struct gmg_solver {
       L.A = DevCSR(); L.P = DevCSR(); L.R = DevCSR();
       L.dinv = L.x = L.dx = L.rcur = nullptr;
       L.rbuf[0] = L.rbuf[1] = nullptr;
+      L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
       L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pre.built = L.post.built = false;
     }
@@ -667,7 +679,7 @@ struct gmg_solver {
              const double *s_old = nullptr, double *s_new = nullptr)
   {
     Level &L = lev[l];
-    if (comm.nranks > 1) exchange(l, const_cast<double *>(s_old ? s_old : r_old));
+    if (comm.nranks > 1) begin_exchange(l, const_cast<double *>(s_old ? s_old : r_old));
     const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();
     if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
     {
@@ -684,6 +696,7 @@ struct gmg_solver {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
       prof_used += 2;
     }
+    if (comm.nranks > 1) finish_ghost<2>(l, s_old, r_new, S.omega, s_new);   // distributed => one-gather sweep
   }
 
   void copy(double *dst, const double *src, int64_t n)
@@ -732,7 +745,8 @@ struct gmg_solver {
     }
   }
   // consistent!(v): owner -> ghost copy of the level-l vector `v` (length nvec)
-  void exchange(int l, double *v)
+  void exchange(int l, double *v) { exchange_on(l, v, stream); }
+  void exchange_on(int l, double *v, hipStream_t stream)
   {
     HaloPlan &H = lev[l].halo;
     if (comm.nranks <= 1 || !H.present || H.nbr.empty()) return;
@@ -757,6 +771,51 @@ struct gmg_solver {
       comm.xfn(comm.ctx, (int)H.nbr.size(), H.nbr.data(), H.h_send, H.snd_ptr.data(), H.h_recv, H.rcv_ptr.data());
       if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(ghost, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, stream));
     }
+  }
+  // Split mat-vec with A_l: start the halo of `src`, (caller runs the own x own kernel), then
+  // finish the boundary rows.  With RCCL the exchange runs on comm_stream concurrently with the
+  // own x own kernel; with the host transport it is synchronous (same data flow, no overlap).
+  void begin_exchange(int l, double *src)
+  {
+    if (comm.nranks <= 1 || !lev[l].halo.present) return;
+    if (comm.kind == COMM_RCCL && overlap && comm_stream) {
+      HIP_CHECK(hipEventRecord(ev_ready, stream));
+      HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
+      exchange_on(l, src, comm_stream);
+      HIP_CHECK(hipEventRecord(ev_done, comm_stream));
+    } else {
+      exchange_on(l, src, stream);
+    }
+  }
+  template <int MODE>
+  void finish_ghost(int l, const double *src, double *y, double omega = 0.0, double *s_out = nullptr)
+  {
+    Level &L = lev[l];
+    if (comm.nranks <= 1 || !L.halo.present) return;
+    if (comm.kind == COMM_RCCL && overlap && comm_stream) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
+    if (!L.split || L.nbnd == 0) return;
+    hipLaunchKernelGGL((ghost_fix_kernel<MODE>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
+                       L.gh_ptr, L.gh_col, L.gh_val, src, y, L.dinv, omega, s_out);
+    HIP_CHECK(hipGetLastError());
+  }
+  // y = A_l x ; y -= A_l x ; y = b - A_l x   with the halo of x folded in
+  void apply_A_set(int l, double *x, double *y)
+  {
+    begin_exchange(l, x);
+    spmv_set(lev[l].A, x, y);
+    finish_ghost<0>(l, x, y);
+  }
+  void apply_A_sub(int l, double *x, double *y)
+  {
+    begin_exchange(l, x);
+    spmv_sub(lev[l].A, x, y);
+    finish_ghost<1>(l, x, y);
+  }
+  void apply_A_resid(int l, double *x, const double *b, double *y)
+  {
+    begin_exchange(l, x);
+    spmv_resid(lev[l].A, x, b, y);
+    finish_ghost<1>(l, x, y);
   }
   double fetch_scalar(int slot)
   {
@@ -822,8 +881,7 @@ struct gmg_solver {
     if (x_zero) zero(x, n);
     for (int it = 0; it < S.niter; ++it) {
       patch_precond(L, S, r, S.omega, true, L.dx, x);      // :91-93
-      exchange(l, L.dx);
-      spmv_sub(L.A, L.dx, r);                              // :94-95
+      apply_A_sub(l, L.dx, r);                             // :94-95
     }
     return r;
   }
@@ -883,8 +941,7 @@ struct gmg_solver {
       cycle(l + 1, C.x, C.rbuf[0], true, child);           // :488
       exchange(l + 1, C.x);
       spmv_addto(L.P, C.x, L.dx, x);                       // :491,494 dxh = P dxH ; xh += dxh
-      exchange(l, L.dx);
-      spmv_sub(L.A, L.dx, r);                              // :495-496 rh -= Ah dxh
+      apply_A_sub(l, L.dx, r);                             // :495-496 rh -= Ah dxh
     }
     r = smooth(l, L.post, x, r, false);                    // :499
     L.rcur = r;
@@ -903,8 +960,7 @@ struct gmg_solver {
       x_zero = true;  // fill!(x,0) folded into the first sweep
       r_in = b;       // copy!(rh,b) folded: the first sweep reads b, writes rh
     } else {                                               // :621-625
-      exchange(0, x);                                      // callers pass x with ghost space when distributed
-      spmv_resid(L0.A, x, b, L0.rbuf[0]);
+      apply_A_resid(0, x, b, L0.rbuf[0]);                  // callers pass x with ghost space when distributed
       r_in = L0.rbuf[0];
       x_zero = false;
     }
@@ -1214,6 +1270,30 @@ void gmg_solver::setup()
   if (!h_scalars) HIP_CHECK(hipHostMalloc((void **)&h_scalars, kScalarSlots * sizeof(double)));
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
+    if (L.halo.present && comm.nranks > 1) {
+      // own x own / own x ghost split: A keeps the owned columns, the ghost columns of the rows
+      // that have any go to a small CSR applied after the halo has arrived (finish_ghost)
+      HostCSR loc;
+      loc.nrows = L.hA.nrows; loc.ncols = L.hA.ncols;
+      loc.ptr.assign((size_t)L.n + 1, 0);
+      std::vector<int32_t> brows, bcol;
+      std::vector<int64_t> bptr(1, 0);
+      std::vector<double> bval;
+      for (int64_t i = 0; i < L.n; ++i) {
+        bool any = false;
+        for (int64_t k = L.hA.ptr[i]; k < L.hA.ptr[i + 1]; ++k) {
+          if (L.hA.col[k] < L.n) { loc.col.push_back(L.hA.col[k]); loc.val.push_back(L.hA.val[k]); }
+          else { bcol.push_back(L.hA.col[k]); bval.push_back(L.hA.val[k]); any = true; }
+        }
+        loc.ptr[i + 1] = (int64_t)loc.col.size();
+        if (any) { brows.push_back((int32_t)i); bptr.push_back((int64_t)bcol.size()); }
+      }
+      L.split = true;
+      L.nbnd = (int64_t)brows.size();
+      L.gh_rows = upload(brows); L.gh_ptr = upload(bptr); L.gh_col = upload(bcol); L.gh_val = upload(bval);
+      L.A = upload_csr(loc);
+      L.A.nnz_model = L.hA.nnz();
+    } else
     L.A = upload_csr(L.hA);                                 // :185 gmg_compute_matrices
     L.rbuf[0] = dvec(L.nvec);                               // :187,188 rh / rH
     if (l > 0) L.x = dvec(L.nvec);                          // :188 dxH
@@ -1351,7 +1431,11 @@ int gmg_destroy(gmg_handle_t h)
     if (L.halo.h_recv) (void)hipHostFree(L.halo.h_recv);
   }
   if (h->h_rep_full) (void)hipHostFree(h->h_rep_full);
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->comm.kind == COMM_RCCL && h->comm.comm) (void)h->comm.api.CommDestroy(h->comm.comm);
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
   if (h->h_scalars) (void)hipHostFree(h->h_scalars);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1507,8 +1591,7 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
     ConvLog log;
     log.configure(maxiter, atol, rtol);
 
-    S.exchange(0, dx);
-    S.spmv_resid(L0.A, dx, db, r);                         // CGSolvers.jl:79  w = A x ; r = b - w
+    S.apply_A_resid(0, dx, db, r);                         // CGSolvers.jl:79  w = A x ; r = b - w
     S.zero(p, n);                                          // :80
     S.zero(z, n);                                          // :81
     double gamma = 1.0, beta = 0.0, alpha = 0.0;           // :82
@@ -1529,8 +1612,7 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
       }
       hipLaunchKernelGGL(xpby_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, S.stream, n, z, beta, p); // :101
       HIP_CHECK(hipGetLastError());
-      S.exchange(0, p);
-      S.spmv_set(L0.A, p, w);                              // :104
+      S.apply_A_set(0, p, w);                              // :104
       alpha = gamma / S.dot(n, p, w);                      // :105
       hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, alpha, p, w, dx, r, S.d_partials); // :108-109
       HIP_CHECK(hipGetLastError());
@@ -1578,8 +1660,7 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
     const int grid = gmg_solver::grid_for(n);
 
     // krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 ; FGMRESSolvers.jl:136-140
-    S.exchange(0, dx);
-    S.spmv_resid(L0.A, dx, db, V[0]);
+    S.apply_A_resid(0, dx, db, V[0]);
     double beta = S.norm(n, V[0]);                         // :141
     bool done = log.init(beta);                            // :142
     while (!done) {
@@ -1596,8 +1677,7 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
         double *Vn = V[j], *Zj = Z[j - 1];
         // krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25
         S.krylov_precond(use_precond, Zj, V[j - 1], -1.0);
-        S.exchange(0, Zj);
-        S.spmv_set(L0.A, Zj, Vn);                          // :159
+        S.apply_A_set(0, Zj, Vn);                          // :159
         for (int i = 1; i <= j; ++i) {                     // :160-163 modified Gram-Schmidt
           S.dot_async(n, Vn, V[i - 1], i, false);
           hipLaunchKernelGGL(axmy_dev_kernel, dim3(grid), dim3(256), 0, S.stream, n, S.d_scalars + i, V[i - 1], Vn);
@@ -1646,8 +1726,7 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
         hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, g[i - 1], Z[i - 1], dx);
         HIP_CHECK(hipGetLastError());
       }
-      S.exchange(0, dx);
-      S.spmv_resid(L0.A, dx, db, V[0]);                    // :194
+      S.apply_A_resid(0, dx, db, V[0]);                    // :194
     }
     S.out_vec(x, dx, n, memspace);
     log.export_to(res, hist, hist_cap, beta);              // :197
@@ -1669,8 +1748,11 @@ int gmg_op_apply(gmg_handle_t h, int lev, int op, const double *x, double *y, in
       double *sx = h->scratch_vec(0, h->lev[0].nvec);
       HIP_CHECK(hipMemcpyAsync(sx, x, sizeof(double) * (size_t)h->lev[src].n,
                                memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
-      h->exchange(src, sx);
-      dxv = sx;
+      double *dy = memspace == GMG_MEM_DEVICE ? y : h->scratch_vec(1, h->lev[0].nvec);
+      if (op == GMG_OP_A) h->apply_A_set(lev, sx, dy);      // own x own kernel overlapping the halo + boundary rows
+      else { h->exchange(src, sx); h->spmv_set(*M, sx, dy); }
+      h->out_vec(y, dy, M->nrows, memspace);
+      return;
     } else {
       dxv = h->in_vec(x, M->ncols, memspace, h->scratch_vec(0, h->lev[0].nvec));
     }
@@ -1770,6 +1852,10 @@ int gmg_comm_init_rccl(gmg_handle_t h, const char *rccl_path, const char *unique
     const int rc = h->comm.api.CommInitRank(&h->comm.comm, nranks, id, rank);
     REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclCommInitRank: ") + h->comm.api.GetErrorString(rc));
     h->comm.kind = COMM_RCCL; h->comm.rank = rank; h->comm.nranks = nranks;
+    h->overlap = env_int("GMG_OVERLAP", 1);
+    if (!h->comm_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    if (!h->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    if (!h->ev_done) HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
     h->setup_done = false;
   });
 }
@@ -1887,10 +1973,10 @@ int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
     out->launches = h->prof_launches;
     out->total_ms = h->prof_ms;
     out->rows = L.n;
-    out->nnz = L.A.nnz;
+    out->nnz = L.A.nnz_model >= 0 ? L.A.nnz_model : L.A.nnz;
     // B_sweep = 12 Z + 68 N  (fp64 value + int32 column per nnz; row pointer,
     // r, D^-1, x, dx read / dx, x, Adx, r written as in RichardsonSmoothers.jl:91-95)
-    out->alg_bytes = 12.0 * (double)L.A.nnz + 68.0 * (double)L.n;
+    out->alg_bytes = 12.0 * (double)out->nnz + 68.0 * (double)L.n;
   });
 }
 
