@@ -409,7 +409,7 @@ struct gmg_solver {
   {
     DevCSR D;
     D.nrows = H.nrows; D.ncols = H.ncols; D.nnz = H.nnz();
-    D.ptr64 = D.nnz >= (int64_t)INT32_MAX;
+    D.ptr64 = D.nnz >= (int64_t)INT32_MAX || env_int("GMG_FORCE_PTR64", 0) != 0;   // 64-bit row pointers for >= 2^31 nnz (config 3 scale)
     if (D.ptr64) D.rowptr = upload(H.ptr);
     else {
       std::vector<int32_t> p32(H.ptr.begin(), H.ptr.end());

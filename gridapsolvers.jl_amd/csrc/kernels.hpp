@@ -1,16 +1,19 @@
 // kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the GMG hot path.
 //
-// All kernels are HBM-bandwidth bound (~0.16 flop/byte): no MFMA.  Design rules
-// (cdna_hip_programming.md / MI355X_MICROARCH.md):
-//   * matrix streams (12 B/nnz) are read with perfectly coalesced, block-wide
-//     loads into registers, multiplied with the gathered vector entry and the
-//     products staged in LDS ("CSR-stream"); rows are then reduced by G lanes
-//     each with a wave64 shuffle (__shfl_xor) tail;
-//   * the gathered vectors (x, r, D^-1) live in L2 / Infinity Cache; the
-//     blockIdx -> row-range map is XCD-aware so that each XCD's private L2 sees
-//     one contiguous window of them;
-//   * element-wise work of the reference's Richardson sweep is fused into the
-//     SpMV epilogue / gather (see csr_stream_kernel EPI_SWEEP).
+// All kernels are HBM-bandwidth bound (~0.16 flop/byte): no MFMA.  Three operator layouts,
+// all produced at setup from the caller's CSR/CSC (profiles/r01_tuning.md has the numbers):
+//   * SELL-64 (`sell_kernel`): lane = row, slices of 64 rows stored column-major, so the
+//     (col,val) stream, the row-wise operands and (for banded matrices) the gather are all
+//     coalesced; no LDS, barrier or shuffle; rows summed left to right (bit-identical to a
+//     sequential CPU SpMV).  Chosen when the padding is small.
+//   * SELL-C (`sellc_kernel`): the same kernel fed by a losslessly compressed stream -- 8-bit
+//     value dictionary (LDS) + 16-bit column offsets per slice column: 12 -> 3 B/nnz.
+//   * CSR-stream (`csr_stream1_kernel`): block-wide coalesced loads of a 2048-nnz tile,
+//     products staged in LDS, G lanes per row with a wave64 __shfl_xor tail -- the generic
+//     path for ragged matrices (P) and rows longer than a tile.
+// Element-wise work of the reference's Richardson sweep is fused into the mat-vec
+// (EPI_SWEEP); the gathered vector lives in L2 / Infinity Cache, the matrix stream is read
+// with non-temporal loads when it is larger than the cache.
 //
 // Reference operations realised here (GridapSolvers.jl v0.7.1, src/):
 //   K1 mul!(y,A,x)            LinearSolvers/RichardsonSmoothers.jl:94, GMGLinearSolvers.jl:495, CGSolvers.jl:79,104
@@ -125,9 +128,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream1_kernel(StreamArgs2 a)
         e0 = a.b[row];                               // r_old
         e1 = ONEG ? xg[row] : dinv[row];             // s_old | dinv
         e2 = a.x_zero ? 0.0 : a.x2[row];             // x
-        if (ONEG) e0 = a.b[row];
       }
-      if ((EMIT_S || (EPI == EPI_SWEEP && ONEG)) && !(EPI == EPI_SWEEP && !ONEG)) { /* dinv needed for s_new */ }
     }
     double dinv_row = 0.0;
     if (owner && (EMIT_S || (EPI == EPI_SWEEP && ONEG))) dinv_row = dinv[row];

@@ -480,3 +480,28 @@ def test_numerical_setup_bang_updates_values(S, po, orc, hierarchy):
     go = orc.GMG(H2["mats"], H2["prolongations"], H2["restrictions"], maxiter=1)
     xo, nit, _, _ = orc.cg_solve(A2, b, Pl=go, maxiter=30, atol=1e-14, rtol=1e-10)
     assert solver.log.num_iters == nit and rel_err(x2, xo) < 1e-10
+
+
+def test_int64_row_pointer_path(S, po, orc, hierarchy, monkeypatch):
+    """Matrices with >= 2^31 stored entries (config 3: 8.5e9 nnz) need 64-bit row pointers; the code path is
+    forced here on a small hierarchy (CSR-stream kernels, D^-1 extraction and patch-block extraction all take
+    the pointer type as a template parameter)."""
+    monkeypatch.setenv("GMG_FORCE_PTR64", "1")
+    monkeypatch.setenv("GMG_SELL", "0")
+    nc, nlev, order = (8, 8, 8), 2, 2
+    H = hierarchy(nc, nlev, order)
+    pp, pd = po.vertex_star_patches(nc, order)
+    gmg = make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2)])
+    ns = setup(S, gmg, H["mats"][0])
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd)], maxiter=1)
+    r = seeded(H["mats"][0].shape[0], 19)
+    z = np.zeros_like(r)
+    S.solve_(z, ns, r)
+    assert rel_err(z, go.solve(r)[0]) <= TOL_VCYCLE
+    H1 = hierarchy((16, 16, 16), 3)
+    b = po.dirichlet_lift_rhs((16, 16, 16), 1)
+    solver = S.CGSolver(make_gmg(S, H1), maxiter=20, atol=1e-14, rtol=1e-6)
+    x = np.zeros_like(b); S.solve_(x, setup(S, solver, H1["mats"][0]), b)
+    g1 = orc.GMG(H1["mats"], H1["prolongations"], H1["restrictions"], maxiter=1)
+    xo, nit, _, hist = orc.cg_solve(H1["mats"][0], b, Pl=g1, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert solver.log.num_iters == nit and rel_err(x, xo) <= 1e-10
