@@ -195,6 +195,12 @@ struct Smoother {
   int32_t *d_pdofs = nullptr;
   int64_t *d_boff = nullptr;
   double *d_binv = nullptr;
+  // de-duplicated blocks (uniform meshes): patch -> unique block id, compact block store
+  bool dedup = false;
+  int64_t nuniq = 0;
+  int32_t *d_ublock = nullptr;
+  int64_t *d_uboff = nullptr;
+  double *d_ubinv = nullptr;
   int64_t *d_iptr = nullptr, *d_inc = nullptr;
   double *d_contrib = nullptr;
   bool built = false;
@@ -463,7 +469,25 @@ struct gmg_solver {
       soff[sl + 1] = soff[sl] + w * 64;
     }
     const int64_t zp = soff[ns];
-    if ((double)zp > sell_maxpad * (double)D.nnz) return;   // ragged matrix: keep the CSR-stream kernel
+    if ((double)zp > sell_maxpad * (double)D.nnz) {
+      // Ragged matrix.  SELL still wins when the stream compresses (<= 256 distinct values): a padded
+      // entry then costs ~3 B instead of the 12 B a real entry costs in CSR (e.g. Q2 stiffness matrices:
+      // padding 1.65, 38 distinct values).  Otherwise keep the CSR-stream kernel.
+      bool few_values = use_vdict != 0;
+      if (few_values) {
+        std::vector<uint64_t> keys;
+        for (int64_t k = 0; k < (int64_t)H.val.size() && few_values; ++k) {
+          uint64_t bits;
+          std::memcpy(&bits, &H.val[k], 8);
+          auto it = std::lower_bound(keys.begin(), keys.end(), bits);
+          if (it == keys.end() || *it != bits) {
+            if (keys.size() == 256) few_values = false;
+            else keys.insert(it, bits);
+          }
+        }
+      }
+      if (!few_values || 4.0 * (double)zp > 0.8 * 12.0 * (double)D.nnz) return;
+    }
     std::vector<int32_t> scol((size_t)zp), rowlen((size_t)H.nrows);
     std::vector<double> sval((size_t)zp, 0.0);
     for (int64_t sl = 0; sl < ns; ++sl) {
@@ -1087,6 +1111,57 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
     HIP_CHECK(hipStreamSynchronize(stream));
     (void)hipFree(scratch);
     REQUIRE(nsing == 0, GMG_ERR_SINGULAR, "singular patch block (BlockJacobiSolvers.jl:163 'Factorization failed')");
+    // ---- de-duplicate bitwise-identical inverse blocks (lossless; SURVEY 7 "patch-factor de-duplication") ----
+    if (env_int("GMG_PATCH_DEDUP", 1) && max_np <= 32 && npatch >= 64) {
+      unsigned long long *d_hash = nullptr;
+      HIP_CHECK(hipMalloc((void **)&d_hash, sizeof(unsigned long long) * (size_t)npatch));
+      hipLaunchKernelGGL(block_hash_kernel, dim3((unsigned)((npatch + 255) / 256)), dim3(256), 0, stream, npatch, S.d_pptr, S.d_boff, S.d_binv, d_hash);
+      HIP_CHECK(hipGetLastError());
+      std::vector<unsigned long long> hash((size_t)npatch);
+      HIP_CHECK(hipMemcpyAsync(hash.data(), d_hash, sizeof(unsigned long long) * (size_t)npatch, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      (void)hipFree(d_hash);
+      std::vector<int64_t> order((size_t)npatch);
+      for (int64_t p = 0; p < npatch; ++p) order[p] = p;
+      std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return hash[a] != hash[b] ? hash[a] < hash[b] : a < b; });
+      std::vector<int64_t> rep((size_t)npatch);
+      std::vector<int32_t> ublock((size_t)npatch, 0);
+      std::vector<int64_t> reps;   // representative patch of every unique block
+      for (int64_t i = 0; i < npatch; ++i) {
+        const int64_t p = order[i];
+        if (i == 0 || hash[p] != hash[order[i - 1]]) reps.push_back(p);
+        rep[p] = reps.back();
+        ublock[p] = (int32_t)(reps.size() - 1);
+      }
+      if ((int64_t)reps.size() * 4 <= npatch) {
+        int64_t *d_rep = upload(rep);
+        int *d_nmis = dalloc<int>(1);
+        HIP_CHECK(hipMemsetAsync(d_nmis, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(block_verify_kernel, dim3((unsigned)((npatch + 255) / 256)), dim3(256), 0, stream, npatch, S.d_pptr, S.d_boff, S.d_binv, d_rep, d_nmis);
+        HIP_CHECK(hipGetLastError());
+        int nmis = 0;
+        HIP_CHECK(hipMemcpyAsync(&nmis, d_nmis, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (nmis == 0) {   // no hash collision: every patch is bitwise equal to its representative
+          const int64_t nu = (int64_t)reps.size();
+          std::vector<int64_t> src((size_t)nu), dst((size_t)nu + 1, 0);
+          for (int64_t u = 0; u < nu; ++u) {
+            const int64_t np = S.h_pptr[reps[u] + 1] - S.h_pptr[reps[u]];
+            src[u] = boff[reps[u]];
+            dst[u + 1] = dst[u] + np * np;
+          }
+          int64_t *d_src = upload(src);
+          S.d_uboff = upload(dst);
+          S.d_ubinv = dalloc<double>((size_t)dst[nu]);
+          hipLaunchKernelGGL(block_compact_kernel, dim3((unsigned)nu), dim3(64), 0, stream, nu, d_src, S.d_uboff, S.d_binv, S.d_ubinv);
+          HIP_CHECK(hipGetLastError());
+          S.d_ublock = upload(ublock);
+          S.nuniq = nu;
+          S.dedup = true;
+          HIP_CHECK(hipStreamSynchronize(stream));
+        }
+      }
+    }
   }
   S.built = true;
 }
@@ -1095,7 +1170,11 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
 void gmg_solver::patch_precond(Level &L, Smoother &S, const double *r, double omega, bool relax, double *dx, double *x)
 {
   if (S.npatch > 0) {
-    if (S.max_np <= 64) {
+    if (S.dedup) {
+      const int grid = (int)((S.npatch + kPatchChunk - 1) / kPatchChunk);
+      hipLaunchKernelGGL(patch_apply_dedup_kernel, dim3(grid), dim3(kBlock), 0, stream, S.npatch, S.d_pptr, S.d_pdofs, S.d_ublock,
+                         S.d_uboff, S.d_ubinv, r, S.d_contrib);
+    } else if (S.max_np <= 64) {
       const int grid = (int)((S.npatch + 3) / 4);
       hipLaunchKernelGGL(patch_apply_kernel, dim3(grid), dim3(kBlock), 0, stream, S.npatch, S.d_pptr, S.d_pdofs, S.d_boff,
                          S.d_binv, r, S.d_contrib);

@@ -724,6 +724,91 @@ __global__ __launch_bounds__(kBlock) void patch_apply_kernel(int64_t npatch, con
   }
 }
 
+// ---- patch-block de-duplication (uniform meshes: a handful of distinct blocks) -------------
+// 64-bit hash of every inverse block (bit patterns, FNV-1a style), one thread per patch.
+__global__ void block_hash_kernel(int64_t npatch, const int64_t *__restrict__ pptr, const int64_t *__restrict__ boff,
+                                  const double *__restrict__ binv, unsigned long long *__restrict__ hash)
+{
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npatch) return;
+  const int np = (int)(pptr[p + 1] - pptr[p]);
+  const unsigned long long *b = reinterpret_cast<const unsigned long long *>(binv + boff[p]);
+  unsigned long long h = 1469598103934665603ull ^ (unsigned long long)np;
+  for (int k = 0; k < np * np; ++k) { h ^= b[k]; h *= 1099511628211ull; }
+  hash[p] = h;
+}
+// bitwise comparison of every block with its group's representative (hash collisions -> mismatch)
+__global__ void block_verify_kernel(int64_t npatch, const int64_t *__restrict__ pptr, const int64_t *__restrict__ boff,
+                                    const double *__restrict__ binv, const int64_t *__restrict__ rep, int *__restrict__ nmis)
+{
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npatch) return;
+  const int64_t q = rep[p];
+  if (q == p) return;
+  const int np = (int)(pptr[p + 1] - pptr[p]);
+  const unsigned long long *a = reinterpret_cast<const unsigned long long *>(binv + boff[p]);
+  const unsigned long long *b = reinterpret_cast<const unsigned long long *>(binv + boff[q]);
+  bool same = (pptr[q + 1] - pptr[q]) == np;
+  for (int k = 0; k < np * np && same; ++k) same = a[k] == b[k];
+  if (!same) atomicAdd(nmis, 1);
+}
+// gather the representatives' blocks into the compact store
+__global__ void block_compact_kernel(int64_t nuniq, const int64_t *__restrict__ src_off, const int64_t *__restrict__ dst_off,
+                                     const double *__restrict__ binv, double *__restrict__ ubinv)
+{
+  const int64_t u = blockIdx.x;
+  const int64_t len = dst_off[u + 1] - dst_off[u];
+  for (int64_t k = threadIdx.x; k < len; k += blockDim.x) ubinv[dst_off[u] + k] = binv[src_off[u] + k];
+}
+
+// De-duplicated patch solve.  A workgroup walks CHUNK consecutive patches; the block of the
+// chunk's first patch is cached in LDS (on a uniform mesh almost every patch of the chunk
+// shares it) and each half-wave (32 lanes, n_p <= 32) solves one patch per step:
+// lane = row of the block, b_p staged in LDS.  Blocks that differ from the cached one are
+// read from the compact store (a few KB in L2).
+constexpr int kPatchChunk = 64;
+__global__ __launch_bounds__(kBlock) void patch_apply_dedup_kernel(int64_t npatch, const int64_t *__restrict__ pptr,
+                                                                   const int32_t *__restrict__ pdofs,
+                                                                   const int32_t *__restrict__ ublock,
+                                                                   const int64_t *__restrict__ uboff,
+                                                                   const double *__restrict__ ubinv,
+                                                                   const double *__restrict__ b,
+                                                                   double *__restrict__ contrib)
+{
+  __shared__ double sB[32 * 32];
+  __shared__ double sb[8][32];
+  const int64_t p0 = (int64_t)blockIdx.x * kPatchChunk;
+  const int64_t p1 = min(p0 + (int64_t)kPatchChunk, npatch);
+  const int cached = ublock[p0];
+  const int64_t co = uboff[cached];
+  const int clen = (int)(uboff[cached + 1] - co);
+  for (int k = threadIdx.x; k < clen; k += kBlock) sB[k] = ubinv[co + k];
+  __syncthreads();
+  const int hw = threadIdx.x >> 5, lane = threadIdx.x & 31;   // 8 half-waves
+  for (int64_t p = p0 + hw; p < p1; p += 8) {
+    const int64_t q0 = pptr[p];
+    const int np = (int)(pptr[p + 1] - q0);
+    if (np == 0) continue;
+    if (lane < np) sb[hw][lane] = b[pdofs[q0 + lane]];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ub = ublock[p];
+    if (lane < np) {
+      double s = 0.0;
+      if (ub == cached) {
+        const double *row = sB + lane * np;
+        for (int k = 0; k < np; ++k) s += row[k] * sb[hw][k];
+      } else {
+        const double *row = ubinv + uboff[ub] + (size_t)lane * np;
+        for (int k = 0; k < np; ++k) s += row[k] * sb[hw][k];
+      }
+      contrib[q0 + lane] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Generic fallback for patches with n_p > 64: one workgroup per patch.
 __global__ __launch_bounds__(kBlock) void patch_apply_big_kernel(int64_t npatch, const int64_t *__restrict__ pptr,
                                                                  const int32_t *__restrict__ pdofs,
