@@ -603,7 +603,7 @@ struct gmg_solver {
     SellCArgs a;
     std::memset(&a, 0, sizeof(a));
     a.soff = M.soff; a.poff = M.poff; a.scol = M.scol; a.sval = M.sval; a.pidx = M.pidx; a.pcode = M.pcode; a.pbase = M.pbase;
-    a.smode = M.smode; a.dict = M.dict; a.rowlen = M.rowlen; a.nrows = M.nrows; a.nslices = M.nslices;
+    a.smode = M.smode; a.dict = M.dict; a.rowlen = M.rowlen; a.nrows = M.nrows; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
     a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
     const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
     const dim3 g((M.nslices + wpb - 1) / wpb), b(64 * wpb);
@@ -623,7 +623,7 @@ struct gmg_solver {
     if (M.comp_idx || M.vdict) { launch_sellc<EPI, ONEG>(M, a2); return; }
     SellArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.soff = M.soff; a.scol = M.scol; a.sval = M.sval; a.rowlen = M.rowlen; a.nrows = M.nrows; a.nslices = M.nslices;
+    a.soff = M.soff; a.scol = M.scol; a.sval = M.sval; a.rowlen = M.rowlen; a.nrows = M.nrows; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
     a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
     // one wave per slice; small levels get single-wave workgroups so that they spread over all CUs
     const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);

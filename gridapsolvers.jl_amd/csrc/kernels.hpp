@@ -232,6 +232,7 @@ struct SellArgs {
   int64_t nrows;
   int nslices;
   int x_zero;
+  int xcd_remap;           // contiguous slice ranges per XCD (L2 locality of the gather on big levels)
   const double *x;         // gather source (ONEG sweep: s_old)
   const double *dinv;
   double omega;
@@ -245,7 +246,7 @@ template <int EPI, bool ONEG, int UN, bool NT>
 __global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
 {
   const int lane = threadIdx.x & 63;
-  const int slice = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // any block size that is a multiple of 64
+  const int slice = remap_block(blockIdx.x, gridDim.x, a.xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6);   // any block size that is a multiple of 64
   if (slice >= a.nslices) return;
   const int64_t base = a.soff[slice];
   const int w = (int)((a.soff[slice + 1] - base) >> 6);
@@ -344,6 +345,7 @@ struct SellCArgs {
   int64_t nrows;
   int nslices;
   int x_zero;
+  int xcd_remap;
   const double *x;
   const double *dinv;
   double omega;
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void sellc_kernel(SellCArgs a)
   }
   const int lane = threadIdx.x & 63;
   // wave-uniform by construction; readfirstlane makes it provably so (scalar loads, SGPR loop bounds)
-  const int slice = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const int slice = __builtin_amdgcn_readfirstlane((int)(remap_block(blockIdx.x, gridDim.x, a.xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
   if (slice >= a.nslices) return;
   const int64_t base = a.soff[slice];
   const int w = (int)((a.soff[slice + 1] - base) >> 6);
