@@ -92,3 +92,21 @@ def test_julia_wrapper_binds_only_declared_symbols():
     txt = open(jl).read()
     used = set(re.findall(r":(gmg_\w+)", txt))
     assert used and used <= set(_header_symbols())
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/gmg_amd.h must be consumable by a C compiler (ccall / cgo / ctypes generators read C, not C++),
+    and a C translation unit calling every entry point must link against the library."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "gmg_amd.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    src = tmp_path / "link_check.c"
+    calls = "\n".join(f"  p[{i}] = (void *)&{name};" for i, name in enumerate(_header_symbols()))
+    src.write_text(f'#include "gmg_amd.h"\n#include <stdio.h>\nint main(void) {{\n  void *p[{len(_header_symbols())}];\n{calls}\n'
+                   f'  printf("%d %p\\n", gmg_version(), p[0]);\n  return gmg_destroy(0);\n}}\n')
+    exe = tmp_path / "link_check"
+    libdir = os.path.join(ROOT, "gridapsolvers.jl_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-l:libgmgamd.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split()[0] == "100", (out.stdout, out.stderr)
