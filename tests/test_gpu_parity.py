@@ -545,3 +545,33 @@ def test_sellc_mixed_slices_wide_and_banded(S, po, orc, monkeypatch):
     ns.smooth(0, xs, rs)
     xo, ro = orc.GMG(H["mats"], H["prolongations"], maxiter=1).smooth(0, np.zeros(n), x)
     assert max_rel(xs, xo) <= TOL_KERNEL and max_rel(rs, ro) <= TOL_KERNEL
+
+
+def test_drop_in_preconditioner_under_a_host_cg(S, po, orc, hierarchy):
+    """Integration mode 1: the reference keeps its own CGSolver and only `solve!(z,Pl,r)`
+    (CGSolvers.jl:94) goes to the device.  A host-side CG written exactly like CGSolvers.jl:73-120, calling
+    the device V-cycle through the host-memory ABI, must reproduce the oracle's iteration."""
+    nc, nlev = (16, 16, 16), 3
+    H = hierarchy(nc, nlev)
+    A = H["mats"][0].to_scipy()
+    b = po.dirichlet_lift_rhs(nc, 1)
+    gmg = make_gmg(S, H)                                   # maxiter=1, :preconditioner
+    Pl = setup(S, gmg, H["mats"][0])
+    x = np.zeros_like(b); r = b - A @ x; p = np.zeros_like(b); z = np.zeros_like(b)
+    gamma = 1.0
+    res0 = res = np.linalg.norm(r); hist = [res]
+    it = 0
+    while not (it >= 20 or (it > 0 and res / res0 < 1e-6) or res < 1e-14):
+        S.solve_(z, Pl, r)                                  # device V-cycle, host vectors
+        beta = gamma; gamma = float(z @ r); beta = gamma / beta
+        p = z + beta * p
+        w = A @ p
+        alpha = gamma / float(p @ w)
+        x += alpha * p; r -= alpha * w
+        res = np.linalg.norm(r); hist.append(res); it += 1
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    xo, nit, flag, histo = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert it == nit
+    np.testing.assert_allclose(hist, histo, rtol=TOL_HIST)
+    assert rel_err(x, xo) <= 1e-10
+    assert gmg.log.num_iters == 1 and gmg.log.residuals[0] > gmg.log.residuals[1] > 0      # GMG's own ConvergenceLog is filled
