@@ -218,6 +218,7 @@ struct Level {
   HaloPlan halo;                  // neighbour exchange plan (multi-GPU)
   // own x ghost part of A on the rows that have ghost columns (A itself then holds own x own only)
   bool split = false;
+  struct HostXfer { struct ::gmg_solver *solver; int level; } hostctx{nullptr, 0};   // hipLaunchHostFunc payload
   int64_t nbnd = 0;
   int32_t *gh_rows = nullptr;
   int64_t *gh_ptr = nullptr;
@@ -322,6 +323,7 @@ struct gmg_solver {
   hipStream_t comm_stream = nullptr;   // halo traffic overlapping the own x own mat-vec (RCCL only)
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   int overlap = 1;                     // GMG_OVERLAP
+  int host_async = 0;                  // GMG_HOST_ASYNC: run the overlapped schedule with the host transport (tests)
   double *cg_x = nullptr;       // solution with ghost space (distributed runs)
 
   // reductions
@@ -799,13 +801,37 @@ struct gmg_solver {
   // Split mat-vec with A_l: start the halo of `src`, (caller runs the own x own kernel), then
   // finish the boundary rows.  With RCCL the exchange runs on comm_stream concurrently with the
   // own x own kernel; with the host transport it is synchronous (same data flow, no overlap).
+  bool overlapped() const { return overlap && comm_stream && (comm.kind == COMM_RCCL || host_async); }
+  static void host_exchange_trampoline(void *p)
+  {
+    // runs on a HIP runtime thread, in comm_stream order; must not call HIP
+    auto *c = static_cast<Level::HostXfer *>(p);
+    HaloPlan &H = c->solver->lev[c->level].halo;
+    c->solver->comm.xfn(c->solver->comm.ctx, (int)H.nbr.size(), H.nbr.data(), H.h_send, H.snd_ptr.data(), H.h_recv, H.rcv_ptr.data());
+  }
   void begin_exchange(int l, double *src)
   {
     if (comm.nranks <= 1 || !lev[l].halo.present) return;
-    if (comm.kind == COMM_RCCL && overlap && comm_stream) {
+    if (overlapped() && comm.kind == COMM_RCCL) {
       HIP_CHECK(hipEventRecord(ev_ready, stream));
       HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
       exchange_on(l, src, comm_stream);
+      HIP_CHECK(hipEventRecord(ev_done, comm_stream));
+    } else if (overlapped()) {
+      // host transport, asynchronous flavour (tests): the same two-stream / two-event schedule as the
+      // RCCL path, with the host callback enqueued on comm_stream
+      HaloPlan &H = lev[l].halo;
+      HIP_CHECK(hipEventRecord(ev_ready, stream));
+      HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
+      const int64_t ns = H.nsend();
+      if (ns > 0) {
+        hipLaunchKernelGGL(halo_pack_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, comm_stream, ns, H.d_snd_idx, src, H.d_sendbuf);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(H.h_send, H.d_sendbuf, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, comm_stream));
+      }
+      lev[l].hostctx = {this, l};
+      HIP_CHECK(hipLaunchHostFunc(comm_stream, host_exchange_trampoline, &lev[l].hostctx));
+      if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(src + H.n_own, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, comm_stream));
       HIP_CHECK(hipEventRecord(ev_done, comm_stream));
     } else {
       exchange_on(l, src, stream);
@@ -816,7 +842,7 @@ struct gmg_solver {
   {
     Level &L = lev[l];
     if (comm.nranks <= 1 || !L.halo.present) return;
-    if (comm.kind == COMM_RCCL && overlap && comm_stream) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
+    if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
     if (!L.split || L.nbnd == 0) return;
     hipLaunchKernelGGL((ghost_fix_kernel<MODE>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
                        L.gh_ptr, L.gh_col, L.gh_val, src, y, L.dinv, omega, s_out);
@@ -1974,6 +2000,13 @@ int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_f
     REQUIRE(h->comm.kind == COMM_NONE, GMG_ERR_STATE, "communicator already initialised");
     h->comm.kind = COMM_HOST; h->comm.rank = rank; h->comm.nranks = nranks;
     h->comm.xfn = xfn; h->comm.rfn = rfn; h->comm.ctx = ctx;
+    h->host_async = env_int("GMG_HOST_ASYNC", 0);
+    h->overlap = env_int("GMG_OVERLAP", 1);
+    if (h->host_async) {
+      if (!h->comm_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+      if (!h->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+      if (!h->ev_done) HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
+    }
     h->setup_done = false;
   });
 }

@@ -19,13 +19,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _launch(mode, world, cells, nlev, tmp_path, transport="host", timeout=600, rep_from=0):
+def _launch(mode, world, cells, nlev, tmp_path, transport="host", timeout=600, rep_from=0, extra_env=None):
     out = os.path.join(str(tmp_path), f"verdict_{mode}_{world}.json")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode,
                                        "x".join(map(str, cells)), str(nlev), out, transport, str(rep_from)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -89,6 +89,16 @@ def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_p
     v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep)
     _check(v)
     assert v["fgmres_iters"] <= v["iters"] + 1 and v["fgmres_vs_cg"] < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cells,nlev,rep", [(2, (16, 16, 16), 3, 0), (8, (8, 8, 8), 3, 1)])
+def test_overlapped_schedule_with_async_host_transport(world, cells, nlev, rep, tmp_path):
+    """The two-stream / two-event schedule of the RCCL path (halo on comm_stream while the own x own kernel
+    runs, boundary rows afterwards) driven by the host transport through hipLaunchHostFunc: real concurrency
+    between the exchange and the kernel, on one GPU."""
+    v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env={"GMG_HOST_ASYNC": "1"})
+    _check(v)
 
 
 @pytest.mark.gpu
