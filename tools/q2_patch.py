@@ -1,7 +1,7 @@
 """Config-3-shaped run (Q2, vertex-star patch smoother, FGMRES outer): python tools_q2.py [cells] [levels]"""
 import sys, time, json, os
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 pkg = entry.import_package(); po, S = pkg.poisson, pkg.solvers
 nc = (int(sys.argv[1]),) * 3 if len(sys.argv) > 1 else (32,) * 3

@@ -3,7 +3,7 @@ import json, os, subprocess, sys
 VARIANTS = json.loads(os.environ.get("TUNE_VARIANTS", "[]")) or [dict()]
 KEYS = ("GMG_ONE_GATHER", "GMG_XCD_REMAP", "GMG_LANES_LOG2", "GMG_NT", "GMG_SELL", "GMG_SELL_UN", "GMG_SELL_BLOCK", "GMG_SELL_MAXPAD", "GMG_VDICT", "GMG_IDX16")
 if len(sys.argv) > 1 and sys.argv[1] == "child":
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import numpy as np, torch
     import __graft_entry__ as entry
     pkg = entry.import_package(); po, S = pkg.poisson, pkg.solvers

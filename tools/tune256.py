@@ -1,7 +1,7 @@
 """A/B of env switches on the 256^3 problem: python tools_tune256.py '<json list of env dicts>'"""
 import json, os, subprocess, sys
 if len(sys.argv) > 1 and sys.argv[1] == "child":
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import time, numpy as np, torch
     import __graft_entry__ as entry
     pkg = entry.import_package(); po, S = pkg.poisson, pkg.solvers
