@@ -212,6 +212,9 @@ struct Level {
   DevCSR A, P, R;
   double *dinv = nullptr;
   Smoother pre, post;
+  Smoother pcorr;                 // patch tables of a patch-corrected prolongation (kind == SM_PATCH when set)
+  bool has_pcorr = false;
+  double *ptmp = nullptr, *pcor = nullptr;
   bool post_shares_pre = true;
   int64_t n = 0;                  // owned rows
   int64_t nvec = 0;               // vector length = owned + ghost
@@ -400,6 +403,7 @@ struct gmg_solver {
       L.A = DevCSR(); L.P = DevCSR(); L.R = DevCSR();
       L.dinv = L.x = L.dx = L.rcur = nullptr;
       L.rbuf[0] = L.rbuf[1] = nullptr;
+      L.ptmp = L.pcor = nullptr; L.pcorr.built = false;
       L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
       L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pre.built = L.post.built = false;
@@ -990,6 +994,14 @@ struct gmg_solver {
       const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
       cycle(l + 1, C.x, C.rbuf[0], true, child);           // :488
       exchange(l + 1, C.x);
+      if (L.has_pcorr) {
+        // PatchProlongationOperator: dxh = P dxH - sum_p A_pp^-1 (A P dxH)_p  (PatchTransferOperators.jl:153-172)
+        spmv_set(L.P, C.x, L.dx);
+        apply_A_set(l, L.dx, L.ptmp);
+        patch_precond(L, L.pcorr, L.ptmp, 1.0, false, L.pcor, nullptr);
+        hipLaunchKernelGGL(prolong_correct_kernel, dim3(grid_for(L.n)), dim3(256), 0, stream, L.n, L.pcor, L.dx, x);
+        HIP_CHECK(hipGetLastError());
+      } else
       spmv_addto(L.P, C.x, L.dx, x);                       // :491,494 dxh = P dxH ; xh += dxh
       apply_A_sub(l, L.dx, r);                             // :495-496 rh -= Ah dxh
     }
@@ -1436,6 +1448,11 @@ void gmg_solver::setup()
       HIP_CHECK(hipStreamSynchronize(stream));
       const bool need_diag = (L.pre.kind == SM_JACOBI) || (L.post.kind == SM_JACOBI);
       REQUIRE(!(need_diag && nzero > 0), GMG_ERR_SINGULAR, "zero diagonal entry on level " + std::to_string(l));
+      if (L.has_pcorr) {
+        REQUIRE(comm.nranks == 1, GMG_ERR_UNSUPPORTED, "patch-corrected prolongation is single-GPU in this round");
+        build_patch(L, L.pcorr);
+        L.ptmp = dvec(L.nvec); L.pcor = dvec(L.nvec);
+      }
       if (L.pre.kind == SM_PATCH) build_patch(L, L.pre);
       if (L.post_shares_pre) L.post = L.pre;
       else if (L.post.kind == SM_PATCH) build_patch(L, L.post);
@@ -1634,6 +1651,29 @@ int gmg_set_smoother_patch(gmg_handle_t h, int lev, int which, int niter, double
     S.h_pdofs.resize((size_t)tot);
     for (int64_t q = 0; q < tot; ++q) S.h_pdofs[q] = (int32_t)(read_index(patch_dofs, q, index_bytes) - index_base);
     assign_smoother(h, lev, which, S);
+  });
+}
+
+int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int kind, int64_t npatch, const void *patch_ptr,
+                                          const void *patch_dofs, int index_base, int index_bytes)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    REQUIRE(npatch >= 0, GMG_ERR_INVALID, "negative npatch");
+    REQUIRE(patch_ptr && (patch_dofs || npatch == 0), GMG_ERR_INVALID, "null patch arrays");
+    REQUIRE(index_bytes == 4 || index_bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
+    REQUIRE(kind == GMG_PATCH_LU || kind == GMG_PATCH_NOPIVOT, GMG_ERR_INVALID, "bad patch kind");
+    Smoother S;
+    S.kind = SM_PATCH; S.niter = 0; S.omega = 1.0; S.patch_kind = kind;
+    S.h_pptr.resize((size_t)npatch + 1);
+    for (int64_t p = 0; p <= npatch; ++p) S.h_pptr[p] = read_index(patch_ptr, p, index_bytes) - index_base;
+    REQUIRE(S.h_pptr[0] == 0, GMG_ERR_INVALID, "patch_ptr does not start at index_base");
+    const int64_t tot = S.h_pptr[npatch];
+    S.h_pdofs.resize((size_t)tot);
+    for (int64_t q = 0; q < tot; ++q) S.h_pdofs[q] = (int32_t)(read_index(patch_dofs, q, index_bytes) - index_base);
+    h->lev[lev].pcorr = S;
+    h->lev[lev].has_pcorr = true;
+    h->setup_done = false;
   });
 }
 

@@ -471,6 +471,17 @@ __global__ __launch_bounds__(kBlock) void sellc_kernel(SellCArgs a)
   }
 }
 
+// dx -= c ; x += dx   (patch-corrected prolongation: y = P x - sum_p A_pp^-1 (A P x)_p,
+// PatchBasedSmoothers/PatchTransferOperators.jl:153-172, then xh .+= dxh GMGLinearSolvers.jl:494)
+__global__ void prolong_correct_kernel(int64_t n, const double *__restrict__ c, double *__restrict__ dx, double *__restrict__ x)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double d = dx[i] - c[i];
+    dx[i] = d;
+    x[i] = x[i] + d;
+  }
+}
+
 // s = omega*(dinv.*r)  (first sweep of a ONEG smoothing pass)
 __global__ void scaled_jacobi_kernel(int64_t n, double omega, const double *__restrict__ dinv,
                                      const double *__restrict__ r, double *__restrict__ s)

@@ -28,7 +28,7 @@ import numpy as np
 
 __all__ = [
     "CSR", "poisson_matrix", "prolongation", "dirichlet_lift_rhs", "nodal_values",
-    "l2_error_sq", "vertex_star_patches", "build_hierarchy", "random_rhs", "level_sizes",
+    "l2_error_sq", "vertex_star_patches", "coarse_cell_interior_patches", "build_hierarchy", "random_rhs", "level_sizes",
 ]
 
 
@@ -349,6 +349,29 @@ def vertex_star_patches(ncells, order=1):
                 ptr.append(ptr[-1] + g.size)
     dofs = np.concatenate(dofs) if dofs else np.zeros(0, dtype=np.int64)
     return np.asarray(ptr, dtype=np.int64), dofs.astype(np.int32)
+
+
+def coarse_cell_interior_patches(ncells_coarse, order=1):
+    """One patch per COARSE cell: the fine free dofs strictly inside it (fine mesh = coarse refined x2) --
+    the patches of CoarsePatchTopology / assembly=:interior used by the reference's patch prolongation
+    (PatchBasedSmoothers/CoarsePatchTopologies.jl, PatchTransferOperators.jl).  Q1: 1 dof, Q2: 3^d dofs."""
+    nc, d = _dims(ncells_coarse)
+    nf = [order * 2 * nc[k] - 1 if k < d else 1 for k in range(3)]
+
+    def axis_lists(k):
+        if k >= d:
+            return [np.zeros(1, dtype=np.int64)]
+        return [np.arange(2 * order * I + 1, 2 * order * (I + 1)) - 1 for I in range(nc[k])]
+
+    ax, ay, az = axis_lists(0), axis_lists(1), axis_lists(2)
+    ptr, dofs = [0], []
+    for lz in az:
+        for ly in ay:
+            for lx in ax:
+                g = (lz[:, None, None] * (nf[1] * nf[0]) + ly[None, :, None] * nf[0] + lx[None, None, :]).reshape(-1)
+                dofs.append(g)
+                ptr.append(ptr[-1] + g.size)
+    return np.asarray(ptr, dtype=np.int64), np.concatenate(dofs).astype(np.int32)
 
 
 def build_hierarchy(ncells_fine, nlevels, order=1, lengths=None):

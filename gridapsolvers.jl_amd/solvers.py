@@ -30,7 +30,7 @@ from . import abi
 
 __all__ = [
     "JacobiLinearSolver", "RichardsonSmoother", "PatchSolver", "BlockJacobiSolver", "LUSolver",
-    "GMGLinearSolver", "CGSolver", "FGMRESSolver", "ConvergenceLog",
+    "GMGLinearSolver", "CGSolver", "FGMRESSolver", "ConvergenceLog", "PatchProlongationOperator",
     "symbolic_setup", "numerical_setup", "numerical_setup_", "solve_", "mul_",
     "SOLVER_CONVERGED_ATOL", "SOLVER_CONVERGED_RTOL", "SOLVER_DIVERGED_MAXITER", "SOLVER_DIVERGED_BREAKDOWN",
 ]
@@ -64,6 +64,17 @@ class PatchSolver:
 class BlockJacobiSolver(PatchSolver):
     """BlockJacobiSolver(patch_rows, patch_cols) -- BlockJacobiSolvers.jl:2-16 (NoPivot LU, :162)."""
     kind = abi.PATCH_NOPIVOT
+
+
+class PatchProlongationOperator:
+    """PatchProlongationOperator (PatchTransferOperators.jl:2-60,153-172) reduced to what its mul! needs: the
+    plain prolongation matrix P and the patch dof tables; y = P x - sum_p A_pp^-1 (A P x)_p."""
+
+    def __init__(self, P, patch_ptr, patch_dofs, pivoting=True):
+        self.P = P
+        self.patch_ptr = np.ascontiguousarray(patch_ptr, dtype=np.int64)
+        self.patch_dofs = np.ascontiguousarray(patch_dofs, dtype=np.int64)
+        self.kind = abi.PATCH_LU if pivoting else abi.PATCH_NOPIVOT
 
 
 class RichardsonSmoother:
@@ -251,7 +262,14 @@ class GMGNumericalSetup:
         for l, A in enumerate(mats):
             _set_op(lib.gmg_set_matrix, h, l, A)
         for l in range(nlev - 1):
-            _set_op(lib.gmg_set_prolongation, h, l, s.interp[l])
+            ip = s.interp[l]
+            if isinstance(ip, PatchProlongationOperator):
+                _set_op(lib.gmg_set_prolongation, h, l, ip.P)
+                abi.check(h, lib.gmg_set_prolongation_patch_correction(
+                    h, l, ip.kind, ip.patch_ptr.size - 1, C.c_void_p(ip.patch_ptr.ctypes.data),
+                    C.c_void_p(ip.patch_dofs.ctypes.data), 0, 8))
+            else:
+                _set_op(lib.gmg_set_prolongation, h, l, ip)
             if s.restrict[l] is not None:
                 _set_op(lib.gmg_set_restriction, h, l, s.restrict[l])
             pre, post = s.pre_smoothers[l], s.post_smoothers[l]

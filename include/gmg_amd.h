@@ -116,6 +116,14 @@ GMG_API int gmg_set_smoother_patch(gmg_handle_t h, int lev, int which, int niter
                                    int kind, int64_t npatch, const void *patch_ptr,
                                    const void *patch_dofs, int index_base, int index_bytes);
 
+/* Patch-corrected prolongation  y = P x - sum_p R_p^T A_pp^-1 R_p (A P x)  over the given patches
+ * (PatchProlongationOperator, PatchBasedSmoothers/PatchTransferOperators.jl:153-172 with rhs = lhs = the
+ * level operator; used by the reference for grad-div problems, test/Applications/StokesGMG.jl:125-133).
+ * Same patch-table format as gmg_set_smoother_patch. */
+GMG_API int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int kind, int64_t npatch,
+                                                  const void *patch_ptr, const void *patch_dofs,
+                                                  int index_base, int index_bytes);
+
 /* ---- solver options --------------------------------------------------------- */
 /* kwargs of GMGLinearSolver: mode, cycle_type, maxiter, atol, rtol (GMGLinearSolvers.jl:56-58). */
 GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, double atol, double rtol);

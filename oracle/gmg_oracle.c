@@ -409,6 +409,9 @@ typedef struct {
   int has_R;
   orc_smoother pre, post;
   int post_is_pre;
+  orc_smoother pcorr;   /* patch tables + LU factors of the patch-corrected prolongation */
+  int has_pcorr;
+  double *ptmp, *pcor;
   /* work vectors GMGLinearSolvers.jl:451-466 + smoother caches RichardsonSmoothers.jl:58-63 */
   double *dxh, *Adxh, *dxH, *rH, *sm_dx, *sm_Adx;
 } orc_level;
@@ -462,6 +465,19 @@ ORC_API void orc_gmg_set_smoother(orc_gmg *g, int l, int which /*0 pre,1 post,2 
   g->lev[l].post_is_pre = (which == 2);
 }
 
+/* PatchProlongationOperator(lev,sh,lhs,rhs,...) with rhs = lhs = level operator:
+ * PatchTransferOperators.jl:2-60 ; mul! :153-172 */
+ORC_API void orc_gmg_set_prolongation_correction(orc_gmg *g, int l, int kind, i64 npatch, const i64 *patch_ptr,
+                                                 const i32 *patch_dofs)
+{
+  orc_smoother s;
+  memset(&s, 0, sizeof(s));
+  s.kind = kind; s.niter = 0; s.omega = 1.0;
+  s.npatch = npatch; s.patch_ptr = patch_ptr; s.patch_dofs = patch_dofs;
+  g->lev[l].pcorr = s;
+  g->lev[l].has_pcorr = 1;
+}
+
 static double *dalloc(i64 n) { return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
 
 /* numerical_setup(GMGSymbolicSetup,mat): GMGLinearSolvers.jl:183-210 */
@@ -478,9 +494,24 @@ ORC_API void orc_gmg_setup(orc_gmg *g, int mode, int cycle, int maxiter, double 
     L->sm_dx = dalloc(n); L->sm_Adx = dalloc(n);
     smoother_setup(&L->pre, &L->A);
     if (L->post_is_pre) L->post = L->pre; else smoother_setup(&L->post, &L->A);
+    if (L->has_pcorr) { smoother_setup(&L->pcorr, &L->A); L->ptmp = dalloc(n); L->pcor = dalloc(n); }
   }
   const orc_csr *AL = &g->lev[g->nlev - 1].A;
   g->coarse = band_factor(AL->n, AL->ptr, AL->idx, AL->val); /* :423-434 */
+}
+
+/* mul!(y,A::PatchProlongationOperator,x): PatchTransferOperators.jl:153-172
+ *   interpolate!(uH,fv_h,Uh)                 -> dxh = P dxH
+ *   patch_b = assemble_vector(liform,...)    -> (A dxh) restricted to the patch rows
+ *   solve_patch_overlapping!(dx_h,...)       -> c = sum_p A_pp^-1 b_p
+ *   fv_h .= fv_h .- dx_h                     -> dxh -= c */
+static void apply_prolongation(orc_level *L, const double *dxH, double *dxh)
+{
+  orc_spmv(L->P.n, L->P.ptr, L->P.idx, L->P.val, dxH, dxh);
+  if (!L->has_pcorr) return;
+  orc_spmv(L->A.n, L->A.ptr, L->A.idx, L->A.val, dxh, L->ptmp);
+  precond_apply(&L->pcorr, &L->A, L->pcor, L->ptmp);
+  for (i64 i = 0; i < L->A.n; ++i) dxh[i] = dxh[i] - L->pcor[i];
 }
 
 static void apply_restriction(const orc_level *L, const double *rh, double *rH)
@@ -509,7 +540,7 @@ static void gmg_cycle(orc_gmg *g, int lev, double *xh, double *rh, int ctype)
   apply_restriction(L, rh, L->rH);                                 /* :484 */
   for (i64 i = 0; i < nH; ++i) L->dxH[i] = 0.0;                    /* :487 */
   gmg_cycle(g, lev + 1, L->dxH, L->rH, ctype);                     /* :488 */
-  orc_spmv(L->P.n, L->P.ptr, L->P.idx, L->P.val, L->dxH, L->dxh);  /* :491 */
+  apply_prolongation(L, L->dxH, L->dxh);                           /* :491 */
   for (i64 i = 0; i < n; ++i) xh[i] = xh[i] + L->dxh[i];           /* :494 */
   orc_spmv(n, L->A.ptr, L->A.idx, L->A.val, L->dxh, L->Adxh);      /* :495 */
   for (i64 i = 0; i < n; ++i) rh[i] = rh[i] - L->Adxh[i];          /* :496 */
@@ -519,7 +550,7 @@ static void gmg_cycle(orc_gmg *g, int lev, double *xh, double *rh, int ctype)
     apply_restriction(L, rh, L->rH);
     for (i64 i = 0; i < nH; ++i) L->dxH[i] = 0.0;
     gmg_cycle(g, lev + 1, L->dxH, L->rH, ctype == ORC_W_CYCLE ? ORC_W_CYCLE : ORC_V_CYCLE);
-    orc_spmv(L->P.n, L->P.ptr, L->P.idx, L->P.val, L->dxH, L->dxh);
+    apply_prolongation(L, L->dxH, L->dxh);
     for (i64 i = 0; i < n; ++i) xh[i] = xh[i] + L->dxh[i];
     orc_spmv(n, L->A.ptr, L->A.idx, L->A.val, L->dxh, L->Adxh);
     for (i64 i = 0; i < n; ++i) rh[i] = rh[i] - L->Adxh[i];
@@ -589,6 +620,7 @@ ORC_API void orc_gmg_destroy(orc_gmg *g)
     free(L->dxh); free(L->Adxh); free(L->dxH); free(L->rH); free(L->sm_dx); free(L->sm_Adx);
     smoother_free(&L->pre);
     if (!L->post_is_pre) smoother_free(&L->post);
+    if (L->has_pcorr) { smoother_free(&L->pcorr); free(L->ptmp); free(L->pcor); }
   }
   band_free(g->coarse);
   free(g->rh); free(g->log.residuals); free(g->lev); free(g);

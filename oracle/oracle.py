@@ -108,7 +108,7 @@ class GMG:
     """Mirror of GMGLinearSolver(smatrices, interp, restrict; ...) -> numerical setup."""
 
     def __init__(self, mats, prolongations, restrictions=None, pre_smoothers=None, post_smoothers=None,
-                 mode=PRECONDITIONER, cycle=V_CYCLE, maxiter=100, atol=1e-14, rtol=1e-8):
+                 mode=PRECONDITIONER, cycle=V_CYCLE, maxiter=100, atol=1e-14, rtol=1e-8, prolongation_patches=None):
         L = lib()
         nlev = len(mats)
         assert len(prolongations) == nlev - 1
@@ -124,6 +124,15 @@ class GMG:
             for l, R in enumerate(restrictions):
                 L.orc_gmg_set_restriction(self.h, C.c_int(l), C.c_int64(R.shape[0]), C.c_int64(R.shape[1]),
                                           _p64(R.ptr), _p32(R.idx), _d(R.val))
+        if prolongation_patches is not None:      # [(kind, patch_ptr, patch_dofs) or None per level]
+            self._keep.append(prolongation_patches)
+            for l, pc in enumerate(prolongation_patches):
+                if pc is not None:
+                    kind, pp, pd = pc
+                    pp = np.ascontiguousarray(pp, dtype=np.int64); pd = np.ascontiguousarray(pd, dtype=np.int32)
+                    self._keep += [pp, pd]
+                    L.orc_gmg_set_prolongation_correction(self.h, C.c_int(l), C.c_int(kind), C.c_int64(len(pp) - 1),
+                                                          _p64(pp), _p32(pd))
         if pre_smoothers is None:
             pre_smoothers = [Smoother() for _ in range(nlev - 1)]
         for l in range(nlev - 1):

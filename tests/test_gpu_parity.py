@@ -575,3 +575,32 @@ def test_drop_in_preconditioner_under_a_host_cg(S, po, orc, hierarchy):
     np.testing.assert_allclose(hist, histo, rtol=TOL_HIST)
     assert rel_err(x, xo) <= 1e-10
     assert gmg.log.num_iters == 1 and gmg.log.residuals[0] > gmg.log.residuals[1] > 0      # GMG's own ConvergenceLog is filled
+
+
+@pytest.mark.parametrize("nc,order,pivot", [((8, 8, 8), 2, True), ((16, 16), 2, False), ((16, 16, 16), 1, True)])
+def test_patch_corrected_prolongation_parity(S, po, orc, hierarchy, nc, order, pivot):
+    """GMG with PatchProlongationOperator transfers (test/LinearSolvers/GMGTests.jl:80-88 ttype=:patch)
+    against the oracle: V-cycle output and an FGMRES solve."""
+    nlev = 2
+    H = hierarchy(nc, nlev, order)
+    coarse = tuple(c // 2 for c in nc)
+    pp, pd = po.coarse_cell_interior_patches(coarse, order)
+    interp = [S.PatchProlongationOperator(H["prolongations"][0], pp, pd, pivoting=pivot)]
+    Hp = dict(mats=H["mats"], prolongations=interp, restrictions=H["restrictions"])
+    gmg = make_gmg(S, Hp)
+    solver = S.FGMRESSolver(5, gmg, maxiter=20, atol=1e-14, rtol=1e-8)
+    ns = setup(S, solver, H["mats"][0])
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1,
+                 prolongation_patches=[(orc.PATCH if pivot else orc.BLOCKJACOBI, pp, pd)])
+    r = seeded(H["mats"][0].shape[0], 29)
+    z = np.zeros_like(r)
+    S.solve_(z, ns.P_ns, r)
+    zo, _, _, ho = go.solve(r)
+    assert rel_err(z, zo) <= TOL_VCYCLE
+    np.testing.assert_allclose(gmg.log.residuals[:2], ho, rtol=TOL_HIST)
+    b = po.dirichlet_lift_rhs(nc, order)
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    xo, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-8)
+    assert solver.log.num_iters == nit and rel_err(x, xo) <= 1e-9
+    assert po.l2_error_sq(nc, order, x) < 1e-8
