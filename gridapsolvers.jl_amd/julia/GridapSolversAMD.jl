@@ -33,7 +33,7 @@ using GridapSolvers
 using GridapSolvers.SolverInterfaces: ConvergenceLog, SolverTolerances
 using GridapSolvers.LinearSolvers: RichardsonSmoother, JacobiLinearSolver
 
-export HipGMGLinearSolver, HipCGSolver, HipFGMRESSolver, PatchTable
+export HipGMGLinearSolver, HipCGSolver, HipFGMRESSolver, PatchTable, HipPatchProlongation
 
 const libgmgamd = get(ENV, "LIBGMGAMD", joinpath(@__DIR__, "..", "libgmgamd.so"))
 
@@ -69,6 +69,13 @@ struct PatchTable
   pivoting   :: Bool            # true: PatchSolver (lu!) ; false: BlockJacobiSolver (NoPivot)
 end
 PatchTable(t::Gridap.Arrays.Table; pivoting=true) = PatchTable(Int64.(t.ptrs), Int64.(t.data), pivoting)
+
+# Patch-corrected prolongation (PatchProlongationOperator, PatchTransferOperators.jl:153-172): the plain
+# prolongation matrix plus the patch dof table; pass it in `interp[l]`.
+struct HipPatchProlongation{M}
+  P       :: M
+  patches :: PatchTable
+end
 
 struct HipGMGLinearSolver{A,B,C,D,E} <: Gridap.Algebra.LinearSolver
   smatrices      :: A
@@ -187,7 +194,18 @@ function Gridap.Algebra.numerical_setup(ss::HipGMGSymbolicSetup, mat::AbstractMa
     _set_op(:matrix, h, l-1, l == 1 ? mat : s.smatrices[l])       # smatrices[1] = mat (:338)
   end
   for l in 1:nlev-1
-    _set_op(:prolongation, h, l-1, s.interp[l])
+    ip = s.interp[l]
+    if ip isa HipPatchProlongation
+      _set_op(:prolongation, h, l-1, ip.P)
+      T = ip.patches
+      GC.@preserve T begin
+        check(h, ccall((:gmg_set_prolongation_patch_correction, libgmgamd), Cint,
+          (Ptr{Cvoid},Cint,Cint,Int64,Ptr{Cvoid},Ptr{Cvoid},Cint,Cint),
+          h, l-1, T.pivoting ? GMG_PATCH_LU : GMG_PATCH_NOPIVOT, length(T.patch_ptr)-1, T.patch_ptr, T.patch_dofs, 1, 8))
+      end
+    else
+      _set_op(:prolongation, h, l-1, ip)
+    end
     !isnothing(s.restrict) && _set_op(:restriction, h, l-1, s.restrict[l])
     if s.post_smoothers[l] === s.pre_smoothers[l]
       _set_smoother(h, l-1, GMG_PRE_AND_POST, s.pre_smoothers[l])
