@@ -388,6 +388,28 @@ struct gmg_solver {
     HIP_CHECK(hipMemset(p + v.size(), 0, pad * sizeof(T)));
     return p;
   }
+  // give device memory back early (setup-only arrays)
+  template <typename T>
+  void release(T *&p, size_t count)
+  {
+    if (!p) return;
+    auto it = std::find(allocs.begin(), allocs.end(), (void *)p);
+    if (it != allocs.end()) {
+      allocs.erase(it);
+      (void)hipFree((void *)p);
+      dev_bytes -= (int64_t)(std::max<size_t>(count, 1) * sizeof(T) + 64);
+    }
+    p = nullptr;
+  }
+  // a SELL matrix never streams its CSR copy: drop (col,val) once D^-1 / patch blocks are built
+  void drop_csr_stream(DevCSR &M)
+  {
+    if (!M.sell) return;
+    HIP_CHECK(hipStreamSynchronize(stream));
+    release(M.col, (size_t)M.nnz + 4096);
+    release(M.val, (size_t)M.nnz + 4096);
+    if (M.vdict) release(M.sval, (size_t)M.zpad);          // values come from the dictionary
+  }
   double *dvec(int64_t n)
   {
     double *p = dalloc<double>((size_t)n);
@@ -1197,6 +1219,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
           S.nuniq = nu;
           S.dedup = true;
           HIP_CHECK(hipStreamSynchronize(stream));
+          release(S.d_binv, (size_t)boff[npatch]);   // every patch now reads the compact store
         }
       }
     }
@@ -1456,7 +1479,10 @@ void gmg_solver::setup()
       if (L.pre.kind == SM_PATCH) build_patch(L, L.pre);
       if (L.post_shares_pre) L.post = L.pre;
       else if (L.post.kind == SM_PATCH) build_patch(L, L.post);
+      drop_csr_stream(L.P);
+      drop_csr_stream(L.R);
     }
+    drop_csr_stream(L.A);
   }
   build_coarse();                                           // :195 gmg_coarse_solver_caches
   const int64_t n0 = lev[0].nvec;

@@ -302,7 +302,7 @@ def run_bench(args, rank, world, local_rank):
             "transport": transport, "replicated_from_level": int(g.local["rep_from"]), "max_abs_error_vs_exact": float(err.item()),
             "setup_s": g.t_setup, "assembly_s": g.t_assembly,
         },
-        "roofline": {"bound": "hbm", "kernel": "sell_kernel<EPI_SWEEP,ONEG> (rank 0, finest level)",
+        "roofline": {"bound": "hbm", "kernel": "fused Richardson-Jacobi sweep, own x own part (rank 0, finest level)",
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                      "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
                      "alg_bytes_per_launch": st["alg_bytes"], "avg_launch_ms": avg_ms, "launches_timed": st["launches"]},
