@@ -285,6 +285,20 @@ struct ConvLog {
 
 constexpr int kScalarSlots = 4096;
 
+// setup-time host loops over independent chunks (slices, columns): plain std::thread fan-out
+template <typename F>
+void parallel_for(int64_t n, F &&fn)
+{
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 32u), std::max<int64_t>(1, n / 256));
+  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] { for (int64_t i = t * chunk; i < std::min(n, (t + 1) * chunk); ++i) fn(i); });
+  for (auto &x : th) x.join();
+}
+
 int env_int(const char *name, int dflt)
 {
   const char *s = std::getenv(name);
@@ -518,7 +532,7 @@ struct gmg_solver {
     }
     std::vector<int32_t> scol((size_t)zp), rowlen((size_t)H.nrows);
     std::vector<double> sval((size_t)zp, 0.0);
-    for (int64_t sl = 0; sl < ns; ++sl) {
+    parallel_for(ns, [&](int64_t sl) {
       const int64_t w = (soff[sl + 1] - soff[sl]) / 64;
       for (int l = 0; l < 64; ++l) {
         const int64_t i = sl * 64 + l;
@@ -531,7 +545,7 @@ struct gmg_solver {
           else { scol[q] = padcol; sval[q] = 0.0; }
         }
       }
-    }
+    });
     D.soff = upload(soff); D.scol = upload(scol); D.sval = upload(sval); D.rowlen = upload(rowlen);
     D.nslices = (int)ns; D.zpad = zp; D.sell = true;
     // ---- lossless compression of the stream (see sellc_kernel) ----
@@ -548,7 +562,7 @@ struct gmg_solver {
     if (use_idx16) {
       pidx.assign((size_t)zpp, 0);
       pbase.assign((size_t)(zpp / 64), 0);
-      for (int64_t sl = 0; sl < ns; ++sl) {
+      parallel_for(ns, [&](int64_t sl) {
         const int64_t w = (soff[sl + 1] - soff[sl]) / 64;
         const int64_t w4 = (poff[sl + 1] - poff[sl]) / 64;
         bool ok = w > 0;
@@ -562,8 +576,8 @@ struct gmg_solver {
           if ((int64_t)hi - lo > 65535) ok = false;
           pbase[poff[sl] / 64 + j] = lo;
         }
-        if (!ok) continue;
-        smode[sl] = 1; ++n16;
+        if (!ok) return;
+        smode[sl] = 1;
         for (int64_t j = w; j < w4; ++j) pbase[poff[sl] / 64 + j] = pbase[poff[sl] / 64 + w - 1];
         for (int64_t j = 0; j < w4; ++j)
           for (int l = 0; l < 64; ++l) {
@@ -573,7 +587,8 @@ struct gmg_solver {
             const int32_t c = real ? scol[soff[sl] + j * 64 + l] : bj;      // padding decodes to the (valid) base column
             pidx[poff[sl] + (j / 4) * 256 + l * 4 + (j % 4)] = (uint16_t)(c - bj);
           }
-      }
+      });
+      for (int64_t sl = 0; sl < ns; ++sl) n16 += smode[sl];
     }
     std::vector<uint8_t> pcode;
     std::vector<double> dict;
@@ -594,7 +609,7 @@ struct gmg_solver {
         dict.assign(256, 0.0);
         for (size_t q = 0; q < keys.size(); ++q) std::memcpy(&dict[q], &keys[q], 8);
         pcode.assign((size_t)zpp, 0);
-        for (int64_t sl = 0; sl < ns; ++sl) {
+        parallel_for(ns, [&](int64_t sl) {
           const int64_t w = (soff[sl + 1] - soff[sl]) / 64;
           for (int64_t j = 0; j < w; ++j)
             for (int l = 0; l < 64; ++l) {
@@ -606,7 +621,7 @@ struct gmg_solver {
                 pcode[poff[sl] + (j / 4) * 256 + l * 4 + (j % 4)] = (uint8_t)code;
               }
             }
-        }
+        });
       }
     }
     // 16-bit offsets pay off only together with the value dictionary (measured: with 8-byte
