@@ -1123,6 +1123,7 @@ struct gmg_solver {
 
   void setup();
   void build_coarse();
+  void build_coarse_device(const HostCSR &A);
 };
 
 // ----------------------------------------------------------------------------
@@ -1339,10 +1340,14 @@ void gmg_solver::build_coarse()
 {
   const HostCSR &A = lev[nlev - 1].hA;
   const int n = (int)A.nrows;
-  // the exact factorisation + inversion runs on the host (setup only): O(n^2 * bandwidth)
-  REQUIRE(n <= env_int("GMG_MAX_COARSE", 12000), GMG_ERR_UNSUPPORTED,
-          "coarsest level has " + std::to_string(n) + " dofs: too large for the dense-inverse coarse solver; "
-          "add multigrid levels (or raise GMG_MAX_COARSE and accept a long setup)");
+  // Small coarse levels: exact banded LU with partial pivoting on the host (O(n^2 * bandwidth)).
+  // Large ones: blocked Gauss-Jordan on the device (no pivoting; result verified below).
+  if (n > env_int("GMG_COARSE_HOST_MAX", 6000)) {
+    REQUIRE((double)n * n * 8.0 <= 64.0e9, GMG_ERR_UNSUPPORTED,
+            "coarsest level has " + std::to_string(n) + " dofs: its dense inverse would not fit; add multigrid levels");
+    build_coarse_device(A);
+    return;
+  }
   BandLU lu;
   REQUIRE(lu.factor(A), GMG_ERR_SINGULAR, "coarsest-level matrix is singular");
   std::vector<double> inv((size_t)n * n);
@@ -1363,6 +1368,52 @@ void gmg_solver::build_coarse()
   for (auto &t : th) t.join();
   d_Ainv = upload(inv);
   HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void gmg_solver::build_coarse_device(const HostCSR &A)
+{
+  const int n = (int)A.nrows;
+  double *D = dalloc<double>((size_t)n * n);
+  HIP_CHECK(hipMemsetAsync(D, 0, sizeof(double) * (size_t)n * n, stream));
+  int64_t *d_ptr = upload(A.ptr);
+  int32_t *d_col = upload(A.col);
+  double *d_val = upload(A.val);
+  hipLaunchKernelGGL((densify_kernel<int64_t>), dim3((n + 255) / 256), dim3(256), 0, stream, (int64_t)n, d_ptr, d_col, d_val, D);
+  HIP_CHECK(hipGetLastError());
+  double *Pinv = dvec(GJ_B * GJ_B), *R = dvec((int64_t)GJ_B * n), *C = dvec((int64_t)GJ_B * n), *Cp = dvec((int64_t)GJ_B * n);
+  int *d_bad = dalloc<int>(1);
+  HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
+  const dim3 tiles((n + 63) / 64, (n + 63) / 64);
+  for (int k0 = 0; k0 < n; k0 += GJ_B) {
+    const int b = std::min(GJ_B, n - k0);
+    hipLaunchKernelGGL(gj_diag_kernel, dim3(1), dim3(GJ_B * GJ_B), 0, stream, n, k0, b, D, Pinv, d_bad);
+    hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)(((int64_t)n * b + 255) / 256)), dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
+    hipLaunchKernelGGL(gj_update_kernel, tiles, dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
+    HIP_CHECK(hipGetLastError());
+  }
+  int bad = 0;
+  HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  REQUIRE(bad == 0, GMG_ERR_SINGULAR, "coarsest-level matrix needs pivoting (zero pivot in the device inversion); add multigrid levels");
+  d_Ainv = D;
+  // verify: A*(Ainv*v) == v for a deterministic vector (host sparse product, device GEMV)
+  std::vector<double> v((size_t)n), w((size_t)n);
+  for (int i = 0; i < n; ++i) v[i] = 1.0 + 0.5 * std::sin(0.37 * i);
+  double *dv = upload(v), *dw = dvec(n);
+  const int grid = (n + 3) / 4;
+  hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid), dim3(kBlock), 0, stream, n, d_Ainv, dv, dw);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(w.data(), dw, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  double err = 0.0, nv = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double sAw = 0.0;
+    for (int64_t k = A.ptr[i]; k < A.ptr[i + 1]; ++k) sAw += A.val[k] * w[A.col[k]];
+    err += (sAw - v[i]) * (sAw - v[i]);
+    nv += v[i] * v[i];
+  }
+  REQUIRE(std::isfinite(err) && std::sqrt(err / nv) < 1.0e-8, GMG_ERR_SINGULAR,
+          "device inversion of the coarsest level is inaccurate (matrix needs pivoting); add multigrid levels");
 }
 
 // numerical_setup(ss::GMGSymbolicSetup,mat): GMGLinearSolvers.jl:183-210

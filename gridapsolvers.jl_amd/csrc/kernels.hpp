@@ -642,6 +642,112 @@ __global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int n, const double 
 }
 
 // ---------------------------------------------------------------------------
+// Device-side dense inversion of a large coarsest-level matrix (setup only): blocked
+// Gauss-Jordan without pivoting, panel width GJ_B.  For panel K = [k0,k0+b):
+//   Pinv = A[K,K]^-1 ; R = Pinv*A[K,:] ; C = A[:,K]
+//   A[i,j] -= C[i,:]*R[:,j]  (i,j not in K) ; A[K,notK] = R ; A[notK,K] = -C*Pinv ; A[K,K] = Pinv
+// After the last panel A holds A^-1.  Valid for matrices that need no pivoting (SPD /
+// diagonally dominant coarse operators); the caller verifies the result.
+// ---------------------------------------------------------------------------
+constexpr int GJ_B = 32;
+
+// densify: D[i*n + col] += val
+template <typename PtrT>
+__global__ void densify_kernel(int64_t n, const PtrT *__restrict__ rowptr, const int32_t *__restrict__ col,
+                               const double *__restrict__ val, double *__restrict__ D)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (PtrT k = rowptr[i]; k < rowptr[i + 1]; ++k) D[(size_t)i * n + col[k]] += val[k];
+}
+
+// one workgroup: Pinv = A[K,K]^-1 (Gauss-Jordan in LDS, no pivoting); flags a zero pivot
+__global__ __launch_bounds__(GJ_B *GJ_B) void gj_diag_kernel(int n, int k0, int b, const double *__restrict__ A,
+                                                               double *__restrict__ Pinv, int *__restrict__ bad)
+{
+  __shared__ double M[GJ_B][GJ_B + 1], X[GJ_B][GJ_B + 1];
+  const int r = threadIdx.x / GJ_B, c = threadIdx.x % GJ_B;
+  const bool in = r < b && c < b;
+  M[r][c] = in ? A[(size_t)(k0 + r) * n + k0 + c] : (r == c ? 1.0 : 0.0);
+  X[r][c] = (r == c) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int j = 0; j < GJ_B; ++j) {
+    // all reads of step j first, then one barrier, then the writes
+    const double d = M[j][j];
+    const double mjc = M[j][c] / d, xjc = X[j][c] / d;
+    const double f = M[r][j];
+    __syncthreads();
+    if (d == 0.0) { if (threadIdx.x == 0) atomicAdd(bad, 1); return; }   // uniform
+    if (r == j) { M[j][c] = mjc; X[j][c] = xjc; }
+    else { M[r][c] -= f * mjc; X[r][c] -= f * xjc; }
+    __syncthreads();
+  }
+  if (in) Pinv[r * GJ_B + c] = X[r][c];
+}
+
+// panels: R[t][j] = sum_u Pinv[t][u]*A[k0+u][j] ; C[i][t] = A[i][k0+t] ; Cp[i][t] = -sum_u C[i][u]*Pinv[u][t]
+__global__ void gj_panels_kernel(int n, int k0, int b, const double *__restrict__ A, const double *__restrict__ Pinv,
+                                 double *__restrict__ R, double *__restrict__ C, double *__restrict__ Cp)
+{
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over n*b
+  if (idx >= (int64_t)n * b) return;
+  const int t = (int)(idx % b);
+  const int64_t q = idx / b;                                              // column j (for R) / row i (for C)
+  double s = 0.0;
+  for (int u = 0; u < b; ++u) s += Pinv[t * GJ_B + u] * A[(size_t)(k0 + u) * n + q];
+  R[(size_t)t * n + q] = s;
+  C[(size_t)q * GJ_B + t] = A[(size_t)q * n + k0 + t];
+  double sp = 0.0;
+  for (int u = 0; u < b; ++u) sp += A[(size_t)q * n + k0 + u] * Pinv[u * GJ_B + t];
+  Cp[(size_t)q * GJ_B + t] = -sp;
+}
+
+// trailing update, 64x64 tile per workgroup, 4x4 outputs per thread
+__global__ __launch_bounds__(256) void gj_update_kernel(int n, int k0, int b, double *__restrict__ A,
+                                                        const double *__restrict__ Pinv, const double *__restrict__ R,
+                                                        const double *__restrict__ C, const double *__restrict__ Cp)
+{
+  __shared__ double sC[64][GJ_B + 1], sR[GJ_B][64 + 1];
+  const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * GJ_B; e += 256) {
+    const int i = e / GJ_B, t = e % GJ_B;
+    sC[i][t] = (ti + i < n && t < b) ? C[(size_t)(ti + i) * GJ_B + t] : 0.0;
+    const int tt = e / 64, j = e % 64;
+    sR[tt][j] = (tj + j < n && tt < b) ? R[(size_t)tt * n + tj + j] : 0.0;
+  }
+  __syncthreads();
+  const int li = (threadIdx.x / 16) * 4, lj = (threadIdx.x % 16) * 4;
+  double acc[4][4] = {};
+  for (int t = 0; t < GJ_B; ++t) {
+    double cv[4], rv[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { cv[a] = sC[li + a][t]; rv[a] = sR[t][lj + a]; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] += cv[a] * rv[c];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = ti + li + a;
+    if (i >= n) continue;
+    const bool iK = i >= k0 && i < k0 + b;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int j = tj + lj + c;
+      if (j >= n) continue;
+      const bool jK = j >= k0 && j < k0 + b;
+      double v;
+      if (iK && jK) v = Pinv[(i - k0) * GJ_B + (j - k0)];
+      else if (iK) v = R[(size_t)(i - k0) * n + j];
+      else if (jK) v = Cp[(size_t)i * GJ_B + (j - k0)];
+      else v = A[(size_t)i * n + j] - acc[a][c];
+      A[(size_t)i * n + j] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K9/K10: patch smoother.
 //  setup : extract A[p,p] (BlockJacobiSolvers.jl:160), factorise (LU with partial
 //          pivoting = PatchSolvers.jl:176 lu!, or NoPivot = BlockJacobiSolvers.jl:162)

@@ -130,7 +130,8 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
 
 /* numerical_setup(ss,A): GMGLinearSolvers.jl:183-210 -- uploads operators, builds
  * D^-1, R = P^T, patch factors, work vectors and the coarse solver
- * (coarsest_solver = LUSolver(), :54,423-434 -> dense inverse on the device). */
+ * (coarsest_solver = LUSolver(), :54,423-434 -> dense inverse applied as one GEMV per cycle;
+ * factorised on the host up to 6000 dofs, inverted on the device above). */
 GMG_API int gmg_setup(gmg_handle_t h);
 
 /* ---- hot path ---------------------------------------------------------------- */
