@@ -16,6 +16,8 @@ CONVERGED_ATOL, CONVERGED_RTOL, DIVERGED_MAXITER, DIVERGED_BREAKDOWN = 0, 1, 2, 
 PRE, POST, PRE_AND_POST = 0, 1, 2
 PATCH_LU, PATCH_NOPIVOT = 0, 1
 OP_A, OP_P, OP_R = 0, 1, 2
+BLOCK_DIAGONAL, BLOCK_LOWER, BLOCK_UPPER = 0, 1, 2
+BLOCK_GMG, BLOCK_CG_JACOBI, BLOCK_LU, BLOCK_JACOBI = 1, 2, 3, 4
 
 
 class Result(C.Structure):
@@ -70,6 +72,26 @@ SYMBOLS = {
     "gmg_level_format": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                          C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gmg_device_bytes": [C.c_void_p, C.POINTER(C.c_int64)],
+    "gmg_block_create": [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int],
+    "gmg_block_destroy": [C.c_void_p],
+    "gmg_block_last_error": [C.c_void_p],
+    "gmg_block_set_system_block": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_int],
+    "gmg_block_set_precond_block": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_int],
+    "gmg_block_set_coeff": [C.c_void_p, C.c_int, C.c_int, C.c_double],
+    "gmg_block_set_diag_gmg": [C.c_void_p, C.c_int, C.c_void_p],
+    "gmg_block_set_diag_solver": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double],
+    "gmg_block_set_diag_matrix": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_int],
+    "gmg_block_setup": [C.c_void_p],
+    "gmg_block_precond_apply": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
+    "gmg_block_apply_system": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
+    "gmg_block_fgmres_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_double, C.c_double, C.c_int, C.POINTER(Result), C.c_void_p, C.c_int],
+    "gmg_block_cg_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                           C.POINTER(Result), C.c_void_p, C.c_int],
+    "gmg_block_diag_log": [C.c_void_p, C.c_int, C.POINTER(Result)],
 }
 
 HOST_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double),
@@ -106,7 +128,7 @@ def load(path=None):
     for name, args in SYMBOLS.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_char_p if name == "gmg_last_error" else C.c_int
+        fn.restype = C.c_char_p if name in ("gmg_last_error", "gmg_block_last_error") else C.c_int
     _LIB = lib
     return lib
 
@@ -114,5 +136,12 @@ def load(path=None):
 def check(handle, status):
     if status != OK:
         msg = load().gmg_last_error(handle)
+        raise GmgError(status, msg.decode() if msg else "")
+    return status
+
+
+def check_block(handle, status):
+    if status != OK:
+        msg = load().gmg_block_last_error(handle)
         raise GmgError(status, msg.decode() if msg else "")
     return status

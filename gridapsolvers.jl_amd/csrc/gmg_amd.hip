@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -310,9 +312,17 @@ int env_int(const char *name, int dflt)
 // ----------------------------------------------------------------------------
 // the solver object behind gmg_handle_t
 // ----------------------------------------------------------------------------
+// operator / preconditioner callbacks of the Krylov drivers (cg_core, fgmres_core)
+struct KrylovOps {
+  std::function<void(double *x, const double *b, double *r)> resid;          // r = b - A x
+  std::function<void(double *x, double *y)> apply;                           // y = A x
+  std::function<void(double *z, const double *r, double known_res)> precond; // empty: Pl === nothing
+};
+
 struct gmg_solver {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream work is issued on (a block solver re-points it at its own)
+  hipStream_t own_stream = nullptr;  // the stream this handle created and destroys
   int nlev = 0;
   std::vector<Level> lev;
   std::string err;
@@ -1000,15 +1010,16 @@ struct gmg_solver {
     }
   }
 
-  void coarse_solve(const double *r, double *x)
+  // x = Ainv r (row-major dense inverse, one wave per row)
+  void dense_solve(const double *Ainv, int n, const double *r, double *x)
   {
-    const int n = (int)lev[nlev - 1].n;
     const int waves_per_block = kBlock / 64;
-    // (in distributed runs the coarsest level is replicated: same kernel, global matrix)
     const int grid = (n + waves_per_block - 1) / waves_per_block;
-    hipLaunchKernelGGL(dense_gemv_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, stream, n, d_Ainv, r, x);
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, stream, n, Ainv, r, x);
     HIP_CHECK(hipGetLastError());
   }
+  // (in distributed runs the coarsest level is replicated: same kernel, global matrix)
+  void coarse_solve(const double *r, double *x) { dense_solve(d_Ainv, (int)lev[nlev - 1].n, r, x); }
 
   // gmg_v_cycle! / gmg_w_cycle! / gmg_f_cycle!, GMGLinearSolvers.jl:468-610
   void cycle(int l, double *x, const double *r_in, bool x_zero, int ctype)
@@ -1121,10 +1132,192 @@ struct gmg_solver {
     return st_extra[i];
   }
 
+  void read_tuning()
+  {
+    xcd_remap = env_int("GMG_XCD_REMAP", 0);   // measured: no gain from XCD-contiguous ranges (profiles/r01_tuning.md)
+    lanes_override = env_int("GMG_LANES_LOG2", -1);
+    one_gather_sweep = env_int("GMG_ONE_GATHER", 1);
+    use_sell = env_int("GMG_SELL", 1);
+    use_idx16 = env_int("GMG_IDX16", 1);
+    use_vdict = env_int("GMG_VDICT", 1);
+    sell_un = env_int("GMG_SELL_UN", 6);
+    sell_block = std::min(256, env_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
+    if (const char *mp = std::getenv("GMG_SELL_MAXPAD")) sell_maxpad = std::atof(mp);
+    nt_loads = env_int("GMG_NT", 1);
+    tile = kTile;
+  }
+  // inv_diag = 1 ./ diag(A) (JacobiLinearSolvers.jl:20-23); needs the CSR stream of A (before drop_csr_stream)
+  double *build_inv_diag(const DevCSR &A, int &nzero)
+  {
+    const int64_t n = A.nrows;
+    double *dinv = dalloc<double>((size_t)n);
+    int *d_nzero = dalloc<int>(1);
+    HIP_CHECK(hipMemsetAsync(d_nzero, 0, sizeof(int), stream));
+    const int grid = (int)std::max<int64_t>(1, (n + 255) / 256);
+    if (A.ptr64)
+      hipLaunchKernelGGL((inv_diag_kernel<int64_t>), dim3(grid), dim3(256), 0, stream, n, (const int64_t *)A.rowptr, A.col, A.val, dinv, d_nzero);
+    else
+      hipLaunchKernelGGL((inv_diag_kernel<int32_t>), dim3(grid), dim3(256), 0, stream, n, (const int32_t *)A.rowptr, A.col, A.val, dinv, d_nzero);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(&nzero, d_nzero, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return dinv;
+  }
+  // reductions + pinned scalars (also all a block-solver engine without levels needs)
+  void init_reductions()
+  {
+    d_partials = dvec(kRedBlocks);
+    d_scalars = dvec(kScalarSlots);
+    if (!h_scalars) HIP_CHECK(hipHostMalloc((void **)&h_scalars, kScalarSlots * sizeof(double)));
+  }
+  KrylovOps level0_ops(int use_precond);
   void setup();
   void build_coarse();
-  void build_coarse_device(const HostCSR &A);
+  double *build_dense_inverse(const HostCSR &A, const std::string &what);
+  double *build_coarse_device(const HostCSR &A, const std::string &what);
 };
+
+// ----------------------------------------------------------------------------
+// Krylov drivers, written against callbacks so that the single-matrix solvers
+// (gmg_cg_solve / gmg_fgmres_solve) and the block solvers (gmg_block_*) share them.
+// `S` supplies the stream, the reductions and the vector kernels.
+// ----------------------------------------------------------------------------
+
+KrylovOps gmg_solver::level0_ops(int use_precond)
+{
+  KrylovOps ops;
+  ops.resid = [this](double *x, const double *b, double *r) { apply_A_resid(0, x, b, r); };
+  ops.apply = [this](double *x, double *y) { apply_A_set(0, x, y); };
+  if (use_precond) ops.precond = [this, use_precond](double *z, const double *r, double known) { krylov_precond(use_precond, z, r, known); };
+  return ops;
+}
+
+// solve!(x,ns::CGNumericalSetup,b), Krylov/CGSolvers.jl:73-120
+static double cg_core(gmg_solver &S, int64_t n, const double *db, double *dx, double *w, double *p, double *z, double *r,
+               const KrylovOps &ops, bool flexible, ConvLog &log)
+{
+  ops.resid(dx, db, r);                                  // CGSolvers.jl:79  w = A x ; r = b - w
+  S.zero(p, n);                                          // :80
+  S.zero(z, n);                                          // :81
+  double gamma = 1.0, beta = 0.0, alpha = 0.0;           // :82
+  double resn = S.norm(n, r);                            // :85
+  bool done = log.init(resn);                            // :86
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kBlock - 1) / kBlock));
+  while (!done) {
+    if (!ops.precond) {                                  // :90-92
+      S.copy(z, r, n);
+      beta = gamma; gamma = S.dot(n, r, r); beta = gamma / beta;
+    } else if (!flexible) {                              // :93-95
+      ops.precond(z, r, resn);
+      beta = gamma; gamma = S.dot(n, z, r); beta = gamma / beta;
+    } else {                                             // :96-99
+      const double delta = S.dot(n, z, r);
+      ops.precond(z, r, resn);
+      beta = gamma; gamma = S.dot(n, z, r); beta = (gamma - delta) / beta;
+    }
+    hipLaunchKernelGGL(xpby_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, S.stream, n, z, beta, p); // :101
+    HIP_CHECK(hipGetLastError());
+    ops.apply(p, w);                                     // :104
+    alpha = gamma / S.dot(n, p, w);                      // :105
+    hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, alpha, p, w, dx, r, S.d_partials); // :108-109
+    HIP_CHECK(hipGetLastError());
+    S.finish_reduction(nb, 0, true);
+    resn = S.fetch_scalar(0);                            // :111
+    done = log.update(resn);                             // :112
+  }
+  return resn;
+}
+
+// solve!(x,ns::FGMRESNumericalSetup,b), Krylov/FGMRESSolvers.jl:130-199.  V/Z are the caller's basis
+// caches (:58-70); they grow by m_add when the basis outgrows them (:151-154).  nv = allocation length
+// of a basis vector (n plus ghost space in distributed runs).
+static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db, double *dx, std::vector<double *> &V,
+                   std::vector<double *> &Z, const KrylovOps &ops, int m0, bool restart, int m_add, ConvLog &log)
+{
+  int m = std::max<int>(m0, (int)Z.size());
+  while ((int)V.size() < m + 1) V.push_back(S.dvec(nv));
+  while ((int)Z.size() < m) Z.push_back(S.dvec(nv));
+  m = (int)Z.size();
+  // Hessenberg / rotations sized for the largest basis reachable in maxiter steps
+  const int hcap = std::max(m, log.maxiter + 1) + 1;
+  const int ldh = hcap + 1;
+  REQUIRE(hcap + 2 < kScalarSlots, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer");
+  std::vector<double> H((size_t)ldh * hcap, 0.0), g((size_t)hcap + 1, 0.0), c((size_t)hcap, 0.0), s((size_t)hcap, 0.0);
+  auto Hm = [&](int i, int j) -> double & { return H[(size_t)(i - 1) + (size_t)(j - 1) * ldh]; };
+  const int grid = gmg_solver::grid_for(n);
+
+  // krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 ; FGMRESSolvers.jl:136-140
+  ops.resid(dx, db, V[0]);
+  double beta = S.norm(n, V[0]);                         // :141
+  bool done = log.init(beta);                            // :142
+  while (!done) {
+    int j = 1;                                           // :145
+    hipLaunchKernelGGL(div_kernel, dim3(grid), dim3(256), 0, S.stream, n, beta, V[0]); // :146
+    HIP_CHECK(hipGetLastError());
+    std::fill(H.begin(), H.end(), 0.0);                  // :147
+    std::fill(g.begin(), g.end(), 0.0); g[0] = beta;     // :148
+    while (!done && !(restart && j > m0)) {              // :149
+      if (j > m) {                                       // :151-154
+        for (int q = 0; q < m_add; ++q) { V.push_back(S.dvec(nv)); Z.push_back(S.dvec(nv)); }
+        m += m_add;
+      }
+      double *Vn = V[j], *Zj = Z[j - 1];
+      // krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25
+      if (ops.precond) ops.precond(Zj, V[j - 1], -1.0);
+      else S.copy(Zj, V[j - 1], n);
+      ops.apply(Zj, Vn);                                 // :159
+      for (int i = 1; i <= j; ++i) {                     // :160-163 modified Gram-Schmidt
+        S.dot_async(n, Vn, V[i - 1], i, false);
+        hipLaunchKernelGGL(axmy_dev_kernel, dim3(grid), dim3(256), 0, S.stream, n, S.d_scalars + i, V[i - 1], Vn);
+        HIP_CHECK(hipGetLastError());
+      }
+      S.dot_async(n, Vn, Vn, j + 1, true);               // :164
+      hipLaunchKernelGGL(div_dev_kernel, dim3(grid), dim3(256), 0, S.stream, n, S.d_scalars + (j + 1), Vn); // :165
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(S.h_scalars + 1, S.d_scalars + 1, sizeof(double) * (size_t)(j + 1), hipMemcpyDeviceToHost, S.stream));
+      HIP_CHECK(hipStreamSynchronize(S.stream));
+      for (int i = 1; i <= j + 1; ++i) Hm(i, j) = S.h_scalars[i];
+      for (int i = 1; i <= j - 1; ++i) {                 // :168-172
+        const double gm = c[i - 1] * Hm(i, j) + s[i - 1] * Hm(i + 1, j);
+        Hm(i + 1, j) = -s[i - 1] * Hm(i, j) + c[i - 1] * Hm(i + 1, j);
+        Hm(i, j) = gm;
+      }
+      { // LinearAlgebra.givensAlgorithm (:175), normal-range branch + LAPACK sign rule
+        const double f = Hm(j, j), gg = Hm(j + 1, j);
+        double cs, sn;
+        if (gg == 0.0) { cs = 1.0; sn = 0.0; }
+        else if (f == 0.0) { cs = 0.0; sn = 1.0; }
+        else {
+          const double safmn2 = std::ldexp(1.0, -485), safmx2 = 1.0 / safmn2;
+          double f1 = f, g1 = gg, scale = std::max(std::fabs(f1), std::fabs(g1));
+          while (scale >= safmx2) { f1 *= safmn2; g1 *= safmn2; scale = std::max(std::fabs(f1), std::fabs(g1)); }
+          while (scale <= safmn2) { f1 *= safmx2; g1 *= safmx2; scale = std::max(std::fabs(f1), std::fabs(g1)); }
+          const double rr = std::sqrt(f1 * f1 + g1 * g1);
+          cs = f1 / rr; sn = g1 / rr;
+          if (std::fabs(f) > std::fabs(gg) && cs < 0.0) { cs = -cs; sn = -sn; }
+        }
+        c[j - 1] = cs; s[j - 1] = sn;
+      }
+      Hm(j, j) = c[j - 1] * Hm(j, j) + s[j - 1] * Hm(j + 1, j); Hm(j + 1, j) = 0.0; // :176
+      g[j] = -s[j - 1] * g[j - 1]; g[j - 1] = c[j - 1] * g[j - 1];                  // :177
+      beta = std::fabs(g[j]);                            // :179
+      j += 1;                                            // :180
+      done = log.update(beta);                           // :181
+    }
+    j = j - 1;                                           // :183
+    for (int i = j; i >= 1; --i) {                       // :186-188
+      double acc = 0.0;
+      for (int k = i + 1; k <= j; ++k) acc += Hm(i, k) * g[k - 1];
+      g[i - 1] = (g[i - 1] - acc) / Hm(i, i);
+    }
+    for (int i = 1; i <= j; ++i) {                       // :191-193
+      hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, g[i - 1], Z[i - 1], dx);
+      HIP_CHECK(hipGetLastError());
+    }
+    ops.resid(dx, db, V[0]);                             // :194
+  }
+  return beta;
+}
 
 // ----------------------------------------------------------------------------
 // patch smoother: setup + application
@@ -1338,18 +1531,22 @@ struct BandLU {
 
 void gmg_solver::build_coarse()
 {
-  const HostCSR &A = lev[nlev - 1].hA;
+  d_Ainv = build_dense_inverse(lev[nlev - 1].hA, "coarsest-level matrix");
+}
+
+// LUSolver() on a small sparse matrix: row-major dense inverse on the device.
+double *gmg_solver::build_dense_inverse(const HostCSR &A, const std::string &what)
+{
   const int n = (int)A.nrows;
-  // Small coarse levels: exact banded LU with partial pivoting on the host (O(n^2 * bandwidth)).
+  // Small matrices: exact banded LU with partial pivoting on the host (O(n^2 * bandwidth)).
   // Large ones: blocked Gauss-Jordan on the device (no pivoting; result verified below).
   if (n > env_int("GMG_COARSE_HOST_MAX", 6000)) {
     REQUIRE((double)n * n * 8.0 <= 64.0e9, GMG_ERR_UNSUPPORTED,
-            "coarsest level has " + std::to_string(n) + " dofs: its dense inverse would not fit; add multigrid levels");
-    build_coarse_device(A);
-    return;
+            what + " has " + std::to_string(n) + " dofs: its dense inverse would not fit; add multigrid levels");
+    return build_coarse_device(A, what);
   }
   BandLU lu;
-  REQUIRE(lu.factor(A), GMG_ERR_SINGULAR, "coarsest-level matrix is singular");
+  REQUIRE(lu.factor(A), GMG_ERR_SINGULAR, what + " is singular");
   std::vector<double> inv((size_t)n * n);
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const int nthreads = (int)std::min<unsigned>(hw, (unsigned)std::max(1, n / 16));
@@ -1366,11 +1563,12 @@ void gmg_solver::build_coarse()
   for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
   work(0);
   for (auto &t : th) t.join();
-  d_Ainv = upload(inv);
+  double *d = upload(inv);
   HIP_CHECK(hipStreamSynchronize(stream));
+  return d;
 }
 
-void gmg_solver::build_coarse_device(const HostCSR &A)
+double *gmg_solver::build_coarse_device(const HostCSR &A, const std::string &what)
 {
   const int n = (int)A.nrows;
   double *D = dalloc<double>((size_t)n * n);
@@ -1394,14 +1592,13 @@ void gmg_solver::build_coarse_device(const HostCSR &A)
   int bad = 0;
   HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
-  REQUIRE(bad == 0, GMG_ERR_SINGULAR, "coarsest-level matrix needs pivoting (zero pivot in the device inversion); add multigrid levels");
-  d_Ainv = D;
+  REQUIRE(bad == 0, GMG_ERR_SINGULAR, what + " needs pivoting (zero pivot in the device inversion); add multigrid levels");
   // verify: A*(Ainv*v) == v for a deterministic vector (host sparse product, device GEMV)
   std::vector<double> v((size_t)n), w((size_t)n);
   for (int i = 0; i < n; ++i) v[i] = 1.0 + 0.5 * std::sin(0.37 * i);
   double *dv = upload(v), *dw = dvec(n);
   const int grid = (n + 3) / 4;
-  hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid), dim3(kBlock), 0, stream, n, d_Ainv, dv, dw);
+  hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid), dim3(kBlock), 0, stream, n, D, dv, dw);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(w.data(), dw, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
@@ -1413,7 +1610,8 @@ void gmg_solver::build_coarse_device(const HostCSR &A)
     nv += v[i] * v[i];
   }
   REQUIRE(std::isfinite(err) && std::sqrt(err / nv) < 1.0e-8, GMG_ERR_SINGULAR,
-          "device inversion of the coarsest level is inaccurate (matrix needs pivoting); add multigrid levels");
+          "device inversion of the " + what + " is inaccurate (matrix needs pivoting); add multigrid levels");
+  return D;
 }
 
 // numerical_setup(ss::GMGSymbolicSetup,mat): GMGLinearSolvers.jl:183-210
@@ -1421,17 +1619,7 @@ void gmg_solver::setup()
 {
   HIP_CHECK(hipSetDevice(device));
   free_all();
-  xcd_remap = env_int("GMG_XCD_REMAP", 0);   // measured: no gain from XCD-contiguous ranges (profiles/r01_tuning.md)
-  lanes_override = env_int("GMG_LANES_LOG2", -1);
-  one_gather_sweep = env_int("GMG_ONE_GATHER", 1);
-  use_sell = env_int("GMG_SELL", 1);
-  use_idx16 = env_int("GMG_IDX16", 1);
-  use_vdict = env_int("GMG_VDICT", 1);
-  sell_un = env_int("GMG_SELL_UN", 6);
-  sell_block = std::min(256, env_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
-  if (const char *mp = std::getenv("GMG_SELL_MAXPAD")) sell_maxpad = std::atof(mp);
-  nt_loads = env_int("GMG_NT", 1);
-  tile = kTile;
+  read_tuning();
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));
@@ -1471,9 +1659,7 @@ void gmg_solver::setup()
     one_gather_sweep = 1;   // the one-gather sweep needs only s-ghosts
     for (int64_t g : h_rep_gid) REQUIRE(g >= 0 && g < lev[rep_from].n, GMG_ERR_INVALID, "replication: global id out of range");
   }
-  d_partials = dvec(kRedBlocks);
-  d_scalars = dvec(kScalarSlots);
-  if (!h_scalars) HIP_CHECK(hipHostMalloc((void **)&h_scalars, kScalarSlots * sizeof(double)));
+  init_reductions();
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     if (L.halo.present && comm.nranks > 1) {
@@ -1523,18 +1709,8 @@ void gmg_solver::setup()
         L.R = upload_csr(Rt);
       }
       // :189-190 smoother caches: inv_diag = 1 ./ diag(A) (JacobiLinearSolvers.jl:20-23)
-      L.dinv = dalloc<double>((size_t)L.n);
-      int *d_nzero = dalloc<int>(1);
-      HIP_CHECK(hipMemsetAsync(d_nzero, 0, sizeof(int), stream));
-      const int grid = (int)std::max<int64_t>(1, (L.n + 255) / 256);
-      if (L.A.ptr64)
-        hipLaunchKernelGGL((inv_diag_kernel<int64_t>), dim3(grid), dim3(256), 0, stream, L.n, (const int64_t *)L.A.rowptr, L.A.col, L.A.val, L.dinv, d_nzero);
-      else
-        hipLaunchKernelGGL((inv_diag_kernel<int32_t>), dim3(grid), dim3(256), 0, stream, L.n, (const int32_t *)L.A.rowptr, L.A.col, L.A.val, L.dinv, d_nzero);
-      HIP_CHECK(hipGetLastError());
       int nzero = 0;
-      HIP_CHECK(hipMemcpyAsync(&nzero, d_nzero, sizeof(int), hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipStreamSynchronize(stream));
+      L.dinv = build_inv_diag(L.A, nzero);
       const bool need_diag = (L.pre.kind == SM_JACOBI) || (L.post.kind == SM_JACOBI);
       REQUIRE(!(need_diag && nzero > 0), GMG_ERR_SINGULAR, "zero diagonal entry on level " + std::to_string(l));
       if (L.has_pcorr) {
@@ -1630,6 +1806,7 @@ int gmg_create(gmg_handle_t *out, int nlevels, int device_id)
       delete s;
       throw GmgError{GMG_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)};
     }
+    s->own_stream = s->stream;
     *out = s;
   });
 }
@@ -1652,7 +1829,7 @@ int gmg_destroy(gmg_handle_t h)
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
   if (h->h_scalars) (void)hipHostFree(h->h_scalars);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return GMG_OK;
 }
@@ -1824,39 +2001,10 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
     double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
     if (memspace == GMG_MEM_HOST || dist)
       HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
-    double *w = S.cg_w, *p = S.cg_p, *z = S.cg_z, *r = S.cg_r;
     ConvLog log;
     log.configure(maxiter, atol, rtol);
-
-    S.apply_A_resid(0, dx, db, r);                         // CGSolvers.jl:79  w = A x ; r = b - w
-    S.zero(p, n);                                          // :80
-    S.zero(z, n);                                          // :81
-    double gamma = 1.0, beta = 0.0, alpha = 0.0;           // :82
-    double resn = S.norm(n, r);                            // :85
-    bool done = log.init(resn);                            // :86
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kBlock - 1) / kBlock));
-    while (!done) {
-      if (!use_precond) {                                  // :90-92
-        S.copy(z, r, n);
-        beta = gamma; gamma = S.dot(n, r, r); beta = gamma / beta;
-      } else if (!flexible) {                              // :93-95
-        S.krylov_precond(use_precond, z, r, resn);
-        beta = gamma; gamma = S.dot(n, z, r); beta = gamma / beta;
-      } else {                                             // :96-99
-        const double delta = S.dot(n, z, r);
-        S.krylov_precond(use_precond, z, r, resn);
-        beta = gamma; gamma = S.dot(n, z, r); beta = (gamma - delta) / beta;
-      }
-      hipLaunchKernelGGL(xpby_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, S.stream, n, z, beta, p); // :101
-      HIP_CHECK(hipGetLastError());
-      S.apply_A_set(0, p, w);                              // :104
-      alpha = gamma / S.dot(n, p, w);                      // :105
-      hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, alpha, p, w, dx, r, S.d_partials); // :108-109
-      HIP_CHECK(hipGetLastError());
-      S.finish_reduction(nb, 0, true);
-      resn = S.fetch_scalar(0);                            // :111
-      done = log.update(resn);                             // :112
-    }
+    KrylovOps ops = S.level0_ops(use_precond);
+    const double resn = cg_core(S, n, db, dx, S.cg_w, S.cg_p, S.cg_z, S.cg_r, ops, flexible != 0, log);
     S.out_vec(x, dx, n, memspace);
     log.export_to(res, hist, hist_cap, resn);              // :118
   });
@@ -1879,92 +2027,10 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
     double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
     if (memspace == GMG_MEM_HOST || dist)
       HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
-    // caches FGMRESSolvers.jl:58-70
-    int m = std::max<int>(m0, (int)S.fg_Z.size());
-    while ((int)S.fg_V.size() < m + 1) S.fg_V.push_back(S.dvec(nv));
-    while ((int)S.fg_Z.size() < m) S.fg_Z.push_back(S.dvec(nv));
-    m = (int)S.fg_Z.size();
-    auto &V = S.fg_V;
-    auto &Z = S.fg_Z;
-    // Hessenberg / rotations sized for the largest basis reachable in maxiter steps
-    const int hcap = std::max(m, maxiter + 1) + 1;
-    const int ldh = hcap + 1;
-    REQUIRE(hcap + 2 < kScalarSlots, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer");
-    std::vector<double> H((size_t)ldh * hcap, 0.0), g((size_t)hcap + 1, 0.0), c((size_t)hcap, 0.0), s((size_t)hcap, 0.0);
-    auto Hm = [&](int i, int j) -> double & { return H[(size_t)(i - 1) + (size_t)(j - 1) * ldh]; };
     ConvLog log;
     log.configure(maxiter, atol, rtol);
-    const int grid = gmg_solver::grid_for(n);
-
-    // krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 ; FGMRESSolvers.jl:136-140
-    S.apply_A_resid(0, dx, db, V[0]);
-    double beta = S.norm(n, V[0]);                         // :141
-    bool done = log.init(beta);                            // :142
-    while (!done) {
-      int j = 1;                                           // :145
-      hipLaunchKernelGGL(div_kernel, dim3(grid), dim3(256), 0, S.stream, n, beta, V[0]); // :146
-      HIP_CHECK(hipGetLastError());
-      std::fill(H.begin(), H.end(), 0.0);                  // :147
-      std::fill(g.begin(), g.end(), 0.0); g[0] = beta;     // :148
-      while (!done && !(restart && j > m0)) {              // :149
-        if (j > m) {                                       // :151-154
-          for (int q = 0; q < m_add; ++q) { V.push_back(S.dvec(nv)); Z.push_back(S.dvec(nv)); }
-          m += m_add;
-        }
-        double *Vn = V[j], *Zj = Z[j - 1];
-        // krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25
-        S.krylov_precond(use_precond, Zj, V[j - 1], -1.0);
-        S.apply_A_set(0, Zj, Vn);                          // :159
-        for (int i = 1; i <= j; ++i) {                     // :160-163 modified Gram-Schmidt
-          S.dot_async(n, Vn, V[i - 1], i, false);
-          hipLaunchKernelGGL(axmy_dev_kernel, dim3(grid), dim3(256), 0, S.stream, n, S.d_scalars + i, V[i - 1], Vn);
-          HIP_CHECK(hipGetLastError());
-        }
-        S.dot_async(n, Vn, Vn, j + 1, true);               // :164
-        hipLaunchKernelGGL(div_dev_kernel, dim3(grid), dim3(256), 0, S.stream, n, S.d_scalars + (j + 1), Vn); // :165
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(S.h_scalars + 1, S.d_scalars + 1, sizeof(double) * (size_t)(j + 1), hipMemcpyDeviceToHost, S.stream));
-        HIP_CHECK(hipStreamSynchronize(S.stream));
-        for (int i = 1; i <= j + 1; ++i) Hm(i, j) = S.h_scalars[i];
-        for (int i = 1; i <= j - 1; ++i) {                 // :168-172
-          const double gm = c[i - 1] * Hm(i, j) + s[i - 1] * Hm(i + 1, j);
-          Hm(i + 1, j) = -s[i - 1] * Hm(i, j) + c[i - 1] * Hm(i + 1, j);
-          Hm(i, j) = gm;
-        }
-        { // LinearAlgebra.givensAlgorithm (:175), normal-range branch + LAPACK sign rule
-          const double f = Hm(j, j), gg = Hm(j + 1, j);
-          double cs, sn;
-          if (gg == 0.0) { cs = 1.0; sn = 0.0; }
-          else if (f == 0.0) { cs = 0.0; sn = 1.0; }
-          else {
-            const double safmn2 = std::ldexp(1.0, -485), safmx2 = 1.0 / safmn2;
-            double f1 = f, g1 = gg, scale = std::max(std::fabs(f1), std::fabs(g1));
-            while (scale >= safmx2) { f1 *= safmn2; g1 *= safmn2; scale = std::max(std::fabs(f1), std::fabs(g1)); }
-            while (scale <= safmn2) { f1 *= safmx2; g1 *= safmx2; scale = std::max(std::fabs(f1), std::fabs(g1)); }
-            const double rr = std::sqrt(f1 * f1 + g1 * g1);
-            cs = f1 / rr; sn = g1 / rr;
-            if (std::fabs(f) > std::fabs(gg) && cs < 0.0) { cs = -cs; sn = -sn; }
-          }
-          c[j - 1] = cs; s[j - 1] = sn;
-        }
-        Hm(j, j) = c[j - 1] * Hm(j, j) + s[j - 1] * Hm(j + 1, j); Hm(j + 1, j) = 0.0; // :176
-        g[j] = -s[j - 1] * g[j - 1]; g[j - 1] = c[j - 1] * g[j - 1];                  // :177
-        beta = std::fabs(g[j]);                            // :179
-        j += 1;                                            // :180
-        done = log.update(beta);                           // :181
-      }
-      j = j - 1;                                           // :183
-      for (int i = j; i >= 1; --i) {                       // :186-188
-        double acc = 0.0;
-        for (int k = i + 1; k <= j; ++k) acc += Hm(i, k) * g[k - 1];
-        g[i - 1] = (g[i - 1] - acc) / Hm(i, i);
-      }
-      for (int i = 1; i <= j; ++i) {                       // :191-193
-        hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, g[i - 1], Z[i - 1], dx);
-        HIP_CHECK(hipGetLastError());
-      }
-      S.apply_A_resid(0, dx, db, V[0]);                    // :194
-    }
+    KrylovOps ops = S.level0_ops(use_precond);
+    const double beta = fgmres_core(S, n, nv, db, dx, S.fg_V, S.fg_Z, ops, m0, restart != 0, m_add, log);
     S.out_vec(x, dx, n, memspace);
     log.export_to(res, hist, hist_cap, beta);              // :197
   });
@@ -2265,3 +2331,5 @@ int gmg_device_bytes(gmg_handle_t h, int64_t *bytes)
 }
 
 } // extern "C"
+
+#include "block.inc.hpp"

@@ -27,6 +27,7 @@ module GridapSolversAMD
 
 using LinearAlgebra
 using SparseArrays
+using BlockArrays: blocks
 using Gridap
 using Gridap.Algebra
 using GridapSolvers
@@ -34,6 +35,7 @@ using GridapSolvers.SolverInterfaces: ConvergenceLog, SolverTolerances
 using GridapSolvers.LinearSolvers: RichardsonSmoother, JacobiLinearSolver
 
 export HipGMGLinearSolver, HipCGSolver, HipFGMRESSolver, PatchTable, HipPatchProlongation
+export HipBlockTriangularSolver, HipBlockDiagonalSolver, HipBlockFGMRESSolver, block_mul!, block_cg_solve!
 
 const libgmgamd = get(ENV, "LIBGMGAMD", joinpath(@__DIR__, "..", "libgmgamd.so"))
 
@@ -342,6 +344,179 @@ function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<
       h, b, x, GMG_MEM_HOST, s.m, s.restart ? 1 : 0, s.m_add, tols.maxiter, tols.atol, tols.rtol, 1, res, hist, length(hist)))
   end
   _fill_log!(s.log, res[], hist)
+  return x
+end
+
+# ------------------------------------------------------------------------------------------------
+# Block preconditioners on the device (include/gmg_amd.h, "block preconditioners"):
+# BlockDiagonalSolver / BlockTriangularSolver (BlockSolvers/BlockTriangularSolvers.jl:55-85,186-242)
+# with the outer FGMRES on the BlockArrays system, the solver shape of test/Applications/StokesGMG.jl:142-153:
+#
+#     P      = HipBlockTriangularSolver([solver_u, solver_p]; mats=Dict((2,2)=>Mp), coeffs=[1.0 1.0; 0.0 1.0], half=:upper)
+#     solver = HipBlockFGMRESSolver(20, P; atol=1e-10, rtol=1e-12)
+#     ns = numerical_setup(symbolic_setup(solver,A),A); solve!(x,ns,b)       # A::BlockMatrix, x,b::BlockVector
+#
+# solvers[i]: HipGMGLinearSolver | CGSolver(JacobiLinearSolver()) | LUSolver() | JacobiLinearSolver().
+# `mats[(i,j)]` replaces the system block in the preconditioner (MatrixBlock / an assembled BiformBlock).
+# ------------------------------------------------------------------------------------------------
+const GMG_BLOCK_DIAGONAL, GMG_BLOCK_LOWER, GMG_BLOCK_UPPER = Cint(0), Cint(1), Cint(2)
+const GMG_BLOCK_GMG, GMG_BLOCK_CG_JACOBI, GMG_BLOCK_LU, GMG_BLOCK_JACOBI = Cint(1), Cint(2), Cint(3), Cint(4)
+
+function check_block(h::Ptr{Cvoid}, status::Cint)
+  if status != 0
+    msg = unsafe_string(ccall((:gmg_block_last_error, libgmgamd), Cstring, (Ptr{Cvoid},), h))
+    error("libgmgamd status $status: $msg")
+  end
+  return nothing
+end
+
+struct HipBlockTriangularSolver <: Gridap.Algebra.LinearSolver
+  solvers :: Vector{Any}
+  mats    :: Dict{Tuple{Int,Int},Any}
+  coeffs  :: Matrix{Float64}
+  half    :: Symbol                      # :upper | :lower | :diagonal (BlockDiagonalSolver)
+end
+function HipBlockTriangularSolver(solvers::AbstractVector; mats=Dict{Tuple{Int,Int},Any}(),
+                                  coeffs=fill(1.0,length(solvers),length(solvers)), half=:upper)
+  @assert half in (:upper,:lower,:diagonal)                                   # BlockTriangularSolvers.jl:65
+  @assert size(coeffs) == (length(solvers),length(solvers))
+  HipBlockTriangularSolver(collect(Any,solvers), Dict{Tuple{Int,Int},Any}(mats), Matrix{Float64}(coeffs), half)
+end
+HipBlockDiagonalSolver(solvers::AbstractVector; mats=Dict{Tuple{Int,Int},Any}()) =
+  HipBlockTriangularSolver(solvers; mats=mats, half=:diagonal)
+
+struct HipBlockFGMRESSolver <: Gridap.Algebra.LinearSolver
+  m :: Int; restart :: Bool; m_add :: Int
+  Pr :: HipBlockTriangularSolver
+  log :: ConvergenceLog{Float64}
+end
+HipBlockFGMRESSolver(m, Pr::HipBlockTriangularSolver; restart=false, m_add=1, maxiter=100, atol=1e-12, rtol=1.e-6,
+                     verbose=false, name="FGMRES-MI355X") =
+  HipBlockFGMRESSolver(m, restart, m_add, Pr, ConvergenceLog(name, SolverTolerances{Float64}(maxiter=maxiter,atol=atol,rtol=rtol); verbose=verbose))
+
+struct HipBlockSymbolicSetup{A} <: Gridap.Algebra.SymbolicSetup
+  solver :: A
+end
+Gridap.Algebra.symbolic_setup(s::Union{HipBlockTriangularSolver,HipBlockFGMRESSolver}, ::AbstractMatrix) = HipBlockSymbolicSetup(s)
+
+mutable struct HipBlockNumericalSetup{A} <: Gridap.Algebra.NumericalSetup
+  solver   :: A
+  handle   :: Ptr{Cvoid}
+  block_ns :: Vector{Any}                # the GMG numerical setups the handle borrows
+  n        :: Int
+end
+
+function _set_block(sym::Symbol, h, i, j, M::AbstractMatrix)
+  C = M isa SparseMatrixCSC{Float64} ? M : SparseMatrixCSC{Float64,Int64}(sparse(M))
+  nb = Cint(sizeof(eltype(C.colptr)))
+  GC.@preserve C begin
+    st = if sym === :system
+      ccall((:gmg_block_set_system_block, libgmgamd), Cint,
+        (Ptr{Cvoid},Cint,Cint,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+        h, i, j, size(C,1), size(C,2), nnz(C), C.colptr, C.rowval, C.nzval, GMG_CSC, 1, nb)
+    elseif sym === :precond
+      ccall((:gmg_block_set_precond_block, libgmgamd), Cint,
+        (Ptr{Cvoid},Cint,Cint,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+        h, i, j, size(C,1), size(C,2), nnz(C), C.colptr, C.rowval, C.nzval, GMG_CSC, 1, nb)
+    else
+      ccall((:gmg_block_set_diag_matrix, libgmgamd), Cint,
+        (Ptr{Cvoid},Cint,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+        h, i, size(C,1), nnz(C), C.colptr, C.rowval, C.nzval, GMG_CSC, 1, nb)
+    end
+  end
+  check_block(h, st)
+end
+
+# `mat` is a BlockArrays.BlockMatrix: blocks(mat)[i,j] (BlockTriangularSolvers.jl:132-152)
+function _block_numerical_setup(P::HipBlockTriangularSolver, mat, owner)
+  B  = blocks(mat); NB = length(P.solvers)
+  sizes = Int64[size(B[i,i],1) for i in 1:NB]
+  kind = P.half === :upper ? GMG_BLOCK_UPPER : (P.half === :lower ? GMG_BLOCK_LOWER : GMG_BLOCK_DIAGONAL)
+  href = Ref{Ptr{Cvoid}}(C_NULL)
+  check_block(C_NULL, ccall((:gmg_block_create, libgmgamd), Cint, (Ref{Ptr{Cvoid}},Cint,Ptr{Int64},Cint,Cint), href, NB, sizes, kind, 0))
+  ns = HipBlockNumericalSetup(owner, href[], Any[], sum(sizes))
+  finalizer(x -> ccall((:gmg_block_destroy, libgmgamd), Cint, (Ptr{Cvoid},), x.handle), ns)   # before the GMG setups it borrows
+  h = ns.handle
+  for i in 1:NB, j in 1:NB
+    iszero(nnz(sparse(B[i,j]))) || _set_block(:system, h, i-1, j-1, B[i,j])
+    if i != j
+      haskey(P.mats,(i,j)) && _set_block(:precond, h, i-1, j-1, P.mats[(i,j)])
+      check_block(h, ccall((:gmg_block_set_coeff, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Float64), h, i-1, j-1, P.coeffs[i,j]))
+    end
+  end
+  for (i,s) in enumerate(P.solvers)
+    Mi = get(P.mats, (i,i), B[i,i])
+    if s isa HipGMGLinearSolver
+      g = numerical_setup(symbolic_setup(s,Mi),Mi); push!(ns.block_ns, g)
+      check_block(h, ccall((:gmg_block_set_diag_gmg, libgmgamd), Cint, (Ptr{Cvoid},Cint,Ptr{Cvoid}), h, i-1, g.handle))
+      continue
+    end
+    kind_i, maxiter, atol, rtol = if s isa GridapSolvers.LinearSolvers.CGSolver
+      @assert s.Pl isa JacobiLinearSolver && !s.flexible
+      GMG_BLOCK_CG_JACOBI, s.log.tols.maxiter, s.log.tols.atol, s.log.tols.rtol
+    elseif s isa Gridap.Algebra.LUSolver
+      GMG_BLOCK_LU, 0, 0.0, 0.0
+    else
+      @assert s isa JacobiLinearSolver
+      GMG_BLOCK_JACOBI, 0, 0.0, 0.0
+    end
+    check_block(h, ccall((:gmg_block_set_diag_solver, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Cint,Float64,Float64), h, i-1, kind_i, maxiter, atol, rtol))
+    haskey(P.mats,(i,i)) && _set_block(:diag, h, i-1, 0, Mi)
+  end
+  check_block(h, ccall((:gmg_block_setup, libgmgamd), Cint, (Ptr{Cvoid},), h))
+  return ns
+end
+Gridap.Algebra.numerical_setup(ss::HipBlockSymbolicSetup{HipBlockTriangularSolver}, mat::AbstractMatrix) = _block_numerical_setup(ss.solver, mat, ss.solver)
+Gridap.Algebra.numerical_setup(ss::HipBlockSymbolicSetup{HipBlockFGMRESSolver}, mat::AbstractMatrix) = _block_numerical_setup(ss.solver.Pr, mat, ss.solver)
+
+# block vectors are passed as their contiguous parent (BlockArrays stores a BlockVector's blocks back to back)
+_flat(v::AbstractVector) = v isa Vector{Float64} ? v : parent(v)
+
+function _fill_block_logs!(ns::HipBlockNumericalSetup, P::HipBlockTriangularSolver)
+  for (i,s) in enumerate(P.solvers)
+    (s isa HipGMGLinearSolver || s isa GridapSolvers.LinearSolvers.CGSolver) || continue
+    res = Ref(GmgResult(0,0,0.0,0.0))
+    check_block(ns.handle, ccall((:gmg_block_diag_log, libgmgamd), Cint, (Ptr{Cvoid},Cint,Ref{GmgResult}), ns.handle, i-1, res))
+    s.log.num_iters = res[].niters
+  end
+end
+
+# solve!(x,ns::BlockTriangularSolverNS,b)
+function Gridap.Algebra.solve!(x::AbstractVector, ns::HipBlockNumericalSetup{HipBlockTriangularSolver}, b::AbstractVector)
+  xf, bf = _flat(x), _flat(b)
+  GC.@preserve xf bf check_block(ns.handle, ccall((:gmg_block_precond_apply, libgmgamd), Cint,
+    (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint), ns.handle, bf, xf, GMG_MEM_HOST))
+  _fill_block_logs!(ns, ns.solver)
+  return x
+end
+# mul!(y,A,x) on the block system held by the handle
+function block_mul!(y::AbstractVector, ns::HipBlockNumericalSetup, x::AbstractVector)
+  yf, xf = _flat(y), _flat(x)
+  GC.@preserve yf xf check_block(ns.handle, ccall((:gmg_block_apply_system, libgmgamd), Cint,
+    (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint), ns.handle, xf, yf, GMG_MEM_HOST))
+  return y
+end
+# solve!(x,ns::FGMRESNumericalSetup,b) with Pr = the block preconditioner
+function Gridap.Algebra.solve!(x::AbstractVector, ns::HipBlockNumericalSetup{HipBlockFGMRESSolver}, b::AbstractVector)
+  s = ns.solver; tols = s.log.tols
+  res  = Ref(GmgResult(0,0,0.0,0.0)); hist = zeros(tols.maxiter+1)
+  xf, bf = _flat(x), _flat(b)
+  GC.@preserve xf bf hist check_block(ns.handle, ccall((:gmg_block_fgmres_solve, libgmgamd), Cint,
+    (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Cint,Cint,Cint,Cint,Float64,Float64,Cint,Ref{GmgResult},Ptr{Float64},Cint),
+    ns.handle, bf, xf, GMG_MEM_HOST, s.m, s.restart ? 1 : 0, s.m_add, tols.maxiter, tols.atol, tols.rtol, 1, res, hist, length(hist)))
+  _fill_log!(s.log, res[], hist)
+  _fill_block_logs!(ns, s.Pr)
+  return x
+end
+# CGSolver(P) on an SPD block system
+function block_cg_solve!(x::AbstractVector, ns::HipBlockNumericalSetup, b::AbstractVector, log::ConvergenceLog; flexible=false)
+  tols = log.tols
+  res  = Ref(GmgResult(0,0,0.0,0.0)); hist = zeros(tols.maxiter+1)
+  xf, bf = _flat(x), _flat(b)
+  GC.@preserve xf bf hist check_block(ns.handle, ccall((:gmg_block_cg_solve, libgmgamd), Cint,
+    (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Cint,Float64,Float64,Cint,Cint,Ref{GmgResult},Ptr{Float64},Cint),
+    ns.handle, bf, xf, GMG_MEM_HOST, tols.maxiter, tols.atol, tols.rtol, flexible ? 1 : 0, 1, res, hist, length(hist)))
+  _fill_log!(log, res[], hist)
   return x
 end
 

@@ -14,6 +14,9 @@ julia/GridapSolversAMD.jl.
     GMGLinearSolver(mats,P,R;...)   GMGLinearSolvers.jl:48-69       GMGLinearSolver
     CGSolver(Pl;...)                Krylov/CGSolvers.jl:19          CGSolver
     FGMRESSolver(m,Pr;...)          Krylov/FGMRESSolvers.jl:26      FGMRESSolver
+    BlockDiagonalSolver(blocks,solvers)   BlockSolvers/BlockDiagonalSolvers.jl:20-45     BlockDiagonalSolver
+    BlockTriangularSolver(blocks,solvers,coeffs,half)  BlockTriangularSolvers.jl:55-85    BlockTriangularSolver
+    LinearSystemBlock / MatrixBlock BlockSolvers/BlockSolverInterfaces.jl            same names
     symbolic_setup / numerical_setup / numerical_setup! / solve!    same names (solve_ = solve!)
     ConvergenceLog                  SolverInterfaces/ConvergenceLogs.jl:42   ConvergenceLog
 
@@ -31,6 +34,7 @@ from . import abi
 __all__ = [
     "JacobiLinearSolver", "RichardsonSmoother", "PatchSolver", "BlockJacobiSolver", "LUSolver",
     "GMGLinearSolver", "CGSolver", "FGMRESSolver", "ConvergenceLog", "PatchProlongationOperator",
+    "BlockDiagonalSolver", "BlockTriangularSolver", "LinearSystemBlock", "MatrixBlock",
     "symbolic_setup", "numerical_setup", "numerical_setup_", "solve_", "mul_",
     "SOLVER_CONVERGED_ATOL", "SOLVER_CONVERGED_RTOL", "SOLVER_DIVERGED_MAXITER", "SOLVER_DIVERGED_BREAKDOWN",
 ]
@@ -166,6 +170,57 @@ class FGMRESSolver:
             raise NotImplementedError("left preconditioner of FGMRES is not on the device path")
         self.m, self.Pr, self.restart, self.m_add = int(m), Pr, bool(restart), int(m_add)
         self.log = ConvergenceLog(name, maxiter, atol, rtol)
+
+
+class LinearSystemBlock:
+    """LinearSystemBlock(): the block is taken from the system matrix (BlockSolverInterfaces.jl)."""
+
+
+class MatrixBlock:
+    """MatrixBlock(mat): an explicit matrix (also what a BiformBlock assembles to)."""
+
+    def __init__(self, mat):
+        self.mat = mat
+
+
+class BlockDiagonalSolver:
+    """BlockDiagonalSolver(blocks, solvers) / BlockDiagonalSolver(solvers) -- BlockDiagonalSolvers.jl:20-45.
+    solvers[i]: GMGLinearSolver | CGSolver(JacobiLinearSolver()) | LUSolver() | JacobiLinearSolver()."""
+
+    half = "diagonal"
+
+    def __init__(self, blocks, solvers=None):
+        if solvers is None:
+            blocks, solvers = None, blocks
+        self.solvers = list(solvers)
+        nb = len(self.solvers)
+        diag = [LinearSystemBlock() for _ in range(nb)] if blocks is None else list(blocks)
+        if len(diag) != nb:
+            raise ValueError("blocks and solvers must have the same length")   # @check :27
+        self.blocks = [[diag[i] if i == j else LinearSystemBlock() for j in range(nb)] for i in range(nb)]
+        self.coeffs = np.ones((nb, nb))
+
+
+class BlockTriangularSolver:
+    """BlockTriangularSolver(blocks, solvers, coeffs=fill(1.0,size(blocks)), half=:upper) /
+    BlockTriangularSolver(solvers; coeffs, half) -- BlockTriangularSolvers.jl:55-85."""
+
+    def __init__(self, blocks, solvers=None, coeffs=None, half="upper"):
+        if solvers is None:
+            blocks, solvers = None, blocks
+        self.solvers = list(solvers)
+        nb = len(self.solvers)
+        if blocks is None:
+            blocks = [[LinearSystemBlock() for _ in range(nb)] for _ in range(nb)]
+        self.blocks = [list(row) for row in blocks]
+        if len(self.blocks) != nb or any(len(r) != nb for r in self.blocks):
+            raise ValueError("blocks must be a square matrix matching solvers")  # @check :63-64
+        if half not in ("upper", "lower"):
+            raise ValueError("half must be :upper or :lower")                     # @check :65
+        self.coeffs = np.ones((nb, nb)) if coeffs is None else np.asarray(coeffs, dtype=np.float64)
+        if self.coeffs.shape != (nb, nb):
+            raise ValueError("coeffs must match blocks")
+        self.half = half
 
 
 # ----------------------------------------------------------------------------
@@ -382,6 +437,123 @@ class GMGNumericalSetup:
         return v.value
 
 
+def _set_block(fn, h, i, j, M):
+    shape, ptr, idx, val, layout, base = _csr_fields(M)
+    if ptr.dtype != idx.dtype:
+        ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
+    abi.check_block(h, fn(h, i, j, shape[0], shape[1], int(val.size), C.c_void_p(ptr.ctypes.data),
+                          C.c_void_p(idx.ctypes.data), C.c_void_p(val.ctypes.data), layout, base, ptr.dtype.itemsize))
+
+
+class BlockSymbolicSetup:
+    def __init__(self, solver):
+        self.solver = solver
+
+
+class BlockNumericalSetup:
+    """BlockDiagonalSolverNS / BlockTriangularSolverNS (BlockTriangularSolvers.jl:132-152) on a native handle.
+    `mat` is the block system matrix as a nested list (None = zero block)."""
+
+    _HALF = {"diagonal": abi.BLOCK_DIAGONAL, "lower": abi.BLOCK_LOWER, "upper": abi.BLOCK_UPPER}
+
+    def __init__(self, solver, mat, device_id=None):
+        lib = abi.load()
+        self.solver, self._lib = solver, lib
+        nb = len(solver.solvers)
+        if len(mat) != nb or any(len(r) != nb for r in mat):
+            raise ValueError("block matrix does not match the number of solvers")
+        sizes = np.zeros(nb, dtype=np.int64)
+        for i in range(nb):
+            row = [m for m in mat[i] if m is not None]
+            if not row:
+                raise ValueError(f"block row {i} is empty")
+            sizes[i] = int(_csr_fields(row[0])[0][0])
+        self.sizes, self.n = sizes, int(sizes.sum())
+        if device_id is None:
+            device_id = 0
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    device_id = torch.cuda.current_device()
+            except Exception:
+                pass
+        h = C.c_void_p()
+        abi.check_block(None, lib.gmg_block_create(C.byref(h), nb, C.c_void_p(sizes.ctypes.data), self._HALF[solver.half], device_id))
+        self.h = h
+        self.block_ns = [None] * nb
+        try:
+            for i in range(nb):
+                for j in range(nb):
+                    if mat[i][j] is not None:
+                        _set_block(lib.gmg_block_set_system_block, h, i, j, mat[i][j])
+                    blk = solver.blocks[i][j]
+                    if i != j:
+                        if isinstance(blk, MatrixBlock):
+                            _set_block(lib.gmg_block_set_precond_block, h, i, j, blk.mat)
+                        abi.check_block(h, lib.gmg_block_set_coeff(h, i, j, float(solver.coeffs[i][j])))
+            for i, sv in enumerate(solver.solvers):
+                blk = solver.blocks[i][i]
+                Mi = blk.mat if isinstance(blk, MatrixBlock) else mat[i][i]
+                if isinstance(sv, GMGLinearSolver):
+                    g = GMGNumericalSetup(sv, Mi, device_id)
+                    self.block_ns[i] = g
+                    abi.check_block(h, lib.gmg_block_set_diag_gmg(h, i, g.h))
+                    continue
+                if isinstance(sv, CGSolver) and isinstance(sv.Pl, JacobiLinearSolver) and not sv.flexible:
+                    kind, (mi, at, rt) = abi.BLOCK_CG_JACOBI, (sv.log.maxiter, sv.log.atol, sv.log.rtol)
+                elif isinstance(sv, LUSolver):
+                    kind, (mi, at, rt) = abi.BLOCK_LU, (0, 0.0, 0.0)
+                elif isinstance(sv, JacobiLinearSolver):
+                    kind, (mi, at, rt) = abi.BLOCK_JACOBI, (0, 0.0, 0.0)
+                else:
+                    raise NotImplementedError("block solvers on the device: GMGLinearSolver, CGSolver(JacobiLinearSolver()), "
+                                              "LUSolver(), JacobiLinearSolver()")
+                abi.check_block(h, lib.gmg_block_set_diag_solver(h, i, kind, mi, at, rt))
+                if isinstance(blk, MatrixBlock):
+                    shape, ptr, idx, val, layout, base = _csr_fields(blk.mat)
+                    if ptr.dtype != idx.dtype:
+                        ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
+                    abi.check_block(h, lib.gmg_block_set_diag_matrix(h, i, shape[0], int(val.size), C.c_void_p(ptr.ctypes.data),
+                                                                     C.c_void_p(idx.ctypes.data), C.c_void_p(val.ctypes.data),
+                                                                     layout, base, ptr.dtype.itemsize))
+            abi.check_block(h, lib.gmg_block_setup(h))
+        except Exception:
+            self.close()
+            raise
+
+    def _fill_logs(self):
+        """copy the block solvers' ConvergenceLogs back (their last application)"""
+        for i, sv in enumerate(self.solver.solvers):
+            if isinstance(sv, (GMGLinearSolver, CGSolver)):
+                res = abi.Result()
+                abi.check_block(self.h, self._lib.gmg_block_diag_log(self.h, i, C.byref(res)))
+                sv.log.num_iters, sv.log.flag = int(res.niters), int(res.flag)
+
+    def mul(self, y, x):
+        """mul!(y, A, x) on the block system"""
+        px, ms, _k1 = _vec(x, self.n)
+        py, ms2, _k2 = _vec(y, self.n, writable=True)
+        if ms != ms2:
+            raise TypeError("x and y must live in the same memory space")
+        abi.check_block(self.h, self._lib.gmg_block_apply_system(self.h, px, py, ms))
+        return y
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.gmg_block_destroy(self.h)       # before the GMG handles it borrows
+            self.h = None
+        for g in getattr(self, "block_ns", []):
+            if g is not None:
+                g.close()
+        self.block_ns = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _KrylovSymbolicSetup:
     def __init__(self, solver):
         self.solver = solver
@@ -394,6 +566,11 @@ class _KrylovNumericalSetup:
     def __init__(self, solver, A, device_id=None):
         self.solver = solver
         P = solver.Pl if isinstance(solver, CGSolver) else solver.Pr
+        if isinstance(P, (BlockDiagonalSolver, BlockTriangularSolver)):
+            self.pc_kind = 1
+            self.P_ns = BlockNumericalSetup(P, A, device_id)
+            self.n = self.P_ns.n
+            return
         if isinstance(P, GMGLinearSolver):
             self.pc_kind, gmg = 1, P
         elif isinstance(P, tuple) and len(P) == 2 and isinstance(P[1], GMGLinearSolver) and \
@@ -413,6 +590,8 @@ def symbolic_setup(solver, A=None):
         return GMGSymbolicSetup(solver)
     if isinstance(solver, (CGSolver, FGMRESSolver)):
         return _KrylovSymbolicSetup(solver)
+    if isinstance(solver, (BlockDiagonalSolver, BlockTriangularSolver)):
+        return BlockSymbolicSetup(solver)
     raise TypeError(f"no symbolic_setup for {type(solver).__name__}")
 
 
@@ -422,6 +601,8 @@ def numerical_setup(ss, A=None, device_id=None):
         return GMGNumericalSetup(ss.solver, A, device_id)
     if isinstance(ss, _KrylovSymbolicSetup):
         return _KrylovNumericalSetup(ss.solver, A, device_id)
+    if isinstance(ss, BlockSymbolicSetup):
+        return BlockNumericalSetup(ss.solver, A, device_id)
     raise TypeError(f"no numerical_setup for {type(ss).__name__}")
 
 
@@ -447,6 +628,33 @@ def solve_(x, ns, b):
         hist = np.zeros(log.maxiter + 1)
         abi.check(ns.h, ns._lib.gmg_apply(ns.h, pb, px, ms, C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
         log._fill(res, hist)
+        return x
+    if isinstance(ns, BlockNumericalSetup):
+        pb, ms, _kb = _vec(b, ns.n)
+        px, ms2, _kx = _vec(x, ns.n, writable=True)
+        if ms != ms2:
+            raise TypeError("x and b must live in the same memory space")
+        abi.check_block(ns.h, ns._lib.gmg_block_precond_apply(ns.h, pb, px, ms))
+        ns._fill_logs()
+        return x
+    if isinstance(ns, _KrylovNumericalSetup) and isinstance(ns.P_ns, BlockNumericalSetup):
+        s, g = ns.solver, ns.P_ns
+        log = s.log
+        pb, ms, _kb = _vec(b, ns.n)
+        px, ms2, _kx = _vec(x, ns.n, writable=True)
+        if ms != ms2:
+            raise TypeError("x and b must live in the same memory space")
+        res = abi.Result()
+        hist = np.zeros(log.maxiter + 1)
+        if isinstance(s, CGSolver):
+            abi.check_block(g.h, g._lib.gmg_block_cg_solve(g.h, pb, px, ms, log.maxiter, log.atol, log.rtol, int(s.flexible),
+                                                           ns.pc_kind, C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
+        else:
+            abi.check_block(g.h, g._lib.gmg_block_fgmres_solve(g.h, pb, px, ms, s.m, int(s.restart), s.m_add, log.maxiter,
+                                                               log.atol, log.rtol, ns.pc_kind, C.byref(res),
+                                                               C.c_void_p(hist.ctypes.data), hist.size))
+        log._fill(res, hist)
+        g._fill_logs()
         return x
     if isinstance(ns, _KrylovNumericalSetup):
         s, g = ns.solver, ns.P_ns

@@ -218,6 +218,62 @@ GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int
 /* Device memory held by the handle, bytes. */
 GMG_API int gmg_device_bytes(gmg_handle_t h, int64_t *bytes);
 
+/* ---- block preconditioners --------------------------------------------------
+ * The glue that calls the GMG hot path once per outer FGMRES iteration in the reference's block
+ * applications (test/Applications/StokesGMG.jl:142-153): BlockDiagonalSolver
+ * (BlockSolvers/BlockDiagonalSolvers.jl:165-177) and BlockTriangularSolver
+ * (BlockSolvers/BlockTriangularSolvers.jl:186-242) with the outer CG / FGMRES on the block system,
+ * all on the device.  Block vectors are contiguous: block i occupies [off_i, off_i + size_i).
+ * Single GPU.  A gmg handle given to gmg_block_set_diag_gmg stays owned by the caller, must be set up
+ * first, must outlive the block handle's use of it and issues its work on the block handle's stream
+ * from gmg_block_setup until gmg_block_destroy. */
+typedef struct gmg_block_solver *gmg_block_handle_t;
+enum gmg_block_kind { GMG_BLOCK_DIAGONAL = 0, GMG_BLOCK_LOWER = 1, GMG_BLOCK_UPPER = 2 };
+enum gmg_block_diag_kind {
+  GMG_BLOCK_GMG = 1,        /* a GMGLinearSolver numerical setup (gmg handle) */
+  GMG_BLOCK_CG_JACOBI = 2,  /* CGSolver(JacobiLinearSolver();maxiter,atol,rtol), CGSolvers.jl:73-120 */
+  GMG_BLOCK_LU = 3,         /* LUSolver() on a small block: dense inverse on the device */
+  GMG_BLOCK_JACOBI = 4      /* JacobiLinearSolver(), JacobiLinearSolvers.jl:43-47 */
+};
+/* BlockDiagonalSolver(solvers) / BlockTriangularSolver(blocks,solvers,coeffs,half): BlockTriangularSolvers.jl:55-85 */
+GMG_API int gmg_block_create(gmg_block_handle_t *h, int nblocks, const int64_t *block_sizes, int kind, int device_id);
+GMG_API int gmg_block_destroy(gmg_block_handle_t h);
+GMG_API const char *gmg_block_last_error(gmg_block_handle_t h);
+/* blocks(mat)[i,j] of the system matrix (numerical_setup(ss,mat::AbstractBlockMatrix), BlockTriangularSolvers.jl:132-152);
+ * absent blocks are zero. */
+GMG_API int gmg_block_set_system_block(gmg_block_handle_t h, int i, int j, int64_t nrows, int64_t ncols, int64_t nnz,
+                                       const void *ptr, const void *idx, const double *val,
+                                       int layout, int index_base, int index_bytes);
+/* Off-diagonal block of the PRECONDITIONER when it is not the system's (MatrixBlock / BiformBlock,
+ * BlockSolverInterfaces.jl); default = the system block (LinearSystemBlock). */
+GMG_API int gmg_block_set_precond_block(gmg_block_handle_t h, int i, int j, int64_t nrows, int64_t ncols, int64_t nnz,
+                                        const void *ptr, const void *idx, const double *val,
+                                        int layout, int index_base, int index_bytes);
+/* coeffs[i,j] (default 1.0; a zero coefficient drops the block, BlockTriangularSolvers.jl:194,223) */
+GMG_API int gmg_block_set_coeff(gmg_block_handle_t h, int i, int j, double c);
+/* solvers[i] */
+GMG_API int gmg_block_set_diag_gmg(gmg_block_handle_t h, int i, gmg_handle_t g);
+GMG_API int gmg_block_set_diag_solver(gmg_block_handle_t h, int i, int kind, int maxiter, double atol, double rtol);
+/* matrix the solver of block i is set up on when it is not the system block (i,i) (e.g. the -1/alpha
+ * pressure mass matrix, StokesGMG.jl:145) */
+GMG_API int gmg_block_set_diag_matrix(gmg_block_handle_t h, int i, int64_t n, int64_t nnz, const void *ptr,
+                                      const void *idx, const double *val, int layout, int index_base, int index_bytes);
+/* numerical_setup */
+GMG_API int gmg_block_setup(gmg_block_handle_t h);
+/* solve!(x,ns::BlockDiagonalSolverNS|BlockTriangularSolverNS,b) */
+GMG_API int gmg_block_precond_apply(gmg_block_handle_t h, const double *b, double *x, int memspace);
+/* mul!(y,A,x) on the block system */
+GMG_API int gmg_block_apply_system(gmg_block_handle_t h, const double *x, double *y, int memspace);
+/* FGMRESSolver(m,P) / CGSolver(P) on the block system with P = this block preconditioner (use_precond=1)
+ * or nothing (0): FGMRESSolvers.jl:130-199, CGSolvers.jl:73-120 */
+GMG_API int gmg_block_fgmres_solve(gmg_block_handle_t h, const double *b, double *x, int memspace, int m, int restart,
+                                   int m_add, int maxiter, double atol, double rtol, int use_precond,
+                                   gmg_result *res, double *hist, int hist_cap);
+GMG_API int gmg_block_cg_solve(gmg_block_handle_t h, const double *b, double *x, int memspace, int maxiter, double atol,
+                               double rtol, int flexible, int use_precond, gmg_result *res, double *hist, int hist_cap);
+/* ConvergenceLog of the last solve of diagonal block i (GMG / CG blocks) */
+GMG_API int gmg_block_diag_log(gmg_block_handle_t h, int i, gmg_result *res);
+
 #ifdef __cplusplus
 }
 #endif

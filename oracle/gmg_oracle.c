@@ -628,11 +628,14 @@ ORC_API void orc_gmg_destroy(orc_gmg *g)
 
 /* preconditioner dispatch for the Krylov solvers.
  * kind 0: nothing ; 1: GMG (pc = orc_gmg*) ; 2: JacobiLinearSolver (pc = inv_diag,
- * JacobiLinearSolvers.jl:43-47) */
-enum { ORC_PC_NONE = 0, ORC_PC_GMG = 1, ORC_PC_JACOBI = 2 };
+ * JacobiLinearSolvers.jl:43-47) ; 3: block diagonal / triangular solver (pc = orc_block*) */
+enum { ORC_PC_NONE = 0, ORC_PC_GMG = 1, ORC_PC_JACOBI = 2, ORC_PC_BLOCK = 3 };
+typedef struct orc_block orc_block;
+ORC_API void orc_block_apply(orc_block *B, double *x, const double *b);
 static void pc_solve(int kind, void *pc, i64 n, double *z, const double *r)
 {
   if (kind == ORC_PC_GMG) orc_gmg_solve((orc_gmg *)pc, z, r, NULL, NULL);
+  else if (kind == ORC_PC_BLOCK) orc_block_apply((orc_block *)pc, z, r);
   else if (kind == ORC_PC_JACOBI) { const double *d = (const double *)pc; for (i64 i = 0; i < n; ++i) z[i] = d[i] * r[i]; }
   else memcpy(z, r, (size_t)n * sizeof(double));
 }
@@ -842,4 +845,120 @@ ORC_API int orc_cg_smoother_solve(i64 n, const i64 *ptr, const i32 *idx, const d
   free(w); free(p); free(z); free(r); free(aux); free(dx); free(Adx); free(log.residuals);
   smoother_free(&S);
   return flag;
+}
+
+/* ------------------------------------------------------------------ */
+/* Block preconditioners: the glue that calls the GMG  */
+/* hot path once per outer FGMRES iteration in the Stokes application   */
+/* (test/Applications/StokesGMG.jl:142-153).                            */
+/*   BlockDiagonalSolver   solve!: BlockDiagonalSolvers.jl:165-177      */
+/*   BlockTriangularSolver solve!: BlockTriangularSolvers.jl:186-242    */
+/* Block vectors are contiguous, block i at off[i]..off[i+1].           */
+/* ------------------------------------------------------------------ */
+enum { ORC_BLOCK_DIAGONAL = 0, ORC_BLOCK_LOWER = 1, ORC_BLOCK_UPPER = 2 };
+enum { ORC_BD_GMG = 1, ORC_BD_CG_JACOBI = 2, ORC_BD_LU = 3, ORC_BD_JACOBI = 4 };
+
+typedef struct {
+  int kind;
+  orc_gmg *gmg;                 /* ORC_BD_GMG */
+  orc_csr M;                    /* matrix of the block solver (CG / LU / Jacobi) */
+  double *inv_diag;             /* JacobiLinearSolvers.jl:20-23 */
+  orc_band *lu;
+  int maxiter; double atol, rtol;
+} orc_bdiag;
+
+struct orc_block {
+  int nb, kind;
+  i64 *off;
+  orc_bdiag *diag;
+  orc_csr *offd;                /* nb*nb, row-major; ptr == NULL: no block */
+  double *coeff;                /* nb*nb */
+  double *w, *y;                /* work caches, BlockTriangularSolvers.jl:145-150 */
+};
+
+ORC_API orc_block *orc_block_create(int nb, const i64 *sizes, int kind)
+{
+  orc_block *B = (orc_block *)calloc(1, sizeof(orc_block));
+  B->nb = nb; B->kind = kind;
+  B->off = (i64 *)calloc((size_t)nb + 1, sizeof(i64));
+  for (int i = 0; i < nb; ++i) B->off[i + 1] = B->off[i] + sizes[i];
+  B->diag = (orc_bdiag *)calloc((size_t)nb, sizeof(orc_bdiag));
+  B->offd = (orc_csr *)calloc((size_t)nb * nb, sizeof(orc_csr));
+  B->coeff = (double *)calloc((size_t)nb * nb, sizeof(double));
+  for (int i = 0; i < nb * nb; ++i) B->coeff[i] = 1.0;       /* BlockTriangularSolvers.jl:66 coeffs=fill(1.0,...) */
+  B->w = dalloc(B->off[nb]); B->y = dalloc(B->off[nb]);       /* zero-initialised like allocate_in_domain + fill! */
+  return B;
+}
+ORC_API void orc_block_set_offdiag(orc_block *B, int i, int j, i64 nrows, i64 ncols, const i64 *ptr, const i32 *idx,
+                                   const double *val, double coeff)
+{
+  orc_csr M = { nrows, ncols, ptr, idx, val };
+  B->offd[i * B->nb + j] = M;
+  B->coeff[i * B->nb + j] = coeff;
+}
+ORC_API void orc_block_set_diag_gmg(orc_block *B, int i, orc_gmg *g) { B->diag[i].kind = ORC_BD_GMG; B->diag[i].gmg = g; }
+/* kind: ORC_BD_CG_JACOBI = CGSolver(JacobiLinearSolver();maxiter,atol,rtol), ORC_BD_LU = LUSolver(),
+ * ORC_BD_JACOBI = JacobiLinearSolver() */
+ORC_API void orc_block_set_diag_matrix(orc_block *B, int i, int kind, i64 n, const i64 *ptr, const i32 *idx,
+                                       const double *val, int maxiter, double atol, double rtol)
+{
+  orc_bdiag *D = &B->diag[i];
+  orc_csr M = { n, n, ptr, idx, val };
+  D->kind = kind; D->M = M; D->maxiter = maxiter; D->atol = atol; D->rtol = rtol;
+  if (kind == ORC_BD_CG_JACOBI || kind == ORC_BD_JACOBI) {
+    D->inv_diag = dalloc(n);
+    orc_jacobi_setup(n, ptr, idx, val, D->inv_diag);
+  } else if (kind == ORC_BD_LU) {
+    D->lu = band_factor(n, ptr, idx, val);
+  }
+}
+static void bdiag_solve(orc_bdiag *D, i64 n, double *y, const double *w)
+{
+  switch (D->kind) {
+  case ORC_BD_GMG: orc_gmg_solve(D->gmg, y, w, NULL, NULL); break;
+  case ORC_BD_CG_JACOBI:                                     /* y keeps its previous content = initial guess */
+    orc_cg_solve(n, D->M.ptr, D->M.idx, D->M.val, ORC_PC_JACOBI, D->inv_diag, y, w, D->maxiter, D->atol, D->rtol, 0, NULL, NULL);
+    break;
+  case ORC_BD_LU: memcpy(y, w, (size_t)n * sizeof(double)); band_solve(D->lu, y); break;
+  case ORC_BD_JACOBI: for (i64 k = 0; k < n; ++k) y[k] = D->inv_diag[k] * w[k]; break;
+  default: memcpy(y, w, (size_t)n * sizeof(double));
+  }
+}
+/* eps(x) of Julia for a Float64 */
+static double julia_eps(double x) { x = fabs(x); return nextafter(x, INFINITY) - x; }
+
+/* solve!(x,ns,b) */
+ORC_API void orc_block_apply(orc_block *B, double *x, const double *b)
+{
+  const int NB = B->nb;
+  for (int step = 0; step < NB; ++step) {
+    const int iB = (B->kind == ORC_BLOCK_UPPER) ? NB - 1 - step : step;   /* :218 NB:-1:1 / :190 1:NB */
+    const i64 o = B->off[iB], n = B->off[iB + 1] - o;
+    double *wi = B->w + o, *yi = B->y + o;
+    memcpy(wi, b + o, (size_t)n * sizeof(double));           /* :192,221 copy!(wi,bi) */
+    if (B->kind != ORC_BLOCK_DIAGONAL) {
+      const int j0 = (B->kind == ORC_BLOCK_UPPER) ? iB + 1 : 0;
+      const int j1 = (B->kind == ORC_BLOCK_UPPER) ? NB : iB;
+      for (int jB = j0; jB < j1; ++jB) {
+        const double cij = B->coeff[iB * NB + jB];
+        const orc_csr *M = &B->offd[iB * NB + jB];
+        if (fabs(cij) > julia_eps(cij) && M->ptr) {          /* :194-197,223-226 mul!(wi,M,xj,-cij,1.0) */
+          const double *xj = x + B->off[jB];
+          for (i64 r = 0; r < n; ++r) {
+            double s = wi[r];
+            for (i64 k = M->ptr[r]; k < M->ptr[r + 1]; ++k) s += M->val[k] * (xj[M->idx[k]] * (-cij));
+            wi[r] = s;
+          }
+        }
+      }
+    }
+    bdiag_solve(&B->diag[iB], n, yi, wi);                    /* :202-205,231-234 solve!(yi,nsi,wi) */
+    memcpy(x + o, yi, (size_t)n * sizeof(double));           /* copy!(xi,yi) */
+  }
+}
+ORC_API void orc_block_destroy(orc_block *B)
+{
+  if (!B) return;
+  for (int i = 0; i < B->nb; ++i) { free(B->diag[i].inv_diag); band_free(B->diag[i].lu); }
+  free(B->off); free(B->diag); free(B->offd); free(B->coeff); free(B->w); free(B->y); free(B);
 }

@@ -41,6 +41,7 @@ def lib():
         L.orc_dot.restype = C.c_double
         L.orc_norm.restype = C.c_double
         L.orc_gmg_create.restype = C.c_void_p
+        L.orc_block_create.restype = C.c_void_p
         for name in ("orc_gmg_solve", "orc_cg_solve", "orc_fgmres_solve", "orc_cg_smoother_solve"):
             getattr(L, name).restype = C.c_int
     return _LIB
@@ -196,12 +197,59 @@ class GMG:
             pass
 
 
+DIAGONAL, LOWER, UPPER = 0, 1, 2
+BD_GMG, BD_CG_JACOBI, BD_LU, BD_JACOBI = 1, 2, 3, 4
+
+
+class BlockPreconditioner:
+    """BlockDiagonalSolver / BlockTriangularSolver numerical setup on contiguous block vectors.
+
+    diag[i] is a GMG (oracle) object or a tuple (kind, M[, maxiter, atol, rtol]) with kind in
+    {BD_CG_JACOBI, BD_LU, BD_JACOBI}; offdiag = {(i,j): (CSR, coeff)}.
+    """
+
+    def __init__(self, sizes, diag, offdiag=None, kind=DIAGONAL):
+        L = lib()
+        sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+        self.n = int(sizes.sum())
+        self._keep = [sizes, diag, offdiag]
+        self.h = C.c_void_p(L.orc_block_create(C.c_int(len(sizes)), _p64(sizes), C.c_int(kind)))
+        for i, d in enumerate(diag):
+            if isinstance(d, GMG):
+                L.orc_block_set_diag_gmg(self.h, C.c_int(i), d.h)
+            else:
+                k, M = d[0], d[1]
+                maxiter, atol, rtol = (list(d[2:]) + [1000, 1e-12, 1e-6][len(d) - 2:])[:3]
+                L.orc_block_set_diag_matrix(self.h, C.c_int(i), C.c_int(k), C.c_int64(M.shape[0]), _p64(M.ptr), _p32(M.idx),
+                                            _d(M.val), C.c_int(maxiter), C.c_double(atol), C.c_double(rtol))
+        for (i, j), (M, c) in (offdiag or {}).items():
+            L.orc_block_set_offdiag(self.h, C.c_int(i), C.c_int(j), C.c_int64(M.shape[0]), C.c_int64(M.shape[1]),
+                                    _p64(M.ptr), _p32(M.idx), _d(M.val), C.c_double(c))
+
+    def apply(self, b):
+        """solve!(x, ns, b) (stateful: the block work caches persist between calls, as in the reference)."""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros(self.n)
+        lib().orc_block_apply(self.h, _d(x), _d(b))
+        return x
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_block_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 def _pc(A, P):
     """Preconditioner dispatch: None | GMG | "jacobi" (JacobiLinearSolver())."""
     if P is None:
         return 0, None, None
     if isinstance(P, GMG):
         return 1, P.h, P
+    if isinstance(P, BlockPreconditioner):
+        return 3, P.h, P
     if P == "jacobi":
         d = jacobi_inv_diag(A)
         return 2, C.cast(_d(d), C.c_void_p), d

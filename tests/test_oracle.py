@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
 from conftest import max_rel, rel_err
@@ -258,3 +259,75 @@ def test_patch_corrected_prolongation(po, orc, nc, order):
             d = pd[pp[p]:pp[p + 1]]
             yy[d] -= np.linalg.solve(Ad[np.ix_(d, d)], tt[d])
         assert rel_err(z, yy) < 1e-12
+
+
+# ---------------------------------------------------------------- block preconditioners
+def _csr(po, M):
+    M = M.tocsr(); M.sort_indices()
+    return po.CSR(M.shape, M.indptr, M.indices, M.data)
+
+
+def test_block_triangular_lu_blocks_reference_test_problem(po, orc):
+    """test/BlockSolvers/BlockTriangularSolversTests.jl:22-45: a = u1 v1 + u2 v2 + u1 v2 - u2 v1, i.e. the block
+    matrix [[M, -M], [M, M]] with LU block solvers, :upper and :lower.  The reference asserts nothing; here the
+    block back/forward substitution identities are checked (BlockTriangularSolvers.jl:186-242), and
+    BlockDiagonalSolversTests.jl:38-45 (block-diagonal system, LU blocks => exact solve, norm(x1-x) < 1e-8)."""
+    M = po.poisson_matrix((8, 8), 1)
+    Ms = M.to_scipy()
+    n = M.shape[0]
+    negM = _csr(po, -Ms)
+    b = np.random.default_rng(0).uniform(-1, 1, 2 * n)
+    lu = spla.splu(Ms.tocsc())
+    up = orc.BlockPreconditioner([n, n], [(orc.BD_LU, M), (orc.BD_LU, M)], {(0, 1): (negM, 1.0), (1, 0): (M, 1.0)}, orc.UPPER)
+    x = up.apply(b)
+    x2 = lu.solve(b[n:]); x1 = lu.solve(b[:n] + Ms @ x2)
+    assert rel_err(x, np.concatenate([x1, x2])) < 1e-12
+    lo = orc.BlockPreconditioner([n, n], [(orc.BD_LU, M), (orc.BD_LU, M)], {(0, 1): (negM, 1.0), (1, 0): (M, 1.0)}, orc.LOWER)
+    x = lo.apply(b)
+    y1 = lu.solve(b[:n]); y2 = lu.solve(b[n:] - Ms @ y1)
+    assert rel_err(x, np.concatenate([y1, y2])) < 1e-12
+    dg = orc.BlockPreconditioner([n, n], [(orc.BD_LU, M), (orc.BD_LU, M)], None, orc.DIAGONAL)
+    x = dg.apply(b)
+    assert np.linalg.norm(x - np.concatenate([lu.solve(b[:n]), lu.solve(b[n:])])) < 1e-8
+
+
+def test_block_triangular_coefficients_and_stateful_cg_block(po, orc):
+    """coeffs[i,j] scale the off-diagonal contribution and a zero coefficient drops it (:194-197); a CG block solver
+    starts from the previous application's result (the work cache y persists, :202-205)."""
+    A = po.poisson_matrix((8, 8), 1); n = A.shape[0]
+    As = A.to_scipy()
+    rng = np.random.default_rng(1)
+    C12 = _csr(po, sp.random(n, n, density=0.05, random_state=3, format="csr"))
+    b = rng.uniform(-1, 1, 2 * n)
+    lu = spla.splu(As.tocsc())
+    for c in (0.0, 1.0, -2.5):
+        P = orc.BlockPreconditioner([n, n], [(orc.BD_LU, A), (orc.BD_JACOBI, A)], {(0, 1): (C12, c)}, orc.UPPER)
+        x = P.apply(b)
+        x2 = b[n:] / As.diagonal()
+        x1 = lu.solve(b[:n] - c * (C12.to_scipy() @ x2))
+        assert rel_err(x, np.concatenate([x1, x2])) < 1e-12
+    P = orc.BlockPreconditioner([n], [(orc.BD_CG_JACOBI, A, 3, 1e-30, 1e-30)], None, orc.DIAGONAL)
+    xa = P.apply(b[:n]); xb = P.apply(b[:n])          # second call continues from xa: 3 + 3 CG iterations (restarted)
+    ref3 = orc.cg_solve(A, b[:n], Pl="jacobi", maxiter=3, atol=1e-30, rtol=1e-30)[0]
+    ref33 = orc.cg_solve(A, b[:n], Pl="jacobi", x0=ref3, maxiter=3, atol=1e-30, rtol=1e-30)[0]
+    assert np.array_equal(xa, ref3) and np.array_equal(xb, ref33)
+
+
+def test_fgmres_block_triangular_gmg_stokes_like(po, orc, hierarchy):
+    """The StokesGMG.jl:142-153 solver shape on a synthetic saddle-point system: FGMRES(20) right-preconditioned by
+    BlockTriangularSolver([GMG(maxiter=4), CG-Jacobi(maxiter=20, rtol=1e-6)], coeffs=[1 1;0 1], :upper) with the
+    pressure block solver set up on -1/alpha * Mp.  Converges and solves the system."""
+    H = hierarchy((8, 8, 8), 2)
+    A = H["mats"][0]; n1 = A.shape[0]
+    R = H["restrictions"][0]; n2 = R.shape[0]
+    alpha = 10.0
+    B = _csr(po, 0.5 * R.to_scipy())
+    Bt = _csr(po, 0.5 * R.to_scipy().T)
+    Mp = _csr(po, (-1.0 / alpha) * (sp.identity(n2) + 0.1 * H["mats"][1].to_scipy()))
+    K = _csr(po, sp.bmat([[A.to_scipy(), Bt.to_scipy()], [B.to_scipy(), None]]))
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=4, rtol=1e-8)
+    P = orc.BlockPreconditioner([n1, n2], [g, (orc.BD_CG_JACOBI, Mp, 20, 1e-14, 1e-6)], {(0, 1): (Bt, 1.0), (1, 0): (B, 0.0)}, orc.UPPER)
+    b = np.random.default_rng(5).uniform(-1, 1, n1 + n2)
+    x, nit, flag, hist = orc.fgmres_solve(K, b, Pr=P, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+    assert flag in (0, 1) and nit < 100
+    assert np.linalg.norm(K.to_scipy() @ x - b) < 1e-7      # StokesGMG.jl:166 @test norm(r) < 1.e-7
