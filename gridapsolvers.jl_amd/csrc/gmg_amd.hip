@@ -28,6 +28,8 @@
 #include <map>
 #include <string>
 #include <thread>
+#include <atomic>
+#include <unordered_map>
 #include <vector>
 
 using namespace gmg;
@@ -177,6 +179,18 @@ struct DevCSR {
   double *dict = nullptr;
   int64_t zpack = 0;
   double stream_bytes_per_nnz = 12.0;
+  // row-pattern dictionary (SELL-P): see kernels.hpp sellp_kernel
+  bool pat = false;
+  int pat_np = 0, pat_w = 0;
+  uint16_t *rowpid = nullptr;
+  int32_t *rowbase = nullptr;   // nullptr: offsets relative to the row index
+  int32_t *plen = nullptr, *ppoff = nullptr;
+  double *ppval = nullptr;
+  // shared-offset ("stencil") form of the pattern table: see kernels.hpp sells_kernel
+  bool pat_shared = false;
+  PatEntry *ptab = nullptr;
+  int32_t *prun = nullptr;
+  int pat_nruns = 0, pat_minoff = 0, pat_maxoff = 0;
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -375,6 +389,11 @@ struct gmg_solver {
   int sell_block = 0;   // GMG_SELL_BLOCK: 0 = auto (256 threads on big levels, 64 on small ones)
   int sell_un = 6;      // GMG_SELL_UN: independent (col,val,gather) triples in flight per lane
   int nt_loads = 1;     // GMG_NT: non-temporal matrix stream
+  int use_pattern = 1;  // GMG_PATTERN: row-pattern dictionary (SELL-P) when the matrix has few distinct rows
+  int pat_un = 9;       // GMG_PAT_UN: gathers in flight per lane in sellp_kernel
+  int pat_wgs = 2048;   // GMG_PAT_WGS: resident workgroups of the persistent sellp launch
+  int pat_rb = 3;       // GMG_PAT_RB: runs (of 3 offsets) loaded per batch in sells_kernel (3 or 9)
+  int pat_shared = 1;   // GMG_PAT_SHARED: shared-offset (stencil) form when the offsets are row-relative
   int one_gather_sweep = 1;   // GMG_ONE_GATHER: sweep gathers s = w*Dinv*r (1) or r and Dinv (0)
   int tile = kTile;
 
@@ -432,7 +451,7 @@ struct gmg_solver {
     HIP_CHECK(hipStreamSynchronize(stream));
     release(M.col, (size_t)M.nnz + 4096);
     release(M.val, (size_t)M.nnz + 4096);
-    if (M.vdict) release(M.sval, (size_t)M.zpad);          // values come from the dictionary
+    if (M.vdict && M.sval) release(M.sval, (size_t)M.zpad);          // values come from the dictionary
   }
   double *dvec(int64_t n)
   {
@@ -509,10 +528,249 @@ struct gmg_solver {
     return D;
   }
 
+  // Row-pattern detection (setup): rows are equal when their lengths, their column offsets (relative to
+  // the row index, mode 0, or to their first column, mode 1) and the BITS of their values are equal.
+  // Chunks of rows are scanned in parallel with thread-local tables that are merged in chunk order
+  // (deterministic ids).  Gives up as soon as the table outgrows LDS.
+  bool detect_patterns(const HostCSR &H, int mode, std::vector<uint16_t> &rowpid, std::vector<int32_t> &rowbase,
+                       std::vector<int32_t> &plen, std::vector<int32_t> &poff, std::vector<double> &pval, int &W)
+  {
+    constexpr int kMaxTableBytes = 48 * 1024;
+    const int64_t n = H.nrows;
+    int64_t wmax = 0;
+    for (int64_t i = 0; i < n; ++i) wmax = std::max(wmax, H.ptr[i + 1] - H.ptr[i]);
+    if (wmax == 0 || wmax > 1024) return false;
+    W = (int)wmax;
+    const int max_np = (int)std::min<int64_t>(65534, kMaxTableBytes / (12 * wmax + 4) - 1);
+    if (max_np < 1) return false;
+    struct Local {
+      std::vector<int32_t> len, start;       // per local pattern
+      std::vector<int32_t> off;
+      std::vector<uint64_t> val;
+      std::vector<uint64_t> hash;
+      std::unordered_map<uint64_t, std::vector<int32_t>> index;
+    };
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), (n + 4095) / 4096));
+    std::vector<Local> loc((size_t)T);
+    std::vector<int32_t> lid((size_t)n);
+    std::atomic<bool> fail(false);
+    const int64_t per = (n + T - 1) / T;
+    auto row_equal = [&](const Local &L, int32_t p, int64_t i, int32_t base) {
+      const int64_t k0 = H.ptr[i], len = H.ptr[i + 1] - k0;
+      if (L.len[p] != (int32_t)len) return false;
+      const int32_t st = L.start[p];
+      for (int64_t j = 0; j < len; ++j) {
+        uint64_t bits;
+        std::memcpy(&bits, &H.val[k0 + j], 8);
+        if (L.off[st + j] != H.col[k0 + j] - base || L.val[st + j] != bits) return false;
+      }
+      return true;
+    };
+    parallel_for(T, [&](int64_t t) {
+      Local &L = loc[(size_t)t];
+      for (int64_t i = t * per; i < std::min(n, (t + 1) * per); ++i) {
+        if (fail.load(std::memory_order_relaxed)) return;
+        const int64_t k0 = H.ptr[i], len = H.ptr[i + 1] - k0;
+        const int32_t base = mode == 0 ? (int32_t)i : (len > 0 ? H.col[k0] : 0);
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
+        for (int64_t j = 0; j < len; ++j) {
+          uint64_t bits;
+          std::memcpy(&bits, &H.val[k0 + j], 8);
+          h = (h ^ (uint64_t)(uint32_t)(H.col[k0 + j] - base)) * 1099511628211ull;
+          h = (h ^ bits) * 1099511628211ull;
+          h ^= h >> 29;
+        }
+        auto &bucket = L.index[h];
+        int32_t found = -1;
+        for (int32_t p : bucket)
+          if (row_equal(L, p, i, base)) { found = p; break; }
+        if (found < 0) {
+          if ((int)L.len.size() >= max_np) { fail.store(true); return; }
+          found = (int32_t)L.len.size();
+          L.len.push_back((int32_t)len);
+          L.start.push_back((int32_t)L.off.size());
+          L.hash.push_back(h);
+          for (int64_t j = 0; j < len; ++j) {
+            uint64_t bits;
+            std::memcpy(&bits, &H.val[k0 + j], 8);
+            L.off.push_back(H.col[k0 + j] - base);
+            L.val.push_back(bits);
+          }
+          bucket.push_back(found);
+        }
+        lid[(size_t)i] = found;
+      }
+    });
+    if (fail.load()) return false;
+    // merge in chunk order
+    Local G;
+    std::vector<std::vector<int32_t>> l2g((size_t)T);
+    for (int t = 0; t < T; ++t) {
+      const Local &L = loc[(size_t)t];
+      l2g[(size_t)t].resize(L.len.size());
+      for (size_t p = 0; p < L.len.size(); ++p) {
+        auto &bucket = G.index[L.hash[p]];
+        int32_t found = -1;
+        for (int32_t q : bucket) {
+          if (G.len[q] != L.len[p]) continue;
+          bool eq = true;
+          for (int32_t j = 0; j < L.len[p] && eq; ++j)
+            eq = G.off[G.start[q] + j] == L.off[L.start[p] + j] && G.val[G.start[q] + j] == L.val[L.start[p] + j];
+          if (eq) { found = q; break; }
+        }
+        if (found < 0) {
+          if ((int)G.len.size() >= max_np) return false;
+          found = (int32_t)G.len.size();
+          G.len.push_back(L.len[p]);
+          G.start.push_back((int32_t)G.off.size());
+          G.off.insert(G.off.end(), L.off.begin() + L.start[p], L.off.begin() + L.start[p] + L.len[p]);
+          G.val.insert(G.val.end(), L.val.begin() + L.start[p], L.val.begin() + L.start[p] + L.len[p]);
+          bucket.push_back(found);
+        }
+        l2g[(size_t)t][p] = found;
+      }
+    }
+    const int np = (int)G.len.size();
+    rowpid.resize((size_t)n);
+    if (mode == 1) rowbase.resize((size_t)n); else rowbase.clear();
+    parallel_for(T, [&](int64_t t) {
+      for (int64_t i = t * per; i < std::min(n, (t + 1) * per); ++i) {
+        rowpid[(size_t)i] = (uint16_t)l2g[(size_t)t][(size_t)lid[(size_t)i]];
+        if (mode == 1) rowbase[(size_t)i] = H.ptr[i + 1] > H.ptr[i] ? H.col[H.ptr[i]] : 0;
+      }
+    });
+    plen = G.len;
+    plen.push_back(0);                                      // trailing empty pattern for the lanes past nrows
+    const int un = pat_un_eff();
+    W = (W + un - 1) / un * un;                             // row stride: the kernel reads UN entries at a time
+    if ((int64_t)(np + 1) * (12 * W + 4) > kMaxTableBytes) return false;
+    poff.assign((size_t)(np + 1) * W, 0);
+    pval.assign((size_t)(np + 1) * W, 0.0);
+    for (int p = 0; p < np; ++p)
+      for (int32_t j = 0; j < G.len[p]; ++j) {
+        poff[(size_t)p * W + j] = 8 * G.off[G.start[p] + j]; // byte offsets (32-bit lane offset + uniform base)
+        std::memcpy(&pval[(size_t)p * W + j], &G.val[G.start[p] + j], 8);
+      }
+    return true;
+  }
+  int pat_un_eff() const { return pat_un >= 27 ? 27 : pat_un >= 14 ? 14 : pat_un >= 9 ? 9 : pat_un >= 6 ? 6 : 3; }
+  bool build_pattern(const HostCSR &H, DevCSR &D)
+  {
+    // byte offsets into the gathered vector are 32-bit: ncols * 8 < 2^31
+    if (!use_pattern || H.nrows < 64 || D.nnz == 0 || H.ncols >= (int64_t)(1 << 28)) return false;
+    std::vector<uint16_t> rowpid;
+    std::vector<int32_t> rowbase, plen, poff;
+    std::vector<double> pval;
+    int W = 0;
+    bool ok = (H.ncols >= H.nrows) && detect_patterns(H, 0, rowpid, rowbase, plen, poff, pval, W);
+    if (!ok) ok = detect_patterns(H, 1, rowpid, rowbase, plen, poff, pval, W);
+    if (!ok) return false;
+    if (rowbase.empty() && pat_shared) build_shared_offsets(D, plen, poff, pval, W, H.ncols);
+    D.rowpid = upload_padded(rowpid, 64);
+    D.rowbase = rowbase.empty() ? nullptr : upload_padded(rowbase, 64);
+    D.plen = upload(plen); D.ppoff = upload(poff); D.ppval = upload(pval);
+    D.pat_np = (int)plen.size(); D.pat_w = W;
+    D.nslices = (int)((H.nrows + 63) / 64);
+    D.pat = true; D.sell = true;
+    D.zpad = D.nnz;
+    D.stream_bytes_per_nnz = (rowbase.empty() ? 2.0 : 6.0) * (double)H.nrows / (double)D.nnz;
+    return true;
+  }
+  // Shared-offset form of a row-relative pattern table (sells_kernel): the union of all offsets, covered
+  // greedily by runs of three consecutive offsets; every pattern becomes a dense coefficient vector over it.
+  void build_shared_offsets(DevCSR &D, const std::vector<int32_t> &plen, const std::vector<int32_t> &poff8,
+                            const std::vector<double> &pval, int W, int64_t ncols)
+  {
+    const int np = (int)plen.size();                       // includes the trailing empty pattern
+    std::vector<int32_t> U;
+    for (int p = 0; p < np; ++p)
+      for (int j = 0; j < plen[p]; ++j) {
+        const int32_t o = poff8[(size_t)p * W + j] / 8;
+        if (j > 0 && o <= poff8[(size_t)p * W + j - 1] / 8) return;   // unsorted or duplicate columns: keep the generic form
+        U.push_back(o);
+      }
+    std::sort(U.begin(), U.end());
+    U.erase(std::unique(U.begin(), U.end()), U.end());
+    if (U.empty()) return;
+    std::vector<int32_t> runs;
+    for (size_t i = 0; i < U.size();) {
+      const int32_t o = U[i];
+      runs.push_back(o);
+      while (i < U.size() && U[i] <= o + 2) ++i;
+    }
+    // more loads than the generic kernel would issue: not worth it
+    size_t maxlen = 0;
+    for (int p = 0; p < np; ++p) maxlen = std::max(maxlen, (size_t)plen[p]);
+    if (2 * runs.size() > maxlen + 2) return;
+    const size_t nreal = runs.size();                       // sorted ascending
+    while (runs.size() % (size_t)pat_rb) runs.push_back(0);     // dummy runs: zero coefficients on x[row..row+2]
+    const int nruns = (int)runs.size(), nu = 3 * nruns;
+    if ((int64_t)np * nu * (int64_t)sizeof(PatEntry) > 48 * 1024) return;
+    std::vector<PatEntry> tab((size_t)np * nu);
+    std::memset(tab.data(), 0, tab.size() * sizeof(PatEntry));
+    for (int p = 0; p < np; ++p)
+      for (int j = 0; j < plen[p]; ++j) {
+        const int32_t o = poff8[(size_t)p * W + j] / 8;
+        const auto it = std::upper_bound(runs.begin(), runs.begin() + nreal, o);   // the run that holds o
+        const size_t r = (size_t)(it - runs.begin()) - 1;
+        PatEntry &e = tab[(size_t)p * nu + r * 3 + (size_t)(o - runs[r])];
+        e.v = pval[(size_t)p * W + j];
+        e.m = 0xffffffffu;
+      }
+    D.ptab = upload(tab);
+    D.prun = upload(runs);
+    D.pat_nruns = nruns;
+    D.pat_minoff = *std::min_element(runs.begin(), runs.end());
+    D.pat_maxoff = *std::max_element(runs.begin(), runs.end());
+    D.pat_shared = ncols < (int64_t)(1 << 28);
+  }
+  template <int EPI, bool ONEG>
+  void launch_sells(const DevCSR &M, const StreamArgs2 &a2)
+  {
+    SellSArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rowpid = M.rowpid; a.tab = M.ptab; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
+    a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff;
+    a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
+    a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
+    const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
+    const int nwg = std::max(1, std::min((M.nslices + wpb - 1) / wpb, pat_wgs));
+    const size_t lds = (size_t)M.pat_np * 3 * M.pat_nruns * 12;
+    if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
+    else hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
+    HIP_CHECK(hipGetLastError());
+  }
+  template <int EPI, bool ONEG>
+  void launch_sellp(const DevCSR &M, const StreamArgs2 &a2)
+  {
+    if (M.pat_shared && (EPI != EPI_SWEEP || ONEG)) { launch_sells<EPI, ONEG>(M, a2); return; }
+    SellPArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rowpid = M.rowpid; a.rowbase = M.rowbase; a.plen = M.plen; a.poff = M.ppoff; a.pval = M.ppval; a.np = M.pat_np; a.W = M.pat_w;
+    a.nrows = M.nrows; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
+    a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
+    // persistent launch: the pattern table is staged into LDS once per workgroup
+    const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
+    const int nwg = std::max(1, std::min((M.nslices + wpb - 1) / wpb, pat_wgs));
+    const size_t lds = (size_t)M.pat_np * M.pat_w * 12 + (size_t)M.pat_np * 4;
+    const dim3 g(nwg), b(64 * wpb);
+#define GMG_SELLP_LAUNCH(UNV) hipLaunchKernelGGL((sellp_kernel<EPI, ONEG, UNV>), g, b, lds, stream, a)
+    switch (pat_un_eff()) {
+    case 27: GMG_SELLP_LAUNCH(27); break;
+    case 14: GMG_SELLP_LAUNCH(14); break;
+    case 9: GMG_SELLP_LAUNCH(9); break;
+    case 6: GMG_SELLP_LAUNCH(6); break;
+    default: GMG_SELLP_LAUNCH(3); break;
+    }
+#undef GMG_SELLP_LAUNCH
+    HIP_CHECK(hipGetLastError());
+  }
+
   // SELL-64 conversion (setup): slices of 64 rows, width = longest row of the slice.
   void build_sell(const HostCSR &H, DevCSR &D)
   {
     if (!use_sell || H.nrows == 0 || D.nnz == 0) return;
+    if (build_pattern(H, D)) return;
     const int64_t ns = (H.nrows + 63) / 64;
     std::vector<int64_t> soff((size_t)ns + 1, 0);
     for (int64_t sl = 0; sl < ns; ++sl) {
@@ -673,6 +931,7 @@ struct gmg_solver {
   template <int EPI, bool ONEG>
   void launch_sell(const DevCSR &M, const StreamArgs2 &a2)
   {
+    if (M.pat) { launch_sellp<EPI, ONEG>(M, a2); return; }
     if (M.comp_idx || M.vdict) { launch_sellc<EPI, ONEG>(M, a2); return; }
     SellArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -1134,7 +1393,7 @@ struct gmg_solver {
 
   void read_tuning()
   {
-    xcd_remap = env_int("GMG_XCD_REMAP", 0);   // measured: no gain from XCD-contiguous ranges (profiles/r01_tuning.md)
+    xcd_remap = env_int("GMG_XCD_REMAP", 1);   // XCD-contiguous row ranges: each L2 sees 1/8 of the gathered vector (pattern kernels: -6 % per solve)
     lanes_override = env_int("GMG_LANES_LOG2", -1);
     one_gather_sweep = env_int("GMG_ONE_GATHER", 1);
     use_sell = env_int("GMG_SELL", 1);
@@ -1144,6 +1403,11 @@ struct gmg_solver {
     sell_block = std::min(256, env_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
     if (const char *mp = std::getenv("GMG_SELL_MAXPAD")) sell_maxpad = std::atof(mp);
     nt_loads = env_int("GMG_NT", 1);
+    use_pattern = env_int("GMG_PATTERN", 1);
+    pat_un = env_int("GMG_PAT_UN", 9);
+    pat_wgs = std::max(1, env_int("GMG_PAT_WGS", 2048));
+    pat_shared = env_int("GMG_PAT_SHARED", 1);
+    pat_rb = env_int("GMG_PAT_RB", 3) >= 9 ? 9 : 3;
     tile = kTile;
   }
   // inv_diag = 1 ./ diag(A) (JacobiLinearSolvers.jl:20-23); needs the CSR stream of A (before drop_csr_stream)
@@ -2314,10 +2578,10 @@ int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
     check_ready(h);
     check_level(h, lev, false);
     const DevCSR &A = h->lev[lev].A;
-    if (sell) *sell = A.sell ? 1 : 0;
+    if (sell) *sell = A.pat ? 2 : (A.sell ? 1 : 0);
     if (vdict) *vdict = A.vdict ? 1 : 0;
     if (idx16) *idx16 = A.comp_idx ? 1 : 0;
-    if (stream_bytes_per_nnz) *stream_bytes_per_nnz = (A.sell && (A.vdict || A.comp_idx)) ? A.stream_bytes_per_nnz : 12.0;
+    if (stream_bytes_per_nnz) *stream_bytes_per_nnz = (A.sell && (A.pat || A.vdict || A.comp_idx)) ? A.stream_bytes_per_nnz : 12.0;
     if (padding) *padding = A.sell && A.nnz > 0 ? (double)A.zpad / (double)A.nnz : 1.0;
   });
 }

@@ -1,6 +1,6 @@
 // kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the GMG hot path.
 //
-// All kernels are HBM-bandwidth bound (~0.16 flop/byte): no MFMA.  Three operator layouts,
+// All kernels are HBM-bandwidth bound (~0.16 flop/byte): no MFMA.  Four operator layouts,
 // all produced at setup from the caller's CSR/CSC (profiles/r01_tuning.md has the numbers):
 //   * SELL-64 (`sell_kernel`): lane = row, slices of 64 rows stored column-major, so the
 //     (col,val) stream, the row-wise operands and (for banded matrices) the gather are all
@@ -8,6 +8,8 @@
 //     sequential CPU SpMV).  Chosen when the padding is small.
 //   * SELL-C (`sellc_kernel`): the same kernel fed by a losslessly compressed stream -- 8-bit
 //     value dictionary (LDS) + 16-bit column offsets per slice column: 12 -> 3 B/nnz.
+//   * SELL-P (`sellp_kernel`): row-pattern dictionary for structured constant-coefficient
+//     operators: a 16-bit pattern id per row, the (offset,value) patterns in LDS.
 //   * CSR-stream (`csr_stream1_kernel`): block-wide coalesced loads of a 2048-nnz tile,
 //     products staged in LDS, G lanes per row with a wave64 __shfl_xor tail -- the generic
 //     path for ragged matrices (P) and rows longer than a tile.
@@ -467,6 +469,279 @@ __global__ __launch_bounds__(kBlock) void sellc_kernel(SellCArgs a)
       const double rn = e0 - s;
       a.y[row] = rn;
       if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Row-pattern SELL ("SELL-P"): operators assembled on structured grids with constant
+// coefficients hold only a handful of DISTINCT ROWS once a row is written as
+// (column offsets relative to a base, values): a 27-point Q1 stiffness matrix with
+// Dirichlet rows eliminated has 27 such patterns, its prolongation ~64.  The setup
+// detects them exactly (bitwise equal values, equal offsets) and the matrix stream
+// collapses to a 16-bit pattern id per row (+ a 32-bit base column when offsets are
+// not relative to the row index): 324 B/row -> 2 B/row for the 27-point operator.
+// The pattern table (offsets + fp64 values, a few KB) lives in LDS; lane = row as in
+// SELL-64, rows are summed left to right in CSR order (bit-identical to the oracle),
+// lanes of a wave mostly share a pattern, so the table reads are LDS broadcasts and the
+// gather x[base+off] is contiguous across lanes.  What is left is the vector traffic.
+// ---------------------------------------------------------------------------
+struct SellPArgs {
+  const uint16_t *rowpid;   // [nrows] pattern of each row
+  const int32_t *rowbase;   // [nrows] base column, or nullptr: offsets are relative to the row index
+  const int32_t *plen;      // [np]  (the last pattern is an empty row, used by the lanes past nrows)
+  const int32_t *poff;      // [np*W] BYTE offsets (8*column offset), zero padded
+  const double *pval;       // [np*W] zero padded
+  int np, W;                // W = row stride of the table, a multiple of the kernel's UN
+  int64_t nrows;
+  int nslices;
+  int x_zero;
+  int xcd_remap;
+  const double *x;
+  const double *dinv;
+  double omega;
+  double *y;
+  const double *b;
+  double *x2;
+  double *s_out;
+};
+
+// x[byte offset]: uniform base + 32-bit lane offset (the saddr + voffset form of global_load)
+__device__ __forceinline__ double ld_off(const double *__restrict__ base, uint32_t byteoff)
+{
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff);
+}
+
+template <int EPI, bool ONEG, int UN>
+__global__ __launch_bounds__(kBlock) void sellp_kernel(SellPArgs a)
+{
+  extern __shared__ double sp_smem[];
+  const int tot = a.np * a.W;
+  double *s_val = sp_smem;
+  int32_t *s_off = reinterpret_cast<int32_t *>(sp_smem + tot);
+  int32_t *s_len = s_off + tot;
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.pval[i]; s_off[i] = a.poff[i]; }
+  for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_len[i] = a.plen[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  // every workgroup owns a contiguous chunk of slices (its waves interleave inside it); with
+  // xcd_remap the chunks of one XCD are contiguous too, so each L2 sees 1/8 of the gathered vector
+  const int nwg = gridDim.x;
+  const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
+  const int chunk = (a.nslices + nwg - 1) / nwg;
+  const int s_begin = blk * chunk;
+  const int s_end = min(a.nslices, s_begin + chunk);
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  const int W = a.W;
+  for (int slice = s_begin + wave; slice < s_end; slice += wpb) {
+    const int64_t row = (int64_t)slice * 64 + lane;
+    const bool valid = row < a.nrows;
+    const int pid = valid ? (int)a.rowpid[row] : a.np - 1;    // the last pattern is empty: lanes past the end gather x[0] * 0
+    const int len = s_len[pid];
+    const uint32_t base8 = valid ? 8u * (uint32_t)(a.rowbase ? a.rowbase[row] : (int32_t)row) : 0u;
+    double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+    if (valid) {
+      if (EPI == EPI_SUB) e0 = a.y[row];
+      else if (EPI == EPI_RESID) e0 = a.b[row];
+      else if (EPI == EPI_ADDTO) e0 = a.x2[row];
+      else if (EPI == EPI_SWEEP) {
+        e0 = a.b[row];
+        e1 = ONEG ? xg[row] : dinv[row];
+        e2 = a.x_zero ? 0.0 : a.x2[row];
+        if (ONEG) dinv_row = dinv[row];
+      }
+    }
+    int lmax = len;                                        // longest row of the wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o));
+    lmax = __builtin_amdgcn_readfirstlane(lmax);
+    const double *tv = s_val + pid * W;
+    const int32_t *to = s_off + pid * W;
+    double s = 0.0;
+    for (int j = 0; j < lmax; j += UN) {                   // j + UN <= W: the table rows are padded to a multiple of UN
+      double v[UN], g[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        // entries past the end of a row are (offset 0, value 0.0): they gather the row's base column
+        // (valid) and multiply it by zero; clearing the high word of the gathered value for those
+        // lanes keeps the product an exact zero even if that entry of x is Inf/NaN.
+        v[u] = tv[j + u];
+        const uint32_t c8 = base8 + (uint32_t)to[j + u];
+        if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (ld_off(dinv, c8) * ld_off(xg, c8));
+        else g[u] = ld_off(xg, c8);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        double gu = g[u];
+        if (!(j + u < len)) gu = __hiloint2double(0, __double2loint(gu));
+        s = s + v[u] * gu;                                 // padded entries add an exact +0.0: s is unchanged
+      }
+    }
+    if (valid) {
+      if (EPI == EPI_SET) a.y[row] = s;
+      else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+      else if (EPI == EPI_RESID) a.y[row] = e0 - s;
+      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+      else {
+        const double dxi = ONEG ? e1 : omega * (e1 * e0);
+        a.x2[row] = e2 + dxi;
+        const double rn = e0 - s;
+        a.y[row] = rn;
+        if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// SELL-P, shared-offset form ("stencil mode"): when the offsets are relative to the row index, every
+// row pattern is a subset of the union U of all offsets, so ALL rows can share one offset list and
+// differ only in their coefficients (absent entries become explicit zeros, which add an exact +0.0;
+// a per-entry mask clears the high word of the gathered value so that the product stays an exact zero
+// even for a non-finite x).  U is covered by runs of 3 consecutive offsets (o,o+1,o+2).  Per run a
+// lane loads x[row+o] once; x[row+o+1] and x[row+o+2] are its right neighbours' values, fetched with
+// DPP wave shifts (lanes 62/63 take theirs from a 2-lane tail load).  A 27-point operator needs 9+9
+// load instructions per 64 rows instead of 27, which is what bounded the generic pattern kernel
+// (L1 line traffic of the overlapping gathers).  Rows are still summed in ascending column order.
+// ---------------------------------------------------------------------------
+struct alignas(16) PatEntry {
+  double v;
+  uint32_t m;      // 0xffffffff: entry present ; 0: padding
+  uint32_t pad;
+};
+
+struct SellSArgs {
+  const uint16_t *rowpid;
+  const PatEntry *tab;      // [np * nu], nu = 3 * nruns ; the last pattern is empty
+  const int32_t *run_off;   // [nruns] first offset of each run (elements)
+  int np, nruns;            // nruns is a multiple of the kernel's RB
+  int minoff, maxoff;       // over all runs (maxoff includes the +2)
+  int64_t nrows, ncols;
+  int nslices;
+  int x_zero;
+  int xcd_remap;
+  const double *x;
+  const double *dinv;
+  double omega;
+  double *y;
+  const double *b;
+  double *x2;
+  double *s_out;
+};
+
+// lane i <- lane i+1 ; lane 63 <- `tail`
+__device__ __forceinline__ double wave_shl1(double v, double tail)
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(tail), __double2loint(v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(tail), __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast_lane(double v, int l)
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int EPI, bool ONEG, int RB>
+__global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
+{
+  extern __shared__ double sp_smem[];
+  const int nu = 3 * a.nruns;
+  const int tot = a.np * nu;
+  double *s_val = sp_smem;                                 // [np * nu] coefficients
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);   // [np * nu] high-word masks
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int nwg = gridDim.x;
+  const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
+  const int chunk = (a.nslices + nwg - 1) / nwg;
+  const int s_begin = blk * chunk;
+  const int s_end = min(a.nslices, s_begin + chunk);
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  const int last = (int)a.ncols - 1;
+
+  // row-wise operands of a slice ("head"): requested one slice ahead, so that their HBM latency is
+  // covered by the previous slice's taps; the gathers do not depend on them (shared offsets).
+  int pid_n = a.np - 1;
+  double e0_n = 0.0, e1_n = 0.0, e2_n = 0.0, dr_n = 0.0;
+  auto load_head = [&](int slice) {
+    const int64_t row = (int64_t)slice * 64 + lane;
+    pid_n = a.np - 1; e0_n = e1_n = e2_n = dr_n = 0.0;
+    if (slice < s_end && row < a.nrows) {
+      pid_n = (int)a.rowpid[row];
+      if (EPI == EPI_SUB) e0_n = a.y[row];
+      else if (EPI == EPI_RESID) e0_n = a.b[row];
+      else if (EPI == EPI_ADDTO) e0_n = a.x2[row];
+      else if (EPI == EPI_SWEEP) {
+        e0_n = a.b[row];
+        e1_n = xg[row];
+        e2_n = a.x_zero ? 0.0 : a.x2[row];
+        dr_n = dinv[row];
+      }
+    }
+  };
+  load_head(s_begin + wave);
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
+  __syncthreads();
+
+  for (int slice = s_begin + wave; slice < s_end; slice += wpb) {
+    const int row0 = slice * 64;
+    const int64_t row = (int64_t)row0 + lane;
+    const int pid = pid_n;
+    const double e0 = e0_n, e1 = e1_n, e2 = e2_n, dinv_row = dr_n;
+    // slices whose windows leave [0,ncols) clamp their addresses (the clamped entries have zero coefficients)
+    const bool edge = (row0 + a.minoff < 0) || (row0 + 65 + a.maxoff > last);
+    const uint32_t row8 = 8u * (uint32_t)row;
+    double s = 0.0;
+    double A[RB], B[RB];
+    auto gather = [&](int r0) {
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int o = a.run_off[r0 + q];                   // uniform: scalar load
+        if (!edge) {
+          const double *xo = xg + o;
+          A[q] = ld_off(xo, row8);
+          B[q] = (lane < 2) ? ld_off(xo + 64, row8) : 0.0;
+        } else {
+          A[q] = xg[min(max((int)row + o, 0), last)];
+          B[q] = (lane < 2) ? xg[min(max((int)row + 64 + o, 0), last)] : 0.0;
+        }
+      }
+    };
+    gather(0);
+    load_head(slice + wpb);                                // younger than the first gathers: not waited for with them
+    const double *tv = s_val + pid * nu;
+    const uint32_t *tm = s_msk + pid * nu;
+    for (int r0 = 0; r0 < a.nruns; r0 += RB) {
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        double cur = A[q];
+        const double bq = B[q];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if (t > 0) cur = wave_shl1(cur, bcast_lane(bq, t - 1));
+          const int j = (r0 + q) * 3 + t;
+          const double g = __hiloint2double(__double2hiint(cur) & (int)tm[j], __double2loint(cur));
+          s = s + tv[j] * g;
+        }
+      }
+      if (r0 + RB < a.nruns) gather(r0 + RB);
+    }
+    if (row < a.nrows) {
+      if (EPI == EPI_SET) a.y[row] = s;
+      else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+      else if (EPI == EPI_RESID) a.y[row] = e0 - s;
+      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+      else {
+        a.x2[row] = e2 + e1;
+        const double rn = e0 - s;
+        a.y[row] = rn;
+        a.s_out[row] = omega * (dinv_row * rn);
+      }
     }
   }
 }

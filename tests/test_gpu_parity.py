@@ -419,11 +419,16 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
     b = po.dirichlet_lift_rhs(nc, 1)
     r = seeded(b.size, 41)
     out = {}
-    for name, env in {"csr": dict(GMG_SELL="0"), "sell": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="0"),
-                      "sellc": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="1"),
-                      "sell_idx16": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="2"),
-                      "sell_dict": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="0")}.items():
-        for k in ("GMG_SELL", "GMG_VDICT", "GMG_IDX16"):
+    for name, env in {"csr": dict(GMG_SELL="0"), "sell": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="0", GMG_PATTERN="0"),
+                      "sellc": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="1", GMG_PATTERN="0"),
+                      "sell_idx16": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="2", GMG_PATTERN="0"),
+                      "sell_dict": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="0", GMG_PATTERN="0"),
+                      "pattern_shared": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1"),
+                      "pattern_shared_rb9": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_RB="9"),
+                      "pattern_generic": dict(GMG_PATTERN="1", GMG_PAT_SHARED="0"),
+                      "pattern_generic_un3": dict(GMG_PATTERN="1", GMG_PAT_SHARED="0", GMG_PAT_UN="3"),
+                      "pattern_two_gather": dict(GMG_PATTERN="1", GMG_ONE_GATHER="0")}.items():
+        for k in ("GMG_SELL", "GMG_VDICT", "GMG_IDX16", "GMG_PATTERN", "GMG_PAT_SHARED", "GMG_PAT_RB", "GMG_PAT_UN", "GMG_ONE_GATHER"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -434,6 +439,7 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
         z = np.zeros_like(r)
         S.solve_(z, ns.P_ns, r)
         out[name] = (x, z, solver.log.num_iters, solver.log.residuals[: solver.log.num_iters + 1].copy())
+        assert ns.P_ns.level_format(0)["layout"] == ("CSR-stream" if name == "csr" else "SELL-P" if name.startswith("pattern") else "SELL-64"), name
     go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
     xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
     zo = go.solve(r)[0]
@@ -441,7 +447,8 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
         assert it == nit, name
         assert rel_err(x, xo) <= 1e-10 and rel_err(z, zo) <= TOL_VCYCLE, name
         np.testing.assert_allclose(h, hist, rtol=TOL_HIST)
-    for name in ("sellc", "sell_idx16", "sell_dict"):
+    # (the row-pattern kernels add explicit +0.0 terms for absent entries: the bits of the sums do not change)
+    for name in ("sellc", "sell_idx16", "sell_dict", "pattern_shared", "pattern_shared_rb9", "pattern_generic", "pattern_generic_un3"):
         assert np.array_equal(out[name][0], out["sell"][0]) and np.array_equal(out[name][1], out["sell"][1]), name
 
 
@@ -533,6 +540,7 @@ def test_sellc_mixed_slices_wide_and_banded(S, po, orc, monkeypatch):
     AH = (Pm.T @ B @ Pm).tocsr(); AH.sort_indices()
     H = dict(mats=[A, po.CSR((nH, nH), AH.indptr, AH.indices, AH.data)], prolongations=[P], restrictions=[P.transpose()])
     monkeypatch.setenv("GMG_SELL_MAXPAD", "3.0")
+    monkeypatch.setenv("GMG_PATTERN", "0")
     ns = setup(S, make_gmg(S, H), A)
     fmt = ns.level_format(0)
     assert fmt["layout"] == "SELL-64" and fmt["value_dictionary"] and fmt["idx16"]
@@ -622,3 +630,67 @@ def test_device_coarse_inversion_matches_host_factorisation(S, po, orc, hierarch
     xo = orc.GMG(H["mats"], H["prolongations"], maxiter=1).coarse_solve(rc)
     assert max_rel(out["host"], xo) <= 1e-12 and max_rel(out["device"], xo) <= 1e-11
     assert max_rel(out["device"], out["host"]) <= 1e-11
+
+
+def test_row_pattern_format_details(S, po, orc, hierarchy, monkeypatch):
+    """SELL-P (row-pattern dictionary): square operators use offsets relative to the row (shared-offset kernel with
+    DPP neighbour exchange), the rectangular transfers offsets relative to their first column; domain ends are clamped;
+    a non-finite entry of x must only reach the rows that hold a stored coefficient for it; matrices whose rows are
+    all different fall back to the other layouts."""
+    from gridapsolvers_jl_amd import abi
+    nc, nlev = (12, 20, 8), 2                                  # 11*19*7 = 1463 rows: ragged last slice, many edge slices
+    H = hierarchy(nc, nlev)
+    ns = setup(S, make_gmg(S, H), H["mats"][0])
+    assert ns.level_format(0)["layout"] == "SELL-P" and ns.level_format(0)["stream_bytes_per_nnz"] < 0.2
+    A, P, R = H["mats"][0], H["prolongations"][0], H["restrictions"][0]
+    x = seeded(A.shape[0], 5)
+    for op, M, xin in ((abi.OP_A, A, x), (abi.OP_R, R, x), (abi.OP_P, P, seeded(P.shape[1], 6))):
+        y = np.zeros(M.shape[0])
+        ns.op_apply(0, op, xin, y)
+        assert np.array_equal(y, orc.spmv(M, xin)), op         # sequential row sums in CSR order: bit-identical
+    # an Inf in x reaches exactly the rows that store a coefficient for that column
+    k = A.shape[0] // 2
+    xi = x.copy(); xi[k] = np.inf
+    y = np.zeros_like(xi)
+    ns.op_apply(0, abi.OP_A, xi, y)
+    touched = np.zeros(A.shape[0], dtype=bool)
+    As = A.to_scipy().tocsc()
+    touched[As.indices[As.indptr[k]:As.indptr[k + 1]]] = True
+    assert np.all(np.isfinite(y[~touched])) and not np.any(np.isfinite(y[touched]))
+    assert np.array_equal(y[~touched], orc.spmv(A, x)[~touched])
+    ns.close()
+    # all rows different (random symmetric scaling): no pattern dictionary
+    D = np.random.default_rng(8).uniform(0.5, 2.0, A.shape[0])
+    As = A.to_scipy().multiply(D[:, None]).multiply(D[None, :]).tocsr(); As.sort_indices()
+    A2 = po.CSR(A.shape, As.indptr, As.indices, As.data)
+    H2 = dict(mats=[A2, H["mats"][1]], prolongations=H["prolongations"], restrictions=H["restrictions"])
+    ns2 = setup(S, make_gmg(S, H2), A2)
+    assert ns2.level_format(0)["layout"] != "SELL-P"
+    y = np.zeros_like(x)
+    ns2.op_apply(0, abi.OP_A, x, y)
+    assert max_rel(y, orc.spmv(A2, x)) <= 1e-15
+    ns2.close()
+
+
+def test_row_pattern_unsorted_and_duplicate_columns(S, po, orc, pkg):
+    """Rows given with unsorted or repeated column indices keep their summation order: the shared-offset form
+    (ascending offsets) must not be chosen for them, the generic pattern form sums in the given order."""
+    from gridapsolvers_jl_amd import abi
+    n = 256
+    ptr = np.arange(0, 4 * n + 1, 4, dtype=np.int64)
+    idx = np.zeros(4 * n, dtype=np.int32)
+    val = np.zeros(4 * n)
+    for i in range(n):
+        cols = [(i + 1) % n, i, (i + n - 1) % n, i]             # unsorted, diagonal twice
+        idx[4 * i:4 * i + 4] = cols
+        val[4 * i:4 * i + 4] = [-1.0, 2.5, -1.0, 1.5]
+    A = po.CSR((n, n), ptr, idx, val)
+    Ac = po.CSR((2, 2), [0, 1, 2], [0, 1], [1.0, 1.0])
+    Pm = po.CSR((n, 2), np.arange(n + 1), (np.arange(n) % 2).astype(np.int32), np.ones(n))
+    gmg = S.GMGLinearSolver([A, Ac], [Pm], None, pre_smoothers=jac(S, 2, 1, 0.5), post_smoothers=jac(S, 2, 1, 0.5), maxiter=1)
+    ns = setup(S, gmg, A)
+    x = seeded(n, 2)
+    y = np.zeros(n)
+    ns.op_apply(0, abi.OP_A, x, y)
+    assert np.array_equal(y, orc.spmv(A, x))
+    ns.close()
