@@ -1460,34 +1460,45 @@ KrylovOps gmg_solver::level0_ops(int use_precond)
 static double cg_core(gmg_solver &S, int64_t n, const double *db, double *dx, double *w, double *p, double *z, double *r,
                const KrylovOps &ops, bool flexible, ConvLog &log)
 {
+  // Scalars stay on the device: gamma (ping-pong), delta and dot(p,w) live in d_scalars and the vector
+  // kernels form beta / alpha from them, so an iteration has ONE host round trip (the residual norm that
+  // the stopping rule needs) instead of three.
+  constexpr int kG0 = kScalarSlots - 8, kG1 = kScalarSlots - 7, kDelta = kScalarSlots - 6, kPW = kScalarSlots - 5;
+  int g_old = kG0, g_new = kG1;
   ops.resid(dx, db, r);                                  // CGSolvers.jl:79  w = A x ; r = b - w
-  S.zero(p, n);                                          // :80
-  S.zero(z, n);                                          // :81
-  double gamma = 1.0, beta = 0.0, alpha = 0.0;           // :82
+  // :80 fill!(p,0): folded into the first p = z + beta*p ; :81 fill!(z,0): only the flexible variant reads z before writing it
+  if (flexible) S.zero(z, n);
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, S.stream, S.d_scalars + g_old, 1.0);   // :82 gamma = 1
+  HIP_CHECK(hipGetLastError());
   double resn = S.norm(n, r);                            // :85
   bool done = log.init(resn);                            // :86
+  bool first = true;
   const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kBlock - 1) / kBlock));
   while (!done) {
     if (!ops.precond) {                                  // :90-92
       S.copy(z, r, n);
-      beta = gamma; gamma = S.dot(n, r, r); beta = gamma / beta;
+      S.dot_async(n, r, r, g_new, false);
     } else if (!flexible) {                              // :93-95
       ops.precond(z, r, resn);
-      beta = gamma; gamma = S.dot(n, z, r); beta = gamma / beta;
+      S.dot_async(n, z, r, g_new, false);
     } else {                                             // :96-99
-      const double delta = S.dot(n, z, r);
+      S.dot_async(n, z, r, kDelta, false);
       ops.precond(z, r, resn);
-      beta = gamma; gamma = S.dot(n, z, r); beta = (gamma - delta) / beta;
+      S.dot_async(n, z, r, g_new, false);
     }
-    hipLaunchKernelGGL(xpby_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, S.stream, n, z, beta, p); // :101
+    hipLaunchKernelGGL(xpby_dev_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, S.stream, n, z, S.d_scalars + g_new,
+                       S.d_scalars + g_old, (ops.precond && flexible) ? S.d_scalars + kDelta : nullptr, p, first ? 1 : 0); // :101
     HIP_CHECK(hipGetLastError());
     ops.apply(p, w);                                     // :104
-    alpha = gamma / S.dot(n, p, w);                      // :105
-    hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, alpha, p, w, dx, r, S.d_partials); // :108-109
+    S.dot_async(n, p, w, kPW, false);                    // :105
+    hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, S.d_scalars + g_new, S.d_scalars + kPW, p, w, dx, r,
+                       S.d_partials); // :108-109
     HIP_CHECK(hipGetLastError());
     S.finish_reduction(nb, 0, true);
     resn = S.fetch_scalar(0);                            // :111
     done = log.update(resn);                             // :112
+    std::swap(g_old, g_new);
+    first = false;
   }
   return resn;
 }
@@ -1505,7 +1516,7 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
   // Hessenberg / rotations sized for the largest basis reachable in maxiter steps
   const int hcap = std::max(m, log.maxiter + 1) + 1;
   const int ldh = hcap + 1;
-  REQUIRE(hcap + 2 < kScalarSlots, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer");
+  REQUIRE(hcap + 2 < kScalarSlots - 8, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer");
   std::vector<double> H((size_t)ldh * hcap, 0.0), g((size_t)hcap + 1, 0.0), c((size_t)hcap, 0.0), s((size_t)hcap, 0.0);
   auto Hm = [&](int i, int j) -> double & { return H[(size_t)(i - 1) + (size_t)(j - 1) * ldh]; };
   const int grid = gmg_solver::grid_for(n);

@@ -849,12 +849,27 @@ __global__ void xpby_kernel(int64_t n, const double *__restrict__ z, double beta
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     p[i] = z[i] + beta * p[i];
 }
+// The same with beta formed on the device from reduction results: beta = gamma/gamma_old, or
+// (gamma - delta)/gamma_old for the flexible variant (CGSolvers.jl:95,99) -- no host round trip.
+// first != 0: p is the zero vector of CGSolvers.jl:80 and is not read.
+__global__ void xpby_dev_kernel(int64_t n, const double *__restrict__ z, const double *__restrict__ gamma,
+                                const double *__restrict__ gamma_old, const double *__restrict__ delta,
+                                double *__restrict__ p, int first)
+{
+  const double beta = delta ? (gamma[0] - delta[0]) / gamma_old[0] : gamma[0] / gamma_old[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = z[i] + beta * (first ? 0.0 : p[i]);
+}
+__global__ void set_scalar_kernel(double *__restrict__ dst, double v) { dst[0] = v; }
 // x += alpha*p ; r -= alpha*w ; partial ||r||^2   (CGSolvers.jl:108-111)
-__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double alpha, const double *__restrict__ p,
+// alpha = gamma / dot(p,w) (CGSolvers.jl:105) formed on the device from the two reduction results
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, const double *__restrict__ gamma,
+                                                           const double *__restrict__ pw, const double *__restrict__ p,
                                                            const double *__restrict__ w, double *__restrict__ x,
                                                            double *__restrict__ r, double *__restrict__ partials)
 {
   __shared__ double sh[4];
+  const double alpha = gamma[0] / pw[0];
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     x[i] += alpha * p[i];
