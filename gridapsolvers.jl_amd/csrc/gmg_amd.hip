@@ -191,6 +191,7 @@ struct DevCSR {
   PatEntry *ptab = nullptr;
   int32_t *prun = nullptr;
   int pat_nruns = 0, pat_minoff = 0, pat_maxoff = 0;
+  double *pdinv = nullptr;      // [np] 1/diag per pattern (nullptr: some pattern has no diagonal entry)
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -393,6 +394,8 @@ struct gmg_solver {
   int pat_un = 9;       // GMG_PAT_UN: gathers in flight per lane in sellp_kernel
   int pat_wgs = 2048;   // GMG_PAT_WGS: resident workgroups of the persistent sellp launch
   int pat_rb = 3;       // GMG_PAT_RB: runs (of 3 offsets) loaded per batch in sells_kernel (3 or 9)
+  int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
+  int pat_dinv = 1;     // GMG_PAT_DINV: Jacobi inverse diagonal from the pattern table instead of its vector
   int pat_shared = 1;   // GMG_PAT_SHARED: shared-offset (stencil) form when the offsets are row-relative
   int one_gather_sweep = 1;   // GMG_ONE_GATHER: sweep gathers s = w*Dinv*r (1) or r and Dinv (0)
   int tile = kTile;
@@ -717,6 +720,17 @@ struct gmg_solver {
         e.v = pval[(size_t)p * W + j];
         e.m = 0xffffffffu;
       }
+    {   // inverse diagonal per pattern (JacobiLinearSolvers.jl:20-23: 1 ./ diag(A)); rows of the same pattern share it
+      std::vector<double> pd((size_t)np, 0.0);
+      bool all = D.nrows == D.ncols;
+      for (int p = 0; p < np - 1 && all; ++p) {
+        bool found = false;
+        for (int j = 0; j < plen[p]; ++j)
+          if (poff8[(size_t)p * W + j] == 0) { pd[p] = 1.0 / pval[(size_t)p * W + j]; found = true; }
+        all = found;
+      }
+      if (all) D.pdinv = upload(pd);
+    }
     D.ptab = upload(tab);
     D.prun = upload(runs);
     D.pat_nruns = nruns;
@@ -731,11 +745,12 @@ struct gmg_solver {
     std::memset(&a, 0, sizeof(a));
     a.rowpid = M.rowpid; a.tab = M.ptab; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
     a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff;
+    a.xmode = a2.xmode; a.pdinv = (EPI == EPI_SWEEP && a2.dinv_from_table) ? M.pdinv : nullptr;
     a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
     a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
     const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
     const int nwg = std::max(1, std::min((M.nslices + wpb - 1) / wpb, pat_wgs));
-    const size_t lds = (size_t)M.pat_np * 3 * M.pat_nruns * 12;
+    const size_t lds = (size_t)M.pat_np * 3 * M.pat_nruns * 12 + 8 + (size_t)M.pat_np * 8;
     if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
     else hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
     HIP_CHECK(hipGetLastError());
@@ -1012,7 +1027,7 @@ struct gmg_solver {
   // fused Richardson-Jacobi sweep: x += w*Dinv*r_old ; r_new = r_old - A*(w*Dinv*r_old)
   // one-gather form: s_old = w*Dinv*r_old is an input, s_new = w*Dinv*r_new an output.
   void sweep(int l, const Smoother &S, double *x, const double *r_old, double *r_new, bool x_zero,
-             const double *s_old = nullptr, double *s_new = nullptr)
+             const double *s_old = nullptr, double *s_new = nullptr, int xmode = 0)
   {
     Level &L = lev[l];
     if (comm.nranks > 1) begin_exchange(l, const_cast<double *>(s_old ? s_old : r_old));
@@ -1021,6 +1036,7 @@ struct gmg_solver {
     {
       StreamArgs2 a = base_args1(L.A);
       a.b = r_old; a.dinv = L.dinv; a.omega = S.omega; a.y = r_new; a.x2 = x; a.x_zero = x_zero ? 1 : 0;
+      a.xmode = xmode; a.dinv_from_table = pat_dinv;      // L.dinv is 1 ./ diag(L.A): the pattern table holds the same numbers
       if (L.A.sell) {
         if (s_old) { a.x = s_old; a.s_out = s_new; launch_sell<EPI_SWEEP, true>(L.A, a); }
         else { a.x = r_old; launch_sell<EPI_SWEEP, false>(L.A, a); }
@@ -1218,8 +1234,17 @@ struct gmg_solver {
       HIP_CHECK(hipGetLastError());
       const double *cur = r_in;
       double *out = r_internal ? const_cast<double *>(r_in) : L.rbuf[0];
+      // shared-offset pattern kernel: x is updated every second sweep with both increments,
+      // x = (x + s_{k-1}) + s_k (the same two roundings), which saves one read+write of x per pair
+      const bool defer = pat_defer && L.A.pat_shared;
       for (int it = 0; it < S.niter; ++it) {
-        sweep(l, S, x, cur, out, x_zero && it == 0, L.sbuf[it & 1], L.sbuf[(it + 1) & 1]);
+        int xmode = 0;
+        bool xz = x_zero && it == 0;
+        if (defer) {
+          if ((it & 1) == 0 && it + 1 < S.niter) xmode = 1;
+          else if (it & 1) { xmode = 2; xz = x_zero && it == 1; }
+        }
+        sweep(l, S, x, cur, out, xz, L.sbuf[it & 1], L.sbuf[(it + 1) & 1], xmode);
         cur = out;
       }
       return out;
@@ -1407,6 +1432,8 @@ struct gmg_solver {
     pat_un = env_int("GMG_PAT_UN", 9);
     pat_wgs = std::max(1, env_int("GMG_PAT_WGS", 2048));
     pat_shared = env_int("GMG_PAT_SHARED", 1);
+    pat_defer = env_int("GMG_PAT_DEFER", 1);
+    pat_dinv = env_int("GMG_PAT_DINV", 1);
     pat_rb = env_int("GMG_PAT_RB", 3) >= 9 ? 9 : 3;
     tile = kTile;
   }

@@ -88,6 +88,8 @@ struct StreamArgs2 {
   const double *b;     // RESID: b ; sweep: r_old (row-wise)
   double *x2;          // sweep / ADDTO: x
   double *s_out;       // ONEG sweep and *_S epilogues: s_new = omega*(dinv.*r_new)
+  int xmode;           // sells_kernel sweeps only: see SellSArgs::xmode
+  int dinv_from_table; // sells_kernel sweeps only: the level's dinv is 1/diag of this very matrix
 };
 
 template <int EPI, typename PtrT, int TILE, bool ONEG, bool EMIT_S>
@@ -618,11 +620,13 @@ struct SellSArgs {
   const PatEntry *tab;      // [np * nu], nu = 3 * nruns ; the last pattern is empty
   const int32_t *run_off;   // [nruns] first offset of each run (elements)
   int np, nruns;            // nruns is a multiple of the kernel's RB
-  int minoff, maxoff;       // over all runs (maxoff includes the +2)
+  int minoff, maxoff;       // smallest / largest first offset of a run
   int64_t nrows, ncols;
   int nslices;
   int x_zero;
+  int xmode;                // sweep: 0 x += s_k ; 1 x untouched (deferred) ; 2 x = (x + s_{k-1}) + s_k, s_{k-1} read from s_out
   int xcd_remap;
+  const double *pdinv;      // [np] 1/diag of each pattern (Jacobi inverse diagonal without its 8 B/row stream), or nullptr
   const double *x;
   const double *dinv;
   double omega;
@@ -667,10 +671,12 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
   // row-wise operands of a slice ("head"): requested one slice ahead, so that their HBM latency is
   // covered by the previous slice's taps; the gathers do not depend on them (shared offsets).
   int pid_n = a.np - 1;
-  double e0_n = 0.0, e1_n = 0.0, e2_n = 0.0, dr_n = 0.0;
+  double e0_n = 0.0, e1_n = 0.0, e2_n = 0.0, dr_n = 0.0, sp_n = 0.0;
+  const int xmode = a.xmode;
+  const bool tab_dinv = a.pdinv != nullptr;
   auto load_head = [&](int slice) {
     const int64_t row = (int64_t)slice * 64 + lane;
-    pid_n = a.np - 1; e0_n = e1_n = e2_n = dr_n = 0.0;
+    pid_n = a.np - 1; e0_n = e1_n = e2_n = dr_n = sp_n = 0.0;
     if (slice < s_end && row < a.nrows) {
       pid_n = (int)a.rowpid[row];
       if (EPI == EPI_SUB) e0_n = a.y[row];
@@ -679,20 +685,25 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       else if (EPI == EPI_SWEEP) {
         e0_n = a.b[row];
         e1_n = xg[row];
-        e2_n = a.x_zero ? 0.0 : a.x2[row];
-        dr_n = dinv[row];
+        if (xmode != 1) e2_n = a.x_zero ? 0.0 : a.x2[row];
+        if (xmode == 2) sp_n = a.s_out[row];               // s_{k-1}, about to be overwritten by s_{k+1}
+        if (!tab_dinv) dr_n = dinv[row];
       }
     }
   };
   load_head(s_begin + wave);
+  double *s_dinv = reinterpret_cast<double *>(s_msk + tot + (tot & 1));   // [np]
   for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
+  if (EPI == EPI_SWEEP && tab_dinv)
+    for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
   __syncthreads();
 
   for (int slice = s_begin + wave; slice < s_end; slice += wpb) {
     const int row0 = slice * 64;
     const int64_t row = (int64_t)row0 + lane;
     const int pid = pid_n;
-    const double e0 = e0_n, e1 = e1_n, e2 = e2_n, dinv_row = dr_n;
+    const double e0 = e0_n, e1 = e1_n, e2 = e2_n, sp = sp_n;
+    const double dinv_row = (EPI == EPI_SWEEP && tab_dinv) ? s_dinv[pid] : dr_n;
     // slices whose windows leave [0,ncols) clamp their addresses (the clamped entries have zero coefficients)
     const bool edge = (row0 + a.minoff < 0) || (row0 + 65 + a.maxoff > last);
     const uint32_t row8 = 8u * (uint32_t)row;
@@ -737,7 +748,8 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       else if (EPI == EPI_RESID) a.y[row] = e0 - s;
       else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
       else {
-        a.x2[row] = e2 + e1;
+        if (xmode == 0) a.x2[row] = e2 + e1;               // x += s_k
+        else if (xmode == 2) a.x2[row] = (e2 + sp) + e1;   // the deferred x += s_{k-1}, then x += s_k: same two roundings
         const double rn = e0 - s;
         a.y[row] = rn;
         a.s_out[row] = omega * (dinv_row * rn);
