@@ -746,12 +746,14 @@ struct gmg_solver {
     a.rowpid = M.rowpid; a.tab = M.ptab; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
     a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff;
     a.xmode = a2.xmode; a.pdinv = (EPI == EPI_SWEEP && a2.dinv_from_table) ? M.pdinv : nullptr;
-    a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
+    const int nsl = (int)((M.nrows + kSellsRows - 1) / kSellsRows);
+    a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl; a.xcd_remap = xcd_remap;
     a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
-    const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
-    const int nwg = std::max(1, std::min((M.nslices + wpb - 1) / wpb, pat_wgs));
+    const int wpb = sell_block > 0 ? sell_block / 64 : (nsl >= 256 * 32 ? 4 : 1);
+    const int nwg = std::max(1, std::min((nsl + wpb - 1) / wpb, pat_wgs));
     const size_t lds = (size_t)M.pat_np * 3 * M.pat_nruns * 12 + 8 + (size_t)M.pat_np * 8;
     if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
+    else if (pat_rb == 1) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 1>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
     else hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
     HIP_CHECK(hipGetLastError());
   }
@@ -1434,7 +1436,7 @@ struct gmg_solver {
     pat_shared = env_int("GMG_PAT_SHARED", 1);
     pat_defer = env_int("GMG_PAT_DEFER", 1);
     pat_dinv = env_int("GMG_PAT_DINV", 1);
-    pat_rb = env_int("GMG_PAT_RB", 3) >= 9 ? 9 : 3;
+    pat_rb = env_int("GMG_PAT_RB", 3); pat_rb = pat_rb >= 9 ? 9 : (pat_rb <= 1 ? 1 : 3);
     tile = kTile;
   }
   // inv_diag = 1 ./ diag(A) (JacobiLinearSolvers.jl:20-23); needs the CSR stream of A (before drop_csr_stream)

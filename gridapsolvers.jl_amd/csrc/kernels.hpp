@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kBlock) void sellp_kernel(SellPArgs a)
 // a per-entry mask clears the high word of the gathered value so that the product stays an exact zero
 // even for a non-finite x).  U is covered by runs of 3 consecutive offsets (o,o+1,o+2).  Per run a
 // lane loads x[row+o] once; x[row+o+1] and x[row+o+2] are its right neighbours' values, fetched with
-// DPP wave shifts (lanes 62/63 take theirs from a 2-lane tail load).  A 27-point operator needs 9+9
+// DPP wave shifts (a slice is 62 rows: lanes 62/63 only carry the halo).  A 27-point operator needs 9+9
 // load instructions per 64 rows instead of 27, which is what bounded the generic pattern kernel
 // (L1 line traffic of the overlapping gathers).  Rows are still summed in ascending column order.
 // ---------------------------------------------------------------------------
@@ -648,6 +648,10 @@ __device__ __forceinline__ double bcast_lane(double v, int l)
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+// A slice is kSellsRows = 62 rows: the 64 lanes load x[row0+o .. row0+o+63], lanes 0..61 own a row and find their
+// two right neighbours inside the wave, lanes 62/63 only carry the halo (no separate tail loads: 9 gather
+// instructions per slice for a 27-point operator).
+constexpr int kSellsRows = 62;
 template <int EPI, bool ONEG, int RB>
 __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 {
@@ -675,9 +679,9 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
   const int xmode = a.xmode;
   const bool tab_dinv = a.pdinv != nullptr;
   auto load_head = [&](int slice) {
-    const int64_t row = (int64_t)slice * 64 + lane;
+    const int64_t row = (int64_t)slice * kSellsRows + lane;
     pid_n = a.np - 1; e0_n = e1_n = e2_n = dr_n = sp_n = 0.0;
-    if (slice < s_end && row < a.nrows) {
+    if (slice < s_end && lane < kSellsRows && row < a.nrows) {
       pid_n = (int)a.rowpid[row];
       if (EPI == EPI_SUB) e0_n = a.y[row];
       else if (EPI == EPI_RESID) e0_n = a.b[row];
@@ -699,28 +703,22 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
   __syncthreads();
 
   for (int slice = s_begin + wave; slice < s_end; slice += wpb) {
-    const int row0 = slice * 64;
+    const int row0 = slice * kSellsRows;
     const int64_t row = (int64_t)row0 + lane;
     const int pid = pid_n;
     const double e0 = e0_n, e1 = e1_n, e2 = e2_n, sp = sp_n;
     const double dinv_row = (EPI == EPI_SWEEP && tab_dinv) ? s_dinv[pid] : dr_n;
     // slices whose windows leave [0,ncols) clamp their addresses (the clamped entries have zero coefficients)
-    const bool edge = (row0 + a.minoff < 0) || (row0 + 65 + a.maxoff > last);
+    const bool edge = (row0 + a.minoff < 0) || (row0 + 63 + a.maxoff > last);
     const uint32_t row8 = 8u * (uint32_t)row;
     double s = 0.0;
-    double A[RB], B[RB];
+    double A[RB];
     auto gather = [&](int r0) {
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         const int o = a.run_off[r0 + q];                   // uniform: scalar load
-        if (!edge) {
-          const double *xo = xg + o;
-          A[q] = ld_off(xo, row8);
-          B[q] = (lane < 2) ? ld_off(xo + 64, row8) : 0.0;
-        } else {
-          A[q] = xg[min(max((int)row + o, 0), last)];
-          B[q] = (lane < 2) ? xg[min(max((int)row + 64 + o, 0), last)] : 0.0;
-        }
+        if (!edge) A[q] = ld_off(xg + o, row8);
+        else A[q] = xg[min(max((int)row + o, 0), last)];
       }
     };
     gather(0);
@@ -731,10 +729,9 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         double cur = A[q];
-        const double bq = B[q];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          if (t > 0) cur = wave_shl1(cur, bcast_lane(bq, t - 1));
+          if (t > 0) cur = wave_shl1(cur, 0.0);            // lanes 62/63 receive junk: they own no row
           const int j = (r0 + q) * 3 + t;
           const double g = __hiloint2double(__double2hiint(cur) & (int)tm[j], __double2loint(cur));
           s = s + tv[j] * g;
@@ -742,7 +739,7 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       }
       if (r0 + RB < a.nruns) gather(r0 + RB);
     }
-    if (row < a.nrows) {
+    if (lane < kSellsRows && row < a.nrows) {
       if (EPI == EPI_SET) a.y[row] = s;
       else if (EPI == EPI_SUB) a.y[row] = e0 - s;
       else if (EPI == EPI_RESID) a.y[row] = e0 - s;

@@ -7,7 +7,7 @@ OUT=$ROOTDIR/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $ROOTDIR/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o bench -- $CMD > $OUT/write.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/trace.log 2>&1
+timeout -k 5 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o bench -- $CMD > $OUT/fetch.log 2>&1
+timeout -k 5 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o bench -- $CMD > $OUT/write.log 2>&1
 find $OUT -type f | head -50
