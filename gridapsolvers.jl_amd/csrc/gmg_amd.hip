@@ -402,6 +402,8 @@ struct gmg_solver {
 
   // profiling of the fused sweep
   int prof_level = -1;
+  int prof_stride = 8;          // GMG_PROF_STRIDE
+  uint64_t prof_seq = 0;
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
   double prof_ms = 0.0;
@@ -1033,7 +1035,9 @@ struct gmg_solver {
   {
     Level &L = lev[l];
     if (comm.nranks > 1) begin_exchange(l, const_cast<double *>(s_old ? s_old : r_old));
-    const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();
+    // HIP events around every prof_stride-th sweep launch of the profiled level: an event pair costs ~4 us of
+    // stream time, timing every launch would slow the solve it measures by > 10 %
+    const bool prof = (l == prof_level) && (prof_seq++ % (uint64_t)prof_stride == 0) && prof_used + 2 <= prof_ev.size();
     if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
     {
       StreamArgs2 a = base_args1(L.A);
@@ -1434,6 +1438,7 @@ struct gmg_solver {
     pat_un = env_int("GMG_PAT_UN", 9);
     pat_wgs = std::max(1, env_int("GMG_PAT_WGS", 2048));
     pat_shared = env_int("GMG_PAT_SHARED", 1);
+    prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
     pat_defer = env_int("GMG_PAT_DEFER", 1);
     pat_dinv = env_int("GMG_PAT_DINV", 1);
     pat_rb = env_int("GMG_PAT_RB", 3); pat_rb = pat_rb >= 9 ? 9 : (pat_rb <= 1 ? 1 : 3);
