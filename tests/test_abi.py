@@ -110,3 +110,19 @@ def test_header_is_plain_c(tmp_path):
                            "-L", libdir, "-l:libgmgamd.so", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.split()[0] == "100", (out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_plain_c_program_drives_the_abi(tmp_path):
+    """tests/c/abi_smoke.c: the boundary used from C99 without Python or torch in the process -- 1-D Poisson,
+    3-level GMG inside CG, checked against the Thomas algorithm inside the program."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "gridapsolvers.jl_amd")
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lgmgamd", "-lm"])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = libdir + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
