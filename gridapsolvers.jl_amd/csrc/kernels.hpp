@@ -636,11 +636,11 @@ struct SellSArgs {
   double *s_out;
 };
 
-// lane i <- lane i+1 ; lane 63 <- `tail`
-__device__ __forceinline__ double wave_shl1(double v, double tail)
+// lane i <- lane i+1 ; lane 63 <- 0 (bound_ctrl: no separate initialisation of the destination)
+__device__ __forceinline__ double wave_shl1(double v)
 {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(tail), __double2loint(v), 0x130, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(tail), __double2hiint(v), 0x130, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double bcast_lane(double v, int l)
@@ -708,17 +708,14 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
     const int pid = pid_n;
     const double e0 = e0_n, e1 = e1_n, e2 = e2_n, sp = sp_n;
     const double dinv_row = (EPI == EPI_SWEEP && tab_dinv) ? s_dinv[pid] : dr_n;
-    // slices whose windows leave [0,ncols) clamp their addresses (the clamped entries have zero coefficients)
-    const bool edge = (row0 + a.minoff < 0) || (row0 + 63 + a.maxoff > last);
-    const uint32_t row8 = 8u * (uint32_t)row;
     double s = 0.0;
     double A[RB];
     auto gather = [&](int r0) {
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         const int o = a.run_off[r0 + q];                   // uniform: scalar load
-        if (!edge) A[q] = ld_off(xg + o, row8);
-        else A[q] = xg[min(max((int)row + o, 0), last)];
+        // column index clamped to [0,ncols) (the clamped entries have zero coefficients); uniform base + 32-bit lane offset
+        A[q] = ld_off(xg, 8u * (uint32_t)min(max((int)row + o, 0), last));
       }
     };
     gather(0);
@@ -731,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
         double cur = A[q];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          if (t > 0) cur = wave_shl1(cur, 0.0);            // lanes 62/63 receive junk: they own no row
+          if (t > 0) cur = wave_shl1(cur);                 // lanes 62/63 receive junk: they own no row
           const int j = (r0 + q) * 3 + t;
           const double g = __hiloint2double(__double2hiint(cur) & (int)tm[j], __double2loint(cur));
           s = s + tv[j] * g;
