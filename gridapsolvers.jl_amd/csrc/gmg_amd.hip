@@ -394,6 +394,8 @@ struct gmg_solver {
   int pat_un = 9;       // GMG_PAT_UN: gathers in flight per lane in sellp_kernel
   int pat_wgs = 2048;   // GMG_PAT_WGS: resident workgroups of the persistent sellp launch
   int pat_rb = 3;       // GMG_PAT_RB: runs (of 3 offsets) loaded per batch in sells_kernel (3 or 9)
+  int pat_small_wpb = 4;   // GMG_PAT_SMALL_WPB: waves per workgroup of sells_kernel on levels with < 8192 slices (table staging amortised)
+  int pat_small_wpb2 = 1;  // GMG_PAT_SMALL_WPB2: the same for sellp_kernel
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
   int pat_dinv = 1;     // GMG_PAT_DINV: Jacobi inverse diagonal from the pattern table instead of its vector
   int pat_shared = 1;   // GMG_PAT_SHARED: shared-offset (stencil) form when the offsets are row-relative
@@ -751,7 +753,7 @@ struct gmg_solver {
     const int nsl = (int)((M.nrows + kSellsRows - 1) / kSellsRows);
     a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl; a.xcd_remap = xcd_remap;
     a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
-    const int wpb = sell_block > 0 ? sell_block / 64 : (nsl >= 256 * 32 ? 4 : 1);
+    const int wpb = sell_block > 0 ? sell_block / 64 : (nsl >= 256 * 32 ? 4 : pat_small_wpb);
     const int nwg = std::max(1, std::min((nsl + wpb - 1) / wpb, pat_wgs));
     const size_t lds = (size_t)M.pat_np * 3 * M.pat_nruns * 12 + 8 + (size_t)M.pat_np * 8;
     if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
@@ -769,7 +771,7 @@ struct gmg_solver {
     a.nrows = M.nrows; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
     a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
     // persistent launch: the pattern table is staged into LDS once per workgroup
-    const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
+    const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : pat_small_wpb2);
     const int nwg = std::max(1, std::min((M.nslices + wpb - 1) / wpb, pat_wgs));
     const size_t lds = (size_t)M.pat_np * M.pat_w * 12 + (size_t)M.pat_np * 4;
     const dim3 g(nwg), b(64 * wpb);
@@ -1440,6 +1442,8 @@ struct gmg_solver {
     pat_shared = env_int("GMG_PAT_SHARED", 1);
     prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
     pat_defer = env_int("GMG_PAT_DEFER", 1);
+    pat_small_wpb = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB", 4)));
+    pat_small_wpb2 = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB2", 1)));
     pat_dinv = env_int("GMG_PAT_DINV", 1);
     pat_rb = env_int("GMG_PAT_RB", 3); pat_rb = pat_rb >= 9 ? 9 : (pat_rb <= 1 ? 1 : 3);
     tile = kTile;
