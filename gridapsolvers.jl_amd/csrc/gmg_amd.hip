@@ -224,6 +224,10 @@ struct Smoother {
 };
 
 struct Level {
+  // s = omega*(Dinv*r) already written into sbuf[0] by the kernel that produced r (restriction / r -= A dx)
+  bool s0_ready = false;
+  const double *s0_src = nullptr;
+  double s0_omega = 0.0;
   HostCSR hA, hP, hR;
   bool hasA = false, hasP = false, hasR = false;
   DevCSR A, P, R;
@@ -396,6 +400,7 @@ struct gmg_solver {
   int pat_rb = 3;       // GMG_PAT_RB: runs (of 3 offsets) loaded per batch in sells_kernel (3 or 9)
   int pat_small_wpb = 4;   // GMG_PAT_SMALL_WPB: waves per workgroup of sells_kernel on levels with < 8192 slices (table staging amortised)
   int pat_small_wpb2 = 1;  // GMG_PAT_SMALL_WPB2: the same for sellp_kernel
+  int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
   int pat_dinv = 1;     // GMG_PAT_DINV: Jacobi inverse diagonal from the pattern table instead of its vector
   int pat_shared = 1;   // GMG_PAT_SHARED: shared-offset (stencil) form when the offsets are row-relative
@@ -479,6 +484,7 @@ struct gmg_solver {
       L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
       L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pre.built = L.post.built = false;
+      L.s0_ready = false;
     }
     d_Ainv = d_partials = d_scalars = nullptr;
     d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr;
@@ -1002,16 +1008,19 @@ struct gmg_solver {
     return a;
   }
   // y = M x
-  void spmv_set(const DevCSR &M, const double *x, double *y)
+  // emit_s/emit_dinv/emit_omega: pattern layouts can also write s = omega*(Dinv*y) for the smoothing pass that consumes y
+  void spmv_set(const DevCSR &M, const double *x, double *y, double *emit_s = nullptr, const double *emit_dinv = nullptr, double emit_omega = 0.0)
   {
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y;
+    if (emit_s && M.pat) { a.s_out = emit_s; a.dinv = emit_dinv; a.omega = emit_omega; }
     if (M.sell) { launch_sell<EPI_SET, false>(M, a); return; }
     launch_stream1<EPI_SET, false, false>(M, a);
   }
   // y -= M x
-  void spmv_sub(const DevCSR &M, const double *x, double *y)
+  void spmv_sub(const DevCSR &M, const double *x, double *y, double *emit_s = nullptr, const double *emit_dinv = nullptr, double emit_omega = 0.0)
   {
     StreamArgs2 a = base_args1(M); a.x = x; a.y = y;
+    if (emit_s && M.pat) { a.s_out = emit_s; a.dinv = emit_dinv; a.omega = emit_omega; }
     if (M.sell) { launch_sell<EPI_SUB, false>(M, a); return; }
     launch_stream1<EPI_SUB, false, false>(M, a);
   }
@@ -1189,11 +1198,21 @@ struct gmg_solver {
     spmv_set(lev[l].A, x, y);
     finish_ghost<0>(l, x, y);
   }
-  void apply_A_sub(int l, double *x, double *y)
+  void apply_A_sub(int l, double *x, double *y, const Smoother *next = nullptr)
   {
     begin_exchange(l, x);
-    spmv_sub(lev[l].A, x, y);
+    Level &L = lev[l];
+    // the smoothing pass that follows starts from s = omega*(Dinv*y): let this kernel write it
+    if (next && emits_s0(L, *next, L.A)) {
+      spmv_sub(L.A, x, y, L.sbuf[0], L.dinv, next->omega);
+      L.s0_ready = true; L.s0_src = y; L.s0_omega = next->omega;
+    } else
+    spmv_sub(L.A, x, y);
     finish_ghost<1>(l, x, y);
+  }
+  bool emits_s0(const Level &L, const Smoother &S, const DevCSR &producer) const
+  {
+    return pat_emit && comm.nranks == 1 && producer.pat && S.kind == SM_JACOBI && one_gather() && S.niter > 0 && L.sbuf[0] != nullptr && L.dinv != nullptr;
   }
   void apply_A_resid(int l, double *x, const double *b, double *y)
   {
@@ -1238,8 +1257,11 @@ struct gmg_solver {
     if (S.kind == SM_JACOBI && one_gather()) {
       // s_0 = w*Dinv*r_in ; then each sweep: x += s_k ; r -= A s_k (in place after the
       // first sweep) ; s_{k+1} = w*Dinv*r
-      hipLaunchKernelGGL(scaled_jacobi_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, S.omega, L.dinv, r_in, L.sbuf[0]);
-      HIP_CHECK(hipGetLastError());
+      if (!(L.s0_ready && L.s0_src == r_in && L.s0_omega == S.omega)) {
+        hipLaunchKernelGGL(scaled_jacobi_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, S.omega, L.dinv, r_in, L.sbuf[0]);
+        HIP_CHECK(hipGetLastError());
+      }
+      L.s0_ready = false;
       const double *cur = r_in;
       double *out = r_internal ? const_cast<double *>(r_in) : L.rbuf[0];
       // shared-offset pattern kernel: x is updated every second sweep with both increments,
@@ -1328,7 +1350,10 @@ struct gmg_solver {
       if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
       exchange(l, r);
       if (comm.nranks > 1 && l + 1 == rep_from) restrict_replicate(l, r, C.rbuf[0]);
-      else
+      else if (l + 1 < nlev - 1 && emits_s0(C, C.pre, L.R)) {
+        spmv_set(L.R, r, C.rbuf[0], C.sbuf[0], C.dinv, C.pre.omega);   // :484 rH = R rh (+ the child's first s)
+        C.s0_ready = true; C.s0_src = C.rbuf[0]; C.s0_omega = C.pre.omega;
+      } else
       spmv_set(L.R, r, C.rbuf[0]);                         // :484 rH = R rh
       // :487 fill!(dxH,0) is implicit: the first sweep below / the coarse solve write dxH
       const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
@@ -1343,7 +1368,7 @@ struct gmg_solver {
         HIP_CHECK(hipGetLastError());
       } else
       spmv_addto(L.P, C.x, L.dx, x);                       // :491,494 dxh = P dxH ; xh += dxh
-      apply_A_sub(l, L.dx, r);                             // :495-496 rh -= Ah dxh
+      apply_A_sub(l, L.dx, r, &L.post);                    // :495-496 rh -= Ah dxh (+ the post-smoother's first s)
     }
     r = smooth(l, L.post, x, r, false);                    // :499
     L.rcur = r;
@@ -1442,6 +1467,7 @@ struct gmg_solver {
     pat_shared = env_int("GMG_PAT_SHARED", 1);
     prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
     pat_defer = env_int("GMG_PAT_DEFER", 1);
+    pat_emit = env_int("GMG_PAT_EMIT", 1);
     pat_small_wpb = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB", 4)));
     pat_small_wpb2 = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB2", 1)));
     pat_dinv = env_int("GMG_PAT_DINV", 1);

@@ -583,8 +583,8 @@ __global__ __launch_bounds__(kBlock) void sellp_kernel(SellPArgs a)
       }
     }
     if (valid) {
-      if (EPI == EPI_SET) a.y[row] = s;
-      else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+      if (EPI == EPI_SET) { a.y[row] = s; if (a.s_out) a.s_out[row] = omega * (dinv[row] * s); }      // optional s emission, see sells_kernel
+      else if (EPI == EPI_SUB) { const double yn = e0 - s; a.y[row] = yn; if (a.s_out) a.s_out[row] = omega * (dinv[row] * yn); }
       else if (EPI == EPI_RESID) a.y[row] = e0 - s;
       else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
       else {
@@ -737,8 +737,10 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       if (r0 + RB < a.nruns) gather(r0 + RB);
     }
     if (lane < kSellsRows && row < a.nrows) {
-      if (EPI == EPI_SET) a.y[row] = s;
-      else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+      // non-sweep epilogues may also emit s = omega*(Dinv*y) for the smoothing pass that follows (saves its
+      // scaled_jacobi launch): requested by passing s_out / dinv / omega
+      if (EPI == EPI_SET) { a.y[row] = s; if (a.s_out) a.s_out[row] = omega * (dinv[row] * s); }
+      else if (EPI == EPI_SUB) { const double yn = e0 - s; a.y[row] = yn; if (a.s_out) a.s_out[row] = omega * (dinv[row] * yn); }
       else if (EPI == EPI_RESID) a.y[row] = e0 - s;
       else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
       else {

@@ -1,7 +1,7 @@
 """Kernel-variant timing harness (GPU box): python tools_tune.py  -> one line per variant."""
 import json, os, subprocess, sys
 VARIANTS = json.loads(os.environ.get("TUNE_VARIANTS", "[]")) or [dict()]
-KEYS = ("GMG_ONE_GATHER", "GMG_XCD_REMAP", "GMG_LANES_LOG2", "GMG_NT", "GMG_SELL", "GMG_SELL_UN", "GMG_SELL_BLOCK", "GMG_SELL_MAXPAD", "GMG_VDICT", "GMG_IDX16", "GMG_PATTERN", "GMG_PAT_UN", "GMG_PAT_WGS", "GMG_PAT_DBG", "GMG_PAT_SHARED", "GMG_PAT_RB", "GMG_PAT_DEFER", "GMG_PAT_DINV", "GMG_PAT_SMALL_WPB", "GMG_PAT_SMALL_WPB2")
+KEYS = ("GMG_ONE_GATHER", "GMG_XCD_REMAP", "GMG_LANES_LOG2", "GMG_NT", "GMG_SELL", "GMG_SELL_UN", "GMG_SELL_BLOCK", "GMG_SELL_MAXPAD", "GMG_VDICT", "GMG_IDX16", "GMG_PATTERN", "GMG_PAT_UN", "GMG_PAT_WGS", "GMG_PAT_DBG", "GMG_PAT_SHARED", "GMG_PAT_RB", "GMG_PAT_DEFER", "GMG_PAT_DINV", "GMG_PAT_SMALL_WPB", "GMG_PAT_SMALL_WPB2", "GMG_PAT_EMIT")
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import numpy as np, torch
