@@ -1420,7 +1420,10 @@ struct gmg_solver {
   {
     const int64_t n = lev[0].n;
     if (kind == 1) gmg_solve_dev(z, r, known_res0);
-    else if (kind == 2) {
+    else if (kind == 3) {
+      // LinearSolverFromSmoother(pre_smoothers[1]): x = 0 ; r = copy(b) ; solve!(x,smoother,r)  (LinearSolverFromSmoothers.jl:44-50)
+      smooth(0, lev[0].pre, z, r, true);
+    } else if (kind == 2) {
       hipLaunchKernelGGL(jacobi_apply_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, lev[0].dinv, r, z);
       HIP_CHECK(hipGetLastError());
     } else copy(z, r, n);
@@ -2331,7 +2334,7 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
     check_ready(h);
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
-    REQUIRE(use_precond >= 0 && use_precond <= 2, GMG_ERR_INVALID, "use_precond must be 0, 1 or 2");
+    REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
     gmg_solver &S = *h;
     Level &L0 = S.lev[0];
     const int64_t n = L0.n;
@@ -2356,7 +2359,7 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
     check_ready(h);
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(m0 >= 1 && m_add >= 1 && maxiter >= 0, GMG_ERR_INVALID, "bad FGMRES sizes");
-    REQUIRE(use_precond >= 0 && use_precond <= 2, GMG_ERR_INVALID, "use_precond must be 0, 1 or 2");
+    REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
     gmg_solver &S = *h;
     Level &L0 = S.lev[0];
     const int64_t n = L0.n;

@@ -34,7 +34,7 @@ from . import abi
 __all__ = [
     "JacobiLinearSolver", "RichardsonSmoother", "PatchSolver", "BlockJacobiSolver", "LUSolver",
     "GMGLinearSolver", "CGSolver", "FGMRESSolver", "ConvergenceLog", "PatchProlongationOperator",
-    "BlockDiagonalSolver", "BlockTriangularSolver", "LinearSystemBlock", "MatrixBlock",
+    "BlockDiagonalSolver", "BlockTriangularSolver", "LinearSystemBlock", "MatrixBlock", "LinearSolverFromSmoother",
     "symbolic_setup", "numerical_setup", "numerical_setup_", "solve_", "mul_",
     "SOLVER_CONVERGED_ATOL", "SOLVER_CONVERGED_RTOL", "SOLVER_DIVERGED_MAXITER", "SOLVER_DIVERGED_BREAKDOWN",
 ]
@@ -88,6 +88,15 @@ class RichardsonSmoother:
         if not isinstance(M, (JacobiLinearSolver, PatchSolver)):
             raise TypeError("RichardsonSmoother: M must be JacobiLinearSolver, PatchSolver or BlockJacobiSolver")
         self.M, self.niter, self.omega = M, int(niter), float(omega)
+
+
+class LinearSolverFromSmoother:
+    """LinearSolverFromSmoother(smoother) -- LinearSolverFromSmoothers.jl:2-4: x = 0; r = copy(b); solve!(x,smoother,r)."""
+
+    def __init__(self, smoother):
+        if not isinstance(smoother, RichardsonSmoother):
+            raise TypeError("smoother must be a RichardsonSmoother")
+        self.smoother = smoother
 
 
 class ConvergenceLog:
@@ -574,9 +583,15 @@ class _KrylovNumericalSetup:
         if isinstance(P, GMGLinearSolver):
             self.pc_kind, gmg = 1, P
         elif isinstance(P, tuple) and len(P) == 2 and isinstance(P[1], GMGLinearSolver) and \
-                (P[0] is None or isinstance(P[0], JacobiLinearSolver)):
-            # (None | JacobiLinearSolver(), gmg): Krylov on the handle's finest matrix with Pl = nothing / Jacobi
-            self.pc_kind, gmg = (0 if P[0] is None else 2), P[1]
+                (P[0] is None or isinstance(P[0], (JacobiLinearSolver, LinearSolverFromSmoother))):
+            # (None | JacobiLinearSolver() | LinearSolverFromSmoother(gmg.pre_smoothers[0]), gmg):
+            # Krylov on the handle's finest matrix with Pl = nothing / Jacobi / the finest pre-smoother
+            if isinstance(P[0], LinearSolverFromSmoother):
+                if P[0].smoother is not P[1].pre_smoothers[0]:
+                    raise ValueError("LinearSolverFromSmoother must wrap the GMG's finest pre-smoother")
+                self.pc_kind, gmg = 3, P[1]
+            else:
+                self.pc_kind, gmg = (0 if P[0] is None else 2), P[1]
         else:
             raise NotImplementedError("the device Krylov solvers take a GMGLinearSolver preconditioner "
                                       "(or (None|JacobiLinearSolver(), gmg) to reuse its finest matrix)")

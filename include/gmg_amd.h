@@ -141,7 +141,9 @@ GMG_API int gmg_apply(gmg_handle_t h, const double *b, double *x, int memspace,
                       gmg_result *res, double *hist, int hist_cap);
 /* solve!(x,ns::CGNumericalSetup,b) with Pl = this GMG: Krylov/CGSolvers.jl:73-120.
  * use_precond: 0 = Pl nothing, 1 = this GMG, 2 = JacobiLinearSolver() on the finest
- * matrix (the reference's CGSolver(JacobiLinearSolver())).  x = initial guess on entry. */
+ * matrix (the reference's CGSolver(JacobiLinearSolver())), 3 = LinearSolverFromSmoother(finest
+ * pre-smoother) (LinearSolverFromSmoothers.jl:44-50, test/LinearSolvers/SmoothersTests.jl).
+ * x = initial guess on entry. */
 GMG_API int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace,
                          int maxiter, double atol, double rtol, int flexible, int use_precond,
                          gmg_result *res, double *hist, int hist_cap);

@@ -694,3 +694,24 @@ def test_row_pattern_unsorted_and_duplicate_columns(S, po, orc, pkg):
     ns.op_apply(0, abi.OP_A, x, y)
     assert np.array_equal(y, orc.spmv(A, x))
     ns.close()
+
+
+@pytest.mark.parametrize("nc", [(8, 8), (8, 8, 8), (32, 32, 32)])
+def test_reference_smoothers_test_on_device(S, po, orc, hierarchy, nc):
+    """test/LinearSolvers/SmoothersTests.jl:13-43,58-74 on the device: CGSolver(LinearSolverFromSmoother(
+    RichardsonSmoother(JacobiLinearSolver(),5,2/3)); rtol=1e-8), u = x1 + x2, `@test E < 1.e-8` -- the reference's own
+    known-answer criterion -- plus parity with the oracle's literal execution of the same solver."""
+    H = hierarchy(nc, 2)
+    sm = S.RichardsonSmoother(S.JacobiLinearSolver(), 5, 2.0 / 3.0)
+    gmg = S.GMGLinearSolver(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[sm], post_smoothers=[sm], maxiter=1)
+    solver = S.CGSolver((S.LinearSolverFromSmoother(sm), gmg), maxiter=1000, atol=1e-12, rtol=1e-8)
+    ns = setup(S, solver, H["mats"][0])
+    b = po.dirichlet_lift_rhs(nc, 1)
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    assert solver.log.flag in (S.SOLVER_CONVERGED_ATOL, S.SOLVER_CONVERGED_RTOL)
+    assert po.l2_error_sq(nc, 1, x) < 1.0e-8                              # SmoothersTests.jl:43
+    xo, nit, flag, hist = orc.cg_smoother_solve(H["mats"][0], b, 5, 2.0 / 3.0, maxiter=1000, atol=1e-12, rtol=1e-8)
+    assert solver.log.num_iters == nit
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6, atol=1e-9 * hist[0])
+    assert rel_err(x, xo) <= 1e-8
