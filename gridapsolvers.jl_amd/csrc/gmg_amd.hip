@@ -2378,6 +2378,42 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
   });
 }
 
+int gmg_richardson_solve(gmg_handle_t h, const double *b, double *x, int memspace, double omega, int maxiter, double atol,
+                         double rtol, int use_precond, gmg_result *res, double *hist, int hist_cap)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
+    REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
+    REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
+    gmg_solver &S = *h;
+    const int64_t n = S.lev[0].n;
+    const double *db = S.in_vec(b, n, memspace, S.st_b);
+    const bool dist = S.comm.nranks > 1;
+    double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
+    if (memspace == GMG_MEM_HOST || dist)
+      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
+    double *z = S.cg_z, *r = S.cg_r;
+    ConvLog log;
+    log.configure(maxiter, atol, rtol);
+    const int grid = gmg_solver::grid_for(n);
+    S.apply_A_resid(0, dx, db, r);                         // RichardsonLinearSolvers.jl:84-85
+    double resn = S.norm(n, r);
+    bool done = log.init(resn);                            // :86
+    while (!done) {
+      const double *dir = r;
+      if (use_precond) { S.krylov_precond(use_precond, z, r, resn); dir = z; }   // :89
+      hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, omega, dir, dx);   // :90,98 x .+= w .* z
+      HIP_CHECK(hipGetLastError());
+      S.apply_A_resid(0, dx, db, r);                       // :91-92
+      resn = S.norm(n, r);
+      done = log.update(resn);                             // :93
+    }
+    S.out_vec(x, dx, n, memspace);
+    log.export_to(res, hist, hist_cap, resn);              // :95
+  });
+}
+
 int gmg_op_apply(gmg_handle_t h, int lev, int op, const double *x, double *y, int memspace)
 {
   return guarded(h, [&] {

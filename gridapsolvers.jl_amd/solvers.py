@@ -34,7 +34,7 @@ from . import abi
 __all__ = [
     "JacobiLinearSolver", "RichardsonSmoother", "PatchSolver", "BlockJacobiSolver", "LUSolver",
     "GMGLinearSolver", "CGSolver", "FGMRESSolver", "ConvergenceLog", "PatchProlongationOperator",
-    "BlockDiagonalSolver", "BlockTriangularSolver", "LinearSystemBlock", "MatrixBlock", "LinearSolverFromSmoother",
+    "RichardsonLinearSolver", "BlockDiagonalSolver", "BlockTriangularSolver", "LinearSystemBlock", "MatrixBlock", "LinearSolverFromSmoother",
     "symbolic_setup", "numerical_setup", "numerical_setup_", "solve_", "mul_",
     "SOLVER_CONVERGED_ATOL", "SOLVER_CONVERGED_RTOL", "SOLVER_DIVERGED_MAXITER", "SOLVER_DIVERGED_BREAKDOWN",
 ]
@@ -166,6 +166,17 @@ class CGSolver:
 
     def __init__(self, Pl=None, maxiter=1000, atol=1e-12, rtol=1.0e-6, flexible=False, verbose=0, name="CG"):
         self.Pl, self.flexible = Pl, bool(flexible)
+        self.log = ConvergenceLog(name, maxiter, atol, rtol)
+
+
+class RichardsonLinearSolver:
+    """RichardsonLinearSolver(omega, maxiter; Pl=nothing, rtol=1e-10, atol=1e-6) -- RichardsonLinearSolvers.jl:13-23
+    (scalar omega on the device path)."""
+
+    def __init__(self, omega, maxiter, Pl=None, rtol=1e-10, atol=1e-6, verbose=True, name="RichardsonLinearSolver"):
+        if not np.isscalar(omega):
+            raise NotImplementedError("vector-valued omega is not on the device path")
+        self.omega, self.Pl = float(omega), Pl
         self.log = ConvergenceLog(name, maxiter, atol, rtol)
 
 
@@ -574,7 +585,7 @@ class _KrylovNumericalSetup:
 
     def __init__(self, solver, A, device_id=None):
         self.solver = solver
-        P = solver.Pl if isinstance(solver, CGSolver) else solver.Pr
+        P = solver.Pr if isinstance(solver, FGMRESSolver) else solver.Pl
         if isinstance(P, (BlockDiagonalSolver, BlockTriangularSolver)):
             self.pc_kind = 1
             self.P_ns = BlockNumericalSetup(P, A, device_id)
@@ -603,7 +614,7 @@ def symbolic_setup(solver, A=None):
     """Gridap.Algebra.symbolic_setup(solver, A)."""
     if isinstance(solver, GMGLinearSolver):
         return GMGSymbolicSetup(solver)
-    if isinstance(solver, (CGSolver, FGMRESSolver)):
+    if isinstance(solver, (CGSolver, FGMRESSolver, RichardsonLinearSolver)):
         return _KrylovSymbolicSetup(solver)
     if isinstance(solver, (BlockDiagonalSolver, BlockTriangularSolver)):
         return BlockSymbolicSetup(solver)
@@ -683,6 +694,9 @@ def solve_(x, ns, b):
         if isinstance(s, CGSolver):
             abi.check(g.h, g._lib.gmg_cg_solve(g.h, pb, px, ms, log.maxiter, log.atol, log.rtol, int(s.flexible), ns.pc_kind,
                                                C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
+        elif isinstance(s, RichardsonLinearSolver):
+            abi.check(g.h, g._lib.gmg_richardson_solve(g.h, pb, px, ms, s.omega, log.maxiter, log.atol, log.rtol, ns.pc_kind,
+                                                       C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
         else:
             abi.check(g.h, g._lib.gmg_fgmres_solve(g.h, pb, px, ms, s.m, int(s.restart), s.m_add, log.maxiter,
                                                    log.atol, log.rtol, ns.pc_kind, C.byref(res),

@@ -152,6 +152,11 @@ GMG_API int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspac
 GMG_API int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace,
                              int m, int restart, int m_add, int maxiter, double atol, double rtol,
                              int use_precond, gmg_result *res, double *hist, int hist_cap);
+/* solve!(x,ns::RichardsonLinearNumericalSetup,b): RichardsonLinearSolvers.jl:79-106, scalar omega;
+ * use_precond as in gmg_cg_solve (Pl = nothing / this GMG / Jacobi / the finest pre-smoother). */
+GMG_API int gmg_richardson_solve(gmg_handle_t h, const double *b, double *x, int memspace, double omega,
+                                 int maxiter, double atol, double rtol, int use_precond,
+                                 gmg_result *res, double *hist, int hist_cap);
 
 /* ---- operator-level entry points (duck-typed `mul!` / smoother `solve!`) ------ */
 /* mul!(y,op,x) for op in {A_lev, P_lev, R_lev}: RichardsonSmoothers.jl:94,

@@ -24,7 +24,9 @@
  * test/LinearSolvers/GMGTests.jl asserts nothing.  What IS pinned (see
  * tests/test_oracle.py): the reference's own known-answer criteria
  * test/LinearSolvers/SmoothersTests.jl:43 (E<1e-8), KrylovTests.jl:25
- * (E<1e-6) on the same problem definitions, plus operator identities.
+ * (E<1e-6), RichardsonLinearTests.jl:26 (E<1e-6), BlockDiagonalSolversTests.jl:45
+ * (norm(x1-x)<1e-8), Applications/StokesGMG.jl:166 (residual<1e-7 criterion on a
+ * synthetic saddle point) on the same problem definitions, plus operator identities.
  *
  * Index conventions: 0-based CSR, int64 row pointers, int32 column indices.
  */
@@ -961,4 +963,42 @@ ORC_API void orc_block_destroy(orc_block *B)
   if (!B) return;
   for (int i = 0; i < B->nb; ++i) { free(B->diag[i].inv_diag); band_free(B->diag[i].lu); }
   free(B->off); free(B->diag); free(B->offd); free(B->coeff); free(B->w); free(B->y); free(B);
+}
+
+/* ------------------------------------------------------------------ */
+/* RichardsonLinearSolver(omega,maxiter;Pl): RichardsonLinearSolvers.jl:79-106 */
+/* r .= b ; mul!(r,A,x,-1,1) accumulates entry by entry into r (SparseArrays 5-arg mul!). */
+/* ------------------------------------------------------------------ */
+static void resid_accumulate(i64 n, const i64 *ptr, const i32 *idx, const double *val, const double *x, const double *b, double *r)
+{
+  for (i64 i = 0; i < n; ++i) {
+    double s = b[i];
+    for (i64 k = ptr[i]; k < ptr[i + 1]; ++k) s += val[k] * (x[idx[k]] * -1.0);
+    r[i] = s;
+  }
+}
+ORC_API int orc_richardson_solve(i64 n, const i64 *ptr, const i32 *idx, const double *val, int pc_kind, void *Pl, double omega,
+                                 double *x, const double *b, int maxiter, double atol, double rtol, int *niters, double *hist)
+{
+  double *z = dalloc(n), *r = dalloc(n);
+  orc_log log = { maxiter, atol, rtol, 0, (double *)calloc((size_t)(maxiter > 0 ? maxiter : 0) + 1, sizeof(double)) };
+  resid_accumulate(n, ptr, idx, val, x, b, r);               /* :84-85 */
+  double res = orc_norm(n, r);
+  int done = log_init(&log, res);                            /* :86 */
+  while (!done) {
+    if (pc_kind != ORC_PC_NONE) {                            /* :88-94 */
+      pc_solve(pc_kind, Pl, n, z, r);
+      for (i64 i = 0; i < n; ++i) x[i] += omega * z[i];
+    } else {                                                 /* :97-102 */
+      for (i64 i = 0; i < n; ++i) x[i] += omega * r[i];
+    }
+    resid_accumulate(n, ptr, idx, val, x, b, r);
+    res = orc_norm(n, r);
+    done = log_update(&log, res);
+  }
+  int flag = log_finalize(&log, res);
+  if (niters) *niters = log.num_iters;
+  if (hist) memcpy(hist, log.residuals, (size_t)(log.num_iters + 1) * sizeof(double));
+  free(z); free(r); free(log.residuals);
+  return flag;
 }

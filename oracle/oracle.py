@@ -42,7 +42,7 @@ def lib():
         L.orc_norm.restype = C.c_double
         L.orc_gmg_create.restype = C.c_void_p
         L.orc_block_create.restype = C.c_void_p
-        for name in ("orc_gmg_solve", "orc_cg_solve", "orc_fgmres_solve", "orc_cg_smoother_solve"):
+        for name in ("orc_gmg_solve", "orc_cg_solve", "orc_fgmres_solve", "orc_cg_smoother_solve", "orc_richardson_solve"):
             getattr(L, name).restype = C.c_int
     return _LIB
 
@@ -295,4 +295,17 @@ def cg_smoother_solve(A, b, sm_niter=5, sm_omega=2.0 / 3.0, maxiter=1000, atol=1
     flag = lib().orc_cg_smoother_solve(C.c_int64(n), _p64(A.ptr), _p32(A.idx), _d(A.val), C.c_int(sm_niter),
                                        C.c_double(sm_omega), _d(x), _d(b), C.c_int(maxiter), C.c_double(atol),
                                        C.c_double(rtol), C.byref(nit), _d(hist))
+    return x, nit.value, flag, hist[: nit.value + 1].copy()
+
+
+def richardson_solve(A, b, omega, Pl=None, x0=None, maxiter=1000, atol=1e-6, rtol=1e-10):
+    """solve!(x, RichardsonLinearNumericalSetup, b) -- returns (x, niters, flag, hist).  Defaults: RichardsonLinearSolvers.jl:19."""
+    n = A.shape[0]
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    hist = np.zeros(maxiter + 1)
+    nit = C.c_int(0)
+    kind, pc, _keep = _pc(A, Pl)
+    flag = lib().orc_richardson_solve(C.c_int64(n), _p64(A.ptr), _p32(A.idx), _d(A.val), C.c_int(kind), pc, C.c_double(omega),
+                                      _d(x), _d(b), C.c_int(maxiter), C.c_double(atol), C.c_double(rtol), C.byref(nit), _d(hist))
     return x, nit.value, flag, hist[: nit.value + 1].copy()

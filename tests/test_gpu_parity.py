@@ -715,3 +715,24 @@ def test_reference_smoothers_test_on_device(S, po, orc, hierarchy, nc):
     assert solver.log.num_iters == nit
     np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6, atol=1e-9 * hist[0])
     assert rel_err(x, xo) <= 1e-8
+
+
+@pytest.mark.parametrize("nc", [(8, 8), (8, 8, 8)])
+@pytest.mark.parametrize("pl", ["jacobi", "none", "gmg"])
+def test_reference_richardson_linear_test_on_device(S, po, orc, hierarchy, nc, pl):
+    """test/LinearSolvers/RichardsonLinearTests.jl:14-26,64-73 on the device (`@test E < 1.e-6`), parity with the oracle;
+    Pl = GMG additionally (the Richardson iteration as the outer caller of the V-cycle)."""
+    H = hierarchy(nc, 2)
+    gmg = make_gmg(S, H)
+    P = {"jacobi": (S.JacobiLinearSolver(), gmg), "none": (None, gmg), "gmg": gmg}[pl]
+    solver = S.RichardsonLinearSolver(0.5, 1000, Pl=P, rtol=1e-8)
+    ns = setup(S, solver, H["mats"][0])
+    b = po.dirichlet_lift_rhs(nc, 1)
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    assert po.l2_error_sq(nc, 1, x) < 1.0e-6                              # RichardsonLinearTests.jl:26
+    Po = {"jacobi": "jacobi", "none": None, "gmg": orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)}[pl]
+    xo, nit, flag, hist = orc.richardson_solve(H["mats"][0], b, 0.5, Pl=Po, maxiter=1000, rtol=1e-8)
+    assert solver.log.num_iters == nit and solver.log.flag == flag
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6, atol=1e-9 * hist[0])
+    assert rel_err(x, xo) <= 1e-8

@@ -30,6 +30,17 @@ def test_reference_smoothers_test(po, orc, nc):
 
 
 @pytest.mark.parametrize("nc", [(8, 8), (8, 8, 8)])
+@pytest.mark.parametrize("Pl", ["jacobi", None])
+def test_reference_richardson_linear_test(po, orc, nc, Pl):
+    """test/LinearSolvers/RichardsonLinearTests.jl:14-26,64-73: RichardsonLinearSolver(0.5,1000;Pl=JacobiLinearSolver(),rtol=1e-8)
+    and without preconditioner, u = x1+x2, @test E < 1e-6."""
+    A = po.poisson_matrix(nc, 1)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    x, nit, flag, hist = orc.richardson_solve(A, b, 0.5, Pl=Pl, maxiter=1000, rtol=1e-8)
+    assert po.l2_error_sq(nc, 1, x) < 1.0e-6
+
+
+@pytest.mark.parametrize("nc", [(8, 8), (8, 8, 8)])
 @pytest.mark.parametrize("which", ["fgmres", "fgmres_restart", "cg", "pcg", "fpcg"])
 def test_reference_krylov_tests(po, orc, nc, which):
     """test/LinearSolvers/KrylovTests.jl:12-25,77-90: P = JacobiLinearSolver(), rtol 1e-8, @test E < 1e-6."""
