@@ -35,7 +35,7 @@ using GridapSolvers.SolverInterfaces: ConvergenceLog, SolverTolerances
 using GridapSolvers.LinearSolvers: RichardsonSmoother, JacobiLinearSolver
 
 export HipGMGLinearSolver, HipCGSolver, HipFGMRESSolver, PatchTable, HipPatchProlongation
-export HipBlockTriangularSolver, HipBlockDiagonalSolver, HipBlockFGMRESSolver, block_mul!, block_cg_solve!
+export HipRichardsonLinearSolver, HipBlockTriangularSolver, HipBlockDiagonalSolver, HipBlockFGMRESSolver, block_mul!, block_cg_solve!
 
 const libgmgamd = get(ENV, "LIBGMGAMD", joinpath(@__DIR__, "..", "libgmgamd.so"))
 
@@ -310,7 +310,7 @@ mutable struct HipKrylovNumericalSetup{A,B} <: Gridap.Algebra.NumericalSetup
   P_ns   :: B
 end
 function Gridap.Algebra.numerical_setup(ss::HipKrylovSymbolicSetup, A::AbstractMatrix)
-  P = ss.solver isa HipCGSolver ? ss.solver.Pl : ss.solver.Pr
+  P = ss.solver isa HipFGMRESSolver ? ss.solver.Pr : ss.solver.Pl
   P_ns = numerical_setup(symbolic_setup(P,A),A)                              # CGSolvers.jl:52
   return HipKrylovNumericalSetup(ss.solver, P_ns)
 end
@@ -342,6 +342,31 @@ function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<
     check(h, ccall((:gmg_fgmres_solve, libgmgamd), Cint,
       (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Cint,Cint,Cint,Cint,Float64,Float64,Cint,Ref{GmgResult},Ptr{Float64},Cint),
       h, b, x, GMG_MEM_HOST, s.m, s.restart ? 1 : 0, s.m_add, tols.maxiter, tols.atol, tols.rtol, 1, res, hist, length(hist)))
+  end
+  _fill_log!(s.log, res[], hist)
+  return x
+end
+
+# RichardsonLinearSolver(omega,maxiter;Pl=gmg) on the device: RichardsonLinearSolvers.jl:79-106
+struct HipRichardsonLinearSolver{A} <: Gridap.Algebra.LinearSolver
+  omega :: Float64
+  Pl    :: A
+  log   :: ConvergenceLog{Float64}
+end
+function HipRichardsonLinearSolver(omega::Real, maxiter::Integer, Pl::HipGMGLinearSolver; rtol=1e-10, atol=1e-6, verbose=true, name="Richardson-MI355X")
+  tols = SolverTolerances{Float64}(maxiter=maxiter,atol=atol,rtol=rtol)
+  return HipRichardsonLinearSolver(Float64(omega), Pl, ConvergenceLog(name,tols;verbose=verbose))
+end
+Gridap.Algebra.symbolic_setup(s::HipRichardsonLinearSolver, ::AbstractMatrix) = HipKrylovSymbolicSetup(s)
+function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<:HipRichardsonLinearSolver}, b::Vector{Float64})
+  s, h = ns.solver, ns.P_ns.handle
+  tols = s.log.tols
+  res  = Ref(GmgResult(0,0,0.0,0.0))
+  hist = zeros(tols.maxiter+1)
+  GC.@preserve x b hist begin
+    check(h, ccall((:gmg_richardson_solve, libgmgamd), Cint,
+      (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Float64,Cint,Float64,Float64,Cint,Ref{GmgResult},Ptr{Float64},Cint),
+      h, b, x, GMG_MEM_HOST, s.omega, tols.maxiter, tols.atol, tols.rtol, 1, res, hist, length(hist)))
   end
   _fill_log!(s.log, res[], hist)
   return x
