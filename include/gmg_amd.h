@@ -212,14 +212,16 @@ GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_
 GMG_API int gmg_set_replication(gmg_handle_t h, int lev, const int64_t *own_global_ids, int64_t n_own);
 
 /* ---- measurement --------------------------------------------------------------- */
-/* Bracket every launch of the fused Richardson-Jacobi sweep on `lev` with HIP
- * events on the handle's stream (enable=0 stops).  Read with gmg_get_kernel_stats. */
+/* Bracket launches of the fused Richardson-Jacobi sweep on `lev` with HIP events on the handle's
+ * stream: every GMG_PROF_STRIDE-th launch (default 8; an event pair costs ~4 us of stream time);
+ * enable=0 stops.  Read with gmg_get_kernel_stats. */
 GMG_API int gmg_profile_enable(gmg_handle_t h, int lev, int enable);
 GMG_API int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out);
 /* Algorithmic bytes (SURVEY 8d byte model) of one V-cycle / one CG iteration. */
 GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes);
-/* Storage chosen for A_lev at setup: SELL-64 (vs CSR-stream), 8-bit value dictionary,
- * 16-bit column offsets, bytes streamed per stored nonzero, padding factor. */
+/* Storage chosen for A_lev at setup: *sell = 0 CSR-stream, 1 SELL-64 / SELL-C, 2 SELL-P (row-pattern
+ * dictionary); 8-bit value dictionary, 16-bit column offsets, bytes of matrix stream per stored nonzero,
+ * padding factor. */
 GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
                              double *stream_bytes_per_nnz, double *padding);
 /* Device memory held by the handle, bytes. */
