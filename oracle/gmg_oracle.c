@@ -41,6 +41,18 @@ typedef int32_t i32;
 
 #define ORC_API __attribute__((visibility("default")))
 
+/* liboracle_omp.so (bench.py's cpu_baseline only) is this file compiled with -fopenmp -DORC_OMP: the row loops and the
+ * reductions run on all host cores -- the analogue of the reference under MPI on P ranks.  The checker (liboracle.so)
+ * is always the sequential build: its sums are left-to-right. */
+#ifdef ORC_OMP
+#include <omp.h>
+#define ORC_PFOR _Pragma("omp parallel for schedule(static)")
+#define ORC_PSUM(var) _Pragma("omp parallel for schedule(static) reduction(+:s)")
+#else
+#define ORC_PFOR
+#define ORC_PSUM(var)
+#endif
+
 /* ------------------------------------------------------------------ */
 /* L0 primitives (third-party in the reference)                        */
 /* ------------------------------------------------------------------ */
@@ -50,6 +62,7 @@ typedef int32_t i32;
 ORC_API void orc_spmv(i64 n, const i64 *ptr, const i32 *idx, const double *val,
                       const double *x, double *y)
 {
+  ORC_PFOR
   for (i64 i = 0; i < n; ++i) {
     double s = 0.0;
     for (i64 k = ptr[i]; k < ptr[i + 1]; ++k) s += val[k] * x[idx[k]];
@@ -61,6 +74,7 @@ ORC_API void orc_spmv(i64 n, const i64 *ptr, const i32 *idx, const double *val,
 ORC_API double orc_dot(i64 n, const double *a, const double *b)
 {
   double s = 0.0;
+  ORC_PSUM(s)
   for (i64 i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
 }
@@ -342,6 +356,7 @@ static void smoother_setup(orc_smoother *s, const orc_csr *A)
 /* solve!(x,ns::JacobiNumericalSetup,b): JacobiLinearSolvers.jl:43-47 */
 static void jacobi_apply(const orc_smoother *s, i64 n, double *x, const double *b)
 {
+  ORC_PFOR
   for (i64 i = 0; i < n; ++i) x[i] = s->inv_diag[i] * b[i];
 }
 
@@ -392,9 +407,12 @@ static void richardson_solve(orc_smoother *s, const orc_csr *A, double *x, doubl
   for (i64 i = 0; i < n; ++i) dx[i] = 0.0;               /* :89 */
   while (iter <= s->niter) {                              /* :90 */
     precond_apply(s, A, dx, r);                           /* :91 solve!(dx,Mns,r) */
+    ORC_PFOR
     for (i64 i = 0; i < n; ++i) dx[i] = s->omega * dx[i]; /* :92 */
+    ORC_PFOR
     for (i64 i = 0; i < n; ++i) x[i] = x[i] + dx[i];      /* :93 */
     orc_spmv(n, A->ptr, A->idx, A->val, dx, Adx);         /* :94 */
+    ORC_PFOR
     for (i64 i = 0; i < n; ++i) r[i] = r[i] - Adx[i];     /* :95 */
     iter += 1;
   }
@@ -543,8 +561,10 @@ static void gmg_cycle(orc_gmg *g, int lev, double *xh, double *rh, int ctype)
   for (i64 i = 0; i < nH; ++i) L->dxH[i] = 0.0;                    /* :487 */
   gmg_cycle(g, lev + 1, L->dxH, L->rH, ctype);                     /* :488 */
   apply_prolongation(L, L->dxH, L->dxh);                           /* :491 */
+  ORC_PFOR
   for (i64 i = 0; i < n; ++i) xh[i] = xh[i] + L->dxh[i];           /* :494 */
   orc_spmv(n, L->A.ptr, L->A.idx, L->A.val, L->dxh, L->Adxh);      /* :495 */
+  ORC_PFOR
   for (i64 i = 0; i < n; ++i) rh[i] = rh[i] - L->Adxh[i];          /* :496 */
   if (ctype != ORC_V_CYCLE) {
     /* W: :531-547 ; F: :584-600 (second visit is a V-cycle in F) */
@@ -670,10 +690,13 @@ ORC_API int orc_cg_solve(i64 n, const i64 *ptr, const i32 *idx, const double *va
       pc_solve(pc_kind, Pl, n, z, r);
       beta = gamma; gamma = orc_dot(n, z, r); beta = (gamma - delta) / beta;
     }
+    ORC_PFOR
     for (i64 i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];  /* :101 */
     orc_spmv(n, ptr, idx, val, p, w);                       /* :104 */
     alpha = gamma / orc_dot(n, p, w);                       /* :105 */
+    ORC_PFOR
     for (i64 i = 0; i < n; ++i) x[i] += alpha * p[i];       /* :108 */
+    ORC_PFOR
     for (i64 i = 0; i < n; ++i) r[i] -= alpha * w[i];       /* :109 */
     res = orc_norm(n, r);                                   /* :111 */
     done = log_update(&log, res);                           /* :112 */
@@ -1001,4 +1024,13 @@ ORC_API int orc_richardson_solve(i64 n, const i64 *ptr, const i32 *idx, const do
   if (hist) memcpy(hist, log.residuals, (size_t)(log.num_iters + 1) * sizeof(double));
   free(z); free(r); free(log.residuals);
   return flag;
+}
+
+ORC_API int orc_threads(void)
+{
+#ifdef ORC_OMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
 }

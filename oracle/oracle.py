@@ -25,12 +25,28 @@ _i32p = C.POINTER(C.c_int32)
 _ip = C.POINTER(C.c_int)
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+_VARIANT = "seq"      # "seq": liboracle.so (the checker) ; "omp": liboracle_omp.so (all host cores; bench.py cpu_baseline only)
+
+
+def build(force=False, variant=None):
+    name = "liboracle_omp.so" if (variant or _VARIANT) == "omp" else "liboracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "gmg_oracle.c")
     if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", name])
     return so
+
+
+def set_variant(name):
+    """Switch between the sequential checker and the OpenMP build (objects created before the switch stay on theirs)."""
+    global _VARIANT, _LIB
+    assert name in ("seq", "omp")
+    if name != _VARIANT:
+        _VARIANT, _LIB = name, None
+
+
+def threads():
+    return int(lib().orc_threads())
 
 
 def lib():
