@@ -736,3 +736,47 @@ def test_reference_richardson_linear_test_on_device(S, po, orc, hierarchy, nc, p
     assert solver.log.num_iters == nit and solver.log.flag == flag
     np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6, atol=1e-9 * hist[0])
     assert rel_err(x, xo) <= 1e-8
+
+
+@pytest.mark.parametrize("seed,n,noff", [(1, 1000, 5), (2, 4099, 11), (3, 700, 2), (4, 2500, 30)])
+def test_row_pattern_random_banded_and_circulant(S, po, orc, seed, n, noff):
+    """Row-pattern layouts on matrices that are NOT finite-element stencils: a circulant matrix with random offsets
+    (wrap-around rows have their own patterns; runs of 1-3 offsets, dummy runs padded in), its banded truncation, and a
+    rectangular restriction-like operator (offsets relative to the first column).  Bit-identical to the sequential SpMV."""
+    from gridapsolvers_jl_amd import abi
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    offs = np.unique(np.concatenate([[0], rng.integers(-n // 3, n // 3, size=noff)]))
+    vals = rng.uniform(-1.0, 1.0, offs.size); vals[offs == 0] = 4.0 + offs.size
+    rows = np.repeat(np.arange(n), offs.size)
+    cols = (rows + np.tile(offs, n)) % n
+    Acirc = sp.csr_matrix((np.tile(vals, n), (rows, cols)), shape=(n, n)); Acirc.sum_duplicates(); Acirc.sort_indices()
+    keep = np.abs((rows + np.tile(offs, n)) - cols) == 0            # entries that did not wrap
+    Aband = sp.csr_matrix((np.tile(vals, n)[keep], (rows[keep], cols[keep])), shape=(n, n)); Aband.sort_indices()
+    nc = n // 2
+    prow = np.repeat(np.arange(n), 2); pcol = np.minimum(np.stack([np.arange(n) // 2, np.arange(n) // 2 + 1], 1).ravel(), nc - 1)
+    Pm = sp.csr_matrix((np.tile([0.75, 0.25], n), (prow, pcol)), shape=(n, nc)); Pm.sum_duplicates(); Pm.sort_indices()
+    Ac = sp.identity(nc, format="csr") * 3.0
+    for A in (Acirc, Aband):
+        H = dict(mats=[po.CSR(A.shape, A.indptr, A.indices, A.data), po.CSR(Ac.shape, Ac.indptr, Ac.indices, Ac.data)],
+                 prolongations=[po.CSR(Pm.shape, Pm.indptr, Pm.indices, Pm.data)], restrictions=[None])
+        gmg = S.GMGLinearSolver(H["mats"], H["prolongations"], None, pre_smoothers=jac(S, 2, 2, 0.5), post_smoothers=jac(S, 2, 2, 0.5), maxiter=1)
+        ns = setup(S, gmg, H["mats"][0])
+        assert ns.level_format(0)["layout"] == "SELL-P"
+        x = seeded(n, 10 + seed)
+        y = np.zeros(n); ns.op_apply(0, abi.OP_A, x, y)
+        assert np.array_equal(y, orc.spmv(H["mats"][0], x))
+        xc = seeded(nc, 20 + seed)
+        yp = np.zeros(n); ns.op_apply(0, abi.OP_P, xc, yp)
+        assert np.array_equal(yp, orc.spmv(H["prolongations"][0], xc))
+        yr = np.zeros(nc); ns.op_apply(0, abi.OP_R, x, yr)
+        Rt = Pm.T.tocsr(); Rt.sort_indices()
+        assert max_rel(yr, orc.spmv(po.CSR(Rt.shape, Rt.indptr, Rt.indices, Rt.data), x)) <= 1e-15
+        # a smoothing pass (fused sweeps with deferred x update, table D^-1) against the oracle's literal loop
+        go = orc.GMG(H["mats"], H["prolongations"], pre_smoothers=[orc.Smoother(orc.JACOBI, 2, 0.5)], maxiter=1)
+        x0, r0 = seeded(n, 30 + seed), seeded(n, 40 + seed)
+        xs, rs = x0.copy(), r0.copy()
+        ns.smooth(0, xs, rs)
+        xo, ro = go.smooth(0, x0, r0)
+        assert max_rel(xs, xo) <= TOL_KERNEL and max_rel(rs, ro) <= TOL_KERNEL
+        ns.close()
