@@ -219,6 +219,8 @@ struct Smoother {
   int64_t *d_uboff = nullptr;
   double *d_ubinv = nullptr;
   int64_t *d_iptr = nullptr, *d_inc = nullptr;
+  int64_t *d_isoff = nullptr;   // sliced-ELL incidence (patch_gather_sell_kernel); nullptr: CSR-like lists
+  int32_t *d_isinc = nullptr;
   double *d_contrib = nullptr;
   bool built = false;
 };
@@ -1685,7 +1687,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
   S.d_pdofs = upload(S.h_pdofs);
   S.d_boff = upload(boff);
   S.d_binv = dalloc<double>((size_t)boff[npatch]);
-  S.d_contrib = dvec(ndof_entries);
+  S.d_contrib = dvec(ndof_entries + 1);                    // + one slot that stays 0.0: the padding target of the sliced incidence
   // dof -> contribution slots, ascending patch order (= reference loop order PatchSolvers.jl:288)
   std::vector<int64_t> iptr((size_t)L.n + 1, 0), inc((size_t)ndof_entries);
   for (int64_t q = 0; q < ndof_entries; ++q) iptr[S.h_pdofs[q] + 1]++;
@@ -1694,8 +1696,29 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
     std::vector<int64_t> fill(iptr.begin(), iptr.end() - 1);
     for (int64_t q = 0; q < ndof_entries; ++q) inc[fill[S.h_pdofs[q]]++] = q;
   }
-  S.d_iptr = upload(iptr);
-  S.d_inc = upload(inc);
+  if (ndof_entries < (int64_t)INT32_MAX && L.n > 0) {
+    const int64_t ns = (L.n + 63) / 64;
+    std::vector<int64_t> soff((size_t)ns + 1, 0);
+    for (int64_t sl = 0; sl < ns; ++sl) {
+      int64_t w = 0;
+      for (int64_t i = sl * 64; i < std::min<int64_t>(L.n, sl * 64 + 64); ++i) w = std::max(w, iptr[i + 1] - iptr[i]);
+      soff[sl + 1] = soff[sl] + w * 64;
+    }
+    std::vector<int32_t> sinc((size_t)soff[ns], (int32_t)ndof_entries);   // padding -> the zero slot
+    parallel_for(ns, [&](int64_t sl) {
+      for (int l = 0; l < 64; ++l) {
+        const int64_t i = sl * 64 + l;
+        if (i >= L.n) break;
+        for (int64_t k = iptr[i]; k < iptr[i + 1]; ++k) sinc[(size_t)(soff[sl] + (k - iptr[i]) * 64 + l)] = (int32_t)inc[k];
+      }
+    });
+    S.d_isoff = upload(soff);
+    S.d_isinc = upload_padded(sinc, 64);
+    S.d_iptr = nullptr; S.d_inc = nullptr;
+  } else {
+    S.d_iptr = upload(iptr);
+    S.d_inc = upload(inc);
+  }
   // factorise in chunks so the scratch stays bounded
   if (npatch > 0 && max_np > 0) {
     const size_t per = (size_t)max_np * max_np;
@@ -1797,6 +1820,10 @@ void gmg_solver::patch_precond(Level &L, Smoother &S, const double *r, double om
     HIP_CHECK(hipGetLastError());
   }
   const int grid = (int)((L.n + 255) / 256);
+  if (S.d_isoff)
+    hipLaunchKernelGGL(patch_gather_sell_kernel, dim3(std::max(grid, 1)), dim3(256), 0, stream, L.n, S.d_isoff, S.d_isinc, S.d_contrib,
+                       omega, relax ? 1 : 0, dx, x);
+  else
   hipLaunchKernelGGL(patch_gather_kernel, dim3(std::max(grid, 1)), dim3(256), 0, stream, L.n, S.d_iptr, S.d_inc, S.d_contrib,
                      omega, relax ? 1 : 0, dx, x);
   HIP_CHECK(hipGetLastError());

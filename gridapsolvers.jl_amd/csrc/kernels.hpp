@@ -1261,4 +1261,26 @@ __global__ void patch_gather_kernel(int64_t n, const int64_t *__restrict__ iptr,
   dx[i] = s;
 }
 
+// The same gather with the incidence lists in sliced-ELL form (64 dofs per slice, column-major, 32-bit slots,
+// padding -> a slot that holds 0.0): the index loads are coalesced.  Slots of a dof keep their ascending patch order.
+__global__ void patch_gather_sell_kernel(int64_t n, const int64_t *__restrict__ soff, const int32_t *__restrict__ sinc,
+                                         const double *__restrict__ contrib, double omega, int relax,
+                                         double *__restrict__ dx, double *__restrict__ x)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t slice = i >> 6;
+  const int lane = (int)(i & 63);
+  const int64_t base = soff[slice];
+  const int w = (int)((soff[slice + 1] - base) >> 6);
+  const int32_t *ip = sinc + base + lane;
+  double s = 0.0;
+  for (int j = 0; j < w; ++j) s += contrib[ip[(int64_t)j * 64]];
+  if (relax) {
+    s = omega * s;
+    x[i] = x[i] + s;
+  }
+  dx[i] = s;
+}
+
 } // namespace gmg
