@@ -192,6 +192,11 @@ struct DevCSR {
   int32_t *prun = nullptr;
   int pat_nruns = 0, pat_minoff = 0, pat_maxoff = 0;
   double *pdinv = nullptr;      // [np] 1/diag per pattern (nullptr: some pattern has no diagonal entry)
+  bool pat_generic = false;     // the per-lane-offset table (sellp_kernel) fits LDS
+  int pat_k = 3;                // offsets per run of the shared form
+  bool pat_coded = false;       // shared form with one-byte value codes + dictionary
+  uint8_t *pcodes = nullptr;
+  double *pdict = nullptr;
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -403,6 +408,7 @@ struct gmg_solver {
   int pat_small_wpb = 4;   // GMG_PAT_SMALL_WPB: waves per workgroup of sells_kernel on levels with < 8192 slices (table staging amortised)
   int pat_small_wpb2 = 1;  // GMG_PAT_SMALL_WPB2: the same for sellp_kernel
   int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
+  int64_t pat_coded_min_rows = 500000;   // GMG_PAT_CODED_MIN_ROWS
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
   int pat_dinv = 1;     // GMG_PAT_DINV: Jacobi inverse diagonal from the pattern table instead of its vector
   int pat_shared = 1;   // GMG_PAT_SHARED: shared-offset (stencil) form when the offsets are row-relative
@@ -548,15 +554,18 @@ struct gmg_solver {
   // Chunks of rows are scanned in parallel with thread-local tables that are merged in chunk order
   // (deterministic ids).  Gives up as soon as the table outgrows LDS.
   bool detect_patterns(const HostCSR &H, int mode, std::vector<uint16_t> &rowpid, std::vector<int32_t> &rowbase,
-                       std::vector<int32_t> &plen, std::vector<int32_t> &poff, std::vector<double> &pval, int &W)
+                       std::vector<int32_t> &plen, std::vector<int32_t> &poff, std::vector<double> &pval, int &W,
+                       bool allow_big, bool &generic_fits)
   {
     constexpr int kMaxTableBytes = 48 * 1024;
+    generic_fits = false;
     const int64_t n = H.nrows;
     int64_t wmax = 0;
     for (int64_t i = 0; i < n; ++i) wmax = std::max(wmax, H.ptr[i + 1] - H.ptr[i]);
     if (wmax == 0 || wmax > 1024) return false;
     W = (int)wmax;
-    const int max_np = (int)std::min<int64_t>(65534, kMaxTableBytes / (12 * wmax + 4) - 1);
+    // allow_big: the caller may still find a compact (shared-offset, coded) table for many / wide patterns
+    const int max_np = allow_big ? 4096 : (int)std::min<int64_t>(65534, kMaxTableBytes / (12 * wmax + 4) - 1);
     if (max_np < 1) return false;
     struct Local {
       std::vector<int32_t> len, start;       // per local pattern
@@ -658,7 +667,8 @@ struct gmg_solver {
     plen.push_back(0);                                      // trailing empty pattern for the lanes past nrows
     const int un = pat_un_eff();
     W = (W + un - 1) / un * un;                             // row stride: the kernel reads UN entries at a time
-    if ((int64_t)(np + 1) * (12 * W + 4) > kMaxTableBytes) return false;
+    generic_fits = (int64_t)(np + 1) * (12 * W + 4) <= kMaxTableBytes;
+    if (!generic_fits && !allow_big) return false;
     poff.assign((size_t)(np + 1) * W, 0);
     pval.assign((size_t)(np + 1) * W, 0.0);
     for (int p = 0; p < np; ++p)
@@ -677,13 +687,24 @@ struct gmg_solver {
     std::vector<int32_t> rowbase, plen, poff;
     std::vector<double> pval;
     int W = 0;
-    bool ok = (H.ncols >= H.nrows) && detect_patterns(H, 0, rowpid, rowbase, plen, poff, pval, W);
-    if (!ok) ok = detect_patterns(H, 1, rowpid, rowbase, plen, poff, pval, W);
+    bool generic = false;
+    bool ok = (H.ncols >= H.nrows) && detect_patterns(H, 0, rowpid, rowbase, plen, poff, pval, W, pat_shared && one_gather(), generic);
+    if (ok) {
+      if (pat_shared) build_shared_offsets(D, plen, poff, pval, W, H.ncols, generic);
+      if (!generic && !D.pat_shared) ok = false;            // neither table fits LDS
+      // the coded kernel walks the whole superset of offsets (Q2: 125 taps per row where 62 are stored on average): it only
+      // pays where the matrix stream is the bottleneck, i.e. on big levels; small ones keep SELL-C
+      if (ok && !generic && D.pat_coded && H.nrows < pat_coded_min_rows) { ok = false; D.pat_shared = false; D.pat_coded = false; return false; }
+    }
+    if (!ok) {
+      D.pat_shared = false;
+      ok = detect_patterns(H, 1, rowpid, rowbase, plen, poff, pval, W, false, generic);
+    }
     if (!ok) return false;
-    if (rowbase.empty() && pat_shared) build_shared_offsets(D, plen, poff, pval, W, H.ncols);
     D.rowpid = upload_padded(rowpid, 64);
     D.rowbase = rowbase.empty() ? nullptr : upload_padded(rowbase, 64);
-    D.plen = upload(plen); D.ppoff = upload(poff); D.ppval = upload(pval);
+    D.pat_generic = generic;
+    if (generic) { D.plen = upload(plen); D.ppoff = upload(poff); D.ppval = upload(pval); }
     D.pat_np = (int)plen.size(); D.pat_w = W;
     D.nslices = (int)((H.nrows + 63) / 64);
     D.pat = true; D.sell = true;
@@ -694,9 +715,10 @@ struct gmg_solver {
   // Shared-offset form of a row-relative pattern table (sells_kernel): the union of all offsets, covered
   // greedily by runs of three consecutive offsets; every pattern becomes a dense coefficient vector over it.
   void build_shared_offsets(DevCSR &D, const std::vector<int32_t> &plen, const std::vector<int32_t> &poff8,
-                            const std::vector<double> &pval, int W, int64_t ncols)
+                            const std::vector<double> &pval, int W, int64_t ncols, bool generic_fits)
   {
     const int np = (int)plen.size();                       // includes the trailing empty pattern
+    if (ncols >= (int64_t)(1 << 28)) return;
     std::vector<int32_t> U;
     for (int p = 0; p < np; ++p)
       for (int j = 0; j < plen[p]; ++j) {
@@ -707,48 +729,82 @@ struct gmg_solver {
     std::sort(U.begin(), U.end());
     U.erase(std::unique(U.begin(), U.end()), U.end());
     if (U.empty()) return;
-    std::vector<int32_t> runs;
-    for (size_t i = 0; i < U.size();) {
-      const int32_t o = U[i];
-      runs.push_back(o);
-      while (i < U.size() && U[i] <= o + 2) ++i;
-    }
-    // more loads than the generic kernel would issue: not worth it
     size_t maxlen = 0;
     for (int p = 0; p < np; ++p) maxlen = std::max(maxlen, (size_t)plen[p]);
-    if (2 * runs.size() > maxlen + 2) return;
-    const size_t nreal = runs.size();                       // sorted ascending
-    while (runs.size() % (size_t)pat_rb) runs.push_back(0);     // dummy runs: zero coefficients on x[row..row+2]
-    const int nruns = (int)runs.size(), nu = 3 * nruns;
-    if ((int64_t)np * nu * (int64_t)sizeof(PatEntry) > 48 * 1024) return;
-    std::vector<PatEntry> tab((size_t)np * nu);
-    std::memset(tab.data(), 0, tab.size() * sizeof(PatEntry));
-    for (int p = 0; p < np; ++p)
-      for (int j = 0; j < plen[p]; ++j) {
-        const int32_t o = poff8[(size_t)p * W + j] / 8;
-        const auto it = std::upper_bound(runs.begin(), runs.begin() + nreal, o);   // the run that holds o
-        const size_t r = (size_t)(it - runs.begin()) - 1;
-        PatEntry &e = tab[(size_t)p * nu + r * 3 + (size_t)(o - runs[r])];
-        e.v = pval[(size_t)p * W + j];
-        e.m = 0xffffffffu;
+    // distinct values (coded form)
+    std::vector<uint64_t> keys;
+    bool few_values = true;
+    for (int p = 0; p < np && few_values; ++p)
+      for (int j = 0; j < plen[p] && few_values; ++j) {
+        uint64_t bits;
+        std::memcpy(&bits, &pval[(size_t)p * W + j], 8);
+        auto it = std::lower_bound(keys.begin(), keys.end(), bits);
+        if (it == keys.end() || *it != bits) {
+          if (keys.size() == 255) few_values = false;
+          else keys.insert(it, bits);
+        }
       }
-    {   // inverse diagonal per pattern (JacobiLinearSolvers.jl:20-23: 1 ./ diag(A)); rows of the same pattern share it
-      std::vector<double> pd((size_t)np, 0.0);
-      bool all = D.nrows == D.ncols;
-      for (int p = 0; p < np - 1 && all; ++p) {
-        bool found = false;
-        for (int j = 0; j < plen[p]; ++j)
-          if (poff8[(size_t)p * W + j] == 0) { pd[p] = 1.0 / pval[(size_t)p * W + j]; found = true; }
-        all = found;
+    // candidates: plain table with runs of 3 (12 B per entry), coded table with runs of 5 or 3 (1 B per entry)
+    struct Cand { int k; bool coded; int rb; };
+    const Cand cands[] = {{3, false, pat_rb}, {5, true, 5}, {3, true, 3}};
+    for (const Cand &c : cands) {
+      if (c.coded && !few_values) continue;
+      std::vector<int32_t> runs;
+      for (size_t i = 0; i < U.size();) {
+        const int32_t o = U[i];
+        runs.push_back(o);
+        while (i < U.size() && U[i] <= o + c.k - 1) ++i;
       }
-      if (all) D.pdinv = upload(pd);
+      // more loads than the generic kernel would issue: not worth it (when the generic kernel is an option)
+      if (generic_fits && 2 * runs.size() > maxlen + 2) continue;
+      const size_t nreal = runs.size();                     // sorted ascending
+      while (runs.size() % (size_t)c.rb) runs.push_back(0); // dummy runs: zero coefficients on x[row..row+k-1]
+      const int nruns = (int)runs.size(), nu = c.k * nruns;
+      const int64_t lds = c.coded ? (int64_t)2048 + (((int64_t)np * nu + 7) / 8) * 8 + (int64_t)np * 8
+                                  : (int64_t)np * nu * 12 + 8 + (int64_t)np * 8;
+      if (lds > 48 * 1024) continue;
+      std::vector<PatEntry> tab;
+      std::vector<uint8_t> codes;
+      if (c.coded) codes.assign((size_t)np * nu, (uint8_t)255);
+      else { tab.resize((size_t)np * nu); std::memset(tab.data(), 0, tab.size() * sizeof(PatEntry)); }
+      for (int p = 0; p < np; ++p)
+        for (int j = 0; j < plen[p]; ++j) {
+          const int32_t o = poff8[(size_t)p * W + j] / 8;
+          const auto it = std::upper_bound(runs.begin(), runs.begin() + nreal, o);   // the run that holds o
+          const size_t r = (size_t)(it - runs.begin()) - 1;
+          const size_t e = (size_t)p * nu + r * c.k + (size_t)(o - runs[r]);
+          if (c.coded) {
+            uint64_t bits;
+            std::memcpy(&bits, &pval[(size_t)p * W + j], 8);
+            codes[e] = (uint8_t)(std::lower_bound(keys.begin(), keys.end(), bits) - keys.begin());
+          } else { tab[e].v = pval[(size_t)p * W + j]; tab[e].m = 0xffffffffu; }
+        }
+      {   // inverse diagonal per pattern (JacobiLinearSolvers.jl:20-23: 1 ./ diag(A)); rows of the same pattern share it
+        std::vector<double> pd((size_t)np, 0.0);
+        bool all = D.nrows == D.ncols;
+        for (int p = 0; p < np - 1 && all; ++p) {
+          bool found = false;
+          for (int j = 0; j < plen[p]; ++j)
+            if (poff8[(size_t)p * W + j] == 0) { pd[p] = 1.0 / pval[(size_t)p * W + j]; found = true; }
+          all = found;
+        }
+        if (all) D.pdinv = upload(pd);
+      }
+      if (c.coded) {
+        std::vector<double> dict(256, 0.0);
+        for (size_t q = 0; q < keys.size(); ++q) std::memcpy(&dict[q], &keys[q], 8);
+        D.pcodes = upload_padded(codes, 64);
+        D.pdict = upload(dict);
+      } else D.ptab = upload(tab);
+      D.prun = upload(runs);
+      D.pat_nruns = nruns;
+      D.pat_k = c.k;
+      D.pat_coded = c.coded;
+      D.pat_minoff = *std::min_element(runs.begin(), runs.end());
+      D.pat_maxoff = *std::max_element(runs.begin(), runs.end());
+      D.pat_shared = true;
+      return;
     }
-    D.ptab = upload(tab);
-    D.prun = upload(runs);
-    D.pat_nruns = nruns;
-    D.pat_minoff = *std::min_element(runs.begin(), runs.end());
-    D.pat_maxoff = *std::max_element(runs.begin(), runs.end());
-    D.pat_shared = ncols < (int64_t)(1 << 28);
   }
   template <int EPI, bool ONEG>
   void launch_sells(const DevCSR &M, const StreamArgs2 &a2)
@@ -758,21 +814,29 @@ struct gmg_solver {
     a.rowpid = M.rowpid; a.tab = M.ptab; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
     a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff;
     a.xmode = a2.xmode; a.pdinv = (EPI == EPI_SWEEP && a2.dinv_from_table) ? M.pdinv : nullptr;
-    const int nsl = (int)((M.nrows + kSellsRows - 1) / kSellsRows);
+    a.codes = M.pcodes; a.dict = M.pdict;
+    const int rows = 65 - M.pat_k;
+    const int nsl = (int)((M.nrows + rows - 1) / rows);
     a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl; a.xcd_remap = xcd_remap;
     a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
     const int wpb = sell_block > 0 ? sell_block / 64 : (nsl >= 256 * 32 ? 4 : pat_small_wpb);
     const int nwg = std::max(1, std::min((nsl + wpb - 1) / wpb, pat_wgs));
-    const size_t lds = (size_t)M.pat_np * 3 * M.pat_nruns * 12 + 8 + (size_t)M.pat_np * 8;
-    if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
-    else if (pat_rb == 1) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 1>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
-    else hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3>), dim3(nwg), dim3(64 * wpb), lds, stream, a);
+    const int nu = M.pat_k * M.pat_nruns;
+    const size_t lds = M.pat_coded ? (size_t)2048 + (((size_t)M.pat_np * nu + 7) / 8) * 8 + (size_t)M.pat_np * 8
+                                   : (size_t)M.pat_np * nu * 12 + 8 + (size_t)M.pat_np * 8;
+    const dim3 g(nwg), b(64 * wpb);
+    if (M.pat_coded && M.pat_k == 5) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true>), g, b, lds, stream, a);
+    else if (M.pat_coded) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3, 3, true>), g, b, lds, stream, a);
+    else if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), g, b, lds, stream, a);
+    else if (pat_rb == 1) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 1>), g, b, lds, stream, a);
+    else hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3>), g, b, lds, stream, a);
     HIP_CHECK(hipGetLastError());
   }
   template <int EPI, bool ONEG>
   void launch_sellp(const DevCSR &M, const StreamArgs2 &a2)
   {
     if (M.pat_shared && (EPI != EPI_SWEEP || ONEG)) { launch_sells<EPI, ONEG>(M, a2); return; }
+    REQUIRE(M.pat_generic, GMG_ERR_UNSUPPORTED, "this operator only has the shared-offset pattern form (one-gather sweeps)");
     SellPArgs a;
     std::memset(&a, 0, sizeof(a));
     a.rowpid = M.rowpid; a.rowbase = M.rowbase; a.plen = M.plen; a.poff = M.ppoff; a.pval = M.ppval; a.np = M.pat_np; a.W = M.pat_w;
@@ -1472,6 +1536,7 @@ struct gmg_solver {
     pat_shared = env_int("GMG_PAT_SHARED", 1);
     prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
     pat_defer = env_int("GMG_PAT_DEFER", 1);
+    pat_coded_min_rows = env_int("GMG_PAT_CODED_MIN_ROWS", 500000);
     pat_emit = env_int("GMG_PAT_EMIT", 1);
     pat_small_wpb = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB", 4)));
     pat_small_wpb2 = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB2", 1)));

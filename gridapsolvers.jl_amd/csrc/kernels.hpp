@@ -617,7 +617,9 @@ struct alignas(16) PatEntry {
 
 struct SellSArgs {
   const uint16_t *rowpid;
-  const PatEntry *tab;      // [np * nu], nu = 3 * nruns ; the last pattern is empty
+  const PatEntry *tab;      // [np * nu], nu = K * nruns ; the last pattern is empty
+  const uint8_t *codes;     // coded form (VD): [np * nu] index into dict, 255 = entry absent
+  const double *dict;       // coded form: [256] distinct values, dict[255] = 0.0
   const int32_t *run_off;   // [nruns] first offset of each run (elements)
   int np, nruns;            // nruns is a multiple of the kernel's RB
   int minoff, maxoff;       // smallest / largest first offset of a run
@@ -651,15 +653,21 @@ __device__ __forceinline__ double bcast_lane(double v, int l)
 // A slice is kSellsRows = 62 rows: the 64 lanes load x[row0+o .. row0+o+63], lanes 0..61 own a row and find their
 // two right neighbours inside the wave, lanes 62/63 only carry the halo (no separate tail loads: 9 gather
 // instructions per slice for a 27-point operator).
+// K = offsets per run (3: 27-point operators; 5: Q2-type operators whose lines hold 5 consecutive offsets) and the slice is
+// 65-K rows.  VD = coded table: one byte per entry indexing a dictionary of <= 255 distinct values (wide rows / many
+// patterns would not fit LDS otherwise: Q2 stiffness = 217 patterns x 125 entries = 27 KB of codes).
 constexpr int kSellsRows = 62;
-template <int EPI, bool ONEG, int RB>
+template <int EPI, bool ONEG, int RB, int K = 3, bool VD = false>
 __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 {
+  constexpr int ROWS = 65 - K;
   extern __shared__ double sp_smem[];
-  const int nu = 3 * a.nruns;
+  const int nu = K * a.nruns;
   const int tot = a.np * nu;
-  double *s_val = sp_smem;                                 // [np * nu] coefficients
-  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);   // [np * nu] high-word masks
+  // plain: [np*nu] coefficients | [np*nu] high-word masks | [np] 1/diag ; coded: [256] dictionary | [np*nu] codes | [np] 1/diag
+  double *s_val = sp_smem;
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
+  const uint8_t *s_code = reinterpret_cast<const uint8_t *>(sp_smem + 256);
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x;
@@ -679,9 +687,9 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
   const int xmode = a.xmode;
   const bool tab_dinv = a.pdinv != nullptr;
   auto load_head = [&](int slice) {
-    const int64_t row = (int64_t)slice * kSellsRows + lane;
+    const int64_t row = (int64_t)slice * ROWS + lane;
     pid_n = a.np - 1; e0_n = e1_n = e2_n = dr_n = sp_n = 0.0;
-    if (slice < s_end && lane < kSellsRows && row < a.nrows) {
+    if (slice < s_end && lane < ROWS && row < a.nrows) {
       pid_n = (int)a.rowpid[row];
       if (EPI == EPI_SUB) e0_n = a.y[row];
       else if (EPI == EPI_RESID) e0_n = a.b[row];
@@ -696,14 +704,19 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
     }
   };
   load_head(s_begin + wave);
-  double *s_dinv = reinterpret_cast<double *>(s_msk + tot + (tot & 1));   // [np]
+  double *s_dinv = VD ? sp_smem + 256 + ((tot + 7) >> 3) : reinterpret_cast<double *>(s_msk + tot + (tot & 1));   // [np]
+  if (VD) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) sp_smem[i] = a.dict[i];
+    uint8_t *wc = reinterpret_cast<uint8_t *>(sp_smem + 256);
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) wc[i] = a.codes[i];
+  } else
   for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
   if (EPI == EPI_SWEEP && tab_dinv)
     for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
   __syncthreads();
 
   for (int slice = s_begin + wave; slice < s_end; slice += wpb) {
-    const int row0 = slice * kSellsRows;
+    const int row0 = slice * ROWS;
     const int64_t row = (int64_t)row0 + lane;
     const int pid = pid_n;
     const double e0 = e0_n, e1 = e1_n, e2 = e2_n, sp = sp_n;
@@ -727,16 +740,20 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       for (int q = 0; q < RB; ++q) {
         double cur = A[q];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          if (t > 0) cur = wave_shl1(cur);                 // lanes 62/63 receive junk: they own no row
-          const int j = (r0 + q) * 3 + t;
-          const double g = __hiloint2double(__double2hiint(cur) & (int)tm[j], __double2loint(cur));
-          s = s + tv[j] * g;
+        for (int t = 0; t < K; ++t) {
+          if (t > 0) cur = wave_shl1(cur);                 // the last K-1 lanes receive junk: they own no row
+          const int j = (r0 + q) * K + t;
+          double v;
+          int m;
+          if (VD) { const int code = s_code[pid * nu + j]; v = sp_smem[code]; m = (code == 255) ? 0 : -1; }
+          else { v = tv[j]; m = (int)tm[j]; }
+          const double g = __hiloint2double(__double2hiint(cur) & m, __double2loint(cur));
+          s = s + v * g;
         }
       }
       if (r0 + RB < a.nruns) gather(r0 + RB);
     }
-    if (lane < kSellsRows && row < a.nrows) {
+    if (lane < ROWS && row < a.nrows) {
       // non-sweep epilogues may also emit s = omega*(Dinv*y) for the smoothing pass that follows (saves its
       // scaled_jacobi launch): requested by passing s_out / dinv / omega
       if (EPI == EPI_SET) { a.y[row] = s; if (a.s_out) a.s_out[row] = omega * (dinv[row] * s); }

@@ -780,3 +780,38 @@ def test_row_pattern_random_banded_and_circulant(S, po, orc, seed, n, noff):
         xo, ro = go.smooth(0, x0, r0)
         assert max_rel(xs, xo) <= TOL_KERNEL and max_rel(rs, ro) <= TOL_KERNEL
         ns.close()
+
+
+def test_row_pattern_coded_table_q2(S, po, orc, hierarchy, monkeypatch):
+    """Q2 stiffness matrices have 216 row patterns of up to 125 entries: too wide for the 12-byte-per-entry tables, so the
+    shared-offset kernel runs on a coded table (one byte per entry into a dictionary of the 38 distinct values, runs of
+    5 consecutive offsets).  Forced on a small problem here (by default only levels >= 5e5 rows take it)."""
+    from gridapsolvers_jl_amd import abi
+    monkeypatch.setenv("GMG_PAT_CODED_MIN_ROWS", "0")
+    nc, nlev = (8, 8, 8), 2
+    H = hierarchy(nc, nlev, 2)
+    pp, pd = po.vertex_star_patches(nc, 2)
+    sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 3, 0.2)]
+    gmg = S.GMGLinearSolver(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=sm, post_smoothers=sm, maxiter=1)
+    ns = setup(S, gmg, H["mats"][0])
+    fmt = ns.level_format(0)
+    assert fmt["layout"] == "SELL-P" and fmt["stream_bytes_per_nnz"] < 0.1
+    A = H["mats"][0]
+    x = seeded(A.shape[0], 77)
+    y = np.zeros_like(x)
+    ns.op_apply(0, abi.OP_A, x, y)
+    assert np.array_equal(y, orc.spmv(A, x))                  # explicit zeros of the superset add nothing: bit-identical
+    r = seeded(A.shape[0], 78)
+    z = np.zeros_like(r)
+    S.solve_(z, ns, r)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.PATCH, 3, 0.2, pp, pd)], maxiter=1)
+    assert rel_err(z, go.solve(r)[0]) <= TOL_VCYCLE
+    # Jacobi sweeps on the same operator (fused sweep epilogue of the coded kernel, table D^-1)
+    gj = S.GMGLinearSolver(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=jac(S, 2, 3, 0.5), post_smoothers=jac(S, 2, 3, 0.5), maxiter=1)
+    nj = setup(S, gj, A)
+    x0, r0 = seeded(A.shape[0], 1), seeded(A.shape[0], 2)
+    xs, rs = x0.copy(), r0.copy()
+    nj.smooth(0, xs, rs)
+    xo, ro = orc.GMG(H["mats"], H["prolongations"], pre_smoothers=[orc.Smoother(orc.JACOBI, 3, 0.5)], maxiter=1).smooth(0, x0, r0)
+    assert max_rel(xs, xo) <= TOL_KERNEL and max_rel(rs, ro) <= TOL_KERNEL
+    ns.close(); nj.close()
