@@ -197,6 +197,7 @@ struct DevCSR {
   bool pat_coded = false;       // shared form with one-byte value codes + dictionary
   uint8_t *pcodes = nullptr;
   double *pdict = nullptr;
+  uint32_t *prunmask = nullptr;
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -760,7 +761,7 @@ struct gmg_solver {
       const size_t nreal = runs.size();                     // sorted ascending
       while (runs.size() % (size_t)c.rb) runs.push_back(0); // dummy runs: zero coefficients on x[row..row+k-1]
       const int nruns = (int)runs.size(), nu = c.k * nruns;
-      const int64_t lds = c.coded ? (int64_t)2048 + (((int64_t)np * nu + 7) / 8) * 8 + (int64_t)np * 8
+      const int64_t lds = c.coded ? (int64_t)2048 + (((int64_t)np * nu + 7) / 8) * 8 + (int64_t)np * 12 + 8
                                   : (int64_t)np * nu * 12 + 8 + (int64_t)np * 8;
       if (lds > 48 * 1024) continue;
       std::vector<PatEntry> tab;
@@ -791,6 +792,12 @@ struct gmg_solver {
         if (all) D.pdinv = upload(pd);
       }
       if (c.coded) {
+        if (nruns > 32) continue;                           // run masks are 32-bit
+        std::vector<uint32_t> rmask((size_t)np, 0u);
+        for (int p = 0; p < np; ++p)
+          for (int e = 0; e < nu; ++e)
+            if (codes[(size_t)p * nu + e] != 255) rmask[p] |= 1u << (e / c.k);
+        D.prunmask = upload(rmask);
         std::vector<double> dict(256, 0.0);
         for (size_t q = 0; q < keys.size(); ++q) std::memcpy(&dict[q], &keys[q], 8);
         D.pcodes = upload_padded(codes, 64);
@@ -814,7 +821,7 @@ struct gmg_solver {
     a.rowpid = M.rowpid; a.tab = M.ptab; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
     a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff;
     a.xmode = a2.xmode; a.pdinv = (EPI == EPI_SWEEP && a2.dinv_from_table) ? M.pdinv : nullptr;
-    a.codes = M.pcodes; a.dict = M.pdict;
+    a.codes = M.pcodes; a.dict = M.pdict; a.runmask = M.prunmask;
     const int rows = 65 - M.pat_k;
     const int nsl = (int)((M.nrows + rows - 1) / rows);
     a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl; a.xcd_remap = xcd_remap;
@@ -822,7 +829,7 @@ struct gmg_solver {
     const int wpb = sell_block > 0 ? sell_block / 64 : (nsl >= 256 * 32 ? 4 : pat_small_wpb);
     const int nwg = std::max(1, std::min((nsl + wpb - 1) / wpb, pat_wgs));
     const int nu = M.pat_k * M.pat_nruns;
-    const size_t lds = M.pat_coded ? (size_t)2048 + (((size_t)M.pat_np * nu + 7) / 8) * 8 + (size_t)M.pat_np * 8
+    const size_t lds = M.pat_coded ? (size_t)2048 + (((size_t)M.pat_np * nu + 7) / 8) * 8 + (size_t)M.pat_np * 12 + 8
                                    : (size_t)M.pat_np * nu * 12 + 8 + (size_t)M.pat_np * 8;
     const dim3 g(nwg), b(64 * wpb);
     if (M.pat_coded && M.pat_k == 5) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true>), g, b, lds, stream, a);

@@ -620,6 +620,7 @@ struct SellSArgs {
   const PatEntry *tab;      // [np * nu], nu = K * nruns ; the last pattern is empty
   const uint8_t *codes;     // coded form (VD): [np * nu] index into dict, 255 = entry absent
   const double *dict;       // coded form: [256] distinct values, dict[255] = 0.0
+  const uint32_t *runmask;  // coded form: [np] bit r set when the pattern has an entry in run r (nruns <= 32)
   const int32_t *run_off;   // [nruns] first offset of each run (elements)
   int np, nruns;            // nruns is a multiple of the kernel's RB
   int minoff, maxoff;       // smallest / largest first offset of a run
@@ -705,10 +706,12 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
   };
   load_head(s_begin + wave);
   double *s_dinv = VD ? sp_smem + 256 + ((tot + 7) >> 3) : reinterpret_cast<double *>(s_msk + tot + (tot & 1));   // [np]
+  uint32_t *s_rmask = reinterpret_cast<uint32_t *>(s_dinv + a.np);                                                 // [np] (coded form)
   if (VD) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) sp_smem[i] = a.dict[i];
     uint8_t *wc = reinterpret_cast<uint8_t *>(sp_smem + 256);
     for (int i = threadIdx.x; i < tot; i += blockDim.x) wc[i] = a.codes[i];
+    for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_rmask[i] = a.runmask[i];
   } else
   for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
   if (EPI == EPI_SWEEP && tab_dinv)
@@ -731,6 +734,40 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
         A[q] = ld_off(xg, 8u * (uint32_t)min(max((int)row + o, 0), last));
       }
     };
+    if (VD) {
+      // Coded form: rows of a wave are consecutive, so whole runs (lines of the stencil) are absent for the entire wave
+      // (Q2: a line of cell-interior dofs has 9 of the 25 runs).  OR the per-pattern run masks over the wave and visit
+      // only the runs some lane needs -- in ascending order, so the sums keep their order (skipped terms are +0.0).
+      uint32_t M = s_rmask[pid];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) M |= (uint32_t)__shfl_xor((int)M, o);
+      M = (uint32_t)__builtin_amdgcn_readfirstlane((int)M);
+      load_head(slice + wpb);
+      const uint8_t *tc = s_code + pid * nu;
+      while (M) {
+        int rr[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          rr[q] = M ? (int)__builtin_ctz(M) : -1;
+          M &= M - 1;
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+          if (rr[q] >= 0) A[q] = ld_off(xg, 8u * (uint32_t)min(max((int)row + a.run_off[rr[q]], 0), last));
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          if (rr[q] < 0) continue;
+          double cur = A[q];
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) cur = wave_shl1(cur);
+            const int code = tc[rr[q] * K + t];
+            const double g = __hiloint2double(__double2hiint(cur) & ((code == 255) ? 0 : -1), __double2loint(cur));
+            s = s + sp_smem[code] * g;
+          }
+        }
+      }
+    } else {
     gather(0);
     load_head(slice + wpb);                                // younger than the first gathers: not waited for with them
     const double *tv = s_val + pid * nu;
@@ -743,15 +780,12 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
         for (int t = 0; t < K; ++t) {
           if (t > 0) cur = wave_shl1(cur);                 // the last K-1 lanes receive junk: they own no row
           const int j = (r0 + q) * K + t;
-          double v;
-          int m;
-          if (VD) { const int code = s_code[pid * nu + j]; v = sp_smem[code]; m = (code == 255) ? 0 : -1; }
-          else { v = tv[j]; m = (int)tm[j]; }
-          const double g = __hiloint2double(__double2hiint(cur) & m, __double2loint(cur));
-          s = s + v * g;
+          const double g = __hiloint2double(__double2hiint(cur) & (int)tm[j], __double2loint(cur));
+          s = s + tv[j] * g;
         }
       }
       if (r0 + RB < a.nruns) gather(r0 + RB);
+    }
     }
     if (lane < ROWS && row < a.nrows) {
       // non-sweep epilogues may also emit s = omega*(Dinv*y) for the smoothing pass that follows (saves its
