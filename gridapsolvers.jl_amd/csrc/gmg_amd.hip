@@ -29,6 +29,7 @@
 #include <string>
 #include <thread>
 #include <atomic>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -2061,6 +2062,16 @@ void gmg_solver::setup()
   HIP_CHECK(hipSetDevice(device));
   free_all();
   read_tuning();
+  // GMG_SETUP_TIMING=1: per-phase wall times of the numerical setup on stderr
+  const bool timing = env_int("GMG_SETUP_TIMING", 0) != 0;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what, int l) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(stream);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[gmg_setup] level %d %-28s %8.1f ms\n", l, what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));
@@ -2128,6 +2139,7 @@ void gmg_solver::setup()
       L.A.nnz_model = L.hA.nnz();
     } else
     L.A = upload_csr(L.hA);                                 // :185 gmg_compute_matrices
+    lap("A: upload + layout", l);
     L.rbuf[0] = dvec(L.nvec);                               // :187,188 rh / rH
     if (l > 0) L.x = dvec(L.nvec);                          // :188 dxH
     if (L.halo.present) {
@@ -2149,6 +2161,7 @@ void gmg_solver::setup()
         HostCSR Rt = transpose(L.hP);                       // R = P^T, GridTransferOperators.jl:536-547
         L.R = upload_csr(Rt);
       }
+      lap("P, R: upload + layout", l);
       // :189-190 smoother caches: inv_diag = 1 ./ diag(A) (JacobiLinearSolvers.jl:20-23)
       int nzero = 0;
       L.dinv = build_inv_diag(L.A, nzero);
@@ -2164,10 +2177,12 @@ void gmg_solver::setup()
       else if (L.post.kind == SM_PATCH) build_patch(L, L.post);
       drop_csr_stream(L.P);
       drop_csr_stream(L.R);
+      lap("D^-1, patch blocks", l);
     }
     drop_csr_stream(L.A);
   }
   build_coarse();                                           // :195 gmg_coarse_solver_caches
+  lap("coarse inverse", nlev - 1);
   const int64_t n0 = lev[0].nvec;
   cg_w = dvec(n0); cg_p = dvec(n0); cg_z = dvec(n0); cg_r = dvec(n0);
   st_b = dvec(n0); st_x = dvec(n0);
