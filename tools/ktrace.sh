@@ -7,7 +7,7 @@ OUT=$ROOTDIR/gpurun_out/kt_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export TUNE_VARIANTS='[{}]'
-rocprofv3 --kernel-trace -d $OUT/trace -o p -- python3 $ROOTDIR/tools/tune.py child > $OUT/trace.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace -d $OUT/trace -o p -- python3 $ROOTDIR/tools/tune.py child > $OUT/trace.log 2>&1
 python3 - "$OUT" <<'PY' > $OUT/summary.txt 2>&1
 import glob, os, sqlite3, sys
 out = sys.argv[1]
