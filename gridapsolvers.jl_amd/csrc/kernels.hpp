@@ -984,9 +984,24 @@ __global__ __launch_bounds__(kBlock) void dense_gemv_kernel(int n, const double 
   const int lane = threadIdx.x & 63;
   if (wave >= n) return;
   const double *row = Ainv + (size_t)wave * n;
-  double s = 0.0;
-  for (int j = lane; j < n; j += 64) s += row[j] * r[j];
-  s = wave_sum(s);
+  // 4 independent 16-byte loads per lane and iteration (4 KB of the row in flight per wave); rows of an odd n are only
+  // 8-byte aligned, which global loads allow
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int base = 0;
+  for (; base + 512 <= n; base += 512) {
+    const int j = base + 2 * lane;
+    const d2u a0 = *reinterpret_cast<const d2u *>(row + j), a1 = *reinterpret_cast<const d2u *>(row + j + 128);
+    const d2u a2 = *reinterpret_cast<const d2u *>(row + j + 256), a3 = *reinterpret_cast<const d2u *>(row + j + 384);
+    const d2u r0 = *reinterpret_cast<const d2u *>(r + j), r1 = *reinterpret_cast<const d2u *>(r + j + 128);
+    const d2u r2 = *reinterpret_cast<const d2u *>(r + j + 256), r3 = *reinterpret_cast<const d2u *>(r + j + 384);
+    s0 += a0.x * r0.x + a0.y * r0.y;
+    s1 += a1.x * r1.x + a1.y * r1.y;
+    s2 += a2.x * r2.x + a2.y * r2.y;
+    s3 += a3.x * r3.x + a3.y * r3.y;
+  }
+  for (int j = base + lane; j < n; j += 64) s0 += row[j] * r[j];
+  const double s = wave_sum((s0 + s1) + (s2 + s3));
   if (lane == 0) x[wave] = s;
 }
 
