@@ -93,6 +93,9 @@ struct HaloPlan {
   int64_t *d_snd_idx = nullptr;
   double *d_sendbuf = nullptr;
   double *h_send = nullptr, *h_recv = nullptr; // pinned, host transport only
+  // boundary row -> its slots in the send buffer (pack fused into ghost_fix_kernel); null when some sent row has no ghost column
+  int64_t *d_pk_ptr = nullptr;
+  int32_t *d_pk_slot = nullptr;
   int64_t nsend() const { return snd_ptr.empty() ? 0 : snd_ptr.back(); }
 };
 
@@ -133,11 +136,15 @@ __global__ void sqrt_inplace_kernel(double *v) { v[0] = sqrt(v[0]); }
 //   MODE 2: y[row] -= g ; s[row] = omega*(dinv[row]*y[row])   (fused sweep: r and s = w*Dinv*r)
 // The owned-column part ran while the exchange was in flight (own x own / own x ghost split of
 // the local matrix, the standard PartitionedArrays-style overlap).
+// pk_ptr / pk_slot / sendbuf (MODE 2, optional): the boundary rows are exactly the rows the neighbours need, so the
+// fix-up also writes the row's new s into its slots of the send buffer -- the next sweep's exchange starts without a
+// pack kernel.
 template <int MODE>
 __global__ void ghost_fix_kernel(int64_t nb, const int32_t *__restrict__ rows, const int64_t *__restrict__ ptr,
                                  const int32_t *__restrict__ col, const double *__restrict__ val,
                                  const double *__restrict__ v, double *__restrict__ y, const double *__restrict__ dinv,
-                                 double omega, double *__restrict__ s_out)
+                                 double omega, double *__restrict__ s_out, const int64_t *__restrict__ pk_ptr = nullptr,
+                                 const int32_t *__restrict__ pk_slot = nullptr, double *__restrict__ sendbuf = nullptr)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
@@ -149,7 +156,10 @@ __global__ void ghost_fix_kernel(int64_t nb, const int32_t *__restrict__ rows, c
   else {
     const double rn = y[row] - g;
     y[row] = rn;
-    s_out[row] = omega * (dinv[row] * rn);
+    const double sn = omega * (dinv[row] * rn);
+    s_out[row] = sn;
+    if (pk_ptr)
+      for (int64_t k = pk_ptr[i]; k < pk_ptr[i + 1]; ++k) sendbuf[pk_slot[k]] = sn;
   }
 }
 

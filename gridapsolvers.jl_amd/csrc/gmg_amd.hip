@@ -377,6 +377,7 @@ struct gmg_solver {
   Comm comm;
   hipStream_t comm_stream = nullptr;   // halo traffic overlapping the own x own mat-vec (RCCL only)
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  int halo_fuse_pack = 1;              // GMG_HALO_FUSE_PACK: the boundary fix-up of a sweep packs the next sweep's send buffer
   int overlap = 1;                     // GMG_OVERLAP
   int host_async = 0;                  // GMG_HOST_ASYNC: run the overlapped schedule with the host transport (tests)
   double *cg_x = nullptr;       // solution with ghost space (distributed runs)
@@ -498,7 +499,7 @@ struct gmg_solver {
     }
     d_Ainv = d_partials = d_scalars = nullptr;
     d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr;
-    for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; }
+    for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; L.halo.d_pk_ptr = nullptr; L.halo.d_pk_slot = nullptr; }
     cg_w = cg_p = cg_z = cg_r = st_b = st_x = nullptr;
     fg_V.clear(); fg_Z.clear(); st_extra.clear();
     setup_done = false;
@@ -1116,10 +1117,10 @@ struct gmg_solver {
   // fused Richardson-Jacobi sweep: x += w*Dinv*r_old ; r_new = r_old - A*(w*Dinv*r_old)
   // one-gather form: s_old = w*Dinv*r_old is an input, s_new = w*Dinv*r_new an output.
   void sweep(int l, const Smoother &S, double *x, const double *r_old, double *r_new, bool x_zero,
-             const double *s_old = nullptr, double *s_new = nullptr, int xmode = 0)
+             const double *s_old = nullptr, double *s_new = nullptr, int xmode = 0, bool prepacked = false, bool pack_next = false)
   {
     Level &L = lev[l];
-    if (comm.nranks > 1) begin_exchange(l, const_cast<double *>(s_old ? s_old : r_old));
+    if (comm.nranks > 1) begin_exchange(l, const_cast<double *>(s_old ? s_old : r_old), prepacked);
     // HIP events around every prof_stride-th sweep launch of the profiled level: an event pair costs ~4 us of
     // stream time, timing every launch would slow the solve it measures by > 10 %
     const bool prof = (l == prof_level) && (prof_seq++ % (uint64_t)prof_stride == 0) && prof_used + 2 <= prof_ev.size();
@@ -1139,7 +1140,7 @@ struct gmg_solver {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
       prof_used += 2;
     }
-    if (comm.nranks > 1) finish_ghost<2>(l, s_old, r_new, S.omega, s_new);   // distributed => one-gather sweep
+    if (comm.nranks > 1) finish_ghost<2>(l, s_old, r_new, S.omega, s_new, pack_next);   // distributed => one-gather sweep
   }
 
   void copy(double *dst, const double *src, int64_t n)
@@ -1189,12 +1190,13 @@ struct gmg_solver {
   }
   // consistent!(v): owner -> ghost copy of the level-l vector `v` (length nvec)
   void exchange(int l, double *v) { exchange_on(l, v, stream); }
-  void exchange_on(int l, double *v, hipStream_t stream)
+  // prepacked: the send buffer already holds v's boundary entries (written by the previous sweep's ghost_fix_kernel)
+  void exchange_on(int l, double *v, hipStream_t stream, bool prepacked = false)
   {
     HaloPlan &H = lev[l].halo;
     if (comm.nranks <= 1 || !H.present || H.nbr.empty()) return;
     const int64_t ns = H.nsend();
-    if (ns > 0) {
+    if (ns > 0 && !prepacked) {
       hipLaunchKernelGGL(halo_pack_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ns, H.d_snd_idx, v, H.d_sendbuf);
       HIP_CHECK(hipGetLastError());
     }
@@ -1226,13 +1228,13 @@ struct gmg_solver {
     HaloPlan &H = c->solver->lev[c->level].halo;
     c->solver->comm.xfn(c->solver->comm.ctx, (int)H.nbr.size(), H.nbr.data(), H.h_send, H.snd_ptr.data(), H.h_recv, H.rcv_ptr.data());
   }
-  void begin_exchange(int l, double *src)
+  void begin_exchange(int l, double *src, bool prepacked = false)
   {
     if (comm.nranks <= 1 || !lev[l].halo.present) return;
     if (overlapped() && comm.kind == COMM_RCCL) {
       HIP_CHECK(hipEventRecord(ev_ready, stream));
       HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
-      exchange_on(l, src, comm_stream);
+      exchange_on(l, src, comm_stream, prepacked);
       HIP_CHECK(hipEventRecord(ev_done, comm_stream));
     } else if (overlapped()) {
       // host transport, asynchronous flavour (tests): the same two-stream / two-event schedule as the
@@ -1242,8 +1244,10 @@ struct gmg_solver {
       HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
       const int64_t ns = H.nsend();
       if (ns > 0) {
-        hipLaunchKernelGGL(halo_pack_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, comm_stream, ns, H.d_snd_idx, src, H.d_sendbuf);
-        HIP_CHECK(hipGetLastError());
+        if (!prepacked) {
+          hipLaunchKernelGGL(halo_pack_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, comm_stream, ns, H.d_snd_idx, src, H.d_sendbuf);
+          HIP_CHECK(hipGetLastError());
+        }
         HIP_CHECK(hipMemcpyAsync(H.h_send, H.d_sendbuf, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, comm_stream));
       }
       lev[l].hostctx = {this, l};
@@ -1251,20 +1255,24 @@ struct gmg_solver {
       if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(src + H.n_own, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, comm_stream));
       HIP_CHECK(hipEventRecord(ev_done, comm_stream));
     } else {
-      exchange_on(l, src, stream);
+      exchange_on(l, src, stream, prepacked);
     }
   }
+  // pack_next (MODE 2): also fill the send buffer with the new s of the boundary rows for the next sweep's exchange
   template <int MODE>
-  void finish_ghost(int l, const double *src, double *y, double omega = 0.0, double *s_out = nullptr)
+  void finish_ghost(int l, const double *src, double *y, double omega = 0.0, double *s_out = nullptr, bool pack_next = false)
   {
     Level &L = lev[l];
     if (comm.nranks <= 1 || !L.halo.present) return;
     if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
     if (!L.split || L.nbnd == 0) return;
+    const bool pk = pack_next && MODE == 2 && L.halo.d_pk_ptr != nullptr;
     hipLaunchKernelGGL((ghost_fix_kernel<MODE>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
-                       L.gh_ptr, L.gh_col, L.gh_val, src, y, L.dinv, omega, s_out);
+                       L.gh_ptr, L.gh_col, L.gh_val, src, y, L.dinv, omega, s_out, pk ? L.halo.d_pk_ptr : nullptr,
+                       pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr);
     HIP_CHECK(hipGetLastError());
   }
+  bool can_fuse_pack(int l) const { return comm.nranks > 1 && lev[l].halo.present && lev[l].split && lev[l].nbnd > 0 && lev[l].halo.d_pk_ptr != nullptr; }
   // y = A_l x ; y -= A_l x ; y = b - A_l x   with the halo of x folded in
   void apply_A_set(int l, double *x, double *y)
   {
@@ -1348,7 +1356,8 @@ struct gmg_solver {
           if ((it & 1) == 0 && it + 1 < S.niter) xmode = 1;
           else if (it & 1) { xmode = 2; xz = x_zero && it == 1; }
         }
-        sweep(l, S, x, cur, out, xz, L.sbuf[it & 1], L.sbuf[(it + 1) & 1], xmode);
+        const bool fp = can_fuse_pack(l);
+        sweep(l, S, x, cur, out, xz, L.sbuf[it & 1], L.sbuf[(it + 1) & 1], xmode, fp && it > 0, fp && it + 1 < S.niter);
         cur = out;
       }
       return out;
@@ -1542,6 +1551,7 @@ struct gmg_solver {
     pat_un = env_int("GMG_PAT_UN", 9);
     pat_wgs = std::max(1, env_int("GMG_PAT_WGS", 2048));
     pat_shared = env_int("GMG_PAT_SHARED", 1);
+    halo_fuse_pack = env_int("GMG_HALO_FUSE_PACK", 1);
     prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
     pat_defer = env_int("GMG_PAT_DEFER", 1);
     pat_coded_min_rows = env_int("GMG_PAT_CODED_MIN_ROWS", 500000);
@@ -2135,6 +2145,28 @@ void gmg_solver::setup()
       L.split = true;
       L.nbnd = (int64_t)brows.size();
       L.gh_rows = upload(brows); L.gh_ptr = upload(bptr); L.gh_col = upload(bcol); L.gh_val = upload(bval);
+      {   // send slots of every boundary row (fused pack): valid when every sent row is a boundary row
+        HaloPlan &Hp = L.halo;
+        std::vector<int32_t> bidx((size_t)L.n, -1);
+        for (size_t q = 0; q < brows.size(); ++q) bidx[brows[q]] = (int32_t)q;
+        bool ok = halo_fuse_pack != 0 && Hp.nsend() < (int64_t)INT32_MAX;
+        std::vector<int64_t> pkp(brows.size() + 1, 0);
+        for (int64_t sidx = 0; sidx < Hp.nsend() && ok; ++sidx) {
+          const int64_t row = Hp.h_snd_idx[sidx];
+          if (row < 0 || row >= L.n || bidx[row] < 0) ok = false;
+          else pkp[(size_t)bidx[row] + 1]++;
+        }
+        if (ok && !brows.empty()) {
+          for (size_t q = 0; q < brows.size(); ++q) pkp[q + 1] += pkp[q];
+          std::vector<int32_t> slot((size_t)Hp.nsend());
+          std::vector<int64_t> fill(pkp.begin(), pkp.end() - 1);
+          for (int64_t sidx = 0; sidx < Hp.nsend(); ++sidx) slot[(size_t)fill[bidx[Hp.h_snd_idx[sidx]]]++] = (int32_t)sidx;
+          Hp.d_pk_ptr = upload(pkp);
+          Hp.d_pk_slot = upload(slot);
+        } else { Hp.d_pk_ptr = nullptr; Hp.d_pk_slot = nullptr; }
+        if (timing) std::fprintf(stderr, "[gmg_setup] level %d halo: %lld boundary rows, %lld send slots, pack fused into the fix-up: %s\n", l,
+                                 (long long)brows.size(), (long long)Hp.nsend(), Hp.d_pk_ptr ? "yes" : "no");
+      }
       L.A = upload_csr(loc);
       L.A.nnz_model = L.hA.nnz();
     } else
