@@ -26,7 +26,7 @@ class Result(C.Structure):
 
 class KernelStats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("alg_bytes", C.c_double),
-                ("rows", C.c_int64), ("nnz", C.c_int64)]
+                ("rows", C.c_int64), ("nnz", C.c_int64), ("layout_bytes", C.c_double)]
 
 
 # every symbol include/gmg_amd.h declares (tests check the library exports all of them)
@@ -49,6 +49,8 @@ SYMBOLS = {
                                               C.c_int],
     "gmg_set_options": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double],
     "gmg_setup": [C.c_void_p],
+    "gmg_set_verbose": [C.c_void_p, C.c_int],
+    "gmg_get_log": [C.c_void_p, C.POINTER(Result), C.c_void_p, C.c_int],
     "gmg_apply": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Result), C.c_void_p, C.c_int],
     "gmg_cg_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                      C.POINTER(Result), C.c_void_p, C.c_int],
@@ -74,6 +76,7 @@ SYMBOLS = {
     "gmg_level_format": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                          C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gmg_device_bytes": [C.c_void_p, C.POINTER(C.c_int64)],
+    "gmg_stream_probe": [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)],
     "gmg_block_create": [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int],
     "gmg_block_destroy": [C.c_void_p],
     "gmg_block_last_error": [C.c_void_p],

@@ -1,12 +1,15 @@
 """Builds libgmgamd.so (the C-ABI shared library) in-tree with hipcc for gfx950."""
 from __future__ import annotations
 
+import glob
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "gmg_amd.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "kernels.hpp"), os.path.join(HERE, "..", "include", "gmg_amd.h")]
+def deps():
+    """every file compiled into libgmgamd.so: csrc/* (gmg_amd.hip includes kernels.hpp, comm.hpp, block.inc.hpp, ...) + the public header"""
+    return sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + sorted(glob.glob(os.path.join(HERE, "..", "include", "*.h")))
 LIB = os.path.join(HERE, "libgmgamd.so")
 
 
@@ -18,7 +21,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 def build(force=False, verbose=False):

@@ -42,7 +42,10 @@ struct gmg_block_solver {
   void detach()
   {
     for (auto &D : diag)
-      if (D.g && D.g->stream == eng.stream) D.g->stream = D.g->own_stream;
+      if (D.g) {                                           // D.g is nulled by block_forget when its owner destroys it first
+        if (D.g->stream == eng.stream) D.g->stream = D.g->own_stream;
+        if (D.g->attached_to == this) D.g->attached_to = nullptr;
+      }
   }
 
   void setup()
@@ -68,7 +71,9 @@ struct gmg_block_solver {
         REQUIRE(g->comm.nranks == 1, GMG_ERR_UNSUPPORTED, "block solvers are single-GPU in this round");
         REQUIRE(g->lev[0].n == n, GMG_ERR_INVALID, "GMG handle size does not match block " + std::to_string(i));
         HIP_CHECK(hipStreamSynchronize(g->stream));
+        REQUIRE(g->attached_to == nullptr || g->attached_to == this, GMG_ERR_STATE, "GMG handle is already attached to another block solver");
         g->stream = eng.stream;                           // one stream: block glue and V-cycles are ordered without events
+        g->attached_to = this;
         continue;
       }
       const HostCSR *src = nullptr;
@@ -226,6 +231,18 @@ struct gmg_block_solver {
   }
 };
 
+// gmg_destroy on a handle that a block solver still borrows: drop the pointer, the block solver must be set up again
+static void block_forget(gmg_block_solver *B, gmg_solver *g)
+{
+  for (auto &D : B->diag)
+    if (D.g == g) { D.g = nullptr; D.kind = 0; B->setup_done = false; }
+  g->attached_to = nullptr;
+  if (g->stream == B->eng.stream) {
+    (void)hipStreamSynchronize(B->eng.stream);
+    g->stream = g->own_stream;
+  }
+}
+
 namespace {
 template <typename F>
 int guarded_b(gmg_block_handle_t h, F &&f)
@@ -298,6 +315,7 @@ int gmg_block_create(gmg_block_handle_t *out, int nblocks, const int64_t *block_
 
 int gmg_block_destroy(gmg_block_handle_t h)
 {
+  // borrowed GMG handles destroyed earlier have already been forgotten (block_forget): no dangling pointer is touched
   if (!h) return GMG_OK;
   (void)hipSetDevice(h->eng.device);
   (void)hipStreamSynchronize(h->eng.stream);
@@ -348,7 +366,10 @@ int gmg_block_set_diag_gmg(gmg_block_handle_t h, int i, gmg_handle_t g)
     check_block(h, i);
     REQUIRE(g, GMG_ERR_INVALID, "null GMG handle");
     BlockDiag &D = h->diag[i];
-    if (D.g && D.g != g && D.g->stream == h->eng.stream) D.g->stream = D.g->own_stream;
+    if (D.g && D.g != g) {
+      if (D.g->stream == h->eng.stream) D.g->stream = D.g->own_stream;
+      if (D.g->attached_to == h) D.g->attached_to = nullptr;
+    }
     D = BlockDiag();
     D.kind = GMG_BLOCK_GMG; D.g = g;
     h->setup_done = false;

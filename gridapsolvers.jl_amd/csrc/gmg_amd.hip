@@ -347,7 +347,11 @@ struct KrylovOps {
   std::function<void(double *z, const double *r, double known_res)> precond; // empty: Pl === nothing
 };
 
+struct gmg_block_solver;
+static void block_forget(gmg_block_solver *B, gmg_solver *g);   // block.inc.hpp
+
 struct gmg_solver {
+  gmg_block_solver *attached_to = nullptr;   // block preconditioner that borrowed this handle (gmg_block_set_diag_gmg + setup)
   int device = 0;
   hipStream_t stream = nullptr;      // the stream work is issued on (a block solver re-points it at its own)
   hipStream_t own_stream = nullptr;  // the stream this handle created and destroys
@@ -361,6 +365,8 @@ struct gmg_solver {
   // GMGLinearSolver kwargs (GMGLinearSolvers.jl:56-58)
   int mode = GMG_MODE_PRECONDITIONER, cycle_type = GMG_V_CYCLE;
   ConvLog log;
+  double log_last = 0.0;             // last residual norm the GMG's own log saw (NaN: not evaluated, see gmg_set_verbose)
+  int verbose = 0;                   // GMGLinearSolver(...; verbose): > 0 keeps the log complete on every path
 
   // coarse solver
   double *d_Ainv = nullptr;
@@ -1483,10 +1489,12 @@ struct gmg_solver {
       cycle(0, x, r_in, x_zero, cycle_type);               // :630-637
       r_in = L0.rcur;
       x_zero = false;
-      if (single && known_res0 >= 0.0) {
-        // maxiter == 1: update! returns true whatever the norm is (:640); the
-        // post-cycle norm is a logging-only quantity here and is not fetched.
+      if (single && known_res0 >= 0.0 && verbose <= 0) {
+        // maxiter == 1: update! returns true whatever the norm is (:640); the post-cycle norm is a
+        // logging-only quantity here and is not evaluated unless the solver is verbose (gmg_set_verbose):
+        // residuals[1] of the GMG's own log then reads NaN (documented in INTEGRATION.md).
         log.num_iters = 1;
+        if (log.residuals.size() > 1) log.residuals[1] = NAN;
         res = NAN;
         done = true;
       } else {
@@ -1494,6 +1502,7 @@ struct gmg_solver {
         done = log.update(res);                            // :640
       }
     }
+    log_last = res;
     return res;
   }
 
@@ -1586,6 +1595,26 @@ struct gmg_solver {
     d_scalars = dvec(kScalarSlots);
     if (!h_scalars) HIP_CHECK(hipHostMalloc((void **)&h_scalars, kScalarSlots * sizeof(double)));
   }
+  // Bytes one fused sweep launch moves with the storage layout chosen at setup, every operand once, no cache credit:
+  // the matrix stream as stored (padding included) + the row-wise vector traffic of the one-gather sweep
+  // (r in/out, s in/out, x in/out, D^-1) -- what `traffic` (PMC) should show when nothing is re-read.
+  double sweep_layout_bytes(int l) const
+  {
+    const Level &L = lev[l];
+    const DevCSR &A = L.A;
+    const double N = (double)L.n;
+    double vec = 8.0 * 7.0 * N;                            // r, r', s, s', x, x', dinv
+    double mat;
+    if (A.pat && A.pat_shared) {
+      mat = 2.0 * N;                                       // 16-bit pattern id per row; the table lives in LDS
+      if (pat_dinv && A.pdinv) vec -= 8.0 * N;             // 1/diag from the pattern table
+      if (pat_defer) vec -= 4.0 * N;                       // x touched every second sweep: (8+8+8)/2 instead of 8+8
+    } else if (A.pat) mat = (A.rowbase ? 6.0 : 2.0) * N;
+    else if (A.sell && (A.comp_idx || A.vdict)) mat = A.stream_bytes_per_nnz * (double)A.zpack + 4.0 * N + 4.0 * (double)(A.zpack / 64);
+    else if (A.sell) mat = 12.0 * (double)A.zpad + 4.0 * N + 8.0 * (double)A.nslices;
+    else mat = 12.0 * (double)A.nnz + (A.ptr64 ? 8.0 : 4.0) * N;
+    return mat + vec;
+  }
   KrylovOps level0_ops(int use_precond);
   void setup();
   void build_coarse();
@@ -1665,12 +1694,21 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
   while ((int)V.size() < m + 1) V.push_back(S.dvec(nv));
   while ((int)Z.size() < m) Z.push_back(S.dvec(nv));
   m = (int)Z.size();
-  // Hessenberg / rotations sized for the largest basis reachable in maxiter steps
-  const int hcap = std::max(m, log.maxiter + 1) + 1;
-  const int ldh = hcap + 1;
-  REQUIRE(hcap + 2 < kScalarSlots - 8, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer");
+  // Hessenberg / rotations are (m+1) x m like the reference's caches (FGMRESSolvers.jl:58-70) and grow with the
+  // basis (expand_krylov_caches!, :77-94); with restart=true j never exceeds m0.
+  int hcap = m + 1;                                      // rows of H = columns + 1
+  int ldh = hcap + 1;
   std::vector<double> H((size_t)ldh * hcap, 0.0), g((size_t)hcap + 1, 0.0), c((size_t)hcap, 0.0), s((size_t)hcap, 0.0);
   auto Hm = [&](int i, int j) -> double & { return H[(size_t)(i - 1) + (size_t)(j - 1) * ldh]; };
+  auto grow_small = [&](int newcap) {
+    const int nld = newcap + 1;
+    std::vector<double> H2((size_t)nld * newcap, 0.0);
+    for (int jj = 0; jj < hcap; ++jj)
+      for (int ii = 0; ii < ldh; ++ii) H2[(size_t)ii + (size_t)jj * nld] = H[(size_t)ii + (size_t)jj * ldh];
+    H.swap(H2);
+    g.resize((size_t)newcap + 1, 0.0); c.resize((size_t)newcap, 0.0); s.resize((size_t)newcap, 0.0);
+    hcap = newcap; ldh = nld;
+  };
   const int grid = gmg_solver::grid_for(n);
 
   // krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 ; FGMRESSolvers.jl:136-140
@@ -1688,6 +1726,8 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
         for (int q = 0; q < m_add; ++q) { V.push_back(S.dvec(nv)); Z.push_back(S.dvec(nv)); }
         m += m_add;
       }
+      if (j + 1 > hcap) grow_small(m + 1);
+      REQUIRE(j + 3 < kScalarSlots - 8, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer (use restart=true)");
       double *Vn = V[j], *Zj = Z[j - 1];
       // krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25
       if (ops.precond) ops.precond(Zj, V[j - 1], -1.0);
@@ -2302,6 +2342,9 @@ int gmg_create(gmg_handle_t *out, int nlevels, int device_id)
 int gmg_destroy(gmg_handle_t h)
 {
   if (!h) return GMG_OK;
+  // a block preconditioner still borrows this handle: make it forget the pointer (it then needs a new
+  // gmg_block_set_diag_gmg + gmg_block_setup) instead of leaving it dangling -- destruction order is free
+  if (h->attached_to) block_forget(h->attached_to, h);
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   h->free_all();
@@ -2445,6 +2488,22 @@ int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, double ato
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
     h->mode = mode; h->cycle_type = cycle;
     h->log.configure(maxiter, atol, rtol);
+  });
+}
+
+int gmg_set_verbose(gmg_handle_t h, int verbose)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    h->verbose = verbose;
+  });
+}
+
+int gmg_get_log(gmg_handle_t h, gmg_result *res, double *hist, int hist_cap)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    h->log.export_to(res, hist, hist_cap, h->log_last);
   });
 }
 
@@ -2811,6 +2870,7 @@ int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
     // B_sweep = 12 Z + 68 N  (fp64 value + int32 column per nnz; row pointer,
     // r, D^-1, x, dx read / dx, x, Adx, r written as in RichardsonSmoothers.jl:91-95)
     out->alg_bytes = 12.0 * (double)out->nnz + 68.0 * (double)L.n;
+    out->layout_bytes = h->sweep_layout_bytes(l);
   });
 }
 
@@ -2843,6 +2903,35 @@ int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
     if (idx16) *idx16 = A.comp_idx ? 1 : 0;
     if (stream_bytes_per_nnz) *stream_bytes_per_nnz = (A.sell && (A.pat || A.vdict || A.comp_idx)) ? A.stream_bytes_per_nnz : 12.0;
     if (padding) *padding = A.sell && A.nnz > 0 ? (double)A.zpad / (double)A.nnz : 1.0;
+  });
+}
+
+// Streaming ceiling of this device, measured with the library's own copy kernel (16 B/lane, non-temporal) on the handle's
+// stream: the figure bench.py reports next to the 8 TB/s spec, and -- its byte count being exact -- the kernel the
+// FETCH_SIZE / WRITE_SIZE counter corrections of profiles/summarize.py are calibrated on.
+int gmg_stream_probe(gmg_handle_t h, int64_t nbytes, int reps, double *gbytes_per_s)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && gbytes_per_s, GMG_ERR_INVALID, "null argument");
+    REQUIRE(nbytes >= 4096 && reps >= 1, GMG_ERR_INVALID, "bad probe size");
+    const int64_t n2 = nbytes / 16;
+    double *src = nullptr, *dst = nullptr;
+    HIP_CHECK(hipMalloc((void **)&src, (size_t)n2 * 16));
+    if (hipMalloc((void **)&dst, (size_t)n2 * 16) != hipSuccess) { (void)hipFree(src); throw GmgError{GMG_ERR_ALLOC, "probe buffers"}; }
+    HIP_CHECK(hipMemsetAsync(src, 0, (size_t)n2 * 16, h->stream));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    const int grid = (int)std::min<int64_t>((n2 + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, h->stream, n2, src, dst);   // warm-up
+    HIP_CHECK(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, h->stream, n2, src, dst);
+    HIP_CHECK(hipEventRecord(e1, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(dst);
+    *gbytes_per_s = 2.0 * 16.0 * (double)n2 * reps / ((double)ms * 1e-3) / 1e9;
   });
 }
 

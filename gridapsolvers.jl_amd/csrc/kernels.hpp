@@ -816,6 +816,16 @@ __global__ void prolong_correct_kernel(int64_t n, const double *__restrict__ c, 
   }
 }
 
+// dst = src, 16 B per lane, non-temporal: the streaming-ceiling probe (gmg_stream_probe).  Moves exactly 32*n2 bytes.
+__global__ __launch_bounds__(256) void stream_copy_kernel(int64_t n2, const double *__restrict__ src, double *__restrict__ dst)
+{
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 *s2 = reinterpret_cast<const d2 *>(src);
+  d2 *t2 = reinterpret_cast<d2 *>(dst);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(s2 + i), t2 + i);
+}
+
 // s = omega*(dinv.*r)  (first sweep of a ONEG smoothing pass)
 __global__ void scaled_jacobi_kernel(int64_t n, double omega, const double *__restrict__ dinv,
                                      const double *__restrict__ r, double *__restrict__ s)

@@ -29,6 +29,7 @@ import numpy as np
 __all__ = [
     "CSR", "poisson_matrix", "prolongation", "dirichlet_lift_rhs", "nodal_values",
     "l2_error_sq", "vertex_star_patches", "coarse_cell_interior_patches", "build_hierarchy", "random_rhs", "level_sizes",
+    "poisson_matrix_varcoef", "smooth_kappa",
 ]
 
 
@@ -199,6 +200,79 @@ def poisson_matrix(ncells, order=1, lengths=None) -> CSR:
     if d == 3:
         terms.append((M[0], M[1], K[2]))
     return _tensor_csr(cols, terms, ncols)
+
+
+def smooth_kappa(X, Y, Z):
+    """The smooth, strictly positive diffusion coefficient of the variable-coefficient bench / test leg."""
+    return 1.0 + 0.5 * np.sin(2.0 * np.pi * X + 0.3) * np.cos(3.0 * Y + 0.1) * np.sin(1.7 * np.pi * Z + 0.7) + 0.25 * X * Y
+
+
+def poisson_matrix_varcoef(ncells, kappa=None, lengths=None) -> CSR:
+    """Free-free block of the Q1 stiffness matrix of  a(u,v) = int kappa(x) grad(v).grad(u)  with kappa evaluated at the
+    cell centres (one-point coefficient quadrature), Dirichlet on the whole boundary.  Same structural pattern as
+    `poisson_matrix` (3^d entries per interior row, exact zeros included), but -- kappa being smooth and non-constant --
+    (almost) every row is distinct, which is what a variable-coefficient or mapped-mesh problem hands to the solver:
+    no row-pattern dictionary or value dictionary applies and the operator is streamed as 12 B per stored nonzero."""
+    nc, d = _dims(ncells)
+    if kappa is None:
+        kappa = smooth_kappa
+    Ls = _lengths(lengths, d)
+    h = [Ls[k] / nc[k] for k in range(3)]
+    # element matrices of the d-linear element, kappa = 1: tensor products of the 1-D blocks
+    K1 = [_elem_1d(1, h[k])[0] if k < d else np.ones((1, 1)) for k in range(3)]
+    M1 = [_elem_1d(1, h[k])[1] if k < d else np.ones((1, 1)) for k in range(3)]
+    loc = [2 if k < d else 1 for k in range(3)]
+
+    def ke(ax, bx, ay, by, az, bz):
+        v = K1[0][ax, bx] * M1[1][ay, by] * M1[2][az, bz] + M1[0][ax, bx] * K1[1][ay, by] * M1[2][az, bz]
+        if d == 3:
+            v = v + M1[0][ax, bx] * M1[1][ay, by] * K1[2][az, bz]
+        return v
+
+    # cell-centre coefficient, padded by one layer of zeros so that "cells outside the mesh" contribute nothing
+    xs = [(np.arange(nc[k]) + 0.5) * h[k] if k < d else np.zeros(1) for k in range(3)]
+    Zc, Yc, Xc = np.meshgrid(xs[2], xs[1], xs[0], indexing="ij")
+    kap = np.asarray(kappa(Xc, Yc, Zc), dtype=np.float64)
+    nf = [nc[k] - 1 if k < d else 1 for k in range(3)]                  # free nodes per axis
+    N = nf[0] * nf[1] * nf[2]
+    offs = [(-1, 0, 1) if k < d else (0,) for k in range(3)]
+    W = len(offs[0]) * len(offs[1]) * len(offs[2])
+    vals = np.zeros((nf[2], nf[1], nf[0], W))
+    # node (i,j,k) (free numbering, mesh node = i+1) touches cells (i+a, j+b, k+c), a,b,c in {0,1}; inside such a cell it is
+    # local node (1-a,1-b,1-c) and the neighbour at node offset (ox,oy,oz) is local node (1-a+ox, ...) when that is in {0,1}
+    sl = []
+    for a in range(loc[0]):
+        for b in range(loc[1]):
+            for c in range(loc[2]):
+                kc = kap[(slice(c, c + nf[2]) if d == 3 else slice(0, 1)), b:b + nf[1], a:a + nf[0]]
+                la, lb, lc = (1 - a if loc[0] == 2 else 0), (1 - b if loc[1] == 2 else 0), (1 - c if loc[2] == 2 else 0)
+                w = 0
+                for oz in offs[2]:
+                    for oy in offs[1]:
+                        for ox in offs[0]:
+                            ma, mb, mc = la + ox, lb + oy, lc + oz
+                            if 0 <= ma < loc[0] and 0 <= mb < loc[1] and 0 <= mc < loc[2]:
+                                vals[..., w] += kc * ke(la, ma, lb, mb, lc, mc)
+                            w += 1
+    # columns + Dirichlet pruning
+    I = np.arange(nf[0])[None, None, :]
+    J = np.arange(nf[1])[None, :, None]
+    Kk = np.arange(nf[2])[:, None, None]
+    cols = np.empty((nf[2], nf[1], nf[0], W), dtype=np.int64)
+    keep = np.empty((nf[2], nf[1], nf[0], W), dtype=bool)
+    w = 0
+    for oz in offs[2]:
+        for oy in offs[1]:
+            for ox in offs[0]:
+                ii, jj, kk = I + ox, J + oy, Kk + oz
+                ok = (ii >= 0) & (ii < nf[0]) & (jj >= 0) & (jj < nf[1]) & (kk >= 0) & (kk < nf[2])
+                keep[..., w] = ok
+                cols[..., w] = (kk * nf[1] + jj) * nf[0] + ii
+                w += 1
+    keep = keep.reshape(N, W)
+    ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(keep.sum(axis=1), out=ptr[1:])
+    return CSR((N, N), ptr, cols.reshape(N, W)[keep].astype(np.int32), vals.reshape(N, W)[keep])
 
 
 def _interp_1d(nc_coarse, order):
@@ -374,8 +448,10 @@ def coarse_cell_interior_patches(ncells_coarse, order=1):
     return np.asarray(ptr, dtype=np.int64), np.concatenate(dofs).astype(np.int32)
 
 
-def build_hierarchy(ncells_fine, nlevels, order=1, lengths=None):
+def build_hierarchy(ncells_fine, nlevels, order=1, lengths=None, kappa=None):
     """Level 1 = finest (reference convention, ModelHierarchies.jl:80-111).
+    kappa (Q1 only): callable kappa(X,Y,Z) -> every level is the re-discretised variable-coefficient operator
+    (GMGLinearSolvers.jl:342-353 assembles the level matrices from the weak form per level).
 
     Returns dict(mats=[A_1..A_L], prolongations=[P_1..P_{L-1}] (P_l: level l+1 -> l),
     restrictions=[R_l = P_l^T], ncells=[...], order=order)."""
@@ -384,7 +460,12 @@ def build_hierarchy(ncells_fine, nlevels, order=1, lengths=None):
     for l in range(nlevels):
         if any(cells[l][k] * 2 ** l != nc[k] or cells[l][k] < 2 for k in range(len(nc))):
             raise ValueError("ncells must be divisible by 2^(nlevels-1) with >=2 coarsest cells")
-    mats = [poisson_matrix(c, order, lengths) for c in cells]
+    if kappa is not None:
+        if order != 1:
+            raise ValueError("variable-coefficient generator is Q1 only")
+        mats = [poisson_matrix_varcoef(c, kappa, lengths) for c in cells]
+    else:
+        mats = [poisson_matrix(c, order, lengths) for c in cells]
     Ps = [prolongation(cells[l + 1], order) for l in range(nlevels - 1)]
     Rs = [P.transpose() for P in Ps]
     return dict(mats=mats, prolongations=Ps, restrictions=Rs, ncells=cells, order=order)

@@ -155,6 +155,7 @@ class GMGLinearSolver:
         self.smatrices, self.interp, self.restrict = list(smatrices), list(interp), list(restrict)
         self.pre_smoothers, self.post_smoothers = list(pre_smoothers), list(post_smoothers)
         self.mode, self.cycle_type = mode, cycle_type
+        self.verbose = int(verbose)
         self.log = ConvergenceLog("GMG", maxiter, atol, rtol)
 
     def num_levels(self):
@@ -354,6 +355,7 @@ class GMGNumericalSetup:
                 self._set_smoother(l, abi.PRE, pre)
                 self._set_smoother(l, abi.POST, post)
         abi.check(h, lib.gmg_set_options(h, _MODES[s.mode], _CYCLES[s.cycle_type], s.log.maxiter, s.log.atol, s.log.rtol))
+        abi.check(h, lib.gmg_set_verbose(h, s.verbose))
         abi.check(h, lib.gmg_setup(h))
         self.n = int(_csr_fields(mats[0])[0][0])
         self.sizes = [int(_csr_fields(A)[0][0]) for A in mats]
@@ -431,13 +433,28 @@ class GMGNumericalSetup:
         abi.check(self.h, self._lib.gmg_dot(self.h, n, pa, pb, ms, C.byref(out)))
         return out.value
 
+    def fill_log(self):
+        """ns.solver.log of the GMG after it ran inside a Krylov call (gmg_get_log)."""
+        log = self.solver.log
+        res = abi.Result()
+        hist = np.zeros(log.maxiter + 1)
+        abi.check(self.h, self._lib.gmg_get_log(self.h, C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
+        log._fill(res, hist)
+        return log
+
     def profile(self, lev=0, enable=True):
         abi.check(self.h, self._lib.gmg_profile_enable(self.h, lev, 1 if enable else 0))
 
     def kernel_stats(self):
         st = abi.KernelStats()
         abi.check(self.h, self._lib.gmg_get_kernel_stats(self.h, C.byref(st)))
-        return dict(launches=st.launches, total_ms=st.total_ms, alg_bytes=st.alg_bytes, rows=st.rows, nnz=st.nnz)
+        return dict(launches=st.launches, total_ms=st.total_ms, alg_bytes=st.alg_bytes, rows=st.rows, nnz=st.nnz,
+                    layout_bytes=st.layout_bytes)
+
+    def stream_probe(self, nbytes=1 << 30, reps=10):
+        v = C.c_double(0.0)
+        abi.check(self.h, self._lib.gmg_stream_probe(self.h, nbytes, reps, C.byref(v)))
+        return v.value
 
     def model_bytes(self):
         a, b = C.c_double(0.0), C.c_double(0.0)
@@ -702,6 +719,8 @@ def solve_(x, ns, b):
                                                    log.atol, log.rtol, ns.pc_kind, C.byref(res),
                                                    C.c_void_p(hist.ctypes.data), hist.size))
         log._fill(res, hist)
+        if ns.pc_kind == 1:
+            g.fill_log()
         return x
     raise TypeError(f"no solve! for {type(ns).__name__}")
 

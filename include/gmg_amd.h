@@ -76,6 +76,9 @@ typedef struct {
   double total_ms;         /* sum of HIP-event durations on the handle's stream */
   double alg_bytes;        /* algorithmic bytes of ONE launch (SURVEY 8d byte model) */
   int64_t rows, nnz;       /* shape of the operator the kernel streams */
+  double layout_bytes;     /* bytes ONE launch moves with the storage layout chosen at setup (matrix stream as
+                              stored + row-wise vectors, each once): equals alg_bytes only for the plain 12 B/nnz
+                              layouts; far smaller for the row-pattern / dictionary layouts */
 } gmg_kernel_stats;
 
 /* ---- lifetime ------------------------------------------------------------- */
@@ -127,6 +130,14 @@ GMG_API int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int k
 /* ---- solver options --------------------------------------------------------- */
 /* kwargs of GMGLinearSolver: mode, cycle_type, maxiter, atol, rtol (GMGLinearSolvers.jl:56-58). */
 GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, double atol, double rtol);
+
+/* kwarg `verbose` of GMGLinearSolver (GMGLinearSolvers.jl:58).  The library never prints; verbose > 0 makes the GMG's own
+ * ConvergenceLog complete on every path: as a preconditioner with maxiter = 1 inside gmg_cg_solve / gmg_fgmres_solve the
+ * post-cycle norm(rh) of GMGLinearSolvers.jl:639 only feeds that log (update! returns true at maxiter regardless), so
+ * with verbose = 0 (default) it is not evaluated and residuals[2] of the GMG log reads NaN. */
+GMG_API int gmg_set_verbose(gmg_handle_t h, int verbose);
+/* ns.solver.log of the GMG after the last solve!/ldiv! (also when it ran as a preconditioner inside a Krylov call). */
+GMG_API int gmg_get_log(gmg_handle_t h, gmg_result *res, double *hist, int hist_cap);
 
 /* numerical_setup(ss,A): GMGLinearSolvers.jl:183-210 -- uploads operators, builds
  * D^-1, R = P^T, patch factors, work vectors and the coarse solver
@@ -224,6 +235,9 @@ GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_ite
  * padding factor. */
 GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
                              double *stream_bytes_per_nnz, double *padding);
+/* Measured streaming ceiling: a 16 B/lane copy kernel over nbytes (read) + nbytes (write), reps launches timed with HIP
+ * events on the handle's stream; *gbytes_per_s = moved bytes / time.  Reported by bench.py beside the 8 TB/s spec. */
+GMG_API int gmg_stream_probe(gmg_handle_t h, int64_t nbytes, int reps, double *gbytes_per_s);
 /* Device memory held by the handle, bytes. */
 GMG_API int gmg_device_bytes(gmg_handle_t h, int64_t *bytes);
 

@@ -1034,3 +1034,12 @@ ORC_API int orc_threads(void)
   return 1;
 #endif
 }
+
+/* cpu_baseline only: dst = src copied by the same static row-block schedule the OpenMP loops use, so that the pages of
+ * the operator arrays are first touched (NUMA-placed) by the threads that will stream them.  `dst` must be untouched
+ * memory (np.empty).  elem = bytes per element, n = elements. */
+ORC_API void orc_parallel_copy(void *dst, const void *src, i64 n, int elem)
+{
+  ORC_PFOR
+  for (i64 i = 0; i < n; ++i) memcpy((char *)dst + (size_t)i * elem, (const char *)src + (size_t)i * elem, (size_t)elem);
+}

@@ -1,28 +1,47 @@
 #!/usr/bin/env python3
-"""Summarises rocprofv3 rocpd databases (gpurun_out/prof_<tag>/{trace,fetch,write}/*.db)
-into the text files committed under profiles/.
+"""Summarises rocprofv3 rocpd databases (gpurun_out/prof_<tag>/{trace,fetch,write}/*.db) into the text files
+committed under profiles/.
 
-    python profiles/summarize.py gpurun_out/prof_r01 profiles/r01
+    python profiles/summarize.py gpurun_out/prof_r02 profiles/r02 [--cells 128 --levels 4 --cmd "..."]
 
-Writes <out>_kernel_stats.txt (the `--kernel-trace --stats` view: per kernel and per
-grid size, so multigrid levels are told apart) and <out>_hbm_traffic.txt / .json
-(FETCH_SIZE / WRITE_SIZE per launch of the dominant kernel, separate --pmc passes).
-gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly 1/2 of
-the bytes of a wide coalesced streaming read -> doubled before use; units are KiB."""
+Writes <out>_kernel_stats.txt (the `--kernel-trace --stats` view: per kernel and per grid size, so multigrid levels
+are told apart) and <out>_hbm_traffic.txt / .json (FETCH_SIZE / WRITE_SIZE per launch of the finest-level fused sweep
+kernels, separate --pmc passes) and refreshes profiles/traffic_latest.json, which bench.py attaches as
+`roofline.traffic` only when kernel family / problem / row count match its own run.
+
+Counter corrections (MI355X_MICROARCH.md, HBM section): units are KiB; on gfx950 FETCH_SIZE reports half of the bytes
+of a wide coalesced streaming read.  Both factors are CALIBRATED in the same passes on `stream_copy_kernel`
+(gmg_stream_probe: exactly 2^30 B read + 2^30 B written per launch) and the calibrated factors are what is applied;
+the guide's x2 / x1 are the fallback when the probe kernel is absent."""
+import argparse
 import glob
 import json
 import os
 import sqlite3
-import sys
 
 
 def db(path):
-    f = glob.glob(os.path.join(path, "*.db"))
+    f = glob.glob(os.path.join(path, "**", "*.db"), recursive=True)
     return sqlite3.connect(f[0]) if f else None
 
 
+def family(name):
+    for fam in ("sells_kernel", "sellp_kernel", "sellc_kernel", "sell_kernel", "csr_stream1_kernel"):
+        if "gmg::" + fam + "<" in name:
+            return fam
+    return None
+
+
 def main():
-    src, out = sys.argv[1], sys.argv[2]
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("out")
+    ap.add_argument("--cells", type=int, default=128)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--cmd", default="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
+    ap.add_argument("--no-latest", action="store_true")
+    a = ap.parse_args()
+    src, out = a.src, a.out
     lines = []
     con = db(os.path.join(src, "trace"))
     rows = con.execute(
@@ -30,48 +49,67 @@ def main():
         "min(end-start)/1e3, max(end-start)/1e3, max(vgpr_count), max(sgpr_count), max(lds_size) "
         "from kernels group by name, grid_x order by 5 desc").fetchall()
     tot = sum(r[4] for r in rows)
-    lines.append(f"# rocprofv3 --kernel-trace --stats : python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
+    lines.append(f"# rocprofv3 --kernel-trace --stats : {a.cmd}")
     lines.append(f"# total kernel time {tot/1e3:.3f} ms ; columns: calls total_us avg_us min_us max_us pct | grid wg vgpr sgpr lds")
     for r in rows:
         lines.append(f"{r[3]:6d} {r[4]:12.1f} {r[5]:9.2f} {r[6]:9.2f} {r[7]:9.2f} {100*r[4]/tot:5.1f}% | "
-                     f"{r[1]:8d} {r[2]:4d} {r[8]:4d} {r[9]:4d} {r[10]:6d} | {r[0][:100]}")
+                     f"{r[1]:8d} {r[2]:4d} {r[8]:4d} {r[9]:4d} {r[10]:6d} | {r[0][:110]}")
     open(out + "_kernel_stats.txt", "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[:14]))
+    print("\n".join(lines[:16]))
 
-    # The bench command runs the product path (steps+warmup solves) and then a shorter pass with the
-    # operator compression switched off (roofline_generic).  Dominant kernel of the PRODUCT path = the fused
-    # sweep (EPI_SWEEP = 3) with the most launches; the generic pass' sweep is reported next to it.
-    sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*), sum(end-start) from kernels "
-                     "where name like '%_kernel<3,%' group by name, grid_x order by count(*) desc, sum(end-start) desc").fetchall()
-    tl, res = [], {}
-    picks = [("", sw[0])]
-    for r in sw[1:]:
-        if r[0] != sw[0][0] and r[4] == max(q[4] for q in sw if q[0] != sw[0][0]):
-            picks.append(("generic_", r))
-    for prefix, dom in picks:
-        res[prefix + "kernel"] = dom[0]; res[prefix + "grid_x"] = dom[1]
-        res[prefix + "avg_us_kernel_trace"] = dom[2]; res[prefix + "launches"] = dom[3]
-        tl.append(f"# {'product' if not prefix else 'uncompressed (roofline_generic) pass'}: {dom[0]} grid_x={dom[1]} avg {dom[2]:.2f} us over {dom[3]} launches (kernel-trace pass)")
-        for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-            c = db(os.path.join(src, sub))
-            if c is None:
-                continue
-            r = c.execute("select avg(value), min(value), max(value), count(*), avg(end-start)/1e3 from counters_collection "
-                          "where counter_name=? and kernel_name=? and grid_size_x=?", (cname, dom[0], dom[1])).fetchone()
-            if r and r[3]:
-                res[prefix + cname + "_KiB_avg"] = r[0]
-                res[prefix + cname + "_launches"] = r[3]
-                res[prefix + cname + "_pass_avg_us"] = r[4]
-                tl.append(f"{cname}: avg {r[0]:.1f} KiB (min {r[1]:.1f} max {r[2]:.1f}) over {r[3]} launches, avg {r[4]:.2f} us in that pass")
-        if prefix + "FETCH_SIZE_KiB_avg" in res and prefix + "WRITE_SIZE_KiB_avg" in res:
-            fetch = 2.0 * res[prefix + "FETCH_SIZE_KiB_avg"] * 1024.0     # gfx950: x2 for wide coalesced streams
-            write = res[prefix + "WRITE_SIZE_KiB_avg"] * 1024.0
-            res[(prefix or "sweep_") + "hbm_bytes_per_launch"] = fetch + write
-            res[prefix + "fetch_bytes_corrected"] = fetch
-            res[prefix + "write_bytes"] = write
-            tl.append(f"HBM traffic per launch = 2*FETCH_SIZE + WRITE_SIZE = {fetch/1e6:.1f} MB + {write/1e6:.1f} MB = {(fetch+write)/1e6:.1f} MB")
+    cdb = {c: db(os.path.join(src, sub)) for c, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"))}
+
+    def counter(cname, kname, grid):
+        c = cdb[cname]
+        if c is None:
+            return None
+        r = c.execute("select avg(value), min(value), max(value), count(*), avg(end-start)/1e3 from counters_collection "
+                      "where counter_name=? and kernel_name=? and grid_size_x=?", (cname, kname, grid)).fetchone()
+        return r if r and r[3] else None
+
+    tl = []
+    # ---- calibration on the copy probe (exact byte counts) ----
+    ffac, wfac, cal = 2.0, 1.0, "guide defaults (x2 FETCH_SIZE, x1 WRITE_SIZE): probe kernel not found"
+    pk = con.execute("select name, grid_x, count(*) from kernels where name like '%stream_copy_kernel%' group by name, grid_x").fetchall()
+    if pk:
+        f = counter("FETCH_SIZE", pk[0][0], pk[0][1])
+        w = counter("WRITE_SIZE", pk[0][0], pk[0][1])
+        exact = float(1 << 30)
+        if f and w:
+            ffac, wfac = exact / (f[0] * 1024.0), exact / (w[0] * 1024.0)
+            cal = (f"calibrated on stream_copy_kernel (2^30 B read + 2^30 B written per launch): FETCH_SIZE avg {f[0]:.0f} KiB -> x{ffac:.3f}, "
+                   f"WRITE_SIZE avg {w[0]:.0f} KiB -> x{wfac:.3f}")
+    tl.append("# counter corrections: " + cal)
+
+    # ---- finest-level fused sweeps (EPI_SWEEP = 3): per kernel name the largest grid ----
+    sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%_kernel<3,%' "
+                     "group by name, grid_x order by grid_x desc").fetchall()
+    seen, recs = set(), []
+    nrows = (a.cells - 1) ** 3
+    for name, grid, avg_us, cnt in sw:
+        fam = family(name)
+        if fam is None or name in seen:
+            continue
+        seen.add(name)
+        rec = dict(family=fam, kernel=name, grid_x=grid, avg_us_kernel_trace=avg_us, launches=cnt, cells=a.cells, levels=a.levels, rows=nrows)
+        tl.append(f"# {name} grid_x={grid}: avg {avg_us:.2f} us over {cnt} launches (kernel-trace pass)")
+        f = counter("FETCH_SIZE", name, grid)
+        w = counter("WRITE_SIZE", name, grid)
+        if f and w:
+            fb, wb = ffac * f[0] * 1024.0, wfac * w[0] * 1024.0
+            rec.update(FETCH_SIZE_KiB_avg=f[0], WRITE_SIZE_KiB_avg=w[0], fetch_bytes_corrected=fb, write_bytes_corrected=wb,
+                       hbm_bytes_per_launch=fb + wb, fetch_factor=ffac, write_factor=wfac,
+                       pass_avg_us=dict(fetch=f[4], write=w[4]))
+            tl.append(f"  FETCH_SIZE avg {f[0]:.1f} KiB (min {f[1]:.1f} max {f[2]:.1f}, {f[3]} launches, {f[4]:.2f} us in that pass); "
+                      f"WRITE_SIZE avg {w[0]:.1f} KiB (min {w[1]:.1f} max {w[2]:.1f}, {w[3]} launches, {w[4]:.2f} us)")
+            tl.append(f"  HBM traffic per launch = {ffac:.3f}*FETCH + {wfac:.3f}*WRITE = {fb/1e6:.1f} MB + {wb/1e6:.1f} MB = {(fb+wb)/1e6:.1f} MB "
+                      f"-> {(fb+wb)/avg_us/1e3:.0f} GB/s at the kernel-trace duration")
+        recs.append(rec)
+    res = dict(tag=os.path.basename(out), command=a.cmd, calibration=cal, kernels=recs)
     open(out + "_hbm_traffic.txt", "w").write("\n".join(tl) + "\n")
     json.dump(res, open(out + "_hbm_traffic.json", "w"), indent=1)
+    if not a.no_latest:
+        json.dump(res, open(os.path.join(os.path.dirname(os.path.abspath(out)), "traffic_latest.json"), "w"), indent=1)
     print("\n".join(tl))
 
 

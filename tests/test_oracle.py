@@ -342,3 +342,46 @@ def test_fgmres_block_triangular_gmg_stokes_like(po, orc, hierarchy):
     x, nit, flag, hist = orc.fgmres_solve(K, b, Pr=P, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
     assert flag in (0, 1) and nit < 100
     assert np.linalg.norm(K.to_scipy() @ x - b) < 1e-7      # StokesGMG.jl:166 @test norm(r) < 1.e-7
+
+
+# ---------------------------------------------------------------- round 2: variable-coefficient inputs, cpu_baseline child
+def test_varcoef_generator_reduces_to_constant_and_is_spd(po):
+    import scipy.sparse.linalg as sl
+    for nc in [(8, 8, 8), (6, 10, 4), (12, 8)]:
+        A = po.poisson_matrix(nc, 1)
+        B = po.poisson_matrix_varcoef(nc, lambda X, Y, Z: np.ones_like(X))
+        assert (A.ptr == B.ptr).all() and (A.idx == B.idx).all()
+        assert np.abs(A.val - B.val).max() <= 4e-16 * np.abs(A.val).max()
+    V = po.poisson_matrix_varcoef((12, 12, 12))
+    Sv = V.to_scipy()
+    assert abs(Sv - Sv.T).max() == 0.0
+    assert sl.eigsh(Sv, k=1, which="SA")[0][0] > 0
+    # (almost) every row distinct: what forces the generic storage layout
+    assert len(np.unique(V.val)) > 0.1 * V.nnz
+
+
+def test_varcoef_cg_gmg_oracle_converges_like_constant(po, orc):
+    nc, nlev = (16, 16, 16), 3
+    H = po.build_hierarchy(nc, nlev, 1, kappa=po.smooth_kappa)
+    uex = po.nodal_values(nc, 1)
+    b = H["mats"][0].matvec(uex)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    x, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=g, maxiter=30, atol=1e-14, rtol=1e-8)
+    assert flag == 1 and nit <= 8
+    assert np.max(np.abs(x - uex)) < 1e-6
+
+
+def test_cpu_baseline_child_runs_both_variants():
+    """bench.py's cpu_baseline leg: the child process times the sequential checker and the OpenMP build and agrees on iterations."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for variant, thr in (("seq", 1), ("omp", 2)):
+        env = dict(os.environ, OMP_NUM_THREADS=str(thr), OMP_PROC_BIND="close")
+        p = subprocess.run([sys.executable, os.path.join(root, "oracle", "cpu_baseline.py"), "--cells", "16", "--levels", "3",
+                            "--variant", variant, "--limit-s", "0", "--max-reps", "1"], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-500:]
+        outs[variant] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert outs["seq"]["threads"] == 1 and outs["omp"]["threads"] == 2
+    assert outs["seq"]["iters"] == outs["omp"]["iters"] == 3
+    np.testing.assert_allclose(outs["seq"]["hist"], outs["omp"]["hist"], rtol=1e-9)
