@@ -16,6 +16,7 @@ CONVERGED_ATOL, CONVERGED_RTOL, DIVERGED_MAXITER, DIVERGED_BREAKDOWN = 0, 1, 2, 
 PRE, POST, PRE_AND_POST = 0, 1, 2
 PATCH_LU, PATCH_NOPIVOT = 0, 1
 OP_A, OP_P, OP_R = 0, 1, 2
+COARSE_DENSE_INVERSE, COARSE_CG_JACOBI, COARSE_HOST_CALLBACK = 0, 1, 2
 BLOCK_DIAGONAL, BLOCK_LOWER, BLOCK_UPPER = 0, 1, 2
 BLOCK_GMG, BLOCK_CG_JACOBI, BLOCK_LU, BLOCK_JACOBI = 1, 2, 3, 4
 
@@ -47,6 +48,8 @@ SYMBOLS = {
                                C.c_void_p, C.c_int, C.c_int],
     "gmg_set_prolongation_patch_correction": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int],
+    "gmg_set_coarse_solver": [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
+    "gmg_get_coarse_log": [C.c_void_p, C.POINTER(Result)],
     "gmg_set_options": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double],
     "gmg_setup": [C.c_void_p],
     "gmg_set_verbose": [C.c_void_p, C.c_int],
@@ -102,6 +105,7 @@ SYMBOLS = {
 HOST_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64))
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+COARSE_SOLVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 _LIB = None
 

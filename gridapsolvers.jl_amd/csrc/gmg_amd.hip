@@ -349,6 +349,8 @@ struct KrylovOps {
 
 struct gmg_block_solver;
 static void block_forget(gmg_block_solver *B, gmg_solver *g);   // block.inc.hpp
+static double cg_core(gmg_solver &S, int64_t n, const double *db, double *dx, double *w, double *p, double *z, double *r,
+                      const KrylovOps &ops, bool flexible, ConvLog &log);
 
 struct gmg_solver {
   gmg_block_solver *attached_to = nullptr;   // block preconditioner that borrowed this handle (gmg_block_set_diag_gmg + setup)
@@ -368,8 +370,19 @@ struct gmg_solver {
   double log_last = 0.0;             // last residual norm the GMG's own log saw (NaN: not evaluated, see gmg_set_verbose)
   int verbose = 0;                   // GMGLinearSolver(...; verbose): > 0 keeps the log complete on every path
 
-  // coarse solver
+  // coarse solver (coarsest_solver kwarg, GMGLinearSolvers.jl:54,423-434)
   double *d_Ainv = nullptr;
+  int coarse_kind = GMG_COARSE_DENSE_INVERSE;
+  int coarse_maxiter = 1000;                 // CGSolver defaults, CGSolvers.jl:19
+  double coarse_atol = 1e-12, coarse_rtol = 1e-6;
+  gmg_coarse_solve_fn coarse_fn = nullptr;
+  void *coarse_ctx = nullptr;
+  ConvLog coarse_log;
+  double coarse_last = 0.0;
+  double *cc_w = nullptr, *cc_p = nullptr, *cc_z = nullptr, *cc_r = nullptr;   // CGSolvers.jl:42-48 on the coarsest level
+  double *h_cr = nullptr, *h_cx = nullptr;   // pinned staging of the host callback
+  bool reduce_local = false;                 // reductions over a REPLICATED vector: no all-reduce across ranks
+  int krylov_depth = 0;                      // nesting of cg_core calls (each level owns its scalar slots)
   // distributed runs: levels >= rep_from are REPLICATED (every rank holds the global operators and
   // computes them redundantly, no halo traffic on small levels).  The restricted residual of the last
   // distributed level is assembled with one all-reduce (own rows scattered by global id).
@@ -504,6 +517,7 @@ struct gmg_solver {
       L.s0_ready = false;
     }
     d_Ainv = d_partials = d_scalars = nullptr;
+    cc_w = cc_p = cc_z = cc_r = nullptr;
     d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr;
     for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; L.halo.d_pk_ptr = nullptr; L.halo.d_pk_slot = nullptr; }
     cg_w = cg_p = cg_z = cg_r = st_b = st_x = nullptr;
@@ -1172,7 +1186,7 @@ struct gmg_solver {
   // inside dot/norm on a PVector), then the square root.
   void finish_reduction(int nb, int slot, bool take_sqrt)
   {
-    const bool dist = comm.nranks > 1;
+    const bool dist = comm.nranks > 1 && !reduce_local;
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, stream, nb, d_partials, d_scalars + slot,
                        (take_sqrt && !dist) ? 1 : 0);
     HIP_CHECK(hipGetLastError());
@@ -1421,8 +1435,39 @@ struct gmg_solver {
     hipLaunchKernelGGL(dense_gemv_kernel, dim3(std::max(grid, 1)), dim3(kBlock), 0, stream, n, Ainv, r, x);
     HIP_CHECK(hipGetLastError());
   }
-  // (in distributed runs the coarsest level is replicated: same kernel, global matrix)
-  void coarse_solve(const double *r, double *x) { dense_solve(d_Ainv, (int)lev[nlev - 1].n, r, x); }
+  // solve!(xh, ns.coarsest_solver_cache, rh), GMGLinearSolvers.jl:474.  x arrives as fill!(dxH,0) (:487).
+  // (in distributed runs the coarsest level is replicated: same kernels, global matrix, local reductions)
+  void coarse_solve(const double *r, double *x)
+  {
+    Level &L = lev[nlev - 1];
+    const int64_t n = L.n;
+    if (coarse_kind == GMG_COARSE_DENSE_INVERSE) { dense_solve(d_Ainv, (int)n, r, x); return; }
+    if (coarse_kind == GMG_COARSE_CG_JACOBI) {
+      // CGSolver(JacobiLinearSolver(); maxiter, atol, rtol) on A_L, initial guess 0
+      zero(x, n);
+      KrylovOps ops;
+      ops.resid = [&](double *xx, const double *b, double *rr) { spmv_resid(L.A, xx, b, rr); };
+      ops.apply = [&](double *xx, double *yy) { spmv_set(L.A, xx, yy); };
+      ops.precond = [&, n](double *z, const double *rr, double) {
+        hipLaunchKernelGGL(jacobi_apply_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, L.dinv, rr, z);
+        HIP_CHECK(hipGetLastError());
+      };
+      coarse_log.configure(coarse_maxiter, coarse_atol, coarse_rtol);
+      const bool saved = reduce_local;
+      reduce_local = true;
+      try { coarse_last = cg_core(*this, n, r, x, cc_w, cc_p, cc_z, cc_r, ops, false, coarse_log); }
+      catch (...) { reduce_local = saved; throw; }
+      reduce_local = saved;
+      return;
+    }
+    // host callback: the caller's own LinearSolver (PETSc, UMFPACK ... in the Julia host) on host vectors
+    HIP_CHECK(hipMemcpyAsync(h_cr, r, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    std::memset(h_cx, 0, sizeof(double) * (size_t)n);
+    const int rc = coarse_fn(coarse_ctx, n, h_cr, h_cx);
+    REQUIRE(rc == 0, GMG_ERR_INVALID, "coarse-solver callback reported failure (" + std::to_string(rc) + ")");
+    HIP_CHECK(hipMemcpyAsync(x, h_cx, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
+  }
 
   // gmg_v_cycle! / gmg_w_cycle! / gmg_f_cycle!, GMGLinearSolvers.jl:468-610
   void cycle(int l, double *x, const double *r_in, bool x_zero, int ctype)
@@ -1644,7 +1689,12 @@ static double cg_core(gmg_solver &S, int64_t n, const double *db, double *dx, do
   // Scalars stay on the device: gamma (ping-pong), delta and dot(p,w) live in d_scalars and the vector
   // kernels form beta / alpha from them, so an iteration has ONE host round trip (the residual norm that
   // the stopping rule needs) instead of three.
-  constexpr int kG0 = kScalarSlots - 8, kG1 = kScalarSlots - 7, kDelta = kScalarSlots - 6, kPW = kScalarSlots - 5;
+  // A CG can run inside another Krylov solve (CG-Jacobi diagonal block or coarsest solver under an outer CG): every nesting
+  // level owns its four slots.
+  REQUIRE(S.krylov_depth < 4, GMG_ERR_UNSUPPORTED, "Krylov solvers nested deeper than 4");
+  struct Depth { int &d; Depth(int &x) : d(x) { ++d; } ~Depth() { --d; } } depth_guard(S.krylov_depth);
+  const int sbase = kScalarSlots - 8 * S.krylov_depth;
+  const int kG0 = sbase, kG1 = sbase + 1, kDelta = sbase + 2, kPW = sbase + 3;
   int g_old = kG0, g_new = kG1;
   ops.resid(dx, db, r);                                  // CGSolvers.jl:79  w = A x ; r = b - w
   // :80 fill!(p,0): folded into the first p = z + beta*p ; :81 fill!(z,0): only the flexible variant reads z before writing it
@@ -1727,7 +1777,7 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
         m += m_add;
       }
       if (j + 1 > hcap) grow_small(m + 1);
-      REQUIRE(j + 3 < kScalarSlots - 8, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer (use restart=true)");
+      REQUIRE(j + 3 < kScalarSlots - 40, GMG_ERR_UNSUPPORTED, "Krylov basis larger than the scalar buffer (use restart=true)");
       double *Vn = V[j], *Zj = Z[j - 1];
       // krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25
       if (ops.precond) ops.precond(Zj, V[j - 1], -1.0);
@@ -2023,7 +2073,15 @@ struct BandLU {
 
 void gmg_solver::build_coarse()
 {
-  d_Ainv = build_dense_inverse(lev[nlev - 1].hA, "coarsest-level matrix");
+  const int64_t n = lev[nlev - 1].n;
+  if (coarse_kind == GMG_COARSE_DENSE_INVERSE) d_Ainv = build_dense_inverse(lev[nlev - 1].hA, "coarsest-level matrix");
+  else if (coarse_kind == GMG_COARSE_CG_JACOBI) { cc_w = dvec(n); cc_p = dvec(n); cc_z = dvec(n); cc_r = dvec(n); }
+  else {
+    REQUIRE(coarse_fn, GMG_ERR_STATE, "coarse-solver callback missing");
+    if (h_cr) { (void)hipHostFree(h_cr); (void)hipHostFree(h_cx); h_cr = h_cx = nullptr; }
+    HIP_CHECK(hipHostMalloc((void **)&h_cr, sizeof(double) * (size_t)std::max<int64_t>(1, n)));
+    HIP_CHECK(hipHostMalloc((void **)&h_cx, sizeof(double) * (size_t)std::max<int64_t>(1, n)));
+  }
 }
 
 // LUSolver() on a small sparse matrix: row-major dense inverse on the device.
@@ -2251,6 +2309,11 @@ void gmg_solver::setup()
       drop_csr_stream(L.R);
       lap("D^-1, patch blocks", l);
     }
+    if (l == nlev - 1 && coarse_kind == GMG_COARSE_CG_JACOBI) {
+      int nzero = 0;
+      L.dinv = build_inv_diag(L.A, nzero);                  // JacobiLinearSolvers.jl:20-23 on the coarsest matrix
+      REQUIRE(nzero == 0, GMG_ERR_SINGULAR, "zero diagonal entry on the coarsest level");
+    }
     drop_csr_stream(L.A);
   }
   build_coarse();                                           // :195 gmg_coarse_solver_caches
@@ -2353,6 +2416,8 @@ int gmg_destroy(gmg_handle_t h)
     if (L.halo.h_recv) (void)hipHostFree(L.halo.h_recv);
   }
   if (h->h_rep_full) (void)hipHostFree(h->h_rep_full);
+  if (h->h_cr) (void)hipHostFree(h->h_cr);
+  if (h->h_cx) (void)hipHostFree(h->h_cx);
   if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
   if (h->comm.kind == COMM_RCCL && h->comm.comm) (void)h->comm.api.CommDestroy(h->comm.comm);
   if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
@@ -2488,6 +2553,30 @@ int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, double ato
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
     h->mode = mode; h->cycle_type = cycle;
     h->log.configure(maxiter, atol, rtol);
+  });
+}
+
+int gmg_set_coarse_solver(gmg_handle_t h, int kind, int maxiter, double atol, double rtol, gmg_coarse_solve_fn fn, void *ctx)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    REQUIRE(kind == GMG_COARSE_DENSE_INVERSE || kind == GMG_COARSE_CG_JACOBI || kind == GMG_COARSE_HOST_CALLBACK, GMG_ERR_INVALID,
+            "unknown coarse solver kind");
+    if (kind == GMG_COARSE_CG_JACOBI) REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
+    if (kind == GMG_COARSE_HOST_CALLBACK) REQUIRE(fn, GMG_ERR_INVALID, "null callback");
+    h->coarse_kind = kind;
+    if (kind == GMG_COARSE_CG_JACOBI) { h->coarse_maxiter = maxiter; h->coarse_atol = atol; h->coarse_rtol = rtol; }
+    h->coarse_fn = fn; h->coarse_ctx = ctx;
+    h->setup_done = false;
+  });
+}
+
+int gmg_get_coarse_log(gmg_handle_t h, gmg_result *res)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && res, GMG_ERR_INVALID, "null argument");
+    REQUIRE(h->coarse_kind == GMG_COARSE_CG_JACOBI && !h->coarse_log.residuals.empty(), GMG_ERR_STATE, "no iterative coarse solve has run");
+    h->coarse_log.export_to(res, nullptr, 0, h->coarse_last);
   });
 }
 

@@ -127,6 +127,22 @@ GMG_API int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int k
                                                   const void *patch_ptr, const void *patch_dofs,
                                                   int index_base, int index_bytes);
 
+/* ---- coarsest solver ---------------------------------------------------------- */
+/* kwarg `coarsest_solver` (GMGLinearSolvers.jl:54; cache :423-434; applied at :474).  The reference accepts any LinearSolver:
+ * default LUSolver(); its MPI tests / applications pass iterative or PETSc solvers (joss_paper/scalability/src/stokes_gmg.jl:41-63). */
+enum gmg_coarse_kind {
+  GMG_COARSE_DENSE_INVERSE = 0,  /* LUSolver(): exact; dense inverse built at setup, one GEMV per cycle (default) */
+  GMG_COARSE_CG_JACOBI = 1,      /* CGSolver(JacobiLinearSolver(); maxiter, atol, rtol) on the device, x0 = 0 (CGSolvers.jl:73-120) */
+  GMG_COARSE_HOST_CALLBACK = 2   /* the host language's own solver: fn(ctx, n, r, x) on HOST vectors, x pre-zeroed; returns 0 on success */
+};
+typedef int (*gmg_coarse_solve_fn)(void *ctx, int64_t n, const double *r, double *x);
+/* maxiter/atol/rtol: CG_JACOBI only.  fn/ctx: HOST_CALLBACK only (must stay valid while the handle is used; it is called
+ * from the thread that calls the solve entry point, once per cycle visit of the coarsest level). */
+GMG_API int gmg_set_coarse_solver(gmg_handle_t h, int kind, int maxiter, double atol, double rtol,
+                                  gmg_coarse_solve_fn fn, void *ctx);
+/* ConvergenceLog summary of the last iterative coarse solve (GMG_COARSE_CG_JACOBI). */
+GMG_API int gmg_get_coarse_log(gmg_handle_t h, gmg_result *res);
+
 /* ---- solver options --------------------------------------------------------- */
 /* kwargs of GMGLinearSolver: mode, cycle_type, maxiter, atol, rtol (GMGLinearSolvers.jl:56-58). */
 GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, double atol, double rtol);
@@ -141,8 +157,8 @@ GMG_API int gmg_get_log(gmg_handle_t h, gmg_result *res, double *hist, int hist_
 
 /* numerical_setup(ss,A): GMGLinearSolvers.jl:183-210 -- uploads operators, builds
  * D^-1, R = P^T, patch factors, work vectors and the coarse solver
- * (coarsest_solver = LUSolver(), :54,423-434 -> dense inverse applied as one GEMV per cycle;
- * factorised on the host up to 6000 dofs, inverted on the device above). */
+ * (default coarsest_solver = LUSolver(), :54,423-434 -> dense inverse applied as one GEMV per cycle;
+ * factorised on the host up to 6000 dofs, inverted on the device above; see gmg_set_coarse_solver). */
 GMG_API int gmg_setup(gmg_handle_t h);
 
 /* ---- hot path ---------------------------------------------------------------- */

@@ -440,6 +440,11 @@ typedef struct {
   int nlev;
   orc_level *lev;
   orc_band *coarse;
+  /* coarsest_solver other than LUSolver(): CGSolver(JacobiLinearSolver();maxiter,atol,rtol) (GMGLinearSolvers.jl:54,423-434
+   * accept any LinearSolver; the reference's MPI tests and applications pass iterative / PETSc solvers) */
+  int coarse_cg, coarse_maxiter, coarse_niters;
+  double coarse_atol, coarse_rtol;
+  double *coarse_inv_diag;
   double *rh; /* finest_level_cache :391-396 */
   int mode, cycle;
   orc_log log;
@@ -500,6 +505,27 @@ ORC_API void orc_gmg_set_prolongation_correction(orc_gmg *g, int l, int kind, i6
 
 static double *dalloc(i64 n) { return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
 
+ORC_API void orc_gmg_set_coarse_cg(orc_gmg *g, int maxiter, double atol, double rtol)
+{
+  g->coarse_cg = 1; g->coarse_maxiter = maxiter; g->coarse_atol = atol; g->coarse_rtol = rtol;
+}
+ORC_API int orc_gmg_coarse_niters(const orc_gmg *g) { return g->coarse_niters; }
+ORC_API int orc_cg_solve(i64 n, const i64 *ptr, const i32 *idx, const double *val, int pc_kind, void *Pl,
+                         double *x, const double *b, int maxiter, double atol, double rtol,
+                         int flexible, int *niters, double *hist);
+/* solve!(xh, coarsest_solver_cache, rh) GMGLinearSolvers.jl:474 ; xh holds fill!(dxH,0) (:487) = CG's initial guess */
+static void coarse_solve(orc_gmg *g, double *xh, const double *rh)
+{
+  const orc_csr *A = &g->lev[g->nlev - 1].A;
+  if (g->coarse_cg) {
+    orc_cg_solve(A->n, A->ptr, A->idx, A->val, 2 /* ORC_PC_JACOBI */, g->coarse_inv_diag, xh, rh,
+                 g->coarse_maxiter, g->coarse_atol, g->coarse_rtol, 0, &g->coarse_niters, NULL);
+    return;
+  }
+  memcpy(xh, rh, (size_t)A->n * sizeof(double));
+  band_solve(g->coarse, xh);
+}
+
 /* numerical_setup(GMGSymbolicSetup,mat): GMGLinearSolvers.jl:183-210 */
 ORC_API void orc_gmg_setup(orc_gmg *g, int mode, int cycle, int maxiter, double atol, double rtol)
 {
@@ -517,6 +543,14 @@ ORC_API void orc_gmg_setup(orc_gmg *g, int mode, int cycle, int maxiter, double 
     if (L->has_pcorr) { smoother_setup(&L->pcorr, &L->A); L->ptmp = dalloc(n); L->pcor = dalloc(n); }
   }
   const orc_csr *AL = &g->lev[g->nlev - 1].A;
+  if (g->coarse_cg) {                                           /* JacobiLinearSolvers.jl:20-23 */
+    g->coarse_inv_diag = dalloc(AL->n);
+    for (i64 i = 0; i < AL->n; ++i) {
+      double d = 0.0;
+      for (i64 k = AL->ptr[i]; k < AL->ptr[i + 1]; ++k) if (AL->idx[k] == i) d += AL->val[k];
+      g->coarse_inv_diag[i] = 1.0 / d;
+    }
+  } else
   g->coarse = band_factor(AL->n, AL->ptr, AL->idx, AL->val); /* :423-434 */
 }
 
@@ -549,9 +583,7 @@ static void apply_restriction(const orc_level *L, const double *rh, double *rH)
 static void gmg_cycle(orc_gmg *g, int lev, double *xh, double *rh, int ctype)
 {
   if (lev == g->nlev - 1) {                                     /* :472-474 */
-    i64 n = g->lev[lev].A.n;
-    memcpy(xh, rh, (size_t)n * sizeof(double));
-    band_solve(g->coarse, xh);
+    coarse_solve(g, xh, rh);
     return;
   }
   orc_level *L = &g->lev[lev];
@@ -624,8 +656,8 @@ ORC_API void orc_gmg_restrict(orc_gmg *g, int l, const double *rh, double *rH)
 }
 ORC_API void orc_gmg_coarse_solve(orc_gmg *g, const double *rhs, double *x)
 {
-  memcpy(x, rhs, (size_t)g->lev[g->nlev - 1].A.n * sizeof(double));
-  band_solve(g->coarse, x);
+  for (i64 i = 0; i < g->lev[g->nlev - 1].A.n; ++i) x[i] = 0.0;
+  coarse_solve(g, x, rhs);
 }
 
 static void smoother_free(orc_smoother *s)
@@ -644,7 +676,8 @@ ORC_API void orc_gmg_destroy(orc_gmg *g)
     if (!L->post_is_pre) smoother_free(&L->post);
     if (L->has_pcorr) { smoother_free(&L->pcorr); free(L->ptmp); free(L->pcor); }
   }
-  band_free(g->coarse);
+  if (g->coarse) band_free(g->coarse);
+  free(g->coarse_inv_diag);
   free(g->rh); free(g->log.residuals); free(g->lev); free(g);
 }
 

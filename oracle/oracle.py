@@ -125,7 +125,8 @@ class GMG:
     """Mirror of GMGLinearSolver(smatrices, interp, restrict; ...) -> numerical setup."""
 
     def __init__(self, mats, prolongations, restrictions=None, pre_smoothers=None, post_smoothers=None,
-                 mode=PRECONDITIONER, cycle=V_CYCLE, maxiter=100, atol=1e-14, rtol=1e-8, prolongation_patches=None):
+                 mode=PRECONDITIONER, cycle=V_CYCLE, maxiter=100, atol=1e-14, rtol=1e-8, prolongation_patches=None,
+                 coarse_cg=None):
         L = lib()
         nlev = len(mats)
         assert len(prolongations) == nlev - 1
@@ -160,6 +161,8 @@ class GMG:
             else:
                 self._set_sm(l, 0, pre)
                 self._set_sm(l, 1, post)
+        if coarse_cg is not None:      # (maxiter, atol, rtol) of coarsest_solver = CGSolver(JacobiLinearSolver(); ...)
+            L.orc_gmg_set_coarse_cg(self.h, C.c_int(coarse_cg[0]), C.c_double(coarse_cg[1]), C.c_double(coarse_cg[2]))
         L.orc_gmg_setup(self.h, C.c_int(mode), C.c_int(cycle), C.c_int(maxiter), C.c_double(atol), C.c_double(rtol))
         self.maxiter = maxiter
 
