@@ -46,6 +46,8 @@ SYMBOLS = {
     "gmg_set_smoother_jacobi": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double],
     "gmg_set_smoother_patch": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_void_p,
                                C.c_void_p, C.c_int, C.c_int],
+    "gmg_set_smoother_patch_matrices": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "gmg_set_prolongation_patch_correction": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int],
     "gmg_set_coarse_solver": [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p],

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <atomic>
@@ -208,10 +209,18 @@ struct Smoother {
   int kind = SM_JACOBI;
   int niter = 10;             // GMGLinearSolvers.jl:52 default RichardsonSmoother(Jacobi,10)
   double omega = 1.0;         // RichardsonSmoothers.jl:28 default
-  // patch data (host copy kept until setup)
+  // patch data (host copy kept until setup; shared between the copies of a smoother)
   int patch_kind = GMG_PATCH_LU;
-  std::vector<int64_t> h_pptr;
-  std::vector<int32_t> h_pdofs;
+  struct Tables {
+    std::vector<int64_t> pptr;
+    std::vector<int32_t> prow;     // patch_rows: b[rows_p] is the local right-hand side   (PatchSolvers.jl:237-240)
+    std::vector<int32_t> pcol;     // patch_cols: x[cols_p] += x_p (:296); empty = patch_rows
+    // caller-assembled patch matrices (column-major n_p x n_p, concatenated) or their lu! factors + LAPACK pivots (1-based)
+    std::vector<double> blocks;
+    std::vector<int32_t> piv;
+    bool has_blocks = false, are_factors = false;
+  };
+  std::shared_ptr<Tables> tab;
   // device
   int64_t npatch = 0;
   int max_np = 0;
@@ -1841,136 +1850,240 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
 // ----------------------------------------------------------------------------
 void gmg_solver::build_patch(Level &L, Smoother &S)
 {
-  const int64_t npatch = (int64_t)S.h_pptr.size() - 1;
+  REQUIRE(S.tab, GMG_ERR_INVALID, "patch tables missing");
+  const Smoother::Tables &T = *S.tab;
+  const int64_t npatch = (int64_t)T.pptr.size() - 1;
   REQUIRE(npatch >= 0, GMG_ERR_INVALID, "patch_ptr missing");
   S.npatch = npatch;
+  const std::vector<int32_t> &pcolv = T.pcol.empty() ? T.prow : T.pcol;
   std::vector<int64_t> boff((size_t)npatch + 1, 0);
   int max_np = 0;
   for (int64_t p = 0; p < npatch; ++p) {
-    const int64_t np = S.h_pptr[p + 1] - S.h_pptr[p];
+    const int64_t np = T.pptr[p + 1] - T.pptr[p];
     REQUIRE(np >= 0, GMG_ERR_INVALID, "patch_ptr not monotone");
     boff[p + 1] = boff[p] + np * np;
     max_np = std::max<int>(max_np, (int)np);
   }
-  const int64_t ndof_entries = S.h_pptr[npatch];
+  const int64_t ndof_entries = T.pptr[npatch];
+  REQUIRE((int64_t)T.prow.size() == ndof_entries && (int64_t)pcolv.size() == ndof_entries, GMG_ERR_INVALID, "patch tables have the wrong length");
   for (int64_t q = 0; q < ndof_entries; ++q)
-    REQUIRE(S.h_pdofs[q] >= 0 && S.h_pdofs[q] < L.n, GMG_ERR_INVALID, "patch dof out of range");
+    REQUIRE(T.prow[q] >= 0 && T.prow[q] < L.n && pcolv[q] >= 0 && pcolv[q] < L.n, GMG_ERR_INVALID, "patch dof out of range");
+  if (T.has_blocks) REQUIRE((int64_t)T.blocks.size() == boff[npatch], GMG_ERR_INVALID, "patch blocks have the wrong total size");
   S.max_np = max_np;
-  S.d_pptr = upload(S.h_pptr);
-  S.d_pdofs = upload(S.h_pdofs);
-  S.d_boff = upload(boff);
-  S.d_binv = dalloc<double>((size_t)boff[npatch]);
+  S.d_pptr = upload(T.pptr);
+  S.d_pdofs = upload(T.prow);
+  int32_t *d_pcol = T.pcol.empty() ? S.d_pdofs : upload(T.pcol);
   S.d_contrib = dvec(ndof_entries + 1);                    // + one slot that stays 0.0: the padding target of the sliced incidence
   // dof -> contribution slots, ascending patch order (= reference loop order PatchSolvers.jl:288)
-  std::vector<int64_t> iptr((size_t)L.n + 1, 0), inc((size_t)ndof_entries);
-  for (int64_t q = 0; q < ndof_entries; ++q) iptr[S.h_pdofs[q] + 1]++;
-  for (int64_t i = 0; i < L.n; ++i) iptr[i + 1] += iptr[i];
   {
-    std::vector<int64_t> fill(iptr.begin(), iptr.end() - 1);
-    for (int64_t q = 0; q < ndof_entries; ++q) inc[fill[S.h_pdofs[q]]++] = q;
-  }
-  if (ndof_entries < (int64_t)INT32_MAX && L.n > 0) {
-    const int64_t ns = (L.n + 63) / 64;
-    std::vector<int64_t> soff((size_t)ns + 1, 0);
-    for (int64_t sl = 0; sl < ns; ++sl) {
-      int64_t w = 0;
-      for (int64_t i = sl * 64; i < std::min<int64_t>(L.n, sl * 64 + 64); ++i) w = std::max(w, iptr[i + 1] - iptr[i]);
-      soff[sl + 1] = soff[sl] + w * 64;
+    std::vector<int64_t> iptr((size_t)L.n + 1, 0), inc((size_t)ndof_entries);
+    for (int64_t q = 0; q < ndof_entries; ++q) iptr[pcolv[q] + 1]++;
+    for (int64_t i = 0; i < L.n; ++i) iptr[i + 1] += iptr[i];
+    {
+      std::vector<int64_t> fill(iptr.begin(), iptr.end() - 1);
+      for (int64_t q = 0; q < ndof_entries; ++q) inc[fill[pcolv[q]]++] = q;
     }
-    std::vector<int32_t> sinc((size_t)soff[ns], (int32_t)ndof_entries);   // padding -> the zero slot
-    parallel_for(ns, [&](int64_t sl) {
-      for (int l = 0; l < 64; ++l) {
-        const int64_t i = sl * 64 + l;
-        if (i >= L.n) break;
-        for (int64_t k = iptr[i]; k < iptr[i + 1]; ++k) sinc[(size_t)(soff[sl] + (k - iptr[i]) * 64 + l)] = (int32_t)inc[k];
+    if (ndof_entries < (int64_t)INT32_MAX && L.n > 0) {
+      const int64_t ns = (L.n + 63) / 64;
+      std::vector<int64_t> soff((size_t)ns + 1, 0);
+      for (int64_t sl = 0; sl < ns; ++sl) {
+        int64_t w = 0;
+        for (int64_t i = sl * 64; i < std::min<int64_t>(L.n, sl * 64 + 64); ++i) w = std::max(w, iptr[i + 1] - iptr[i]);
+        soff[sl + 1] = soff[sl] + w * 64;
       }
-    });
-    S.d_isoff = upload(soff);
-    S.d_isinc = upload_padded(sinc, 64);
-    S.d_iptr = nullptr; S.d_inc = nullptr;
-  } else {
-    S.d_iptr = upload(iptr);
-    S.d_inc = upload(inc);
-  }
-  // factorise in chunks so the scratch stays bounded
-  if (npatch > 0 && max_np > 0) {
-    const size_t per = (size_t)max_np * max_np;
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(npatch, (int64_t)((256u << 20) / (per * sizeof(double)))));
-    double *scratch = nullptr;
-    HIP_CHECK(hipMalloc((void **)&scratch, per * sizeof(double) * (size_t)chunk));
-    int *d_nsing = dalloc<int>(1);
-    HIP_CHECK(hipMemsetAsync(d_nsing, 0, sizeof(int), stream));
-    const int pivoting = (S.patch_kind == GMG_PATCH_LU) ? 1 : 0;
-    for (int64_t p0 = 0; p0 < npatch; p0 += chunk) {
-      const int64_t cnt = std::min(chunk, npatch - p0);
-      const int grid = (int)((cnt + 63) / 64);
-      // shift the patch tables instead of the patch id: pptr/boff are absolute
-      if (L.A.ptr64)
-        hipLaunchKernelGGL((patch_factor_kernel<int64_t>), dim3(grid), dim3(64), 0, stream, cnt, S.d_pptr + p0, S.d_pdofs,
-                           S.d_boff + p0, (const int64_t *)L.A.rowptr, L.A.col, L.A.val, S.d_binv, scratch, max_np, pivoting, d_nsing);
-      else
-        hipLaunchKernelGGL((patch_factor_kernel<int32_t>), dim3(grid), dim3(64), 0, stream, cnt, S.d_pptr + p0, S.d_pdofs,
-                           S.d_boff + p0, (const int32_t *)L.A.rowptr, L.A.col, L.A.val, S.d_binv, scratch, max_np, pivoting, d_nsing);
-      HIP_CHECK(hipGetLastError());
-    }
-    int nsing = 0;
-    HIP_CHECK(hipMemcpyAsync(&nsing, d_nsing, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    (void)hipFree(scratch);
-    REQUIRE(nsing == 0, GMG_ERR_SINGULAR, "singular patch block (BlockJacobiSolvers.jl:163 'Factorization failed')");
-    // ---- de-duplicate bitwise-identical inverse blocks (lossless; SURVEY 7 "patch-factor de-duplication") ----
-    if (env_int("GMG_PATCH_DEDUP", 1) && max_np <= 32 && npatch >= 64) {
-      unsigned long long *d_hash = nullptr;
-      HIP_CHECK(hipMalloc((void **)&d_hash, sizeof(unsigned long long) * (size_t)npatch));
-      hipLaunchKernelGGL(block_hash_kernel, dim3((unsigned)((npatch + 255) / 256)), dim3(256), 0, stream, npatch, S.d_pptr, S.d_boff, S.d_binv, d_hash);
-      HIP_CHECK(hipGetLastError());
-      std::vector<unsigned long long> hash((size_t)npatch);
-      HIP_CHECK(hipMemcpyAsync(hash.data(), d_hash, sizeof(unsigned long long) * (size_t)npatch, hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipStreamSynchronize(stream));
-      (void)hipFree(d_hash);
-      std::vector<int64_t> order((size_t)npatch);
-      for (int64_t p = 0; p < npatch; ++p) order[p] = p;
-      std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return hash[a] != hash[b] ? hash[a] < hash[b] : a < b; });
-      std::vector<int64_t> rep((size_t)npatch);
-      std::vector<int32_t> ublock((size_t)npatch, 0);
-      std::vector<int64_t> reps;   // representative patch of every unique block
-      for (int64_t i = 0; i < npatch; ++i) {
-        const int64_t p = order[i];
-        if (i == 0 || hash[p] != hash[order[i - 1]]) reps.push_back(p);
-        rep[p] = reps.back();
-        ublock[p] = (int32_t)(reps.size() - 1);
-      }
-      if ((int64_t)reps.size() * 4 <= npatch) {
-        int64_t *d_rep = upload(rep);
-        int *d_nmis = dalloc<int>(1);
-        HIP_CHECK(hipMemsetAsync(d_nmis, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(block_verify_kernel, dim3((unsigned)((npatch + 255) / 256)), dim3(256), 0, stream, npatch, S.d_pptr, S.d_boff, S.d_binv, d_rep, d_nmis);
-        HIP_CHECK(hipGetLastError());
-        int nmis = 0;
-        HIP_CHECK(hipMemcpyAsync(&nmis, d_nmis, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        if (nmis == 0) {   // no hash collision: every patch is bitwise equal to its representative
-          const int64_t nu = (int64_t)reps.size();
-          std::vector<int64_t> src((size_t)nu), dst((size_t)nu + 1, 0);
-          for (int64_t u = 0; u < nu; ++u) {
-            const int64_t np = S.h_pptr[reps[u] + 1] - S.h_pptr[reps[u]];
-            src[u] = boff[reps[u]];
-            dst[u + 1] = dst[u] + np * np;
-          }
-          int64_t *d_src = upload(src);
-          S.d_uboff = upload(dst);
-          S.d_ubinv = dalloc<double>((size_t)dst[nu]);
-          hipLaunchKernelGGL(block_compact_kernel, dim3((unsigned)nu), dim3(64), 0, stream, nu, d_src, S.d_uboff, S.d_binv, S.d_ubinv);
-          HIP_CHECK(hipGetLastError());
-          S.d_ublock = upload(ublock);
-          S.nuniq = nu;
-          S.dedup = true;
-          HIP_CHECK(hipStreamSynchronize(stream));
-          release(S.d_binv, (size_t)boff[npatch]);   // every patch now reads the compact store
+      std::vector<int32_t> sinc((size_t)soff[ns], (int32_t)ndof_entries);   // padding -> the zero slot
+      parallel_for(ns, [&](int64_t sl) {
+        for (int l = 0; l < 64; ++l) {
+          const int64_t i = sl * 64 + l;
+          if (i >= L.n) break;
+          for (int64_t k = iptr[i]; k < iptr[i + 1]; ++k) sinc[(size_t)(soff[sl] + (k - iptr[i]) * 64 + l)] = (int32_t)inc[k];
         }
-      }
+      });
+      S.d_isoff = upload(soff);
+      S.d_isinc = upload_padded(sinc, 64);
+      S.d_iptr = nullptr; S.d_inc = nullptr;
+    } else {
+      S.d_iptr = upload(iptr);
+      S.d_inc = upload(inc);
     }
   }
+  if (npatch == 0 || max_np == 0) { S.built = true; return; }
+
+  // ---- inverse blocks, built in batches (bounded scratch) and de-duplicated on the fly -------------------------------
+  // Block sources: caller's lu! factors (inverted on the host exactly as ldiv! would solve against the identity), caller's
+  // patch matrices, or A[rows_p, cols_p] gathered on the device from the CSR / row-pattern form of the level operator.
+  const bool from_factors = T.has_blocks && T.are_factors;
+  const bool from_dense = T.has_blocks && !T.are_factors;
+  const bool from_pattern = !T.has_blocks && L.A.rowptr == nullptr;
+  if (from_pattern) REQUIRE(L.A.pat && L.A.plen && L.A.ppoff && L.A.ppval, GMG_ERR_STATE, "level operator holds neither a CSR nor a pattern table for the patch blocks");
+  const bool wave_kernel = max_np <= 64;
+  REQUIRE(wave_kernel || (!T.has_blocks && !from_pattern), GMG_ERR_UNSUPPORTED, "patches larger than 64 dofs need the level's CSR");
+  const int pivoting = (S.patch_kind == GMG_PATCH_LU) ? 1 : 0;
+  const size_t per = (size_t)max_np * max_np;
+  const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(npatch, (int64_t)((512u << 20) / (per * sizeof(double)))));
+  const bool want_dedup = env_int("GMG_PATCH_DEDUP", 1) && max_np <= 32 && npatch >= 64;
+  int *d_nsing = dalloc<int>(1);
+  S.d_boff = upload(boff);
+  int64_t tmp_elems = 1;
+  for (int64_t p0 = 0; p0 < npatch; p0 += batch) tmp_elems = std::max(tmp_elems, boff[std::min(npatch, p0 + batch)] - boff[p0]);
+
+  struct DevTmp {                                           // setup-only scratch, freed on every exit path
+    std::vector<void *> ptrs;
+    void *get(size_t bytes) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) throw GmgError{GMG_ERR_ALLOC, "patch setup scratch"}; ptrs.push_back(q); return q; }
+    void drop(void *q) { auto it = std::find(ptrs.begin(), ptrs.end(), q); if (it != ptrs.end()) { ptrs.erase(it); (void)hipFree(q); } }
+    ~DevTmp() { for (void *q : ptrs) (void)hipFree(q); }
+  };
+
+  // returns false when de-duplication should be abandoned (almost all blocks distinct, or a hash collision)
+  auto build_blocks = [&](bool dedup) -> bool {
+    DevTmp tmp;
+    HIP_CHECK(hipMemsetAsync(d_nsing, 0, sizeof(int), stream));
+    double *d_tmp = nullptr, *d_dense = nullptr, *d_scratch = nullptr, *d_ustore = nullptr;
+    unsigned long long *d_hash = nullptr;
+    int64_t *d_rep = nullptr;
+    int *d_nmis = nullptr;
+    std::unordered_map<unsigned long long, int32_t> uniq;   // hash -> unique id
+    std::vector<int64_t> uboff(1, 0);
+    std::vector<int32_t> ublock;
+    int64_t ucap = 0, uused = 0;
+    if (dedup) {
+      ublock.assign((size_t)npatch, 0);
+      d_tmp = (double *)tmp.get(sizeof(double) * (size_t)tmp_elems);
+      d_hash = (unsigned long long *)tmp.get(sizeof(unsigned long long) * (size_t)batch);
+      d_rep = (int64_t *)tmp.get(sizeof(int64_t) * (size_t)batch);
+      d_nmis = (int *)tmp.get(sizeof(int));
+      HIP_CHECK(hipMemsetAsync(d_nmis, 0, sizeof(int), stream));
+    } else if (!S.d_binv) S.d_binv = dalloc<double>((size_t)boff[npatch]);
+    if (from_dense) d_dense = (double *)tmp.get(sizeof(double) * (size_t)tmp_elems);
+    if (!wave_kernel) d_scratch = (double *)tmp.get(per * sizeof(double) * (size_t)batch);
+    std::vector<double> hinv;                               // host-inverted batch (caller's factors)
+    std::vector<unsigned long long> hash((size_t)batch);
+    std::vector<int64_t> rep((size_t)batch);
+    for (int64_t p0 = 0; p0 < npatch; p0 += batch) {
+      const int64_t cnt = std::min(batch, npatch - p0);
+      const int64_t e0 = boff[p0], ne = boff[p0 + cnt] - e0;
+      double *out = dedup ? d_tmp : S.d_binv + e0;           // batch-relative base: block p sits at out[boff[p]-e0]
+      if (from_factors) {
+        // inverse = ldiv!(F, I): the row-permuted identity through the unit-lower and the upper factor (LAPACK getrs
+        // order), column by column; factors column-major as lu! leaves them, pivots 1-based (ipiv)
+        hinv.assign((size_t)ne, 0.0);
+        std::atomic<int> bad(0);
+        parallel_for(cnt, [&](int64_t i) {
+          const int64_t pg = p0 + i;
+          const int np = (int)(T.pptr[pg + 1] - T.pptr[pg]);
+          if (np == 0) return;
+          const double *F = T.blocks.data() + boff[pg];
+          const int32_t *ip = T.piv.empty() ? nullptr : T.piv.data() + T.pptr[pg];
+          double *Xo = hinv.data() + (boff[pg] - e0);
+          std::vector<double> col((size_t)np);
+          for (int c = 0; c < np; ++c) {
+            for (int r = 0; r < np; ++r) col[r] = (r == c) ? 1.0 : 0.0;
+            if (ip) for (int r = 0; r < np; ++r) { const int q = ip[r] - 1; if (q != r && q >= 0 && q < np) std::swap(col[r], col[q]); }
+            for (int k = 0; k < np; ++k)                     // L y = P e_c (unit diagonal)
+              if (col[k] != 0.0) for (int r = k + 1; r < np; ++r) col[r] -= col[k] * F[r + (size_t)k * np];
+            for (int k = np - 1; k >= 0; --k) {              // U x = y
+              if (F[k + (size_t)k * np] == 0.0) { bad.store(1); return; }
+              if (col[k] != 0.0) {
+                col[k] /= F[k + (size_t)k * np];
+                for (int r = 0; r < k; ++r) col[r] -= col[k] * F[r + (size_t)k * np];
+              }
+            }
+            for (int r = 0; r < np; ++r) Xo[(size_t)r * np + c] = col[r];   // row-major inverse
+          }
+        });
+        REQUIRE(bad.load() == 0, GMG_ERR_SINGULAR, "singular patch factor (zero on the diagonal of U)");
+        HIP_CHECK(hipMemcpyAsync(out, hinv.data(), sizeof(double) * (size_t)ne, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+      } else if (wave_kernel) {
+        PatchSrc src;
+        std::memset(&src, 0, sizeof(src));
+        const size_t lds = 2 * per * sizeof(double) + (size_t)max_np * sizeof(int32_t) + 8;
+        const dim3 g((unsigned)cnt), b(64);
+        if (from_dense) {
+          HIP_CHECK(hipMemcpyAsync(d_dense, T.blocks.data() + e0, sizeof(double) * (size_t)ne, hipMemcpyHostToDevice, stream));
+          src.dense = d_dense; src.dense_off0 = e0;
+          hipLaunchKernelGGL((patch_invert_kernel<PSRC_DENSE>), g, b, lds, stream, cnt, S.d_pptr + p0, S.d_pdofs, d_pcol, S.d_boff + p0, e0, src,
+                             pivoting, out, max_np, d_nsing);
+        } else if (from_pattern) {
+          src.rowpid = L.A.rowpid; src.rowbase = L.A.rowbase; src.plen = L.A.plen; src.poff8 = L.A.ppoff; src.pval = L.A.ppval; src.W = L.A.pat_w;
+          hipLaunchKernelGGL((patch_invert_kernel<PSRC_PATTERN>), g, b, lds, stream, cnt, S.d_pptr + p0, S.d_pdofs, d_pcol, S.d_boff + p0, e0, src,
+                             pivoting, out, max_np, d_nsing);
+        } else {
+          src.rowptr = L.A.rowptr; src.col = L.A.col; src.val = L.A.val; src.ptr64 = L.A.ptr64 ? 1 : 0;
+          hipLaunchKernelGGL((patch_invert_kernel<PSRC_CSR>), g, b, lds, stream, cnt, S.d_pptr + p0, S.d_pdofs, d_pcol, S.d_boff + p0, e0, src,
+                             pivoting, out, max_np, d_nsing);
+        }
+        HIP_CHECK(hipGetLastError());
+        if (from_dense) HIP_CHECK(hipStreamSynchronize(stream));   // d_dense is refilled by the next batch
+      } else {
+        // patches with more than 64 dofs: one thread per patch on global scratch (rows = cols, CSR source)
+        const int grid = (int)((cnt + 63) / 64);
+        if (L.A.ptr64)
+          hipLaunchKernelGGL((patch_factor_kernel<int64_t>), dim3(grid), dim3(64), 0, stream, cnt, S.d_pptr + p0, S.d_pdofs,
+                             S.d_boff + p0, (const int64_t *)L.A.rowptr, L.A.col, L.A.val, out - e0, d_scratch, max_np, pivoting, d_nsing);
+        else
+          hipLaunchKernelGGL((patch_factor_kernel<int32_t>), dim3(grid), dim3(64), 0, stream, cnt, S.d_pptr + p0, S.d_pdofs,
+                             S.d_boff + p0, (const int32_t *)L.A.rowptr, L.A.col, L.A.val, out - e0, d_scratch, max_np, pivoting, d_nsing);
+        HIP_CHECK(hipGetLastError());
+      }
+      if (!dedup) continue;
+      // ---- de-duplicate bitwise-identical inverse blocks (lossless; uniform meshes hold a few dozen distinct blocks) ----
+      hipLaunchKernelGGL(block_hash_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, cnt, S.d_pptr + p0, S.d_boff + p0, d_tmp - e0, d_hash);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(hash.data(), d_hash, sizeof(unsigned long long) * (size_t)cnt, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      std::vector<int64_t> new_src, new_dst, new_len;       // unique blocks first seen in this batch
+      for (int64_t i = 0; i < cnt; ++i) {
+        const int64_t pg = p0 + i;
+        const int64_t np = T.pptr[pg + 1] - T.pptr[pg];
+        auto it = uniq.find(hash[(size_t)i]);
+        if (it == uniq.end()) {
+          it = uniq.emplace(hash[(size_t)i], (int32_t)(uboff.size() - 1)).first;
+          new_src.push_back(boff[pg] - e0); new_dst.push_back(uboff.back()); new_len.push_back(np * np);
+          uboff.push_back(uboff.back() + np * np);
+        }
+        ublock[(size_t)pg] = it->second;
+        rep[(size_t)i] = uboff[(size_t)it->second];
+      }
+      // (almost) every block distinct: the compact store would be the full store plus overhead
+      if ((int64_t)(uboff.size() - 1) * 4 > p0 + cnt) return false;
+      if (uboff.back() > ucap) {
+        const int64_t ncap = std::max<int64_t>(uboff.back() * 2, 1 << 16);
+        double *nst = (double *)tmp.get(sizeof(double) * (size_t)ncap);
+        if (d_ustore) {
+          HIP_CHECK(hipMemcpyAsync(nst, d_ustore, sizeof(double) * (size_t)uused, hipMemcpyDeviceToDevice, stream));
+          HIP_CHECK(hipStreamSynchronize(stream));
+          tmp.drop(d_ustore);
+        }
+        d_ustore = nst; ucap = ncap;
+      }
+      for (size_t q = 0; q < new_src.size(); ++q)
+        HIP_CHECK(hipMemcpyAsync(d_ustore + new_dst[q], d_tmp + new_src[q], sizeof(double) * (size_t)new_len[q], hipMemcpyDeviceToDevice, stream));
+      uused = uboff.back();
+      HIP_CHECK(hipMemcpyAsync(d_rep, rep.data(), sizeof(int64_t) * (size_t)cnt, hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(block_verify_store_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, stream, cnt, S.d_pptr + p0, S.d_boff + p0,
+                         d_tmp - e0, d_ustore, d_rep, d_nmis);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(stream));              // rep / hash / d_tmp are reused by the next batch
+    }
+    int nsing = 0, nmis = 0;
+    HIP_CHECK(hipMemcpyAsync(&nsing, d_nsing, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (d_nmis) HIP_CHECK(hipMemcpyAsync(&nmis, d_nmis, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    REQUIRE(nsing == 0, GMG_ERR_SINGULAR, "singular patch block (BlockJacobiSolvers.jl:163 'Factorization failed')");
+    if (!dedup) return true;
+    if (nmis != 0) return false;                            // hash collision: every patch must be bitwise equal to its representative
+    S.d_uboff = upload(uboff);
+    S.d_ubinv = dalloc<double>((size_t)uboff.back());
+    HIP_CHECK(hipMemcpyAsync(S.d_ubinv, d_ustore, sizeof(double) * (size_t)uboff.back(), hipMemcpyDeviceToDevice, stream));
+    S.d_ublock = upload(ublock);
+    S.nuniq = (int64_t)uboff.size() - 1;
+    S.dedup = true;
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return true;
+  };
+  if (!(want_dedup && build_blocks(true))) build_blocks(false);
+  if (S.dedup) release(S.d_boff, (size_t)npatch + 1);        // the de-duplicated solve addresses blocks through ublock / uboff
   S.built = true;
 }
 
@@ -2498,23 +2611,65 @@ int gmg_set_smoother_jacobi(gmg_handle_t h, int lev, int which, int niter, doubl
   });
 }
 
+// patch tables of PatchSolver / BlockJacobiSolver / PatchProlongationOperator (0-based int32 copies, shared by smoother copies)
+static Smoother make_patch_smoother(int niter, double omega, int kind, int64_t npatch, const void *patch_ptr, const void *patch_rows,
+                                    const void *patch_cols, int index_base, int index_bytes)
+{
+  REQUIRE(niter >= 0 && npatch >= 0, GMG_ERR_INVALID, "negative niter / npatch");
+  REQUIRE(patch_ptr && (patch_rows || npatch == 0), GMG_ERR_INVALID, "null patch arrays");
+  REQUIRE(index_bytes == 4 || index_bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
+  REQUIRE(index_base == 0 || index_base == 1, GMG_ERR_INVALID, "index_base must be 0 or 1");
+  REQUIRE(kind == GMG_PATCH_LU || kind == GMG_PATCH_NOPIVOT, GMG_ERR_INVALID, "bad patch kind");
+  Smoother S;
+  S.kind = SM_PATCH; S.niter = niter; S.omega = omega; S.patch_kind = kind;
+  S.tab = std::make_shared<Smoother::Tables>();
+  Smoother::Tables &T = *S.tab;
+  T.pptr.resize((size_t)npatch + 1);
+  for (int64_t p = 0; p <= npatch; ++p) T.pptr[p] = read_index(patch_ptr, p, index_bytes) - index_base;
+  REQUIRE(T.pptr[0] == 0, GMG_ERR_INVALID, "patch_ptr does not start at index_base");
+  for (int64_t p = 0; p < npatch; ++p) REQUIRE(T.pptr[p] <= T.pptr[p + 1], GMG_ERR_INVALID, "patch_ptr not monotone");
+  const int64_t tot = T.pptr[npatch];
+  T.prow.resize((size_t)tot);
+  for (int64_t q = 0; q < tot; ++q) T.prow[q] = (int32_t)(read_index(patch_rows, q, index_bytes) - index_base);
+  if (patch_cols && patch_cols != patch_rows) {
+    T.pcol.resize((size_t)tot);
+    bool same = true;
+    for (int64_t q = 0; q < tot; ++q) { T.pcol[q] = (int32_t)(read_index(patch_cols, q, index_bytes) - index_base); same = same && T.pcol[q] == T.prow[q]; }
+    if (same) { T.pcol.clear(); T.pcol.shrink_to_fit(); }
+  }
+  return S;
+}
+
 int gmg_set_smoother_patch(gmg_handle_t h, int lev, int which, int niter, double omega, int kind, int64_t npatch,
                            const void *patch_ptr, const void *patch_dofs, int index_base, int index_bytes)
 {
   return guarded(h, [&] {
     check_level(h, lev, true);
-    REQUIRE(niter >= 0 && npatch >= 0, GMG_ERR_INVALID, "negative niter / npatch");
-    REQUIRE(patch_ptr && (patch_dofs || npatch == 0), GMG_ERR_INVALID, "null patch arrays");
-    REQUIRE(index_bytes == 4 || index_bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
-    REQUIRE(kind == GMG_PATCH_LU || kind == GMG_PATCH_NOPIVOT, GMG_ERR_INVALID, "bad patch kind");
-    Smoother S;
-    S.kind = SM_PATCH; S.niter = niter; S.omega = omega; S.patch_kind = kind;
-    S.h_pptr.resize((size_t)npatch + 1);
-    for (int64_t p = 0; p <= npatch; ++p) S.h_pptr[p] = read_index(patch_ptr, p, index_bytes) - index_base;
-    REQUIRE(S.h_pptr[0] == 0, GMG_ERR_INVALID, "patch_ptr does not start at index_base");
-    const int64_t tot = S.h_pptr[npatch];
-    S.h_pdofs.resize((size_t)tot);
-    for (int64_t q = 0; q < tot; ++q) S.h_pdofs[q] = (int32_t)(read_index(patch_dofs, q, index_bytes) - index_base);
+    assign_smoother(h, lev, which, make_patch_smoother(niter, omega, kind, npatch, patch_ptr, patch_dofs, nullptr, index_base, index_bytes));
+  });
+}
+
+int gmg_set_smoother_patch_matrices(gmg_handle_t h, int lev, int which, int niter, double omega, int kind, int64_t npatch,
+                                    const void *patch_ptr, const void *patch_rows, const void *patch_cols, int index_base,
+                                    int index_bytes, const double *blocks, int blocks_are_factors, const int32_t *pivots)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    Smoother S = make_patch_smoother(niter, omega, kind, npatch, patch_ptr, patch_rows, patch_cols, index_base, index_bytes);
+    Smoother::Tables &T = *S.tab;
+    if (blocks) {
+      int64_t tot = 0;
+      for (int64_t p = 0; p < npatch; ++p) { const int64_t np = T.pptr[p + 1] - T.pptr[p]; tot += np * np; }
+      T.blocks.assign(blocks, blocks + tot);
+      T.has_blocks = true;
+      T.are_factors = blocks_are_factors != 0;
+      if (T.are_factors && pivots) {
+        T.piv.assign(pivots, pivots + T.pptr[npatch]);
+        for (int64_t p = 0; p < npatch; ++p)
+          for (int64_t q = T.pptr[p]; q < T.pptr[p + 1]; ++q)
+            REQUIRE(T.piv[q] >= 1 && T.piv[q] <= T.pptr[p + 1] - T.pptr[p], GMG_ERR_INVALID, "pivot index out of range (LAPACK ipiv is 1-based)");
+      }
+    } else REQUIRE(!blocks_are_factors && !pivots, GMG_ERR_INVALID, "factors / pivots given without blocks");
     assign_smoother(h, lev, which, S);
   });
 }
@@ -2524,18 +2679,7 @@ int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int kind, int
 {
   return guarded(h, [&] {
     check_level(h, lev, true);
-    REQUIRE(npatch >= 0, GMG_ERR_INVALID, "negative npatch");
-    REQUIRE(patch_ptr && (patch_dofs || npatch == 0), GMG_ERR_INVALID, "null patch arrays");
-    REQUIRE(index_bytes == 4 || index_bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
-    REQUIRE(kind == GMG_PATCH_LU || kind == GMG_PATCH_NOPIVOT, GMG_ERR_INVALID, "bad patch kind");
-    Smoother S;
-    S.kind = SM_PATCH; S.niter = 0; S.omega = 1.0; S.patch_kind = kind;
-    S.h_pptr.resize((size_t)npatch + 1);
-    for (int64_t p = 0; p <= npatch; ++p) S.h_pptr[p] = read_index(patch_ptr, p, index_bytes) - index_base;
-    REQUIRE(S.h_pptr[0] == 0, GMG_ERR_INVALID, "patch_ptr does not start at index_base");
-    const int64_t tot = S.h_pptr[npatch];
-    S.h_pdofs.resize((size_t)tot);
-    for (int64_t q = 0; q < tot; ++q) S.h_pdofs[q] = (int32_t)(read_index(patch_dofs, q, index_bytes) - index_base);
+    Smoother S = make_patch_smoother(0, 1.0, kind, npatch, patch_ptr, patch_dofs, nullptr, index_base, index_bytes);
     h->lev[lev].pcorr = S;
     h->lev[lev].has_pcorr = true;
     h->setup_done = false;

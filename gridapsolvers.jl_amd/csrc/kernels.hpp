@@ -1192,6 +1192,121 @@ __global__ void patch_factor_kernel(int64_t npatch, const int64_t *__restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Wave-per-patch inversion (setup): the same LU-ordered elimination as patch_factor_kernel (same operation order per
+// entry, hence the same bits), with the n_p x 2 n_p augmented block [M | X] in LDS and lane = column.  Block sources:
+//   PSRC_CSR     A[rows_p, cols_p] gathered from the level's device CSR              (BlockJacobiSolvers.jl:160)
+//   PSRC_PATTERN the same from the row-pattern form of A (streamed operators never hold a CSR)
+//   PSRC_DENSE   the caller's own patch matrices, column-major as Julia stores them  (PatchSolvers.jl:137-150:
+//                assemble_matrix(biform, assem, trial, test) of the SOLVER's weak form)
+// n_p <= 64.  Output: explicit inverse, row-major, at binv[boff[p] - boff0].
+// ---------------------------------------------------------------------------
+enum PatchSrcKind : int { PSRC_CSR = 0, PSRC_PATTERN = 1, PSRC_DENSE = 2 };
+struct PatchSrc {
+  const void *rowptr; const int32_t *col; const double *val; int ptr64;                                  // CSR
+  const uint16_t *rowpid; const int32_t *rowbase; const int32_t *plen, *poff8; const double *pval; int W; // pattern table (byte offsets)
+  const double *dense; int64_t dense_off0;                                                                // blocks of this batch
+};
+
+template <int SRC>
+__global__ __launch_bounds__(64) void patch_invert_kernel(int64_t npatch, const int64_t *__restrict__ pptr,
+                                                          const int32_t *__restrict__ prow, const int32_t *__restrict__ pcol,
+                                                          const int64_t *__restrict__ boff, int64_t boff0, PatchSrc src,
+                                                          int pivoting, double *__restrict__ binv, int max_np,
+                                                          int *__restrict__ nsing)
+{
+  extern __shared__ double pi_smem[];
+  const int64_t p = blockIdx.x;
+  if (p >= npatch) return;
+  const int64_t q0 = pptr[p];
+  const int np = (int)(pptr[p + 1] - q0);
+  if (np == 0) return;
+  double *M = pi_smem, *X = pi_smem + (size_t)max_np * max_np;
+  int32_t *cols = reinterpret_cast<int32_t *>(X + (size_t)max_np * max_np);
+  const int lane = threadIdx.x;
+  if (lane < np) cols[lane] = pcol[q0 + lane];
+  for (int e = lane; e < np * np; e += 64) { M[e] = 0.0; X[e] = ((e / np) == (e % np)) ? 1.0 : 0.0; }
+  __syncthreads();
+  if (lane < np) {
+    const int r = lane;
+    const int32_t gr = prow[q0 + r];
+    if (SRC == PSRC_CSR) {
+      int64_t k0, k1;
+      if (src.ptr64) { k0 = reinterpret_cast<const int64_t *>(src.rowptr)[gr]; k1 = reinterpret_cast<const int64_t *>(src.rowptr)[gr + 1]; }
+      else { k0 = reinterpret_cast<const int32_t *>(src.rowptr)[gr]; k1 = reinterpret_cast<const int32_t *>(src.rowptr)[gr + 1]; }
+      for (int64_t k = k0; k < k1; ++k) {
+        const int32_t gc = src.col[k];
+        for (int c = 0; c < np; ++c)
+          if (cols[c] == gc) M[r * np + c] += src.val[k];
+      }
+    } else if (SRC == PSRC_PATTERN) {
+      const int pid = src.rowpid[gr];
+      const int len = src.plen[pid];
+      const int32_t base = src.rowbase ? src.rowbase[gr] : gr;
+      for (int j = 0; j < len; ++j) {
+        const int32_t gc = base + src.poff8[(size_t)pid * src.W + j] / 8;
+        const double v = src.pval[(size_t)pid * src.W + j];
+        for (int c = 0; c < np; ++c)
+          if (cols[c] == gc) M[r * np + c] += v;
+      }
+    } else {
+      const double *B = src.dense + (boff[p] - src.dense_off0);
+      for (int c = 0; c < np; ++c) M[r * np + c] = B[r + (size_t)c * np];
+    }
+  }
+  __syncthreads();
+  const int c = lane;                                        // this lane's column of M and of X
+  for (int j = 0; j < np; ++j) {
+    int piv = j;
+    if (pivoting) {
+      double v = (lane >= j && lane < np) ? fabs(M[lane * np + j]) : -1.0;
+      int idx = lane;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(v, o);
+        const int i2 = __shfl_xor(idx, o);
+        if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
+      }
+      piv = idx;                                             // first row holding the maximum (dgetf2's idamax)
+    }
+    __syncthreads();
+    if (piv != j && c < np) {
+      double t = M[j * np + c]; M[j * np + c] = M[piv * np + c]; M[piv * np + c] = t;
+      t = X[j * np + c]; X[j * np + c] = X[piv * np + c]; X[piv * np + c] = t;
+    }
+    __syncthreads();
+    const double d = M[j * np + j];
+    if (d == 0.0) { if (lane == 0) atomicAdd(nsing, 1); return; }   // uniform
+    for (int i = j + 1; i < np; ++i) {
+      const double l = M[i * np + j] / d;
+      __syncthreads();                                       // everyone has read M[i][j] before column j clears it
+      if (l != 0.0 && c < np) {
+        if (c > j) M[i * np + c] -= l * M[j * np + c];
+        X[i * np + c] -= l * X[j * np + c];
+      }
+      if (c == j) M[i * np + j] = 0.0;
+    }
+    __syncthreads();
+  }
+  if (c < np)
+    for (int j = np - 1; j >= 0; --j) {
+      const double d = M[j * np + j];
+      double sacc = X[j * np + c];
+      for (int k = j + 1; k < np; ++k) sacc -= M[j * np + k] * X[k * np + c];
+      X[j * np + c] = sacc / d;
+    }
+  __syncthreads();
+  double *out = binv + (boff[p] - boff0);
+  for (int e = lane; e < np * np; e += 64) out[e] = X[e];
+}
+
+// dinv[i] = pdinv[rowpid[i]]: the Jacobi inverse diagonal of a row-pattern operator (no CSR needed)
+__global__ void expand_pattern_dinv_kernel(int64_t n, const uint16_t *__restrict__ rowpid, const double *__restrict__ pdinv,
+                                           double *__restrict__ dinv)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dinv[i] = pdinv[rowpid[i]];
+}
+
 // One wave per patch: lanes = rows of the block (n_p <= 64), b_p staged in LDS.
 __global__ __launch_bounds__(kBlock) void patch_apply_kernel(int64_t npatch, const int64_t *__restrict__ pptr,
                                                              const int32_t *__restrict__ pdofs,
@@ -1242,6 +1357,20 @@ __global__ void block_verify_kernel(int64_t npatch, const int64_t *__restrict__ 
   const unsigned long long *a = reinterpret_cast<const unsigned long long *>(binv + boff[p]);
   const unsigned long long *b = reinterpret_cast<const unsigned long long *>(binv + boff[q]);
   bool same = (pptr[q + 1] - pptr[q]) == np;
+  for (int k = 0; k < np * np && same; ++k) same = a[k] == b[k];
+  if (!same) atomicAdd(nmis, 1);
+}
+// the same against a compact store: rep[p] = element offset of the representative block
+__global__ void block_verify_store_kernel(int64_t npatch, const int64_t *__restrict__ pptr, const int64_t *__restrict__ boff,
+                                          const double *__restrict__ binv, const double *__restrict__ store,
+                                          const int64_t *__restrict__ rep, int *__restrict__ nmis)
+{
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npatch) return;
+  const int np = (int)(pptr[p + 1] - pptr[p]);
+  const unsigned long long *a = reinterpret_cast<const unsigned long long *>(binv + boff[p]);
+  const unsigned long long *b = reinterpret_cast<const unsigned long long *>(store + rep[p]);
+  bool same = true;
   for (int k = 0; k < np * np && same; ++k) same = a[k] == b[k];
   if (!same) atomicAdd(nmis, 1);
 }

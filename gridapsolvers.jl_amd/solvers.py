@@ -53,16 +53,33 @@ class LUSolver:
     """Gridap.Algebra.LUSolver(): the default coarsest_solver (GMGLinearSolvers.jl:54)."""
 
 
+class HostCallbackSolver:
+    """coarsest_solver implemented by the host language: `fn(r) -> x` on numpy vectors (GMG_COARSE_HOST_CALLBACK).
+    In Julia this is an `@cfunction` around `solve!(x, ns_coarse, r)` of any Gridap LinearSolver."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+
 class PatchSolver:
     """PatchBasedSmoothers.PatchSolver restricted to what reaches solve!: the
     patch dof tables (patch_rows == patch_cols for :star assembly) -- PatchSolvers.jl:18-54."""
     kind = abi.PATCH_LU
 
-    def __init__(self, patch_ptr, patch_dofs):
+    def __init__(self, patch_ptr, patch_dofs, patch_cols=None, patch_mats=None, factors=None, pivots=None):
+        """patch_dofs = patch_rows.  Optional, as held by the reference's PatchNS (PatchSolvers.jl:100-150):
+        patch_cols (separate column table), patch_mats (the solver's own assembled patch matrices, column-major,
+        concatenated) or factors (+ 1-based LAPACK pivots) = the output of lu!(patch_mat)."""
         self.patch_ptr = np.ascontiguousarray(patch_ptr, dtype=np.int64)
         self.patch_dofs = np.ascontiguousarray(patch_dofs, dtype=np.int32)
         if self.patch_ptr.ndim != 1 or self.patch_ptr.size < 1:
             raise ValueError("patch_ptr must have npatch+1 entries")
+        self.patch_cols = None if patch_cols is None else np.ascontiguousarray(patch_cols, dtype=np.int32)
+        if patch_mats is not None and factors is not None:
+            raise ValueError("give patch_mats or factors, not both")
+        self.patch_mats = None if patch_mats is None else np.ascontiguousarray(patch_mats, dtype=np.float64)
+        self.factors = None if factors is None else np.ascontiguousarray(factors, dtype=np.float64)
+        self.pivots = None if pivots is None else np.ascontiguousarray(pivots, dtype=np.int32)
 
 
 class BlockJacobiSolver(PatchSolver):
@@ -150,8 +167,13 @@ class GMGLinearSolver:
             raise ValueError("mode must be 'preconditioner' or 'solver'")
         if cycle_type not in _CYCLES:   # :61
             raise ValueError("cycle_type must be 'v_cycle', 'w_cycle' or 'f_cycle'")
-        if coarsest_solver is not None and not isinstance(coarsest_solver, LUSolver):
-            raise NotImplementedError("only coarsest_solver=LUSolver() is provided on the device")
+        # coarsest_solver: LUSolver() (default, GMGLinearSolvers.jl:54), CGSolver(JacobiLinearSolver();...) on the device, or any
+        # host-side solver wrapped in HostCallbackSolver (the analogue of passing PETSc / UMFPACK objects in Julia)
+        if coarsest_solver is not None and not isinstance(coarsest_solver, (LUSolver, HostCallbackSolver)):
+            if not (isinstance(coarsest_solver, CGSolver) and isinstance(coarsest_solver.Pl, JacobiLinearSolver)
+                    and not coarsest_solver.flexible):
+                raise NotImplementedError("coarsest_solver on the device: LUSolver(), CGSolver(JacobiLinearSolver()) or HostCallbackSolver(fn)")
+        self.coarsest_solver = coarsest_solver
         self.smatrices, self.interp, self.restrict = list(smatrices), list(interp), list(restrict)
         self.pre_smoothers, self.post_smoothers = list(pre_smoothers), list(post_smoothers)
         self.mode, self.cycle_type = mode, cycle_type
@@ -356,6 +378,19 @@ class GMGNumericalSetup:
                 self._set_smoother(l, abi.POST, post)
         abi.check(h, lib.gmg_set_options(h, _MODES[s.mode], _CYCLES[s.cycle_type], s.log.maxiter, s.log.atol, s.log.rtol))
         abi.check(h, lib.gmg_set_verbose(h, s.verbose))
+        cs = s.coarsest_solver
+        if isinstance(cs, CGSolver):
+            abi.check(h, lib.gmg_set_coarse_solver(h, abi.COARSE_CG_JACOBI, cs.log.maxiter, cs.log.atol, cs.log.rtol, None, None))
+        elif isinstance(cs, HostCallbackSolver):
+            def _cb(ctx, n, r, x, fn=cs.fn):
+                try:
+                    out = np.asarray(fn(np.ctypeslib.as_array(r, shape=(n,)).copy()), dtype=np.float64)
+                    np.ctypeslib.as_array(x, shape=(n,))[:] = out
+                    return 0
+                except Exception:      # never unwind through the C frames
+                    return 1
+            self._coarse_cb = abi.COARSE_SOLVE_FN(_cb)
+            abi.check(h, lib.gmg_set_coarse_solver(h, abi.COARSE_HOST_CALLBACK, 0, 0.0, 0.0, C.cast(self._coarse_cb, C.c_void_p), None))
         abi.check(h, lib.gmg_setup(h))
         self.n = int(_csr_fields(mats[0])[0][0])
         self.sizes = [int(_csr_fields(A)[0][0]) for A in mats]
@@ -367,9 +402,19 @@ class GMGNumericalSetup:
         if isinstance(sm.M, JacobiLinearSolver):
             abi.check(h, lib.gmg_set_smoother_jacobi(h, l, which, sm.niter, sm.omega))
         else:
-            pp, pd = sm.M.patch_ptr, sm.M.patch_dofs.astype(np.int64)
-            abi.check(h, lib.gmg_set_smoother_patch(h, l, which, sm.niter, sm.omega, sm.M.kind, pp.size - 1,
-                                                    C.c_void_p(pp.ctypes.data), C.c_void_p(pd.ctypes.data), 0, 8))
+            M = sm.M
+            pp, pd = M.patch_ptr, M.patch_dofs.astype(np.int64)
+            if M.patch_cols is None and M.patch_mats is None and M.factors is None:
+                abi.check(h, lib.gmg_set_smoother_patch(h, l, which, sm.niter, sm.omega, M.kind, pp.size - 1,
+                                                        C.c_void_p(pp.ctypes.data), C.c_void_p(pd.ctypes.data), 0, 8))
+            else:
+                pc = None if M.patch_cols is None else M.patch_cols.astype(np.int64)
+                blk = M.patch_mats if M.patch_mats is not None else M.factors
+                abi.check(h, lib.gmg_set_smoother_patch_matrices(
+                    h, l, which, sm.niter, sm.omega, M.kind, pp.size - 1, C.c_void_p(pp.ctypes.data), C.c_void_p(pd.ctypes.data),
+                    None if pc is None else C.c_void_p(pc.ctypes.data), 0, 8,
+                    None if blk is None else C.c_void_p(blk.ctypes.data), 1 if M.factors is not None else 0,
+                    None if M.pivots is None else C.c_void_p(M.pivots.ctypes.data)))
 
     # -- numerical_setup!(ns, A): FromMatrices variant is unsupported in the reference
     #    (GMGLinearSolvers.jl:249-258 logs @error); here new values on the same pattern are accepted.
@@ -432,6 +477,11 @@ class GMGNumericalSetup:
         n = a.numel() if _is_device(a) else _k1.size
         abi.check(self.h, self._lib.gmg_dot(self.h, n, pa, pb, ms, C.byref(out)))
         return out.value
+
+    def coarse_log(self):
+        res = abi.Result()
+        abi.check(self.h, self._lib.gmg_get_coarse_log(self.h, C.byref(res)))
+        return dict(niters=int(res.niters), flag=int(res.flag), res0=res.res0, res=res.res)
 
     def fill_log(self):
         """ns.solver.log of the GMG after it ran inside a Krylov call (gmg_get_log)."""

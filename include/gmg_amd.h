@@ -119,6 +119,20 @@ GMG_API int gmg_set_smoother_patch(gmg_handle_t h, int lev, int which, int niter
                                    int kind, int64_t npatch, const void *patch_ptr,
                                    const void *patch_dofs, int index_base, int index_bytes);
 
+/* The same smoother with the patch data the reference's numerical setup holds (PatchSolvers.jl:137-150,175-188):
+ *   patch_rows / patch_cols  separate index tables (b[rows_p] is the local rhs, x[cols_p] += x_p; PatchSolvers.jl:237-240,296);
+ *                            patch_cols = NULL means patch_cols = patch_rows;
+ *   blocks                   NULL: blocks A[rows_p, cols_p] are gathered from the level matrix on the device (BlockJacobiSolvers.jl:160);
+ *                            else the caller's own n_p x n_p patch matrices, COLUMN-major (Julia Matrix{Float64}), concatenated in
+ *                            patch order -- assemble_matrix(biform, assem, trial, test) of the SOLVER'S weak form, which need not equal A[p,p];
+ *   blocks_are_factors = 1   `blocks` hold the packed output of lu!(patch_mat) and `pivots` its 1-based LAPACK ipiv (patch_ptr layout;
+ *                            NULL for NoPivot factors): the library forms F \ I exactly as ldiv! would and never re-factorises.
+ * kind (GMG_PATCH_LU / GMG_PATCH_NOPIVOT) selects the pivoting of the device factorisation when matrices are given. */
+GMG_API int gmg_set_smoother_patch_matrices(gmg_handle_t h, int lev, int which, int niter, double omega, int kind,
+                                            int64_t npatch, const void *patch_ptr, const void *patch_rows,
+                                            const void *patch_cols, int index_base, int index_bytes,
+                                            const double *blocks, int blocks_are_factors, const int32_t *pivots);
+
 /* Patch-corrected prolongation  y = P x - sum_p R_p^T A_pp^-1 R_p (A P x)  over the given patches
  * (PatchProlongationOperator, PatchBasedSmoothers/PatchTransferOperators.jl:153-172 with rhs = lhs = the
  * level operator; used by the reference for grad-div problems, test/Applications/StokesGMG.jl:125-133).

@@ -286,7 +286,9 @@ typedef struct {
   /* Patch / block-Jacobi */
   i64 npatch;
   const i64 *patch_ptr;
-  const i32 *patch_dofs;
+  const i32 *patch_dofs;       /* patch_rows: b[rows_p] (PatchSolvers.jl:237-240) */
+  const i32 *patch_cols;       /* patch_cols: x[cols_p] += x_p (:296); NULL = patch_rows */
+  const double *user_mats;     /* caller-assembled patch matrices, column-major, concatenated (PatchSolvers.jl:137-150); NULL: A[rows_p,cols_p] */
   double **factors; /* per patch, column-major n_p x n_p LU (PatchSolvers.jl:176) */
   int **pivots;
   int max_np;
@@ -317,11 +319,13 @@ ORC_API void orc_jacobi_setup(i64 n, const i64 *ptr, const i32 *idx, const doubl
 }
 
 /* copyto!(Ak, view(A,rows,cols)): BlockJacobiSolvers.jl:160 */
-static void extract_block(const orc_csr *A, int np, const i32 *dofs, double *Ak)
+static void extract_block2(const orc_csr *A, int np, const i32 *rows, const i32 *cols, double *Ak)
 {
   for (int c = 0; c < np; ++c)
-    for (int r = 0; r < np; ++r) Ak[r + (size_t)c * np] = csr_get(A, dofs[r], dofs[c]);
+    for (int r = 0; r < np; ++r) Ak[r + (size_t)c * np] = csr_get(A, rows[r], cols[c]);
 }
+static void extract_block(const orc_csr *A, int np, const i32 *dofs, double *Ak) { extract_block2(A, np, dofs, dofs, Ak); }
+static const i32 *sm_cols(const orc_smoother *s, i64 p) { return (s->patch_cols ? s->patch_cols : s->patch_dofs) + s->patch_ptr[p]; }
 
 static void smoother_setup(orc_smoother *s, const orc_csr *A)
 {
@@ -342,12 +346,14 @@ static void smoother_setup(orc_smoother *s, const orc_csr *A)
      * PatchSolvers.jl:175-188 (collect_factorizations=true) */
     s->factors = (double **)calloc((size_t)s->npatch, sizeof(double *));
     s->pivots = (int **)calloc((size_t)s->npatch, sizeof(int *));
+    size_t moff = 0;
     for (i64 p = 0; p < s->npatch; ++p) {
       int np = (int)(s->patch_ptr[p + 1] - s->patch_ptr[p]);
       if (np == 0) continue;
       s->factors[p] = (double *)malloc((size_t)np * np * sizeof(double));
       s->pivots[p] = (int *)malloc((size_t)np * sizeof(int));
-      extract_block(A, np, s->patch_dofs + s->patch_ptr[p], s->factors[p]);
+      if (s->user_mats) { memcpy(s->factors[p], s->user_mats + moff, (size_t)np * np * sizeof(double)); moff += (size_t)np * np; }
+      else extract_block2(A, np, s->patch_dofs + s->patch_ptr[p], sm_cols(s, p), s->factors[p]);
       dense_lu_pivot(np, s->factors[p], s->pivots[p]);
     }
   }
@@ -367,8 +373,9 @@ static void patch_apply(orc_smoother *s, i64 n, double *x, const double *b)
   for (i64 p = 0; p < s->npatch; ++p) {                 /* :288 */
     int np = (int)(s->patch_ptr[p + 1] - s->patch_ptr[p]);
     if (np == 0) continue;                              /* :290 */
-    const i32 *cols = s->patch_dofs + s->patch_ptr[p];
-    for (int k = 0; k < np; ++k) s->xp[k] = b[cols[k]]; /* :237-240 Reindex(b) */
+    const i32 *rows = s->patch_dofs + s->patch_ptr[p];
+    const i32 *cols = sm_cols(s, p);
+    for (int k = 0; k < np; ++k) s->xp[k] = b[rows[k]]; /* :237-240 Reindex(b) over patch_rows */
     dense_lu_solve(np, s->factors[p], s->pivots[p], s->xp); /* :295 ldiv! */
     for (int k = 0; k < np; ++k) x[cols[k]] += s->xp[k];    /* :296 */
   }
@@ -381,9 +388,10 @@ static void blockjacobi_apply(orc_smoother *s, const orc_csr *A, i64 n, double *
   for (i64 p = 0; p < s->npatch; ++p) {                 /* :149 */
     int np = (int)(s->patch_ptr[p + 1] - s->patch_ptr[p]);
     if (np == 0) continue;
-    const i32 *cols = s->patch_dofs + s->patch_ptr[p];
-    extract_block(A, np, cols, s->Ak);                  /* :160 */
-    for (int k = 0; k < np; ++k) s->xp[k] = b[cols[k]]; /* :161 */
+    const i32 *rows = s->patch_dofs + s->patch_ptr[p];
+    const i32 *cols = sm_cols(s, p);
+    extract_block2(A, np, rows, cols, s->Ak);           /* :160 */
+    for (int k = 0; k < np; ++k) s->xp[k] = b[rows[k]]; /* :161 */
     dense_lu_nopivot(np, s->Ak);                        /* :162 */
     dense_lu_solve(np, s->Ak, NULL, s->xp);             /* :164 */
     for (int k = 0; k < np; ++k) x[cols[k]] += s->xp[k];/* :166 */
@@ -477,14 +485,23 @@ ORC_API void orc_gmg_set_restriction(orc_gmg *g, int l, i64 n, i64 m, const i64 
   g->lev[l].R = (orc_csr){ n, m, ptr, idx, val };
   g->lev[l].has_R = 1;
 }
+/* patch_cols / user_mats: see orc_smoother; both optional (NULL) */
+ORC_API void orc_gmg_set_smoother_ex(orc_gmg *g, int l, int which, int kind, int niter, double omega, i64 npatch,
+                                     const i64 *patch_ptr, const i32 *patch_rows, const i32 *patch_cols, const double *user_mats);
 ORC_API void orc_gmg_set_smoother(orc_gmg *g, int l, int which /*0 pre,1 post,2 both*/, int kind,
                                   int niter, double omega, i64 npatch, const i64 *patch_ptr,
                                   const i32 *patch_dofs)
+{
+  orc_gmg_set_smoother_ex(g, l, which, kind, niter, omega, npatch, patch_ptr, patch_dofs, NULL, NULL);
+}
+ORC_API void orc_gmg_set_smoother_ex(orc_gmg *g, int l, int which, int kind, int niter, double omega, i64 npatch,
+                                     const i64 *patch_ptr, const i32 *patch_dofs, const i32 *patch_cols, const double *user_mats)
 {
   orc_smoother s;
   memset(&s, 0, sizeof(s));
   s.kind = kind; s.niter = niter; s.omega = omega;
   s.npatch = npatch; s.patch_ptr = patch_ptr; s.patch_dofs = patch_dofs;
+  s.patch_cols = patch_cols; s.user_mats = user_mats;
   if (which == 0 || which == 2) g->lev[l].pre = s;
   if (which == 1 || which == 2) g->lev[l].post = s;
   g->lev[l].post_is_pre = (which == 2);

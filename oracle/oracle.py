@@ -115,10 +115,14 @@ def givens(f, g):
 class Smoother:
     """RichardsonSmoother(M, niter, omega) with M in {Jacobi, PatchSolver, BlockJacobiSolver}."""
 
-    def __init__(self, kind=JACOBI, niter=10, omega=2.0 / 3.0, patch_ptr=None, patch_dofs=None):
+    def __init__(self, kind=JACOBI, niter=10, omega=2.0 / 3.0, patch_ptr=None, patch_dofs=None, patch_cols=None, patch_mats=None):
+        """patch_dofs = patch_rows; patch_cols (optional) = separate column table; patch_mats (optional) = the caller's own
+        patch matrices, column-major and concatenated (PatchSolvers.jl:137-150)."""
         self.kind, self.niter, self.omega = kind, int(niter), float(omega)
         self.patch_ptr = None if patch_ptr is None else np.ascontiguousarray(patch_ptr, dtype=np.int64)
         self.patch_dofs = None if patch_dofs is None else np.ascontiguousarray(patch_dofs, dtype=np.int32)
+        self.patch_cols = None if patch_cols is None else np.ascontiguousarray(patch_cols, dtype=np.int32)
+        self.patch_mats = None if patch_mats is None else np.ascontiguousarray(patch_mats, dtype=np.float64)
 
 
 class GMG:
@@ -170,8 +174,10 @@ class GMG:
         pp = _p64(s.patch_ptr) if s.patch_ptr is not None else None
         pd = _p32(s.patch_dofs) if s.patch_dofs is not None else None
         npatch = 0 if s.patch_ptr is None else len(s.patch_ptr) - 1
-        lib().orc_gmg_set_smoother(self.h, C.c_int(l), C.c_int(which), C.c_int(s.kind), C.c_int(s.niter),
-                                   C.c_double(s.omega), C.c_int64(npatch), pp, pd)
+        pc = _p32(s.patch_cols) if getattr(s, "patch_cols", None) is not None else None
+        pm = _d(s.patch_mats) if getattr(s, "patch_mats", None) is not None else None
+        lib().orc_gmg_set_smoother_ex(self.h, C.c_int(l), C.c_int(which), C.c_int(s.kind), C.c_int(s.niter),
+                                      C.c_double(s.omega), C.c_int64(npatch), pp, pd, pc, pm)
 
     def solve(self, b, x=None):
         """solve!(x, ns, b); returns (x, niters, flag, residual_history)."""

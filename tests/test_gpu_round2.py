@@ -160,3 +160,162 @@ def test_block_and_gmg_handles_destroy_in_any_order(S, po, pkg, gmg_first):
         S.solve_(z, g, b[:n])
         assert np.all(np.isfinite(z)) and np.linalg.norm(z) > 0
         g.close()
+
+
+# ---------------------------------------------------------------- coarsest_solver hook (GMGLinearSolvers.jl:54,423-434)
+@pytest.mark.parametrize("cg_maxiter", [1000, 3])
+def test_coarse_solver_cg_jacobi_matches_oracle(S, po, orc, hierarchy, cg_maxiter):
+    """coarsest_solver = CGSolver(JacobiLinearSolver(); maxiter, atol, rtol) on the device, also truncated (maxiter=3):
+    outer CG iteration count, history and solution equal the oracle's with the same coarse solver."""
+    nc, nlev = (16, 16, 16), 3
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    cs = S.CGSolver(S.JacobiLinearSolver(), maxiter=cg_maxiter, atol=1e-14, rtol=1e-10)
+    solver = S.CGSolver(make_gmg(S, H, coarsest_solver=cs), maxiter=20, atol=1e-14, rtol=1e-6, flexible=(cg_maxiter == 3))
+    ns = setup(S, solver, H["mats"][0])
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1, coarse_cg=(cg_maxiter, 1e-14, 1e-10))
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=g, maxiter=20, atol=1e-14, rtol=1e-6, flexible=(cg_maxiter == 3))
+    assert solver.log.num_iters == nit and solver.log.flag == flag
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-7)
+    assert rel_err(x, xo) <= 1e-9
+    cl = ns.P_ns.coarse_log()
+    assert cl["niters"] == orc.lib().orc_gmg_coarse_niters(g.h) and cl["niters"] <= cg_maxiter
+    # standalone coarse solve through the ABI
+    nL = H["mats"][-1].shape[0]
+    rc = np.random.default_rng(1).uniform(-1, 1, nL); xc = np.full(nL, 7.0)
+    ns.P_ns.coarse_solve(rc, xc)
+    assert rel_err(xc, g.coarse_solve(rc)) <= 1e-10
+
+
+def test_coarse_solver_host_callback(S, po, orc, hierarchy):
+    """GMG_COARSE_HOST_CALLBACK: the host language's own exact solver (here scipy's sparse LU, the analogue of LUSolver() /
+    PETSc in the Julia host) gives the same CG iteration as the device's dense inverse."""
+    import scipy.sparse.linalg as spla
+    nc, nlev = (16, 16, 16), 3
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    lu = spla.splu(H["mats"][-1].to_scipy().tocsc())
+    calls = []
+
+    def coarse(r):
+        calls.append(r.size)
+        return lu.solve(r)
+    solver = S.CGSolver(make_gmg(S, H, coarsest_solver=S.HostCallbackSolver(coarse)), maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = setup(S, solver, H["mats"][0])
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=g, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert solver.log.num_iters == nit and len(calls) == nit
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=TOL_HIST)
+    assert rel_err(x, xo) <= 1e-10
+    # a failing callback surfaces as an error status, not as a crash or a silent wrong answer
+    bad = S.CGSolver(make_gmg(S, H, coarsest_solver=S.HostCallbackSolver(lambda r: 1 / 0)), maxiter=20, atol=1e-14, rtol=1e-6)
+    nsb = setup(S, bad, H["mats"][0])
+    from gridapsolvers_jl_amd import abi
+    with pytest.raises(abi.GmgError):
+        S.solve_(np.zeros_like(b), nsb, b)
+
+
+def test_nested_cg_inside_cg_keeps_scalars_apart(S, po, orc):
+    """outer CG on a block system whose diagonal blocks are CG-Jacobi solves: both cg_core instances live on one engine and
+    must not share their device scalar slots (gamma / dot(p,w))."""
+    M = po.poisson_matrix((12, 12), 1); n = M.shape[0]
+    inner = S.CGSolver(S.JacobiLinearSolver(), maxiter=200, atol=1e-14, rtol=1e-12)
+    solver = S.CGSolver(S.BlockDiagonalSolver([inner, inner]), maxiter=30, atol=1e-14, rtol=1e-10, flexible=True)
+    ns = setup(S, solver, [[M, None], [None, M]])
+    b = np.random.default_rng(3).uniform(-1, 1, 2 * n); x = np.zeros(2 * n)
+    S.solve_(x, ns, b)
+    import scipy.sparse.linalg as spla
+    lu = spla.splu(M.to_scipy().tocsc())
+    xe = np.concatenate([lu.solve(b[:n]), lu.solve(b[n:])])
+    assert solver.log.num_iters <= 3                         # an (almost) exact preconditioner
+    assert rel_err(x, xe) <= 1e-8
+
+
+# ---------------------------------------------------------------- caller-supplied patch matrices / factors, patch_rows != patch_cols
+def _patch_blocks(A, pp, rows, cols=None, shift=0.0, jitter=None):
+    """column-major, concatenated blocks A[rows_p, cols_p] (+ shift*I, + a per-patch relative perturbation)"""
+    Sd = A.to_scipy().tocsr()
+    cols = rows if cols is None else cols
+    out = []
+    for p in range(pp.size - 1):
+        r, c = rows[pp[p]:pp[p + 1]], cols[pp[p]:pp[p + 1]]
+        B = Sd[r][:, c].toarray() + shift * np.eye(r.size)
+        if jitter is not None:
+            B = B * (1.0 + 1e-3 * jitter.uniform(-1, 1, B.shape))
+        out.append(B.reshape(-1, order="F"))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("variant", ["mats", "factors", "distinct"])
+def test_patch_smoother_with_caller_matrices(S, po, orc, hierarchy, variant):
+    """PatchSolvers.jl:137-150,175-188: the patch matrices come from the SOLVER's weak form (here A[p,p] + 0.5 I, i.e. a
+    reaction term the system matrix does not have), optionally already factorised by lu! (LAPACK getrf via scipy)."""
+    import scipy.linalg as sla
+    nc, nlev, order = (8, 8, 8), 2, 2
+    H = hierarchy(nc, nlev, order)
+    A = H["mats"][0]
+    pp, pd = po.vertex_star_patches(nc, order)
+    rng = np.random.default_rng(5) if variant == "distinct" else None      # every block distinct: de-duplication must give up
+    blocks = _patch_blocks(A, pp, pd, shift=0.5, jitter=rng)
+    if variant == "factors":
+        fac, piv = [], []
+        off = 0
+        for p in range(pp.size - 1):
+            n_p = int(pp[p + 1] - pp[p])
+            lu, ip = sla.lu_factor(blocks[off:off + n_p * n_p].reshape(n_p, n_p, order="F"))
+            fac.append(lu.reshape(-1, order="F")); piv.append(ip.astype(np.int32) + 1)   # LAPACK ipiv is 1-based
+            off += n_p * n_p
+        M = S.PatchSolver(pp, pd, factors=np.concatenate(fac), pivots=np.concatenate(piv))
+    else:
+        M = S.PatchSolver(pp, pd, patch_mats=blocks)
+    gmg = make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(M, 5, 0.2)])
+    ns = setup(S, gmg, A)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"],
+                 pre_smoothers=[orc.Smoother(orc.PATCH, 5, 0.2, pp, pd, patch_mats=blocks)], maxiter=1)
+    r = np.random.default_rng(17).uniform(-1, 1, A.shape[0])
+    dx = np.zeros_like(r)
+    ns.precond(0, r, dx)
+    assert max_rel(dx, go.precond(0, r)) <= 1e-12
+    z = np.zeros_like(r)
+    S.solve_(z, ns, r)
+    zo, _, _, ho = go.solve(r)
+    assert rel_err(z, zo) <= 1e-11
+    np.testing.assert_allclose(gmg.log.residuals[:2], ho, rtol=TOL_HIST)
+    # the caller's matrices really are used: the A[p,p] smoother gives something else
+    ns0 = setup(S, make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(S.PatchSolver(pp, pd), 5, 0.2)]), A)
+    dx0 = np.zeros_like(r); ns0.precond(0, r, dx0)
+    assert max_rel(dx0, dx) > 1e-3
+
+
+@pytest.mark.parametrize("kind", ["patch", "block"])
+def test_patch_rows_differ_from_cols(S, po, orc, hierarchy, kind):
+    """separate patch_rows / patch_cols tables (PatchSolvers.jl:237-240,296; BlockJacobiSolvers.jl:141-170): x[cols_p] += A[rows_p,cols_p]^-1 b[rows_p]
+    with the columns of every patch listed in another order than its rows."""
+    nc, nlev, order = (16, 16), 2, 2
+    H = hierarchy(nc, nlev, order)
+    A = H["mats"][0]
+    pp, pd = po.vertex_star_patches(nc, order)
+    pc = pd.copy()
+    for p in range(pp.size - 1):
+        pc[pp[p]:pp[p + 1]] = pd[pp[p]:pp[p + 1]][::-1]                    # same dofs, reversed
+    M = (S.PatchSolver if kind == "patch" else S.BlockJacobiSolver)(pp, pd, patch_cols=pc)
+    gmg = make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(M, 4, 0.2)])
+    ns = setup(S, gmg, A)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"],
+                 pre_smoothers=[orc.Smoother(orc.PATCH if kind == "patch" else orc.BLOCKJACOBI, 4, 0.2, pp, pd, patch_cols=pc)], maxiter=1)
+    r = np.random.default_rng(3).uniform(-1, 1, A.shape[0])
+    dx = np.zeros_like(r)
+    ns.precond(0, r, dx)
+    assert max_rel(dx, go.precond(0, r)) <= 1e-12
+    z = np.zeros_like(r)
+    S.solve_(z, ns, r)
+    zo, _, _, ho = go.solve(r)
+    assert rel_err(z, zo) <= 1e-11
+    # and (mathematically) the same smoother as rows == cols
+    ns1 = setup(S, make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(type(M)(pp, pd), 4, 0.2)]), A)
+    z1 = np.zeros_like(r); S.solve_(z1, ns1, r)
+    assert rel_err(z, z1) <= 1e-10
