@@ -38,6 +38,8 @@ SYMBOLS = {
     "gmg_version": [],
     "gmg_set_matrix": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_int, C.c_int, C.c_int],
+    "gmg_set_operator_rows": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_int, C.c_int],
     "gmg_update_values": [C.c_void_p, C.c_int, C.c_void_p],
     "gmg_set_prolongation": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int, C.c_int, C.c_int],

@@ -149,6 +149,23 @@ HostCSR transpose(const HostCSR &A)
 }
 
 // ----------------------------------------------------------------------------
+// Streamed operators (gmg_set_operator_rows): the caller hands over consecutive row blocks and the library keeps only the
+// row-pattern form -- a 16-bit pattern id (+ a 32-bit base column) per row and the dictionary of distinct rows -- never a
+// CSR.  Host memory is O(block), which is what lets BASELINE config 3 (8.5e9 nonzeros) through the setup.
+// mode 0: column offsets relative to the row index (square level matrices); mode 1: relative to the row's first column.
+// ----------------------------------------------------------------------------
+struct PatStream {
+  int mode = 0;
+  int64_t nrows = 0, ncols = 0, rows_seen = 0, nnz = 0, wmax = 0;
+  std::vector<int32_t> len, start, off;
+  std::vector<uint64_t> val;
+  std::unordered_map<uint64_t, std::vector<int32_t>> index;
+  std::vector<uint16_t> rowpid;
+  std::vector<int32_t> rowbase;
+  bool complete() const { return rows_seen == nrows; }
+};
+
+// ----------------------------------------------------------------------------
 // device containers
 // ----------------------------------------------------------------------------
 struct DevCSR {
@@ -248,6 +265,7 @@ struct Level {
   double s0_omega = 0.0;
   HostCSR hA, hP, hR;
   bool hasA = false, hasP = false, hasR = false;
+  std::shared_ptr<PatStream> sA, sP, sR;   // streamed operators (hA/hP/hR then carry the shape only)
   DevCSR A, P, R;
   double *dinv = nullptr;
   Smoother pre, post;
@@ -733,16 +751,156 @@ struct gmg_solver {
       ok = detect_patterns(H, 1, rowpid, rowbase, plen, poff, pval, W, false, generic);
     }
     if (!ok) return false;
+    upload_pattern(D, H.nrows, rowpid, rowbase, plen, poff, pval, W, generic, false);
+    return true;
+  }
+  void upload_pattern(DevCSR &D, int64_t nrows, const std::vector<uint16_t> &rowpid, const std::vector<int32_t> &rowbase,
+                      const std::vector<int32_t> &plen, const std::vector<int32_t> &poff, const std::vector<double> &pval, int W,
+                      bool generic, bool keep_table)
+  {
     D.rowpid = upload_padded(rowpid, 64);
     D.rowbase = rowbase.empty() ? nullptr : upload_padded(rowbase, 64);
     D.pat_generic = generic;
-    if (generic) { D.plen = upload(plen); D.ppoff = upload(poff); D.ppval = upload(pval); }
+    // keep_table: the (offset,value) table also serves the patch-block extraction of operators that hold no CSR
+    if (generic || keep_table) { D.plen = upload(plen); D.ppoff = upload(poff); D.ppval = upload(pval); }
     D.pat_np = (int)plen.size(); D.pat_w = W;
-    D.nslices = (int)((H.nrows + 63) / 64);
+    D.nslices = (int)((nrows + 63) / 64);
     D.pat = true; D.sell = true;
     D.zpad = D.nnz;
-    D.stream_bytes_per_nnz = (rowbase.empty() ? 2.0 : 6.0) * (double)H.nrows / (double)D.nnz;
-    return true;
+    D.stream_bytes_per_nnz = (rowbase.empty() ? 2.0 : 6.0) * (double)nrows / (double)std::max<int64_t>(D.nnz, 1);
+  }
+
+  // ---- streamed operators ---------------------------------------------------------------------------------------------
+  // One more block of rows: hash every row (parallel, dictionary read-only), then insert the rows whose pattern is new
+  // (sequential; a handful per operator).  Pattern ids are assigned in row order => deterministic.
+  void stream_append(PatStream &P, int64_t row0, int64_t nr, const void *ptr, const void *idx, const double *val, int base, int bytes)
+  {
+    REQUIRE(row0 == P.rows_seen, GMG_ERR_STATE, "row blocks must arrive in order (expected row " + std::to_string(P.rows_seen) + ")");
+    REQUIRE(nr >= 0 && row0 + nr <= P.nrows, GMG_ERR_INVALID, "row block exceeds the operator");
+    REQUIRE(ptr && (nr == 0 || (idx && val)), GMG_ERR_INVALID, "null row block");
+    const int64_t p0 = read_index(ptr, 0, bytes);
+    REQUIRE(p0 == base, GMG_ERR_INVALID, "row pointers of a block start at index_base");
+    constexpr int kMaxPatterns = 4096;
+    std::vector<int32_t> found((size_t)nr, -1);
+    std::vector<uint64_t> hashes((size_t)nr);
+    std::atomic<int> bad(0);
+    std::atomic<int64_t> wmax(P.wmax);
+    parallel_for(nr, [&](int64_t i) {
+      const int64_t k0 = read_index(ptr, i, bytes) - base, k1 = read_index(ptr, i + 1, bytes) - base;
+      if (k1 < k0 || k1 - k0 > 1024) { bad.store(1); return; }
+      const int64_t len = k1 - k0;
+      const int64_t c0 = len > 0 ? read_index(idx, k0, bytes) - base : 0;
+      const int64_t ref = P.mode == 0 ? row0 + i : c0;
+      uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
+      int64_t prev = -1;
+      for (int64_t j = 0; j < len; ++j) {
+        const int64_t c = read_index(idx, k0 + j, bytes) - base;
+        if (c < 0 || c >= P.ncols) { bad.store(2); return; }
+        if (c <= prev) { bad.store(3); return; }             // sorted, duplicate-free rows only (what assemblers emit)
+        prev = c;
+        uint64_t bits;
+        std::memcpy(&bits, &val[k0 + j], 8);
+        h = (h ^ (uint64_t)(uint32_t)(int32_t)(c - ref)) * 1099511628211ull;
+        h = (h ^ bits) * 1099511628211ull;
+        h ^= h >> 29;
+      }
+      hashes[(size_t)i] = h;
+      int64_t w = wmax.load(std::memory_order_relaxed);
+      while (len > w && !wmax.compare_exchange_weak(w, len)) {}
+      auto it = P.index.find(h);
+      if (it == P.index.end()) return;
+      for (int32_t q : it->second) {
+        if (P.len[q] != (int32_t)len) continue;
+        bool eq = true;
+        for (int64_t j = 0; j < len && eq; ++j) {
+          uint64_t bits;
+          std::memcpy(&bits, &val[k0 + j], 8);
+          eq = P.off[P.start[q] + j] == (int32_t)(read_index(idx, k0 + j, bytes) - base - ref) && P.val[P.start[q] + j] == bits;
+        }
+        if (eq) { found[(size_t)i] = q; return; }
+      }
+    });
+    REQUIRE(bad.load() != 1, GMG_ERR_INVALID, "row pointers not monotone, or a row longer than 1024 entries");
+    REQUIRE(bad.load() != 2, GMG_ERR_INVALID, "column index out of range");
+    REQUIRE(bad.load() != 3, GMG_ERR_UNSUPPORTED, "streamed rows must have sorted, duplicate-free columns");
+    P.wmax = wmax.load();
+    P.rowpid.resize((size_t)(row0 + nr));
+    if (P.mode == 1) P.rowbase.resize((size_t)(row0 + nr));
+    for (int64_t i = 0; i < nr; ++i) {
+      const int64_t k0 = read_index(ptr, i, bytes) - base, len = read_index(ptr, i + 1, bytes) - base - k0;
+      const int64_t c0 = len > 0 ? read_index(idx, k0, bytes) - base : 0;
+      const int64_t ref = P.mode == 0 ? row0 + i : c0;
+      int32_t q = found[(size_t)i];
+      if (q < 0) {
+        auto &bucket = P.index[hashes[(size_t)i]];
+        for (int32_t cand : bucket) {                        // inserted earlier in this very block?
+          if (P.len[cand] != (int32_t)len) continue;
+          bool eq = true;
+          for (int64_t j = 0; j < len && eq; ++j) {
+            uint64_t bits;
+            std::memcpy(&bits, &val[k0 + j], 8);
+            eq = P.off[P.start[cand] + j] == (int32_t)(read_index(idx, k0 + j, bytes) - base - ref) && P.val[P.start[cand] + j] == bits;
+          }
+          if (eq) { q = cand; break; }
+        }
+        if (q < 0) {
+          REQUIRE((int)P.len.size() < kMaxPatterns, GMG_ERR_UNSUPPORTED,
+                  "streamed operator has more than 4096 distinct rows: it is not pattern-compressible; pass it whole (gmg_set_matrix)");
+          q = (int32_t)P.len.size();
+          P.len.push_back((int32_t)len);
+          P.start.push_back((int32_t)P.off.size());
+          for (int64_t j = 0; j < len; ++j) {
+            uint64_t bits;
+            std::memcpy(&bits, &val[k0 + j], 8);
+            P.off.push_back((int32_t)(read_index(idx, k0 + j, bytes) - base - ref));
+            P.val.push_back(bits);
+          }
+          bucket.push_back(q);
+        }
+      }
+      P.rowpid[(size_t)(row0 + i)] = (uint16_t)q;
+      if (P.mode == 1) P.rowbase[(size_t)(row0 + i)] = (int32_t)c0;
+      P.nnz += len;
+    }
+    P.rows_seen = row0 + nr;
+  }
+  // device form of a completed stream (the counterpart of upload_csr)
+  DevCSR finish_stream(PatStream &P, const char *what)
+  {
+    REQUIRE(P.complete(), GMG_ERR_STATE, std::string(what) + ": row stream incomplete (" + std::to_string(P.rows_seen) + " of " + std::to_string(P.nrows) + " rows)");
+    REQUIRE(use_pattern && use_sell, GMG_ERR_UNSUPPORTED, "streamed operators need the row-pattern layout (GMG_PATTERN=1, GMG_SELL=1)");
+    REQUIRE(P.ncols < (int64_t)(1 << 28) && P.nrows >= 1 && P.nnz > 0, GMG_ERR_UNSUPPORTED, "streamed operator: unsupported shape");
+    DevCSR D;
+    D.nrows = P.nrows; D.ncols = P.ncols; D.nnz = P.nnz;
+    const int np = (int)P.len.size();
+    std::vector<int32_t> plen(P.len);
+    plen.push_back(0);                                      // trailing empty pattern for the lanes past nrows
+    const int un = pat_un_eff();
+    const int W = (int)((std::max<int64_t>(P.wmax, 1) + un - 1) / un * un);
+    const bool generic = (int64_t)(np + 1) * (12 * W + 4) <= 48 * 1024;
+    std::vector<int32_t> poff((size_t)(np + 1) * W, 0);
+    std::vector<double> pval((size_t)(np + 1) * W, 0.0);
+    for (int p = 0; p < np; ++p)
+      for (int32_t j = 0; j < P.len[p]; ++j) {
+        poff[(size_t)p * W + j] = 8 * P.off[P.start[p] + j];
+        std::memcpy(&pval[(size_t)p * W + j], &P.val[P.start[p] + j], 8);
+      }
+    if (P.mode == 0 && pat_shared && one_gather()) build_shared_offsets(D, plen, poff, pval, W, P.ncols, generic);
+    REQUIRE(generic || D.pat_shared, GMG_ERR_UNSUPPORTED,
+            std::string(what) + ": the pattern table of the streamed operator fits neither LDS form; pass it whole (gmg_set_matrix)");
+    if (P.mode == 0 && P.nrows == P.ncols && !D.pdinv) {    // 1 ./ diag per pattern (JacobiLinearSolvers.jl:20-23)
+      std::vector<double> pd((size_t)np + 1, 0.0);
+      bool all = true;
+      for (int p = 0; p < np && all; ++p) {
+        bool f = false;
+        for (int32_t j = 0; j < P.len[p]; ++j)
+          if (P.off[P.start[p] + j] == 0) { double v; std::memcpy(&v, &P.val[P.start[p] + j], 8); pd[p] = 1.0 / v; f = true; }
+        all = f;
+      }
+      if (all) D.pdinv = upload(pd);
+    }
+    upload_pattern(D, P.nrows, P.rowpid, P.rowbase, plen, poff, pval, W, generic, true);
+    return D;                                                // P keeps its per-row ids (2-6 B/row): gmg_setup may run again
   }
   // Shared-offset form of a row-relative pattern table (sells_kernel): the union of all offsets, covered
   // greedily by runs of three consecutive offsets; every pattern becomes a dense coefficient vector over it.
@@ -1630,6 +1788,17 @@ struct gmg_solver {
   {
     const int64_t n = A.nrows;
     double *dinv = dalloc<double>((size_t)n);
+    if (A.rowptr == nullptr) {                               // streamed operator: 1/diag per pattern, expanded per row
+      nzero = 0;
+      if (!A.pdinv) { nzero = 1; return dinv; }              // some row pattern has no diagonal entry
+      hipLaunchKernelGGL(expand_pattern_dinv_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, A.rowpid, A.pdinv, dinv);
+      HIP_CHECK(hipGetLastError());
+      std::vector<double> pd((size_t)A.pat_np);
+      HIP_CHECK(hipMemcpyAsync(pd.data(), A.pdinv, sizeof(double) * pd.size(), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      for (int q = 0; q + 1 < A.pat_np; ++q) if (!std::isfinite(pd[(size_t)q])) nzero++;
+      return dinv;
+    }
     int *d_nzero = dalloc<int>(1);
     HIP_CHECK(hipMemsetAsync(d_nzero, 0, sizeof(int), stream));
     const int grid = (int)std::max<int64_t>(1, (n + 255) / 256);
@@ -2187,6 +2356,8 @@ struct BandLU {
 void gmg_solver::build_coarse()
 {
   const int64_t n = lev[nlev - 1].n;
+  REQUIRE(!(lev[nlev - 1].sA && coarse_kind == GMG_COARSE_DENSE_INVERSE), GMG_ERR_UNSUPPORTED,
+          "the dense-inverse coarse solver needs the coarsest matrix whole (gmg_set_matrix), not streamed");
   if (coarse_kind == GMG_COARSE_DENSE_INVERSE) d_Ainv = build_dense_inverse(lev[nlev - 1].hA, "coarsest-level matrix");
   else if (coarse_kind == GMG_COARSE_CG_JACOBI) { cc_w = dvec(n); cc_p = dvec(n); cc_z = dvec(n); cc_r = dvec(n); }
   else {
@@ -2336,6 +2507,7 @@ void gmg_solver::setup()
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     if (L.halo.present && comm.nranks > 1) {
+      REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "streamed operators are single-GPU in this round");
       // own x own / own x ghost split: A keeps the owned columns, the ghost columns of the rows
       // that have any go to a small CSR applied after the halo has arrived (finish_ghost)
       HostCSR loc;
@@ -2380,7 +2552,8 @@ void gmg_solver::setup()
       }
       L.A = upload_csr(loc);
       L.A.nnz_model = L.hA.nnz();
-    } else
+    } else if (L.sA) L.A = finish_stream(*L.sA, "level matrix");
+    else
     L.A = upload_csr(L.hA);                                 // :185 gmg_compute_matrices
     lap("A: upload + layout", l);
     L.rbuf[0] = dvec(L.nvec);                               // :187,188 rh / rH
@@ -2398,9 +2571,10 @@ void gmg_solver::setup()
       L.rbuf[1] = dvec(L.nvec);
       L.dx = dvec(L.nvec);
       if (one_gather()) { L.sbuf[0] = dvec(L.nvec); L.sbuf[1] = dvec(L.nvec); }                                     // :188 dxh (Adxh is fused away)
-      L.P = upload_csr(L.hP);
-      if (L.hasR) L.R = upload_csr(L.hR);
+      L.P = L.sP ? finish_stream(*L.sP, "prolongation") : upload_csr(L.hP);
+      if (L.hasR) L.R = L.sR ? finish_stream(*L.sR, "restriction") : upload_csr(L.hR);
       else {
+        REQUIRE(!L.sP, GMG_ERR_STATE, "a streamed prolongation needs a streamed restriction too (R = P^T is not formed from a stream)");
         HostCSR Rt = transpose(L.hP);                       // R = P^T, GridTransferOperators.jl:536-547
         L.R = upload_csr(Rt);
       }
@@ -2550,8 +2724,38 @@ int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_
     check_level(h, lev, false);
     REQUIRE(nrows == ncols || h->comm.nranks > 1, GMG_ERR_INVALID, "level matrix must be square");
     h->lev[lev].hA = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
-    h->lev[lev].hasA = true;
+    h->lev[lev].hasA = true; h->lev[lev].sA.reset();
     h->setup_done = false;
+  });
+}
+
+int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, int64_t ncols, int64_t row0, int64_t nrows_block,
+                          const void *ptr, const void *idx, const double *val, int index_base, int index_bytes)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, op != GMG_OP_A);
+    REQUIRE(op == GMG_OP_A || op == GMG_OP_P || op == GMG_OP_R, GMG_ERR_INVALID, "unknown operator");
+    REQUIRE(index_bytes == 4 || index_bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
+    REQUIRE(index_base == 0 || index_base == 1, GMG_ERR_INVALID, "index_base must be 0 or 1");
+    REQUIRE(nrows_total >= 1 && ncols >= 1 && nrows_total < (int64_t)INT32_MAX && ncols < (int64_t)INT32_MAX, GMG_ERR_INVALID, "bad operator shape");
+    REQUIRE(h->comm.nranks == 1, GMG_ERR_UNSUPPORTED, "streamed operators are single-GPU in this round");
+    Level &L = h->lev[lev];
+    std::shared_ptr<PatStream> &S = op == GMG_OP_A ? L.sA : op == GMG_OP_P ? L.sP : L.sR;
+    HostCSR &H = op == GMG_OP_A ? L.hA : op == GMG_OP_P ? L.hP : L.hR;
+    bool &has = op == GMG_OP_A ? L.hasA : op == GMG_OP_P ? L.hasP : L.hasR;
+    if (row0 == 0) {                                        // first block: (re)start the stream
+      if (op == GMG_OP_A) REQUIRE(nrows_total == ncols, GMG_ERR_INVALID, "level matrix must be square");
+      S = std::make_shared<PatStream>();
+      S->mode = (op == GMG_OP_A) ? 0 : 1;
+      S->nrows = nrows_total; S->ncols = ncols;
+      H = HostCSR();
+      H.nrows = nrows_total; H.ncols = ncols;               // shape only: the rows are never kept
+      has = false;
+      h->setup_done = false;
+    }
+    REQUIRE(S && S->nrows == nrows_total && S->ncols == ncols, GMG_ERR_STATE, "row block does not continue the stream started with row0 = 0");
+    h->stream_append(*S, row0, nrows_block, ptr, idx, val, index_base, index_bytes);
+    if (S->complete()) has = true;
   });
 }
 
@@ -2561,6 +2765,7 @@ int gmg_update_values(gmg_handle_t h, int lev, const double *val)
     check_level(h, lev, false);
     Level &L = h->lev[lev];
     REQUIRE(L.hasA, GMG_ERR_STATE, "no matrix set on this level");
+    REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "streamed operators are refreshed by streaming them again");
     REQUIRE(val, GMG_ERR_INVALID, "null values");
     // values are given in the 0-based CSR order held by the handle
     std::memcpy(L.hA.val.data(), val, sizeof(double) * (size_t)L.hA.nnz());
@@ -2574,7 +2779,7 @@ int gmg_set_prolongation(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, 
   return guarded(h, [&] {
     check_level(h, lev, true);
     h->lev[lev].hP = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
-    h->lev[lev].hasP = true;
+    h->lev[lev].hasP = true; h->lev[lev].sP.reset();
     h->setup_done = false;
   });
 }
@@ -2585,7 +2790,7 @@ int gmg_set_restriction(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, i
   return guarded(h, [&] {
     check_level(h, lev, true);
     h->lev[lev].hR = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
-    h->lev[lev].hasR = true;
+    h->lev[lev].hasR = true; h->lev[lev].sR.reset();
     h->setup_done = false;
   });
 }

@@ -29,7 +29,8 @@ import numpy as np
 __all__ = [
     "CSR", "poisson_matrix", "prolongation", "dirichlet_lift_rhs", "nodal_values",
     "l2_error_sq", "vertex_star_patches", "coarse_cell_interior_patches", "build_hierarchy", "random_rhs", "level_sizes",
-    "poisson_matrix_varcoef", "smooth_kappa",
+    "poisson_matrix_varcoef", "smooth_kappa", "StreamedCSR", "poisson_matrix_stream", "prolongation_stream",
+    "restriction_stream",
 ]
 
 
@@ -57,6 +58,31 @@ class CSR:
 
     def matvec(self, x):
         return self.to_scipy() @ x
+
+
+class StreamedCSR:
+    """An operator delivered as consecutive row blocks instead of one CSR (shape known up front).
+
+    `row_blocks()` yields (row0, CSR block) with global column indices; the solver hands every block to
+    gmg_set_operator_rows and drops it, so the host never holds more than one block -- the driver-side counterpart of an
+    assembler that emits the matrix slab by slab."""
+
+    def __init__(self, shape, blocks_fn):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self._fn = blocks_fn
+
+    def row_blocks(self):
+        return self._fn()
+
+    def materialize(self):
+        """the whole operator as one CSR (tests / small sizes)"""
+        ptrs, idxs, vals, base = [np.zeros(1, dtype=np.int64)], [], [], 0
+        for row0, B in self.row_blocks():
+            ptrs.append(B.ptr[1:] + base)
+            idxs.append(B.idx); vals.append(B.val)
+            base += B.nnz
+        return CSR(self.shape, np.concatenate(ptrs), np.concatenate(idxs) if idxs else np.zeros(0, np.int32),
+                   np.concatenate(vals) if vals else np.zeros(0))
 
 
 # --------------------------------------------------------------------------
@@ -174,6 +200,40 @@ def _tensor_csr(axes, terms, ncols_axes):
     return CSR((nx * ny * nz, ncx * ncy * ncz), ptr, idx, val)
 
 
+def _tensor_csr_blocks(axes, terms, ncols_axes):
+    """The same operator as `_tensor_csr`, one z-plane of rows at a time: yields (row0, CSR block).  Values are formed by
+    the same products and sums (bit-identical to `_tensor_csr`).  Planes whose 1-D z-rows agree up to a shift of the
+    column index (all interior planes of a uniform mesh, period `order`) reuse the first such plane's arrays: the
+    columns get a constant added, the values are the very same array."""
+    cx, cy, cz = axes
+    nx, ny, nz = cx.shape[0], cy.shape[0], cz.shape[0]
+    ncx, ncy, ncz = ncols_axes
+    mx, my, mz = cx >= 0, cy >= 0, cz >= 0
+    cache = {}
+    for z in range(nz):
+        valid = np.nonzero(mz[z])[0]
+        first = int(cz[z, valid[0]]) if valid.size else 0
+        key = (tuple(np.where(mz[z], cz[z] - first, -1).tolist()),) + tuple(tuple(t[2][z].tolist()) for t in terms)
+        hit = cache.get(key)
+        if hit is None:
+            mask = (mz[z:z + 1, None, None, :, None, None] & my[None, :, None, None, :, None] & mx[None, None, :, None, None, :])
+            col = (cz[z:z + 1, None, None, :, None, None] * (ncy * ncx) + cy[None, :, None, None, :, None] * ncx
+                   + cx[None, None, :, None, None, :])
+            v = None
+            for (vx, vy, vz) in terms:
+                t = (vz[z:z + 1, None, None, :, None, None] * vy[None, :, None, None, :, None] * vx[None, None, :, None, None, :])
+                v = t if v is None else v + t
+            ptr = np.zeros(ny * nx + 1, dtype=np.int64)
+            np.cumsum(mask.reshape(ny * nx, -1).sum(axis=1), out=ptr[1:])
+            hit = (first, ptr, col[mask].astype(np.int64), np.ascontiguousarray(v[mask]))
+            del mask, col, v
+            if len(cache) < 12:
+                cache[key] = hit
+        f0, ptr, idx0, val = hit
+        idx = idx0 + (first - f0) * (ncy * ncx) if first != f0 else idx0
+        yield z * ny * nx, CSR((ny * nx, ncx * ncy * ncz), ptr, idx, val)
+
+
 def _dims(ncells):
     nc = tuple(int(c) for c in ncells)
     if len(nc) not in (2, 3):
@@ -275,6 +335,23 @@ def poisson_matrix_varcoef(ncells, kappa=None, lengths=None) -> CSR:
     return CSR((N, N), ptr, cols.reshape(N, W)[keep].astype(np.int32), vals.reshape(N, W)[keep])
 
 
+def poisson_matrix_stream(ncells, order=1, lengths=None) -> StreamedCSR:
+    """`poisson_matrix` as a row-block stream (one z-plane of nodes per block)."""
+    nc, d = _dims(ncells)
+    Ls = _lengths(lengths, d)
+
+    def blocks():
+        tabs = [_axis_tables(nc[k], order, k < d, Ls[k]) for k in range(3)]
+        K = [t[2] for t in tabs]
+        M = [t[3] for t in tabs]
+        terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
+        if d == 3:
+            terms.append((M[0], M[1], K[2]))
+        return _tensor_csr_blocks([t[1] for t in tabs], terms, [t[0] for t in tabs])
+    n = level_sizes(ncells, order)
+    return StreamedCSR((n, n), blocks)
+
+
 def _interp_1d(nc_coarse, order):
     """Dense 1-D interpolation, fine nodes (2*nc cells) x coarse nodes."""
     nH = order * nc_coarse + 1
@@ -315,6 +392,50 @@ def prolongation(ncells_coarse, order=1) -> CSR:
         c, (v,) = _padded_rows(S, [P], free_h, col_map)
         cols.append(c); vals.append(v); ncols.append(nH - 2)
     return _tensor_csr(cols, [tuple(vals)], ncols)
+
+
+def _transfer_tables(ncells_coarse, order, transpose):
+    nc, d = _dims(ncells_coarse)
+    cols, vals, ncols = [], [], []
+    for k in range(3):
+        if k >= d:
+            cols.append(np.zeros((1, 1), dtype=np.int64)); vals.append(np.ones((1, 1))); ncols.append(1)
+            continue
+        P, S = _interp_1d(nc[k], order)
+        nh, nH = P.shape
+        if transpose:                                       # rows = coarse free nodes, columns = fine free nodes
+            col_map = -np.ones(nh, dtype=np.int64)
+            col_map[1:nh - 1] = np.arange(nh - 2)
+            c, (v,) = _padded_rows(S.T.copy(), [P.T.copy()], np.arange(1, nH - 1), col_map)
+            ncols.append(nh - 2)
+        else:
+            col_map = -np.ones(nH, dtype=np.int64)
+            col_map[1:nH - 1] = np.arange(nH - 2)
+            c, (v,) = _padded_rows(S, [P], np.arange(1, nh - 1), col_map)
+            ncols.append(nH - 2)
+        cols.append(c); vals.append(v)
+    return cols, vals, ncols
+
+
+def prolongation_stream(ncells_coarse, order=1) -> StreamedCSR:
+    """`prolongation` as a row-block stream."""
+    nc = tuple(int(c) for c in ncells_coarse)
+
+    def blocks():
+        cols, vals, ncols = _transfer_tables(nc, order, False)
+        return _tensor_csr_blocks(cols, [tuple(vals)], ncols)
+    return StreamedCSR((level_sizes(tuple(2 * c for c in nc), order), level_sizes(nc, order)), blocks)
+
+
+def restriction_stream(ncells_coarse, order=1) -> StreamedCSR:
+    """R = P^T as a row-block stream (rows = coarse dofs): the tensor product of the transposed 1-D interpolations, so the
+    entries are the very numbers of `prolongation(...).transpose()`."""
+    nc = tuple(int(c) for c in ncells_coarse)
+
+    def blocks():
+        cols, vals, ncols = _transfer_tables(nc, order, True)
+        return _tensor_csr_blocks(cols, [tuple(vals)], ncols)
+    return StreamedCSR((level_sizes(nc, order), level_sizes(tuple(2 * c for c in nc), order)), blocks)
 
 
 def _apply_axes(G, mats):
@@ -411,18 +532,31 @@ def vertex_star_patches(ncells, order=1):
         return out
 
     ax, ay, az = axis_lists(0), axis_lists(1), axis_lists(2)
-    ptr = [0]
-    dofs = []
+    # vectorised over one z-layer of vertices at a time (16.6 M patches at 256^3): per axis the dof lists are runs
+    # [start, start+cnt); a patch is their tensor product, dofs ascending = z-major enumeration of the product
+    sx = np.array([l[0] if len(l) else 0 for l in ax], dtype=np.int64); cxn = np.array([len(l) for l in ax], dtype=np.int64)
+    sy = np.array([l[0] if len(l) else 0 for l in ay], dtype=np.int64); cyn = np.array([len(l) for l in ay], dtype=np.int64)
+    sizes_xy = (cyn[:, None] * cxn[None, :]).reshape(-1)
+    ptr_parts, dof_parts, base = [np.zeros(1, dtype=np.int64)], [], 0
     for lz in az:
-        for ly in ay:
-            for lx in ax:
-                if len(lx) == 0 or len(ly) == 0 or len(lz) == 0:
-                    ptr.append(ptr[-1]); continue
-                g = (lz[:, None, None] * (nf[1] * nf[0]) + ly[None, :, None] * nf[0] + lx[None, None, :]).reshape(-1)
-                dofs.append(g)
-                ptr.append(ptr[-1] + g.size)
-    dofs = np.concatenate(dofs) if dofs else np.zeros(0, dtype=np.int64)
-    return np.asarray(ptr, dtype=np.int64), dofs.astype(np.int32)
+        cz = len(lz)
+        sizes = sizes_xy * cz
+        ptr_parts.append(base + np.cumsum(sizes))
+        tot = int(sizes.sum())
+        base += tot
+        if tot == 0:
+            continue
+        pid = np.repeat(np.arange(sizes.size, dtype=np.int64), sizes)
+        t = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(sizes) - sizes, sizes)      # index inside the patch
+        py, px = pid // cxn.size, pid % cxn.size
+        nxp, nyp = cxn[px], cyn[py]
+        iz = t // (nyp * nxp)
+        iy = (t // nxp) % nyp
+        ix = t % nxp
+        g = (lz[0] + iz) * (nf[1] * nf[0]) + (sy[py] + iy) * nf[0] + (sx[px] + ix)
+        dof_parts.append(g.astype(np.int32))
+    dofs = np.concatenate(dof_parts) if dof_parts else np.zeros(0, dtype=np.int32)
+    return np.concatenate(ptr_parts), dofs
 
 
 def coarse_cell_interior_patches(ncells_coarse, order=1):
@@ -448,10 +582,12 @@ def coarse_cell_interior_patches(ncells_coarse, order=1):
     return np.asarray(ptr, dtype=np.int64), np.concatenate(dofs).astype(np.int32)
 
 
-def build_hierarchy(ncells_fine, nlevels, order=1, lengths=None, kappa=None):
+def build_hierarchy(ncells_fine, nlevels, order=1, lengths=None, kappa=None, stream_min_rows=None):
     """Level 1 = finest (reference convention, ModelHierarchies.jl:80-111).
     kappa (Q1 only): callable kappa(X,Y,Z) -> every level is the re-discretised variable-coefficient operator
     (GMGLinearSolvers.jl:342-353 assembles the level matrices from the weak form per level).
+    stream_min_rows: operators with at least that many rows are returned as `StreamedCSR` row-block streams (never
+    materialised here); restrictions of streamed prolongations are streamed too.
 
     Returns dict(mats=[A_1..A_L], prolongations=[P_1..P_{L-1}] (P_l: level l+1 -> l),
     restrictions=[R_l = P_l^T], ncells=[...], order=order)."""
@@ -465,7 +601,11 @@ def build_hierarchy(ncells_fine, nlevels, order=1, lengths=None, kappa=None):
             raise ValueError("variable-coefficient generator is Q1 only")
         mats = [poisson_matrix_varcoef(c, kappa, lengths) for c in cells]
     else:
-        mats = [poisson_matrix(c, order, lengths) for c in cells]
+        big = lambda c: stream_min_rows is not None and level_sizes(c, order) >= stream_min_rows
+        mats = [poisson_matrix_stream(c, order, lengths) if big(c) else poisson_matrix(c, order, lengths) for c in cells]
+        Ps = [prolongation_stream(cells[l + 1], order) if big(cells[l]) else prolongation(cells[l + 1], order) for l in range(nlevels - 1)]
+        Rs = [restriction_stream(cells[l + 1], order) if big(cells[l]) else Ps[l].transpose() for l in range(nlevels - 1)]
+        return dict(mats=mats, prolongations=Ps, restrictions=Rs, ncells=cells, order=order)
     Ps = [prolongation(cells[l + 1], order) for l in range(nlevels - 1)]
     Rs = [P.transpose() for P in Ps]
     return dict(mats=mats, prolongations=Ps, restrictions=Rs, ncells=cells, order=order)

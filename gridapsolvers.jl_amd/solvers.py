@@ -306,6 +306,22 @@ def _csr_fields(M):
 
 
 def _set_op(fn, h, lev, M):
+    if hasattr(M, "row_blocks"):
+        # an operator delivered as consecutive row blocks (poisson.StreamedCSR): gmg_set_operator_rows per block, the block
+        # is dropped right after -- the host never holds the whole CSR
+        lib = abi.load()
+        op = {"gmg_set_matrix": abi.OP_A, "gmg_set_prolongation": abi.OP_P, "gmg_set_restriction": abi.OP_R}[fn.__name__]
+        seen = 0
+        for row0, B in M.row_blocks():
+            ptr = np.ascontiguousarray(B.ptr, dtype=np.int64)
+            idx = np.ascontiguousarray(B.idx, dtype=np.int64)
+            val = np.ascontiguousarray(B.val, dtype=np.float64)
+            abi.check(h, lib.gmg_set_operator_rows(h, lev, op, M.shape[0], M.shape[1], row0, B.shape[0], C.c_void_p(ptr.ctypes.data),
+                                                   C.c_void_p(idx.ctypes.data), C.c_void_p(val.ctypes.data), 0, 8))
+            seen = row0 + B.shape[0]
+        if seen != M.shape[0]:
+            raise ValueError("row-block stream ended early")
+        return
     shape, ptr, idx, val, layout, base = _csr_fields(M)
     if ptr.dtype != idx.dtype:
         ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
@@ -392,8 +408,8 @@ class GMGNumericalSetup:
             self._coarse_cb = abi.COARSE_SOLVE_FN(_cb)
             abi.check(h, lib.gmg_set_coarse_solver(h, abi.COARSE_HOST_CALLBACK, 0, 0.0, 0.0, C.cast(self._coarse_cb, C.c_void_p), None))
         abi.check(h, lib.gmg_setup(h))
-        self.n = int(_csr_fields(mats[0])[0][0])
-        self.sizes = [int(_csr_fields(A)[0][0]) for A in mats]
+        self.n = int(mats[0].shape[0])
+        self.sizes = [int(A.shape[0]) for A in mats]
 
     def _set_smoother(self, l, which, sm):
         lib, h = self._lib, self.h

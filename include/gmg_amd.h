@@ -94,6 +94,18 @@ GMG_API int gmg_version(void);
 GMG_API int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_t nnz,
                            const void *ptr, const void *idx, const double *val,
                            int layout, int index_base, int index_bytes);
+/* The same operators (op = GMG_OP_A, GMG_OP_P or GMG_OP_R of level lev) handed over as a STREAM of consecutive row blocks,
+ * for hierarchies whose CSR the host cannot or need not hold at once (BASELINE config 3: 8.5e9 nonzeros on the finest level).
+ * Each call passes rows [row0, row0 + nrows_block) as a standalone CSR (ptr has nrows_block+1 entries starting at
+ * index_base, columns are global, sorted and duplicate-free); row0 = 0 (re)starts the stream, blocks arrive in order, the
+ * operator is complete when row0 + nrows_block = nrows_total.  The library keeps only the row-pattern form (a pattern id
+ * per row + the dictionary of distinct rows): host memory is O(block).  Operators with more than 4096 distinct rows
+ * (variable coefficients, unstructured meshes) are rejected with GMG_ERR_UNSUPPORTED -- pass those whole.
+ * A streamed P needs a streamed R (R = P^T is not formed from a stream); the coarsest matrix is passed whole unless the
+ * coarse solver is iterative / a callback.  Single GPU. */
+GMG_API int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, int64_t ncols, int64_t row0,
+                                  int64_t nrows_block, const void *ptr, const void *idx, const double *val,
+                                  int index_base, int index_bytes);
 /* numerical_setup!(ns,A): same pattern, new values (GMGLinearSolvers.jl:249-297;
  * JacobiLinearSolvers.jl:25-27).  Requires gmg_setup to be called again. */
 GMG_API int gmg_update_values(gmg_handle_t h, int lev, const double *val);

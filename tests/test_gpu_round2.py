@@ -300,8 +300,9 @@ def test_patch_rows_differ_from_cols(S, po, orc, hierarchy, kind):
     A = H["mats"][0]
     pp, pd = po.vertex_star_patches(nc, order)
     pc = pd.copy()
-    for p in range(pp.size - 1):
-        pc[pp[p]:pp[p + 1]] = pd[pp[p]:pp[p + 1]][::-1]                    # same dofs, reversed
+    if kind == "patch":                                                     # (a column permutation needs pivoting: NoPivot keeps cols == rows,
+        for p in range(pp.size - 1):                                        #  passed as a separate table)
+            pc[pp[p]:pp[p + 1]] = pd[pp[p]:pp[p + 1]][::-1]                # same dofs, reversed
     M = (S.PatchSolver if kind == "patch" else S.BlockJacobiSolver)(pp, pd, patch_cols=pc)
     gmg = make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(M, 4, 0.2)])
     ns = setup(S, gmg, A)
@@ -319,3 +320,121 @@ def test_patch_rows_differ_from_cols(S, po, orc, hierarchy, kind):
     ns1 = setup(S, make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(type(M)(pp, pd), 4, 0.2)]), A)
     z1 = np.zeros_like(r); S.solve_(z1, ns1, r)
     assert rel_err(z, z1) <= 1e-10
+
+
+# ---------------------------------------------------------------- streamed operators (gmg_set_operator_rows)
+@pytest.mark.parametrize("nc,nlev,order", [((16, 16, 16), 3, 1), ((8, 8, 8), 2, 2), ((24, 16), 3, 2)])
+def test_streamed_operators_bitwise_equal_whole(S, po, orc, nc, nlev, order):
+    """the hierarchy handed over as row-block streams (A, P, R of every level but the coarsest) gives bit-identical
+    mat-vecs and V-cycles to the same hierarchy passed whole; the library never sees a CSR of the streamed operators."""
+    from gridapsolvers_jl_amd import abi
+    Hw = po.build_hierarchy(nc, nlev, order)
+    nL = Hw["mats"][-1].shape[0]
+    Hs = po.build_hierarchy(nc, nlev, order, stream_min_rows=nL + 1)        # everything above the coarsest level is streamed
+    assert all(hasattr(M, "row_blocks") for M in Hs["mats"][:-1]) and not hasattr(Hs["mats"][-1], "row_blocks")
+    nw = setup(S, make_gmg(S, Hw), Hw["mats"][0])
+    ns = setup(S, make_gmg(S, Hs), Hs["mats"][0])
+    assert ns.level_format(0)["row_patterns"]
+    for l in range(nlev - 1):
+        A, P = Hw["mats"][l], Hw["prolongations"][l]
+        x = np.random.default_rng(l).uniform(-1, 1, A.shape[0])
+        xc = np.random.default_rng(10 + l).uniform(-1, 1, P.shape[1])
+        for op, v, m in ((abi.OP_A, x, A.shape[0]), (abi.OP_P, xc, P.shape[0]), (abi.OP_R, x, P.shape[1])):
+            y1, y2 = np.zeros(m), np.zeros(m)
+            nw.op_apply(l, op, v, y1); ns.op_apply(l, op, v, y2)
+            np.testing.assert_array_equal(y1, y2)
+        assert max_rel(y2, orc.spmv(Hw["restrictions"][l], x)) <= 1e-13
+    r = np.random.default_rng(99).uniform(-1, 1, Hw["mats"][0].shape[0])
+    z1, z2 = np.zeros_like(r), np.zeros_like(r)
+    S.solve_(z1, nw, r); S.solve_(z2, ns, r)
+    np.testing.assert_array_equal(z1, z2)
+    assert ns.device_bytes() <= nw.device_bytes()
+
+
+def test_streamed_q2_patch_smoother_blocks_from_pattern(S, po, orc):
+    """patch blocks A[p,p] gathered from the ROW-PATTERN form (no CSR exists for a streamed operator): same smoother, same
+    FGMRES iteration as with the whole matrix and as the oracle."""
+    nc, nlev, order = (8, 8, 8), 2, 2
+    Hw = po.build_hierarchy(nc, nlev, order)
+    Hs = po.build_hierarchy(nc, nlev, order, stream_min_rows=Hw["mats"][-1].shape[0] + 1)
+    pp, pd = po.vertex_star_patches(nc, order)
+    sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2)]
+    b = po.dirichlet_lift_rhs(nc, order)
+    xs = []
+    for H in (Hw, Hs):
+        solver = S.FGMRESSolver(5, make_gmg(S, H, pre_smoothers=sm), maxiter=20, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        xs.append((x, solver.log.num_iters, solver.log.residuals[: solver.log.num_iters + 1].copy()))
+    assert xs[0][1] == xs[1][1]
+    np.testing.assert_allclose(xs[1][2], xs[0][2], rtol=1e-12)
+    assert rel_err(xs[1][0], xs[0][0]) <= 1e-13
+    go = orc.GMG(Hw["mats"], Hw["prolongations"], Hw["restrictions"], pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd)], maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(Hw["mats"][0], b, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-8)
+    assert nit == xs[1][1]
+    np.testing.assert_allclose(xs[1][2], hist, rtol=1e-6)
+    assert rel_err(xs[1][0], xo) <= 1e-9
+
+
+def test_streamed_operator_errors(S, po, pkg):
+    lib, abi = pkg.abi.load(), pkg.abi
+    nc = (8, 8, 8)
+    A = po.poisson_matrix(nc, 1)
+    n = A.shape[0]
+    h = C.c_void_p()
+    assert lib.gmg_create(C.byref(h), 2, 0) == abi.OK
+    blocks = list(po.poisson_matrix_stream(nc, 1).row_blocks())
+
+    def send(row0, B, op=abi.OP_A, nrows=n, ncols=n):
+        ptr = B.ptr.astype(np.int64); idx = B.idx.astype(np.int64)
+        return lib.gmg_set_operator_rows(h, 0, op, nrows, ncols, row0, B.shape[0], C.c_void_p(ptr.ctypes.data), C.c_void_p(idx.ctypes.data),
+                                         C.c_void_p(B.val.ctypes.data), 0, 8)
+    assert send(*blocks[0]) == abi.OK
+    assert send(*blocks[2]) == abi.ERR_STATE                                # out of order
+    assert send(*blocks[1]) == abi.OK
+    assert lib.gmg_setup(h) == abi.ERR_STATE                                # incomplete stream: no matrix on level 0 yet
+    # a variable-coefficient operator is not pattern-compressible: rejected, not silently mangled
+    V = po.poisson_matrix_varcoef((24, 24, 24))
+    ptr = V.ptr.astype(np.int64); idx = V.idx.astype(np.int64)
+    st = lib.gmg_set_operator_rows(h, 0, abi.OP_A, V.shape[0], V.shape[1], 0, V.shape[0], C.c_void_p(ptr.ctypes.data), C.c_void_p(idx.ctypes.data),
+                                   C.c_void_p(V.val.ctypes.data), 0, 8)
+    assert st == abi.ERR_UNSUPPORTED and b"4096" in lib.gmg_last_error(h)
+    # unsorted columns
+    B = blocks[0][1]
+    bad = B.idx.astype(np.int64).copy(); bad[[0, 1]] = bad[[1, 0]]
+    ptr = B.ptr.astype(np.int64)
+    st = lib.gmg_set_operator_rows(h, 0, abi.OP_A, n, n, 0, B.shape[0], C.c_void_p(ptr.ctypes.data), C.c_void_p(bad.ctypes.data),
+                                   C.c_void_p(B.val.ctypes.data), 0, 8)
+    assert st == abi.ERR_UNSUPPORTED
+    lib.gmg_destroy(h)
+
+
+# ---------------------------------------------------------------- BASELINE config 3 shape at the largest size the oracle affords
+def test_config3_shape_q2_32cubed_vs_oracle(S, po, orc):
+    """3-D Poisson Q2 32^3, 4 levels, Richardson(PatchSolver,10,0.2) pre = post on every level, FGMRES(5), rtol 1e-6
+    (test/LinearSolvers/GMGTests.jl:18-47,119-123): iteration count identical to the oracle, residual history <= 1e-6,
+    solution <= 1e-9, L2 error below the reference's 1e-8 criterion.  The two finest levels are streamed."""
+    nc, nlev, order = (32, 32, 32), 4, 2
+    Hw = po.build_hierarchy(nc, nlev, order)
+    Hs = po.build_hierarchy(nc, nlev, order, stream_min_rows=20000)
+    assert hasattr(Hs["mats"][0], "row_blocks") and hasattr(Hs["mats"][1], "row_blocks") and not hasattr(Hs["mats"][2], "row_blocks")
+    tabs = [po.vertex_star_patches(c, order) for c in Hw["ncells"][:-1]]
+    sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2) for pp, pd in tabs]
+    solver = S.FGMRESSolver(5, make_gmg(S, Hs, pre_smoothers=sm), maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = setup(S, solver, Hs["mats"][0])
+    b = po.dirichlet_lift_rhs(nc, order)
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    go = orc.GMG(Hw["mats"], Hw["prolongations"], Hw["restrictions"],
+                 pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in tabs], maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(Hw["mats"][0], b, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert solver.log.num_iters == nit and solver.log.flag == flag
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6)
+    assert rel_err(x, xo) <= 1e-9
+    assert po.l2_error_sq(nc, order, x) < 1e-8
+    # true residual through the device operator
+    from gridapsolvers_jl_amd import abi
+    y = np.zeros_like(b)
+    ns.P_ns.op_apply(0, abi.OP_A, x, y)
+    assert np.linalg.norm(b - y) <= 1.01e-6 * np.linalg.norm(b)
