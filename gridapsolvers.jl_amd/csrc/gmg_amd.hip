@@ -886,8 +886,7 @@ struct gmg_solver {
         std::memcpy(&pval[(size_t)p * W + j], &P.val[P.start[p] + j], 8);
       }
     if (P.mode == 0 && pat_shared && one_gather()) build_shared_offsets(D, plen, poff, pval, W, P.ncols, generic);
-    REQUIRE(generic || D.pat_shared, GMG_ERR_UNSUPPORTED,
-            std::string(what) + ": the pattern table of the streamed operator fits neither LDS form; pass it whole (gmg_set_matrix)");
+    // neither LDS form fits (many patterns x wide rows, e.g. Q2 transfer operators): the table is read from global memory / L2
     if (P.mode == 0 && P.nrows == P.ncols && !D.pdinv) {    // 1 ./ diag per pattern (JacobiLinearSolvers.jl:20-23)
       std::vector<double> pd((size_t)np + 1, 0.0);
       bool all = true;
@@ -1032,7 +1031,7 @@ struct gmg_solver {
   void launch_sellp(const DevCSR &M, const StreamArgs2 &a2)
   {
     if (M.pat_shared && (EPI != EPI_SWEEP || ONEG)) { launch_sells<EPI, ONEG>(M, a2); return; }
-    REQUIRE(M.pat_generic, GMG_ERR_UNSUPPORTED, "this operator only has the shared-offset pattern form (one-gather sweeps)");
+    REQUIRE(M.pat_generic || M.plen, GMG_ERR_UNSUPPORTED, "this operator only has the shared-offset pattern form (one-gather sweeps)");
     SellPArgs a;
     std::memset(&a, 0, sizeof(a));
     a.rowpid = M.rowpid; a.rowbase = M.rowbase; a.plen = M.plen; a.poff = M.ppoff; a.pval = M.ppval; a.np = M.pat_np; a.W = M.pat_w;
@@ -1043,6 +1042,17 @@ struct gmg_solver {
     const int nwg = std::max(1, std::min((M.nslices + wpb - 1) / wpb, pat_wgs));
     const size_t lds = (size_t)M.pat_np * M.pat_w * 12 + (size_t)M.pat_np * 4;
     const dim3 g(nwg), b(64 * wpb);
+    if (!M.pat_generic) {                                   // table kept in global memory / L2 (does not fit LDS)
+      switch (pat_un_eff()) {
+      case 27: hipLaunchKernelGGL((sellp_kernel<EPI, ONEG, 27, true>), g, b, 0, stream, a); break;
+      case 14: hipLaunchKernelGGL((sellp_kernel<EPI, ONEG, 14, true>), g, b, 0, stream, a); break;
+      case 9: hipLaunchKernelGGL((sellp_kernel<EPI, ONEG, 9, true>), g, b, 0, stream, a); break;
+      case 6: hipLaunchKernelGGL((sellp_kernel<EPI, ONEG, 6, true>), g, b, 0, stream, a); break;
+      default: hipLaunchKernelGGL((sellp_kernel<EPI, ONEG, 3, true>), g, b, 0, stream, a); break;
+      }
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
 #define GMG_SELLP_LAUNCH(UNV) hipLaunchKernelGGL((sellp_kernel<EPI, ONEG, UNV>), g, b, lds, stream, a)
     switch (pat_un_eff()) {
     case 27: GMG_SELLP_LAUNCH(27); break;

@@ -514,17 +514,24 @@ __device__ __forceinline__ double ld_off(const double *__restrict__ base, uint32
   return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff);
 }
 
-template <int EPI, bool ONEG, int UN>
+// GT = true: the pattern table is too big for LDS (many patterns x wide rows, e.g. Q2 transfer operators) and is read
+// from global memory instead -- it is a few hundred KB and stays in L2; same arithmetic, same order.
+template <int EPI, bool ONEG, int UN, bool GT = false>
 __global__ __launch_bounds__(kBlock) void sellp_kernel(SellPArgs a)
 {
   extern __shared__ double sp_smem[];
   const int tot = a.np * a.W;
-  double *s_val = sp_smem;
-  int32_t *s_off = reinterpret_cast<int32_t *>(sp_smem + tot);
-  int32_t *s_len = s_off + tot;
-  for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.pval[i]; s_off[i] = a.poff[i]; }
-  for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_len[i] = a.plen[i];
-  __syncthreads();
+  const double *s_val = GT ? a.pval : sp_smem;
+  const int32_t *s_off = GT ? a.poff : reinterpret_cast<const int32_t *>(sp_smem + tot);
+  const int32_t *s_len = GT ? a.plen : s_off + tot;
+  if (!GT) {
+    double *w_val = sp_smem;
+    int32_t *w_off = reinterpret_cast<int32_t *>(sp_smem + tot);
+    int32_t *w_len = w_off + tot;
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) { w_val[i] = a.pval[i]; w_off[i] = a.poff[i]; }
+    for (int i = threadIdx.x; i < a.np; i += blockDim.x) w_len[i] = a.plen[i];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
   // every workgroup owns a contiguous chunk of slices (its waves interleave inside it); with

@@ -4,7 +4,7 @@ ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/kt_q2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 400 rocprofv3 --kernel-trace -d $OUT/trace -o p -- python3 $ROOTDIR/tools/q2_patch.py ${1:-64} ${2:-4} > $OUT/trace.log 2>&1
+timeout -k 5 400 rocprofv3 --kernel-trace -d $OUT/trace -o p -- python3 $ROOTDIR/tools/config3.py --cells ${1:-64} --levels ${2:-4} > $OUT/trace.log 2>&1
 python3 - "$OUT" <<'PY' > $OUT/summary.txt 2>&1
 import glob, os, sqlite3, sys
 out = sys.argv[1]
