@@ -243,8 +243,10 @@ struct Smoother {
   int max_np = 0;
   int64_t *d_pptr = nullptr;
   int32_t *d_pdofs = nullptr;
+  int32_t *d_pcol = nullptr;    // == d_pdofs when patch_cols == patch_rows
   int64_t *d_boff = nullptr;
   double *d_binv = nullptr;
+  int64_t n_binv = 0, n_ubinv = 0, n_uboff = 0;   // allocation sizes (value refresh releases and rebuilds the blocks)
   // de-duplicated blocks (uniform meshes): patch -> unique block id, compact block store
   bool dedup = false;
   int64_t nuniq = 0;
@@ -266,6 +268,7 @@ struct Level {
   HostCSR hA, hP, hR;
   bool hasA = false, hasP = false, hasR = false;
   std::shared_ptr<PatStream> sA, sP, sR;   // streamed operators (hA/hP/hR then carry the shape only)
+  bool values_dirty = false;               // gmg_update_values since the last setup
   DevCSR A, P, R;
   double *dinv = nullptr;
   Smoother pre, post;
@@ -388,6 +391,9 @@ struct gmg_solver {
   std::vector<Level> lev;
   std::string err;
   bool setup_done = false;
+  bool structure_dirty = true;       // anything but values changed since the last setup
+  bool was_setup = false;
+  void touch() { setup_done = false; structure_dirty = true; }
   int64_t dev_bytes = 0;
   std::vector<void *> allocs;
 
@@ -1517,7 +1523,7 @@ struct gmg_solver {
   }
 
   // ---- smoother ---------------------------------------------------------------
-  void build_patch(Level &L, Smoother &S);
+  void build_patch(Level &L, Smoother &S, bool blocks_only = false);
   void patch_precond(Level &L, Smoother &S, const double *r, double omega, bool relax, double *dx, double *x);
 
   // solve!(x,ns::RichardsonSmootherNumericalSetup,r), RichardsonSmoothers.jl:84-98.
@@ -1849,6 +1855,8 @@ struct gmg_solver {
     return mat + vec;
   }
   KrylovOps level0_ops(int use_precond);
+  bool can_refresh() const;
+  void refresh_values();
   void setup();
   void build_coarse();
   double *build_dense_inverse(const HostCSR &A, const std::string &what);
@@ -2027,7 +2035,8 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
 // ----------------------------------------------------------------------------
 // patch smoother: setup + application
 // ----------------------------------------------------------------------------
-void gmg_solver::build_patch(Level &L, Smoother &S)
+// blocks_only: numerical_setup! -- the patch tables and incidence lists stay, the inverse blocks are rebuilt from the new values
+void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
 {
   REQUIRE(S.tab, GMG_ERR_INVALID, "patch tables missing");
   const Smoother::Tables &T = *S.tab;
@@ -2049,12 +2058,24 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
     REQUIRE(T.prow[q] >= 0 && T.prow[q] < L.n && pcolv[q] >= 0 && pcolv[q] < L.n, GMG_ERR_INVALID, "patch dof out of range");
   if (T.has_blocks) REQUIRE((int64_t)T.blocks.size() == boff[npatch], GMG_ERR_INVALID, "patch blocks have the wrong total size");
   S.max_np = max_np;
+  if (blocks_only) {
+    REQUIRE(S.built && S.d_pptr, GMG_ERR_STATE, "patch smoother was never set up");
+    HIP_CHECK(hipStreamSynchronize(stream));
+    release(S.d_binv, (size_t)S.n_binv);
+    release(S.d_ubinv, (size_t)S.n_ubinv);
+    release(S.d_uboff, (size_t)S.n_uboff);
+    release(S.d_ublock, (size_t)npatch);
+    release(S.d_boff, (size_t)npatch + 1);
+    S.dedup = false; S.nuniq = 0;
+  } else {
   S.d_pptr = upload(T.pptr);
   S.d_pdofs = upload(T.prow);
-  int32_t *d_pcol = T.pcol.empty() ? S.d_pdofs : upload(T.pcol);
+  S.d_pcol = T.pcol.empty() ? S.d_pdofs : upload(T.pcol);
   S.d_contrib = dvec(ndof_entries + 1);                    // + one slot that stays 0.0: the padding target of the sliced incidence
+  }
+  int32_t *d_pcol = S.d_pcol;
   // dof -> contribution slots, ascending patch order (= reference loop order PatchSolvers.jl:288)
-  {
+  if (!blocks_only) {
     std::vector<int64_t> iptr((size_t)L.n + 1, 0), inc((size_t)ndof_entries);
     for (int64_t q = 0; q < ndof_entries; ++q) iptr[pcolv[q] + 1]++;
     for (int64_t i = 0; i < L.n; ++i) iptr[i + 1] += iptr[i];
@@ -2093,10 +2114,11 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
   // patch matrices, or A[rows_p, cols_p] gathered on the device from the CSR / row-pattern form of the level operator.
   const bool from_factors = T.has_blocks && T.are_factors;
   const bool from_dense = T.has_blocks && !T.are_factors;
-  const bool from_pattern = !T.has_blocks && L.A.rowptr == nullptr;
+  const bool from_sell = !T.has_blocks && L.A.col == nullptr && L.A.sell && !L.A.pat && L.A.scol && L.A.sval;   // CSR stream dropped after the first setup
+  const bool from_pattern = !T.has_blocks && !from_sell && (L.A.rowptr == nullptr || L.A.col == nullptr);
   if (from_pattern) REQUIRE(L.A.pat && L.A.plen && L.A.ppoff && L.A.ppval, GMG_ERR_STATE, "level operator holds neither a CSR nor a pattern table for the patch blocks");
   const bool wave_kernel = max_np <= 64;
-  REQUIRE(wave_kernel || (!T.has_blocks && !from_pattern), GMG_ERR_UNSUPPORTED, "patches larger than 64 dofs need the level's CSR");
+  REQUIRE(wave_kernel || (!T.has_blocks && !from_pattern && !from_sell), GMG_ERR_UNSUPPORTED, "patches larger than 64 dofs need the level's CSR");
   const int pivoting = (S.patch_kind == GMG_PATCH_LU) ? 1 : 0;
   const size_t per = (size_t)max_np * max_np;
   const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(npatch, (int64_t)((512u << 20) / (per * sizeof(double)))));
@@ -2132,7 +2154,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
       d_rep = (int64_t *)tmp.get(sizeof(int64_t) * (size_t)batch);
       d_nmis = (int *)tmp.get(sizeof(int));
       HIP_CHECK(hipMemsetAsync(d_nmis, 0, sizeof(int), stream));
-    } else if (!S.d_binv) S.d_binv = dalloc<double>((size_t)boff[npatch]);
+    } else if (!S.d_binv) { S.d_binv = dalloc<double>((size_t)boff[npatch]); S.n_binv = boff[npatch]; }
     if (from_dense) d_dense = (double *)tmp.get(sizeof(double) * (size_t)tmp_elems);
     if (!wave_kernel) d_scratch = (double *)tmp.get(per * sizeof(double) * (size_t)batch);
     std::vector<double> hinv;                               // host-inverted batch (caller's factors)
@@ -2182,6 +2204,10 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
           HIP_CHECK(hipMemcpyAsync(d_dense, T.blocks.data() + e0, sizeof(double) * (size_t)ne, hipMemcpyHostToDevice, stream));
           src.dense = d_dense; src.dense_off0 = e0;
           hipLaunchKernelGGL((patch_invert_kernel<PSRC_DENSE>), g, b, lds, stream, cnt, S.d_pptr + p0, S.d_pdofs, d_pcol, S.d_boff + p0, e0, src,
+                             pivoting, out, max_np, d_nsing);
+        } else if (from_sell) {
+          src.soff = L.A.soff; src.scol = L.A.scol; src.sval = L.A.sval; src.rowlen = L.A.rowlen;
+          hipLaunchKernelGGL((patch_invert_kernel<PSRC_SELL>), g, b, lds, stream, cnt, S.d_pptr + p0, S.d_pdofs, d_pcol, S.d_boff + p0, e0, src,
                              pivoting, out, max_np, d_nsing);
         } else if (from_pattern) {
           src.rowpid = L.A.rowpid; src.rowbase = L.A.rowbase; src.plen = L.A.plen; src.poff8 = L.A.ppoff; src.pval = L.A.ppval; src.W = L.A.pat_w;
@@ -2252,8 +2278,8 @@ void gmg_solver::build_patch(Level &L, Smoother &S)
     REQUIRE(nsing == 0, GMG_ERR_SINGULAR, "singular patch block (BlockJacobiSolvers.jl:163 'Factorization failed')");
     if (!dedup) return true;
     if (nmis != 0) return false;                            // hash collision: every patch must be bitwise equal to its representative
-    S.d_uboff = upload(uboff);
-    S.d_ubinv = dalloc<double>((size_t)uboff.back());
+    S.d_uboff = upload(uboff); S.n_uboff = (int64_t)uboff.size();
+    S.d_ubinv = dalloc<double>((size_t)uboff.back()); S.n_ubinv = uboff.back();
     HIP_CHECK(hipMemcpyAsync(S.d_ubinv, d_ustore, sizeof(double) * (size_t)uboff.back(), hipMemcpyDeviceToDevice, stream));
     S.d_ublock = upload(ublock);
     S.nuniq = (int64_t)uboff.size() - 1;
@@ -2384,7 +2410,7 @@ double *gmg_solver::build_dense_inverse(const HostCSR &A, const std::string &wha
   const int n = (int)A.nrows;
   // Small matrices: exact banded LU with partial pivoting on the host (O(n^2 * bandwidth)).
   // Large ones: blocked Gauss-Jordan on the device (no pivoting; result verified below).
-  if (n > env_int("GMG_COARSE_HOST_MAX", 6000)) {
+  if (n > env_int("GMG_COARSE_HOST_MAX", 1500)) {
     REQUIRE((double)n * n * 8.0 <= 64.0e9, GMG_ERR_UNSUPPORTED,
             what + " has " + std::to_string(n) + " dofs: its dense inverse would not fit; add multigrid levels");
     return build_coarse_device(A, what);
@@ -2415,7 +2441,10 @@ double *gmg_solver::build_dense_inverse(const HostCSR &A, const std::string &wha
 double *gmg_solver::build_coarse_device(const HostCSR &A, const std::string &what)
 {
   const int n = (int)A.nrows;
+  const size_t mark = allocs.size();
+  const int64_t bytes0 = dev_bytes;
   double *D = dalloc<double>((size_t)n * n);
+  const int64_t bytesD = dev_bytes - bytes0;
   HIP_CHECK(hipMemsetAsync(D, 0, sizeof(double) * (size_t)n * n, stream));
   int64_t *d_ptr = upload(A.ptr);
   int32_t *d_col = upload(A.col);
@@ -2455,6 +2484,10 @@ double *gmg_solver::build_coarse_device(const HostCSR &A, const std::string &wha
   }
   REQUIRE(std::isfinite(err) && std::sqrt(err / nv) < 1.0e-8, GMG_ERR_SINGULAR,
           "device inversion of the " + what + " is inaccurate (matrix needs pivoting); add multigrid levels");
+  // panels, the CSR copy and the check vectors were setup scratch
+  for (size_t i = allocs.size(); i-- > mark;)
+    if (allocs[i] != (void *)D) { (void)hipFree(allocs[i]); allocs.erase(allocs.begin() + (long)i); }
+  dev_bytes = bytes0 + bytesD;
   return D;
 }
 
@@ -2627,6 +2660,96 @@ void gmg_solver::setup()
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   setup_done = true;
+  was_setup = true;
+  structure_dirty = false;
+  for (auto &L : lev) L.values_dirty = false;
+}
+
+// numerical_setup!(ns, A): same sparsity, new values (GMGLinearSolvers.jl:260-297, JacobiLinearSolvers.jl:25-27).  Keeps every
+// layout decision, table and work vector; rewrites the value arrays on the device, recomputes D^-1, re-factorises the patch
+// blocks and the coarse solver.  Possible when the operator of every refreshed level is stored with explicit values
+// (SELL-64 / CSR-stream: what variable-coefficient operators get); dictionary / pattern layouts depend on the values
+// themselves, so those fall back to a full setup.  Results are bit-identical to a fresh setup with the new values (tested).
+bool gmg_solver::can_refresh() const
+{
+  if (!was_setup || structure_dirty || comm.nranks != 1 || !env_int("GMG_REFRESH", 1)) return false;
+  for (int l = 0; l < nlev; ++l) {
+    const Level &L = lev[l];
+    if (!L.values_dirty) continue;
+    if (L.sA) return false;
+    const DevCSR &A = L.A;
+    if (A.sell && (A.pat || A.vdict || A.comp_idx || !A.sval)) return false;
+    if (!A.rowptr) return false;
+  }
+  return true;
+}
+
+void gmg_solver::refresh_values()
+{
+  HIP_CHECK(hipSetDevice(device));
+  const bool timing = env_int("GMG_SETUP_TIMING", 0) != 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  int *d_nzero = nullptr;
+  HIP_CHECK(hipMalloc((void **)&d_nzero, sizeof(int)));
+  double *d_val = nullptr;
+  size_t cap = 0;
+  try {
+    for (int l = 0; l < nlev; ++l) {
+      Level &L = lev[l];
+      if (!L.values_dirty) continue;
+      DevCSR &A = L.A;
+      const int64_t nnz = L.hA.nnz(), n = L.n;
+      HIP_CHECK(hipMemsetAsync(d_nzero, 0, sizeof(int), stream));
+      const bool want_dinv = L.dinv != nullptr;
+      if (!A.sell) {
+        // CSR-stream layout: the value array itself is streamed
+        HIP_CHECK(hipMemcpyAsync(A.val, L.hA.val.data(), sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, stream));
+        if (want_dinv) {
+          const int grid = (int)std::max<int64_t>(1, (n + 255) / 256);
+          if (A.ptr64) hipLaunchKernelGGL((inv_diag_kernel<int64_t>), dim3(grid), dim3(256), 0, stream, n, (const int64_t *)A.rowptr, A.col, A.val, L.dinv, d_nzero);
+          else hipLaunchKernelGGL((inv_diag_kernel<int32_t>), dim3(grid), dim3(256), 0, stream, n, (const int32_t *)A.rowptr, A.col, A.val, L.dinv, d_nzero);
+          HIP_CHECK(hipGetLastError());
+        }
+      } else {
+        if ((size_t)nnz > cap) {
+          if (d_val) { HIP_CHECK(hipStreamSynchronize(stream)); (void)hipFree(d_val); d_val = nullptr; }
+          HIP_CHECK(hipMalloc((void **)&d_val, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1)));
+          cap = (size_t)nnz;
+        }
+        HIP_CHECK(hipMemcpyAsync(d_val, L.hA.val.data(), sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, stream));
+        const int grid = (int)std::max<int64_t>(1, (n + 255) / 256);
+        if (A.ptr64) hipLaunchKernelGGL((sell_refill_kernel<int64_t>), dim3(grid), dim3(256), 0, stream, n, (const int64_t *)A.rowptr, A.soff, A.scol, d_val, A.sval, L.dinv, d_nzero);
+        else hipLaunchKernelGGL((sell_refill_kernel<int32_t>), dim3(grid), dim3(256), 0, stream, n, (const int32_t *)A.rowptr, A.soff, A.scol, d_val, A.sval, L.dinv, d_nzero);
+        HIP_CHECK(hipGetLastError());
+      }
+      int nzero = 0;
+      HIP_CHECK(hipMemcpyAsync(&nzero, d_nzero, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      const bool need_diag = l < nlev - 1 ? (L.pre.kind == SM_JACOBI || L.post.kind == SM_JACOBI) : coarse_kind == GMG_COARSE_CG_JACOBI;
+      REQUIRE(!(want_dinv && need_diag && nzero > 0), GMG_ERR_SINGULAR, "zero diagonal entry on level " + std::to_string(l));
+      L.s0_ready = false;
+      if (l < nlev - 1) {
+        if (L.has_pcorr) build_patch(L, L.pcorr, true);
+        if (L.pre.kind == SM_PATCH) build_patch(L, L.pre, true);
+        if (L.post_shares_pre) L.post = L.pre;
+        else if (L.post.kind == SM_PATCH) build_patch(L, L.post, true);
+      } else if (coarse_kind == GMG_COARSE_DENSE_INVERSE) {
+        release(d_Ainv, (size_t)n * (size_t)n);
+        build_coarse();
+      }
+      L.values_dirty = false;
+    }
+  } catch (...) {
+    if (d_val) (void)hipFree(d_val);
+    (void)hipFree(d_nzero);
+    throw;
+  }
+  HIP_CHECK(hipStreamSynchronize(stream));
+  if (d_val) (void)hipFree(d_val);
+  (void)hipFree(d_nzero);
+  setup_done = true;
+  if (timing) std::fprintf(stderr, "[gmg_setup] value refresh %8.1f ms\n",
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 }
 
 // ----------------------------------------------------------------------------
@@ -2735,7 +2858,7 @@ int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_
     REQUIRE(nrows == ncols || h->comm.nranks > 1, GMG_ERR_INVALID, "level matrix must be square");
     h->lev[lev].hA = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
     h->lev[lev].hasA = true; h->lev[lev].sA.reset();
-    h->setup_done = false;
+    h->touch();
   });
 }
 
@@ -2761,7 +2884,7 @@ int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, 
       H = HostCSR();
       H.nrows = nrows_total; H.ncols = ncols;               // shape only: the rows are never kept
       has = false;
-      h->setup_done = false;
+      h->touch();
     }
     REQUIRE(S && S->nrows == nrows_total && S->ncols == ncols, GMG_ERR_STATE, "row block does not continue the stream started with row0 = 0");
     h->stream_append(*S, row0, nrows_block, ptr, idx, val, index_base, index_bytes);
@@ -2779,7 +2902,8 @@ int gmg_update_values(gmg_handle_t h, int lev, const double *val)
     REQUIRE(val, GMG_ERR_INVALID, "null values");
     // values are given in the 0-based CSR order held by the handle
     std::memcpy(L.hA.val.data(), val, sizeof(double) * (size_t)L.hA.nnz());
-    h->setup_done = false;
+    L.values_dirty = true;
+    h->setup_done = false;                                  // structure untouched: gmg_setup takes the value-refresh path when it can
   });
 }
 
@@ -2790,7 +2914,7 @@ int gmg_set_prolongation(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, 
     check_level(h, lev, true);
     h->lev[lev].hP = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
     h->lev[lev].hasP = true; h->lev[lev].sP.reset();
-    h->setup_done = false;
+    h->touch();
   });
 }
 
@@ -2801,7 +2925,7 @@ int gmg_set_restriction(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, i
     check_level(h, lev, true);
     h->lev[lev].hR = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
     h->lev[lev].hasR = true; h->lev[lev].sR.reset();
-    h->setup_done = false;
+    h->touch();
   });
 }
 
@@ -2812,7 +2936,7 @@ static void assign_smoother(gmg_handle_t h, int lev, int which, const Smoother &
   if (which == GMG_PRE_AND_POST) { L.pre = S; L.post_shares_pre = true; }
   else if (which == GMG_PRE) { L.pre = S; if (L.post_shares_pre) { L.post_shares_pre = false; } }
   else { L.post = S; L.post_shares_pre = false; }
-  h->setup_done = false;
+  h->touch();
 }
 
 int gmg_set_smoother_jacobi(gmg_handle_t h, int lev, int which, int niter, double omega)
@@ -2897,7 +3021,7 @@ int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int kind, int
     Smoother S = make_patch_smoother(0, 1.0, kind, npatch, patch_ptr, patch_dofs, nullptr, index_base, index_bytes);
     h->lev[lev].pcorr = S;
     h->lev[lev].has_pcorr = true;
-    h->setup_done = false;
+    h->touch();
   });
 }
 
@@ -2926,7 +3050,7 @@ int gmg_set_coarse_solver(gmg_handle_t h, int kind, int maxiter, double atol, do
     h->coarse_kind = kind;
     if (kind == GMG_COARSE_CG_JACOBI) { h->coarse_maxiter = maxiter; h->coarse_atol = atol; h->coarse_rtol = rtol; }
     h->coarse_fn = fn; h->coarse_ctx = ctx;
-    h->setup_done = false;
+    h->touch();
   });
 }
 
@@ -2959,7 +3083,8 @@ int gmg_setup(gmg_handle_t h)
 {
   return guarded(h, [&] {
     REQUIRE(h, GMG_ERR_INVALID, "null handle");
-    h->setup();
+    if (h->can_refresh()) h->refresh_values();             // numerical_setup!: only values changed and the layouts carry values
+    else h->setup();
   });
 }
 
@@ -3190,7 +3315,7 @@ int gmg_comm_init_rccl(gmg_handle_t h, const char *rccl_path, const char *unique
     if (!h->comm_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     if (!h->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     if (!h->ev_done) HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
-    h->setup_done = false;
+    h->touch();
   });
 }
 
@@ -3236,7 +3361,7 @@ int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_f
       if (!h->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
       if (!h->ev_done) HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
     }
-    h->setup_done = false;
+    h->touch();
   });
 }
 
@@ -3263,7 +3388,7 @@ int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, i
     REQUIRE(ns == 0 || snd_idx, GMG_ERR_INVALID, "null snd_idx");
     H.h_snd_idx.assign(snd_idx, snd_idx + ns);
     for (int64_t i = 0; i < ns; ++i) REQUIRE(snd_idx[i] >= 0 && snd_idx[i] < n_own, GMG_ERR_INVALID, "snd_idx must address owned entries");
-    h->setup_done = false;
+    h->touch();
   });
 }
 
@@ -3275,7 +3400,7 @@ int gmg_set_replication(gmg_handle_t h, int lev, const int64_t *own_global_ids, 
     REQUIRE(n_own == 0 || own_global_ids, GMG_ERR_INVALID, "null own_global_ids");
     h->rep_from = lev;
     h->h_rep_gid.assign(own_global_ids, own_global_ids + n_own);
-    h->setup_done = false;
+    h->touch();
   });
 }
 

@@ -1204,15 +1204,17 @@ __global__ void patch_factor_kernel(int64_t npatch, const int64_t *__restrict__ 
 // entry, hence the same bits), with the n_p x 2 n_p augmented block [M | X] in LDS and lane = column.  Block sources:
 //   PSRC_CSR     A[rows_p, cols_p] gathered from the level's device CSR              (BlockJacobiSolvers.jl:160)
 //   PSRC_PATTERN the same from the row-pattern form of A (streamed operators never hold a CSR)
+//   PSRC_SELL    the same from the SELL-64 arrays (numerical_setup!: the CSR copy was dropped after the first setup)
 //   PSRC_DENSE   the caller's own patch matrices, column-major as Julia stores them  (PatchSolvers.jl:137-150:
 //                assemble_matrix(biform, assem, trial, test) of the SOLVER's weak form)
 // n_p <= 64.  Output: explicit inverse, row-major, at binv[boff[p] - boff0].
 // ---------------------------------------------------------------------------
-enum PatchSrcKind : int { PSRC_CSR = 0, PSRC_PATTERN = 1, PSRC_DENSE = 2 };
+enum PatchSrcKind : int { PSRC_CSR = 0, PSRC_PATTERN = 1, PSRC_DENSE = 2, PSRC_SELL = 3 };
 struct PatchSrc {
   const void *rowptr; const int32_t *col; const double *val; int ptr64;                                  // CSR
   const uint16_t *rowpid; const int32_t *rowbase; const int32_t *plen, *poff8; const double *pval; int W; // pattern table (byte offsets)
   const double *dense; int64_t dense_off0;                                                                // blocks of this batch
+  const int64_t *soff; const int32_t *scol; const double *sval; const int32_t *rowlen;                    // SELL-64 arrays (value refresh: the CSR stream is gone)
 };
 
 template <int SRC>
@@ -1253,6 +1255,16 @@ __global__ __launch_bounds__(64) void patch_invert_kernel(int64_t npatch, const 
       for (int j = 0; j < len; ++j) {
         const int32_t gc = base + src.poff8[(size_t)pid * src.W + j] / 8;
         const double v = src.pval[(size_t)pid * src.W + j];
+        for (int c = 0; c < np; ++c)
+          if (cols[c] == gc) M[r * np + c] += v;
+      }
+    } else if (SRC == PSRC_SELL) {
+      const int64_t base = src.soff[gr >> 6];
+      const int len = src.rowlen[gr];
+      for (int j = 0; j < len; ++j) {
+        const int64_t q = base + (int64_t)j * 64 + (gr & 63);
+        const int32_t gc = src.scol[q];
+        const double v = src.sval[q];
         for (int c = 0; c < np; ++c)
           if (cols[c] == gc) M[r * np + c] += v;
       }
@@ -1305,6 +1317,30 @@ __global__ __launch_bounds__(64) void patch_invert_kernel(int64_t npatch, const 
   __syncthreads();
   double *out = binv + (boff[p] - boff0);
   for (int e = lane; e < np * np; e += 64) out[e] = X[e];
+}
+
+// numerical_setup!: new values into an existing SELL-64 layout (sval[slice, j, lane] = val[rowptr[row] + j]) and the
+// Jacobi inverse diagonal recomputed from the refreshed rows.  PtrT = row pointer type of the kept CSR row pointers.
+template <typename PtrT>
+__global__ void sell_refill_kernel(int64_t nrows, const PtrT *__restrict__ rowptr, const int64_t *__restrict__ soff,
+                                   const int32_t *__restrict__ scol, const double *__restrict__ val, double *__restrict__ sval,
+                                   double *__restrict__ dinv, int *__restrict__ nzero)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows) return;
+  const int64_t base = soff[i >> 6] + (i & 63);
+  const PtrT k0 = rowptr[i], k1 = rowptr[i + 1];
+  double d = 0.0;
+  for (PtrT k = k0; k < k1; ++k) {
+    const int64_t q = base + (int64_t)(k - k0) * 64;
+    const double v = val[k];
+    sval[q] = v;
+    if (scol[q] == (int32_t)i) d += v;
+  }
+  if (dinv) {
+    if (d == 0.0) atomicAdd(nzero, 1);
+    dinv[i] = 1.0 / d;
+  }
 }
 
 // dinv[i] = pdinv[rowpid[i]]: the Jacobi inverse diagonal of a row-pattern operator (no CSR needed)

@@ -434,11 +434,17 @@ class GMGNumericalSetup:
 
     # -- numerical_setup!(ns, A): FromMatrices variant is unsupported in the reference
     #    (GMGLinearSolvers.jl:249-258 logs @error); here new values on the same pattern are accepted.
-    def update(self, mat):
-        shape, ptr, idx, val, layout, base = _csr_fields(mat)
-        if layout != abi.CSR:
-            raise NotImplementedError("numerical_setup! needs CSR values in the handle's order")
-        abi.check(self.h, self._lib.gmg_update_values(self.h, 0, C.c_void_p(val.ctypes.data)))
+    def update(self, mat, smatrices=None):
+        """numerical_setup!(ns, A): new values on the same sparsity.  `smatrices` (optional) = the re-assembled matrices of ALL
+        levels, as the FromWeakform variant recomputes them (GMGLinearSolvers.jl:260-297); default: only the finest changes."""
+        mats = [mat] if smatrices is None else [mat] + list(smatrices[1:])
+        for l, M in enumerate(mats):
+            if M is None:
+                continue
+            shape, ptr, idx, val, layout, base = _csr_fields(M)
+            if layout != abi.CSR:
+                raise NotImplementedError("numerical_setup! needs CSR values in the handle's order")
+            abi.check(self.h, self._lib.gmg_update_values(self.h, l, C.c_void_p(val.ctypes.data)))
         abi.check(self.h, self._lib.gmg_setup(self.h))
         return self
 
@@ -715,12 +721,12 @@ def numerical_setup(ss, A=None, device_id=None):
     raise TypeError(f"no numerical_setup for {type(ss).__name__}")
 
 
-def numerical_setup_(ns, A):
-    """Gridap.Algebra.numerical_setup!(ns, A)."""
+def numerical_setup_(ns, A, smatrices=None):
+    """Gridap.Algebra.numerical_setup!(ns, A) (smatrices: re-assembled matrices of all levels, optional)."""
     if isinstance(ns, GMGNumericalSetup):
-        return ns.update(A)
+        return ns.update(A, smatrices)
     if isinstance(ns, _KrylovNumericalSetup):
-        ns.P_ns.update(A)
+        ns.P_ns.update(A, smatrices)
         return ns
     raise TypeError(f"no numerical_setup! for {type(ns).__name__}")
 

@@ -106,8 +106,12 @@ GMG_API int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols
 GMG_API int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, int64_t ncols, int64_t row0,
                                   int64_t nrows_block, const void *ptr, const void *idx, const double *val,
                                   int index_base, int index_bytes);
-/* numerical_setup!(ns,A): same pattern, new values (GMGLinearSolvers.jl:249-297;
- * JacobiLinearSolvers.jl:25-27).  Requires gmg_setup to be called again. */
+/* numerical_setup!(ns,A): same pattern, new values in the handle's 0-based CSR order (GMGLinearSolvers.jl:249-297;
+ * JacobiLinearSolvers.jl:25-27), any level.  Requires gmg_setup to be called again; when nothing but values changed
+ * since the last setup and the refreshed levels are stored with explicit values (SELL-64 / CSR-stream: what
+ * variable-coefficient operators get), that gmg_setup keeps every layout, table and work vector and only rewrites the
+ * value arrays, D^-1, the patch inverse blocks and the coarse inverse on the device -- bit-identical to a fresh setup.
+ * Dictionary / row-pattern layouts depend on the values themselves: those levels trigger a full setup. */
 GMG_API int gmg_update_values(gmg_handle_t h, int lev, const double *val);
 /* interp[lev+1] : level lev+1 -> lev, `mul!(dxh,interp,dxH)` GMGLinearSolvers.jl:491
  * (y = P x, GridTransferOperators.jl:391-401).  nrows = n(lev), ncols = n(lev+1). */
@@ -184,7 +188,7 @@ GMG_API int gmg_get_log(gmg_handle_t h, gmg_result *res, double *hist, int hist_
 /* numerical_setup(ss,A): GMGLinearSolvers.jl:183-210 -- uploads operators, builds
  * D^-1, R = P^T, patch factors, work vectors and the coarse solver
  * (default coarsest_solver = LUSolver(), :54,423-434 -> dense inverse applied as one GEMV per cycle;
- * factorised on the host up to 6000 dofs, inverted on the device above; see gmg_set_coarse_solver). */
+ * factorised on the host up to 1500 dofs, inverted on the device above; see gmg_set_coarse_solver). */
 GMG_API int gmg_setup(gmg_handle_t h);
 
 /* ---- hot path ---------------------------------------------------------------- */

@@ -443,3 +443,64 @@ def test_config3_shape_q2_32cubed_vs_oracle(S, po, orc):
     y = np.zeros_like(b)
     ns.P_ns.op_apply(0, abi.OP_A, x, y)
     assert np.linalg.norm(b - y) <= 1.01e-6 * np.linalg.norm(b)
+
+
+# ---------------------------------------------------------------- numerical_setup! value refresh
+@pytest.mark.parametrize("smoother", ["jacobi", "patch"])
+def test_value_refresh_is_bitwise_a_fresh_setup(S, po, orc, smoother, monkeypatch):
+    """numerical_setup!(ns, A) with new values on the same sparsity (GMGLinearSolvers.jl:260-297): the refresh path keeps
+    layouts / tables / work vectors and must give bit-identical results to a fresh numerical_setup on the new matrices."""
+    import time
+    monkeypatch.setenv("GMG_COARSE_HOST_MAX", "100000")      # same (host) coarse factorisation in both runs
+    nc, nlev = (24, 24, 24), 3
+    k1 = po.smooth_kappa
+    k2 = lambda X, Y, Z: 2.0 + np.cos(3.0 * X) * np.sin(2.0 * Y + 0.2) + 0.5 * Z * Z
+    H1 = po.build_hierarchy(nc, nlev, 1, kappa=k1)
+    H2 = po.build_hierarchy(nc, nlev, 1, kappa=k2)
+    assert all((a.ptr == b.ptr).all() and (a.idx == b.idx).all() for a, b in zip(H1["mats"], H2["mats"]))
+    if smoother == "patch":
+        # Q1 vertex-star patches are single dofs; use 2x2x2-node blocks to get real dense patch blocks
+        n1 = nc[0] - 1
+        def blocks(n):
+            ids = np.arange(n ** 3).reshape(n, n, n)
+            pp, pd = [0], []
+            for k in range(0, n - 1, 2):
+                for j in range(0, n - 1, 2):
+                    for i in range(0, n - 1, 2):
+                        pd.append(ids[k:k + 2, j:j + 2, i:i + 2].reshape(-1)); pp.append(pp[-1] + 8)
+            return np.asarray(pp, dtype=np.int64), np.concatenate(pd).astype(np.int32)
+        tabs = [blocks(c[0] - 1) for c in H1["ncells"][:-1]]
+        mk = lambda: [S.RichardsonSmoother(S.BlockJacobiSolver(pp, pd), 4, 0.5) for pp, pd in tabs]
+    else:
+        mk = lambda: jac(S, nlev)
+    uex = po.nodal_values(nc, 1)
+    b2 = H2["mats"][0].matvec(uex)
+    solver = S.CGSolver(make_gmg(S, H1, pre_smoothers=mk()), maxiter=40, atol=1e-14, rtol=1e-8, flexible=(smoother == "patch"))
+    ns = setup(S, solver, H1["mats"][0])
+    x0 = np.zeros_like(b2); S.solve_(x0, ns, H1["mats"][0].matvec(uex))       # use the first operator once
+    t0 = time.perf_counter()
+    S.numerical_setup_(ns, H2["mats"][0], H2["mats"])                          # refresh every level
+    t_refresh = time.perf_counter() - t0
+    x = np.zeros_like(b2)
+    S.solve_(x, ns, b2)
+    it_refresh, hist_refresh = solver.log.num_iters, solver.log.residuals[: solver.log.num_iters + 1].copy()
+    solver2 = S.CGSolver(make_gmg(S, H2, pre_smoothers=mk()), maxiter=40, atol=1e-14, rtol=1e-8, flexible=(smoother == "patch"))
+    t0 = time.perf_counter()
+    ns2 = setup(S, solver2, H2["mats"][0])
+    t_fresh = time.perf_counter() - t0
+    xf = np.zeros_like(b2)
+    S.solve_(xf, ns2, b2)
+    assert it_refresh == solver2.log.num_iters
+    np.testing.assert_array_equal(hist_refresh, solver2.log.residuals[: solver2.log.num_iters + 1])
+    np.testing.assert_array_equal(x, xf)
+    assert np.max(np.abs(x - uex)) < 1e-6
+    assert t_refresh < t_fresh                                                 # and it is the cheaper path
+    # a compressed (pattern) layout depends on the values: update falls back to a full setup and is still right
+    Hc = po.build_hierarchy(nc, nlev, 1)
+    sc = S.CGSolver(make_gmg(S, Hc), maxiter=20, atol=1e-14, rtol=1e-8)
+    nsc = setup(S, sc, Hc["mats"][0])
+    scaled = po.CSR(Hc["mats"][0].shape, Hc["mats"][0].ptr, Hc["mats"][0].idx, 2.0 * Hc["mats"][0].val)
+    S.numerical_setup_(nsc, scaled)
+    bc = scaled.matvec(uex); xc = np.zeros_like(bc)
+    S.solve_(xc, nsc, bc)
+    assert np.max(np.abs(xc - uex)) < 1e-6
