@@ -92,6 +92,7 @@ struct HaloPlan {
   std::vector<int64_t> snd_ptr, rcv_ptr, h_snd_idx;
   int64_t *d_snd_idx = nullptr;
   double *d_sendbuf = nullptr;
+  double *d_recvbuf = nullptr;                 // assemble!: ghost contributions arriving for the rows in snd_idx
   double *h_send = nullptr, *h_recv = nullptr; // pinned, host transport only
   // boundary row -> its slots in the send buffer (pack fused into ghost_fix_kernel); null when some sent row has no ghost column
   int64_t *d_pk_ptr = nullptr;
@@ -105,6 +106,23 @@ __global__ void halo_pack_kernel(int64_t n, const int64_t *__restrict__ idx, con
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) sendbuf[i] = v[idx[i]];
+}
+// assemble!(v) (PatchSolvers.jl:254): v[idx[i]] += buf[i] -- the ghost copies' contributions added to the owner's entry.
+// One launch per neighbour, in neighbour order: targets are unique inside a neighbour's list, so the sum order is fixed.
+__global__ void halo_unpack_add_kernel(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ buf,
+                                       double *__restrict__ v)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[idx[i]] = v[idx[i]] + buf[i];
+}
+// dx .= omega .* dx ; x .+= dx  (RichardsonSmoothers.jl:92-93) after the patch contributions have been assembled
+__global__ void relax_update_kernel(int64_t n, double omega, double *__restrict__ dx, double *__restrict__ x)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double d = omega * dx[i];
+    dx[i] = d;
+    x[i] = x[i] + d;
+  }
 }
 // full[gid[i]] = r[i]  (coarse-level gather into the replicated vector)
 __global__ void scatter_gid_kernel(int64_t n, const int64_t *__restrict__ gid, const double *__restrict__ r,

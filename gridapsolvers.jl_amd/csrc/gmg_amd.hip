@@ -552,7 +552,7 @@ struct gmg_solver {
     d_Ainv = d_partials = d_scalars = nullptr;
     cc_w = cc_p = cc_z = cc_r = nullptr;
     d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr;
-    for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; L.halo.d_pk_ptr = nullptr; L.halo.d_pk_slot = nullptr; }
+    for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; L.halo.d_recvbuf = nullptr; L.halo.d_pk_ptr = nullptr; L.halo.d_pk_slot = nullptr; }
     cg_w = cg_p = cg_z = cg_r = st_b = st_x = nullptr;
     fg_V.clear(); fg_Z.clear(); st_extra.clear();
     setup_done = false;
@@ -1420,6 +1420,38 @@ struct gmg_solver {
       if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(ghost, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, stream));
     }
   }
+  // assemble!(v): ghost -> owner add (the reverse of consistent!), PatchSolvers.jl:254 / BlockJacobiSolvers.jl:134.
+  // v has n_own + n_ghost entries; afterwards the owned entries hold own + all ghost copies' contributions.
+  void assemble_add(int l, double *v)
+  {
+    HaloPlan &H = lev[l].halo;
+    if (comm.nranks <= 1 || !H.present || H.nbr.empty()) return;
+    const int64_t ns = H.nsend();
+    double *ghost = v + H.n_own;
+    if (comm.kind == COMM_RCCL) {
+      int rc = comm.api.GroupStart();
+      for (size_t k = 0; k < H.nbr.size() && rc == 0; ++k) {
+        const int64_t sc = H.snd_ptr[k + 1] - H.snd_ptr[k], rcn = H.rcv_ptr[k + 1] - H.rcv_ptr[k];
+        if (rcn > 0) rc = comm.api.Send(ghost + H.rcv_ptr[k], (size_t)rcn, kNcclDouble, H.nbr[k], comm.comm, stream);
+        if (rc == 0 && sc > 0) rc = comm.api.Recv(H.d_recvbuf + H.snd_ptr[k], (size_t)sc, kNcclDouble, H.nbr[k], comm.comm, stream);
+      }
+      const int rc2 = comm.api.GroupEnd();
+      REQUIRE(rc == 0 && rc2 == 0, GMG_ERR_COMM, std::string("RCCL reverse halo: ") + comm.api.GetErrorString(rc ? rc : rc2));
+    } else {
+      if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(H.h_recv, ghost, sizeof(double) * (size_t)H.n_ghost, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      // roles swapped: the ghost segment is what is sent, the send lists are what is received
+      comm.xfn(comm.ctx, (int)H.nbr.size(), H.nbr.data(), H.h_recv, H.rcv_ptr.data(), H.h_send, H.snd_ptr.data());
+      if (ns > 0) HIP_CHECK(hipMemcpyAsync(H.d_recvbuf, H.h_send, sizeof(double) * (size_t)ns, hipMemcpyHostToDevice, stream));
+    }
+    for (size_t k = 0; k < H.nbr.size(); ++k) {
+      const int64_t sc = H.snd_ptr[k + 1] - H.snd_ptr[k];
+      if (sc == 0) continue;
+      hipLaunchKernelGGL(halo_unpack_add_kernel, dim3((unsigned)((sc + 255) / 256)), dim3(256), 0, stream, sc, H.d_snd_idx + H.snd_ptr[k],
+                         H.d_recvbuf + H.snd_ptr[k], v);
+      HIP_CHECK(hipGetLastError());
+    }
+  }
   // Split mat-vec with A_l: start the halo of `src`, (caller runs the own x own kernel), then
   // finish the boundary rows.  With RCCL the exchange runs on comm_stream concurrently with the
   // own x own kernel; with the host transport it is synchronous (same data flow, no overlap).
@@ -1581,8 +1613,9 @@ struct gmg_solver {
     else { r = L.rbuf[0]; copy(r, r_in, n); }
     if (x_zero) zero(x, n);
     for (int it = 0; it < S.niter; ++it) {
+      exchange(l, r);                                      // consistent!(b) PatchSolvers.jl:231 (no-op on one GPU)
       patch_precond(L, S, r, S.omega, true, L.dx, x);      // :91-93
-      apply_A_sub(l, L.dx, r);                             // :94-95
+      apply_A_sub(l, L.dx, r);                             // :94-95 (exchanges dx itself: consistent!(x), PatchSolvers.jl:256)
     }
     return r;
   }
@@ -2053,9 +2086,10 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
     max_np = std::max<int>(max_np, (int)np);
   }
   const int64_t ndof_entries = T.pptr[npatch];
+  const int64_t nloc = L.nvec;                              // patches of a distributed level reach into the ghost dofs (own | ghost numbering)
   REQUIRE((int64_t)T.prow.size() == ndof_entries && (int64_t)pcolv.size() == ndof_entries, GMG_ERR_INVALID, "patch tables have the wrong length");
   for (int64_t q = 0; q < ndof_entries; ++q)
-    REQUIRE(T.prow[q] >= 0 && T.prow[q] < L.n && pcolv[q] >= 0 && pcolv[q] < L.n, GMG_ERR_INVALID, "patch dof out of range");
+    REQUIRE(T.prow[q] >= 0 && T.prow[q] < nloc && pcolv[q] >= 0 && pcolv[q] < nloc, GMG_ERR_INVALID, "patch dof out of range");
   if (T.has_blocks) REQUIRE((int64_t)T.blocks.size() == boff[npatch], GMG_ERR_INVALID, "patch blocks have the wrong total size");
   S.max_np = max_np;
   if (blocks_only) {
@@ -2076,26 +2110,26 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
   int32_t *d_pcol = S.d_pcol;
   // dof -> contribution slots, ascending patch order (= reference loop order PatchSolvers.jl:288)
   if (!blocks_only) {
-    std::vector<int64_t> iptr((size_t)L.n + 1, 0), inc((size_t)ndof_entries);
+    std::vector<int64_t> iptr((size_t)nloc + 1, 0), inc((size_t)ndof_entries);
     for (int64_t q = 0; q < ndof_entries; ++q) iptr[pcolv[q] + 1]++;
-    for (int64_t i = 0; i < L.n; ++i) iptr[i + 1] += iptr[i];
+    for (int64_t i = 0; i < nloc; ++i) iptr[i + 1] += iptr[i];
     {
       std::vector<int64_t> fill(iptr.begin(), iptr.end() - 1);
       for (int64_t q = 0; q < ndof_entries; ++q) inc[fill[pcolv[q]]++] = q;
     }
-    if (ndof_entries < (int64_t)INT32_MAX && L.n > 0) {
-      const int64_t ns = (L.n + 63) / 64;
+    if (ndof_entries < (int64_t)INT32_MAX && nloc > 0) {
+      const int64_t ns = (nloc + 63) / 64;
       std::vector<int64_t> soff((size_t)ns + 1, 0);
       for (int64_t sl = 0; sl < ns; ++sl) {
         int64_t w = 0;
-        for (int64_t i = sl * 64; i < std::min<int64_t>(L.n, sl * 64 + 64); ++i) w = std::max(w, iptr[i + 1] - iptr[i]);
+        for (int64_t i = sl * 64; i < std::min<int64_t>(nloc, sl * 64 + 64); ++i) w = std::max(w, iptr[i + 1] - iptr[i]);
         soff[sl + 1] = soff[sl] + w * 64;
       }
       std::vector<int32_t> sinc((size_t)soff[ns], (int32_t)ndof_entries);   // padding -> the zero slot
       parallel_for(ns, [&](int64_t sl) {
         for (int l = 0; l < 64; ++l) {
           const int64_t i = sl * 64 + l;
-          if (i >= L.n) break;
+          if (i >= nloc) break;
           for (int64_t k = iptr[i]; k < iptr[i + 1]; ++k) sinc[(size_t)(soff[sl] + (k - iptr[i]) * 64 + l)] = (int32_t)inc[k];
         }
       });
@@ -2310,14 +2344,28 @@ void gmg_solver::patch_precond(Level &L, Smoother &S, const double *r, double om
     }
     HIP_CHECK(hipGetLastError());
   }
-  const int grid = (int)((L.n + 255) / 256);
+  // distributed level: the owned patches reach into ghost dofs.  consistent!(b) happened at the caller (see smooth()); here the
+  // local contributions are gathered for ALL local dofs, the ghost ones are added to their owners (assemble!,
+  // PatchSolvers.jl:251-258), then the relaxation runs on the owned entries.
+  const int l = (int)(&L - &lev[0]);
+  const bool dist = comm.nranks > 1 && L.halo.present;
+  const int64_t ng = dist ? L.nvec : L.n;
+  const int grid = (int)((ng + 255) / 256);
+  const int fused_relax = (relax && !dist) ? 1 : 0;
   if (S.d_isoff)
-    hipLaunchKernelGGL(patch_gather_sell_kernel, dim3(std::max(grid, 1)), dim3(256), 0, stream, L.n, S.d_isoff, S.d_isinc, S.d_contrib,
-                       omega, relax ? 1 : 0, dx, x);
+    hipLaunchKernelGGL(patch_gather_sell_kernel, dim3(std::max(grid, 1)), dim3(256), 0, stream, ng, S.d_isoff, S.d_isinc, S.d_contrib,
+                       omega, fused_relax, dx, x);
   else
-  hipLaunchKernelGGL(patch_gather_kernel, dim3(std::max(grid, 1)), dim3(256), 0, stream, L.n, S.d_iptr, S.d_inc, S.d_contrib,
-                     omega, relax ? 1 : 0, dx, x);
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(std::max(grid, 1)), dim3(256), 0, stream, ng, S.d_iptr, S.d_inc, S.d_contrib,
+                     omega, fused_relax, dx, x);
   HIP_CHECK(hipGetLastError());
+  if (dist) {
+    assemble_add(l, dx);
+    if (relax) {
+      hipLaunchKernelGGL(relax_update_kernel, dim3(grid_for(L.n)), dim3(256), 0, stream, L.n, omega, dx, x);
+      HIP_CHECK(hipGetLastError());
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------
@@ -2538,9 +2586,11 @@ void gmg_solver::setup()
       REQUIRE((boundary ? L.hR.nrows == (int64_t)h_rep_gid.size() : L.hR.nrows == lev[l + 1].n) && L.hR.ncols == L.nvec,
               GMG_ERR_INVALID, "restriction shape mismatch");
     }
-    if (comm.nranks > 1)
-      REQUIRE(L.pre.kind == SM_JACOBI && L.post.kind == SM_JACOBI, GMG_ERR_UNSUPPORTED,
-              "patch smoothers are single-GPU in this round (need assemble! of ghost rows, PatchSolvers.jl:254)");
+    if (comm.nranks > 1 && L.halo.present)
+      for (const Smoother *sp : {&L.pre, &L.post})
+        REQUIRE(sp->kind == SM_JACOBI || (sp->tab && sp->tab->has_blocks), GMG_ERR_UNSUPPORTED,
+                "distributed patch smoothers need the caller's patch matrices (gmg_set_smoother_patch_matrices): a rank's local matrix "
+                "holds the owned rows only, the blocks of patches reaching into ghost dofs cannot be gathered from it");
   }
   if (comm.nranks > 1) {
     one_gather_sweep = 1;   // the one-gather sweep needs only s-ghosts
@@ -2605,6 +2655,7 @@ void gmg_solver::setup()
       HaloPlan &H = L.halo;
       H.d_snd_idx = upload(H.h_snd_idx);
       H.d_sendbuf = dvec(H.nsend());
+      H.d_recvbuf = dvec(H.nsend());
       if (comm.kind == COMM_HOST) {
         if (!H.h_send) HIP_CHECK(hipHostMalloc((void **)&H.h_send, sizeof(double) * (size_t)std::max<int64_t>(1, H.nsend())));
         if (!H.h_recv) HIP_CHECK(hipHostMalloc((void **)&H.h_recv, sizeof(double) * (size_t)std::max<int64_t>(1, H.n_ghost)));
@@ -3251,6 +3302,13 @@ int gmg_precond_apply(gmg_handle_t h, int lev, int which, const double *r, doubl
     if (S.kind == SM_JACOBI) {
       hipLaunchKernelGGL(jacobi_apply_kernel, dim3(gmg_solver::grid_for(L.n)), dim3(256), 0, h->stream, L.n, L.dinv, dr, out);
       HIP_CHECK(hipGetLastError());
+    } else if (h->comm.nranks > 1 && L.halo.present) {
+      // solve!(x::PVector, ns::PatchNS, b::PVector), PatchSolvers.jl:227-236: consistent!(b), local solves, assemble!(x)
+      double *rr = h->scratch_vec(2, h->lev[0].nvec), *oo = h->scratch_vec(3, h->lev[0].nvec);
+      h->copy(rr, dr, L.n);
+      h->exchange(lev, rr);
+      h->patch_precond(L, S, rr, 1.0, false, oo, nullptr);
+      out = oo;
     } else {
       h->patch_precond(L, S, dr, 1.0, false, out, nullptr);
     }
