@@ -258,6 +258,14 @@ struct Smoother {
   int32_t *d_isinc = nullptr;
   double *d_contrib = nullptr;
   bool built = false;
+  // every device array above was freed with the handle's allocations
+  void reset_device()
+  {
+    d_pptr = nullptr; d_pdofs = nullptr; d_pcol = nullptr; d_boff = nullptr; d_binv = nullptr;
+    d_ublock = nullptr; d_uboff = nullptr; d_ubinv = nullptr; d_iptr = nullptr; d_inc = nullptr; d_isoff = nullptr; d_isinc = nullptr;
+    d_contrib = nullptr;
+    n_binv = n_ubinv = n_uboff = 0; dedup = false; nuniq = 0; npatch = 0; built = false;
+  }
 };
 
 struct Level {
@@ -546,7 +554,7 @@ struct gmg_solver {
       L.ptmp = L.pcor = nullptr; L.pcorr.built = false;
       L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
       L.sbuf[0] = L.sbuf[1] = nullptr;
-      L.pre.built = L.post.built = false;
+      for (Smoother *sp : {&L.pre, &L.post, &L.pcorr}) sp->reset_device();
       L.s0_ready = false;
     }
     d_Ainv = d_partials = d_scalars = nullptr;

@@ -464,10 +464,11 @@ def test_value_refresh_is_bitwise_a_fresh_setup(S, po, orc, smoother, monkeypatc
         def blocks(n):
             ids = np.arange(n ** 3).reshape(n, n, n)
             pp, pd = [0], []
-            for k in range(0, n - 1, 2):
-                for j in range(0, n - 1, 2):
-                    for i in range(0, n - 1, 2):
-                        pd.append(ids[k:k + 2, j:j + 2, i:i + 2].reshape(-1)); pp.append(pp[-1] + 8)
+            for k in range(0, n, 2):                                         # covers every dof (n odd: thinner last blocks)
+                for j in range(0, n, 2):
+                    for i in range(0, n, 2):
+                        blk = ids[k:k + 2, j:j + 2, i:i + 2].reshape(-1)
+                        pd.append(blk); pp.append(pp[-1] + blk.size)
             return np.asarray(pp, dtype=np.int64), np.concatenate(pd).astype(np.int32)
         tabs = [blocks(c[0] - 1) for c in H1["ncells"][:-1]]
         mk = lambda: [S.RichardsonSmoother(S.BlockJacobiSolver(pp, pd), 4, 0.5) for pp, pd in tabs]
@@ -484,12 +485,22 @@ def test_value_refresh_is_bitwise_a_fresh_setup(S, po, orc, smoother, monkeypatc
     x = np.zeros_like(b2)
     S.solve_(x, ns, b2)
     it_refresh, hist_refresh = solver.log.num_iters, solver.log.residuals[: solver.log.num_iters + 1].copy()
+    if it_refresh >= 40:
+        pytest.fail("refreshed solver did not converge")
     solver2 = S.CGSolver(make_gmg(S, H2, pre_smoothers=mk()), maxiter=40, atol=1e-14, rtol=1e-8, flexible=(smoother == "patch"))
     t0 = time.perf_counter()
     ns2 = setup(S, solver2, H2["mats"][0])
     t_fresh = time.perf_counter() - t0
     xf = np.zeros_like(b2)
     S.solve_(xf, ns2, b2)
+    from gridapsolvers_jl_amd import abi
+    for l in range(nlev - 1):                                                  # level by level: operator, smoother's inner solve
+        v = np.random.default_rng(l).uniform(-1, 1, H2["mats"][l].shape[0])
+        y1, y2 = np.zeros_like(v), np.zeros_like(v)
+        ns.P_ns.op_apply(l, abi.OP_A, v, y1); ns2.P_ns.op_apply(l, abi.OP_A, v, y2)
+        np.testing.assert_array_equal(y1, y2, err_msg=f"operator of level {l} after refresh")
+        ns.P_ns.precond(l, v, y1); ns2.P_ns.precond(l, v, y2)
+        np.testing.assert_array_equal(y1, y2, err_msg=f"smoother blocks / D^-1 of level {l} after refresh")
     assert it_refresh == solver2.log.num_iters
     np.testing.assert_array_equal(hist_refresh, solver2.log.residuals[: solver2.log.num_iters + 1])
     np.testing.assert_array_equal(x, xf)
