@@ -74,7 +74,13 @@ class DistributedGMG:
 
     def __init__(self, cells_per_rank, nlevels, rank, world, device_id=0, transport="rccl", group=None,
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
-                 gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None):
+                 gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None,
+                 smoother="jacobi"):
+        """smoother = "jacobi": Richardson(Jacobi, niter, omega); "patch": Richardson(PatchSolver, niter, omega) with the
+        vertex-star patches OWNED by this rank (partition.local_vertex_star_patches) and caller-assembled patch matrices --
+        a rank's local matrix has the owned rows only, so the blocks of patches reaching into ghost dofs come from the
+        driver, as the reference assembles them from the solver's weak form on the local (ghosted) mesh
+        (PatchSolvers.jl:137-150)."""
         import torch.distributed as dist
         lib = abi.load()
         self._lib, self.rank, self.world = lib, rank, world
@@ -121,7 +127,10 @@ class DistributedGMG:
             if l < nlevels - 1:
                 self._set(lib.gmg_set_prolongation, l, L.P)
                 self._set(lib.gmg_set_restriction, l, L.R)
-                abi.check(h, lib.gmg_set_smoother_jacobi(h, l, abi.PRE_AND_POST, niter, omega))
+                if smoother == "patch":
+                    self._set_patch_smoother(l, L, niter, omega)
+                else:
+                    abi.check(h, lib.gmg_set_smoother_jacobi(h, l, abi.PRE_AND_POST, niter, omega))
         if world > 1:
             gid = self.local["rep_gid"]
             self._keep.append(gid)
@@ -135,6 +144,26 @@ class DistributedGMG:
         self.n_own = levels[0].n_own
         self.n_global = po.level_sizes(self.cells_global, order)
         self.nnz_local = levels[0].A.nnz
+
+    def _set_patch_smoother(self, l, L, niter, omega):
+        lib, h = self._lib, self.h
+        cells_l = self.local["cells"][l]
+        if L.replicated or self.world == 1:
+            pp, pd = po.vertex_star_patches(cells_l, self.order)
+            pd64 = pd.astype(np.int64)
+            self._keep += [pp, pd64]
+            abi.check(h, lib.gmg_set_smoother_patch(h, l, abi.PRE_AND_POST, niter, omega, abi.PATCH_LU, pp.size - 1,
+                                                    C.c_void_p(pp.ctypes.data), C.c_void_p(pd64.ctypes.data), 0, 8))
+            return
+        pp, pl, pg = pa.local_vertex_star_patches(cells_l, self.order, self.grid, self.rank)
+        Ag = po.poisson_matrix(cells_l, self.order, self.lengths).to_scipy().tocsr()   # driver-side assembly of the patch matrices
+        blocks = [Ag[pg[pp[p]:pp[p + 1]]][:, pg[pp[p]:pp[p + 1]]].toarray().reshape(-1, order="F") for p in range(pp.size - 1)]
+        blocks = np.ascontiguousarray(np.concatenate(blocks)) if blocks else np.zeros(0)
+        pl64 = pl.astype(np.int64)
+        self._keep += [pp, pl64, blocks]
+        abi.check(h, lib.gmg_set_smoother_patch_matrices(h, l, abi.PRE_AND_POST, niter, omega, abi.PATCH_LU, pp.size - 1,
+                                                         C.c_void_p(pp.ctypes.data), C.c_void_p(pl64.ctypes.data), None, 0, 8,
+                                                         C.c_void_p(blocks.ctypes.data), 0, None))
 
     def _set(self, fn, l, M):
         idx64 = M.idx.astype(np.int64)

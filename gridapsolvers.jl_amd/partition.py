@@ -19,7 +19,7 @@ import numpy as np
 
 from . import poisson as po
 
-__all__ = ["rank_grid", "LocalLevel", "build_local_hierarchy", "global_cells"]
+__all__ = ["rank_grid", "LocalLevel", "build_local_hierarchy", "global_cells", "local_vertex_star_patches"]
 
 
 def rank_grid(nranks, dim=3):
@@ -70,10 +70,10 @@ def _axis_ranges(ncell_global, order, nparts, coord):
     c0, c1 = coord * per, (coord + 1) * per
     nlast = order * ncell_global - 1                  # last free node
     lo, hi = order * c0 + 1, min(order * c1, nlast)   # owned free nodes lo..hi inclusive
-    elo, ehi = max(lo - 1, 1), min(hi + 1, nlast)     # one-layer halo of the 27-pt operator
-    # for order 2 the operator couples nodes up to distance 2 inside a cell
-    if order == 2:
-        elo, ehi = max(lo - 2, 1), min(hi + 2, nlast)
+    # halo width in nodes: the operator couples nodes up to `order` apart; the restriction R = P^T of the quadratic
+    # element reaches fine nodes up to 3 away from a coarse node (quarter points of both adjacent coarse cells)
+    w = 1 if order == 1 else 3
+    elo, ehi = max(lo - w, 1), min(hi + w, nlast)
     return lo, hi, elo, ehi
 
 
@@ -168,6 +168,56 @@ class _LevelGeom:
     def remap(self, M):
         """Columns from extended-box numbering to [own | ghost]."""
         return po.CSR((M.shape[0], self.n_own + self.n_ghost), M.ptr, self.ext2loc[M.idx], M.val)
+
+
+def local_vertex_star_patches(cells_global, order, grid, rank):
+    """Vertex-star patches OWNED by `rank` on one level, for the distributed patch smoother (PatchSolvers.jl:227-258).
+
+    Every mesh vertex -- and with it its patch -- belongs to exactly one rank: the owner of the vertex node (a Dirichlet
+    boundary vertex goes with the adjacent free node).  A patch's dofs are the free dofs strictly inside the star of
+    the vertex; those of an interface vertex reach into the neighbour's dofs, which are GHOST dofs here -- hence
+    consistent!(b) before the local solves and assemble!(x) after.  Returns (patch_ptr, patch_dofs in this rank's
+    [own | ghost] numbering, the same dofs as global free-dof ids), patches in lexicographic vertex order, dofs ascending
+    by global id inside a patch (the serial `poisson.vertex_star_patches` order restricted to the owned vertices)."""
+    nc = tuple(int(c) for c in cells_global)
+    d = len(nc)
+    nc3 = nc + (1,) * (3 - d)
+    grid = tuple(grid) + (1,) * (3 - len(grid))
+    g = _LevelGeom(nc3, order, grid, rank, d)
+    ext_shape = g.ext_shape                                   # extended box, x fastest
+
+    def axis_lists(k):
+        """per owned vertex of axis k: its free nodes (global node indices)"""
+        if k >= d:
+            return [np.zeros(1, dtype=np.int64)]
+        lo, hi = g.rng[k][0], g.rng[k][1]
+        nlast = order * nc3[k] - 1
+        out = []
+        for v in range(nc3[k] + 1):
+            node = order * v
+            key = min(max(node, 1), nlast)                    # boundary vertices go with the adjacent free node
+            if not (lo <= key <= hi):
+                continue
+            a, b = max(node - (order - 1), 1), min(node + (order - 1), nlast)
+            out.append(np.arange(a, b + 1, dtype=np.int64))
+        return out
+
+    ax, ay, az = axis_lists(0), axis_lists(1), axis_lists(2)
+    off = [1 if k < d else 0 for k in range(3)]
+    ptr, loc, glob = [0], [], []
+    for lz in az:
+        for ly in ay:
+            for lx in ax:
+                if len(lx) == 0 or len(ly) == 0 or len(lz) == 0:
+                    ptr.append(ptr[-1]); continue
+                ex = ((lz[:, None, None] - g.rng[2][2]) * (ext_shape[1] * ext_shape[0]) + (ly[None, :, None] - g.rng[1][2]) * ext_shape[0]
+                      + (lx[None, None, :] - g.rng[0][2])).reshape(-1)
+                gid = ((lx[None, None, :] - off[0]) + g.nfree[0] * ((ly[None, :, None] - off[1]) + g.nfree[1] * (lz[:, None, None] - off[2]))).reshape(-1)
+                loc.append(g.ext2loc[ex]); glob.append(gid)
+                ptr.append(ptr[-1] + ex.size)
+    loc = np.concatenate(loc) if loc else np.zeros(0, dtype=np.int64)
+    glob = np.concatenate(glob) if glob else np.zeros(0, dtype=np.int64)
+    return np.asarray(ptr, dtype=np.int64), loc.astype(np.int32), glob.astype(np.int64)
 
 
 def _exchange_plan(me):

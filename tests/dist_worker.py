@@ -17,7 +17,9 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 
-def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, rtol, niter=10, omega=2.0 / 3.0):
+def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, rtol, niter=10, omega=2.0 / 3.0, patches=None):
+    """patches: None (Richardson-Jacobi) or per level (patch_ptr, local dofs, list of inverse blocks) -> the distributed patch
+    smoother of PatchSolvers.jl:227-258: consistent!(b), local solves on the OWNED patches, assemble!(x), consistent!(x)."""
     import scipy.sparse.linalg as spla
     levels = local["levels"]
     nlev = len(levels)
@@ -45,6 +47,24 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
         for t, r0, r1 in keep:
             v[L.n_own + r0: L.n_own + r1] = t.numpy()
 
+    def assemble(l, v):
+        """ghost -> owner add (reverse of `exchange`)"""
+        L = levels[l]
+        ops, keep = [], []
+        for k, q in enumerate(L.nbr_rank):
+            s0, s1 = L.snd_ptr[k], L.snd_ptr[k + 1]
+            if s1 > s0:
+                t = torch.zeros(int(s1 - s0), dtype=torch.float64); keep.append((t, s0, s1))
+                ops.append(dist.P2POp(dist.irecv, t, int(q)))
+            r0, r1 = L.rcv_ptr[k], L.rcv_ptr[k + 1]
+            if r1 > r0:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(v[L.n_own + r0: L.n_own + r1].copy()), int(q)))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, s0, s1 in keep:                               # neighbour order: deterministic sums
+            np.add.at(v, L.snd_idx[s0:s1], t.numpy())
+
     def gdot(a, c):
         t = torch.tensor([float(np.dot(a, c))], dtype=torch.float64)
         dist.all_reduce(t)
@@ -55,6 +75,22 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
 
     def smooth(l, x, r):
         n = levels[l].n_own
+        if patches is not None:
+            pp, pl, Binv = patches[l]
+            for _ in range(niter):
+                exchange(l, r)                               # consistent!(b), PatchSolvers.jl:231
+                dx = vec(l)
+                for p in range(pp.size - 1):                 # owned patches, ascending (PatchSolvers.jl:288)
+                    idx = pl[pp[p]:pp[p + 1]]
+                    if idx.size:
+                        dx[idx] += Binv[p] @ r[idx]
+                assemble(l, dx)                              # PatchSolvers.jl:254
+                dx[n:] = 0.0
+                dx[:n] *= omega
+                x[:n] += dx[:n]
+                exchange(l, dx)                              # consistent!(x), :256
+                r[:n] -= A[l] @ dx
+            return
         for _ in range(niter):
             dx = vec(l)
             dx[:n] = omega * (dinv[l] * r[:n])
@@ -124,17 +160,38 @@ def main():
     grid = pa.rank_grid(world, d)
     cg = pa.global_cells(cells, grid)
     maxiter, atol, rtol = 20, 1e-14, 1e-6
+    order = int(os.environ.get("GMG_TEST_ORDER", "1"))
+    smoother = os.environ.get("GMG_TEST_SMOOTHER", "jacobi")
+    p_niter, p_omega = 4, 0.2
     verdict = {}
     if mode == "numpy":
-        local = pa.build_local_hierarchy(cg, nlev, grid, rank, 1, None, rep_from)
-        b = po.dirichlet_lift_rhs(cg, 1)[local["levels"][0].own_gid]
-        x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol)
+        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from)
+        b = po.dirichlet_lift_rhs(cg, order)[local["levels"][0].own_gid]
+        patches = None
+        if smoother == "patch":
+            patches = []
+            for l in range(nlev - 1):
+                Lc = local["levels"][l]
+                Ag = po.poisson_matrix(local["cells"][l], order).to_scipy().tocsr()
+                if Lc.replicated:
+                    pp, pd = po.vertex_star_patches(local["cells"][l], order)
+                    pl, pg = pd.astype(np.int64), pd.astype(np.int64)
+                else:
+                    pp, pl, pg = pa.local_vertex_star_patches(local["cells"][l], order, grid, rank)
+                Binv = [np.linalg.inv(Ag[pg[pp[p]:pp[p + 1]]][:, pg[pp[p]:pp[p + 1]]].toarray()) if pp[p + 1] > pp[p] else None
+                        for p in range(pp.size - 1)]
+                patches.append((pp, pl.astype(np.int64), Binv))
+            x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol, p_niter, p_omega, patches)
+        else:
+            x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol)
         gid = local["levels"][0].own_gid
     else:
         ndev = torch.cuda.device_count()
         dev = rank % max(ndev, 1)
         torch.cuda.set_device(dev)
-        g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=rep_from)
+        g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=rep_from,
+                                    order=order, smoother=smoother, niter=(p_niter if smoother == "patch" else 10),
+                                    omega=(p_omega if smoother == "patch" else 2.0 / 3.0))
         b = g.rhs_lin()
         x = np.zeros(g.n_own)
         log = g.cg_solve(b, x, maxiter, atol, rtol)
@@ -151,9 +208,13 @@ def main():
     dist.all_gather_object(parts, (gid, x, int(nit), hist.tolist()))
     if rank == 0:
         orc = entry.import_oracle()
-        H = po.build_hierarchy(cg, nlev, 1)
-        bg = po.dirichlet_lift_rhs(cg, 1)
-        go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+        H = po.build_hierarchy(cg, nlev, order)
+        bg = po.dirichlet_lift_rhs(cg, order)
+        if smoother == "patch":
+            sms = [orc.Smoother(orc.PATCH, p_niter, p_omega, *po.vertex_star_patches(c, order)) for c in H["ncells"][:-1]]
+            go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=sms, maxiter=1)
+        else:
+            go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
         xo, nit_o, flag, hist_o = orc.cg_solve(H["mats"][0], bg, Pl=go, maxiter=maxiter, atol=atol, rtol=rtol)
         xg = np.zeros_like(xo)
         for gidq, xq, _, _ in parts:
@@ -161,7 +222,7 @@ def main():
         verdict.update(iters=int(nit), iters_oracle=int(nit_o), iters_all_equal=all(p[2] == nit for p in parts),
                        rel_err=float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)),
                        hist_dev=float(np.max(np.abs(np.array(hist) - hist_o) / hist_o)) if len(hist) == len(hist_o) else 1.0,
-                       l2_error_sq=float(po.l2_error_sq(cg, 1, xg)), world=world, grid=list(grid), mode=mode)
+                       l2_error_sq=float(po.l2_error_sq(cg, order, xg)), world=world, grid=list(grid), mode=mode)
         json.dump(verdict, open(out, "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -83,6 +83,57 @@ def test_partition_operators_match_global(po, pkg):
                     assert np.array_equal(sent, Lq.ghost_gid[Lq.rcv_ptr[kk]:Lq.rcv_ptr[kk + 1]])
 
 
+@pytest.mark.parametrize("world,cells,nlev,rep", [(2, (4, 4, 4), 2, 0), (4, (8, 8), 3, 0), (8, (4, 4, 4), 2, 0), (2, (8, 8), 3, 1)])
+def test_partitioned_patch_smoother_numpy_gloo(world, cells, nlev, rep, tmp_path):
+    """Q2 + the distributed vertex-star patch smoother (consistent!(b), owned patches, assemble!(x), consistent!(x);
+    PatchSolvers.jl:227-236,251-258) emulated in numpy over gloo: CG+GMG iteration count identical to the serial oracle."""
+    v = _launch("numpy", world, cells, nlev, tmp_path, rep_from=rep, extra_env={"GMG_TEST_ORDER": "2", "GMG_TEST_SMOOTHER": "patch"})
+    _check(v)
+
+
+def test_partition_operators_match_global_q2(po, pkg):
+    """order 2: halo of 3 nodes (R = P^T reaches the quarter points of both adjacent coarse cells); owned vertex-star patches of
+    all ranks = the serial patch set, each patch exactly once, local numbering consistent with the ghost layout."""
+    from gridapsolvers_jl_amd import partition as pa
+    for nc, nlev, nranks in [((8, 8, 8), 2, 8), ((8, 4, 4), 2, 2), ((16, 16), 3, 4)]:
+        grid = pa.rank_grid(nranks, len(nc))
+        Hg = po.build_hierarchy(nc, nlev, 2)
+        locs = [pa.build_local_hierarchy(nc, nlev, grid, r, 2, None, nlev) for r in range(nranks)]
+        for l in range(nlev):
+            N = Hg["mats"][l].shape[0]
+            x = np.random.default_rng(l).uniform(-1, 1, N)
+            yg = Hg["mats"][l].matvec(x)
+            for r in range(nranks):
+                L = locs[r]["levels"][l]
+                xl = np.concatenate([x[L.own_gid], x[L.ghost_gid]])
+                assert np.abs(L.A.matvec(xl) - yg[L.own_gid]).max() < 1e-12
+                if l < nlev - 1:
+                    Lc = locs[r]["levels"][l + 1]
+                    xc = np.random.default_rng(9).uniform(-1, 1, Hg["mats"][l + 1].shape[0])
+                    xcl = np.concatenate([xc[Lc.own_gid], xc[Lc.ghost_gid]])
+                    assert np.abs(L.P.matvec(xcl) - Hg["prolongations"][l].matvec(xc)[L.own_gid]).max() < 1e-13
+                    assert np.abs(L.R.matvec(xl) - Hg["restrictions"][l].matvec(x)[Lc.own_gid]).max() < 1e-12
+        for l in range(nlev - 1):
+            pp, pd = po.vertex_star_patches(Hg["ncells"][l], 2)
+            serial = sorted(tuple(pd[pp[p]:pp[p + 1]]) for p in range(pp.size - 1) if pp[p + 1] > pp[p])
+            got = []
+            for r in range(nranks):
+                lp, ll, lg = pa.local_vertex_star_patches(Hg["ncells"][l], 2, grid, r)
+                L = locs[r]["levels"][l]
+                assert (np.concatenate([L.own_gid, L.ghost_gid])[ll] == lg).all()
+                got += [tuple(lg[lp[p]:lp[p + 1]]) for p in range(lp.size - 1) if lp[p + 1] > lp[p]]
+            assert sorted(got) == serial
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cells,nlev,rep", [(2, (4, 4, 4), 2, 0), (8, (4, 4, 4), 2, 0), (4, (8, 8), 3, 1)])
+def test_partitioned_patch_smoother_on_gpu_host_transport(world, cells, nlev, rep, tmp_path):
+    """the same through libgmgamd: reverse halo (assemble!) + ghost-reaching patches with caller-assembled patch matrices."""
+    v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep,
+                extra_env={"GMG_TEST_ORDER": "2", "GMG_TEST_SMOOTHER": "patch"})
+    _check(v)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,cells,nlev,rep", [(2, (16, 16, 16), 3, 0), (8, (8, 8, 8), 2, 0), (4, (16, 16), 3, 0), (2, (16, 16, 16), 4, 2), (8, (8, 8, 8), 3, 1)])
 def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_path):
