@@ -118,6 +118,8 @@ mutable struct HipGMGNumericalSetup{A} <: Gridap.Algebra.NumericalSetup
   solver :: A
   handle :: Ptr{Cvoid}
   n      :: Int
+  keepalive :: Any          # Julia objects the handle points at (coarse-solver callback context)
+  HipGMGNumericalSetup(solver::A, handle, n) where A = new{A}(solver, handle, n, nothing)
 end
 
 # --- operator upload: SparseMatrixCSC{Float64,Ti} is CSC / 1-based / sizeof(Ti) bytes ----
@@ -460,7 +462,9 @@ function _block_numerical_setup(P::HipBlockTriangularSolver, mat, owner)
   href = Ref{Ptr{Cvoid}}(C_NULL)
   check_block(C_NULL, ccall((:gmg_block_create, libgmgamd), Cint, (Ref{Ptr{Cvoid}},Cint,Ptr{Int64},Cint,Cint), href, NB, sizes, kind, 0))
   ns = HipBlockNumericalSetup(owner, href[], Any[], sum(sizes))
-  finalizer(x -> ccall((:gmg_block_destroy, libgmgamd), Cint, (Ptr{Cvoid},), x.handle), ns)   # before the GMG setups it borrows
+  # Finalizers of objects that die together run in no particular order; the library copes with either order
+  # (gmg_destroy on a borrowed handle makes the block handle forget it, gmg_block_destroy skips forgotten handles).
+  finalizer(x -> ccall((:gmg_block_destroy, libgmgamd), Cint, (Ptr{Cvoid},), x.handle), ns)
   h = ns.handle
   for i in 1:NB, j in 1:NB
     iszero(nnz(sparse(B[i,j]))) || _set_block(:system, h, i-1, j-1, B[i,j])
@@ -544,5 +548,312 @@ function block_cg_solve!(x::AbstractVector, ns::HipBlockNumericalSetup, b::Abstr
   _fill_log!(log, res[], hist)
   return x
 end
+
+# ------------------------------------------------------------------------------------------------
+# Options the reference passes as keyword arguments / solver objects
+# ------------------------------------------------------------------------------------------------
+const GMG_COARSE_DENSE_INVERSE, GMG_COARSE_CG_JACOBI, GMG_COARSE_HOST_CALLBACK = Cint(0), Cint(1), Cint(2)
+
+# coarsest_solver (GMGLinearSolvers.jl:54,423-434).  `LUSolver()` -> dense inverse on the device (default);
+# `CGSolver(JacobiLinearSolver();maxiter,atol,rtol)` -> the same iteration on the device; any other Gridap LinearSolver
+# (PETScLinearSolver, PardisoSolver, ...) -> solved by Julia itself through a callback on host vectors.
+mutable struct CoarseCallback
+  ns   :: Any                 # numerical setup of the caller's solver on the coarsest matrix
+  x    :: Vector{Float64}
+  b    :: Vector{Float64}
+end
+function _coarse_trampoline(ctx::Ptr{Cvoid}, n::Int64, r::Ptr{Float64}, x::Ptr{Float64})::Cint
+  cb = unsafe_pointer_to_objref(ctx)::CoarseCallback
+  try
+    copyto!(cb.b, unsafe_wrap(Array, r, n))
+    fill!(cb.x, 0.0)
+    solve!(cb.x, cb.ns, cb.b)                               # solve!(xh, ns.coarsest_solver_cache, rh), GMGLinearSolvers.jl:474
+    copyto!(unsafe_wrap(Array, x, n), cb.x)
+    return Cint(0)
+  catch
+    return Cint(1)                                          # never unwind through the C frames
+  end
+end
+function set_coarsest_solver!(ns::HipGMGNumericalSetup, solver, Acoarse::AbstractMatrix)
+  h = ns.handle
+  if solver isa Gridap.Algebra.LUSolver
+    check(h, ccall((:gmg_set_coarse_solver, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Float64,Float64,Ptr{Cvoid},Ptr{Cvoid}),
+                   h, GMG_COARSE_DENSE_INVERSE, 0, 0.0, 0.0, C_NULL, C_NULL))
+  elseif solver isa GridapSolvers.LinearSolvers.CGSolver && solver.Pl isa JacobiLinearSolver && !solver.flexible
+    t = solver.log.tols
+    check(h, ccall((:gmg_set_coarse_solver, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Float64,Float64,Ptr{Cvoid},Ptr{Cvoid}),
+                   h, GMG_COARSE_CG_JACOBI, t.maxiter, t.atol, t.rtol, C_NULL, C_NULL))
+  else
+    n  = size(Acoarse,1)
+    cb = CoarseCallback(numerical_setup(symbolic_setup(solver,Acoarse),Acoarse), zeros(n), zeros(n))
+    ns.keepalive = cb                                       # rooted for as long as the handle lives
+    fptr = @cfunction(_coarse_trampoline, Cint, (Ptr{Cvoid},Int64,Ptr{Float64},Ptr{Float64}))
+    check(h, ccall((:gmg_set_coarse_solver, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Float64,Float64,Ptr{Cvoid},Ptr{Cvoid}),
+                   h, GMG_COARSE_HOST_CALLBACK, 0, 0.0, 0.0, fptr, pointer_from_objref(cb)))
+  end
+  check(h, ccall((:gmg_setup, libgmgamd), Cint, (Ptr{Cvoid},), h))
+  return ns
+end
+coarse_log(ns::HipGMGNumericalSetup) = (r = Ref(GmgResult(0,0,0.0,0.0));
+  check(ns.handle, ccall((:gmg_get_coarse_log, libgmgamd), Cint, (Ptr{Cvoid},Ref{GmgResult}), ns.handle, r)); r[])
+
+# verbose kwarg: the library never prints; verbose > 0 keeps the GMG's own ConvergenceLog complete when it runs as a
+# preconditioner inside the device Krylov solvers (GMGLinearSolvers.jl:627-640); gmg_log! copies it into ns.solver.log.
+set_verbose!(ns::HipGMGNumericalSetup, v::Integer) =
+  check(ns.handle, ccall((:gmg_set_verbose, libgmgamd), Cint, (Ptr{Cvoid},Cint), ns.handle, v))
+function gmg_log!(ns::HipGMGNumericalSetup)
+  log = ns.solver.log
+  res = Ref(GmgResult(0,0,0.0,0.0)); hist = zeros(log.tols.maxiter+1)
+  GC.@preserve hist check(ns.handle, ccall((:gmg_get_log, libgmgamd), Cint, (Ptr{Cvoid},Ref{GmgResult},Ptr{Float64},Cint),
+                                          ns.handle, res, hist, length(hist)))
+  return _fill_log!(log, res[], hist)
+end
+
+# PatchSolver numerical setup as the reference holds it (PatchSolvers.jl:100-150): patch_rows, patch_cols, and either the
+# assembled patch matrices (Vector of Matrix{Float64}) or their lu! factorizations (collect_factorizations=true).
+function set_patch_smoother!(ns::HipGMGNumericalSetup, lev::Integer, which::Cint, niter::Integer, ω::Real,
+                             patch_rows::Gridap.Arrays.Table, patch_cols::Gridap.Arrays.Table;
+                             patch_mats = nothing, factorizations = nothing, pivoting = true)
+  ptrs = Int64.(patch_rows.ptrs); rows = Int64.(patch_rows.data); cols = Int64.(patch_cols.data)
+  blocks = Float64[]; piv = Int32[]; are_factors = Cint(0)
+  if !isnothing(factorizations)                              # LinearAlgebra.LU objects: F.factors (packed L\U), F.ipiv (1-based)
+    for F in factorizations
+      append!(blocks, vec(F.factors)); append!(piv, Int32.(F.ipiv))
+    end
+    are_factors = Cint(1)
+  elseif !isnothing(patch_mats)
+    for M in patch_mats
+      append!(blocks, vec(Matrix{Float64}(M)))               # column-major, as stored
+    end
+  end
+  GC.@preserve ptrs rows cols blocks piv begin
+    check(ns.handle, ccall((:gmg_set_smoother_patch_matrices, libgmgamd), Cint,
+      (Ptr{Cvoid},Cint,Cint,Cint,Float64,Cint,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Cvoid},Cint,Cint,Ptr{Float64},Cint,Ptr{Int32}),
+      ns.handle, lev-1, which, niter, ω, pivoting ? GMG_PATCH_LU : GMG_PATCH_NOPIVOT, length(ptrs)-1, ptrs, rows, cols, 1, 8,
+      isempty(blocks) ? C_NULL : pointer(blocks), are_factors, isempty(piv) ? C_NULL : pointer(piv)))
+  end
+  return ns
+end
+
+# Operators too large to hold at once: hand the rows over block by block (CSR blocks, 1-based, e.g. the row slabs an
+# assembler produces); op = 0 (A), 1 (P), 2 (R).  The library keeps only the row-pattern form.
+function set_operator_rows!(ns::HipGMGNumericalSetup, lev::Integer, op::Integer, nrows::Integer, ncols::Integer, row0::Integer,
+                            rowptr::Vector{Int64}, colval::Vector{Int64}, nzval::Vector{Float64})
+  GC.@preserve rowptr colval nzval check(ns.handle, ccall((:gmg_set_operator_rows, libgmgamd), Cint,
+    (Ptr{Cvoid},Cint,Cint,Int64,Int64,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint),
+    ns.handle, lev-1, op, nrows, ncols, row0-1, length(rowptr)-1, rowptr, colval, nzval, 1, 8))
+  return ns
+end
+
+# ------------------------------------------------------------------------------------------------
+# Distributed: PSparseMatrix / PVector (one MPI rank = one GPU), the shape of test/LinearSolvers/mpi/GMGTests.jl:5-8.
+#
+# The reference row-partitions every level with PartitionedArrays: local ids = own then ghost
+# (JacobiLinearSolvers.jl:29-56 uses own_values / partition), `consistent!` moves owner -> ghost, `assemble!` adds
+# ghost -> owner, dot/norm reduce over parts.  The library needs, per level and rank:
+#   * the LOCAL operator rows of the owned dofs with columns numbered [own | ghost], ghosts grouped by owner rank
+#     (PartitionedArrays orders ghosts arbitrarily -> `_ghost_permutation` below renumbers them once);
+#   * the exchange plan of `consistent!`: neighbours, owned ids to send, ghost sub-ranges to receive.
+# Communication runs over RCCL/xGMI (communicator seeded with an id broadcast over MPI) -- or, where ranks share a GPU,
+# through MPI itself via the host-callback transport.
+# ------------------------------------------------------------------------------------------------
+import PartitionedArrays as PA
+import MPI
+
+struct HipDistributedLevel
+  n_own    :: Int
+  n_ghost  :: Int
+  gperm    :: Vector{Int}          # PartitionedArrays ghost position -> library ghost position (grouped by owner)
+  nbr      :: Vector{Int32}        # 0-based MPI ranks
+  snd_ptr  :: Vector{Int64}
+  snd_idx  :: Vector{Int64}        # 0-based owned local ids, per neighbour
+  rcv_ptr  :: Vector{Int64}
+end
+
+# exchange plan of one part of a PRange (`indices = partition(axes(A,2))[part]`)
+function _exchange_plan(indices, all_indices)
+  own_to_local   = PA.own_to_local(indices)
+  ghost_to_local = PA.ghost_to_local(indices)
+  ghost_owner    = PA.ghost_to_owner(indices)               # 1-based part ids
+  n_own, n_ghost = length(own_to_local), length(ghost_to_local)
+  # ghosts grouped by owner (stable inside an owner: ascending global id)
+  gids  = PA.ghost_to_global(indices)
+  order = sortperm(collect(zip(ghost_owner, gids)))
+  gperm = invperm(order)
+  owners_sorted = ghost_owner[order]
+  nbr_rcv = unique(owners_sorted)
+  rcv_ptr = Int64[0]
+  for q in nbr_rcv
+    push!(rcv_ptr, rcv_ptr[end] + count(==(q), owners_sorted))
+  end
+  # what I send: the assembly graph reversed -- assembly sends ghosts to owners, consistent! sends owned values back
+  nbrs_snd, nbrs_rcv = PA.assembly_neighbors(all_indices) |> x -> (map(identity,x[1]), map(identity,x[2]))
+  lids_snd, lids_rcv = PA.assembly_local_indices(all_indices, nbrs_snd, nbrs_rcv)
+  me = PA.part_id(indices)
+  my_rcv_nbrs = PA.getany(nbrs_rcv); my_rcv_lids = PA.getany(lids_rcv)   # owned local ids that RECEIVE in assemble! = SEND in consistent!
+  local_to_own = zeros(Int, PA.local_length(indices)); local_to_own[own_to_local] .= 1:n_own
+  nbr = sort(unique(vcat(collect(my_rcv_nbrs), nbr_rcv)))
+  snd_ptr = Int64[0]; snd_idx = Int64[]; rp = Int64[0]
+  for q in nbr
+    k = findfirst(==(q), my_rcv_nbrs)
+    ids = isnothing(k) ? Int[] : collect(my_rcv_lids[k])
+    append!(snd_idx, local_to_own[ids] .- 1)
+    push!(snd_ptr, length(snd_idx))
+    j = findfirst(==(q), nbr_rcv)
+    push!(rp, rp[end] + (isnothing(j) ? 0 : rcv_ptr[j+1]-rcv_ptr[j]))
+  end
+  # NOTE: both sides must agree on the ORDER inside a message: PartitionedArrays sorts assembly lists by global id on
+  # both ends, which is also the ghost order chosen above.
+  return HipDistributedLevel(n_own, n_ghost, gperm, Int32.(nbr .- 1), snd_ptr, snd_idx, rp)
+end
+
+# local operator rows of the owned dofs, columns [own | ghost(grouped by owner)], as 1-based CSC for _set_op
+function _local_operator(A::PA.PSparseMatrix, plan_cols::HipDistributedLevel)
+  Aoo = PA.getany(PA.own_own_values(A)); Aog = PA.getany(PA.own_ghost_values(A))
+  Pm  = sparse(1:plan_cols.n_ghost, plan_cols.gperm, ones(plan_cols.n_ghost), plan_cols.n_ghost, plan_cols.n_ghost)
+  return SparseMatrixCSC{Float64,Int64}(hcat(sparse(Aoo), sparse(Aog) * Pm))
+end
+
+mutable struct HipDistributedGMGNumericalSetup <: Gridap.Algebra.NumericalSetup
+  solver  :: HipGMGLinearSolver
+  inner   :: HipGMGNumericalSetup
+  plans   :: Vector{HipDistributedLevel}
+  comm    :: MPI.Comm
+end
+
+const _MPI_CTX = Ref{Any}(nothing)
+# host-staged transport (several ranks per GPU, or no RCCL): MPI point-to-point / Allreduce from callbacks
+function _mpi_exchange(ctx::Ptr{Cvoid}, nnbr::Cint, nbr::Ptr{Int32}, snd::Ptr{Float64}, sp::Ptr{Int64}, rcv::Ptr{Float64}, rp::Ptr{Int64})::Cvoid
+  comm = _MPI_CTX[]::MPI.Comm
+  nb = unsafe_wrap(Array, nbr, nnbr); spv = unsafe_wrap(Array, sp, nnbr+1); rpv = unsafe_wrap(Array, rp, nnbr+1)
+  sbuf = unsafe_wrap(Array, snd, spv[end]); rbuf = unsafe_wrap(Array, rcv, rpv[end])
+  reqs = MPI.Request[]
+  for k in 1:nnbr
+    rpv[k+1] > rpv[k] && push!(reqs, MPI.Irecv!(view(rbuf, rpv[k]+1:rpv[k+1]), comm; source=nb[k], tag=7))
+    spv[k+1] > spv[k] && push!(reqs, MPI.Isend(view(sbuf, spv[k]+1:spv[k+1]), comm; dest=nb[k], tag=7))
+  end
+  MPI.Waitall(reqs)
+  return nothing
+end
+function _mpi_allreduce(ctx::Ptr{Cvoid}, vals::Ptr{Float64}, n::Cint)::Cvoid
+  v = unsafe_wrap(Array, vals, n)
+  MPI.Allreduce!(v, +, _MPI_CTX[]::MPI.Comm)
+  return nothing
+end
+
+"""
+    numerical_setup(ss::HipGMGSymbolicSetup, A::PSparseMatrix; comm=MPI.COMM_WORLD, transport=:rccl, replicate_from=nlev)
+
+Distributed counterpart of `numerical_setup(ss, A::AbstractMatrix)`: `s.smatrices`, `s.interp`, `s.restrict` hold the
+PSparseMatrix of every level (explicit R is required: a local Pᵀ misses off-rank rows).  Levels `replicate_from:nlev`
+are gathered (`PA.to_trivial_partition`-style, here `_gather_global`) and computed redundantly on every rank -- the
+analogue of coarse levels living on fewer ranks (ModelHierarchies.jl:80-148) without the redistribution traffic.
+"""
+function Gridap.Algebra.numerical_setup(ss::HipGMGSymbolicSetup, A::PA.PSparseMatrix;
+                                        comm::MPI.Comm = MPI.COMM_WORLD, transport::Symbol = :rccl,
+                                        replicate_from::Integer = length(ss.solver.smatrices))
+  s = ss.solver
+  nlev = length(s.smatrices)
+  @assert !isnothing(s.restrict) "distributed runs need explicit restriction matrices"
+  rank, nranks = MPI.Comm_rank(comm), MPI.Comm_size(comm)
+  href = Ref{Ptr{Cvoid}}(C_NULL)
+  check(C_NULL, ccall((:gmg_create, libgmgamd), Cint, (Ref{Ptr{Cvoid}},Cint,Cint), href, nlev, s.device))
+  h = href[]
+  inner = HipGMGNumericalSetup(s, h, PA.own_length(PA.getany(PA.partition(axes(A,1)))))
+  finalizer(x -> (x.handle != C_NULL && ccall((:gmg_destroy, libgmgamd), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), inner)
+  # --- communicator -------------------------------------------------------------------------------
+  if transport === :rccl
+    uid = zeros(UInt8, 128)
+    rank == 0 && check(C_NULL, ccall((:gmg_comm_unique_id, libgmgamd), Cint, (Cstring,Ptr{UInt8}), C_NULL, uid))
+    MPI.Bcast!(uid, 0, comm)
+    check(h, ccall((:gmg_comm_init_rccl, libgmgamd), Cint, (Ptr{Cvoid},Cstring,Ptr{UInt8},Cint,Cint), h, C_NULL, uid, rank, nranks))
+  else
+    _MPI_CTX[] = comm
+    xf = @cfunction(_mpi_exchange, Cvoid, (Ptr{Cvoid},Cint,Ptr{Int32},Ptr{Float64},Ptr{Int64},Ptr{Float64},Ptr{Int64}))
+    rf = @cfunction(_mpi_allreduce, Cvoid, (Ptr{Cvoid},Ptr{Float64},Cint))
+    check(h, ccall((:gmg_comm_init_host, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Ptr{Cvoid},Ptr{Cvoid},Ptr{Cvoid}), h, rank, nranks, xf, rf, C_NULL))
+  end
+  # --- levels -------------------------------------------------------------------------------------
+  plans = HipDistributedLevel[]
+  mats = [l == 1 ? A : s.smatrices[l] for l in 1:nlev]
+  for l in 1:nlev
+    if l < replicate_from
+      cols = PA.partition(axes(mats[l],2))
+      pl = _exchange_plan(PA.getany(cols), cols)
+      push!(plans, pl)
+      GC.@preserve pl check(h, ccall((:gmg_set_partition, libgmgamd), Cint,
+        (Ptr{Cvoid},Cint,Int64,Int64,Cint,Ptr{Int32},Ptr{Int64},Ptr{Int64},Ptr{Int64}),
+        h, l-1, pl.n_own, pl.n_ghost, length(pl.nbr), pl.nbr, pl.snd_ptr, pl.snd_idx, pl.rcv_ptr))
+      _set_op(:matrix, h, l-1, _local_operator(mats[l], pl))
+    else
+      _set_op(:matrix, h, l-1, _gather_global(mats[l], comm))                   # replicated level: global operator on every rank
+    end
+  end
+  for l in 1:nlev-1
+    if l+1 < replicate_from
+      _set_op(:prolongation, h, l-1, _local_operator(s.interp[l], plans[l+1]))    # fine owned rows x coarse [own|ghost]
+      _set_op(:restriction,  h, l-1, _local_operator(s.restrict[l], plans[l]))    # coarse owned rows x fine [own|ghost]
+    elseif l+1 == replicate_from
+      _set_op(:prolongation, h, l-1, _rows_global_cols(s.interp[l], comm))        # fine owned rows x GLOBAL coarse columns
+      _set_op(:restriction,  h, l-1, _local_operator(s.restrict[l], plans[l]))
+      gids = Int64.(PA.own_to_global(PA.getany(PA.partition(axes(s.restrict[l],1))))) .- 1
+      GC.@preserve gids check(h, ccall((:gmg_set_replication, libgmgamd), Cint, (Ptr{Cvoid},Cint,Ptr{Int64},Int64), h, l, gids, length(gids)))
+    else
+      _set_op(:prolongation, h, l-1, _gather_global(s.interp[l], comm))
+      _set_op(:restriction,  h, l-1, _gather_global(s.restrict[l], comm))
+    end
+    s.post_smoothers[l] === s.pre_smoothers[l] ? _set_smoother(h, l-1, GMG_PRE_AND_POST, s.pre_smoothers[l]) :
+      (_set_smoother(h, l-1, GMG_PRE, s.pre_smoothers[l]); _set_smoother(h, l-1, GMG_POST, s.post_smoothers[l]))
+  end
+  tols = s.log.tols
+  check(h, ccall((:gmg_set_options, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Cint,Float64,Float64), h,
+                 s.mode == :preconditioner ? 0 : 1, s.cycle_type == :v_cycle ? 0 : (s.cycle_type == :w_cycle ? 1 : 2),
+                 tols.maxiter, tols.atol, tols.rtol))
+  check(h, ccall((:gmg_setup, libgmgamd), Cint, (Ptr{Cvoid},), h))
+  return HipDistributedGMGNumericalSetup(s, inner, plans, comm)
+end
+
+# gather a (small) PSparseMatrix on every rank as one SparseMatrixCSC in GLOBAL numbering
+function _gather_global(M::PA.PSparseMatrix, comm::MPI.Comm)
+  I, J, V = PA.getany(map(PA.partition(M), PA.partition(axes(M,1)), PA.partition(axes(M,2))) do Ml, rows, cols
+    i, j, v = findnz(sparse(Ml))
+    keep = [PA.local_to_owner(rows)[ii] == PA.part_id(rows) for ii in i]      # owned rows only
+    (PA.local_to_global(rows)[i[keep]], PA.local_to_global(cols)[j[keep]], v[keep])
+  end)
+  Ia = MPI.Allgatherv!(MPI.VBuffer(Int64.(I), nothing), comm); Ja = MPI.Allgatherv!(MPI.VBuffer(Int64.(J), nothing), comm)
+  Va = MPI.Allgatherv!(MPI.VBuffer(Float64.(V), nothing), comm)
+  return SparseMatrixCSC{Float64,Int64}(sparse(Ia, Ja, Va, size(M,1), size(M,2)))
+end
+# owned rows of M with GLOBAL column ids (the prolongation across the distributed -> replicated boundary)
+function _rows_global_cols(M::PA.PSparseMatrix, comm::MPI.Comm)
+  rows = PA.getany(PA.partition(axes(M,1))); cols = PA.getany(PA.partition(axes(M,2)))
+  Ml = sparse(PA.getany(PA.partition(M)))
+  i, j, v = findnz(Ml[PA.own_to_local(rows), :])
+  return SparseMatrixCSC{Float64,Int64}(sparse(i, PA.local_to_global(cols)[j], v, PA.own_length(rows), size(M,2)))
+end
+
+# solve!(x::PVector, ns, b::PVector): vectors cross the boundary as their OWNED values (JacobiLinearSolvers.jl:49-56)
+function Gridap.Algebra.solve!(x::PA.PVector, ns::HipDistributedGMGNumericalSetup, b::PA.PVector)
+  xo = PA.getany(PA.own_values(x)); bo = PA.getany(PA.own_values(b))
+  xv, bv = Vector{Float64}(xo), Vector{Float64}(bo)
+  solve!(xv, ns.inner, bv)                                                   # gmg_apply on the owned entries
+  copyto!(xo, xv)
+  PA.consistent!(x) |> wait
+  return x
+end
+function Gridap.Algebra.solve!(x::PA.PVector, ns::HipKrylovNumericalSetup{<:HipCGSolver,<:HipDistributedGMGNumericalSetup}, b::PA.PVector)
+  xo = PA.getany(PA.own_values(x)); bo = PA.getany(PA.own_values(b))
+  xv, bv = Vector{Float64}(xo), Vector{Float64}(bo)
+  solve!(xv, HipKrylovNumericalSetup(ns.solver, ns.P_ns.inner), bv)          # gmg_cg_solve: dots are all-reduced in the library
+  copyto!(xo, xv)
+  PA.consistent!(x) |> wait
+  return x
+end
+function Gridap.Algebra.numerical_setup(ss::HipKrylovSymbolicSetup, A::PA.PSparseMatrix; kwargs...)
+  P = ss.solver isa HipFGMRESSolver ? ss.solver.Pr : ss.solver.Pl
+  return HipKrylovNumericalSetup(ss.solver, numerical_setup(symbolic_setup(P,A),A; kwargs...))
+end
+Gridap.Algebra.symbolic_setup(s::HipGMGLinearSolver, ::PA.PSparseMatrix) = HipGMGSymbolicSetup(s)
+Gridap.Algebra.symbolic_setup(s::Union{HipCGSolver,HipFGMRESSolver}, ::PA.PSparseMatrix) = HipKrylovSymbolicSetup(s)
 
 end # module
