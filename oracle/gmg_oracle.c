@@ -71,6 +71,7 @@ ORC_API void orc_spmv(i64 n, const i64 *ptr, const i32 *idx, const double *val,
 }
 
 /* dot(a,b): CGSolvers.jl:95,105; FGMRESSolvers.jl:161 */
+#ifndef ORC_BLAS_ORDER
 ORC_API double orc_dot(i64 n, const double *a, const double *b)
 {
   double s = 0.0;
@@ -81,6 +82,35 @@ ORC_API double orc_dot(i64 n, const double *a, const double *b)
 
 /* norm(a): CGSolvers.jl:85,111; GMGLinearSolvers.jl:627,639; FGMRESSolvers.jl:141,164 */
 ORC_API double orc_norm(i64 n, const double *a) { return sqrt(orc_dot(n, a, a)); }
+#else
+/* liboracle_blas.so (tests only): the summation orders Julia really uses on Vector{Float64} -- `dot` and `norm` go through
+ * BLAS: ddot with several interleaved partial sums (SIMD lanes x unrolling; here 8 accumulators combined pairwise, the
+ * shape of OpenBLAS' x86-64 kernels) and dnrm2 as a SCALED sum of squares (reference BLAS / LAPACK dlassq recurrence).
+ * tests/test_oracle.py checks that iteration counts are identical and residual histories agree to 1e-8 between this
+ * build and the left-to-right checker: the parity tolerances do not hinge on the summation order. */
+ORC_API double orc_dot(i64 n, const double *a, const double *b)
+{
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  i64 i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int k = 0; k < 8; ++k) acc[k] += a[i + k] * b[i + k];
+  double tail = 0.0;
+  for (; i < n; ++i) tail += a[i] * b[i];
+  return (((acc[0] + acc[4]) + (acc[2] + acc[6])) + ((acc[1] + acc[5]) + (acc[3] + acc[7]))) + tail;
+}
+ORC_API double orc_norm(i64 n, const double *a)
+{
+  double scale = 0.0, ssq = 1.0;                     /* dnrm2 (reference BLAS): scale * sqrt(ssq) */
+  for (i64 i = 0; i < n; ++i) {
+    if (a[i] != 0.0) {
+      const double ax = fabs(a[i]);
+      if (scale < ax) { const double q = scale / ax; ssq = 1.0 + ssq * q * q; scale = ax; }
+      else { const double q = ax / scale; ssq += q * q; }
+    }
+  }
+  return scale * sqrt(ssq);
+}
+#endif
 
 /* ------------------------------------------------------------------ */
 /* A9: SolverTolerances.jl:117-128, ConvergenceLogs.jl:101-150         */

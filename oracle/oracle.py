@@ -29,7 +29,7 @@ _VARIANT = "seq"      # "seq": liboracle.so (the checker) ; "omp": liboracle_omp
 
 
 def build(force=False, variant=None):
-    name = "liboracle_omp.so" if (variant or _VARIANT) == "omp" else "liboracle.so"
+    name = {"omp": "liboracle_omp.so", "blas": "liboracle_blas.so"}.get(variant or _VARIANT, "liboracle.so")
     so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "gmg_oracle.c")
     if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
@@ -40,7 +40,7 @@ def build(force=False, variant=None):
 def set_variant(name):
     """Switch between the sequential checker and the OpenMP build (objects created before the switch stay on theirs)."""
     global _VARIANT, _LIB
-    assert name in ("seq", "omp")
+    assert name in ("seq", "omp", "blas")
     if name != _VARIANT:
         _VARIANT, _LIB = name, None
 

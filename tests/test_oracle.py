@@ -385,3 +385,137 @@ def test_cpu_baseline_child_runs_both_variants():
     assert outs["seq"]["threads"] == 1 and outs["omp"]["threads"] == 2
     assert outs["seq"]["iters"] == outs["omp"]["iters"] == 3
     np.testing.assert_allclose(outs["seq"]["hist"], outs["omp"]["hist"], rtol=1e-9)
+
+
+# ---------------------------------------------------------------- round 2: independent twins of every oracle component
+def _twin():
+    import numpy_twin
+    return numpy_twin
+
+
+def _seed(n, s):
+    return np.random.default_rng(s).uniform(-1, 1, n)
+
+
+@pytest.mark.parametrize("cyc", ["v", "w", "f"])
+@pytest.mark.parametrize("nc,nlev", [((16, 16), 3), ((8, 8, 8), 2)])
+def test_twin_cycles_jacobi(po, orc, cyc, nc, nlev):
+    """V/W/F cycles (GMGLinearSolvers.jl:468-610): oracle == independent numpy twin."""
+    T = _twin()
+    H = po.build_hierarchy(nc, nlev, 1)
+    A = [m.to_scipy().tocsr() for m in H["mats"]]
+    tw = T.GMG(H["mats"], H["prolongations"], H["restrictions"], [(T.Jacobi(A[l]), 10, 2.0 / 3.0) for l in range(nlev - 1)], cycle=cyc)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], cycle={"v": orc.V_CYCLE, "w": orc.W_CYCLE, "f": orc.F_CYCLE}[cyc], maxiter=1)
+    r = _seed(A[0].shape[0], 3)
+    zo, _, _, _ = go.solve(r)
+    zt = tw.solve(r)
+    assert np.linalg.norm(zo - zt) <= 1e-12 * np.linalg.norm(zt)
+
+
+@pytest.mark.parametrize("kind", ["patch", "block"])
+def test_twin_patch_and_block_jacobi(po, orc, kind):
+    """PatchSolvers.jl:279-300 / BlockJacobiSolvers.jl:141-170 incl. caller matrices and rows != cols (LAPACK getrf/getrs twin)."""
+    T = _twin()
+    nc, order = (8, 8), 2
+    A = po.poisson_matrix(nc, order)
+    pp, pd = po.vertex_star_patches(nc, order)
+    r = _seed(A.shape[0], 5)
+    H = po.build_hierarchy(nc, 2, order)
+    okind = orc.PATCH if kind == "patch" else orc.BLOCKJACOBI
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(okind, 3, 0.2, pp, pd)], maxiter=1)
+    tw = T.Patch(A.to_scipy(), pp, pd, pivot=(kind == "patch"))
+    assert np.max(np.abs(go.precond(0, r) - tw.solve(r))) <= 1e-12 * np.max(np.abs(r)) * 10
+    # whole smoothing pass
+    x, rr = np.zeros_like(r), r.copy()
+    T.richardson(A.to_scipy().tocsr(), tw, 3, 0.2, x, rr)
+    xo, ro = go.smooth(0, np.zeros_like(r), r)
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(x) and np.linalg.norm(rr - ro) <= 1e-12 * np.linalg.norm(r)
+    if kind == "patch":
+        pc = pd.copy()
+        for p in range(pp.size - 1):
+            pc[pp[p]:pp[p + 1]] = pd[pp[p]:pp[p + 1]][::-1]
+        go2 = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(okind, 3, 0.2, pp, pd, patch_cols=pc)], maxiter=1)
+        tw2 = T.Patch(A.to_scipy(), pp, pd, cols=pc)
+        assert np.max(np.abs(go2.precond(0, r) - tw2.solve(r))) <= 1e-11
+
+
+@pytest.mark.parametrize("m,restart,m_add", [(5, False, 1), (2, True, 1), (2, False, 2)])
+def test_twin_fgmres_restart_and_growth(po, orc, m, restart, m_add):
+    """FGMRESSolvers.jl:130-199 with a GMG right preconditioner: iteration count and history of the oracle == twin
+    (Givens rotations from LAPACK dlartg, triangular solve from LAPACK)."""
+    T = _twin()
+    nc, nlev = (16, 16), 2
+    H = po.build_hierarchy(nc, nlev, 1)
+    A = [mm.to_scipy().tocsr() for mm in H["mats"]]
+    b = po.dirichlet_lift_rhs(nc, 1)
+    tw = T.GMG(H["mats"], H["prolongations"], H["restrictions"], [(T.Jacobi(A[0]), 1, 0.5)])
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, 1, 0.5)], maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=go, m=m, restart=restart, m_add=m_add, maxiter=40, atol=1e-14, rtol=1e-10)
+    xt, nt, ht = T.fgmres(A[0], b, Pr=tw.solve, m=m, restart=restart, m_add=m_add, maxiter=40, atol=1e-14, rtol=1e-10)
+    assert nit == nt and nit > m
+    np.testing.assert_allclose(hist, ht, rtol=1e-7, atol=1e-15 * hist[0])      # the Givens estimate |g_j| carries eps*|r_0| absolute noise
+    assert np.linalg.norm(xo - xt) <= 1e-9 * np.linalg.norm(xt)
+
+
+@pytest.mark.parametrize("kind", ["upper", "lower", "diagonal"])
+def test_twin_block_triangular_apply(po, orc, kind):
+    """BlockTriangularSolvers.jl:186-242 / BlockDiagonalSolvers.jl:165-177 with LU diagonal blocks and a coefficient."""
+    import scipy.sparse.linalg as spla
+    T = _twin()
+    M = po.poisson_matrix((8, 8), 1); n = M.shape[0]
+    Ms = M.to_scipy().tocsr()
+    negM = po.CSR(M.shape, M.ptr, M.idx, -M.val)
+    lu = spla.splu(Ms.tocsc())
+    okind = {"upper": orc.UPPER, "lower": orc.LOWER, "diagonal": orc.DIAGONAL}[kind]
+    offd = None if kind == "diagonal" else {(0, 1): (negM, 0.5), (1, 0): (M, 2.0)}
+    P = orc.BlockPreconditioner([n, n], [(orc.BD_LU, M), (orc.BD_LU, M)], offd, okind)
+    b = _seed(2 * n, 9)
+    xt = T.block_apply(kind, [lu.solve, lu.solve], {(0, 1): -Ms, (1, 0): Ms}, [[1.0, 0.5], [2.0, 1.0]], [n, n], b)
+    assert np.linalg.norm(P.apply(b) - xt) <= 1e-12 * np.linalg.norm(xt)
+
+
+# ---------------------------------------------------------------- order of summation: left-to-right checker vs BLAS-style dot / nrm2
+@pytest.mark.parametrize("case", ["config1", "config2_32", "q2_patch"])
+def test_iteration_counts_do_not_depend_on_summation_order(po, orc, case):
+    """Julia's dot / norm on Vector{Float64} run through BLAS (interleaved partial sums, scaled nrm2), its CSC mul! scatters by
+    column.  (1) CSC column scatter adds a row's terms in ascending column order -- the very order of the CSR gather, so
+    mul! is bit-identical (checked below).  (2) With BLAS-style dot / nrm2 (oracle/liboracle_blas.so) the Krylov iteration
+    counts are identical and the residual histories agree to 1e-8: the parity tolerances do not hinge on summation order."""
+    if case == "config1":
+        nc, nlev, order, kry = (64, 64), 3, 1, "cg"
+    elif case == "config2_32":
+        nc, nlev, order, kry = (32, 32, 32), 3, 1, "cg"
+    else:
+        nc, nlev, order, kry = (16, 16), 2, 2, "fgmres"
+    H = po.build_hierarchy(nc, nlev, order)
+    b = po.dirichlet_lift_rhs(nc, order)
+    # (1) CSC scatter == CSR gather, bitwise
+    A = H["mats"][0]
+    S = A.to_scipy().tocsc(); S.sort_indices()
+    x = _seed(A.shape[0], 1)
+    y = np.zeros(A.shape[0])
+    for j in range(min(S.shape[1], 400)):                   # mul!(y, ::SparseMatrixCSC, x): y[rowval[k]] += nzval[k]*x[j]
+        for k in range(S.indptr[j], S.indptr[j + 1]):
+            y[S.indices[k]] += S.data[k] * x[j]
+    xx = np.zeros_like(x); xx[:min(S.shape[1], 400)] = x[:min(S.shape[1], 400)]
+    np.testing.assert_array_equal(y, orc.spmv(A, xx))
+    out = {}
+    try:
+        for variant in ("seq", "blas"):
+            orc.set_variant(variant)
+            if order == 2:
+                pp, pd = po.vertex_star_patches(nc, order)
+                g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd)], maxiter=1)
+            else:
+                g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+            if kry == "cg":
+                out[variant] = orc.cg_solve(A, b, Pl=g, maxiter=20, atol=1e-14, rtol=1e-6)
+            else:
+                out[variant] = orc.fgmres_solve(A, b, Pr=g, m=5, maxiter=20, atol=1e-14, rtol=1e-6)
+    finally:
+        orc.set_variant("seq")
+    (x1, n1, f1, h1), (x2, n2, f2, h2) = out["seq"], out["blas"]
+    assert n1 == n2 and f1 == f2
+    np.testing.assert_allclose(h2, h1, rtol=1e-8)
+    assert np.linalg.norm(x1 - x2) <= 1e-10 * np.linalg.norm(x1)
+    assert not np.array_equal(h1, h2) or n1 == 0             # the two builds really sum differently
