@@ -63,6 +63,8 @@ SYMBOLS = {
                      C.POINTER(Result), C.c_void_p, C.c_int],
     "gmg_fgmres_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_double, C.c_double, C.c_int, C.POINTER(Result), C.c_void_p, C.c_int],
+    "gmg_fgmres_solve_pl": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                            C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(Result), C.c_void_p, C.c_int],
     "gmg_richardson_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                              C.POINTER(Result), C.c_void_p, C.c_int],
     "gmg_op_apply": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int],

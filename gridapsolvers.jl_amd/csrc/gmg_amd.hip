@@ -382,7 +382,9 @@ int env_int(const char *name, int dflt)
 struct KrylovOps {
   std::function<void(double *x, const double *b, double *r)> resid;          // r = b - A x
   std::function<void(double *x, double *y)> apply;                           // y = A x
-  std::function<void(double *z, const double *r, double known_res)> precond; // empty: Pl === nothing
+  std::function<void(double *z, const double *r, double known_res)> precond; // empty: Pl === nothing (CG) / Pr === nothing (FGMRES)
+  std::function<void(double *z, const double *r)> precond_left;              // FGMRES only: Pl of KrylovUtils.jl:14-18,46-50
+  double *zl = nullptr;                                                      // its work vector (FGMRESSolvers.jl:66)
 };
 
 struct gmg_block_solver;
@@ -1998,8 +2000,12 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
   };
   const int grid = gmg_solver::grid_for(n);
 
-  // krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 ; FGMRESSolvers.jl:136-140
-  ops.resid(dx, db, V[0]);
+  // krylov_residual!(V[1],x,A,b,Pl,zl): KrylovUtils.jl:46-54 ; FGMRESSolvers.jl:136-140
+  auto residual = [&](double *out) {
+    if (ops.precond_left) { ops.resid(dx, db, ops.zl); ops.precond_left(out, ops.zl); }
+    else ops.resid(dx, db, out);
+  };
+  residual(V[0]);
   double beta = S.norm(n, V[0]);                         // :141
   bool done = log.init(beta);                            // :142
   while (!done) {
@@ -2019,7 +2025,8 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
       // krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25
       if (ops.precond) ops.precond(Zj, V[j - 1], -1.0);
       else S.copy(Zj, V[j - 1], n);
-      ops.apply(Zj, Vn);                                 // :159
+      if (ops.precond_left) { ops.apply(Zj, ops.zl); ops.precond_left(Vn, ops.zl); }   // krylov_mul! with Pl, KrylovUtils.jl:14-18
+      else ops.apply(Zj, Vn);                            // :159
       for (int i = 1; i <= j; ++i) {                     // :160-163 modified Gram-Schmidt
         S.dot_async(n, Vn, V[i - 1], i, false);
         hipLaunchKernelGGL(axmy_dev_kernel, dim3(grid), dim3(256), 0, S.stream, n, S.d_scalars + i, V[i - 1], Vn);
@@ -2068,7 +2075,7 @@ static double fgmres_core(gmg_solver &S, int64_t n, int64_t nv, const double *db
       hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, g[i - 1], Z[i - 1], dx);
       HIP_CHECK(hipGetLastError());
     }
-    ops.resid(dx, db, V[0]);                             // :194
+    residual(V[0]);                                      // :194
   }
   return beta;
 }
@@ -3192,7 +3199,17 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
 int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m0, int restart, int m_add,
                      int maxiter, double atol, double rtol, int use_precond, gmg_result *res, double *hist, int hist_cap)
 {
+  return gmg_fgmres_solve_pl(h, b, x, memspace, m0, restart, m_add, maxiter, atol, rtol, use_precond, 0, res, hist, hist_cap);
+}
+
+int gmg_fgmres_solve_pl(gmg_handle_t h, const double *b, double *x, int memspace, int m0, int restart, int m_add,
+                        int maxiter, double atol, double rtol, int use_precond, int use_precond_left, gmg_result *res,
+                        double *hist, int hist_cap)
+{
   return guarded(h, [&] {
+    REQUIRE(use_precond_left >= 0 && use_precond_left <= 3, GMG_ERR_INVALID, "use_precond_left must be 0, 1, 2 or 3");
+    REQUIRE(!(use_precond == 1 && use_precond_left == 1), GMG_ERR_UNSUPPORTED,
+            "one handle holds one GMG: it can be Pr or Pl, not both (its work vectors are in use)");
     check_ready(h);
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(m0 >= 1 && m_add >= 1 && maxiter >= 0, GMG_ERR_INVALID, "bad FGMRES sizes");
@@ -3209,6 +3226,10 @@ int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace, i
     ConvLog log;
     log.configure(maxiter, atol, rtol);
     KrylovOps ops = S.level0_ops(use_precond);
+    if (use_precond_left) {
+      ops.zl = S.scratch_vec(4, nv);
+      ops.precond_left = [&S, use_precond_left](double *z, const double *r) { S.krylov_precond(use_precond_left, z, r, -1.0); };
+    }
     const double beta = fgmres_core(S, n, nv, db, dx, S.fg_V, S.fg_Z, ops, m0, restart != 0, m_add, log);
     S.out_vec(x, dx, n, memspace);
     log.export_to(res, hist, hist_cap, beta);              // :197

@@ -209,8 +209,11 @@ class FGMRESSolver:
 
     def __init__(self, m, Pr, Pl=None, restart=False, m_add=1, maxiter=100, atol=1e-12, rtol=1.0e-6,
                  verbose=False, name="FGMRES"):
-        if Pl is not None:
-            raise NotImplementedError("left preconditioner of FGMRES is not on the device path")
+        # Pl (KrylovUtils.jl:14-18,46-50): None | JacobiLinearSolver() | LinearSolverFromSmoother(finest pre-smoother) on the
+        # matrix of Pr's handle; the GMG itself serves on one side only
+        if Pl is not None and not isinstance(Pl, (JacobiLinearSolver, LinearSolverFromSmoother)):
+            raise NotImplementedError("FGMRES Pl on the device: JacobiLinearSolver() or LinearSolverFromSmoother(...)")
+        self.Pl = Pl
         self.m, self.Pr, self.restart, self.m_add = int(m), Pr, bool(restart), int(m_add)
         self.log = ConvergenceLog(name, maxiter, atol, rtol)
 
@@ -787,9 +790,11 @@ def solve_(x, ns, b):
             abi.check(g.h, g._lib.gmg_richardson_solve(g.h, pb, px, ms, s.omega, log.maxiter, log.atol, log.rtol, ns.pc_kind,
                                                        C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
         else:
-            abi.check(g.h, g._lib.gmg_fgmres_solve(g.h, pb, px, ms, s.m, int(s.restart), s.m_add, log.maxiter,
-                                                   log.atol, log.rtol, ns.pc_kind, C.byref(res),
-                                                   C.c_void_p(hist.ctypes.data), hist.size))
+            pl = getattr(s, "Pl", None)
+            pl_kind = 0 if pl is None else (2 if isinstance(pl, JacobiLinearSolver) else 3)
+            abi.check(g.h, g._lib.gmg_fgmres_solve_pl(g.h, pb, px, ms, s.m, int(s.restart), s.m_add, log.maxiter,
+                                                      log.atol, log.rtol, ns.pc_kind, pl_kind, C.byref(res),
+                                                      C.c_void_p(hist.ctypes.data), hist.size))
         log._fill(res, hist)
         if ns.pc_kind == 1:
             g.fill_log()

@@ -209,6 +209,12 @@ GMG_API int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspac
 GMG_API int gmg_fgmres_solve(gmg_handle_t h, const double *b, double *x, int memspace,
                              int m, int restart, int m_add, int maxiter, double atol, double rtol,
                              int use_precond, gmg_result *res, double *hist, int hist_cap);
+/* The same with a LEFT preconditioner as well (FGMRESSolver(m,Pr;Pl=...), FGMRESSolvers.jl:26-30; krylov_mul! / krylov_residual!
+ * with Pl, KrylovUtils.jl:14-18,46-50): use_precond_left takes the values of use_precond; the handle's GMG can serve on one
+ * side only. */
+GMG_API int gmg_fgmres_solve_pl(gmg_handle_t h, const double *b, double *x, int memspace,
+                                int m, int restart, int m_add, int maxiter, double atol, double rtol,
+                                int use_precond, int use_precond_left, gmg_result *res, double *hist, int hist_cap);
 /* solve!(x,ns::RichardsonLinearNumericalSetup,b): RichardsonLinearSolvers.jl:79-106, scalar omega;
  * use_precond as in gmg_cg_solve (Pl = nothing / this GMG / Jacobi / the finest pre-smoother). */
 GMG_API int gmg_richardson_solve(gmg_handle_t h, const double *b, double *x, int memspace, double omega,

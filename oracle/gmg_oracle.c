@@ -822,11 +822,22 @@ ORC_API void orc_givens(double f, double g, double *out3) { givens_algorithm(f, 
 /* A8: solve!(x,ns::FGMRESNumericalSetup,b): FGMRESSolvers.jl:130-199  */
 /* Pl = nothing ; Pr = GMG (or NULL = identity: solve!(wr,Pr,x) ~ copy) */
 /* ------------------------------------------------------------------ */
+ORC_API int orc_fgmres_solve_pl(i64 n, const i64 *ptr, const i32 *idx, const double *val, int pc_kind, void *Pr,
+                                int pl_kind, void *Pl, double *x, const double *b, int m0, int restart, int m_add,
+                                int maxiter, double atol, double rtol, int *niters, double *hist);
 ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double *val, int pc_kind, void *Pr,
                              double *x, const double *b, int m0, int restart, int m_add,
                              int maxiter, double atol, double rtol, int *niters, double *hist)
 {
+  return orc_fgmres_solve_pl(n, ptr, idx, val, pc_kind, Pr, ORC_PC_NONE, NULL, x, b, m0, restart, m_add, maxiter, atol, rtol, niters, hist);
+}
+/* Pl != nothing: krylov_residual!(r,x,A,b,Pl,w) KrylovUtils.jl:46-50 and krylov_mul!(y,A,x,Pr,Pl,wr,wl) :14-18 */
+ORC_API int orc_fgmres_solve_pl(i64 n, const i64 *ptr, const i32 *idx, const double *val, int pc_kind, void *Pr,
+                                int pl_kind, void *Pl, double *x, const double *b, int m0, int restart, int m_add,
+                                int maxiter, double atol, double rtol, int *niters, double *hist)
+{
   int m = m0;
+  double *zl = dalloc(n);                                   /* :66 zl cache */
   /* caches :58-70 ; growable :77-94 */
   double **V = (double **)calloc((size_t)m + 1, sizeof(double *));
   double **Z = (double **)calloc((size_t)m, sizeof(double *));
@@ -844,8 +855,14 @@ ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double
 
   for (i64 i = 0; i < n; ++i) V[0][i] = 0.0;                /* :136 */
   /* krylov_residual!(V[1],x,A,b,nothing,zl): KrylovUtils.jl:51-54 */
-  orc_spmv(n, ptr, idx, val, x, V[0]);
-  for (i64 i = 0; i < n; ++i) V[0][i] = b[i] - V[0][i];     /* :140 */
+  if (pl_kind == ORC_PC_NONE) {
+    orc_spmv(n, ptr, idx, val, x, V[0]);
+    for (i64 i = 0; i < n; ++i) V[0][i] = b[i] - V[0][i];   /* :140 */
+  } else {
+    orc_spmv(n, ptr, idx, val, x, zl);
+    for (i64 i = 0; i < n; ++i) zl[i] = b[i] - zl[i];
+    pc_solve(pl_kind, Pl, n, V[0], zl);
+  }
   double beta = orc_norm(n, V[0]);                          /* :141 */
   int done = log_init(&log, beta);                          /* :142 */
   while (!done) {
@@ -867,7 +884,8 @@ ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double
       for (i64 i = 0; i < n; ++i) Zj[i] = 0.0;              /* :158 */
       /* krylov_mul!(V[j+1],A,V[j],Pr,nothing,Z[j],zl): KrylovUtils.jl:22-25 */
       pc_solve(pc_kind, Pr, n, Zj, V[j - 1]);
-      orc_spmv(n, ptr, idx, val, Zj, Vn);                   /* :159 */
+      if (pl_kind == ORC_PC_NONE) orc_spmv(n, ptr, idx, val, Zj, Vn);   /* :159 */
+      else { orc_spmv(n, ptr, idx, val, Zj, zl); pc_solve(pl_kind, Pl, n, Vn, zl); }
       for (int i = 1; i <= j; ++i) {                        /* :160-163 MGS */
         double h = orc_dot(n, Vn, V[i - 1]);
         HH(i, j) = h;
@@ -896,8 +914,14 @@ ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double
     }
     for (int i = 1; i <= j; ++i)                            /* :191-193 */
       for (i64 k = 0; k < n; ++k) x[k] += g[i - 1] * Z[i - 1][k];
-    orc_spmv(n, ptr, idx, val, x, V[0]);                    /* :194 krylov_residual! */
-    for (i64 i = 0; i < n; ++i) V[0][i] = b[i] - V[0][i];
+    if (pl_kind == ORC_PC_NONE) {
+      orc_spmv(n, ptr, idx, val, x, V[0]);                  /* :194 krylov_residual! */
+      for (i64 i = 0; i < n; ++i) V[0][i] = b[i] - V[0][i];
+    } else {
+      orc_spmv(n, ptr, idx, val, x, zl);
+      for (i64 i = 0; i < n; ++i) zl[i] = b[i] - zl[i];
+      pc_solve(pl_kind, Pl, n, V[0], zl);
+    }
   }
 #undef HH
   int flag = log_finalize(&log, beta);                      /* :197 */
@@ -905,7 +929,7 @@ ORC_API int orc_fgmres_solve(i64 n, const i64 *ptr, const i32 *idx, const double
   if (hist) memcpy(hist, log.residuals, (size_t)(log.num_iters + 1) * sizeof(double));
   for (int i = 0; i <= m; ++i) free(V[i]);
   for (int i = 0; i < m; ++i) free(Z[i]);
-  free(V); free(Z); free(H); free(g); free(c); free(s); free(log.residuals);
+  free(V); free(Z); free(H); free(g); free(c); free(s); free(log.residuals); free(zl);
   return flag;
 }
 

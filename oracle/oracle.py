@@ -295,18 +295,21 @@ def cg_solve(A, b, Pl=None, x0=None, maxiter=1000, atol=1e-12, rtol=1e-6, flexib
     return x, nit.value, flag, hist[: nit.value + 1].copy()
 
 
-def fgmres_solve(A, b, Pr=None, x0=None, m=5, restart=False, m_add=1, maxiter=100, atol=1e-12, rtol=1e-6):
-    """solve!(x, FGMRESNumericalSetup, b) -- returns (x, niters, flag, hist)."""
+def fgmres_solve(A, b, Pr=None, x0=None, m=5, restart=False, m_add=1, maxiter=100, atol=1e-12, rtol=1e-6, Pl=None):
+    """solve!(x, FGMRESNumericalSetup, b) -- returns (x, niters, flag, hist).  Pl: optional left preconditioner (KrylovUtils.jl:14-18,46-50)."""
     n = A.shape[0]
     x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     hist = np.zeros(maxiter + 1)
     nit = C.c_int(0)
     kind, pc, _keep = _pc(A, Pr)
-    flag = lib().orc_fgmres_solve(C.c_int64(n), _p64(A.ptr), _p32(A.idx), _d(A.val),
-                                  C.c_int(kind), pc, _d(x), _d(b), C.c_int(m),
-                                  C.c_int(int(restart)), C.c_int(m_add), C.c_int(maxiter), C.c_double(atol),
-                                  C.c_double(rtol), C.byref(nit), _d(hist))
+    lkind, lpc, _lkeep = _pc(A, Pl)
+    L = lib()
+    L.orc_fgmres_solve_pl.restype = C.c_int
+    flag = L.orc_fgmres_solve_pl(C.c_int64(n), _p64(A.ptr), _p32(A.idx), _d(A.val),
+                                 C.c_int(kind), pc, C.c_int(lkind), lpc, _d(x), _d(b), C.c_int(m),
+                                 C.c_int(int(restart)), C.c_int(m_add), C.c_int(maxiter), C.c_double(atol),
+                                 C.c_double(rtol), C.byref(nit), _d(hist))
     return x, nit.value, flag, hist[: nit.value + 1].copy()
 
 

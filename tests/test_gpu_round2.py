@@ -515,3 +515,25 @@ def test_value_refresh_is_bitwise_a_fresh_setup(S, po, orc, smoother, monkeypatc
     bc = scaled.matvec(uex); xc = np.zeros_like(bc)
     S.solve_(xc, nsc, bc)
     assert np.max(np.abs(xc - uex)) < 1e-6
+
+
+# ---------------------------------------------------------------- FGMRES with a left preconditioner (KrylovUtils.jl:14-18,46-50)
+@pytest.mark.parametrize("restart", [False, True])
+def test_fgmres_left_preconditioner(S, po, orc, hierarchy, restart):
+    """FGMRESSolver(m, Pr = GMG; Pl = JacobiLinearSolver()): krylov_residual! / krylov_mul! with Pl -- the history is that of
+    the LEFT-preconditioned residual; iteration count, history and solution equal the oracle's."""
+    nc, nlev = (24, 24), 3
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    solver = S.FGMRESSolver(3, make_gmg(S, H), Pl=S.JacobiLinearSolver(), restart=restart, maxiter=30, atol=1e-14, rtol=1e-9)
+    ns = setup(S, solver, H["mats"][0])
+    x = np.zeros_like(b)
+    S.solve_(x, ns, b)
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=g, Pl="jacobi", m=3, restart=restart, maxiter=30, atol=1e-14, rtol=1e-9)
+    assert solver.log.num_iters == nit and solver.log.flag == flag
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6)
+    assert rel_err(x, xo) <= 1e-9
+    # and it differs from the un-left-preconditioned history (the norm is another one)
+    _, _, _, h0 = orc.fgmres_solve(H["mats"][0], b, Pr=g, m=3, restart=restart, maxiter=30, atol=1e-14, rtol=1e-9)
+    assert abs(h0[0] - hist[0]) > 1e-6 * h0[0]

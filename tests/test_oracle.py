@@ -519,3 +519,19 @@ def test_iteration_counts_do_not_depend_on_summation_order(po, orc, case):
     np.testing.assert_allclose(h2, h1, rtol=1e-8)
     assert np.linalg.norm(x1 - x2) <= 1e-10 * np.linalg.norm(x1)
     assert not np.array_equal(h1, h2) or n1 == 0             # the two builds really sum differently
+
+
+def test_twin_fgmres_left_preconditioner(po, orc):
+    """Pl != nothing (KrylovUtils.jl:14-18,46-50): oracle vs a scipy-free restatement through the numpy twin on the
+    explicitly left-preconditioned system  (D^-1 A) x = D^-1 b."""
+    import scipy.sparse as sp
+    T = _twin()
+    nc = (12, 12)
+    A = po.poisson_matrix(nc, 1); As = A.to_scipy().tocsr()
+    b = _seed(A.shape[0], 2)
+    dinv = 1.0 / As.diagonal()
+    xo, nit, flag, hist = orc.fgmres_solve(A, b, Pr=None, Pl="jacobi", m=4, restart=True, maxiter=60, atol=1e-14, rtol=1e-10)
+    xt, nt, ht = T.fgmres(sp.diags(dinv) @ As, dinv * b, Pr=None, m=4, restart=True, maxiter=60, atol=1e-14, rtol=1e-10)
+    assert nit == nt
+    np.testing.assert_allclose(hist, ht, rtol=1e-6, atol=1e-15 * hist[0])
+    assert np.linalg.norm(xo - xt) <= 1e-8 * np.linalg.norm(xt)
