@@ -880,6 +880,31 @@ struct gmg_solver {
     }
     P.rows_seen = row0 + nr;
   }
+  // gmg_set_matrix / _prolongation / _restriction on a big CSR operator: look at the structure right away, while the caller's
+  // arrays are still borrowed.  When the operator turns out to be a row-pattern operator whose table fits LDS it is kept
+  // in that form ONLY -- no host copy, no CSR upload at setup (the common case of the benchmark hierarchy: 27 distinct
+  // rows).  Anything else (too many patterns, unsorted rows, table too big) returns false and takes the general path.
+  bool try_eager_pattern(std::shared_ptr<PatStream> &out, int mode, int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr,
+                         const void *idx, const double *val, int layout, int base, int bytes)
+  {
+    if (layout != GMG_CSR || comm.nranks != 1 || nrows < env_int("GMG_EAGER_MIN_ROWS", 100000) || !env_int("GMG_EAGER", 1)) return false;
+    if (!env_int("GMG_PATTERN", 1) || !env_int("GMG_SELL", 1) || !ptr || !idx || !val) return false;
+    if (ncols >= (int64_t)(1 << 28) || nnz <= 0) return false;
+    if (read_index(ptr, 0, bytes) != base || read_index(ptr, nrows, bytes) - base != nnz) return false;   // general path reports it
+    auto S = std::make_shared<PatStream>();
+    S->mode = mode; S->nrows = nrows; S->ncols = ncols;
+    try {
+      stream_append(*S, 0, nrows, ptr, idx, val, base, bytes);
+    } catch (const GmgError &) {
+      return false;
+    }
+    const int un = 9;                                        // table stride granularity of the default pattern kernel
+    const int64_t W = (std::max<int64_t>(S->wmax, 1) + un - 1) / un * un;
+    const bool generic = (int64_t)(S->len.size() + 1) * (12 * W + 4) <= 48 * 1024;
+    if (!generic) return false;                              // wide / many patterns: let the general path pick the layout
+    out = S;
+    return true;
+  }
   // device form of a completed stream (the counterpart of upload_csr)
   DevCSR finish_stream(PatStream &P, const char *what)
   {
@@ -2922,8 +2947,13 @@ int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_
   return guarded(h, [&] {
     check_level(h, lev, false);
     REQUIRE(nrows == ncols || h->comm.nranks > 1, GMG_ERR_INVALID, "level matrix must be square");
-    h->lev[lev].hA = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
-    h->lev[lev].hasA = true; h->lev[lev].sA.reset();
+    Level &L = h->lev[lev];
+    L.sA.reset();
+    if (lev < h->nlev - 1 && h->try_eager_pattern(L.sA, 0, nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes)) {
+      L.hA = HostCSR(); L.hA.nrows = nrows; L.hA.ncols = ncols;     // shape only
+    } else
+    L.hA = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    L.hasA = true;
     h->touch();
   });
 }
@@ -2964,7 +2994,7 @@ int gmg_update_values(gmg_handle_t h, int lev, const double *val)
     check_level(h, lev, false);
     Level &L = h->lev[lev];
     REQUIRE(L.hasA, GMG_ERR_STATE, "no matrix set on this level");
-    REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "streamed operators are refreshed by streaming them again");
+    REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "this level is held in row-pattern form only (no CSR copy): pass the new matrix whole (gmg_set_matrix) or stream it again");
     REQUIRE(val, GMG_ERR_INVALID, "null values");
     // values are given in the 0-based CSR order held by the handle
     std::memcpy(L.hA.val.data(), val, sizeof(double) * (size_t)L.hA.nnz());
@@ -2978,8 +3008,11 @@ int gmg_set_prolongation(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, 
 {
   return guarded(h, [&] {
     check_level(h, lev, true);
-    h->lev[lev].hP = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
-    h->lev[lev].hasP = true; h->lev[lev].sP.reset();
+    Level &L = h->lev[lev];
+    L.sP.reset();
+    // (no eager pattern form for P: R = P^T may have to be formed from its CSR copy at setup; P is the small operator anyway)
+    L.hP = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    L.hasP = true;
     h->touch();
   });
 }
@@ -2989,8 +3022,13 @@ int gmg_set_restriction(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, i
 {
   return guarded(h, [&] {
     check_level(h, lev, true);
-    h->lev[lev].hR = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
-    h->lev[lev].hasR = true; h->lev[lev].sR.reset();
+    Level &L = h->lev[lev];
+    L.sR.reset();
+    if (h->try_eager_pattern(L.sR, 1, nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes)) {
+      L.hR = HostCSR(); L.hR.nrows = nrows; L.hR.ncols = ncols;
+    } else
+    L.hR = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    L.hasR = true;
     h->touch();
   });
 }

@@ -327,7 +327,10 @@ def _set_op(fn, h, lev, M):
         return
     shape, ptr, idx, val, layout, base = _csr_fields(M)
     if ptr.dtype != idx.dtype:
-        ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
+        if idx.dtype == np.int32 and val.size < 2 ** 31 - 1:   # narrow the (short) pointer array instead of widening the index array
+            ptr = ptr.astype(np.int32)
+        else:
+            ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
     if ptr.dtype not in (np.int32, np.int64):
         raise TypeError("index arrays must be int32 or int64")
     nnz = int(val.size)
@@ -447,7 +450,11 @@ class GMGNumericalSetup:
             shape, ptr, idx, val, layout, base = _csr_fields(M)
             if layout != abi.CSR:
                 raise NotImplementedError("numerical_setup! needs CSR values in the handle's order")
-            abi.check(self.h, self._lib.gmg_update_values(self.h, l, C.c_void_p(val.ctypes.data)))
+            st = self._lib.gmg_update_values(self.h, l, C.c_void_p(val.ctypes.data))
+            if st == abi.ERR_UNSUPPORTED:       # level held in row-pattern form only: hand the whole matrix over again
+                _set_op(self._lib.gmg_set_matrix, self.h, l, M)
+            else:
+                abi.check(self.h, st)
         abi.check(self.h, self._lib.gmg_setup(self.h))
         return self
 
@@ -552,7 +559,10 @@ class GMGNumericalSetup:
 def _set_block(fn, h, i, j, M):
     shape, ptr, idx, val, layout, base = _csr_fields(M)
     if ptr.dtype != idx.dtype:
-        ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
+        if idx.dtype == np.int32 and val.size < 2 ** 31 - 1:   # narrow the (short) pointer array instead of widening the index array
+            ptr = ptr.astype(np.int32)
+        else:
+            ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
     abi.check_block(h, fn(h, i, j, shape[0], shape[1], int(val.size), C.c_void_p(ptr.ctypes.data),
                           C.c_void_p(idx.ctypes.data), C.c_void_p(val.ctypes.data), layout, base, ptr.dtype.itemsize))
 

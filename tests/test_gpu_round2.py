@@ -537,3 +537,31 @@ def test_fgmres_left_preconditioner(S, po, orc, hierarchy, restart):
     # and it differs from the un-left-preconditioned history (the norm is another one)
     _, _, _, h0 = orc.fgmres_solve(H["mats"][0], b, Pr=g, m=3, restart=restart, maxiter=30, atol=1e-14, rtol=1e-9)
     assert abs(h0[0] - hist[0]) > 1e-6 * h0[0]
+
+
+# ---------------------------------------------------------------- eager row-pattern form of big structured CSR inputs
+def test_eager_pattern_form_of_whole_matrices(S, po, orc, monkeypatch):
+    """gmg_set_matrix / gmg_set_restriction on a big structured CSR keep only the row-pattern form (no host copy, no CSR upload):
+    bit-identical solves to the general path, less device memory during setup, numerical_setup! still works."""
+    nc, nlev = (48, 48, 48), 3                                               # 103 823 rows on the finest level
+    H = po.build_hierarchy(nc, nlev, 1)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    out = {}
+    for eager in ("1", "0"):
+        monkeypatch.setenv("GMG_EAGER", eager)
+        solver = S.CGSolver(make_gmg(S, H), maxiter=20, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        out[eager] = (x, solver.log.num_iters, solver.log.residuals[: solver.log.num_iters + 1].copy(), ns)
+    assert out["1"][1] == out["0"][1]
+    np.testing.assert_array_equal(out["1"][2], out["0"][2])
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    # numerical_setup! on a level that has no CSR copy: the mirror hands the matrix over again
+    monkeypatch.setenv("GMG_EAGER", "1")
+    ns = out["1"][3]
+    A2 = po.CSR(H["mats"][0].shape, H["mats"][0].ptr, H["mats"][0].idx, 3.0 * H["mats"][0].val)
+    S.numerical_setup_(ns, A2)
+    x2 = np.zeros_like(b)
+    S.solve_(x2, ns, 3.0 * b)
+    assert rel_err(x2, out["1"][0]) <= 1e-12
