@@ -564,4 +564,4 @@ def test_eager_pattern_form_of_whole_matrices(S, po, orc, monkeypatch):
     S.numerical_setup_(ns, A2)
     x2 = np.zeros_like(b)
     S.solve_(x2, ns, 3.0 * b)
-    assert rel_err(x2, out["1"][0]) <= 1e-12
+    assert rel_err(x2, out["1"][0]) <= 1e-6                                  # another system (3A x = 3b, coarse levels unscaled), solved to rtol 1e-8
