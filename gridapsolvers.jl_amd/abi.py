@@ -52,6 +52,8 @@ SYMBOLS = {
                                         C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "gmg_set_prolongation_patch_correction": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int],
+    "gmg_set_prolongation_patch_correction_rhs": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_int, C.c_int, C.c_int],
     "gmg_set_coarse_solver": [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     "gmg_get_coarse_log": [C.c_void_p, C.POINTER(Result)],
     "gmg_set_options": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double],

@@ -282,6 +282,9 @@ struct Level {
   Smoother pre, post;
   Smoother pcorr;                 // patch tables of a patch-corrected prolongation (kind == SM_PATCH when set)
   bool has_pcorr = false;
+  HostCSR hG;                     // rhs form of the correction when it is not the level operator (StokesGMG.jl:125-127: graddiv)
+  bool hasG = false;
+  DevCSR G;
   double *ptmp = nullptr, *pcor = nullptr;
   bool post_shares_pre = true;
   int64_t n = 0;                  // owned rows
@@ -550,7 +553,7 @@ struct gmg_solver {
     allocs.clear();
     dev_bytes = 0;
     for (auto &L : lev) {
-      L.A = DevCSR(); L.P = DevCSR(); L.R = DevCSR();
+      L.A = DevCSR(); L.P = DevCSR(); L.R = DevCSR(); L.G = DevCSR();
       L.dinv = L.x = L.dx = L.rcur = nullptr;
       L.rbuf[0] = L.rbuf[1] = nullptr;
       L.ptmp = L.pcor = nullptr; L.pcorr.built = false;
@@ -1747,7 +1750,8 @@ struct gmg_solver {
       if (L.has_pcorr) {
         // PatchProlongationOperator: dxh = P dxH - sum_p A_pp^-1 (A P dxH)_p  (PatchTransferOperators.jl:153-172)
         spmv_set(L.P, C.x, L.dx);
-        apply_A_set(l, L.dx, L.ptmp);
+        if (L.hasG) spmv_set(L.G, L.dx, L.ptmp);           // rhs(uH,v_i) with the caller's rhs form
+        else apply_A_set(l, L.dx, L.ptmp);
         patch_precond(L, L.pcorr, L.ptmp, 1.0, false, L.pcor, nullptr);
         hipLaunchKernelGGL(prolong_correct_kernel, dim3(grid_for(L.n)), dim3(256), 0, stream, L.n, L.pcor, L.dx, x);
         HIP_CHECK(hipGetLastError());
@@ -2721,6 +2725,11 @@ void gmg_solver::setup()
       if (L.has_pcorr) {
         REQUIRE(comm.nranks == 1, GMG_ERR_UNSUPPORTED, "patch-corrected prolongation is single-GPU in this round");
         build_patch(L, L.pcorr);
+        if (L.hasG) {
+          REQUIRE(L.hG.nrows == L.n && L.hG.ncols == L.n, GMG_ERR_INVALID, "rhs operator of the prolongation correction has the wrong shape");
+          L.G = upload_csr(L.hG);
+          drop_csr_stream(L.G);
+        }
         L.ptmp = dvec(L.nvec); L.pcor = dvec(L.nvec);
       }
       if (L.pre.kind == SM_PATCH) build_patch(L, L.pre);
@@ -3125,6 +3134,17 @@ int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int kind, int
     Smoother S = make_patch_smoother(0, 1.0, kind, npatch, patch_ptr, patch_dofs, nullptr, index_base, index_bytes);
     h->lev[lev].pcorr = S;
     h->lev[lev].has_pcorr = true;
+    h->touch();
+  });
+}
+
+int gmg_set_prolongation_patch_correction_rhs(gmg_handle_t h, int lev, int64_t n, int64_t nnz, const void *ptr, const void *idx,
+                                              const double *val, int layout, int index_base, int index_bytes)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    h->lev[lev].hG = convert_input(n, n, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    h->lev[lev].hasG = true;
     h->touch();
   });
 }

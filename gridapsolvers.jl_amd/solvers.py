@@ -91,8 +91,10 @@ class PatchProlongationOperator:
     """PatchProlongationOperator (PatchTransferOperators.jl:2-60,153-172) reduced to what its mul! needs: the
     plain prolongation matrix P and the patch dof tables; y = P x - sum_p A_pp^-1 (A P x)_p."""
 
-    def __init__(self, P, patch_ptr, patch_dofs, pivoting=True):
+    def __init__(self, P, patch_ptr, patch_dofs, pivoting=True, rhs=None):
+        """rhs: assembled rhs form of the local problems when it is not the level operator (StokesGMG.jl:125-127 passes graddiv)."""
         self.P = P
+        self.rhs = rhs
         self.patch_ptr = np.ascontiguousarray(patch_ptr, dtype=np.int64)
         self.patch_dofs = np.ascontiguousarray(patch_dofs, dtype=np.int64)
         self.kind = abi.PATCH_LU if pivoting else abi.PATCH_NOPIVOT
@@ -388,6 +390,13 @@ class GMGNumericalSetup:
                 abi.check(h, lib.gmg_set_prolongation_patch_correction(
                     h, l, ip.kind, ip.patch_ptr.size - 1, C.c_void_p(ip.patch_ptr.ctypes.data),
                     C.c_void_p(ip.patch_dofs.ctypes.data), 0, 8))
+                if ip.rhs is not None:
+                    shape, ptr, idx, val, layout, base = _csr_fields(ip.rhs)
+                    if ptr.dtype != idx.dtype:
+                        ptr = ptr.astype(np.int64); idx = idx.astype(np.int64)
+                    abi.check(h, lib.gmg_set_prolongation_patch_correction_rhs(
+                        h, l, shape[0], int(val.size), C.c_void_p(ptr.ctypes.data), C.c_void_p(idx.ctypes.data),
+                        C.c_void_p(val.ctypes.data), layout, base, ptr.dtype.itemsize))
             else:
                 _set_op(lib.gmg_set_prolongation, h, l, ip)
             if s.restrict[l] is not None:

@@ -157,6 +157,14 @@ GMG_API int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int k
                                                   const void *patch_ptr, const void *patch_dofs,
                                                   int index_base, int index_bytes);
 
+/* rhs form of that correction when it differs from the level operator: PatchProlongationOperator(lev,sh,ptopo,lhs,rhs)
+ * solves lhs(u_i,v_i) = rhs(uH,v_i) (PatchTransferOperators.jl:30-50); the Stokes application passes lhs = the velocity
+ * form and rhs = the grad-div term only (test/Applications/StokesGMG.jl:125-127).  G = the assembled rhs form on level lev
+ * (square, same format options as gmg_set_matrix); lhs patch blocks: A[p,p], or the caller's via the patch tables. */
+GMG_API int gmg_set_prolongation_patch_correction_rhs(gmg_handle_t h, int lev, int64_t n, int64_t nnz, const void *ptr,
+                                                      const void *idx, const double *val, int layout, int index_base,
+                                                      int index_bytes);
+
 /* ---- coarsest solver ---------------------------------------------------------- */
 /* kwarg `coarsest_solver` (GMGLinearSolvers.jl:54; cache :423-434; applied at :474).  The reference accepts any LinearSolver:
  * default LUSolver(); its MPI tests / applications pass iterative or PETSc solvers (joss_paper/scalability/src/stokes_gmg.jl:41-63). */

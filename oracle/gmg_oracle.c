@@ -469,6 +469,8 @@ typedef struct {
   int post_is_pre;
   orc_smoother pcorr;   /* patch tables + LU factors of the patch-corrected prolongation */
   int has_pcorr;
+  orc_csr G;            /* rhs form of the correction (PatchTransferOperators.jl:30-50); has_G = 0: the level operator */
+  int has_G;
   double *ptmp, *pcor;
   /* work vectors GMGLinearSolvers.jl:451-466 + smoother caches RichardsonSmoothers.jl:58-63 */
   double *dxh, *Adxh, *dxH, *rH, *sm_dx, *sm_Adx;
@@ -552,6 +554,12 @@ ORC_API void orc_gmg_set_prolongation_correction(orc_gmg *g, int l, int kind, i6
 
 static double *dalloc(i64 n) { return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
 
+ORC_API void orc_gmg_set_prolongation_correction_rhs(orc_gmg *g, int l, i64 n, const i64 *ptr, const i32 *idx, const double *val)
+{
+  g->lev[l].G = (orc_csr){ n, n, ptr, idx, val };
+  g->lev[l].has_G = 1;
+}
+
 ORC_API void orc_gmg_set_coarse_cg(orc_gmg *g, int maxiter, double atol, double rtol)
 {
   g->coarse_cg = 1; g->coarse_maxiter = maxiter; g->coarse_atol = atol; g->coarse_rtol = rtol;
@@ -610,7 +618,8 @@ static void apply_prolongation(orc_level *L, const double *dxH, double *dxh)
 {
   orc_spmv(L->P.n, L->P.ptr, L->P.idx, L->P.val, dxH, dxh);
   if (!L->has_pcorr) return;
-  orc_spmv(L->A.n, L->A.ptr, L->A.idx, L->A.val, dxh, L->ptmp);
+  if (L->has_G) orc_spmv(L->G.n, L->G.ptr, L->G.idx, L->G.val, dxh, L->ptmp);
+  else orc_spmv(L->A.n, L->A.ptr, L->A.idx, L->A.val, dxh, L->ptmp);
   precond_apply(&L->pcorr, &L->A, L->pcor, L->ptmp);
   for (i64 i = 0; i < L->A.n; ++i) dxh[i] = dxh[i] - L->pcor[i];
 }

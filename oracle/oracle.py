@@ -150,7 +150,10 @@ class GMG:
             self._keep.append(prolongation_patches)
             for l, pc in enumerate(prolongation_patches):
                 if pc is not None:
-                    kind, pp, pd = pc
+                    G = pc[3] if len(pc) > 3 else None
+                    kind, pp, pd = pc[:3]
+                    if G is not None:       # rhs form of the correction differs from the level operator
+                        L.orc_gmg_set_prolongation_correction_rhs(self.h, C.c_int(l), C.c_int64(G.shape[0]), _p64(G.ptr), _p32(G.idx), _d(G.val))
                     pp = np.ascontiguousarray(pp, dtype=np.int64); pd = np.ascontiguousarray(pd, dtype=np.int32)
                     self._keep += [pp, pd]
                     L.orc_gmg_set_prolongation_correction(self.h, C.c_int(l), C.c_int(kind), C.c_int64(len(pp) - 1),

@@ -205,3 +205,62 @@ def test_block_error_behaviour(S, po, hierarchy, pkg):
     S.solve_(x, gns, np.ones_like(x))
     assert np.isfinite(x).all() and np.abs(x).max() > 0
     gns.close()
+
+
+# ---------------------------------------------------------------- real Stokes inputs: Q2 / discontinuous P1, grad-div augmented
+def _real_stokes(S, po, orc, n, nlev, alpha=1.0e3):
+    """test/Applications/StokesGMG.jl:79-166 on synthesised inputs (gridapsolvers.jl_amd/stokes.py): lid-driven cavity,
+    Q2 x P1disc, a_u = grad:grad + alpha (div v) Pi_Qh(div u); velocity GMG with vertex-star patch smoothers
+    Richardson(PatchSolver,10,0.2), patch prolongation with rhs = graddiv, LU coarsest, maxiter=4; pressure block
+    -1/alpha M_p by CG-Jacobi; upper block-triangular preconditioner, FGMRES(20; atol=1e-10, rtol=1e-12)."""
+    from gridapsolvers_jl_amd import stokes as st
+    sysd = st.stokes_system(n, alpha)
+    Hv = st.velocity_hierarchy(n, nlev, alpha)
+    sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2) for pp, pd in Hv["star_patches"]]
+    interp = [S.PatchProlongationOperator(Hv["prolongations"][l], *Hv["interior_patches"][l], pivoting=True, rhs=Hv["graddiv"][l])
+              for l in range(nlev - 1)]
+    gmg = S.GMGLinearSolver(Hv["mats"], interp, Hv["restrictions"], pre_smoothers=sm, post_smoothers=sm,
+                            coarsest_solver=S.LUSolver(), maxiter=4, mode="preconditioner")
+    solver_p = S.CGSolver(S.JacobiLinearSolver(), maxiter=20, atol=1e-14, rtol=1e-6)
+    blocks = [[S.LinearSystemBlock(), S.LinearSystemBlock()], [S.LinearSystemBlock(), S.MatrixBlock(sysd["Mp_scaled"])]]
+    Pd = S.BlockTriangularSolver(blocks, [gmg, solver_p], coeffs=[[1.0, 1.0], [0.0, 1.0]], half="upper")
+    osm = [orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in Hv["star_patches"]]
+    go = orc.GMG(Hv["mats"], Hv["prolongations"], Hv["restrictions"], pre_smoothers=osm, maxiter=4, rtol=1e-8,
+                 prolongation_patches=[(orc.PATCH, *Hv["interior_patches"][l], Hv["graddiv"][l]) for l in range(nlev - 1)])
+    nu, npp = sysd["sizes"]
+    Po = orc.BlockPreconditioner([nu, npp], [go, (orc.BD_CG_JACOBI, sysd["Mp_scaled"], 20, 1e-14, 1e-6)],
+                                 {(0, 1): (sysd["A"][0][1], 1.0), (1, 0): (sysd["A"][1][0], 0.0)}, orc.UPPER)
+    return sysd, Hv, gmg, solver_p, Pd, Po, go
+
+
+@pytest.mark.parametrize("n,nlev", [(8, 2), (16, 3)])
+def test_real_stokes_q2_p1disc_block_triangular_fgmres(S, po, orc, n, nlev):
+    sysd, Hv, gmg, solver_p, Pd, Po, go = _real_stokes(S, po, orc, n, nlev)
+    b = sysd["b"]
+    N = b.size
+    # (1) the velocity GMG alone (patch smoothers + patch prolongation with the grad-div rhs) vs the oracle
+    nsg = setup(S, gmg, Hv["mats"][0])
+    r = np.random.default_rng(2).uniform(-1, 1, sysd["sizes"][0])
+    z = np.zeros_like(r)
+    S.solve_(z, nsg, r)
+    zo, nit_g, _, hist_g = go.solve(r)
+    assert gmg.log.num_iters == nit_g
+    assert rel_err(z, zo) <= 1e-8
+    nsg.close()
+    # (2) the whole solve: FGMRES(20) + upper block-triangular preconditioner
+    sysd, Hv, gmg, solver_p, Pd, Po, go = _real_stokes(S, po, orc, n, nlev)    # fresh (stateful block caches)
+    solver = S.FGMRESSolver(20, Pd, atol=1e-10, rtol=1e-12, maxiter=100)
+    ns = setup(S, solver, sysd["A"])
+    x = np.zeros(N)
+    S.solve_(x, ns, b)
+    Kc = po.CSR(sysd["K"].shape, sysd["K"].indptr, sysd["K"].indices, sysd["K"].data)
+    xo, nit, flag, hist = orc.fgmres_solve(Kc, b, Pr=Po, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+    assert solver.log.num_iters == nit and solver.log.flag == flag
+    assert np.all(np.abs(solver.log.residuals[: nit + 1] - hist) <= 1e-6 * hist[0])
+    assert np.linalg.norm(sysd["K"] @ x - b) < 1e-7                             # StokesGMG.jl:166
+    assert rel_err(x, xo) <= 1e-6
+    # discretely divergence-free velocity, lid velocity visible in the solution
+    nu = sysd["sizes"][0]
+    assert np.linalg.norm(sysd["A"][1][0].to_scipy() @ x[:nu] - b[nu:]) < 1e-7
+    assert x[:nu].max() > 0.3
+    ns.P_ns.close()
