@@ -1440,16 +1440,21 @@ __global__ __launch_bounds__(kBlock) void patch_apply_dedup_kernel(int64_t npatc
                                                                    const double *__restrict__ b,
                                                                    double *__restrict__ contrib)
 {
-  __shared__ double sB[32 * 32];
+  // The chunk's first block is held in REGISTERS, one row per lane (n_p <= 32): the inner product then reads only the
+  // broadcast b_p from LDS -- the LDS pipe, not HBM, bounded the version that kept the block in LDS too.  Rows are summed
+  // k ascending exactly as before.
   __shared__ double sb[8][32];
   const int64_t p0 = (int64_t)blockIdx.x * kPatchChunk;
   const int64_t p1 = min(p0 + (int64_t)kPatchChunk, npatch);
   const int cached = ublock[p0];
   const int64_t co = uboff[cached];
   const int clen = (int)(uboff[cached + 1] - co);
-  for (int k = threadIdx.x; k < clen; k += kBlock) sB[k] = ubinv[co + k];
-  __syncthreads();
+  int cnp = 0;
+  while (cnp * cnp < clen) ++cnp;
   const int hw = threadIdx.x >> 5, lane = threadIdx.x & 31;   // 8 half-waves
+  double row[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) row[k] = (lane < cnp && k < cnp) ? ubinv[co + (int64_t)lane * cnp + k] : 0.0;
   for (int64_t p = p0 + hw; p < p1; p += 8) {
     const int64_t q0 = pptr[p];
     const int np = (int)(pptr[p + 1] - q0);
@@ -1461,11 +1466,12 @@ __global__ __launch_bounds__(kBlock) void patch_apply_dedup_kernel(int64_t npatc
     if (lane < np) {
       double s = 0.0;
       if (ub == cached) {
-        const double *row = sB + lane * np;
-        for (int k = 0; k < np; ++k) s += row[k] * sb[hw][k];
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+          if (k < np) s += row[k] * sb[hw][k];
       } else {
-        const double *row = ubinv + uboff[ub] + (size_t)lane * np;
-        for (int k = 0; k < np; ++k) s += row[k] * sb[hw][k];
+        const double *rowp = ubinv + uboff[ub] + (size_t)lane * np;
+        for (int k = 0; k < np; ++k) s += rowp[k] * sb[hw][k];
       }
       contrib[q0 + lane] = s;
     }
@@ -1523,7 +1529,13 @@ __global__ void patch_gather_sell_kernel(int64_t n, const int64_t *__restrict__ 
   const int w = (int)((soff[slice + 1] - base) >> 6);
   const int32_t *ip = sinc + base + lane;
   double s = 0.0;
-  for (int j = 0; j < w; ++j) s += contrib[ip[(int64_t)j * 64]];
+  int j = 0;
+  for (; j + 4 <= w; j += 4) {                               // four index loads, then four gathers in flight; summed in slot order
+    const int32_t i0 = ip[(int64_t)j * 64], i1 = ip[(int64_t)(j + 1) * 64], i2 = ip[(int64_t)(j + 2) * 64], i3 = ip[(int64_t)(j + 3) * 64];
+    const double c0 = contrib[i0], c1 = contrib[i1], c2 = contrib[i2], c3 = contrib[i3];
+    s += c0; s += c1; s += c2; s += c3;
+  }
+  for (; j < w; ++j) s += contrib[ip[(int64_t)j * 64]];
   if (relax) {
     s = omega * s;
     x[i] = x[i] + s;
