@@ -665,7 +665,9 @@ __device__ __forceinline__ double bcast_lane(double v, int l)
 // 65-K rows.  VD = coded table: one byte per entry indexing a dictionary of <= 255 distinct values (wide rows / many
 // patterns would not fit LDS otherwise: Q2 stiffness = 217 patterns x 125 entries = 27 KB of codes).
 constexpr int kSellsRows = 62;
-template <int EPI, bool ONEG, int RB, int K = 3, bool VD = false>
+// DBG (tools/mb_sells.hip only; the library instantiates DBG = 0): timing ablations that drop one ingredient each --
+// bit0 no high-word mask, bit1 coefficients not read from LDS, bit2 no DPP shifts, bit3 no gathers.  Wrong results by design.
+template <int EPI, bool ONEG, int RB, int K = 3, bool VD = false, int DBG = 0>
 __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 {
   constexpr int ROWS = 65 - K;
@@ -738,6 +740,8 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       for (int q = 0; q < RB; ++q) {
         const int o = a.run_off[r0 + q];                   // uniform: scalar load
         // column index clamped to [0,ncols) (the clamped entries have zero coefficients); uniform base + 32-bit lane offset
+        if (DBG & 8) A[q] = (double)o;
+        else
         A[q] = ld_off(xg, 8u * (uint32_t)min(max((int)row + o, 0), last));
       }
     };
@@ -785,10 +789,10 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
         double cur = A[q];
 #pragma unroll
         for (int t = 0; t < K; ++t) {
-          if (t > 0) cur = wave_shl1(cur);                 // the last K-1 lanes receive junk: they own no row
+          if (t > 0 && !(DBG & 4)) cur = wave_shl1(cur);   // the last K-1 lanes receive junk: they own no row
           const int j = (r0 + q) * K + t;
-          const double g = __hiloint2double(__double2hiint(cur) & (int)tm[j], __double2loint(cur));
-          s = s + tv[j] * g;
+          const double g = (DBG & 1) ? cur : __hiloint2double(__double2hiint(cur) & (int)tm[j], __double2loint(cur));
+          s = s + ((DBG & 2) ? (double)(j + 1) : tv[j]) * g;
         }
       }
       if (r0 + RB < a.nruns) gather(r0 + RB);

@@ -852,8 +852,8 @@ ORC_API int orc_fgmres_solve_pl(i64 n, const i64 *ptr, const i32 *idx, const dou
   double **Z = (double **)calloc((size_t)m, sizeof(double *));
   for (int i = 0; i <= m; ++i) V[i] = dalloc(n);
   for (int i = 0; i < m; ++i) Z[i] = dalloc(n);
-  /* H stored with fixed leading dimension big enough for any growth */
-  int mcap = m + (maxiter + 1) * (m_add > 0 ? m_add : 1) + 1;
+  /* H stored with fixed leading dimension big enough for any growth (with restart the basis never exceeds m0) */
+  int mcap = restart ? m0 + 2 : m + (maxiter + 1) * (m_add > 0 ? m_add : 1) + 1;
   int ldh = mcap + 1;
   double *H = (double *)calloc((size_t)ldh * mcap, sizeof(double));
   double *g = (double *)calloc((size_t)mcap + 1, sizeof(double));
