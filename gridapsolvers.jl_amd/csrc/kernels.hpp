@@ -1444,29 +1444,47 @@ __global__ __launch_bounds__(kBlock) void patch_apply_dedup_kernel(int64_t npatc
                                                                    const double *__restrict__ b,
                                                                    double *__restrict__ contrib)
 {
-  // The chunk's first block is held in REGISTERS, one row per lane (n_p <= 32): the inner product then reads only the
-  // broadcast b_p from LDS -- the LDS pipe, not HBM, bounded the version that kept the block in LDS too.  Rows are summed
-  // k ascending exactly as before.
+  // The chunk's first block is staged in LDS once per workgroup and every lane then keeps ITS ROW in registers (n_p <= 32):
+  // the inner product reads only the broadcast b_p from LDS -- the LDS pipe, not HBM, bounded the version that read the
+  // block row from LDS for every patch.  Rows are summed k ascending exactly as before.
+  __shared__ double sB[32 * 32];
   __shared__ double sb[8][32];
   const int64_t p0 = (int64_t)blockIdx.x * kPatchChunk;
   const int64_t p1 = min(p0 + (int64_t)kPatchChunk, npatch);
   const int cached = ublock[p0];
   const int64_t co = uboff[cached];
   const int clen = (int)(uboff[cached + 1] - co);
+  for (int k = threadIdx.x; k < clen; k += kBlock) sB[k] = ubinv[co + k];
   int cnp = 0;
   while (cnp * cnp < clen) ++cnp;
+  __syncthreads();
   const int hw = threadIdx.x >> 5, lane = threadIdx.x & 31;   // 8 half-waves
   double row[32];
 #pragma unroll
-  for (int k = 0; k < 32; ++k) row[k] = (lane < cnp && k < cnp) ? ubinv[co + (int64_t)lane * cnp + k] : 0.0;
+  for (int k = 0; k < 32; ++k) row[k] = (lane < cnp && k < cnp) ? sB[lane * cnp + k] : 0.0;
+  // software pipeline: the (pdofs -> b) gather of the NEXT patch of this half-wave is in flight while the current one is solved
+  int64_t q0n = 0;
+  int npn = 0, ubn = 0;
+  double bn = 0.0;
+  auto fetch = [&](int64_t p) {
+    q0n = 0; npn = 0; ubn = 0; bn = 0.0;
+    if (p < p1) {
+      q0n = pptr[p];
+      npn = (int)(pptr[p + 1] - q0n);
+      ubn = ublock[p];
+      if (lane < npn) bn = b[pdofs[q0n + lane]];
+    }
+  };
+  fetch(p0 + hw);
   for (int64_t p = p0 + hw; p < p1; p += 8) {
-    const int64_t q0 = pptr[p];
-    const int np = (int)(pptr[p + 1] - q0);
+    const int64_t q0 = q0n;
+    const int np = npn, ub = ubn;
+    const double bcur = bn;
+    fetch(p + 8);
     if (np == 0) continue;
-    if (lane < np) sb[hw][lane] = b[pdofs[q0 + lane]];
+    if (lane < np) sb[hw][lane] = bcur;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int ub = ublock[p];
     if (lane < np) {
       double s = 0.0;
       if (ub == cached) {
