@@ -1444,9 +1444,6 @@ __global__ __launch_bounds__(kBlock) void patch_apply_dedup_kernel(int64_t npatc
                                                                    const double *__restrict__ b,
                                                                    double *__restrict__ contrib)
 {
-  // The chunk's first block is staged in LDS once per workgroup and every lane then keeps ITS ROW in registers (n_p <= 32):
-  // the inner product reads only the broadcast b_p from LDS -- the LDS pipe, not HBM, bounded the version that read the
-  // block row from LDS for every patch.  Rows are summed k ascending exactly as before.
   __shared__ double sB[32 * 32];
   __shared__ double sb[8][32];
   const int64_t p0 = (int64_t)blockIdx.x * kPatchChunk;
@@ -1455,13 +1452,8 @@ __global__ __launch_bounds__(kBlock) void patch_apply_dedup_kernel(int64_t npatc
   const int64_t co = uboff[cached];
   const int clen = (int)(uboff[cached + 1] - co);
   for (int k = threadIdx.x; k < clen; k += kBlock) sB[k] = ubinv[co + k];
-  int cnp = 0;
-  while (cnp * cnp < clen) ++cnp;
   __syncthreads();
   const int hw = threadIdx.x >> 5, lane = threadIdx.x & 31;   // 8 half-waves
-  double row[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) row[k] = (lane < cnp && k < cnp) ? sB[lane * cnp + k] : 0.0;
   // software pipeline: the (pdofs -> b) gather of the NEXT patch of this half-wave is in flight while the current one is solved
   int64_t q0n = 0;
   int npn = 0, ubn = 0;
@@ -1488,9 +1480,8 @@ __global__ __launch_bounds__(kBlock) void patch_apply_dedup_kernel(int64_t npatc
     if (lane < np) {
       double s = 0.0;
       if (ub == cached) {
-#pragma unroll
-        for (int k = 0; k < 32; ++k)
-          if (k < np) s += row[k] * sb[hw][k];
+        const double *rowp = sB + lane * np;
+        for (int k = 0; k < np; ++k) s += rowp[k] * sb[hw][k];
       } else {
         const double *rowp = ubinv + uboff[ub] + (size_t)lane * np;
         for (int k = 0; k < np; ++k) s += rowp[k] * sb[hw][k];
