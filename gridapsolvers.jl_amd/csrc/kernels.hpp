@@ -816,6 +816,106 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------
+// The fused Richardson-Jacobi sweep on the shared-offset table, batched: every wave takes NB slices per iteration --
+// all their row-wise operands and first gathers are requested up front, the taps run slice after slice, all stores go
+// last.  Why: on gfx9 loads and stores share one counter (vmcnt) and return out of order with respect to each other, so
+// a wave that still has stores in flight can only wait for a load with vmcnt(0); the one-slice-per-iteration loop of
+// sells_kernel therefore drained its stores once per slice (four exposed store latencies per wave at 128^3) and its
+// conditional operand loads forced waits at every join.  Here: no divergent or runtime-conditional loads (clamped
+// addresses, XM and TD are template parameters), one drain per NB slices.  Same arithmetic, same order, same bits.
+//   XM = SellSArgs::xmode (0: x += s_k ; 1: x deferred ; 2: x = (x + s_{k-1}) + s_k)   TD: 1/diag from the pattern table
+// Plain (non-coded) table, K = 3, runs in batches of 3 (the 27-point operators).
+// ---------------------------------------------------------------------------
+template <int XM, int NB, bool TD>
+__global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
+{
+  constexpr int K = 3, ROWS = 65 - K, RB = 3;
+  extern __shared__ double sp_smem[];
+  const int nu = K * a.nruns;
+  const int tot = a.np * nu;
+  double *s_val = sp_smem;
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
+  double *s_dinv = reinterpret_cast<double *>(s_msk + tot + (tot & 1));
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
+  if (TD)
+    for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int nwg = gridDim.x;
+  const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
+  const int chunk = (a.nslices + nwg - 1) / nwg;
+  const int s_begin = blk * chunk;
+  const int s_end = min(a.nslices, s_begin + chunk);
+  const double *__restrict__ xg = a.x;
+  const double omega = a.omega;
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  const bool xz = a.x_zero != 0;
+  __syncthreads();
+  for (int sb = s_begin + wave; sb < s_end; sb += wpb * NB) {
+    int pid[NB], row[NB];
+    double e0[NB], e1[NB], e2[NB], sp[NB], dr[NB], A[NB][RB], acc[NB];
+    // ---- phase 1: every load of the batch ----
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int slice = min(sb + i * wpb, s_end - 1);        // a short last batch re-reads its last slice (results unused)
+      row[i] = slice * ROWS + lane;
+      const int rc = min(row[i], lastrow);
+      pid[i] = (int)a.rowpid[rc];
+      e0[i] = a.b[rc];
+      e1[i] = xg[rc];
+      e2[i] = 0.0; sp[i] = 0.0; dr[i] = 0.0;
+      if (XM != 1) { const double xl = a.x2[rc]; e2[i] = xz ? 0.0 : xl; }
+      if (XM == 2) sp[i] = a.s_out[rc];
+      if (!TD) dr[i] = a.dinv[rc];
+#pragma unroll
+      for (int q = 0; q < RB; ++q) A[i][q] = ld_off(xg, 8u * (uint32_t)min(max(row[i] + a.run_off[q], 0), last));
+    }
+    // ---- phase 2: taps, slice after slice (rows summed in ascending column order) ----
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const double *tv = s_val + pid[i] * nu;
+      const uint32_t *tm = s_msk + pid[i] * nu;
+      double s = 0.0;
+      for (int r0 = 0; r0 < a.nruns; r0 += RB) {
+        double cur[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) cur[q] = A[i][q];
+        if (r0 + RB < a.nruns) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) A[i][q] = ld_off(xg, 8u * (uint32_t)min(max(row[i] + a.run_off[r0 + RB + q], 0), last));
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          double c = cur[q];
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) c = wave_shl1(c);                     // the last K-1 lanes receive junk: they own no row
+            const int j = (r0 + q) * K + t;
+            const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
+            s = s + tv[j] * g;
+          }
+        }
+      }
+      acc[i] = s;
+    }
+    // ---- phase 3: every store of the batch ----
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (sb + i * wpb < s_end && lane < ROWS && row[i] <= lastrow) {
+        const int r = row[i];
+        const double dinv_row = TD ? s_dinv[pid[i]] : dr[i];
+        if (XM == 0) a.x2[r] = e2[i] + e1[i];
+        else if (XM == 2) a.x2[r] = (e2[i] + sp[i]) + e1[i];
+        const double rn = e0[i] - acc[i];
+        a.y[r] = rn;
+        a.s_out[r] = omega * (dinv_row * rn);
+      }
+    }
+  }
+}
+
 // dx -= c ; x += dx   (patch-corrected prolongation: y = P x - sum_p A_pp^-1 (A P x)_p,
 // PatchBasedSmoothers/PatchTransferOperators.jl:153-172, then xh .+= dxh GMGLinearSolvers.jl:494)
 __global__ void prolong_correct_kernel(int64_t n, const double *__restrict__ c, double *__restrict__ dx, double *__restrict__ x)

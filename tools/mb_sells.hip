@@ -69,7 +69,7 @@ int main(int argc, char **argv)
       hipLaunchKernelGGL((sells_kernel<EPI_SWEEP, true, 3, 3, false, DBGV>), dim3(nwg), dim3(256), lds, 0, b); }); \
     printf("%-52s %7.2f us per sweep\n", label, t * 1e3 / 2); }
   // launch-geometry sensitivity of the product kernel and of its bare skeleton
-  for (int wpbv : {1, 2, 4}) for (int wg : {1024, 2048, 4096, 8192, 16384}) {
+  for (int wpbv : {4}) for (int wg : {2048}) {
     const int g2 = std::min((a.nslices + wpbv - 1) / wpbv, wg);
     float t0 = time_it([&] { SellSArgs b = a; b.x = s0; b.s_out = s1; b.b = r; b.y = r; b.x2 = x; b.xmode = 1;
       hipLaunchKernelGGL((sells_kernel<EPI_SWEEP, true, 3, 3, false, 0>), dim3(g2), dim3(64 * wpbv), lds, 0, b); b.x = s1; b.s_out = s0; b.xmode = 2;
@@ -79,6 +79,12 @@ int main(int argc, char **argv)
       hipLaunchKernelGGL((sells_kernel<EPI_SWEEP, true, 3, 3, false, 15>), dim3(g2), dim3(64 * wpbv), lds, 0, b); }, 30);
     printf("waves/wg %d workgroups %6d : product %7.2f us   skeleton %7.2f us\n", wpbv, g2, t0 * 1e3 / 2, t1 * 1e3 / 2);
   }
+#define RUNB(NBV, wpbv, wg) { const int g2 = std::min((a.nslices + wpbv - 1) / wpbv, wg); \
+    float t = time_it([&] { SellSArgs b = a; b.x = s0; b.s_out = s1; b.b = r; b.y = r; b.x2 = x; b.xmode = 1; \
+      hipLaunchKernelGGL((sells_sweep_kernel<1, NBV, true>), dim3(g2), dim3(64 * wpbv), lds, 0, b); b.x = s1; b.s_out = s0; b.xmode = 2; \
+      hipLaunchKernelGGL((sells_sweep_kernel<2, NBV, true>), dim3(g2), dim3(64 * wpbv), lds, 0, b); }, 30); \
+    printf("batched sweep NB=%d waves/wg %d workgroups %6d : %7.2f us\n", NBV, wpbv, g2, t * 1e3 / 2); }
+  for (int wg : {1024, 2048, 4096}) { RUNB(1, 4, wg) RUNB(2, 4, wg) RUNB(4, 4, wg) RUNB(2, 2, wg) RUNB(4, 2, wg) RUNB(4, 1, wg) RUNB(8, 1, wg) }
   RUN(0, "product kernel")
   RUN(1, "- high-word mask")
   RUN(2, "- LDS coefficient reads")
