@@ -473,6 +473,8 @@ struct gmg_solver {
   int pat_un = 9;       // GMG_PAT_UN: gathers in flight per lane in sellp_kernel
   int pat_wgs = 2048;   // GMG_PAT_WGS: resident workgroups of the persistent sellp launch
   int pat_rb = 3;       // GMG_PAT_RB: runs (of 3 offsets) loaded per batch in sells_kernel (3 or 9)
+  int pat_batched = 1;  // GMG_PAT_BATCHED: the restructured sweep kernel (sells_sweep_kernel) for plain shared-offset tables
+  int pat_nb = 0;       // GMG_PAT_NB: slices per batch of that kernel (0 = auto: 1, or 2 on levels with >= 200000 slices)
   int pat_small_wpb = 4;   // GMG_PAT_SMALL_WPB: waves per workgroup of sells_kernel on levels with < 8192 slices (table staging amortised)
   int pat_small_wpb2 = 1;  // GMG_PAT_SMALL_WPB2: the same for sellp_kernel
   int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
@@ -1064,6 +1066,23 @@ struct gmg_solver {
     const size_t lds = M.pat_coded ? (size_t)2048 + (((size_t)M.pat_np * nu + 7) / 8) * 8 + (size_t)M.pat_np * 12 + 8
                                    : (size_t)M.pat_np * nu * 12 + 8 + (size_t)M.pat_np * 8;
     const dim3 g(nwg), b(64 * wpb);
+    if (EPI == EPI_SWEEP && ONEG && !M.pat_coded && M.pat_k == 3 && pat_rb == 3 && pat_batched && M.pat_nruns % 3 == 0) {
+      // restructured sweep (sells_sweep_kernel): no conditional operand loads, one store drain per NB slices
+      const bool td = a.pdinv != nullptr;
+      const int nb = pat_nb > 0 ? pat_nb : (nsl >= 200000 ? 2 : 1);
+      const int wg2 = std::max(1, std::min((nsl + wpb - 1) / wpb, nb >= 2 && pat_wgs == 2048 ? 1024 : pat_wgs));
+      const dim3 g2(wg2);
+#define GMG_SWEEP_LAUNCH(XMV, NBV)                                                                             \
+      do {                                                                                                       \
+        if (td) hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, true>), g2, b, lds, stream, a);                 \
+        else hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, false>), g2, b, lds, stream, a);                   \
+      } while (0)
+      if (nb >= 2) { if (a.xmode == 0) GMG_SWEEP_LAUNCH(0, 2); else if (a.xmode == 1) GMG_SWEEP_LAUNCH(1, 2); else GMG_SWEEP_LAUNCH(2, 2); }
+      else { if (a.xmode == 0) GMG_SWEEP_LAUNCH(0, 1); else if (a.xmode == 1) GMG_SWEEP_LAUNCH(1, 1); else GMG_SWEEP_LAUNCH(2, 1); }
+#undef GMG_SWEEP_LAUNCH
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     if (M.pat_coded && M.pat_k == 5) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true>), g, b, lds, stream, a);
     else if (M.pat_coded) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3, 3, true>), g, b, lds, stream, a);
     else if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), g, b, lds, stream, a);
@@ -1869,6 +1888,8 @@ struct gmg_solver {
     pat_small_wpb2 = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB2", 1)));
     pat_dinv = env_int("GMG_PAT_DINV", 1);
     pat_rb = env_int("GMG_PAT_RB", 3); pat_rb = pat_rb >= 9 ? 9 : (pat_rb <= 1 ? 1 : 3);
+    pat_batched = env_int("GMG_PAT_BATCHED", 1);
+    pat_nb = std::min(2, std::max(0, env_int("GMG_PAT_NB", 0)));
     tile = kTile;
   }
   // inv_diag = 1 ./ diag(A) (JacobiLinearSolvers.jl:20-23); needs the CSR stream of A (before drop_csr_stream)

@@ -1554,39 +1554,47 @@ __global__ __launch_bounds__(kBlock) void patch_apply_dedup_kernel(int64_t npatc
   for (int k = threadIdx.x; k < clen; k += kBlock) sB[k] = ubinv[co + k];
   __syncthreads();
   const int hw = threadIdx.x >> 5, lane = threadIdx.x & 31;   // 8 half-waves
-  // software pipeline: the (pdofs -> b) gather of the NEXT patch of this half-wave is in flight while the current one is solved
-  int64_t q0n = 0;
-  int npn = 0, ubn = 0;
-  double bn = 0.0;
-  auto fetch = [&](int64_t p) {
-    q0n = 0; npn = 0; ubn = 0; bn = 0.0;
-    if (p < p1) {
-      q0n = pptr[p];
-      npn = (int)(pptr[p + 1] - q0n);
-      ubn = ublock[p];
-      if (lane < npn) bn = b[pdofs[q0n + lane]];
-    }
-  };
-  fetch(p0 + hw);
-  for (int64_t p = p0 + hw; p < p1; p += 8) {
-    const int64_t q0 = q0n;
-    const int np = npn, ub = ubn;
-    const double bcur = bn;
-    fetch(p + 8);
-    if (np == 0) continue;
-    if (lane < np) sb[hw][lane] = bcur;
+  // Every half-wave solves TWO patches per step (p and p + 8): the chunk's block row is read from LDS once for both
+  // (the LDS pipe bounds this kernel: 27 x 27 block entries per patch), their right-hand sides are gathered together.
+  __shared__ double sb2[8][32];
+  for (int64_t p = p0 + hw; p < p1; p += 16) {
+    const int64_t pB = p + 8;
+    const bool hasB = pB < p1;
+    const int64_t q0 = pptr[p], q0B = hasB ? pptr[pB] : 0;
+    const int np = (int)(pptr[p + 1] - q0), npB = hasB ? (int)(pptr[pB + 1] - q0B) : 0;
+    const int ub = ublock[p], ubB = hasB ? ublock[pB] : -1;
+    double bA = 0.0, bB = 0.0;
+    if (lane < np) bA = b[pdofs[q0 + lane]];
+    if (lane < npB) bB = b[pdofs[q0B + lane]];
+    if (lane < np) sb[hw][lane] = bA;
+    if (lane < npB) sb2[hw][lane] = bB;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < np) {
-      double s = 0.0;
-      if (ub == cached) {
+    if (np > 0 && np == npB && ub == cached && ubB == cached) {
+      if (lane < np) {
         const double *rowp = sB + lane * np;
-        for (int k = 0; k < np; ++k) s += rowp[k] * sb[hw][k];
-      } else {
-        const double *rowp = ubinv + uboff[ub] + (size_t)lane * np;
-        for (int k = 0; k < np; ++k) s += rowp[k] * sb[hw][k];
+        double sA = 0.0, sBv = 0.0;
+        for (int k = 0; k < np; ++k) {
+          const double rk = rowp[k];
+          sA += rk * sb[hw][k];
+          sBv += rk * sb2[hw][k];
+        }
+        contrib[q0 + lane] = sA;
+        contrib[q0B + lane] = sBv;
       }
-      contrib[q0 + lane] = s;
+    } else {
+      if (lane < np) {
+        const double *rowp = (ub == cached) ? sB + lane * np : ubinv + uboff[ub] + (size_t)lane * np;
+        double s = 0.0;
+        for (int k = 0; k < np; ++k) s += rowp[k] * sb[hw][k];
+        contrib[q0 + lane] = s;
+      }
+      if (lane < npB) {
+        const double *rowp = (ubB == cached) ? sB + lane * npB : ubinv + uboff[ubB] + (size_t)lane * npB;
+        double s = 0.0;
+        for (int k = 0; k < npB; ++k) s += rowp[k] * sb2[hw][k];
+        contrib[q0B + lane] = s;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
