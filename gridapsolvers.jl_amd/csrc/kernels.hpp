@@ -690,30 +690,31 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
   const double omega = a.omega;
   const int last = (int)a.ncols - 1;
 
-  // row-wise operands of a slice ("head"): requested one slice ahead, so that their HBM latency is
-  // covered by the previous slice's taps; the gathers do not depend on them (shared offsets).
+  // row-wise operands of a slice ("head"): requested at the top of the slice's iteration with CLAMPED addresses and no
+  // divergent or conditional control flow around the loads (rows past the end / the two halo lanes re-read a valid row and
+  // discard it).  Conditional loads made the compiler wait at every join, and a prefetch across iterations cannot overlap
+  // anyway: on gfx9 loads and stores share vmcnt and return out of order with respect to each other, so a wave with stores in
+  // flight waits for a load with vmcnt(0) (see sells_sweep_kernel and profiles/r02_tuning.md).
   int pid_n = a.np - 1;
   double e0_n = 0.0, e1_n = 0.0, e2_n = 0.0, dr_n = 0.0, sp_n = 0.0;
   const int xmode = a.xmode;
   const bool tab_dinv = a.pdinv != nullptr;
+  const int64_t lastrow = a.nrows - 1;
+  const bool xzero = a.x_zero != 0;
   auto load_head = [&](int slice) {
-    const int64_t row = (int64_t)slice * ROWS + lane;
-    pid_n = a.np - 1; e0_n = e1_n = e2_n = dr_n = sp_n = 0.0;
-    if (slice < s_end && lane < ROWS && row < a.nrows) {
-      pid_n = (int)a.rowpid[row];
-      if (EPI == EPI_SUB) e0_n = a.y[row];
-      else if (EPI == EPI_RESID) e0_n = a.b[row];
-      else if (EPI == EPI_ADDTO) e0_n = a.x2[row];
-      else if (EPI == EPI_SWEEP) {
-        e0_n = a.b[row];
-        e1_n = xg[row];
-        if (xmode != 1) e2_n = a.x_zero ? 0.0 : a.x2[row];
-        if (xmode == 2) sp_n = a.s_out[row];               // s_{k-1}, about to be overwritten by s_{k+1}
-        if (!tab_dinv) dr_n = dinv[row];
-      }
+    const int64_t row = min((int64_t)slice * ROWS + lane, lastrow);
+    if (!VD) pid_n = (int)a.rowpid[row];                   // (coded form: the pattern id is requested one slice ahead, below)
+    if (EPI == EPI_SUB) e0_n = a.y[row];
+    else if (EPI == EPI_RESID) e0_n = a.b[row];
+    else if (EPI == EPI_ADDTO) e0_n = a.x2[row];
+    else if (EPI == EPI_SWEEP) {
+      e0_n = a.b[row];
+      e1_n = xg[row];
+      if (xmode != 1) { const double xl = a.x2[row]; e2_n = xzero ? 0.0 : xl; }
+      if (xmode == 2) sp_n = a.s_out[row];                 // s_{k-1}, about to be overwritten by s_{k+1}
+      if (!tab_dinv) dr_n = dinv[row];
     }
   };
-  load_head(s_begin + wave);
   double *s_dinv = VD ? sp_smem + 256 + ((tot + 7) >> 3) : reinterpret_cast<double *>(s_msk + tot + (tot & 1));   // [np]
   uint32_t *s_rmask = reinterpret_cast<uint32_t *>(s_dinv + a.np);                                                 // [np] (coded form)
   if (VD) {
@@ -727,10 +728,19 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
     for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
   __syncthreads();
 
+  // coded form: the run mask of a slice hangs off its pattern ids (load -> LDS -> wave OR -> gathers), so the ids alone
+  // are requested one slice ahead
+  int pid_ahead = a.np - 1;
+  if (VD && s_begin + wave < s_end) pid_ahead = (int)a.rowpid[min((int64_t)(s_begin + wave) * ROWS + lane, lastrow)];
   for (int slice = s_begin + wave; slice < s_end; slice += wpb) {
     const int row0 = slice * ROWS;
     const int64_t row = (int64_t)row0 + lane;
-    const int pid = pid_n;
+    if (VD) {
+      pid_n = pid_ahead;
+      pid_ahead = (int)a.rowpid[min((int64_t)min(slice + wpb, s_end - 1) * ROWS + lane, lastrow)];
+    }
+    load_head(slice);
+    const int pid = (lane < ROWS && row <= lastrow) ? pid_n : a.np - 1;   // halo lanes / rows past the end: the empty pattern
     const double e0 = e0_n, e1 = e1_n, e2 = e2_n, sp = sp_n;
     const double dinv_row = (EPI == EPI_SWEEP && tab_dinv) ? s_dinv[pid] : dr_n;
     double s = 0.0;
@@ -753,7 +763,6 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) M |= (uint32_t)__shfl_xor((int)M, o);
       M = (uint32_t)__builtin_amdgcn_readfirstlane((int)M);
-      load_head(slice + wpb);
       const uint8_t *tc = s_code + pid * nu;
       while (M) {
         int rr[RB];
@@ -780,7 +789,6 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       }
     } else {
     gather(0);
-    load_head(slice + wpb);                                // younger than the first gathers: not waited for with them
     const double *tv = s_val + pid * nu;
     const uint32_t *tm = s_msk + pid * nu;
     for (int r0 = 0; r0 < a.nruns; r0 += RB) {
