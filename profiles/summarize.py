@@ -26,6 +26,8 @@ def db(path):
 
 
 def family(name):
+    if "gmg::sells_sweep_kernel<" in name:          # the fused sweep on the shared-offset pattern table (XM = 0/1/2 variants)
+        return "sells_kernel"
     for fam in ("sells_kernel", "sellp_kernel", "sellc_kernel", "sell_kernel", "csr_stream1_kernel"):
         if "gmg::" + fam + "<" in name:
             return fam
@@ -81,27 +83,41 @@ def main():
                    f"WRITE_SIZE avg {w[0]:.0f} KiB -> x{wfac:.3f}")
     tl.append("# counter corrections: " + cal)
 
-    # ---- finest-level fused sweeps (EPI_SWEEP = 3): per kernel name the largest grid ----
-    sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%_kernel<3,%' "
+    # ---- finest-level fused sweeps (EPI_SWEEP = 3 kernels and the sells_sweep_kernel variants): largest grid per family;
+    #      variants of one family at that grid (x updated every second sweep) are averaged, weighted by launches ----
+    sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%_kernel<3,%' or name like '%sells_sweep_kernel<%' "
                      "group by name, grid_x order by grid_x desc").fetchall()
-    seen, recs = set(), []
+    recs = []
     nrows = (a.cells - 1) ** 3
+    fams = {}
     for name, grid, avg_us, cnt in sw:
         fam = family(name)
-        if fam is None or name in seen:
+        if fam is None:
             continue
-        seen.add(name)
-        rec = dict(family=fam, kernel=name, grid_x=grid, avg_us_kernel_trace=avg_us, launches=cnt, cells=a.cells, levels=a.levels, rows=nrows)
-        tl.append(f"# {name} grid_x={grid}: avg {avg_us:.2f} us over {cnt} launches (kernel-trace pass)")
-        f = counter("FETCH_SIZE", name, grid)
-        w = counter("WRITE_SIZE", name, grid)
-        if f and w:
-            fb, wb = ffac * f[0] * 1024.0, wfac * w[0] * 1024.0
-            rec.update(FETCH_SIZE_KiB_avg=f[0], WRITE_SIZE_KiB_avg=w[0], fetch_bytes_corrected=fb, write_bytes_corrected=wb,
-                       hbm_bytes_per_launch=fb + wb, fetch_factor=ffac, write_factor=wfac,
-                       pass_avg_us=dict(fetch=f[4], write=w[4]))
-            tl.append(f"  FETCH_SIZE avg {f[0]:.1f} KiB (min {f[1]:.1f} max {f[2]:.1f}, {f[3]} launches, {f[4]:.2f} us in that pass); "
-                      f"WRITE_SIZE avg {w[0]:.1f} KiB (min {w[1]:.1f} max {w[2]:.1f}, {w[3]} launches, {w[4]:.2f} us)")
+        key = (fam, "nt" if ", true>" in name and fam == "sell_kernel" else "")
+        if key not in fams:
+            fams[key] = dict(grid=grid, members=[])
+        if grid == fams[key]["grid"]:
+            fams[key]["members"].append((name, avg_us, cnt))
+    for (fam, _), info in fams.items():
+        grid = info["grid"]
+        tot_cnt = sum(m[2] for m in info["members"])
+        avg_us = sum(m[1] * m[2] for m in info["members"]) / tot_cnt
+        names = [m[0] for m in info["members"]]
+        rec = dict(family=fam, kernel=" | ".join(names), grid_x=grid, avg_us_kernel_trace=avg_us, launches=tot_cnt, cells=a.cells, levels=a.levels, rows=nrows)
+        tl.append(f"# {' | '.join(names)} grid_x={grid}: avg {avg_us:.2f} us over {tot_cnt} launches (kernel-trace pass)")
+        fsum = wsum = n_f = n_w = 0.0
+        for name, _, _ in info["members"]:
+            f = counter("FETCH_SIZE", name, grid)
+            w = counter("WRITE_SIZE", name, grid)
+            if f and w:
+                fsum += f[0] * f[3]; n_f += f[3]; wsum += w[0] * w[3]; n_w += w[3]
+        if n_f and n_w:
+            fk, wk = fsum / n_f, wsum / n_w
+            fb, wb = ffac * fk * 1024.0, wfac * wk * 1024.0
+            rec.update(FETCH_SIZE_KiB_avg=fk, WRITE_SIZE_KiB_avg=wk, fetch_bytes_corrected=fb, write_bytes_corrected=wb,
+                       hbm_bytes_per_launch=fb + wb, fetch_factor=ffac, write_factor=wfac)
+            tl.append(f"  FETCH_SIZE avg {fk:.1f} KiB, WRITE_SIZE avg {wk:.1f} KiB (launch-weighted over the variants)")
             tl.append(f"  HBM traffic per launch = {ffac:.3f}*FETCH + {wfac:.3f}*WRITE = {fb/1e6:.1f} MB + {wb/1e6:.1f} MB = {(fb+wb)/1e6:.1f} MB "
                       f"-> {(fb+wb)/avg_us/1e3:.0f} GB/s at the kernel-trace duration")
         recs.append(rec)
