@@ -845,9 +845,6 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
   double *s_val = sp_smem;
   uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
   double *s_dinv = reinterpret_cast<double *>(s_msk + tot + (tot & 1));
-  for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
-  if (TD)
-    for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x;
@@ -860,11 +857,10 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
   const int last = (int)a.ncols - 1;
   const int lastrow = (int)a.nrows - 1;
   const bool xz = a.x_zero != 0;
-  __syncthreads();
-  for (int sb = s_begin + wave; sb < s_end; sb += wpb * NB) {
-    int pid[NB], row[NB];
-    double e0[NB], e1[NB], e2[NB], sp[NB], dr[NB], A[NB][RB], acc[NB];
-    // ---- phase 1: every load of the batch ----
+  int pid[NB], row[NB];
+  double e0[NB], e1[NB], e2[NB], sp[NB], dr[NB], A[NB][RB], acc[NB];
+  // ---- phase 1: every load of a batch (row-wise operands + the first gathers; none depends on the pattern table) ----
+  auto load_batch = [&](int sb) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int slice = min(sb + i * wpb, s_end - 1);        // a short last batch re-reads its last slice (results unused)
@@ -880,6 +876,14 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
 #pragma unroll
       for (int q = 0; q < RB; ++q) A[i][q] = ld_off(xg, 8u * (uint32_t)min(max(row[i] + a.run_off[q], 0), last));
     }
+  };
+  int sb = s_begin + wave;
+  if (sb < s_end) load_batch(sb);                            // in flight while the table is staged (one round trip, not two)
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
+  if (TD)
+    for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
+  __syncthreads();
+  while (sb < s_end) {
     // ---- phase 2: taps, slice after slice (rows summed in ascending column order) ----
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -921,6 +925,8 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
         a.s_out[r] = omega * (dinv_row * rn);
       }
     }
+    sb += wpb * NB;
+    if (sb < s_end) load_batch(sb);
   }
 }
 
