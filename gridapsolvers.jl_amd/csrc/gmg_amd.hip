@@ -1066,16 +1066,18 @@ struct gmg_solver {
     const size_t lds = M.pat_coded ? (size_t)2048 + (((size_t)M.pat_np * nu + 7) / 8) * 8 + (size_t)M.pat_np * 12 + 8
                                    : (size_t)M.pat_np * nu * 12 + 8 + (size_t)M.pat_np * 8;
     const dim3 g(nwg), b(64 * wpb);
-    if (EPI == EPI_SWEEP && ONEG && !M.pat_coded && M.pat_k == 3 && pat_rb == 3 && pat_batched && M.pat_nruns % 3 == 0) {
+    if (EPI == EPI_SWEEP && ONEG && !M.pat_coded && M.pat_k == 3 && pat_rb == 3 && pat_batched && M.pat_nruns % 3 == 0 &&
+        (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16 <= 64 * 1024) {
       // restructured sweep (sells_sweep_kernel): no conditional operand loads, one store drain per NB slices
       const bool td = a.pdinv != nullptr;
       const int nb = pat_nb > 0 ? pat_nb : (nsl >= 200000 ? 2 : 1);
       const int wg2 = std::max(1, std::min((nsl + wpb - 1) / wpb, nb >= 2 && pat_wgs == 2048 ? 1024 : pat_wgs));
       const dim3 g2(wg2);
+      const size_t lds2 = (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16;    // 16-byte {value, mask} entries
 #define GMG_SWEEP_LAUNCH(XMV, NBV)                                                                             \
       do {                                                                                                       \
-        if (td) hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, true>), g2, b, lds, stream, a);                 \
-        else hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, false>), g2, b, lds, stream, a);                   \
+        if (td) hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, true>), g2, b, lds2, stream, a);                \
+        else hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, false>), g2, b, lds2, stream, a);                  \
       } while (0)
       if (nb >= 2) { if (a.xmode == 0) GMG_SWEEP_LAUNCH(0, 2); else if (a.xmode == 1) GMG_SWEEP_LAUNCH(1, 2); else GMG_SWEEP_LAUNCH(2, 2); }
       else { if (a.xmode == 0) GMG_SWEEP_LAUNCH(0, 1); else if (a.xmode == 1) GMG_SWEEP_LAUNCH(1, 1); else GMG_SWEEP_LAUNCH(2, 1); }

@@ -842,9 +842,9 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
   extern __shared__ double sp_smem[];
   const int nu = K * a.nruns;
   const int tot = a.np * nu;
-  double *s_val = sp_smem;
-  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
-  double *s_dinv = reinterpret_cast<double *>(s_msk + tot + (tot & 1));
+  // LDS: [np*nu] {coefficient, high-word mask} as 16-byte entries (one ds_read_b128 per tap) | [np] 1/diag
+  PatEntry *s_tab = reinterpret_cast<PatEntry *>(sp_smem);
+  double *s_dinv = sp_smem + 2 * (size_t)tot;
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x;
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
   };
   int sb = s_begin + wave;
   if (sb < s_end) load_batch(sb);                            // in flight while the table is staged (one round trip, not two)
-  for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i];
   if (TD)
     for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
   __syncthreads();
@@ -887,8 +887,7 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
     // ---- phase 2: taps, slice after slice (rows summed in ascending column order) ----
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const double *tv = s_val + pid[i] * nu;
-      const uint32_t *tm = s_msk + pid[i] * nu;
+      const PatEntry *te = s_tab + pid[i] * nu;
       double s = 0.0;
       for (int r0 = 0; r0 < a.nruns; r0 += RB) {
         double cur[RB];
@@ -905,8 +904,9 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
           for (int t = 0; t < K; ++t) {
             if (t > 0) c = wave_shl1(c);                     // the last K-1 lanes receive junk: they own no row
             const int j = (r0 + q) * K + t;
-            const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
-            s = s + tv[j] * g;
+            const PatEntry en = te[j];
+            const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
+            s = s + en.v * g;
           }
         }
       }
