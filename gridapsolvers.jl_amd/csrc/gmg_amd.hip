@@ -211,8 +211,6 @@ struct DevCSR {
   int32_t *prun = nullptr;
   int pat_nruns = 0, pat_minoff = 0, pat_maxoff = 0;
   double *pdinv = nullptr;      // [np] 1/diag per pattern (nullptr: some pattern has no diagonal entry)
-  double *pucoef = nullptr;     // [nu] coefficients of the full pattern (all entries present), see sells_sweep_kernel
-  int pat_full = -1;            // its id
   bool pat_generic = false;     // the per-lane-offset table (sellp_kernel) fits LDS
   int pat_k = 3;                // offsets per run of the shared form
   bool pat_coded = false;       // shared form with one-byte value codes + dictionary
@@ -1038,21 +1036,7 @@ struct gmg_solver {
         for (size_t q = 0; q < keys.size(); ++q) std::memcpy(&dict[q], &keys[q], 8);
         D.pcodes = upload_padded(codes, 64);
         D.pdict = upload(dict);
-      } else {
-        D.ptab = upload(tab);
-        // a pattern with EVERY entry of the table present (no padding either): the interior row of a structured operator
-        D.pat_full = -1; D.pucoef = nullptr;
-        for (int p = 0; p < np - 1 && D.pat_full < 0; ++p) {
-          bool full = true;
-          for (int e = 0; e < nu && full; ++e) full = tab[(size_t)p * nu + e].m != 0u;
-          if (full) {
-            std::vector<double> uc((size_t)nu);
-            for (int e = 0; e < nu; ++e) uc[(size_t)e] = tab[(size_t)p * nu + e].v;
-            D.pucoef = upload(uc);
-            D.pat_full = p;
-          }
-        }
-      }
+      } else D.ptab = upload(tab);
       D.prun = upload(runs);
       D.pat_nruns = nruns;
       D.pat_k = c.k;
@@ -1072,7 +1056,6 @@ struct gmg_solver {
     a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff;
     a.xmode = a2.xmode; a.pdinv = (EPI == EPI_SWEEP && a2.dinv_from_table) ? M.pdinv : nullptr;
     a.codes = M.pcodes; a.dict = M.pdict; a.runmask = M.prunmask;
-    a.ucoef = env_int("GMG_PAT_UNIFORM", 1) ? M.pucoef : nullptr; a.full_pid = a.ucoef ? M.pat_full : -1;
     const int rows = 65 - M.pat_k;
     const int nsl = (int)((M.nrows + rows - 1) / rows);
     a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl; a.xcd_remap = xcd_remap;

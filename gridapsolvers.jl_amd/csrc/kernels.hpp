@@ -637,8 +637,6 @@ struct SellSArgs {
   int xmode;                // sweep: 0 x += s_k ; 1 x untouched (deferred) ; 2 x = (x + s_{k-1}) + s_k, s_{k-1} read from s_out
   int xcd_remap;
   const double *pdinv;      // [np] 1/diag of each pattern (Jacobi inverse diagonal without its 8 B/row stream), or nullptr
-  const double *ucoef;      // [nu] coefficients of the FULL pattern (every entry present), or nullptr: see sells_sweep_kernel
-  int full_pid;             // its id, -1 when no pattern is full
   const double *x;
   const double *dinv;
   double omega;
@@ -889,32 +887,8 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
     // ---- phase 2: taps, slice after slice (rows summed in ascending column order) ----
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      double s = 0.0;
-      // A slice whose 64 lanes all carry the FULL pattern (every tap present: the interior rows of a structured operator,
-      // half of the slices at 128^3, three quarters at 256^3) takes the coefficients from scalar registers and needs no
-      // masks: one FMA per tap instead of LDS read + AND + FMA.  Same coefficients, same order => same bits.
-      const bool uni = a.full_pid >= 0 && __builtin_amdgcn_ballot_w64(pid[i] != a.full_pid) == 0ull;
-      if (uni) {
-        for (int r0 = 0; r0 < a.nruns; r0 += RB) {
-          double cur[RB];
-#pragma unroll
-          for (int q = 0; q < RB; ++q) cur[q] = A[i][q];
-          if (r0 + RB < a.nruns) {
-#pragma unroll
-            for (int q = 0; q < RB; ++q) A[i][q] = ld_off(xg, 8u * (uint32_t)min(max(row[i] + a.run_off[r0 + RB + q], 0), last));
-          }
-#pragma unroll
-          for (int q = 0; q < RB; ++q) {
-            double c = cur[q];
-#pragma unroll
-            for (int t = 0; t < K; ++t) {
-              if (t > 0) c = wave_shl1(c);
-              s = s + a.ucoef[(r0 + q) * K + t] * c;           // uniform address: scalar load
-            }
-          }
-        }
-      } else {
       const PatEntry *te = s_tab + pid[i] * nu;
+      double s = 0.0;
       for (int r0 = 0; r0 < a.nruns; r0 += RB) {
         double cur[RB];
 #pragma unroll
@@ -935,7 +909,6 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
             s = s + en.v * g;
           }
         }
-      }
       }
       acc[i] = s;
     }

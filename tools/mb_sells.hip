@@ -57,8 +57,6 @@ int main(int argc, char **argv)
   SellSArgs a;
   std::memset(&a, 0, sizeof(a));
   a.rowpid = d_pid; a.tab = d_tab; a.run_off = d_run; a.np = np; a.nruns = nruns; a.minoff = runs.front(); a.maxoff = runs.back();
-  { std::vector<double> uc(nu); for (int e = 0; e < nu; ++e) uc[e] = tab[(size_t)13 * nu + e].v; double *d_uc; CK(hipMalloc(&d_uc, nu * 8));
-    CK(hipMemcpy(d_uc, uc.data(), nu * 8, hipMemcpyHostToDevice)); a.ucoef = argc > 2 ? nullptr : d_uc; a.full_pid = argc > 2 ? -1 : 13; }
   a.nrows = N; a.ncols = N; a.nslices = (int)((N + 61) / 62); a.xcd_remap = 1; a.pdinv = d_pd; a.omega = 2.0 / 3.0; a.dinv = nullptr;
   const int nwg = std::min((a.nslices + 3) / 4, 2048);
   const size_t lds = (size_t)np * nu * 12 + 8 + (size_t)np * 8;
