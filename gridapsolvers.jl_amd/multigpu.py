@@ -166,18 +166,36 @@ class DistributedGMG:
                                                          C.c_void_p(blocks.ctypes.data), 0, None))
 
     def _set(self, fn, l, M):
+        if M.nnz < 2 ** 31 - 1:            # int32 columns as they are, the (short) pointer array narrowed to match
+            ptr = M.ptr.astype(np.int32)
+            abi.check(self.h, fn(self.h, l, M.shape[0], M.shape[1], M.nnz, C.c_void_p(ptr.ctypes.data),
+                                 C.c_void_p(M.idx.ctypes.data), C.c_void_p(M.val.ctypes.data), abi.CSR, 0, 4))
+            return
         idx64 = M.idx.astype(np.int64)
         abi.check(self.h, fn(self.h, l, M.shape[0], M.shape[1], M.nnz, C.c_void_p(M.ptr.ctypes.data),
                              C.c_void_p(idx64.ctypes.data), C.c_void_p(M.val.ctypes.data), abi.CSR, 0, 8))
 
     # -- right-hand sides ------------------------------------------------------------------
+    def _nodal_u(self, gid):
+        """u = x1 + x2 at the free dofs `gid` (global lexicographic ids, x fastest) -- from coordinates, no global arrays"""
+        d = len(self.cells_global)
+        nf = [self.order * c - 1 for c in self.cells_global]
+        Ls = po._lengths(self.lengths, d)
+        i = gid % nf[0]
+        j = (gid // nf[0]) % nf[1]
+        h0, h1 = Ls[0] / (self.order * self.cells_global[0]), Ls[1] / (self.order * self.cells_global[1])
+        return (i + 1) * h0 + (j + 1) * h1
+
     def rhs_lin(self):
-        """Owned part of the Dirichlet-lift rhs of u = x1 + x2 (reference test problem)."""
-        b = po.dirichlet_lift_rhs(self.cells_global, self.order, None, self.lengths)
-        return np.ascontiguousarray(b[self.local["levels"][0].own_gid])
+        """Owned part of the Dirichlet-lift rhs of u = x1 + x2 (reference test problem, f = 0): u is in the FE space, so
+        A_ff u_f + A_fd u_d = 0 and b = -A_fd u_d = A_ff u_f -- evaluated with this rank's local rows on the nodal values of its
+        [own | ghost] dofs; nothing of global size is formed (576^3 nodes at 8 x 288^3)."""
+        L0 = self.local["levels"][0]
+        u = self._nodal_u(np.concatenate([L0.own_gid, L0.ghost_gid]))
+        return np.ascontiguousarray(L0.A.matvec(u))
 
     def exact_own(self):
-        return np.ascontiguousarray(po.nodal_values(self.cells_global, self.order, None, self.lengths)[self.local["levels"][0].own_gid])
+        return np.ascontiguousarray(self._nodal_u(self.local["levels"][0].own_gid))
 
     # -- solves ----------------------------------------------------------------------------
     def cg_solve(self, b, x, maxiter=20, atol=1e-14, rtol=1e-6, flexible=False):
