@@ -264,12 +264,13 @@ def run_bench(args, rank, world, local_rank):
     # BASELINE configs[3] (SURVEY 8 size table): 288^3 cells per GPU, 6 levels -> 576,288,144,72,36,18 cells per direction on
     # 2x2x2 GPUs; the GLOBAL coarsest level (dense inverse, replicated) has 17^3 dofs
     nlev = args.levels
-    # replicate every level whose GLOBAL size is small (<= 3e5 dofs): those levels are latency bound and a
-    # halo exchange per sweep would cost more than computing them redundantly on every GPU
+    # replicate every level whose GLOBAL size is small (<= 4e5 dofs: at config 4 that is the 72^3 level, 3.6e5 dofs):
+    # those levels are latency bound -- a sweep takes 5-7 us, a grouped RCCL send/recv tens of us -- so computing them
+    # redundantly on every GPU is cheaper than a halo exchange per sweep
     grid3 = pa.rank_grid(world, 3)
     rep_from = nlev - 1
     for l in range(1, nlev):
-        if po.level_sizes(tuple(args.cells * g // 2 ** l for g in grid3), 1) <= 300000:
+        if po.level_sizes(tuple(args.cells * g // 2 ** l for g in grid3), 1) <= 400000:
             rep_from = l
             break
     rdev0 = "cpu" if dist.get_backend() == "gloo" else "cuda"
