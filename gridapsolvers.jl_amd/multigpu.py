@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import time
 
 import numpy as np
@@ -313,7 +314,7 @@ def run_bench(args, rank, world, local_rank):
         # safety net: the overlapped exchange (comm stream + events) cannot be exercised on the 1-GPU
         # development boxes; if it ever misbehaves fall back to in-stream exchanges and say so
         if rank == 0:
-            print("[bench] overlapped halo exchange gave a wrong solution; retrying with GMG_OVERLAP=0", flush=True)
+            print("[bench] overlapped halo exchange gave a wrong solution; retrying with GMG_OVERLAP=0", flush=True, file=sys.stderr)
         os.environ["GMG_OVERLAP"] = "0"
         g.close()
         g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from)
