@@ -35,9 +35,23 @@ struct gmg_block_solver {
   std::vector<double *> fg_V, fg_Z;
   bool setup_done = false;
   std::string err;
+  // distributed runs (one handle per rank): block vectors hold the OWNED entries of every block; a block whose columns reach
+  // into other ranks' entries gets an exchange plan and a work vector with ghost space ([own | ghost], as on GMG levels)
+  std::vector<HaloPlan> plan;
+  std::vector<double *> xg;
 
   int64_t N() const { return off.empty() ? 0 : off.back(); }
   int64_t bsize(int i) const { return off[i + 1] - off[i]; }
+  int64_t ncols_of(int j) const { return bsize(j) + ((size_t)j < plan.size() && plan[j].present ? plan[j].n_ghost : 0); }
+  bool distributed() const { return eng.comm.nranks > 1; }
+  // x_j with its ghost entries filled (consistent!): own part copied into the work vector, halo exchanged
+  const double *with_ghosts(int j, const double *xj)
+  {
+    if (!distributed() || (size_t)j >= plan.size() || !plan[j].present || plan[j].n_ghost == 0) return xj;
+    eng.copy(xg[j], xj, bsize(j));
+    eng.exchange_plan(plan[j], xg[j], eng.stream);
+    return xg[j];
+  }
 
   void detach()
   {
@@ -58,6 +72,17 @@ struct gmg_block_solver {
     eng.init_reductions();
     int64_t nmax = 1;
     for (int i = 0; i < nb; ++i) nmax = std::max(nmax, bsize(i));
+    xg.assign((size_t)nb, nullptr);
+    if (distributed()) {
+      plan.resize((size_t)nb);
+      for (int j = 0; j < nb; ++j)
+        if (plan[j].present) {
+          REQUIRE(plan[j].n_own == bsize(j), GMG_ERR_INVALID, "partition of block " + std::to_string(j) + " does not match its size");
+          plan[j].d_snd_idx = nullptr; plan[j].d_sendbuf = nullptr; plan[j].d_recvbuf = nullptr;
+          eng.alloc_plan_buffers(plan[j]);
+          xg[j] = eng.dvec(bsize(j) + plan[j].n_ghost);
+        }
+    }
     for (auto &kv : hsys) sys[kv.first] = eng.upload_csr(kv.second);
     for (auto &kv : hpre) pre[kv.first] = eng.upload_csr(kv.second);
     for (int i = 0; i < nb; ++i) {
@@ -68,7 +93,7 @@ struct gmg_block_solver {
         gmg_solver *g = D.g;
         REQUIRE(g && g->setup_done, GMG_ERR_STATE, "the GMG handle of block " + std::to_string(i) + " is not set up");
         REQUIRE(g->device == eng.device, GMG_ERR_INVALID, "GMG handle lives on another device");
-        REQUIRE(g->comm.nranks == 1, GMG_ERR_UNSUPPORTED, "block solvers are single-GPU in this round");
+        REQUIRE(g->comm.nranks == eng.comm.nranks, GMG_ERR_INVALID, "the GMG handle of block " + std::to_string(i) + " and the block solver must span the same ranks");
         REQUIRE(g->lev[0].n == n, GMG_ERR_INVALID, "GMG handle size does not match block " + std::to_string(i));
         HIP_CHECK(hipStreamSynchronize(g->stream));
         REQUIRE(g->attached_to == nullptr || g->attached_to == this, GMG_ERR_STATE, "GMG handle is already attached to another block solver");
@@ -83,8 +108,9 @@ struct gmg_block_solver {
         REQUIRE(it != hsys.end(), GMG_ERR_STATE, "block " + std::to_string(i) + ": no solver matrix and no system block (i,i)");
         src = &it->second;
       }
-      REQUIRE(src->nrows == n && src->ncols == n, GMG_ERR_INVALID, "solver matrix of block " + std::to_string(i) + " has the wrong shape");
+      REQUIRE(src->nrows == n && src->ncols == ncols_of(i), GMG_ERR_INVALID, "solver matrix of block " + std::to_string(i) + " has the wrong shape");
       if (D.kind == GMG_BLOCK_LU) {
+        REQUIRE(!distributed(), GMG_ERR_UNSUPPORTED, "LUSolver() diagonal blocks are single-GPU (a dense inverse of a distributed block is not formed)");
         D.Minv = eng.build_dense_inverse(*src, "diagonal block " + std::to_string(i));
         continue;
       }
@@ -132,8 +158,9 @@ struct gmg_block_solver {
       for (int j = 0; j < nb; ++j) {
         const DevCSR *M = sys_block(i, j);
         if (!M) continue;
-        if (first) eng.spmv_set(*M, x + off[j], yi);
-        else eng.spmv_addto(*M, x + off[j], tmp, yi);
+        const double *xj = with_ghosts(j, x + off[j]);
+        if (first) eng.spmv_set(*M, xj, yi);
+        else eng.spmv_addto(*M, xj, tmp, yi);
         first = false;
       }
       if (first) eng.zero(yi, bsize(i));
@@ -148,8 +175,9 @@ struct gmg_block_solver {
       for (int j = 0; j < nb; ++j) {
         const DevCSR *M = sys_block(i, j);
         if (!M) continue;
-        if (first) eng.spmv_resid(*M, x + off[j], b + off[i], ri);
-        else eng.spmv_sub(*M, x + off[j], ri);
+        const double *xj = with_ghosts(j, x + off[j]);
+        if (first) eng.spmv_resid(*M, xj, b + off[i], ri);
+        else eng.spmv_sub(*M, xj, ri);
         first = false;
       }
       if (first) eng.copy(ri, b + off[i], bsize(i));
@@ -163,12 +191,17 @@ struct gmg_block_solver {
     const int64_t n = bsize(i);
     switch (D.kind) {
     case GMG_BLOCK_GMG:
+      if (D.g->comm.nranks > 1) {                           // distributed handle: its solution vector carries ghost space
+        if (D.g->mode == GMG_MODE_SOLVER) eng.copy(D.g->cg_x, yi, n);
+        D.g->gmg_solve_dev(D.g->cg_x, wi, -1.0);
+        eng.copy(yi, D.g->cg_x, n);
+      } else
       D.g->gmg_solve_dev(yi, wi, -1.0);
       break;
     case GMG_BLOCK_CG_JACOBI: {                           // yi keeps its previous content: CG's initial guess
       KrylovOps ops;
-      ops.resid = [&](double *x, const double *b, double *r) { eng.spmv_resid(D.M, x, b, r); };
-      ops.apply = [&](double *x, double *yv) { eng.spmv_set(D.M, x, yv); };
+      ops.resid = [&, i](double *x, const double *b, double *r) { eng.spmv_resid(D.M, with_ghosts(i, x), b, r); };
+      ops.apply = [&, i](double *x, double *yv) { eng.spmv_set(D.M, with_ghosts(i, x), yv); };
       ops.precond = [&, n](double *z, const double *r, double) {
         hipLaunchKernelGGL(jacobi_apply_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, eng.stream, n, D.dinv, r, z);
         HIP_CHECK(hipGetLastError());
@@ -207,9 +240,10 @@ struct gmg_block_solver {
           const DevCSR *M = pre_block(iB, jB);
           if (!(std::fabs(cij) > eps) || !M) continue;                       // :194,223
           if (!touched) { eng.copy(wi, rhs, n); touched = true; }            // :192,221 copy!(wi,bi)
-          if (cij == 1.0) eng.spmv_sub(*M, x + off[jB], wi);                 // :196,225 mul!(wi,M,xj,-cij,1.0)
+          const double *xj = with_ghosts(jB, x + off[jB]);
+          if (cij == 1.0) eng.spmv_sub(*M, xj, wi);                          // :196,225 mul!(wi,M,xj,-cij,1.0)
           else {
-            eng.spmv_set(*M, x + off[jB], tmp);
+            eng.spmv_set(*M, xj, tmp);
             hipLaunchKernelGGL(axpy_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, eng.stream, n, -cij, tmp, wi);
             HIP_CHECK(hipGetLastError());
           }
@@ -321,6 +355,11 @@ int gmg_block_destroy(gmg_block_handle_t h)
   (void)hipStreamSynchronize(h->eng.stream);
   h->detach();                                            // GMG handles get their own stream back
   h->eng.free_all();
+  for (auto &P : h->plan) {
+    if (P.h_send) (void)hipHostFree(P.h_send);
+    if (P.h_recv) (void)hipHostFree(P.h_recv);
+  }
+  if (h->eng.comm.kind == COMM_RCCL && h->eng.comm.comm) (void)h->eng.comm.api.CommDestroy(h->eng.comm.comm);
   if (h->eng.h_scalars) (void)hipHostFree(h->eng.h_scalars);
   if (h->eng.own_stream) (void)hipStreamDestroy(h->eng.own_stream);
   delete h;
@@ -329,12 +368,42 @@ int gmg_block_destroy(gmg_block_handle_t h)
 
 const char *gmg_block_last_error(gmg_block_handle_t h) { return h ? h->err.c_str() : g_last_error.c_str(); }
 
+// ---- distributed block systems: one handle per rank ------------------------------------------------------------------
+int gmg_block_comm_init_rccl(gmg_block_handle_t h, const char *rccl_path, const char *unique_id128, int rank, int nranks)
+{
+  if (!h) return GMG_ERR_INVALID;
+  const int st = gmg_comm_init_rccl(&h->eng, rccl_path, unique_id128, rank, nranks);
+  if (st != GMG_OK) h->err = h->eng.err;
+  h->setup_done = false;
+  return st;
+}
+int gmg_block_comm_init_host(gmg_block_handle_t h, int rank, int nranks, gmg_host_exchange_fn xfn, gmg_host_allreduce_fn rfn, void *ctx)
+{
+  if (!h) return GMG_ERR_INVALID;
+  const int st = gmg_comm_init_host(&h->eng, rank, nranks, xfn, rfn, ctx);
+  if (st != GMG_OK) h->err = h->eng.err;
+  h->setup_done = false;
+  return st;
+}
+int gmg_block_set_partition(gmg_block_handle_t h, int j, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
+                            const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr)
+{
+  return guarded_b(h, [&] {
+    check_block(h, j);
+    REQUIRE(h->eng.comm.nranks > 1, GMG_ERR_STATE, "gmg_block_comm_init_* first");
+    REQUIRE(n_own == h->bsize(j), GMG_ERR_INVALID, "n_own must equal the block size given to gmg_block_create");
+    if (h->plan.size() < (size_t)h->nb) h->plan.resize((size_t)h->nb);
+    fill_plan(h->plan[j], h->eng.comm, n_own, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr);
+    h->setup_done = false;
+  });
+}
+
 int gmg_block_set_system_block(gmg_block_handle_t h, int i, int j, int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr,
                                const void *idx, const double *val, int layout, int index_base, int index_bytes)
 {
   return guarded_b(h, [&] {
     check_block(h, i); check_block(h, j);
-    REQUIRE(nrows == h->bsize(i) && ncols == h->bsize(j), GMG_ERR_INVALID, "block shape does not match the block sizes");
+    REQUIRE(nrows == h->bsize(i) && ncols == h->ncols_of(j), GMG_ERR_INVALID, "block shape does not match the block sizes (columns = own + ghost entries of block j)");
     h->hsys[{i, j}] = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
     h->setup_done = false;
   });
@@ -346,7 +415,7 @@ int gmg_block_set_precond_block(gmg_block_handle_t h, int i, int j, int64_t nrow
   return guarded_b(h, [&] {
     check_block(h, i); check_block(h, j);
     REQUIRE(i != j, GMG_ERR_INVALID, "diagonal blocks are given with gmg_block_set_diag_*");
-    REQUIRE(nrows == h->bsize(i) && ncols == h->bsize(j), GMG_ERR_INVALID, "block shape does not match the block sizes");
+    REQUIRE(nrows == h->bsize(i) && ncols == h->ncols_of(j), GMG_ERR_INVALID, "block shape does not match the block sizes (columns = own + ghost entries of block j)");
     h->hpre[{i, j}] = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
     h->setup_done = false;
   });
@@ -400,7 +469,7 @@ int gmg_block_set_diag_matrix(gmg_block_handle_t h, int i, int64_t n, int64_t nn
   return guarded_b(h, [&] {
     check_block(h, i);
     REQUIRE(n == h->bsize(i), GMG_ERR_INVALID, "matrix size does not match the block size");
-    h->diag[i].hM = convert_input(n, n, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    h->diag[i].hM = convert_input(n, h->ncols_of(i), nnz, ptr, idx, val, layout, index_base, index_bytes);   // distributed: own rows x [own | ghost]
     h->diag[i].hasM = true;
     h->setup_done = false;
   });

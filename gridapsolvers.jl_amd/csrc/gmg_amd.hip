@@ -1453,9 +1453,10 @@ struct gmg_solver {
   // consistent!(v): owner -> ghost copy of the level-l vector `v` (length nvec)
   void exchange(int l, double *v) { exchange_on(l, v, stream); }
   // prepacked: the send buffer already holds v's boundary entries (written by the previous sweep's ghost_fix_kernel)
-  void exchange_on(int l, double *v, hipStream_t stream, bool prepacked = false)
+  void exchange_on(int l, double *v, hipStream_t stream, bool prepacked = false) { exchange_plan(lev[l].halo, v, stream, prepacked); }
+  // the same for any exchange plan (block preconditioners keep one per block)
+  void exchange_plan(HaloPlan &H, double *v, hipStream_t stream, bool prepacked = false)
   {
-    HaloPlan &H = lev[l].halo;
     if (comm.nranks <= 1 || !H.present || H.nbr.empty()) return;
     const int64_t ns = H.nsend();
     if (ns > 0 && !prepacked) {
@@ -1477,6 +1478,16 @@ struct gmg_solver {
       HIP_CHECK(hipStreamSynchronize(stream));
       comm.xfn(comm.ctx, (int)H.nbr.size(), H.nbr.data(), H.h_send, H.snd_ptr.data(), H.h_recv, H.rcv_ptr.data());
       if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(ghost, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, stream));
+    }
+  }
+  void alloc_plan_buffers(HaloPlan &H)
+  {
+    H.d_snd_idx = upload(H.h_snd_idx);
+    H.d_sendbuf = dvec(H.nsend());
+    H.d_recvbuf = dvec(H.nsend());
+    if (comm.kind == COMM_HOST) {
+      if (!H.h_send) HIP_CHECK(hipHostMalloc((void **)&H.h_send, sizeof(double) * (size_t)std::max<int64_t>(1, H.nsend())));
+      if (!H.h_recv) HIP_CHECK(hipHostMalloc((void **)&H.h_recv, sizeof(double) * (size_t)std::max<int64_t>(1, H.n_ghost)));
     }
   }
   // assemble!(v): ghost -> owner add (the reverse of consistent!), PatchSolvers.jl:254 / BlockJacobiSolvers.jl:134.
@@ -2719,14 +2730,7 @@ void gmg_solver::setup()
     L.rbuf[0] = dvec(L.nvec);                               // :187,188 rh / rH
     if (l > 0) L.x = dvec(L.nvec);                          // :188 dxH
     if (L.halo.present) {
-      HaloPlan &H = L.halo;
-      H.d_snd_idx = upload(H.h_snd_idx);
-      H.d_sendbuf = dvec(H.nsend());
-      H.d_recvbuf = dvec(H.nsend());
-      if (comm.kind == COMM_HOST) {
-        if (!H.h_send) HIP_CHECK(hipHostMalloc((void **)&H.h_send, sizeof(double) * (size_t)std::max<int64_t>(1, H.nsend())));
-        if (!H.h_recv) HIP_CHECK(hipHostMalloc((void **)&H.h_recv, sizeof(double) * (size_t)std::max<int64_t>(1, H.n_ghost)));
-      }
+      alloc_plan_buffers(L.halo);
     }
     if (l < nlev - 1) {
       L.rbuf[1] = dvec(L.nvec);
@@ -2905,6 +2909,31 @@ void check_level(gmg_handle_t h, int lev, bool not_coarsest)
   REQUIRE(h, GMG_ERR_INVALID, "null handle");
   REQUIRE(lev >= 0 && lev < h->nlev, GMG_ERR_INVALID, "level out of range");
   if (not_coarsest) REQUIRE(lev < h->nlev - 1, GMG_ERR_INVALID, "level must not be the coarsest");
+}
+// exchange plan of one vector space (PartitionedArrays: assembly neighbours + local indices), validated
+void fill_plan(HaloPlan &H, const Comm &comm, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
+               const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr)
+{
+  REQUIRE(n_own >= 0 && n_ghost >= 0 && nnbr >= 0, GMG_ERR_INVALID, "negative sizes");
+  REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
+  double *hs = H.h_send, *hr = H.h_recv;                   // pinned buffers survive a re-plan only if sizes allow: drop them
+  if (hs) (void)hipHostFree(hs);
+  if (hr) (void)hipHostFree(hr);
+  H = HaloPlan();
+  H.present = true; H.n_own = n_own; H.n_ghost = n_ghost;
+  H.nbr.assign(nbr_rank, nbr_rank + nnbr);
+  H.snd_ptr.assign(1, 0); H.rcv_ptr.assign(1, 0);
+  if (nnbr > 0) { H.snd_ptr.assign(snd_ptr, snd_ptr + nnbr + 1); H.rcv_ptr.assign(rcv_ptr, rcv_ptr + nnbr + 1); }
+  REQUIRE(H.snd_ptr[0] == 0 && H.rcv_ptr[0] == 0, GMG_ERR_INVALID, "snd_ptr / rcv_ptr must start at 0");
+  for (int k = 0; k < nnbr; ++k) {
+    REQUIRE(H.snd_ptr[k] <= H.snd_ptr[k + 1] && H.rcv_ptr[k] <= H.rcv_ptr[k + 1], GMG_ERR_INVALID, "pointers not monotone");
+    REQUIRE(nbr_rank[k] >= 0 && nbr_rank[k] < comm.nranks && nbr_rank[k] != comm.rank, GMG_ERR_INVALID, "bad neighbour rank");
+  }
+  REQUIRE(H.rcv_ptr.back() == n_ghost, GMG_ERR_INVALID, "rcv_ptr must cover exactly the ghost segment");
+  const int64_t ns = H.snd_ptr.back();
+  REQUIRE(ns == 0 || snd_idx, GMG_ERR_INVALID, "null snd_idx");
+  H.h_snd_idx.assign(snd_idx, snd_idx + ns);
+  for (int64_t i = 0; i < ns; ++i) REQUIRE(snd_idx[i] >= 0 && snd_idx[i] < n_own, GMG_ERR_INVALID, "snd_idx must address owned entries");
 }
 void check_ready(gmg_handle_t h)
 {
@@ -3540,22 +3569,7 @@ int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, i
     check_level(h, lev, false);
     REQUIRE(n_own >= 0 && n_ghost >= 0 && nnbr >= 0, GMG_ERR_INVALID, "negative sizes");
     REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
-    HaloPlan &H = h->lev[lev].halo;
-    H = HaloPlan();
-    H.present = true; H.n_own = n_own; H.n_ghost = n_ghost;
-    H.nbr.assign(nbr_rank, nbr_rank + nnbr);
-    H.snd_ptr.assign(1, 0); H.rcv_ptr.assign(1, 0);
-    if (nnbr > 0) { H.snd_ptr.assign(snd_ptr, snd_ptr + nnbr + 1); H.rcv_ptr.assign(rcv_ptr, rcv_ptr + nnbr + 1); }
-    REQUIRE(H.snd_ptr[0] == 0 && H.rcv_ptr[0] == 0, GMG_ERR_INVALID, "snd_ptr / rcv_ptr must start at 0");
-    for (int k = 0; k < nnbr; ++k) {
-      REQUIRE(H.snd_ptr[k] <= H.snd_ptr[k + 1] && H.rcv_ptr[k] <= H.rcv_ptr[k + 1], GMG_ERR_INVALID, "pointers not monotone");
-      REQUIRE(nbr_rank[k] >= 0 && nbr_rank[k] < h->comm.nranks && nbr_rank[k] != h->comm.rank, GMG_ERR_INVALID, "bad neighbour rank");
-    }
-    REQUIRE(H.rcv_ptr.back() == n_ghost, GMG_ERR_INVALID, "rcv_ptr must cover exactly the ghost segment");
-    const int64_t ns = H.snd_ptr.back();
-    REQUIRE(ns == 0 || snd_idx, GMG_ERR_INVALID, "null snd_idx");
-    H.h_snd_idx.assign(snd_idx, snd_idx + ns);
-    for (int64_t i = 0; i < ns; ++i) REQUIRE(snd_idx[i] >= 0 && snd_idx[i] < n_own, GMG_ERR_INVALID, "snd_idx must address owned entries");
+    fill_plan(h->lev[lev].halo, h->comm, n_own, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr);
     h->touch();
   });
 }

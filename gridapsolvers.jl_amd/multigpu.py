@@ -373,3 +373,90 @@ def run_bench(args, rank, world, local_rank):
                      "bytes_per_launch": st["layout_bytes"], "model_12B_per_nnz_GBs": achieved,
                      "avg_launch_ms": avg_ms, "launches_timed": st["launches"]},
     }
+
+
+class DistributedBlockSolver:
+    """Distributed counterpart of solvers.BlockNumericalSetup for a 2x2 block system whose blocks live on two levels of the
+    partitioned hierarchy (the multi-rank shape of test/Applications/mpi/StokesGMG.jl: BlockTriangularSolver on BlockPMatrix /
+    BlockPVector, BlockTriangularSolvers.jl:216-242).  `gmg` is a set-up DistributedGMG (the solver of block 0); block 1 is
+    solved by CGSolver(JacobiLinearSolver()) on `M11`.  All matrices are this rank's LOCAL rows with [own | ghost] columns."""
+
+    def __init__(self, gmg: DistributedGMG, A01, A10, M11, lev0, lev1, A11=None, coeffs=((1.0, 1.0), (0.0, 1.0)), half="upper",
+                 cg=(20, 1e-14, 1e-6)):
+        lib = gmg._lib
+        self._lib, self.gmg = lib, gmg
+        sizes = np.array([lev0.n_own, lev1.n_own], dtype=np.int64)
+        self.sizes, self.n = sizes, int(sizes.sum())
+        h = C.c_void_p()
+        kind = {"diagonal": abi.BLOCK_DIAGONAL, "lower": abi.BLOCK_LOWER, "upper": abi.BLOCK_UPPER}[half]
+        dev = 0
+        try:
+            import torch
+            dev = torch.cuda.current_device()
+        except Exception:
+            pass
+        abi.check_block(None, lib.gmg_block_create(C.byref(h), 2, C.c_void_p(sizes.ctypes.data), kind, dev))
+        self.h = h
+        self._keep = []
+        if gmg.world > 1:
+            if gmg.transport == "rccl":
+                import torch.distributed as dist
+                path = rccl_path().encode()
+                uid = C.create_string_buffer(128)
+                if gmg.rank == 0:
+                    abi.check(None, lib.gmg_comm_unique_id(path, uid))
+                blob = [bytes(uid.raw) if gmg.rank == 0 else None]
+                dist.broadcast_object_list(blob, src=0)
+                abi.check_block(h, lib.gmg_block_comm_init_rccl(h, path, blob[0], gmg.rank, gmg.world))
+            else:
+                hb = gmg._host
+                abi.check_block(h, lib.gmg_block_comm_init_host(h, gmg.rank, gmg.world, C.cast(hb.exchange_cb, C.c_void_p),
+                                                                C.cast(hb.allreduce_cb, C.c_void_p), None))
+            for j, L in enumerate((lev0, lev1)):
+                nbr = np.ascontiguousarray(L.nbr_rank, dtype=np.int32)
+                sp, si, rp = (np.ascontiguousarray(a, dtype=np.int64) for a in (L.snd_ptr, L.snd_idx, L.rcv_ptr))
+                self._keep += [nbr, sp, si, rp]
+                abi.check_block(h, lib.gmg_block_set_partition(h, j, L.n_own, L.n_ghost, nbr.size, C.c_void_p(nbr.ctypes.data),
+                                                               C.c_void_p(sp.ctypes.data), C.c_void_p(si.ctypes.data), C.c_void_p(rp.ctypes.data)))
+
+        def setb(fn, i, j, M):
+            idx64 = M.idx.astype(np.int64)
+            abi.check_block(h, fn(h, i, j, M.shape[0], M.shape[1], M.nnz, C.c_void_p(M.ptr.ctypes.data), C.c_void_p(idx64.ctypes.data),
+                                  C.c_void_p(M.val.ctypes.data), abi.CSR, 0, 8))
+        setb(lib.gmg_block_set_system_block, 0, 0, lev0.A)
+        setb(lib.gmg_block_set_system_block, 0, 1, A01)
+        setb(lib.gmg_block_set_system_block, 1, 0, A10)
+        if A11 is not None:
+            setb(lib.gmg_block_set_system_block, 1, 1, A11)
+        for i in range(2):
+            for j in range(2):
+                if i != j:
+                    abi.check_block(h, lib.gmg_block_set_coeff(h, i, j, float(coeffs[i][j])))
+        abi.check_block(h, lib.gmg_block_set_diag_gmg(h, 0, gmg.h))
+        abi.check_block(h, lib.gmg_block_set_diag_solver(h, 1, abi.BLOCK_CG_JACOBI, cg[0], cg[1], cg[2]))
+        idx64 = M11.idx.astype(np.int64)
+        abi.check_block(h, lib.gmg_block_set_diag_matrix(h, 1, M11.shape[0], M11.nnz, C.c_void_p(M11.ptr.ctypes.data), C.c_void_p(idx64.ctypes.data),
+                                                         C.c_void_p(M11.val.ctypes.data), abi.CSR, 0, 8))
+        abi.check_block(h, lib.gmg_block_setup(h))
+
+    def precond_apply(self, b, x):
+        pb, ms, _k1 = _vec(b, self.n)
+        px, ms2, _k2 = _vec(x, self.n, writable=True)
+        abi.check_block(self.h, self._lib.gmg_block_precond_apply(self.h, pb, px, ms))
+        return x
+
+    def fgmres_solve(self, b, x, m=20, maxiter=100, atol=1e-10, rtol=1e-12):
+        log = ConvergenceLog("FGMRES", maxiter, atol, rtol)
+        pb, ms, _k1 = _vec(b, self.n)
+        px, ms2, _k2 = _vec(x, self.n, writable=True)
+        res = abi.Result()
+        hist = np.zeros(maxiter + 1)
+        abi.check_block(self.h, self._lib.gmg_block_fgmres_solve(self.h, pb, px, ms, m, 0, 1, maxiter, atol, rtol, 1, C.byref(res),
+                                                                 C.c_void_p(hist.ctypes.data), hist.size))
+        log._fill(res, hist)
+        return log
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.gmg_block_destroy(self.h)
+            self.h = None

@@ -307,7 +307,7 @@ GMG_API int gmg_device_bytes(gmg_handle_t h, int64_t *bytes);
  * (BlockSolvers/BlockDiagonalSolvers.jl:165-177) and BlockTriangularSolver
  * (BlockSolvers/BlockTriangularSolvers.jl:186-242) with the outer CG / FGMRES on the block system,
  * all on the device.  Block vectors are contiguous: block i occupies [off_i, off_i + size_i).
- * Single GPU.  A gmg handle given to gmg_block_set_diag_gmg stays owned by the caller, must be set up
+ * A gmg handle given to gmg_block_set_diag_gmg stays owned by the caller, must be set up
  * first, must outlive the block handle's use of it and issues its work on the block handle's stream
  * from gmg_block_setup until gmg_block_destroy. */
 typedef struct gmg_block_solver *gmg_block_handle_t;
@@ -322,6 +322,18 @@ enum gmg_block_diag_kind {
 GMG_API int gmg_block_create(gmg_block_handle_t *h, int nblocks, const int64_t *block_sizes, int kind, int device_id);
 GMG_API int gmg_block_destroy(gmg_block_handle_t h);
 GMG_API const char *gmg_block_last_error(gmg_block_handle_t h);
+/* Distributed block systems (one handle per rank, like the GMG handles): the communicator of the block solver, and per block
+ * the exchange plan of its vector space (same meaning as gmg_set_partition; blocks without ghost columns need none).  Call
+ * before the blocks are set: block (i,j) then has bsize(i) rows and bsize(j) + n_ghost(j) columns ([own | ghost] numbering
+ * of block j), block vectors hold the owned entries of every block, a GMG handle given to gmg_block_set_diag_gmg is itself
+ * distributed over the same ranks.  Reference: BlockTriangularSolvers.jl:216-242 on BlockPVector / BlockPMatrix
+ * (test/Applications/mpi/StokesGMG.jl).  LUSolver() diagonal blocks stay single-GPU. */
+GMG_API int gmg_block_comm_init_rccl(gmg_block_handle_t h, const char *rccl_path, const char *unique_id128, int rank, int nranks);
+GMG_API int gmg_block_comm_init_host(gmg_block_handle_t h, int rank, int nranks, gmg_host_exchange_fn exchange,
+                                     gmg_host_allreduce_fn allreduce, void *ctx);
+GMG_API int gmg_block_set_partition(gmg_block_handle_t h, int j, int64_t n_own, int64_t n_ghost, int nnbr,
+                                    const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
+                                    const int64_t *rcv_ptr);
 /* blocks(mat)[i,j] of the system matrix (numerical_setup(ss,mat::AbstractBlockMatrix), BlockTriangularSolvers.jl:132-152);
  * absent blocks are zero. */
 GMG_API int gmg_block_set_system_block(gmg_block_handle_t h, int i, int j, int64_t nrows, int64_t ncols, int64_t nnz,

@@ -145,6 +145,70 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
     return x[:n].copy(), it, np.array(hist)
 
 
+def block_mode(cells, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, multigpu, grid, cg):
+    """Distributed block-triangular preconditioner + FGMRES on a saddle point built from two levels of the partitioned
+    hierarchy (blocks: A_0, c R_0^T; c R_0, -(1/alpha)(I + 0.1 A_1)), GMG(maxiter=4) on block 0, CG-Jacobi on block 1 --
+    the solver shape of test/Applications/mpi/StokesGMG.jl -- against the serial oracle."""
+    import scipy.sparse as sp
+    alpha, cb = 10.0, 0.05
+    ndev = torch.cuda.device_count()
+    dev = rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
+    g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=2,
+                                gmg_maxiter=4, gmg_rtol=1e-8)
+    L0, L1 = g.local["levels"][0], g.local["levels"][1]
+
+    def scaled(M, c):
+        return po.CSR(M.shape, M.ptr, M.idx, c * M.val)
+    A01 = scaled(L0.P, cb)                               # c P_0 = (c R_0)^T, rows: own fine, cols: [own | ghost] coarse
+    A10 = scaled(L0.R, cb)
+    n2 = L1.n_own
+    I_loc = sp.csr_matrix((np.ones(n2), (np.arange(n2), np.arange(n2))), shape=(n2, n2 + L1.n_ghost))
+    Mloc = ((-1.0 / alpha) * (I_loc + 0.1 * L1.A.to_scipy())).tocsr(); Mloc.sort_indices()
+    M11 = po.CSR(Mloc.shape, Mloc.indptr, Mloc.indices, Mloc.data)
+    blk = multigpu.DistributedBlockSolver(g, A01, A10, M11, L0, L1, A11=M11)
+    N1, N2 = po.level_sizes(cg, 1), po.level_sizes(tuple(c // 2 for c in cg), 1)
+    bg = np.random.default_rng(5).uniform(-1, 1, N1 + N2)
+    b = np.concatenate([bg[:N1][L0.own_gid], bg[N1:][L1.own_gid]])
+    z = np.zeros_like(b)
+    blk.precond_apply(b, z)
+    x = np.zeros_like(b)
+    log = blk.fgmres_solve(b, x, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+    parts = [None] * world
+    dist.all_gather_object(parts, (L0.own_gid, L1.own_gid, x, z, int(log.num_iters), log.residuals[: log.num_iters + 1].tolist()))
+    if rank == 0:
+        orc = entry.import_oracle()
+        H = po.build_hierarchy(cg, nlev, 1)
+        A, R = H["mats"][0], H["restrictions"][0]
+        B = po.CSR(R.shape, R.ptr, R.idx, cb * R.val)
+        Bts = (cb * R.to_scipy().T).tocsr(); Bts.sort_indices()
+        Bt = po.CSR(Bts.shape, Bts.indptr, Bts.indices, Bts.data)
+        Mps = ((-1.0 / alpha) * (sp.identity(N2) + 0.1 * H["mats"][1].to_scipy())).tocsr(); Mps.sort_indices()
+        Mp = po.CSR(Mps.shape, Mps.indptr, Mps.indices, Mps.data)
+        Ks = sp.bmat([[A.to_scipy(), Bts], [B.to_scipy(), Mps]]).tocsr(); Ks.sort_indices()
+        K = po.CSR(Ks.shape, Ks.indptr, Ks.indices, Ks.data)
+        go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=4, rtol=1e-8)
+        Po = orc.BlockPreconditioner([N1, N2], [go, (orc.BD_CG_JACOBI, Mp, 20, 1e-14, 1e-6)], {(0, 1): (Bt, 1.0), (1, 0): (B, 0.0)}, orc.UPPER)
+        zo = Po.apply(bg)
+        go2 = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=4, rtol=1e-8)
+        Po2 = orc.BlockPreconditioner([N1, N2], [go2, (orc.BD_CG_JACOBI, Mp, 20, 1e-14, 1e-6)], {(0, 1): (Bt, 1.0), (1, 0): (B, 0.0)}, orc.UPPER)
+        xo, nit, flag, hist = orc.fgmres_solve(K, bg, Pr=Po2, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+        xg, zg = np.zeros(N1 + N2), np.zeros(N1 + N2)
+        for g0, g1, xq, zq, _, _ in parts:
+            xg[g0] = xq[: g0.size]; xg[N1 + g1] = xq[g0.size:]
+            zg[g0] = zq[: g0.size]; zg[N1 + g1] = zq[g0.size:]
+        hist_d = np.array(parts[0][5])
+        verdict = dict(iters=int(parts[0][4]), iters_oracle=int(nit), iters_all_equal=all(p[4] == parts[0][4] for p in parts),
+                       precond_rel_err=float(np.linalg.norm(zg - zo) / np.linalg.norm(zo)),
+                       rel_err=float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)),
+                       hist_dev=float(np.max(np.abs(hist_d - hist) / hist[0])) if len(hist_d) == len(hist) else 1.0,
+                       true_residual=float(np.linalg.norm(Ks @ xg - bg)), world=world, grid=list(grid), mode="gpu_block")
+        json.dump(verdict, open(out, "w"))
+    dist.barrier()
+    blk.close(); g.close()
+    dist.destroy_process_group()
+
+
 def main():
     mode, cells, nlev, out = sys.argv[1], tuple(int(c) for c in sys.argv[2].split("x")), int(sys.argv[3]), sys.argv[4]
     transport = sys.argv[5] if len(sys.argv) > 5 else "host"
@@ -164,7 +228,9 @@ def main():
     smoother = os.environ.get("GMG_TEST_SMOOTHER", "jacobi")
     p_niter, p_omega = 4, 0.2
     verdict = {}
-    if mode == "numpy":
+    if mode == "gpu_block":
+        pass
+    elif mode == "numpy":
         local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from)
         b = po.dirichlet_lift_rhs(cg, order)[local["levels"][0].own_gid]
         patches = None
@@ -203,6 +269,8 @@ def main():
         verdict["fgmres_vs_cg"] = float(np.max(np.abs(xd.cpu().numpy() - x)))
         gid = g.local["levels"][0].own_gid
         g.close()
+    if mode == "gpu_block":
+        return block_mode(cells, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, multigpu, grid, cg)
     # gather solution on rank 0
     parts = [None] * world
     dist.all_gather_object(parts, (gid, x, int(nit), hist.tolist()))

@@ -153,6 +153,19 @@ def test_overlapped_schedule_with_async_host_transport(world, cells, nlev, rep, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,cells,nlev", [(2, (16, 16, 16), 3), (4, (16, 16), 3), (8, (8, 8, 8), 3)])
+def test_distributed_block_triangular_fgmres_on_gpu_host_transport(world, cells, nlev, tmp_path):
+    """Multi-rank block preconditioner (BlockTriangularSolvers.jl:216-242 on BlockPVector / BlockPMatrix, the solver shape of
+    test/Applications/mpi/StokesGMG.jl): distributed GMG(maxiter=4) on block 0, CG-Jacobi on block 1, upper triangular, outer
+    FGMRES(20) -- one application and the whole solve against the serial oracle; halo exchanges of the off-diagonal blocks'
+    operands, all-reduced dots, distributed GMG handle borrowed by the block handle."""
+    v = _launch("gpu_block", world, cells, nlev, tmp_path, transport="host")
+    assert v["iters"] == v["iters_oracle"] and v["iters_all_equal"], v
+    assert v["precond_rel_err"] < 1e-9 and v["rel_err"] < 1e-7 and v["hist_dev"] < 1e-6, v
+    assert v["true_residual"] < 1e-7, v                                      # StokesGMG.jl:166
+
+
+@pytest.mark.gpu
 def test_rccl_binding_selftest_single_rank(pkg):
     """The dlopen'ed RCCL entry points (ncclGetUniqueId/CommInitRank/AllReduce/Send/Recv/Group*) work on
     real hardware: 1-rank communicator, all-reduce and a grouped self send/recv on the handle's stream."""
