@@ -856,4 +856,44 @@ end
 Gridap.Algebra.symbolic_setup(s::HipGMGLinearSolver, ::PA.PSparseMatrix) = HipGMGSymbolicSetup(s)
 Gridap.Algebra.symbolic_setup(s::Union{HipCGSolver,HipFGMRESSolver}, ::PA.PSparseMatrix) = HipKrylovSymbolicSetup(s)
 
+# Distributed block systems (BlockPMatrix / BlockPVector): the block handle gets its own communicator and one exchange plan
+# per block; blocks are passed as local rows with [own | ghost] columns (_local_operator), vectors as owned values.
+function block_comm_init!(bh::Ptr{Cvoid}, comm::MPI.Comm; transport::Symbol = :rccl)
+  rank, nranks = MPI.Comm_rank(comm), MPI.Comm_size(comm)
+  if transport === :rccl
+    uid = zeros(UInt8, 128)
+    rank == 0 && check(C_NULL, ccall((:gmg_comm_unique_id, libgmgamd), Cint, (Cstring,Ptr{UInt8}), C_NULL, uid))
+    MPI.Bcast!(uid, 0, comm)
+    check_block(bh, ccall((:gmg_block_comm_init_rccl, libgmgamd), Cint, (Ptr{Cvoid},Cstring,Ptr{UInt8},Cint,Cint), bh, C_NULL, uid, rank, nranks))
+  else
+    _MPI_CTX[] = comm
+    xf = @cfunction(_mpi_exchange, Cvoid, (Ptr{Cvoid},Cint,Ptr{Int32},Ptr{Float64},Ptr{Int64},Ptr{Float64},Ptr{Int64}))
+    rf = @cfunction(_mpi_allreduce, Cvoid, (Ptr{Cvoid},Ptr{Float64},Cint))
+    check_block(bh, ccall((:gmg_block_comm_init_host, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Ptr{Cvoid},Ptr{Cvoid},Ptr{Cvoid}), bh, rank, nranks, xf, rf, C_NULL))
+  end
+end
+function block_set_partition!(bh::Ptr{Cvoid}, j::Integer, pl::HipDistributedLevel)
+  GC.@preserve pl check_block(bh, ccall((:gmg_block_set_partition, libgmgamd), Cint,
+    (Ptr{Cvoid},Cint,Int64,Int64,Cint,Ptr{Int32},Ptr{Int64},Ptr{Int64},Ptr{Int64}),
+    bh, j-1, pl.n_own, pl.n_ghost, length(pl.nbr), pl.nbr, pl.snd_ptr, pl.snd_idx, pl.rcv_ptr))
+end
+# rhs form of a patch prolongation when it is not the level operator (StokesGMG.jl:125-127)
+function set_prolongation_correction_rhs!(ns::HipGMGNumericalSetup, lev::Integer, G::SparseMatrixCSC{Float64,Int64})
+  GC.@preserve G check(ns.handle, ccall((:gmg_set_prolongation_patch_correction_rhs, libgmgamd), Cint,
+    (Ptr{Cvoid},Cint,Int64,Int64,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint,Cint),
+    ns.handle, lev-1, size(G,1), nnz(G), G.colptr, G.rowval, G.nzval, GMG_CSC, 1, 8))
+  return ns
+end
+# FGMRES with a left preconditioner as well (KrylovUtils.jl:14-18,46-50): pl = 0 none, 2 Jacobi, 3 the finest pre-smoother
+function fgmres_solve_pl!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<:HipFGMRESSolver}, b::Vector{Float64}, pl::Integer)
+  s, h = ns.solver, ns.P_ns.handle
+  tols = s.log.tols
+  res  = Ref(GmgResult(0,0,0.0,0.0)); hist = zeros(tols.maxiter+1)
+  GC.@preserve x b hist check(h, ccall((:gmg_fgmres_solve_pl, libgmgamd), Cint,
+    (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Cint,Cint,Cint,Cint,Float64,Float64,Cint,Cint,Ref{GmgResult},Ptr{Float64},Cint),
+    h, b, x, GMG_MEM_HOST, s.m, s.restart ? 1 : 0, s.m_add, tols.maxiter, tols.atol, tols.rtol, 1, pl, res, hist, length(hist)))
+  _fill_log!(s.log, res[], hist)
+  return x
+end
+
 end # module
