@@ -217,6 +217,11 @@ struct DevCSR {
   uint8_t *pcodes = nullptr;
   double *pdict = nullptr;
   uint32_t *prunmask = nullptr;
+  // offset-pattern layout (SELL-O): SELL-64 value stream + a 16-bit offset-pattern id per row, no column stream
+  bool opat = false;
+  uint16_t *orowpid = nullptr;
+  int32_t *orowbase = nullptr, *opoff = nullptr;
+  int opat_np = 0, opat_w = 0;
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -473,6 +478,7 @@ struct gmg_solver {
   int pat_un = 9;       // GMG_PAT_UN: gathers in flight per lane in sellp_kernel
   int pat_wgs = 2048;   // GMG_PAT_WGS: resident workgroups of the persistent sellp launch
   int pat_rb = 3;       // GMG_PAT_RB: runs (of 3 offsets) loaded per batch in sells_kernel (3 or 9)
+  int use_opattern = 1; // GMG_OPATTERN: offset-pattern layout (SELL-O) for SELL-64 matrices whose column structure repeats
   int pat_batched = 1;  // GMG_PAT_BATCHED: the restructured sweep kernel (sells_sweep_kernel) for plain shared-offset tables
   int pat_nb = 0;       // GMG_PAT_NB: slices per batch of that kernel (0 = auto: 1, or 2 on levels with >= 200000 slices)
   int pat_small_wpb = 4;   // GMG_PAT_SMALL_WPB: waves per workgroup of sells_kernel on levels with < 8192 slices (table staging amortised)
@@ -624,9 +630,11 @@ struct gmg_solver {
   // the row index, mode 0, or to their first column, mode 1) and the BITS of their values are equal.
   // Chunks of rows are scanned in parallel with thread-local tables that are merged in chunk order
   // (deterministic ids).  Gives up as soon as the table outgrows LDS.
+  // ignore_values: rows are equal when their lengths and column offsets are (values may differ): the offset-pattern layout
+  // of variable-coefficient operators on structured meshes (SELL-O, sello_kernel)
   bool detect_patterns(const HostCSR &H, int mode, std::vector<uint16_t> &rowpid, std::vector<int32_t> &rowbase,
                        std::vector<int32_t> &plen, std::vector<int32_t> &poff, std::vector<double> &pval, int &W,
-                       bool allow_big, bool &generic_fits)
+                       bool allow_big, bool &generic_fits, bool ignore_values = false)
   {
     constexpr int kMaxTableBytes = 48 * 1024;
     generic_fits = false;
@@ -657,7 +665,7 @@ struct gmg_solver {
       for (int64_t j = 0; j < len; ++j) {
         uint64_t bits;
         std::memcpy(&bits, &H.val[k0 + j], 8);
-        if (L.off[st + j] != H.col[k0 + j] - base || L.val[st + j] != bits) return false;
+        if (L.off[st + j] != H.col[k0 + j] - base || (!ignore_values && L.val[st + j] != bits)) return false;
       }
       return true;
     };
@@ -672,7 +680,7 @@ struct gmg_solver {
           uint64_t bits;
           std::memcpy(&bits, &H.val[k0 + j], 8);
           h = (h ^ (uint64_t)(uint32_t)(H.col[k0 + j] - base)) * 1099511628211ull;
-          h = (h ^ bits) * 1099511628211ull;
+          if (!ignore_values) h = (h ^ bits) * 1099511628211ull;
           h ^= h >> 29;
         }
         auto &bucket = L.index[h];
@@ -710,7 +718,7 @@ struct gmg_solver {
           if (G.len[q] != L.len[p]) continue;
           bool eq = true;
           for (int32_t j = 0; j < L.len[p] && eq; ++j)
-            eq = G.off[G.start[q] + j] == L.off[L.start[p] + j] && G.val[G.start[q] + j] == L.val[L.start[p] + j];
+            eq = G.off[G.start[q] + j] == L.off[L.start[p] + j] && (ignore_values || G.val[G.start[q] + j] == L.val[L.start[p] + j]);
           if (eq) { found = q; break; }
         }
         if (found < 0) {
@@ -1260,6 +1268,25 @@ struct gmg_solver {
     // values the packed decode costs more than the 2 B/nnz it saves, profiles/r01_tuning.md)
     D.vdict = !pcode.empty();
     D.comp_idx = n16 > 0 && (D.vdict || use_idx16 > 1);
+    if (!D.vdict && !D.comp_idx && use_opattern && H.nrows >= 64 && H.ncols < (int64_t)(1 << 28)) {
+      // values differ from row to row (no dictionary) but the COLUMN structure may still be a handful of offset patterns
+      // (variable coefficients on a structured mesh): then the 4 B/nnz column stream is replaced by 2 B/row
+      std::vector<uint16_t> orowpid;
+      std::vector<int32_t> orowbase, oplen, opoff;
+      std::vector<double> opval;
+      int OW = 0;
+      bool gfit = false;
+      bool ok = (H.ncols >= H.nrows) && detect_patterns(H, 0, orowpid, orowbase, oplen, opoff, opval, OW, false, gfit, true);
+      if (!ok) ok = detect_patterns(H, 1, orowpid, orowbase, oplen, opoff, opval, OW, false, gfit, true);
+      if (ok && (int64_t)oplen.size() * OW * 4 <= 32 * 1024) {
+        D.orowpid = upload_padded(orowpid, 64);
+        D.orowbase = orowbase.empty() ? nullptr : upload_padded(orowbase, 64);
+        D.opoff = upload(opoff);
+        D.opat_np = (int)oplen.size(); D.opat_w = OW;
+        D.opat = true;
+        D.stream_bytes_per_nnz = 8.0 + (orowbase.empty() ? 2.0 : 6.0) * (double)H.nrows / (double)D.nnz;
+      }
+    }
     if (!D.comp_idx) { std::fill(smode.begin(), smode.end(), 0); n16 = 0; }
     if (D.comp_idx || D.vdict) {
       D.poff = upload(poff); D.smode = upload(smode); D.zpack = zpp;
@@ -1293,10 +1320,34 @@ struct gmg_solver {
     HIP_CHECK(hipGetLastError());
   }
   template <int EPI, bool ONEG>
+  void launch_sello(const DevCSR &M, const StreamArgs2 &a2)
+  {
+    SellOArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.soff = M.soff; a.sval = M.sval; a.rowlen = M.rowlen; a.rowpid = M.orowpid; a.rowbase = M.orowbase; a.poff = M.opoff;
+    a.np = M.opat_np; a.W = M.opat_w; a.nrows = M.nrows; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
+    a.x_zero = a2.x_zero; a.x = a2.x; a.dinv = a2.dinv; a.omega = a2.omega; a.y = a2.y; a.b = a2.b; a.x2 = a2.x2; a.s_out = a2.s_out;
+    const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
+    const dim3 g((M.nslices + wpb - 1) / wpb), b(64 * wpb);
+    const size_t lds = (size_t)M.opat_np * M.opat_w * 4;
+    const bool nt = nt_loads && (8.0 * (double)M.zpad > 128.0e6);
+#define GMG_SELLO_LAUNCH(UNV)                                                                         \
+    do {                                                                                                \
+      if (nt) hipLaunchKernelGGL((sello_kernel<EPI, ONEG, UNV, true>), g, b, lds, stream, a);            \
+      else hipLaunchKernelGGL((sello_kernel<EPI, ONEG, UNV, false>), g, b, lds, stream, a);              \
+    } while (0)
+    if (sell_un >= 27) GMG_SELLO_LAUNCH(27);
+    else if (sell_un >= 9) GMG_SELLO_LAUNCH(9);
+    else GMG_SELLO_LAUNCH(3);
+#undef GMG_SELLO_LAUNCH
+    HIP_CHECK(hipGetLastError());
+  }
+  template <int EPI, bool ONEG>
   void launch_sell(const DevCSR &M, const StreamArgs2 &a2)
   {
     if (M.pat) { launch_sellp<EPI, ONEG>(M, a2); return; }
     if (M.comp_idx || M.vdict) { launch_sellc<EPI, ONEG>(M, a2); return; }
+    if (M.opat) { launch_sello<EPI, ONEG>(M, a2); return; }
     SellArgs a;
     std::memset(&a, 0, sizeof(a));
     a.soff = M.soff; a.scol = M.scol; a.sval = M.sval; a.rowlen = M.rowlen; a.nrows = M.nrows; a.nslices = M.nslices; a.xcd_remap = xcd_remap;
@@ -1902,6 +1953,7 @@ struct gmg_solver {
     pat_dinv = env_int("GMG_PAT_DINV", 1);
     pat_rb = env_int("GMG_PAT_RB", 3); pat_rb = pat_rb >= 9 ? 9 : (pat_rb <= 1 ? 1 : 3);
     pat_batched = env_int("GMG_PAT_BATCHED", 1);
+    use_opattern = env_int("GMG_OPATTERN", 1);
     pat_nb = std::min(2, std::max(0, env_int("GMG_PAT_NB", 0)));
     tile = kTile;
   }
@@ -1955,6 +2007,7 @@ struct gmg_solver {
       if (pat_dinv && A.pdinv) vec -= 8.0 * N;             // 1/diag from the pattern table
       if (pat_defer) vec -= 4.0 * N;                       // x touched every second sweep: (8+8+8)/2 instead of 8+8
     } else if (A.pat) mat = (A.rowbase ? 6.0 : 2.0) * N;
+    else if (A.sell && A.opat) mat = 8.0 * (double)A.zpad + (A.orowbase ? 6.0 : 2.0) * N + 4.0 * N + 8.0 * (double)A.nslices;
     else if (A.sell && (A.comp_idx || A.vdict)) mat = A.stream_bytes_per_nnz * (double)A.zpack + 4.0 * N + 4.0 * (double)(A.zpack / 64);
     else if (A.sell) mat = 12.0 * (double)A.zpad + 4.0 * N + 8.0 * (double)A.nslices;
     else mat = 12.0 * (double)A.nnz + (A.ptr64 ? 8.0 : 4.0) * N;
@@ -3653,10 +3706,10 @@ int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
     check_ready(h);
     check_level(h, lev, false);
     const DevCSR &A = h->lev[lev].A;
-    if (sell) *sell = A.pat ? 2 : (A.sell ? 1 : 0);
+    if (sell) *sell = A.pat ? 2 : (A.sell ? (A.opat ? 3 : 1) : 0);
     if (vdict) *vdict = A.vdict ? 1 : 0;
     if (idx16) *idx16 = A.comp_idx ? 1 : 0;
-    if (stream_bytes_per_nnz) *stream_bytes_per_nnz = (A.sell && (A.pat || A.vdict || A.comp_idx)) ? A.stream_bytes_per_nnz : 12.0;
+    if (stream_bytes_per_nnz) *stream_bytes_per_nnz = (A.sell && (A.pat || A.vdict || A.comp_idx || A.opat)) ? A.stream_bytes_per_nnz : 12.0;
     if (padding) *padding = A.sell && A.nnz > 0 ? (double)A.zpad / (double)A.nnz : 1.0;
   });
 }

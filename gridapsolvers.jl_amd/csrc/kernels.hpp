@@ -320,6 +320,119 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
   }
 }
 
+// x[byte offset]: uniform base + 32-bit lane offset (the saddr + voffset form of global_load)
+__device__ __forceinline__ double ld_off(const double *__restrict__ base, uint32_t byteoff)
+{
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff);
+}
+
+// ---------------------------------------------------------------------------
+// SELL-O ("offset patterns"): the SELL-64 kernel without its column stream.  Variable-coefficient operators on
+// structured meshes have as many distinct VALUES as entries, but their column STRUCTURE is a handful of offset
+// patterns (27-point stencil: 27 boundary types).  The setup detects that (rows equal up to their values), keeps the
+// value stream of SELL-64 (8 B/nnz, coalesced) and replaces the column stream (4 B/nnz) by a 16-bit offset-pattern id
+// per row; the offsets come from a small LDS table.  Same products, same left-to-right order as sell_kernel / the CSR
+// gather: bit-identical.  12 -> 8 B per stored nonzero.
+// ---------------------------------------------------------------------------
+struct SellOArgs {
+  const int64_t *soff;      // [nslices+1] offsets into sval (multiples of 64)
+  const double *sval;       // padded, column-major per slice (padding = 0.0, masked by rowlen)
+  const int32_t *rowlen;
+  const uint16_t *rowpid;   // [nrows] offset pattern of each row
+  const int32_t *rowbase;   // [nrows] base column, or nullptr: offsets are relative to the row index
+  const int32_t *poff;      // [np*W] BYTE offsets (8 * column offset), zero padded (the last pattern is empty)
+  int np, W;
+  int64_t nrows;
+  int nslices;
+  int x_zero;
+  int xcd_remap;
+  const double *x;
+  const double *dinv;
+  double omega;
+  double *y;
+  const double *b;
+  double *x2;
+  double *s_out;
+};
+
+template <int EPI, bool ONEG, int UN, bool NT>
+__global__ __launch_bounds__(kBlock) void sello_kernel(SellOArgs a)
+{
+  extern __shared__ double sp_smem[];
+  int32_t *s_off = reinterpret_cast<int32_t *>(sp_smem);
+  const int tot = a.np * a.W;
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) s_off[i] = a.poff[i];
+  const int lane = threadIdx.x & 63;
+  const int slice = __builtin_amdgcn_readfirstlane((int)(remap_block(blockIdx.x, gridDim.x, a.xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const bool live = slice < a.nslices;
+  const int sc = live ? slice : a.nslices - 1;
+  const int64_t base = a.soff[sc];
+  const int w = (int)((a.soff[sc + 1] - base) >> 6);
+  const int64_t row = (int64_t)sc * 64 + lane;
+  const bool valid = live && row < a.nrows;
+  const int64_t rc = min(row, a.nrows - 1);
+  const int len = valid ? a.rowlen[rc] : 0;
+  const int pid = (int)a.rowpid[rc];
+  const uint32_t base8 = 8u * (uint32_t)(a.rowbase ? a.rowbase[rc] : (int32_t)rc);
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  // row-wise epilogue operands (coalesced), requested before the stream; clamped addresses, no divergence
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+  if (EPI == EPI_SUB) e0 = a.y[rc];
+  else if (EPI == EPI_RESID) e0 = a.b[rc];
+  else if (EPI == EPI_ADDTO) e0 = a.x2[rc];
+  else if (EPI == EPI_SWEEP) {
+    e0 = a.b[rc];
+    e1 = ONEG ? xg[rc] : dinv[rc];
+    { const double xl = a.x2[rc]; e2 = a.x_zero ? 0.0 : xl; }
+    if (ONEG) dinv_row = dinv[rc];
+  }
+  __syncthreads();
+  const double *vp = a.sval + base + lane;
+  const int32_t *to = s_off + pid * a.W;
+  double s = 0.0;
+  int j = 0;
+  for (; j + UN <= w; j += UN) {
+    double v[UN], g[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) v[u] = NT ? __builtin_nontemporal_load(vp + (int64_t)(j + u) * 64) : vp[(int64_t)(j + u) * 64];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {    // entries past the end of the row have offset 0: they gather the row's base column (valid)
+      const uint32_t c8 = base8 + (uint32_t)((j + u < a.W) ? to[j + u] : 0);
+      if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (ld_off(dinv, c8) * ld_off(xg, c8));
+      else g[u] = ld_off(xg, c8);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const double pr = v[u] * g[u];
+      s = (j + u < len) ? s + pr : s;   // masked: padding is never added
+    }
+  }
+  for (; j < w; ++j) {
+    const double v = vp[(int64_t)j * 64];
+    const uint32_t c8 = base8 + (uint32_t)((j < a.W) ? to[j] : 0);
+    double g;
+    if (EPI == EPI_SWEEP && !ONEG) g = omega * (ld_off(dinv, c8) * ld_off(xg, c8));
+    else g = ld_off(xg, c8);
+    const double pr = v * g;
+    s = (j < len) ? s + pr : s;
+  }
+  if (valid) {
+    if (EPI == EPI_SET) a.y[row] = s;
+    else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+    else if (EPI == EPI_RESID) a.y[row] = e0 - s;
+    else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+    else {
+      const double dxi = ONEG ? e1 : omega * (e1 * e0);
+      a.x2[row] = e2 + dxi;
+      const double rn = e0 - s;
+      a.y[row] = rn;
+      if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Compressed SELL-64 ("SELL-C"): the same lane-per-row kernel fed by a losslessly
 // compressed matrix stream.  Two independent, automatically detected compressions:
@@ -507,12 +620,6 @@ struct SellPArgs {
   double *x2;
   double *s_out;
 };
-
-// x[byte offset]: uniform base + 32-bit lane offset (the saddr + voffset form of global_load)
-__device__ __forceinline__ double ld_off(const double *__restrict__ base, uint32_t byteoff)
-{
-  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff);
-}
 
 // GT = true: the pattern table is too big for LDS (many patterns x wide rows, e.g. Q2 transfer operators) and is read
 // from global memory instead -- it is a few hundred KB and stays in L2; same arithmetic, same order.

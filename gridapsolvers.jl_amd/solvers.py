@@ -556,7 +556,7 @@ class GMGNumericalSetup:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         d, e = C.c_double(0.0), C.c_double(0.0)
         abi.check(self.h, self._lib.gmg_level_format(self.h, lev, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e)))
-        return dict(layout=("CSR-stream", "SELL-64", "SELL-P")[a.value], row_patterns=(a.value == 2),
+        return dict(layout=("CSR-stream", "SELL-64", "SELL-P", "SELL-O")[a.value], row_patterns=(a.value == 2),
                     value_dictionary=bool(b.value), idx16=bool(c.value), stream_bytes_per_nnz=d.value, padding=e.value)
 
     def device_bytes(self):

@@ -291,7 +291,7 @@ GMG_API int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out);
 /* Algorithmic bytes (SURVEY 8d byte model) of one V-cycle / one CG iteration. */
 GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes);
 /* Storage chosen for A_lev at setup: *sell = 0 CSR-stream, 1 SELL-64 / SELL-C, 2 SELL-P (row-pattern
- * dictionary); 8-bit value dictionary, 16-bit column offsets, bytes of matrix stream per stored nonzero,
+ * dictionary), 3 SELL-O (SELL-64 value stream, column offsets from an offset-pattern table); 8-bit value dictionary, 16-bit column offsets, bytes of matrix stream per stored nonzero,
  * padding factor. */
 GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
                              double *stream_bytes_per_nnz, double *padding);

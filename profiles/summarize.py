@@ -28,7 +28,7 @@ def db(path):
 def family(name):
     if "gmg::sells_sweep_kernel<" in name:          # the fused sweep on the shared-offset pattern table (XM = 0/1/2 variants)
         return "sells_kernel"
-    for fam in ("sells_kernel", "sellp_kernel", "sellc_kernel", "sell_kernel", "csr_stream1_kernel"):
+    for fam in ("sells_kernel", "sellp_kernel", "sellc_kernel", "sello_kernel", "sell_kernel", "csr_stream1_kernel"):
         if "gmg::" + fam + "<" in name:
             return fam
     return None

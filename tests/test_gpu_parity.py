@@ -419,7 +419,8 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
     b = po.dirichlet_lift_rhs(nc, 1)
     r = seeded(b.size, 41)
     out = {}
-    for name, env in {"csr": dict(GMG_SELL="0"), "sell": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="0", GMG_PATTERN="0"),
+    for name, env in {"csr": dict(GMG_SELL="0"), "sell": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="0", GMG_PATTERN="0", GMG_OPATTERN="0"),
+                      "sell_offsets": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="0", GMG_PATTERN="0", GMG_OPATTERN="1"),
                       "sellc": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="1", GMG_PATTERN="0"),
                       "sell_idx16": dict(GMG_SELL="1", GMG_VDICT="0", GMG_IDX16="2", GMG_PATTERN="0"),
                       "sell_dict": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="0", GMG_PATTERN="0"),
@@ -428,7 +429,7 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
                       "pattern_generic": dict(GMG_PATTERN="1", GMG_PAT_SHARED="0"),
                       "pattern_generic_un3": dict(GMG_PATTERN="1", GMG_PAT_SHARED="0", GMG_PAT_UN="3"),
                       "pattern_two_gather": dict(GMG_PATTERN="1", GMG_ONE_GATHER="0")}.items():
-        for k in ("GMG_SELL", "GMG_VDICT", "GMG_IDX16", "GMG_PATTERN", "GMG_PAT_SHARED", "GMG_PAT_RB", "GMG_PAT_UN", "GMG_ONE_GATHER"):
+        for k in ("GMG_SELL", "GMG_VDICT", "GMG_IDX16", "GMG_PATTERN", "GMG_PAT_SHARED", "GMG_PAT_RB", "GMG_PAT_UN", "GMG_ONE_GATHER", "GMG_OPATTERN"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -439,7 +440,8 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
         z = np.zeros_like(r)
         S.solve_(z, ns.P_ns, r)
         out[name] = (x, z, solver.log.num_iters, solver.log.residuals[: solver.log.num_iters + 1].copy())
-        assert ns.P_ns.level_format(0)["layout"] == ("CSR-stream" if name == "csr" else "SELL-P" if name.startswith("pattern") else "SELL-64"), name
+        assert ns.P_ns.level_format(0)["layout"] == ("CSR-stream" if name == "csr" else "SELL-P" if name.startswith("pattern") else
+                                                    "SELL-O" if name == "sell_offsets" else "SELL-64"), name
     go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
     xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
     zo = go.solve(r)[0]
@@ -448,7 +450,7 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
         assert rel_err(x, xo) <= 1e-10 and rel_err(z, zo) <= TOL_VCYCLE, name
         np.testing.assert_allclose(h, hist, rtol=TOL_HIST)
     # (the row-pattern kernels add explicit +0.0 terms for absent entries: the bits of the sums do not change)
-    for name in ("sellc", "sell_idx16", "sell_dict", "pattern_shared", "pattern_shared_rb9", "pattern_generic", "pattern_generic_un3"):
+    for name in ("sell_offsets", "sellc", "sell_idx16", "sell_dict", "pattern_shared", "pattern_shared_rb9", "pattern_generic", "pattern_generic_un3"):
         assert np.array_equal(out[name][0], out["sell"][0]) and np.array_equal(out[name][1], out["sell"][1]), name
 
 
