@@ -208,6 +208,7 @@ struct DevCSR {
   // shared-offset ("stencil") form of the pattern table: see kernels.hpp sells_kernel
   bool pat_shared = false;
   PatEntry *ptab = nullptr;
+  double *ptab8 = nullptr;        // the coefficients of ptab alone (8 B per entry): unmasked sweep kernels
   int32_t *prun = nullptr;
   int pat_nruns = 0, pat_minoff = 0, pat_maxoff = 0;
   double *pdinv = nullptr;      // [np] 1/diag per pattern (nullptr: some pattern has no diagonal entry)
@@ -306,6 +307,9 @@ struct Level {
   double *x = nullptr;            // correction at this level (levels > 0)
   double *rbuf[2] = {nullptr, nullptr};
   double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
+  uint32_t *pflags = nullptr;     // persistent smoothing pass (sells_smooth_kernel): one progress word per workgroup, 64 B apart
+  int pf_nwg = 0;
+  uint32_t pf_epoch = 1;
   double *dx = nullptr;
   double *rcur = nullptr;         // buffer holding the current residual after a cycle
 };
@@ -485,6 +489,11 @@ struct gmg_solver {
   int pat_small_wpb2 = 1;  // GMG_PAT_SMALL_WPB2: the same for sellp_kernel
   int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
   int64_t pat_coded_min_rows = 500000;   // GMG_PAT_CODED_MIN_ROWS
+  int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
+  int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
+  int persist_max_slices = 0;  // GMG_PERSIST_MAX_SLICES (0: what one workgroup per CU holds)
+  int n_cus = 0;
+  uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
   int pat_dinv = 1;     // GMG_PAT_DINV: Jacobi inverse diagonal from the pattern table instead of its vector
   int pat_shared = 1;   // GMG_PAT_SHARED: shared-offset (stencil) form when the offsets are row-relative
@@ -567,6 +576,7 @@ struct gmg_solver {
       L.ptmp = L.pcor = nullptr; L.pcorr.built = false;
       L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
       L.sbuf[0] = L.sbuf[1] = nullptr;
+      L.pflags = nullptr; L.pf_nwg = 0; L.pf_epoch = 1;
       for (Smoother *sp : {&L.pre, &L.post, &L.pcorr}) sp->reset_device();
       L.s0_ready = false;
     }
@@ -1044,7 +1054,12 @@ struct gmg_solver {
         for (size_t q = 0; q < keys.size(); ++q) std::memcpy(&dict[q], &keys[q], 8);
         D.pcodes = upload_padded(codes, 64);
         D.pdict = upload(dict);
-      } else D.ptab = upload(tab);
+      } else {
+        D.ptab = upload(tab);
+        std::vector<double> tab8(tab.size());
+        for (size_t q = 0; q < tab.size(); ++q) tab8[q] = tab[q].v;
+        D.ptab8 = upload(tab8);
+      }
       D.prun = upload(runs);
       D.pat_nruns = nruns;
       D.pat_k = c.k;
@@ -1060,7 +1075,7 @@ struct gmg_solver {
   {
     SellSArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.rowpid = M.rowpid; a.tab = M.ptab; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
+    a.rowpid = M.rowpid; a.tab = M.ptab; a.tab8 = M.ptab8; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
     a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff;
     a.xmode = a2.xmode; a.pdinv = (EPI == EPI_SWEEP && a2.dinv_from_table) ? M.pdinv : nullptr;
     a.codes = M.pcodes; a.dict = M.pdict; a.runmask = M.prunmask;
@@ -1082,10 +1097,16 @@ struct gmg_solver {
       const int wg2 = std::max(1, std::min((nsl + wpb - 1) / wpb, nb >= 2 && pat_wgs == 2048 ? 1024 : pat_wgs));
       const dim3 g2(wg2);
       const size_t lds2 = (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16;    // 16-byte {value, mask} entries
+      const bool mk = pat_strict || !M.ptab8;
 #define GMG_SWEEP_LAUNCH(XMV, NBV)                                                                             \
       do {                                                                                                       \
-        if (td) hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, true>), g2, b, lds2, stream, a);                \
-        else hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, false>), g2, b, lds2, stream, a);                  \
+        if (mk) {                                                                                                \
+          if (td) hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, true, true>), g2, b, lds2, stream, a);        \
+          else hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, false, true>), g2, b, lds2, stream, a);          \
+        } else {                                                                                                 \
+          if (td) hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, true, false>), g2, b, lds2, stream, a);       \
+          else hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, false, false>), g2, b, lds2, stream, a);         \
+        }                                                                                                        \
       } while (0)
       if (nb >= 2) { if (a.xmode == 0) GMG_SWEEP_LAUNCH(0, 2); else if (a.xmode == 1) GMG_SWEEP_LAUNCH(1, 2); else GMG_SWEEP_LAUNCH(2, 2); }
       else { if (a.xmode == 0) GMG_SWEEP_LAUNCH(0, 1); else if (a.xmode == 1) GMG_SWEEP_LAUNCH(1, 1); else GMG_SWEEP_LAUNCH(2, 1); }
@@ -1662,6 +1683,7 @@ struct gmg_solver {
   {
     HIP_CHECK(hipMemcpyAsync(h_scalars + slot, d_scalars + slot, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
+    check_persistent();
     return h_scalars[slot];
   }
   double dot(int64_t n, const double *a, const double *b)
@@ -1678,6 +1700,74 @@ struct gmg_solver {
   // ---- smoother ---------------------------------------------------------------
   void build_patch(Level &L, Smoother &S, bool blocks_only = false);
   void patch_precond(Level &L, Smoother &S, const double *r, double omega, bool relax, double *dx, double *x);
+
+  // One launch for the whole pass on small single-GPU levels in the shared-offset pattern form (see sells_smooth_kernel).
+  // s_0 is in L.sbuf[0].  Returns false when the level does not qualify (the caller then runs sweep by sweep).
+  bool smooth_persistent(int l, const Smoother &S, double *x, const double *r_in, double *r_out, bool x_zero)
+  {
+    Level &L = lev[l];
+    const DevCSR &M = L.A;
+    if (!persist || comm.nranks > 1 || l == prof_level || S.niter < 2) return false;
+    if (!(M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && M.pat_nruns % 3 == 0)) return false;
+    const int nu = M.pat_k * M.pat_nruns;
+    const size_t lds = (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16;
+    if (lds > 64 * 1024) return false;
+    if (n_cus <= 0) {
+      hipDeviceProp_t prop;
+      HIP_CHECK(hipGetDeviceProperties(&prop, device));
+      n_cus = std::max(1, prop.multiProcessorCount);
+    }
+    const int rows = 65 - M.pat_k;
+    const int nsl = (int)((M.nrows + rows - 1) / rows);
+    const int cap = persist_max_slices > 0 ? persist_max_slices : n_cus * 16 * 2;
+    if (nsl > cap || nsl > n_cus * 16 * 2 || M.nrows >= (int64_t)1 << 30) return false;
+    // geometry: as many workgroups as CUs allow (latency-bound: spread the waves), one or two slices per wave
+    int wpb = 1;
+    while (wpb < 16 && (nsl + wpb - 1) / wpb > n_cus) wpb *= 2;
+    int ns = (nsl + wpb - 1) / wpb > n_cus ? 2 : 1;
+    const int64_t reach = std::max<int64_t>(-(int64_t)M.pat_minoff, (int64_t)M.pat_maxoff + 2);
+    int halo = (int)((reach + (int64_t)wpb * ns * rows - 1) / ((int64_t)wpb * ns * rows));
+    while (2 * halo + 1 > 64 && wpb < 16) { wpb *= 2; halo = (int)((reach + (int64_t)wpb * ns * rows - 1) / ((int64_t)wpb * ns * rows)); }
+    if (2 * halo + 1 > 64) return false;
+    const int nwg = (nsl + wpb * ns - 1) / (wpb * ns);
+    if (nwg > n_cus) return false;
+    if (!L.pflags || L.pf_nwg < nwg) {
+      L.pflags = dalloc<uint32_t>((size_t)nwg * 16);
+      HIP_CHECK(hipMemsetAsync(L.pflags, 0, sizeof(uint32_t) * (size_t)nwg * 16, stream));
+      L.pf_nwg = nwg; L.pf_epoch = 1;
+    }
+    if (!h_perr) {
+      HIP_CHECK(hipHostMalloc((void **)&h_perr, 64, hipHostMallocMapped));
+      *h_perr = 0;
+      HIP_CHECK(hipHostGetDevicePointer((void **)&d_perr, h_perr, 0));
+    }
+    SellSmoothArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rowpid = M.rowpid; a.tab = M.ptab; a.tab8 = M.ptab8; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
+    a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl;
+    a.pdinv = pat_dinv ? M.pdinv : nullptr; a.dinv = L.dinv; a.omega = S.omega;
+    a.niter = S.niter; a.x_zero = x_zero ? 1 : 0;
+    a.r_in = r_in; a.r_out = r_out; a.x = x; a.s_a = L.sbuf[0]; a.s_b = L.sbuf[1];
+    a.flags = L.pflags; a.epoch = L.pf_epoch; a.err = d_perr; a.halo_wg = halo;
+    L.pf_epoch += (uint32_t)S.niter;
+    const dim3 g(nwg), b(64 * wpb);
+    const bool td = a.pdinv != nullptr;
+    const bool mk = pat_strict || !M.ptab8;
+#define GMG_SMOOTH_LAUNCH(NSV, TDV)                                                                            \
+    do {                                                                                                         \
+      if (mk) hipLaunchKernelGGL((sells_smooth_kernel<NSV, TDV, true>), g, b, lds, stream, a);                   \
+      else hipLaunchKernelGGL((sells_smooth_kernel<NSV, TDV, false>), g, b, lds, stream, a);                     \
+    } while (0)
+    if (ns == 2) { if (td) GMG_SMOOTH_LAUNCH(2, true); else GMG_SMOOTH_LAUNCH(2, false); }
+    else { if (td) GMG_SMOOTH_LAUNCH(1, true); else GMG_SMOOTH_LAUNCH(1, false); }
+#undef GMG_SMOOTH_LAUNCH
+    HIP_CHECK(hipGetLastError());
+    return true;
+  }
+  void check_persistent() const
+  {
+    REQUIRE(!(h_perr && *h_perr), GMG_ERR_STATE, "persistent smoothing pass: a neighbour wait timed out (workgroups not co-resident?); set GMG_PERSIST=0");
+  }
 
   // solve!(x,ns::RichardsonSmootherNumericalSetup,r), RichardsonSmoothers.jl:84-98.
   // r_in may be a caller-owned read-only vector; returns the buffer holding the
@@ -1702,6 +1792,7 @@ struct gmg_solver {
       L.s0_ready = false;
       const double *cur = r_in;
       double *out = r_internal ? const_cast<double *>(r_in) : L.rbuf[0];
+      if (smooth_persistent(l, S, x, r_in, out, x_zero)) return out;
       // shared-offset pattern kernel: x is updated every second sweep with both increments,
       // x = (x + s_{k-1}) + s_k (the same two roundings), which saves one read+write of x per pair
       const bool defer = pat_defer && L.A.pat_shared;
@@ -1946,6 +2037,9 @@ struct gmg_solver {
     halo_fuse_pack = env_int("GMG_HALO_FUSE_PACK", 1);
     prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
     pat_defer = env_int("GMG_PAT_DEFER", 1);
+    persist = env_int("GMG_PERSIST", 1);
+    pat_strict = env_int("GMG_PAT_STRICT", 1);
+    persist_max_slices = env_int("GMG_PERSIST_MAX_SLICES", 0);
     pat_coded_min_rows = env_int("GMG_PAT_CODED_MIN_ROWS", 500000);
     pat_emit = env_int("GMG_PAT_EMIT", 1);
     pat_small_wpb = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB", 4)));
@@ -3050,6 +3144,7 @@ int gmg_destroy(gmg_handle_t h)
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
   if (h->h_scalars) (void)hipHostFree(h->h_scalars);
+  if (h->h_perr) (void)hipHostFree(h->h_perr);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return GMG_OK;

@@ -732,6 +732,7 @@ struct alignas(16) PatEntry {
 struct SellSArgs {
   const uint16_t *rowpid;
   const PatEntry *tab;      // [np * nu], nu = K * nruns ; the last pattern is empty
+  const double *tab8;       // the coefficients alone (unmasked sweep kernels)
   const uint8_t *codes;     // coded form (VD): [np * nu] index into dict, 255 = entry absent
   const double *dict;       // coded form: [256] distinct values, dict[255] = 0.0
   const uint32_t *runmask;  // coded form: [np] bit r set when the pattern has an entry in run r (nruns <= 32)
@@ -942,16 +943,24 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 //   XM = SellSArgs::xmode (0: x += s_k ; 1: x deferred ; 2: x = (x + s_{k-1}) + s_k)   TD: 1/diag from the pattern table
 // Plain (non-coded) table, K = 3, runs in batches of 3 (the 27-point operators).
 // ---------------------------------------------------------------------------
-template <int XM, int NB, bool TD>
+// MK = true: 16-byte {coefficient, mask} table entries, the mask clears the high word of the gathered value of an ABSENT entry, so
+//   its product with the table's +0.0 is an exact zero even when that value is Inf/NaN (the operator kernels always do this).
+// MK = false (default for the fused sweeps): 8-byte entries, absent entries are plain +0.0 coefficients.  The LDS return
+//   path (128 B/clk per CU) is what the tap loop waits for -- 27 reads x 16 B per lane were 11.6 us of LDS time per 128^3
+//   sweep -- so halving the entry halves that.  Bit-identical for finite vectors (a +-0.0 term never changes a sum that
+//   started from +0.0); with a non-finite entry in s the rows whose zero-padded taps touch it turn NaN one application
+//   earlier than in the reference -- the iteration is lost either way (every dot product is NaN).  GMG_PAT_STRICT=1 = MK.
+template <int XM, int NB, bool TD, bool MK>
 __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
 {
   constexpr int K = 3, ROWS = 65 - K, RB = 3;
   extern __shared__ double sp_smem[];
   const int nu = K * a.nruns;
   const int tot = a.np * nu;
-  // LDS: [np*nu] {coefficient, high-word mask} as 16-byte entries (one ds_read_b128 per tap) | [np] 1/diag
+  // LDS: [np*nu] {coefficient, high-word mask} as 16-byte entries (one ds_read_b128 per tap), or the coefficients alone | [np] 1/diag
   PatEntry *s_tab = reinterpret_cast<PatEntry *>(sp_smem);
-  double *s_dinv = sp_smem + 2 * (size_t)tot;
+  double *s_tab8 = sp_smem;
+  double *s_dinv = sp_smem + (MK ? 2 : 1) * (size_t)tot;
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x;
@@ -986,7 +995,8 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
   };
   int sb = s_begin + wave;
   if (sb < s_end) load_batch(sb);                            // in flight while the table is staged (one round trip, not two)
-  for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i];
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i]; }
+  else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
   if (TD)
     for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
   __syncthreads();
@@ -995,6 +1005,7 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const PatEntry *te = s_tab + pid[i] * nu;
+      const double *tv = s_tab8 + pid[i] * nu;
       double s = 0.0;
       for (int r0 = 0; r0 < a.nruns; r0 += RB) {
         double cur[RB];
@@ -1011,9 +1022,12 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
           for (int t = 0; t < K; ++t) {
             if (t > 0) c = wave_shl1(c);                     // the last K-1 lanes receive junk: they own no row
             const int j = (r0 + q) * K + t;
-            const PatEntry en = te[j];
-            const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
-            s = s + en.v * g;
+            if (MK) {
+              const PatEntry en = te[j];
+              const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
+              s = s + en.v * g;
+            } else
+              s = s + tv[j] * c;
           }
         }
       }
@@ -1034,6 +1048,170 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
     }
     sb += wpb * NB;
     if (sb < s_end) load_batch(sb);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// A whole Richardson-Jacobi smoothing pass (niter sweeps) of a SMALL level in ONE launch.
+//
+// On levels of a few 10^4 .. 10^5 rows a sweep kernel runs 4.6-5.9 us + ~1.5 us of dependent-launch gap against
+// < 1 us of actual work (profiles/r02_tuning.md, section 2): the level is bound by per-launch latency.  Here every wave keeps
+// NS slices for the whole pass: r, x, 1/diag, the pattern id and the row's own s stay in REGISTERS across the sweeps; the
+// only data that crosses lanes between sweeps is s (the gathered vector), which goes through memory with
+// agent-scope (sc1) 8-byte stores and loads -- coherent across CUs and XCDs without any cache fence -- and a sweep of a
+// workgroup starts as soon as the workgroups that own the rows it gathers from have published the previous sweep
+// (one flag word per workgroup, polled by one lane per neighbour): no grid-wide barrier.
+//   flag[w] = epoch + (number of sweeps whose s-stores of workgroup w are complete)
+//   WAR on the two s buffers: w rewrites s[(k+1)&1] in sweep k+1 only after its neighbours' flags reached k+1, i.e.
+//   after they finished the gathers of sweep k (loads are waited for before a wave stores).
+// Placement independent (no assumption on workgroup -> XCD mapping or dispatch order); needs all workgroups resident
+// at once (the launcher keeps the grid <= one workgroup per CU) and every wait is bounded (timeout -> *err).
+// Arithmetic, operand order and roundings are those of sells_sweep_kernel, sweep after sweep: bit-identical.
+// ---------------------------------------------------------------------------
+struct SellSmoothArgs {
+  const uint16_t *rowpid;
+  const PatEntry *tab;
+  const double *tab8;
+  const int32_t *run_off;
+  int np, nruns;
+  int64_t nrows, ncols;
+  int nslices;
+  const double *pdinv;      // TD: 1/diag per pattern
+  const double *dinv;       // !TD: 1/diag per row
+  double omega;
+  int niter, x_zero;
+  const double *r_in;
+  double *r_out;
+  double *x;
+  double *s_a, *s_b;        // sweep k gathers from (k even ? s_a : s_b) and writes the other; s_a holds s_0 on entry
+  uint32_t *flags;          // [gridDim.x * 16] one word per workgroup, 64 B apart; never reset: epoch advances by niter per launch
+  uint32_t epoch;
+  uint32_t *err;            // host-visible: set when a wait timed out
+  int halo_wg;              // workgroup w waits for w-halo_wg .. w+halo_wg
+};
+
+__device__ __forceinline__ double ld_agent(const double *p)
+{
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double *p, double v)
+{
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// DBG (tools/mb_smooth.hip only, never instantiated by the library): 1 no neighbour waits, 2 plain gather loads, 4 plain s stores,
+// 8 no taps, 16 no store drain / flag publish
+template <int NS, bool TD, bool MK, int DBG = 0>
+__global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
+{
+  constexpr int K = 3, ROWS = 65 - K, RB = 3;
+  extern __shared__ double sp_smem[];
+  const int nu = K * a.nruns;
+  const int tot = a.np * nu;
+  PatEntry *s_tab = reinterpret_cast<PatEntry *>(sp_smem);
+  double *s_tab8 = sp_smem;
+  double *s_dinv = sp_smem + (MK ? 2 : 1) * (size_t)tot;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int w = blockIdx.x;
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  const double omega = a.omega;
+  int pid[NS], row[NS];
+  bool own[NS];
+  double r[NS], xr[NS], so[NS], dv[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int slice = w * (wpb * NS) + i * wpb + wave;
+    row[i] = min(slice, a.nslices - 1) * ROWS + lane;       // slices past the end recompute the last one, store nothing
+    own[i] = slice < a.nslices && lane < ROWS && row[i] <= lastrow;
+    const int rc = min(row[i], lastrow);
+    pid[i] = (int)a.rowpid[rc];
+    r[i] = a.r_in[rc];
+    { const double xl = a.x[rc]; xr[i] = a.x_zero ? 0.0 : xl; }
+    so[i] = a.s_a[rc];
+    dv[i] = TD ? 0.0 : a.dinv[rc];
+  }
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i]; }
+  else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
+  if (TD)
+    for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
+  __syncthreads();
+  if (TD) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) dv[i] = s_dinv[pid[i]];
+  }
+  const double *sin = a.s_a;
+  double *sout = a.s_b;
+  const int nb_lo = max(0, w - a.halo_wg), nb_hi = min((int)gridDim.x - 1, w + a.halo_wg);
+  for (int k = 0; k < a.niter; ++k) {
+    if (k > 0 && !(DBG & 1)) {
+      // neighbours' sweep k-1 published?  one lane per neighbour, relaxed agent-scope polls
+      if (wave == 0 && nb_lo + lane <= nb_hi && nb_lo + lane != w) {
+        const uint32_t *f = a.flags + (size_t)(nb_lo + lane) * 16;
+        const uint32_t want = a.epoch + (uint32_t)k;
+        unsigned spins = 0;
+        while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+          if (++spins > (1u << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+    }
+    double acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      double A[RB];
+#pragma unroll
+      for (int q = 0; q < RB; ++q) { const double *ga = sin + min(max(row[i] + a.run_off[q], 0), last); A[q] = (DBG & 2) ? *ga : ld_agent(ga); }
+      const PatEntry *te = s_tab + pid[i] * nu;
+      const double *tv = s_tab8 + pid[i] * nu;
+      double s = 0.0;
+      for (int r0 = 0; r0 < ((DBG & 8) ? RB : a.nruns); r0 += RB) {
+        double cur[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) cur[q] = A[q];
+        if (r0 + RB < a.nruns) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) { const double *ga = sin + min(max(row[i] + a.run_off[r0 + RB + q], 0), last); A[q] = (DBG & 2) ? *ga : ld_agent(ga); }
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          double c = cur[q];
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) c = wave_shl1(c);
+            const int j = (r0 + q) * K + t;
+            if (MK) {
+              const PatEntry en = te[j];
+              const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
+              s = s + en.v * g;
+            } else
+              s = s + tv[j] * c;
+          }
+        }
+      }
+      acc[i] = s;
+    }
+    const bool publish = k + 1 < a.niter;                    // the s of the last sweep has no reader
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      xr[i] = xr[i] + so[i];                                 // x += s_k
+      const double rn = r[i] - acc[i];                       // r -= A s_k
+      r[i] = rn;
+      so[i] = omega * (dv[i] * rn);                          // s_{k+1} = omega * Dinv r
+      if (publish && own[i]) { if (DBG & 4) sout[row[i]] = so[i]; else st_agent(sout + row[i], so[i]); }
+    }
+    if (publish && !(DBG & 16)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: the stores have left the CU ...
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(a.flags + (size_t)w * 16, a.epoch + (uint32_t)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag
+    }
+    const double *t = sin; sin = sout; sout = const_cast<double *>(t);
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    if (own[i]) { a.x[row[i]] = xr[i]; a.r_out[row[i]] = r[i]; }
   }
 }
 

@@ -426,10 +426,14 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
                       "sell_dict": dict(GMG_SELL="1", GMG_VDICT="1", GMG_IDX16="0", GMG_PATTERN="0"),
                       "pattern_shared": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1"),
                       "pattern_shared_rb9": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_RB="9"),
+                      "pattern_shared_strict": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_STRICT="1"),
+                      "pattern_shared_sweeps": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PERSIST="0"),
+                      "pattern_shared_strict_sweeps": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_STRICT="1", GMG_PERSIST="0"),
                       "pattern_generic": dict(GMG_PATTERN="1", GMG_PAT_SHARED="0"),
                       "pattern_generic_un3": dict(GMG_PATTERN="1", GMG_PAT_SHARED="0", GMG_PAT_UN="3"),
                       "pattern_two_gather": dict(GMG_PATTERN="1", GMG_ONE_GATHER="0")}.items():
-        for k in ("GMG_SELL", "GMG_VDICT", "GMG_IDX16", "GMG_PATTERN", "GMG_PAT_SHARED", "GMG_PAT_RB", "GMG_PAT_UN", "GMG_ONE_GATHER", "GMG_OPATTERN"):
+        for k in ("GMG_SELL", "GMG_VDICT", "GMG_IDX16", "GMG_PATTERN", "GMG_PAT_SHARED", "GMG_PAT_RB", "GMG_PAT_UN", "GMG_ONE_GATHER", "GMG_OPATTERN", "GMG_PAT_STRICT",
+                  "GMG_PERSIST"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -450,7 +454,8 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
         assert rel_err(x, xo) <= 1e-10 and rel_err(z, zo) <= TOL_VCYCLE, name
         np.testing.assert_allclose(h, hist, rtol=TOL_HIST)
     # (the row-pattern kernels add explicit +0.0 terms for absent entries: the bits of the sums do not change)
-    for name in ("sell_offsets", "sellc", "sell_idx16", "sell_dict", "pattern_shared", "pattern_shared_rb9", "pattern_generic", "pattern_generic_un3"):
+    for name in ("sell_offsets", "sellc", "sell_idx16", "sell_dict", "pattern_shared", "pattern_shared_rb9", "pattern_shared_strict",
+                 "pattern_shared_sweeps", "pattern_shared_strict_sweeps", "pattern_generic", "pattern_generic_un3"):
         assert np.array_equal(out[name][0], out["sell"][0]) and np.array_equal(out[name][1], out["sell"][1]), name
 
 

@@ -615,3 +615,42 @@ def test_eager_pattern_form_of_whole_matrices(S, po, orc, monkeypatch):
     x2 = np.zeros_like(b)
     S.solve_(x2, ns, 3.0 * b)
     assert rel_err(x2, out["1"][0]) <= 1e-6                                  # another system (3A x = 3b, coarse levels unscaled), solved to rtol 1e-8
+
+
+# ---------------------------------------------------------------- whole smoothing pass in one launch (small levels)
+@pytest.mark.parametrize("nc,nlev,niter", [((64, 64, 64), 4, 10), ((80, 80, 80), 3, 5), ((96, 96, 96), 3, 10), ((256, 256), 3, 7),
+                                           ((16, 16, 16), 3, 2)])
+def test_persistent_smoothing_pass_is_bitwise_the_sweep_loop(S, po, hierarchy, monkeypatch, nc, nlev, niter):
+    """sells_smooth_kernel keeps r, x and the row's own s in registers for the whole pass and hands s between workgroups with
+    agent-scope stores/loads + per-workgroup progress words; the arithmetic is that of the per-sweep kernel.  Smoothing
+    passes (x given and x = 0 entry), repeated V-cycles (stale-data hazards would show as run-to-run differences) and a
+    CG solve must agree to the last bit with GMG_PERSIST=0."""
+    H = hierarchy(nc, nlev)
+    n = H["mats"][0].shape[0]
+    b = po.dirichlet_lift_rhs(nc, 1)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GMG_PERSIST", flag)
+        solver = S.CGSolver(make_gmg(S, H, pre_smoothers=jac(S, nlev, niter)), maxiter=30, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        out = []
+        for l in range(nlev - 1):
+            nl = H["mats"][l].shape[0]
+            x, r = np.random.default_rng(3 + l).uniform(-1, 1, nl), np.random.default_rng(50 + l).uniform(-1, 1, nl)
+            for _ in range(3):                                       # passes chained: flags / epochs advance between launches
+                ns.P_ns.smooth(l, x, r)
+            out += [x, r]
+        z = np.zeros(n)
+        for rep in range(25):
+            rr = np.random.default_rng(100 + rep % 3).uniform(-1, 1, n)
+            S.solve_(z, ns.P_ns, rr)
+            if rep < 3:
+                out.append(z.copy())
+            else:
+                np.testing.assert_array_equal(z, out[2 * (nlev - 1) + rep % 3], err_msg=f"V-cycle {rep} differs from its first run (persist={flag})")
+        x = np.zeros(n)
+        S.solve_(x, ns, b)
+        out += [x, solver.log.residuals[: solver.log.num_iters + 1].copy()]
+        res[flag] = out
+    for a, c in zip(res["0"], res["1"]):
+        np.testing.assert_array_equal(a, c)
