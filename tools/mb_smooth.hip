@@ -62,12 +62,13 @@ int main(int argc, char **argv)
   const int nsl = (int)((N + rows - 1) / rows);
   int wpb = 1;
   while (wpb < 16 && (nsl + wpb - 1) / wpb > n_cus) wpb *= 2;
-  const int ns = (nsl + wpb - 1) / wpb > n_cus ? 2 : 1;
+  int ns = 1;
+  while ((nsl + wpb * ns - 1) / (wpb * ns) > n_cus) ++ns;   // (the library stops at 2)
   const int64_t reach = std::max<int64_t>(-(int64_t)runs.front(), (int64_t)runs.back() + 2);
   const int halo = (int)((reach + (int64_t)wpb * ns * rows - 1) / ((int64_t)wpb * ns * rows));
   const int nwg = (nsl + wpb * ns - 1) / (wpb * ns);
   printf("rows %lld slices %d : %d workgroups x %d waves, %d slice(s) per wave, neighbours +-%d, %d sweeps per launch\n", (long long)N, nsl, nwg, wpb, ns, halo, niter);
-  if (ns != 1) { printf("(only NS = 1 is instantiated here)\n"); return 0; }
+  if (ns != 1 && ns != 2 && ns != 4 && ns != 9) { printf("(NS = %d is not instantiated here)\n", ns); return 0; }
   SellSmoothArgs a;
   std::memset(&a, 0, sizeof(a));
   a.rowpid = d_pid; a.tab = d_tab; a.tab8 = d_t8; a.run_off = d_run; a.np = np; a.nruns = nruns; a.nrows = N; a.ncols = N; a.nslices = nsl;
@@ -78,7 +79,11 @@ int main(int argc, char **argv)
   const dim3 g(nwg), b(64 * wpb);
 #define RUN(DBGV, label)                                                                                         \
   do {                                                                                                           \
-    const float ms = time_it([&] { a.epoch = epoch; epoch += niter; hipLaunchKernelGGL((sells_smooth_kernel<1, true, true, DBGV>), g, b, lds, 0, a); }); \
+    const float ms = time_it([&] { a.epoch = epoch; epoch += niter;                                              \
+      if (ns == 1) hipLaunchKernelGGL((sells_smooth_kernel<1, true, true, DBGV>), g, b, lds, 0, a);              \
+      else if (ns == 2) hipLaunchKernelGGL((sells_smooth_kernel<2, true, true, DBGV>), g, b, lds, 0, a);         \
+      else if (ns == 4) hipLaunchKernelGGL((sells_smooth_kernel<4, true, true, DBGV>), g, b, lds, 0, a);         \
+      else hipLaunchKernelGGL((sells_smooth_kernel<9, true, true, DBGV>), g, b, lds, 0, a); });                  \
     uint32_t e = 0; CK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));                                            \
     printf("%-58s %8.2f us per launch  %6.2f us per sweep%s\n", label, ms * 1e3, ms * 1e3 / niter, e ? "  (TIMEOUT FLAG SET)" : ""); \
   } while (0)
@@ -92,7 +97,11 @@ int main(int argc, char **argv)
   RUN(1 | 16 | 2 | 4, "no sync, plain loads and stores");
   RUN(1 | 16 | 2 | 4 | 8, "no sync, plain memory ops, no taps (skeleton)");
   {
-    const float ms = time_it([&] { a.epoch = epoch; epoch += niter; hipLaunchKernelGGL((sells_smooth_kernel<1, true, false, 0>), g, b, lds, 0, a); });
+    const float ms = time_it([&] { a.epoch = epoch; epoch += niter;
+      if (ns == 1) hipLaunchKernelGGL((sells_smooth_kernel<1, true, false, 0>), g, b, lds, 0, a);
+      else if (ns == 2) hipLaunchKernelGGL((sells_smooth_kernel<2, true, false, 0>), g, b, lds, 0, a);
+      else if (ns == 4) hipLaunchKernelGGL((sells_smooth_kernel<4, true, false, 0>), g, b, lds, 0, a);
+      else hipLaunchKernelGGL((sells_smooth_kernel<9, true, false, 0>), g, b, lds, 0, a); });
     printf("%-58s %8.2f us per launch  %6.2f us per sweep\n", "product kernel, 8-byte table entries", ms * 1e3, ms * 1e3 / niter);
   }
   return 0;
