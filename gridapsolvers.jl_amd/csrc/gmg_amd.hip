@@ -1707,7 +1707,7 @@ struct gmg_solver {
   {
     Level &L = lev[l];
     const DevCSR &M = L.A;
-    if (!persist || comm.nranks > 1 || l == prof_level || S.niter < 2) return false;
+    if (!persist || (comm.nranks > 1 && L.halo.present) || l == prof_level || S.niter < 2) return false;   // (replicated levels have no halo)
     if (!(M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && M.pat_nruns % 3 == 0)) return false;
     const int nu = M.pat_k * M.pat_nruns;
     const size_t lds = (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16;
