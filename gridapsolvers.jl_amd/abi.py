@@ -27,7 +27,7 @@ class Result(C.Structure):
 
 class KernelStats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("alg_bytes", C.c_double),
-                ("rows", C.c_int64), ("nnz", C.c_int64), ("layout_bytes", C.c_double)]
+                ("rows", C.c_int64), ("nnz", C.c_int64), ("layout_bytes", C.c_double), ("fused_passes", C.c_int64)]
 
 
 # every symbol include/gmg_amd.h declares (tests check the library exports all of them)

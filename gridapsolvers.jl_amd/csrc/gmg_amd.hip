@@ -507,7 +507,8 @@ struct gmg_solver {
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
   double prof_ms = 0.0;
-  int64_t prof_launches = 0;
+  int64_t prof_launches = 0, prof_fused = 0;
+  std::vector<int> prof_w;     // sweeps bracketed by each event pair (1, or niter for a pass run as one launch)
 
   // ---- memory -------------------------------------------------------------
   template <typename T>
@@ -1472,6 +1473,7 @@ struct gmg_solver {
     }
     if (prof) {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
+      prof_w[prof_used / 2] = 1;
       prof_used += 2;
     }
     if (comm.nranks > 1) finish_ghost<2>(l, s_old, r_new, S.omega, s_new, pack_next);   // distributed => one-gather sweep
@@ -1707,7 +1709,7 @@ struct gmg_solver {
   {
     Level &L = lev[l];
     const DevCSR &M = L.A;
-    if (!persist || (comm.nranks > 1 && L.halo.present) || l == prof_level || S.niter < 2) return false;   // (replicated levels have no halo)
+    if (!persist || (comm.nranks > 1 && L.halo.present) || S.niter < 2) return false;   // (replicated levels have no halo)
     if (!(M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && M.pat_nruns % 3 == 0)) return false;
     const int nu = M.pat_k * M.pat_nruns;
     const size_t lds = (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16;
@@ -1753,6 +1755,8 @@ struct gmg_solver {
     const dim3 g(nwg), b(64 * wpb);
     const bool td = a.pdinv != nullptr;
     const bool mk = pat_strict || !M.ptab8;
+    const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();       // every pass: there are niter times fewer of them
+    if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
 #define GMG_SMOOTH_LAUNCH(NSV, TDV)                                                                            \
     do {                                                                                                         \
       if (mk) hipLaunchKernelGGL((sells_smooth_kernel<NSV, TDV, true>), g, b, lds, stream, a);                   \
@@ -1762,6 +1766,11 @@ struct gmg_solver {
     else { if (td) GMG_SMOOTH_LAUNCH(1, true); else GMG_SMOOTH_LAUNCH(1, false); }
 #undef GMG_SMOOTH_LAUNCH
     HIP_CHECK(hipGetLastError());
+    if (prof) {
+      HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
+      prof_w[prof_used / 2] = S.niter;
+      prof_used += 2;
+    }
     return true;
   }
   void check_persistent() const
@@ -3742,12 +3751,13 @@ int gmg_profile_enable(gmg_handle_t h, int lev, int enable)
     check_level(h, lev, true);
     if (h->prof_ev.empty()) {
       h->prof_ev.resize(2 * 8192);
+      h->prof_w.assign(8192, 1);
       for (auto &ev : h->prof_ev) HIP_CHECK(hipEventCreate(&ev));
     }
     h->prof_level = lev;
     h->prof_used = 0;
     h->prof_ms = 0.0;
-    h->prof_launches = 0;
+    h->prof_launches = 0; h->prof_fused = 0;
   });
 }
 
@@ -3761,12 +3771,14 @@ int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
       float ms = 0.f;
       HIP_CHECK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
       h->prof_ms += ms;
-      h->prof_launches += 1;
+      h->prof_launches += h->prof_w[i / 2];
+      if (h->prof_w[i / 2] > 1) h->prof_fused += 1;
     }
     h->prof_used = 0;
     const int l = h->prof_level >= 0 ? h->prof_level : 0;
     const Level &L = h->lev[l];
     out->launches = h->prof_launches;
+    out->fused_passes = h->prof_fused;
     out->total_ms = h->prof_ms;
     out->rows = L.n;
     out->nnz = L.A.nnz_model >= 0 ? L.A.nnz_model : L.A.nnz;

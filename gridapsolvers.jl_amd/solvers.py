@@ -540,7 +540,7 @@ class GMGNumericalSetup:
         st = abi.KernelStats()
         abi.check(self.h, self._lib.gmg_get_kernel_stats(self.h, C.byref(st)))
         return dict(launches=st.launches, total_ms=st.total_ms, alg_bytes=st.alg_bytes, rows=st.rows, nnz=st.nnz,
-                    layout_bytes=st.layout_bytes)
+                    layout_bytes=st.layout_bytes, fused_passes=st.fused_passes)
 
     def stream_probe(self, nbytes=1 << 30, reps=10):
         v = C.c_double(0.0)

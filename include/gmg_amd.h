@@ -72,13 +72,16 @@ typedef struct {
 
 /* Timing / traffic statistics of the profiled kernel class (gmg_profile_enable). */
 typedef struct {
-  int64_t launches;        /* launches measured */
+  int64_t launches;        /* sweeps measured (one per launch, except on levels that run a whole smoothing pass as ONE
+                              launch -- see fused_passes -- where a pass of niter sweeps counts niter) */
   double total_ms;         /* sum of HIP-event durations on the handle's stream */
   double alg_bytes;        /* algorithmic bytes of ONE launch (SURVEY 8d byte model) */
   int64_t rows, nnz;       /* shape of the operator the kernel streams */
   double layout_bytes;     /* bytes ONE launch moves with the storage layout chosen at setup (matrix stream as
                               stored + row-wise vectors, each once): equals alg_bytes only for the plain 12 B/nnz
                               layouts; far smaller for the row-pattern / dictionary layouts */
+  int64_t fused_passes;    /* measured smoothing passes that ran as one launch (sells_smooth_kernel: small single-GPU
+                              levels in the row-pattern layout); 0 on levels swept launch by launch */
 } gmg_kernel_stats;
 
 /* ---- lifetime ------------------------------------------------------------- */
