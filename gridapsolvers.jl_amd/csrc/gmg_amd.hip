@@ -379,6 +379,20 @@ void parallel_for(int64_t n, F &&fn)
   for (auto &x : th) x.join();
 }
 
+// the same for a handful of BIG work items (one chunk of rows each): one thread per item, at most 32
+template <typename F>
+void parallel_chunks(int64_t n, F &&fn)
+{
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 32u), n);
+  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> th;
+  std::atomic<int64_t> next(0);
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&] { for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
+  for (auto &x : th) x.join();
+}
+
 int env_int(const char *name, int dflt)
 {
   const char *s = std::getenv(name);
@@ -489,6 +503,7 @@ struct gmg_solver {
   int pat_small_wpb2 = 1;  // GMG_PAT_SMALL_WPB2: the same for sellp_kernel
   int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
   int64_t pat_coded_min_rows = 500000;   // GMG_PAT_CODED_MIN_ROWS
+  int gj_mfma = 1;      // GMG_GJ_MFMA: trailing update of the device coarse inversion on the FP64 matrix cores
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
   int persist_max_slices = 0;  // GMG_PERSIST_MAX_SLICES (0: what one workgroup per CU holds)
@@ -680,7 +695,7 @@ struct gmg_solver {
       }
       return true;
     };
-    parallel_for(T, [&](int64_t t) {
+    parallel_chunks(T, [&](int64_t t) {
       Local &L = loc[(size_t)t];
       for (int64_t i = t * per; i < std::min(n, (t + 1) * per); ++i) {
         if (fail.load(std::memory_order_relaxed)) return;
@@ -747,7 +762,7 @@ struct gmg_solver {
     const int np = (int)G.len.size();
     rowpid.resize((size_t)n);
     if (mode == 1) rowbase.resize((size_t)n); else rowbase.clear();
-    parallel_for(T, [&](int64_t t) {
+    parallel_chunks(T, [&](int64_t t) {
       for (int64_t i = t * per; i < std::min(n, (t + 1) * per); ++i) {
         rowpid[(size_t)i] = (uint16_t)l2g[(size_t)t][(size_t)lid[(size_t)i]];
         if (mode == 1) rowbase[(size_t)i] = H.ptr[i + 1] > H.ptr[i] ? H.col[H.ptr[i]] : 0;
@@ -824,65 +839,103 @@ struct gmg_solver {
     std::vector<int32_t> found((size_t)nr, -1);
     std::vector<uint64_t> hashes((size_t)nr);
     std::atomic<int> bad(0);
-    std::atomic<int64_t> wmax(P.wmax);
-    parallel_for(nr, [&](int64_t i) {
-      const int64_t k0 = read_index(ptr, i, bytes) - base, k1 = read_index(ptr, i + 1, bytes) - base;
-      if (k1 < k0 || k1 - k0 > 1024) { bad.store(1); return; }
-      const int64_t len = k1 - k0;
-      const int64_t c0 = len > 0 ? read_index(idx, k0, bytes) - base : 0;
-      const int64_t ref = P.mode == 0 ? row0 + i : c0;
-      uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
-      int64_t prev = -1;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(64, (nr + 16383) / 16384));
+    const int64_t per = (nr + T - 1) / T;
+    auto row_ref = [&](int64_t i, int64_t k0, int64_t len) {
+      return P.mode == 0 ? row0 + i : (len > 0 ? read_index(idx, k0, bytes) - base : (int64_t)0);
+    };
+    auto row_is = [&](int32_t q, int64_t k0, int64_t len, int64_t ref) {
+      if (P.len[q] != (int32_t)len) return false;
+      const int32_t st = P.start[q];
       for (int64_t j = 0; j < len; ++j) {
-        const int64_t c = read_index(idx, k0 + j, bytes) - base;
-        if (c < 0 || c >= P.ncols) { bad.store(2); return; }
-        if (c <= prev) { bad.store(3); return; }             // sorted, duplicate-free rows only (what assemblers emit)
-        prev = c;
         uint64_t bits;
         std::memcpy(&bits, &val[k0 + j], 8);
-        h = (h ^ (uint64_t)(uint32_t)(int32_t)(c - ref)) * 1099511628211ull;
-        h = (h ^ bits) * 1099511628211ull;
-        h ^= h >> 29;
+        if (P.off[st + j] != (int32_t)(read_index(idx, k0 + j, bytes) - base - ref) || P.val[st + j] != bits) return false;
       }
-      hashes[(size_t)i] = h;
-      int64_t w = wmax.load(std::memory_order_relaxed);
-      while (len > w && !wmax.compare_exchange_weak(w, len)) {}
-      auto it = P.index.find(h);
-      if (it == P.index.end()) return;
-      for (int32_t q : it->second) {
-        if (P.len[q] != (int32_t)len) continue;
-        bool eq = true;
-        for (int64_t j = 0; j < len && eq; ++j) {
-          uint64_t bits;
-          std::memcpy(&bits, &val[k0 + j], 8);
-          eq = P.off[P.start[q] + j] == (int32_t)(read_index(idx, k0 + j, bytes) - base - ref) && P.val[P.start[q] + j] == bits;
-        }
-        if (eq) { found[(size_t)i] = q; return; }
-      }
-    });
-    REQUIRE(bad.load() != 1, GMG_ERR_INVALID, "row pointers not monotone, or a row longer than 1024 entries");
-    REQUIRE(bad.load() != 2, GMG_ERR_INVALID, "column index out of range");
-    REQUIRE(bad.load() != 3, GMG_ERR_UNSUPPORTED, "streamed rows must have sorted, duplicate-free columns");
-    P.wmax = wmax.load();
-    P.rowpid.resize((size_t)(row0 + nr));
-    if (P.mode == 1) P.rowbase.resize((size_t)(row0 + nr));
-    for (int64_t i = 0; i < nr; ++i) {
-      const int64_t k0 = read_index(ptr, i, bytes) - base, len = read_index(ptr, i + 1, bytes) - base - k0;
-      const int64_t c0 = len > 0 ? read_index(idx, k0, bytes) - base : 0;
-      const int64_t ref = P.mode == 0 ? row0 + i : c0;
-      int32_t q = found[(size_t)i];
-      if (q < 0) {
-        auto &bucket = P.index[hashes[(size_t)i]];
-        for (int32_t cand : bucket) {                        // inserted earlier in this very block?
-          if (P.len[cand] != (int32_t)len) continue;
-          bool eq = true;
-          for (int64_t j = 0; j < len && eq; ++j) {
-            uint64_t bits;
-            std::memcpy(&bits, &val[k0 + j], 8);
-            eq = P.off[P.start[cand] + j] == (int32_t)(read_index(idx, k0 + j, bytes) - base - ref) && P.val[P.start[cand] + j] == bits;
+      return true;
+    };
+    // Rounds: (a) in parallel, every unresolved row is looked up in the dictionary (read-only) -- the first round also
+    // validates the rows and computes their hashes --, each chunk remembering the FIRST row of every hash it could not
+    // resolve; (b) those few rows are inserted sequentially in row order (pattern ids = order of first appearance, as a
+    // sequential scan would give).  A whole matrix handed over as one block needs two rounds; later blocks of a stream one.
+    std::vector<int64_t> wmax_t((size_t)T, 0);
+    for (int round = 0;; ++round) {
+      std::vector<std::vector<std::pair<int64_t, uint64_t>>> fresh((size_t)T);
+      parallel_chunks(T, [&](int64_t t) {
+        std::unordered_map<uint64_t, int64_t> first;
+        struct Hit { uint64_t h; int32_t q; };
+        Hit cache[64];
+        for (auto &c : cache) c = Hit{0, -1};
+        int64_t wloc = 0;                                        // (not wmax_t[t] in the loop: neighbouring chunks share its cache line)
+        for (int64_t i = t * per; i < std::min(nr, (t + 1) * per); ++i) {
+          if (found[(size_t)i] >= 0) continue;
+          const int64_t k0 = read_index(ptr, i, bytes) - base, k1 = read_index(ptr, i + 1, bytes) - base;
+          const int64_t len = k1 - k0;
+          const int64_t ref = row_ref(i, k0, len);
+          uint64_t h;
+          if (round == 0) {
+            if (k1 < k0 || len > 1024) { bad.store(1); return; }
+            h = 1469598103934665603ull ^ (uint64_t)len;
+            int64_t prev = -1;
+            for (int64_t j = 0; j < len; ++j) {
+              const int64_t c = read_index(idx, k0 + j, bytes) - base;
+              if (c < 0 || c >= P.ncols) { bad.store(2); return; }
+              if (c <= prev) { bad.store(3); return; }           // sorted, duplicate-free rows only (what assemblers emit)
+              prev = c;
+              uint64_t bits;
+              std::memcpy(&bits, &val[k0 + j], 8);
+              h = (h ^ (uint64_t)(uint32_t)(int32_t)(c - ref)) * 1099511628211ull;
+              h = (h ^ bits) * 1099511628211ull;
+              h ^= h >> 29;
+            }
+            hashes[(size_t)i] = h;
+            wloc = std::max(wloc, len);
+          } else
+            h = hashes[(size_t)i];
+          Hit &c = cache[h & 63];
+          if (c.q >= 0 && c.h == h && row_is(c.q, k0, len, ref)) { found[(size_t)i] = c.q; continue; }
+          auto it = P.index.find(h);
+          if (it != P.index.end()) {
+            bool ok = false;
+            for (int32_t q : it->second)
+              if (row_is(q, k0, len, ref)) { found[(size_t)i] = q; c = Hit{h, q}; ok = true; break; }
+            if (ok) continue;
           }
-          if (eq) { q = cand; break; }
+          auto ins = first.emplace(h, i);                        // keeps the smallest row of the chunk (rows ascend)
+          if (!ins.second) {
+            // same hash as an earlier unresolved row r of this chunk: when the rows are equal, i takes r's id once r has one
+            // (one pass over a matrix that arrives whole: the dictionary is empty in round 0)
+            const int64_t r = ins.first->second;
+            const int64_t q0 = read_index(ptr, r, bytes) - base, qlen = read_index(ptr, r + 1, bytes) - base - q0;
+            bool eq = qlen == len;
+            if (eq) {
+              const int64_t rref = row_ref(r, q0, qlen);
+              for (int64_t j = 0; j < len && eq; ++j)
+                eq = (read_index(idx, k0 + j, bytes) - ref) == (read_index(idx, q0 + j, bytes) - rref) &&
+                     std::memcmp(&val[k0 + j], &val[q0 + j], 8) == 0;
+            }
+            if (eq) found[(size_t)i] = (int32_t)(-2 - (r - t * per));   // offset of r inside the chunk (< 2^31)
+          }
         }
+        for (const auto &kv : first) fresh[(size_t)t].emplace_back(kv.second, kv.first);   // (row, hash)
+        if (round == 0) wmax_t[(size_t)t] = wloc;
+      });
+      REQUIRE(bad.load() != 1, GMG_ERR_INVALID, "row pointers not monotone, or a row longer than 1024 entries");
+      REQUIRE(bad.load() != 2, GMG_ERR_INVALID, "column index out of range");
+      REQUIRE(bad.load() != 3, GMG_ERR_UNSUPPORTED, "streamed rows must have sorted, duplicate-free columns");
+      std::vector<std::pair<int64_t, uint64_t>> todo;
+      for (auto &f : fresh) todo.insert(todo.end(), f.begin(), f.end());
+      if (todo.empty()) break;
+      REQUIRE(round < 64, GMG_ERR_STATE, "pattern dictionary did not converge");
+      std::sort(todo.begin(), todo.end());
+      for (auto &pr : todo) {
+        const int64_t i = pr.first;
+        const int64_t k0 = read_index(ptr, i, bytes) - base, len = read_index(ptr, i + 1, bytes) - base - k0;
+        const int64_t ref = row_ref(i, k0, len);
+        auto &bucket = P.index[pr.second];
+        int32_t q = -1;
+        for (int32_t cand : bucket)                            // inserted a moment ago for an earlier chunk's first row?
+          if (row_is(cand, k0, len, ref)) { q = cand; break; }
         if (q < 0) {
           REQUIRE((int)P.len.size() < kMaxPatterns, GMG_ERR_UNSUPPORTED,
                   "streamed operator has more than 4096 distinct rows: it is not pattern-compressible; pass it whole (gmg_set_matrix)");
@@ -897,11 +950,24 @@ struct gmg_solver {
           }
           bucket.push_back(q);
         }
+        found[(size_t)i] = q;
       }
-      P.rowpid[(size_t)(row0 + i)] = (uint16_t)q;
-      if (P.mode == 1) P.rowbase[(size_t)(row0 + i)] = (int32_t)c0;
-      P.nnz += len;
+      parallel_chunks(T, [&](int64_t t) {                        // rows that were equal to a chunk-first row take its id
+        for (int64_t i = t * per; i < std::min(nr, (t + 1) * per); ++i)
+          if (found[(size_t)i] <= -2) found[(size_t)i] = found[(size_t)(t * per + (int64_t)(-2 - found[(size_t)i]))];
+      });
     }
+    for (int64_t w : wmax_t) P.wmax = std::max(P.wmax, w);
+    P.rowpid.resize((size_t)(row0 + nr));
+    if (P.mode == 1) P.rowbase.resize((size_t)(row0 + nr));
+    parallel_for(nr, [&](int64_t i) {
+      P.rowpid[(size_t)(row0 + i)] = (uint16_t)found[(size_t)i];
+      if (P.mode == 1) {
+        const int64_t k0 = read_index(ptr, i, bytes) - base, len = read_index(ptr, i + 1, bytes) - base - k0;
+        P.rowbase[(size_t)(row0 + i)] = (int32_t)(len > 0 ? read_index(idx, k0, bytes) - base : 0);
+      }
+    });
+    P.nnz += read_index(ptr, nr, bytes) - base;
     P.rows_seen = row0 + nr;
   }
   // gmg_set_matrix / _prolongation / _restriction on a big CSR operator: look at the structure right away, while the caller's
@@ -911,7 +977,7 @@ struct gmg_solver {
   bool try_eager_pattern(std::shared_ptr<PatStream> &out, int mode, int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr,
                          const void *idx, const double *val, int layout, int base, int bytes)
   {
-    if (layout != GMG_CSR || comm.nranks != 1 || nrows < env_int("GMG_EAGER_MIN_ROWS", 100000) || !env_int("GMG_EAGER", 1)) return false;
+    if (layout != GMG_CSR || comm.nranks != 1 || nrows < env_int("GMG_EAGER_MIN_ROWS", 20000) || !env_int("GMG_EAGER", 1)) return false;
     if (!env_int("GMG_PATTERN", 1) || !env_int("GMG_SELL", 1) || !ptr || !idx || !val) return false;
     if (ncols >= (int64_t)(1 << 28) || nnz <= 0) return false;
     if (read_index(ptr, 0, bytes) != base || read_index(ptr, nrows, bytes) - base != nnz) return false;   // general path reports it
@@ -928,6 +994,26 @@ struct gmg_solver {
     if (!generic) return false;                              // wide / many patterns: let the general path pick the layout
     out = S;
     return true;
+  }
+  // CSR rows of an operator held in row-pattern form (setup only: R = P^T when the caller gave P alone)
+  static HostCSR expand_stream(const PatStream &P)
+  {
+    REQUIRE(P.complete(), GMG_ERR_STATE, "row stream incomplete");
+    HostCSR H;
+    H.nrows = P.nrows; H.ncols = P.ncols;
+    H.ptr.assign((size_t)P.nrows + 1, 0);
+    for (int64_t i = 0; i < P.nrows; ++i) H.ptr[(size_t)i + 1] = H.ptr[(size_t)i] + P.len[P.rowpid[(size_t)i]];
+    H.col.resize((size_t)H.ptr[(size_t)P.nrows]);
+    H.val.resize((size_t)H.ptr[(size_t)P.nrows]);
+    parallel_for(P.nrows, [&](int64_t i) {
+      const int32_t q = P.rowpid[(size_t)i];
+      const int64_t ref = P.mode == 0 ? i : (int64_t)P.rowbase[(size_t)i];
+      for (int32_t j = 0; j < P.len[q]; ++j) {
+        H.col[(size_t)(H.ptr[(size_t)i] + j)] = (int32_t)(ref + P.off[P.start[q] + j]);
+        std::memcpy(&H.val[(size_t)(H.ptr[(size_t)i] + j)], &P.val[P.start[q] + j], 8);
+      }
+    });
+    return H;
   }
   // device form of a completed stream (the counterpart of upload_csr)
   DevCSR finish_stream(PatStream &P, const char *what)
@@ -2048,6 +2134,7 @@ struct gmg_solver {
     pat_defer = env_int("GMG_PAT_DEFER", 1);
     persist = env_int("GMG_PERSIST", 1);
     pat_strict = env_int("GMG_PAT_STRICT", 1);
+    gj_mfma = env_int("GMG_GJ_MFMA", 1);
     persist_max_slices = env_int("GMG_PERSIST_MAX_SLICES", 0);
     pat_coded_min_rows = env_int("GMG_PAT_CODED_MIN_ROWS", 500000);
     pat_emit = env_int("GMG_PAT_EMIT", 1);
@@ -2741,7 +2828,8 @@ double *gmg_solver::build_coarse_device(const HostCSR &A, const std::string &wha
     const int b = std::min(GJ_B, n - k0);
     hipLaunchKernelGGL(gj_diag_kernel, dim3(1), dim3(GJ_B * GJ_B), 0, stream, n, k0, b, D, Pinv, d_bad);
     hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)(((int64_t)n * b + 255) / 256)), dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
-    hipLaunchKernelGGL(gj_update_kernel, tiles, dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
+    if (gj_mfma) hipLaunchKernelGGL(gj_update_mfma_kernel, tiles, dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
+    else hipLaunchKernelGGL(gj_update_kernel, tiles, dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
     HIP_CHECK(hipGetLastError());
   }
   int bad = 0;
@@ -2895,8 +2983,7 @@ void gmg_solver::setup()
       L.P = L.sP ? finish_stream(*L.sP, "prolongation") : upload_csr(L.hP);
       if (L.hasR) L.R = L.sR ? finish_stream(*L.sR, "restriction") : upload_csr(L.hR);
       else {
-        REQUIRE(!L.sP, GMG_ERR_STATE, "a streamed prolongation needs a streamed restriction too (R = P^T is not formed from a stream)");
-        HostCSR Rt = transpose(L.hP);                       // R = P^T, GridTransferOperators.jl:536-547
+        HostCSR Rt = L.sP ? transpose(expand_stream(*L.sP)) : transpose(L.hP);   // R = P^T, GridTransferOperators.jl:536-547
         L.R = upload_csr(Rt);
       }
       lap("P, R: upload + layout", l);
@@ -3228,7 +3315,9 @@ int gmg_set_prolongation(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, 
     check_level(h, lev, true);
     Level &L = h->lev[lev];
     L.sP.reset();
-    // (no eager pattern form for P: R = P^T may have to be formed from its CSR copy at setup; P is the small operator anyway)
+    if (h->try_eager_pattern(L.sP, 1, nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes)) {
+      L.hP = HostCSR(); L.hP.nrows = nrows; L.hP.ncols = ncols;     // shape only (R = P^T, if needed, is formed from the pattern form)
+    } else
     L.hP = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
     L.hasP = true;
     h->touch();

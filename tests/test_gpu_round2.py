@@ -654,3 +654,28 @@ def test_persistent_smoothing_pass_is_bitwise_the_sweep_loop(S, po, hierarchy, m
         res[flag] = out
     for a, c in zip(res["0"], res["1"]):
         np.testing.assert_array_equal(a, c)
+
+
+def test_restriction_from_eager_prolongation(S, po, hierarchy, monkeypatch):
+    """A big structured P is kept in row-pattern form only (no host copy, no CSR upload).  When the caller gives no R, R = P^T
+    (GridTransferOperators.jl:536-547) is formed from that form: must equal the run that hands P^T over explicitly, and the
+    run with the eager path switched off, to the last bit."""
+    nc, nlev = (64, 64, 64), 3                                     # P_0: 250 047 rows >= the eager threshold
+    H = hierarchy(nc, nlev)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    res = []
+    for eager, restr in (("1", None), ("1", H["restrictions"]), ("0", None)):
+        monkeypatch.setenv("GMG_EAGER", eager)
+        solver = S.CGSolver(S.GMGLinearSolver(H["mats"], H["prolongations"], restr, pre_smoothers=jac(S, nlev), post_smoothers=jac(S, nlev),
+                                              maxiter=1), maxiter=30, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        from gridapsolvers_jl_amd import abi
+        v = np.random.default_rng(4).uniform(-1, 1, H["restrictions"][0].shape[1])
+        y = np.zeros(H["restrictions"][0].shape[0])
+        ns.P_ns.op_apply(0, abi.OP_R, v, y)
+        res.append((x, y, solver.log.num_iters))
+        ns.P_ns.close()
+    for x, y, it in res[1:]:
+        np.testing.assert_array_equal(x, res[0][0]); np.testing.assert_array_equal(y, res[0][1]); assert it == res[0][2]
