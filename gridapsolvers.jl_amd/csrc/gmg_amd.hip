@@ -73,6 +73,34 @@ int64_t read_index(const void *p, int64_t i, int bytes)
   return bytes == 8 ? reinterpret_cast<const int64_t *>(p)[i] : (int64_t) reinterpret_cast<const int32_t *>(p)[i];
 }
 
+// setup-time host loops over independent chunks (slices, columns): plain std::thread fan-out
+template <typename F>
+void parallel_for(int64_t n, F &&fn)
+{
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 32u), std::max<int64_t>(1, n / 256));
+  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> th;
+  const int64_t chunk = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] { for (int64_t i = t * chunk; i < std::min(n, (t + 1) * chunk); ++i) fn(i); });
+  for (auto &x : th) x.join();
+}
+
+// the same for a handful of BIG work items (one chunk of rows each): one thread per item, at most 32
+template <typename F>
+void parallel_chunks(int64_t n, F &&fn)
+{
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 32u), n);
+  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> th;
+  std::atomic<int64_t> next(0);
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&] { for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
+  for (auto &x : th) x.join();
+}
+
 // Accepts {CSR|CSC} x {0|1}-based x {int32|int64} (SparseMatrixCSC{Float64,Int}: CSC,1,8;
 // SparseMatrixCSR{1,Float64,Int32}: CSR,1,4 ...) and produces 0-based CSR.
 HostCSR convert_input(int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr, const void *idx,
@@ -98,12 +126,18 @@ HostCSR convert_input(int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr
   if (layout == GMG_CSR) {
     for (int64_t i = 0; i <= nrows; ++i) out.ptr[i] = read_index(ptr, i, bytes) - base;
     for (int64_t i = 0; i < nrows; ++i) REQUIRE(out.ptr[i] <= out.ptr[i + 1], GMG_ERR_INVALID, "row pointers not monotone");
-    for (int64_t k = 0; k < nnz; ++k) {
-      const int64_t c = read_index(idx, k, bytes) - base;
-      REQUIRE(c >= 0 && c < nminor, GMG_ERR_INVALID, "column index out of range");
-      out.col[k] = (int32_t)c;
-    }
-    std::memcpy(out.val.data(), val, sizeof(double) * (size_t)nnz);
+    std::atomic<int> badcol(0);
+    const int64_t nchunk = (nnz + (1 << 20) - 1) >> 20;
+    parallel_chunks(nchunk, [&](int64_t t) {
+      const int64_t k0 = t << 20, k1 = std::min(nnz, k0 + (1 << 20));
+      for (int64_t k = k0; k < k1; ++k) {
+        const int64_t c = read_index(idx, k, bytes) - base;
+        if (c < 0 || c >= nminor) { badcol.store(1); return; }
+        out.col[k] = (int32_t)c;
+      }
+      std::memcpy(out.val.data() + k0, val + k0, sizeof(double) * (size_t)(k1 - k0));
+    });
+    REQUIRE(badcol.load() == 0, GMG_ERR_INVALID, "column index out of range");
   } else {
     // transpose CSC -> CSR by counting sort (keeps columns sorted within a row)
     for (int64_t k = 0; k < nnz; ++k) {
@@ -364,34 +398,6 @@ struct ConvLog {
 };
 
 constexpr int kScalarSlots = 4096;
-
-// setup-time host loops over independent chunks (slices, columns): plain std::thread fan-out
-template <typename F>
-void parallel_for(int64_t n, F &&fn)
-{
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 32u), std::max<int64_t>(1, n / 256));
-  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
-  std::vector<std::thread> th;
-  const int64_t chunk = (n + nt - 1) / nt;
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&, t] { for (int64_t i = t * chunk; i < std::min(n, (t + 1) * chunk); ++i) fn(i); });
-  for (auto &x : th) x.join();
-}
-
-// the same for a handful of BIG work items (one chunk of rows each): one thread per item, at most 32
-template <typename F>
-void parallel_chunks(int64_t n, F &&fn)
-{
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 32u), n);
-  if (nt <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
-  std::vector<std::thread> th;
-  std::atomic<int64_t> next(0);
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&] { for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
-  for (auto &x : th) x.join();
-}
 
 int env_int(const char *name, int dflt)
 {
@@ -901,6 +907,8 @@ struct gmg_solver {
               if (row_is(q, k0, len, ref)) { found[(size_t)i] = q; c = Hit{h, q}; ok = true; break; }
             if (ok) continue;
           }
+          if (bad.load(std::memory_order_relaxed)) return;
+          if ((int)first.size() > kMaxPatterns) { int z = 0; bad.compare_exchange_strong(z, 4); return; }   // not a pattern operator: stop early
           auto ins = first.emplace(h, i);                        // keeps the smallest row of the chunk (rows ascend)
           if (!ins.second) {
             // same hash as an earlier unresolved row r of this chunk: when the rows are equal, i takes r's id once r has one
@@ -923,6 +931,8 @@ struct gmg_solver {
       REQUIRE(bad.load() != 1, GMG_ERR_INVALID, "row pointers not monotone, or a row longer than 1024 entries");
       REQUIRE(bad.load() != 2, GMG_ERR_INVALID, "column index out of range");
       REQUIRE(bad.load() != 3, GMG_ERR_UNSUPPORTED, "streamed rows must have sorted, duplicate-free columns");
+      REQUIRE(bad.load() != 4, GMG_ERR_UNSUPPORTED,
+              "streamed operator has more than 4096 distinct rows: it is not pattern-compressible; pass it whole (gmg_set_matrix)");
       std::vector<std::pair<int64_t, uint64_t>> todo;
       for (auto &f : fresh) todo.insert(todo.end(), f.begin(), f.end());
       if (todo.empty()) break;
@@ -1278,24 +1288,41 @@ struct gmg_solver {
       }
       if (!few_values || 4.0 * (double)zp > 0.8 * 12.0 * (double)D.nnz) return;
     }
-    std::vector<int32_t> scol((size_t)zp), rowlen((size_t)H.nrows);
-    std::vector<double> sval((size_t)zp, 0.0);
-    parallel_for(ns, [&](int64_t sl) {
-      const int64_t w = (soff[sl + 1] - soff[sl]) / 64;
-      for (int l = 0; l < 64; ++l) {
-        const int64_t i = sl * 64 + l;
-        const int64_t len = i < H.nrows ? H.ptr[i + 1] - H.ptr[i] : 0;
-        if (i < H.nrows) rowlen[i] = (int32_t)len;
-        const int32_t padcol = len > 0 ? H.col[H.ptr[i]] : 0;   // any valid column
-        for (int64_t j = 0; j < w; ++j) {
-          const int64_t q = soff[sl] + j * 64 + l;
-          if (j < len) { scol[q] = H.col[H.ptr[i] + j]; sval[q] = H.val[H.ptr[i] + j]; }
-          else { scol[q] = padcol; sval[q] = 0.0; }
+    // the SELL arrays are laid out ON THE DEVICE from the CSR copy that is already there (a host-side build wrote and
+    // uploaded another 12 B per padded entry: 0.2 s for a 5 x 10^7-nonzero operator)
+    D.soff = upload(soff);
+    D.scol = dalloc<int32_t>((size_t)zp); D.sval = dalloc<double>((size_t)zp); D.rowlen = dalloc<int32_t>((size_t)H.nrows);
+    {
+      const int wpb = 4;
+      const dim3 g((unsigned)((ns + wpb - 1) / wpb)), b(64 * wpb);
+      if (D.ptr64) hipLaunchKernelGGL((sell_build_kernel<int64_t>), g, b, 0, stream, H.nrows, ns, (const int64_t *)D.rowptr, D.col, D.val, D.soff, D.scol, D.sval, D.rowlen);
+      else hipLaunchKernelGGL((sell_build_kernel<int32_t>), g, b, 0, stream, H.nrows, ns, (const int32_t *)D.rowptr, D.col, D.val, D.soff, D.scol, D.sval, D.rowlen);
+      HIP_CHECK(hipGetLastError());
+    }
+    D.nslices = (int)ns; D.zpad = zp; D.sell = true;
+    auto rowlen_of = [&](int64_t i) { return (int32_t)(H.ptr[i + 1] - H.ptr[i]); };
+    // (slice entry (j, lane l) of slice sl: column H.col[H.ptr[i] + j] for j < rowlen(i), else the row's first column)
+    auto scol_at = [&](int64_t sl, int64_t j, int l) {
+      const int64_t i = sl * 64 + l;
+      if (i >= H.nrows) return (int32_t)0;
+      const int64_t len = H.ptr[i + 1] - H.ptr[i];
+      return len > 0 ? H.col[H.ptr[i] + (j < len ? j : 0)] : (int32_t)0;
+    };
+    // value dictionary first: without it the 16-bit offsets are not used either (unless forced), so their packing is skipped
+    std::vector<uint64_t> keys;   // distinct bit patterns, sorted
+    bool few_keys = use_vdict != 0;
+    if (few_keys) {
+      keys.reserve(257);
+      for (int64_t k = 0; k < (int64_t)H.val.size() && few_keys; ++k) {
+        uint64_t bits;
+        std::memcpy(&bits, &H.val[k], 8);
+        auto it = std::lower_bound(keys.begin(), keys.end(), bits);
+        if (it == keys.end() || *it != bits) {
+          if (keys.size() == 256) few_keys = false;
+          else keys.insert(it, bits);
         }
       }
-    });
-    D.soff = upload(soff); D.scol = upload(scol); D.sval = upload(sval); D.rowlen = upload(rowlen);
-    D.nslices = (int)ns; D.zpad = zp; D.sell = true;
+    }
     // ---- lossless compression of the stream (see sellc_kernel) ----
     std::vector<int64_t> poff((size_t)ns + 1, 0);
     for (int64_t sl = 0; sl < ns; ++sl) {
@@ -1307,7 +1334,7 @@ struct gmg_solver {
     std::vector<uint16_t> pidx;
     std::vector<int32_t> pbase;
     int64_t n16 = 0;
-    if (use_idx16) {
+    if (use_idx16 && (few_keys || use_idx16 > 1)) {
       pidx.assign((size_t)zpp, 0);
       pbase.assign((size_t)(zpp / 64), 0);
       parallel_for(ns, [&](int64_t sl) {
@@ -1318,9 +1345,9 @@ struct gmg_solver {
           int32_t lo = INT32_MAX, hi = INT32_MIN;
           for (int l = 0; l < 64; ++l) {
             const int64_t i = sl * 64 + l;
-            if (i < H.nrows && j < rowlen[i]) { const int32_t c = scol[soff[sl] + j * 64 + l]; lo = std::min(lo, c); hi = std::max(hi, c); }
+            if (i < H.nrows && j < rowlen_of(i)) { const int32_t c = scol_at(sl, j, l); lo = std::min(lo, c); hi = std::max(hi, c); }
           }
-          if (lo == INT32_MAX) lo = hi = scol[soff[sl] + j * 64];   // all-padding column
+          if (lo == INT32_MAX) lo = hi = scol_at(sl, j, 0);        // all-padding column
           if ((int64_t)hi - lo > 65535) ok = false;
           pbase[poff[sl] / 64 + j] = lo;
         }
@@ -1330,9 +1357,9 @@ struct gmg_solver {
         for (int64_t j = 0; j < w4; ++j)
           for (int l = 0; l < 64; ++l) {
             const int64_t i = sl * 64 + l;
-            const bool real = j < w && i < H.nrows && j < rowlen[i];
+            const bool real = j < w && i < H.nrows && j < rowlen_of(i);
             const int32_t bj = pbase[poff[sl] / 64 + j];
-            const int32_t c = real ? scol[soff[sl] + j * 64 + l] : bj;      // padding decodes to the (valid) base column
+            const int32_t c = real ? scol_at(sl, j, l) : bj;                 // padding decodes to the (valid) base column
             pidx[poff[sl] + (j / 4) * 256 + l * 4 + (j % 4)] = (uint16_t)(c - bj);
           }
       });
@@ -1341,19 +1368,7 @@ struct gmg_solver {
     std::vector<uint8_t> pcode;
     std::vector<double> dict;
     if (use_vdict) {
-      std::vector<uint64_t> keys;   // distinct bit patterns, sorted
-      keys.reserve(257);
-      bool fits = true;
-      for (int64_t k = 0; k < (int64_t)H.val.size() && fits; ++k) {
-        uint64_t bits;
-        std::memcpy(&bits, &H.val[k], 8);
-        auto it = std::lower_bound(keys.begin(), keys.end(), bits);
-        if (it == keys.end() || *it != bits) {
-          if (keys.size() == 256) fits = false;
-          else keys.insert(it, bits);
-        }
-      }
-      if (fits) {
+      if (few_keys) {
         dict.assign(256, 0.0);
         for (size_t q = 0; q < keys.size(); ++q) std::memcpy(&dict[q], &keys[q], 8);
         pcode.assign((size_t)zpp, 0);
@@ -1362,7 +1377,7 @@ struct gmg_solver {
           for (int64_t j = 0; j < w; ++j)
             for (int l = 0; l < 64; ++l) {
               const int64_t i = sl * 64 + l;
-              if (i < H.nrows && j < rowlen[i]) {
+              if (i < H.nrows && j < rowlen_of(i)) {
                 uint64_t bits;
                 std::memcpy(&bits, &H.val[H.ptr[i] + j], 8);
                 const size_t code = std::lower_bound(keys.begin(), keys.end(), bits) - keys.begin();

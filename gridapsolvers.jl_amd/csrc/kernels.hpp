@@ -1772,6 +1772,30 @@ __global__ __launch_bounds__(64) void patch_invert_kernel(int64_t npatch, const 
   for (int e = lane; e < np * np; e += 64) out[e] = X[e];
 }
 
+// CSR -> SELL-64 on the device (setup): one wave per slice, lane = row; entry j of the slice's rows goes to
+// soff[slice] + 64 j + lane (coalesced writes).  Padding: value 0.0, column = the row's first column (any valid one).
+template <typename PtrT>
+__global__ __launch_bounds__(256) void sell_build_kernel(int64_t nrows, int64_t nslices, const PtrT *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ col, const double *__restrict__ val,
+                                                         const int64_t *__restrict__ soff, int32_t *__restrict__ scol,
+                                                         double *__restrict__ sval, int32_t *__restrict__ rowlen)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t sl = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (sl >= nslices) return;
+  const int64_t base = soff[sl];
+  const int64_t w = (soff[sl + 1] - base) >> 6;
+  const int64_t i = sl * 64 + lane;
+  int64_t k0 = 0, len = 0;
+  if (i < nrows) { k0 = (int64_t)rowptr[i]; len = (int64_t)rowptr[i + 1] - k0; rowlen[i] = (int32_t)len; }
+  const int32_t padcol = len > 0 ? col[k0] : 0;
+  for (int64_t j = 0; j < w; ++j) {
+    const int64_t q = base + j * 64 + lane;
+    if (j < len) { scol[q] = col[k0 + j]; sval[q] = val[k0 + j]; }
+    else { scol[q] = padcol; sval[q] = 0.0; }
+  }
+}
+
 // numerical_setup!: new values into an existing SELL-64 layout (sval[slice, j, lane] = val[rowptr[row] + j]) and the
 // Jacobi inverse diagonal recomputed from the refreshed rows.  PtrT = row pointer type of the kept CSR row pointers.
 template <typename PtrT>
