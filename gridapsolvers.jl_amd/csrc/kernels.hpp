@@ -645,9 +645,11 @@ __global__ __launch_bounds__(kBlock) void sellp_kernel(SellPArgs a)
   // xcd_remap the chunks of one XCD are contiguous too, so each L2 sees 1/8 of the gathered vector
   const int nwg = gridDim.x;
   const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
-  const int chunk = (a.nslices + nwg - 1) / nwg;
-  const int s_begin = blk * chunk;
-  const int s_end = min(a.nslices, s_begin + chunk);
+  // balanced chunks: nslices / nwg slices each, the remainder one more for the first workgroups (with ceil-sized chunks every
+  // workgroup of the 128^3 level had 17 slices for its 4 waves -- a fifth, nearly empty round for the whole chip)
+  const int chunk_lo = a.nslices / nwg, chunk_rem = a.nslices % nwg;
+  const int s_begin = blk * chunk_lo + min(blk, chunk_rem);
+  const int s_end = s_begin + chunk_lo + (blk < chunk_rem ? 1 : 0);
   const double *__restrict__ xg = a.x;
   const double *__restrict__ dinv = a.dinv;
   const double omega = a.omega;
@@ -790,9 +792,11 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x;
   const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
-  const int chunk = (a.nslices + nwg - 1) / nwg;
-  const int s_begin = blk * chunk;
-  const int s_end = min(a.nslices, s_begin + chunk);
+  // balanced chunks: nslices / nwg slices each, the remainder one more for the first workgroups (with ceil-sized chunks every
+  // workgroup of the 128^3 level had 17 slices for its 4 waves -- a fifth, nearly empty round for the whole chip)
+  const int chunk_lo = a.nslices / nwg, chunk_rem = a.nslices % nwg;
+  const int s_begin = blk * chunk_lo + min(blk, chunk_rem);
+  const int s_end = s_begin + chunk_lo + (blk < chunk_rem ? 1 : 0);
   const double *__restrict__ xg = a.x;
   const double *__restrict__ dinv = a.dinv;
   const double omega = a.omega;
@@ -965,9 +969,11 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x;
   const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
-  const int chunk = (a.nslices + nwg - 1) / nwg;
-  const int s_begin = blk * chunk;
-  const int s_end = min(a.nslices, s_begin + chunk);
+  // balanced chunks: nslices / nwg slices each, the remainder one more for the first workgroups (with ceil-sized chunks every
+  // workgroup of the 128^3 level had 17 slices for its 4 waves -- a fifth, nearly empty round for the whole chip)
+  const int chunk_lo = a.nslices / nwg, chunk_rem = a.nslices % nwg;
+  const int s_begin = blk * chunk_lo + min(blk, chunk_rem);
+  const int s_end = s_begin + chunk_lo + (blk < chunk_rem ? 1 : 0);
   const double *__restrict__ xg = a.x;
   const double omega = a.omega;
   const int last = (int)a.ncols - 1;
