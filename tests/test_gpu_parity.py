@@ -427,6 +427,8 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
                       "pattern_shared": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1"),
                       "pattern_shared_rb9": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_RB="9"),
                       "pattern_shared_strict": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_STRICT="1"),
+                      "pattern_shared_unmasked": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_STRICT="0"),
+                      "pattern_shared_unmasked_sweeps": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_STRICT="0", GMG_PERSIST="0"),
                       "pattern_shared_sweeps": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PERSIST="0"),
                       "pattern_shared_strict_sweeps": dict(GMG_PATTERN="1", GMG_PAT_SHARED="1", GMG_PAT_STRICT="1", GMG_PERSIST="0"),
                       "pattern_generic": dict(GMG_PATTERN="1", GMG_PAT_SHARED="0"),
@@ -455,6 +457,7 @@ def test_storage_formats_agree_bitwise(S, po, orc, hierarchy, monkeypatch):
         np.testing.assert_allclose(h, hist, rtol=TOL_HIST)
     # (the row-pattern kernels add explicit +0.0 terms for absent entries: the bits of the sums do not change)
     for name in ("sell_offsets", "sellc", "sell_idx16", "sell_dict", "pattern_shared", "pattern_shared_rb9", "pattern_shared_strict",
+                 "pattern_shared_unmasked", "pattern_shared_unmasked_sweeps",
                  "pattern_shared_sweeps", "pattern_shared_strict_sweeps", "pattern_generic", "pattern_generic_un3"):
         assert np.array_equal(out[name][0], out["sell"][0]) and np.array_equal(out[name][1], out["sell"][1]), name
 

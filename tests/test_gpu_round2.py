@@ -679,3 +679,57 @@ def test_restriction_from_eager_prolongation(S, po, hierarchy, monkeypatch):
         ns.P_ns.close()
     for x, y, it in res[1:]:
         np.testing.assert_array_equal(x, res[0][0]); np.testing.assert_array_equal(y, res[0][1]); assert it == res[0][2]
+
+
+def test_offset_patterns_and_eager_form_with_empty_and_ragged_rows(S, po, orc, monkeypatch):
+    """Edge cases of the two structure-detecting layouts: (a) SELL-O on an operator with random values on a banded structure that has
+    empty rows, short boundary rows and a ragged last slice; (b) the eager row-pattern scan (whole CSR handed to
+    gmg_set_restriction / gmg_set_prolongation, >= 20 000 rows) on operators with empty rows.  Products must equal the oracle's
+    left-to-right row sums bit for bit."""
+    import scipy.sparse as sp
+    from gridapsolvers_jl_amd import abi
+    rng = np.random.default_rng(5)
+    n = 64 * 400 + 37                                              # ragged last slice
+    offs = np.array([-301, -300, -299, -1, 0, 1, 299, 300, 301])
+    rows, cols = [], []
+    for o in offs:
+        i = np.arange(max(0, -o), min(n, n - o))
+        rows.append(i); cols.append(i + o)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    keep = np.ones(rows.size, dtype=bool)
+    dead = np.array([5, 6, 70, 1000, n - 1])                       # rows that keep only their diagonal ...
+    keep &= ~(np.isin(rows, dead) & (rows != cols))
+    A = sp.csr_matrix((rng.uniform(-1.0, 1.0, keep.sum()), (rows[keep], cols[keep])), shape=(n, n)).tocsr()
+    A = (A + sp.diags(np.full(n, 20.0))).tocsr(); A.sort_indices()
+    nH = n // 8
+    # P: two entries per row, constant values, every 97th row EMPTY; R = P^T has ~16 entries per row and some empty rows as well
+    pr = np.repeat(np.arange(n), 2); pc = np.minimum(np.stack([np.arange(n) // 8, np.arange(n) // 8 + 1], axis=1).reshape(-1), nH - 1)
+    pk = (pr % 97) != 0
+    pk &= ~((pc == 0) | (pc == 7))                                  # coarse columns 0 and 7 unused -> empty rows of R
+    Pm = sp.csr_matrix((np.where(np.arange(pr.size) % 2 == 0, 0.75, 0.25)[pk], (pr[pk], pc[pk])), shape=(n, nH)).tocsr()
+    Pm.sum_duplicates(); Pm.sort_indices()
+    AH = (Pm.T @ A @ Pm + sp.diags(np.full(nH, 1.0))).tocsr(); AH.sort_indices()
+    mk = lambda M: po.CSR(M.shape, M.indptr, M.indices, M.data)
+    H = dict(mats=[mk(A), mk(AH)], prolongations=[mk(Pm)], restrictions=[mk(Pm.T.tocsr())])
+    out = {}
+    for name, env in {"default": {}, "plain": dict(GMG_OPATTERN="0", GMG_EAGER="0")}.items():
+        for k in ("GMG_OPATTERN", "GMG_EAGER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ns = setup(S, make_gmg(S, H), H["mats"][0])
+        if name == "default":
+            assert ns.level_format(0)["layout"] == "SELL-O"
+        ys = []
+        for op, M in ((abi.OP_A, H["mats"][0]), (abi.OP_P, H["prolongations"][0]), (abi.OP_R, H["restrictions"][0])):
+            v = np.random.default_rng(11).uniform(-1, 1, M.shape[1])
+            y = np.full(M.shape[0], np.nan)
+            ns.op_apply(0, op, v, y)
+            assert np.array_equal(y, orc.spmv(M, v)), (name, op)
+            ys.append(y)
+        x, r = np.zeros(n), np.random.default_rng(12).uniform(-1, 1, n)
+        ns.smooth(0, x, r)
+        out[name] = ys + [x, r]
+        ns.close()
+    for a, b in zip(out["default"], out["plain"]):
+        np.testing.assert_array_equal(a, b)
