@@ -88,6 +88,7 @@ SYMBOLS = {
                          C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gmg_device_bytes": [C.c_void_p, C.POINTER(C.c_int64)],
     "gmg_stream_probe": [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)],
+    "gmg_stream_probe_read": [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)],
     "gmg_block_create": [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int],
     "gmg_block_destroy": [C.c_void_p],
     "gmg_block_last_error": [C.c_void_p],

@@ -3954,6 +3954,32 @@ int gmg_stream_probe(gmg_handle_t h, int64_t nbytes, int reps, double *gbytes_pe
   });
 }
 
+int gmg_stream_probe_read(gmg_handle_t h, int64_t nbytes, int reps, double *gbytes_per_s)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && gbytes_per_s, GMG_ERR_INVALID, "null argument");
+    REQUIRE(nbytes >= 4096 && reps >= 1, GMG_ERR_INVALID, "bad probe size");
+    const int64_t n2 = nbytes / 16;
+    double *src = nullptr, *sink = nullptr;
+    HIP_CHECK(hipMalloc((void **)&src, (size_t)n2 * 16));
+    if (hipMalloc((void **)&sink, 256 * 32 * 256 * sizeof(double)) != hipSuccess) { (void)hipFree(src); throw GmgError{GMG_ERR_ALLOC, "probe buffers"}; }
+    HIP_CHECK(hipMemsetAsync(src, 0, (size_t)n2 * 16, h->stream));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    const int grid = (int)std::min<int64_t>((n2 + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, h->stream, n2, src, sink);   // warm-up
+    HIP_CHECK(hipEventRecord(e0, h->stream));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(stream_read_kernel, dim3(grid), dim3(256), 0, h->stream, n2, src, sink);
+    HIP_CHECK(hipEventRecord(e1, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(sink);
+    *gbytes_per_s = 16.0 * (double)n2 * reps / ((double)ms * 1e-3) / 1e9;
+  });
+}
+
 int gmg_device_bytes(gmg_handle_t h, int64_t *bytes)
 {
   return guarded(h, [&] {

@@ -1242,6 +1242,19 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(int64_t n2, const doub
     __builtin_nontemporal_store(__builtin_nontemporal_load(s2 + i), t2 + i);
 }
 
+// read-only twin of the probe (gmg_stream_probe_read): 16 B per lane, non-temporal loads, one 8-byte result per thread
+__global__ __launch_bounds__(256) void stream_read_kernel(int64_t n2, const double *__restrict__ src, double *__restrict__ sink)
+{
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 *s2 = reinterpret_cast<const d2 *>(src);
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    const d2 v = __builtin_nontemporal_load(s2 + i);
+    acc += v.x + v.y;
+  }
+  sink[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
 // s = omega*(dinv.*r)  (first sweep of a ONEG smoothing pass)
 __global__ void scaled_jacobi_kernel(int64_t n, double omega, const double *__restrict__ dinv,
                                      const double *__restrict__ r, double *__restrict__ s)

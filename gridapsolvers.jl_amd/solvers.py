@@ -547,6 +547,11 @@ class GMGNumericalSetup:
         abi.check(self.h, self._lib.gmg_stream_probe(self.h, nbytes, reps, C.byref(v)))
         return v.value
 
+    def stream_probe_read(self, nbytes=1 << 30, reps=10):
+        v = C.c_double(0.0)
+        abi.check(self.h, self._lib.gmg_stream_probe_read(self.h, nbytes, reps, C.byref(v)))
+        return v.value
+
     def model_bytes(self):
         a, b = C.c_double(0.0), C.c_double(0.0)
         abi.check(self.h, self._lib.gmg_model_bytes(self.h, C.byref(a), C.byref(b)))

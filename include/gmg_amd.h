@@ -301,6 +301,8 @@ GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int
 /* Measured streaming ceiling: a 16 B/lane copy kernel over nbytes (read) + nbytes (write), reps launches timed with HIP
  * events on the handle's stream; *gbytes_per_s = moved bytes / time.  Reported by bench.py beside the 8 TB/s spec. */
 GMG_API int gmg_stream_probe(gmg_handle_t h, int64_t nbytes, int reps, double *gbytes_per_s);
+/* The same for a READ-ONLY stream of nbytes (the sweeps read ~9x more than they write, so their ceiling lies between the two). */
+GMG_API int gmg_stream_probe_read(gmg_handle_t h, int64_t nbytes, int reps, double *gbytes_per_s);
 /* Device memory held by the handle, bytes. */
 GMG_API int gmg_device_bytes(gmg_handle_t h, int64_t *bytes);
 
