@@ -124,6 +124,10 @@ __global__ void relax_update_kernel(int64_t n, double omega, double *__restrict_
     x[i] = x[i] + d;
   }
 }
+__global__ void scale_inplace_kernel(int64_t n, double omega, double *__restrict__ dx)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dx[i] = omega * dx[i];
+}
 // full[gid[i]] = r[i]  (coarse-level gather into the replicated vector)
 __global__ void scatter_gid_kernel(int64_t n, const int64_t *__restrict__ gid, const double *__restrict__ r,
                                    double *__restrict__ full)

@@ -41,7 +41,7 @@ enum Epi : int {
   EPI_SUB = 1,     // y = y - A x                  (K3)
   EPI_RESID = 2,   // y = b - A x                  (CGSolvers.jl:79, GMGLinearSolvers.jl:623-624)
   EPI_SWEEP = 3,   // one Richardson-Jacobi sweep  (K2+K1+K3 fused, see below)
-  EPI_ADDTO = 4    // y = A x ; x2 += y            (K5)
+  EPI_ADDTO = 4    // y = A x ; x2 += y            (K5); with omega != 0: y = omega (A x) ; x2 += y  (relaxed patch-operator update)
 };
 
 __device__ __forceinline__ int remap_block(int b, int nb, int on)
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream1_kernel(StreamArgs2 a)
       if (EPI == EPI_SET) { rn = s; a.y[row] = rn; }
       else if (EPI == EPI_SUB) { rn = e0 - s; a.y[row] = rn; }
       else if (EPI == EPI_RESID) { rn = e0 - s; a.y[row] = rn; }
-      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+      else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
       else { // EPI_SWEEP
         const double dxi = ONEG ? e1 : omega * (e1 * e0);
         a.x2[row] = e2 + dxi;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock) void csr_stream1_kernel(StreamArgs2 a)
       if (EPI == EPI_SET) { rn = s; a.y[row] = rn; }
       else if (EPI == EPI_SUB) { rn = a.y[row] - s; a.y[row] = rn; }
       else if (EPI == EPI_RESID) { rn = a.b[row] - s; a.y[row] = rn; }
-      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = a.x2[row] + s; }
+      else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = a.x2[row] + t; }
       else {
         const double ro = a.b[row];
         const double dxi = ONEG ? xg[row] : omega * (dinv[row] * ro);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
     if (EPI == EPI_SET) a.y[row] = s;
     else if (EPI == EPI_SUB) a.y[row] = e0 - s;
     else if (EPI == EPI_RESID) a.y[row] = e0 - s;
-    else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+    else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
     else {
       const double dxi = ONEG ? e1 : omega * (e1 * e0);
       a.x2[row] = e2 + dxi;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void sello_kernel(SellOArgs a)
     if (EPI == EPI_SET) a.y[row] = s;
     else if (EPI == EPI_SUB) a.y[row] = e0 - s;
     else if (EPI == EPI_RESID) a.y[row] = e0 - s;
-    else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+    else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
     else {
       const double dxi = ONEG ? e1 : omega * (e1 * e0);
       a.x2[row] = e2 + dxi;
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void sellc_kernel(SellCArgs a)
     if (EPI == EPI_SET) a.y[row] = s;
     else if (EPI == EPI_SUB) a.y[row] = e0 - s;
     else if (EPI == EPI_RESID) a.y[row] = e0 - s;
-    else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+    else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
     else {
       const double dxi = ONEG ? e1 : omega * (e1 * e0);
       a.x2[row] = e2 + dxi;
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(kBlock) void sellp_kernel(SellPArgs a)
       if (EPI == EPI_SET) { a.y[row] = s; if (a.s_out) a.s_out[row] = omega * (dinv[row] * s); }      // optional s emission, see sells_kernel
       else if (EPI == EPI_SUB) { const double yn = e0 - s; a.y[row] = yn; if (a.s_out) a.s_out[row] = omega * (dinv[row] * yn); }
       else if (EPI == EPI_RESID) a.y[row] = e0 - s;
-      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+      else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
       else {
         const double dxi = ONEG ? e1 : omega * (e1 * e0);
         a.x2[row] = e2 + dxi;
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       if (EPI == EPI_SET) { a.y[row] = s; if (a.s_out) a.s_out[row] = omega * (dinv[row] * s); }
       else if (EPI == EPI_SUB) { const double yn = e0 - s; a.y[row] = yn; if (a.s_out) a.s_out[row] = omega * (dinv[row] * yn); }
       else if (EPI == EPI_RESID) a.y[row] = e0 - s;
-      else if (EPI == EPI_ADDTO) { a.y[row] = s; a.x2[row] = e0 + s; }
+      else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
       else {
         if (xmode == 0) a.x2[row] = e2 + e1;               // x += s_k
         else if (xmode == 2) a.x2[row] = (e2 + sp) + e1;   // the deferred x += s_{k-1}, then x += s_k: same two roundings
