@@ -733,3 +733,41 @@ def test_offset_patterns_and_eager_form_with_empty_and_ragged_rows(S, po, orc, m
         ns.close()
     for a, b in zip(out["default"], out["plain"]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("nc,nlev", [((12, 12, 12), 2), ((24, 24), 3)])
+def test_patch_operator_form_matches_patch_solves(S, po, orc, hierarchy, monkeypatch, nc, nlev):
+    """The additive-Schwarz operator sum_p R_p^T inv(A_pp) R_p in row-pattern form (default) against the patch-by-patch
+    kernels (GMG_PATCH_OPERATOR=0) and the oracle: one application of the patch preconditioner (<= 1e-12), a V-cycle and the
+    FGMRES solve (same iteration count, histories <= 1e-8).  Pre-summing the coefficients of a column over the patches changes
+    the rounding order, not the operator."""
+    order = 2
+    H = hierarchy(nc, nlev, order)
+    tabs = [po.vertex_star_patches(tuple(c // 2 ** l for c in nc), order) for l in range(nlev - 1)]
+    b = po.dirichlet_lift_rhs(nc, order)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GMG_PATCH_OPERATOR", flag)
+        sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 5, 0.2) for pp, pd in tabs]
+        solver = S.FGMRESSolver(5, make_gmg(S, H, pre_smoothers=sm), maxiter=30, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        r = np.random.default_rng(8).uniform(-1, 1, H["mats"][0].shape[0])
+        dx = np.zeros_like(r)
+        ns.P_ns.precond(0, r, dx)
+        z = np.zeros_like(r)
+        S.solve_(z, ns.P_ns, r)
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        res[flag] = (dx, z, x, solver.log.num_iters, solver.log.residuals[: solver.log.num_iters + 1].copy())
+        ns.P_ns.close()
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"],
+                 pre_smoothers=[orc.Smoother(orc.PATCH, 5, 0.2, pp, pd) for pp, pd in tabs], maxiter=1)
+    r = np.random.default_rng(8).uniform(-1, 1, H["mats"][0].shape[0])
+    dxo = go.precond(0, r)
+    for flag in ("1", "0"):
+        assert max_rel(res[flag][0], dxo) <= 1e-12, flag
+    assert max_rel(res["1"][0], res["0"][0]) <= 1e-12
+    assert rel_err(res["1"][1], res["0"][1]) <= 1e-11
+    assert res["1"][3] == res["0"][3]
+    np.testing.assert_allclose(res["1"][4], res["0"][4], rtol=1e-8)
+    assert rel_err(res["1"][2], res["0"][2]) <= 1e-9
