@@ -3112,6 +3112,16 @@ void gmg_solver::setup()
     std::fprintf(stderr, "[gmg_setup] level %d %-28s %8.1f ms\n", l, what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
+  if (comm.nranks > 1) {
+    // operators handed over BEFORE the communicator was initialised may sit in the (single-GPU) row-pattern-only form: the
+    // distributed setup splits own / ghost columns on the CSR, so give them their rows back
+    for (int l = 0; l < nlev; ++l) {
+      Level &L = lev[l];
+      if (L.sA && L.sA->complete()) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
+      if (L.sP && L.sP->complete()) { L.hP = expand_stream(*L.sP); L.sP.reset(); }
+      if (L.sR && L.sR->complete()) { L.hR = expand_stream(*L.sR); L.sR.reset(); }
+    }
+  }
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
     REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));

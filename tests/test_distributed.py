@@ -143,6 +143,15 @@ def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_p
 
 
 @pytest.mark.gpu
+def test_partitioned_operators_big_enough_for_the_eager_pattern_scan(tmp_path):
+    """Local matrices of >= 20 000 rows: on one GPU such structured CSR inputs are kept in row-pattern form only.  A distributed
+    setup splits own / ghost columns on the CSR, so the scan must stay off once the communicator exists (the ABI requires
+    gmg_comm_init_* before rectangular local matrices are accepted at all)."""
+    v = _launch("gpu", 2, (32, 32, 32), 3, tmp_path, transport="host", rep_from=2)
+    _check(v)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,cells,nlev,rep", [(2, (16, 16, 16), 3, 0), (8, (8, 8, 8), 3, 1)])
 def test_overlapped_schedule_with_async_host_transport(world, cells, nlev, rep, tmp_path):
     """The two-stream / two-event schedule of the RCCL path (halo on comm_stream while the own x own kernel
