@@ -287,6 +287,7 @@ struct Smoother {
   int64_t *d_boff = nullptr;
   double *d_binv = nullptr;
   int64_t n_binv = 0, n_ubinv = 0, n_uboff = 0;   // allocation sizes (value refresh releases and rebuilds the blocks)
+  int64_t n_isoff = 0, n_isinc = 0;
   // de-duplicated blocks (uniform meshes): patch -> unique block id, compact block store
   bool dedup = false;
   int64_t nuniq = 0;
@@ -2480,6 +2481,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
       });
       S.d_isoff = upload(soff);
       S.d_isinc = upload_padded(sinc, 64);
+      S.n_isoff = (int64_t)soff.size(); S.n_isinc = (int64_t)sinc.size() + 64;
       S.d_iptr = nullptr; S.d_inc = nullptr;
     } else {
       S.d_iptr = upload(iptr);
@@ -2848,7 +2850,6 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
     P.wmax = std::max<int64_t>(P.wmax, len);
   }
   P.rowpid.resize((size_t)n);
-  std::vector<int64_t> nnz_t(64, 0);
   parallel_for(n, [&](int64_t i) { P.rowpid[(size_t)i] = (uint16_t)sig[(size_t)i]; });
   for (int64_t i = 0; i < n; ++i) P.nnz += P.len[(size_t)sig[(size_t)i]];
   P.rows_seen = n;
@@ -2863,7 +2864,7 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   // the patch-solve path's buffers are not needed any more
   HIP_CHECK(hipStreamSynchronize(stream));
   release(S.d_contrib, (size_t)ne + 1);
-  if (S.d_isoff) { release(S.d_isoff, (size_t)1); release(S.d_isinc, (size_t)1); }
+  if (S.d_isoff) { release(S.d_isoff, (size_t)S.n_isoff); release(S.d_isinc, (size_t)S.n_isinc); }
   if (S.d_iptr) { release(S.d_iptr, (size_t)n + 1); release(S.d_inc, (size_t)ne); }
   if (env_int("GMG_SETUP_TIMING", 0))
     std::fprintf(stderr, "[gmg_setup] patch operator: %lld rows, %zu shapes, %zu distinct rows, %lld nnz, %.1f ms\n", (long long)n, shape_rep.size(),
