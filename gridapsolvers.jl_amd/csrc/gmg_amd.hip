@@ -2451,11 +2451,13 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
   S.d_pptr = upload(T.pptr);
   S.d_pdofs = upload(T.prow);
   S.d_pcol = T.pcol.empty() ? S.d_pdofs : upload(T.pcol);
-  S.d_contrib = dvec(ndof_entries + 1);                    // + one slot that stays 0.0: the padding target of the sliced incidence
   }
   int32_t *d_pcol = S.d_pcol;
-  // dof -> contribution slots, ascending patch order (= reference loop order PatchSolvers.jl:288)
-  if (!blocks_only) {
+  // dof -> contribution slots, ascending patch order (= reference loop order PatchSolvers.jl:288).  Built at the first setup;
+  // again after a value refresh when the row-pattern form of the patch operator (which had released these buffers) can no
+  // longer be formed.
+  auto make_incidence = [&]() {
+    S.d_contrib = dvec(ndof_entries + 1);                  // + one slot that stays 0.0: the padding target of the sliced incidence
     std::vector<int64_t> iptr((size_t)nloc + 1, 0), inc((size_t)ndof_entries);
     for (int64_t q = 0; q < ndof_entries; ++q) iptr[pcolv[q] + 1]++;
     for (int64_t i = 0; i < nloc; ++i) iptr[i + 1] += iptr[i];
@@ -2487,7 +2489,8 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
       S.d_iptr = upload(iptr);
       S.d_inc = upload(inc);
     }
-  }
+  };
+  if (!blocks_only) make_incidence();
   if (npatch == 0 || max_np == 0) { S.built = true; return; }
 
   // ---- inverse blocks, built in batches (bounded scratch) and de-duplicated on the fly -------------------------------
@@ -2674,6 +2677,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
   S.built = true;
   build_patch_operator(L, S);
   S.h_ublock.clear(); S.h_ublock.shrink_to_fit(); S.h_uboff.clear();
+  if (!S.use_M && !S.d_contrib) make_incidence();           // (value refresh: the patch-by-patch kernels are needed again)
 }
 
 // ----------------------------------------------------------------------------

@@ -771,3 +771,31 @@ def test_patch_operator_form_matches_patch_solves(S, po, orc, hierarchy, monkeyp
     assert res["1"][3] == res["0"][3]
     np.testing.assert_allclose(res["1"][4], res["0"][4], rtol=1e-8)
     assert rel_err(res["1"][2], res["0"][2]) <= 1e-9
+
+
+def test_value_refresh_after_the_patch_operator_released_its_buffers(S, po, hierarchy, monkeypatch):
+    """The row-pattern form of the patch operator releases the contribution buffer and the incidence lists.  A value refresh
+    that cannot form it again (here: switched off between the two setups) must bring the patch-by-patch kernels back and equal a
+    fresh setup made under the same switch, to the last bit."""
+    nc, nlev, order = (12, 12, 12), 2, 2
+    H = hierarchy(nc, nlev, order)
+    pp, pd = po.vertex_star_patches(nc, order)
+    mk = lambda: S.FGMRESSolver(5, make_gmg(S, H, pre_smoothers=[S.RichardsonSmoother(S.PatchSolver(pp, pd), 5, 0.2)]), maxiter=30, atol=1e-14, rtol=1e-8)
+    b = po.dirichlet_lift_rhs(nc, order)
+    monkeypatch.setenv("GMG_PATCH_OPERATOR", "1")
+    monkeypatch.setenv("GMG_VDICT", "0"); monkeypatch.setenv("GMG_PATTERN", "0")     # explicit-value layout: the refresh path applies
+    solver = mk()
+    ns = setup(S, solver, H["mats"][0])
+    x0 = np.zeros_like(b); S.solve_(x0, ns, b)
+    monkeypatch.setenv("GMG_PATCH_OPERATOR", "0")
+    A2 = po.CSR(H["mats"][0].shape, H["mats"][0].ptr, H["mats"][0].idx, 1.25 * H["mats"][0].val)
+    mats2 = [A2] + list(H["mats"][1:])
+    S.numerical_setup_(ns, A2, mats2)
+    x = np.zeros_like(b); S.solve_(x, ns, b)
+    H2 = dict(H, mats=mats2)
+    s2 = S.FGMRESSolver(5, make_gmg(S, H2, pre_smoothers=[S.RichardsonSmoother(S.PatchSolver(pp, pd), 5, 0.2)]), maxiter=30, atol=1e-14, rtol=1e-8)
+    ns2 = setup(S, s2, A2)
+    xf = np.zeros_like(b); S.solve_(xf, ns2, b)
+    np.testing.assert_array_equal(x, xf)
+    assert solver.log.num_iters == s2.log.num_iters
+    assert rel_err(x, x0 / 1.25) < 1e-6
