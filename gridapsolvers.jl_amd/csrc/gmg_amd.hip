@@ -1884,9 +1884,13 @@ struct gmg_solver {
     }
     return true;
   }
-  void check_persistent() const
+  void check_persistent()
   {
-    REQUIRE(!(h_perr && *h_perr), GMG_ERR_STATE, "persistent smoothing pass: a neighbour wait timed out (workgroups not co-resident?); set GMG_PERSIST=0");
+    if (!(h_perr && *h_perr)) return;
+    *h_perr = 0;
+    persist = 0;                                             // later solves of this handle sweep launch by launch
+    throw GmgError{GMG_ERR_STATE, "one-launch smoothing pass: a neighbour wait timed out (its workgroups were not all resident -- is the GPU shared with "
+                                  "other persistent kernels?); the results of this call are invalid, the handle now runs with GMG_PERSIST=0"};
   }
 
   // solve!(x,ns::RichardsonSmootherNumericalSetup,r), RichardsonSmoothers.jl:84-98.
@@ -3382,6 +3386,7 @@ int guarded(gmg_handle_t h, F &&f)
   try {
     if (h) HIP_CHECK(hipSetDevice(h->device));
     f();
+    if (h) h->check_persistent();                           // a bounded wait of the one-launch smoothing pass timed out (host-mapped flag)
     return GMG_OK;
   } catch (const GmgError &e) {
     if (h) h->err = e.msg;
