@@ -799,3 +799,37 @@ def test_value_refresh_after_the_patch_operator_released_its_buffers(S, po, hier
     np.testing.assert_array_equal(x, xf)
     assert solver.log.num_iters == s2.log.num_iters
     assert rel_err(x, x0 / 1.25) < 1e-6
+
+
+def test_persistent_smoothing_pass_under_uneven_load(S, po, hierarchy, monkeypatch):
+    """Inter-workgroup hand-offs must be tested with other work on the chip (stale-data and residency hazards hide on an idle GPU):
+    V-cycles with the one-launch smoothing passes run while a second stream keeps the CUs busy with GEMMs of varying size;
+    every result must equal the per-sweep reference bit for bit."""
+    import torch
+    nc, nlev = (64, 64, 64), 4
+    H = hierarchy(nc, nlev)
+    n = H["mats"][0].shape[0]
+    rs = [np.random.default_rng(300 + k).uniform(-1, 1, n) for k in range(4)]
+    monkeypatch.setenv("GMG_PERSIST", "0")
+    ns0 = setup(S, make_gmg(S, H), H["mats"][0])
+    ref = []
+    for r in rs:
+        z = np.zeros(n); S.solve_(z, ns0, r); ref.append(z)
+    ns0.close()
+    monkeypatch.setenv("GMG_PERSIST", "1")
+    ns = setup(S, make_gmg(S, H), H["mats"][0])
+    side = torch.cuda.Stream()
+    a = torch.randn(3072, 3072, device="cuda"); b = torch.randn(3072, 3072, device="cuda")
+    small = torch.randn(256, 256, device="cuda")
+    rd = [torch.from_numpy(r).cuda() for r in rs]
+    zd = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(60):
+        with torch.cuda.stream(side):                               # uneven background load: big and tiny kernels alternate
+            for k in range(3):
+                (a @ b) if (rep + k) % 2 == 0 else (small @ small)
+        S.solve_(zd, ns, rd[rep % 4])
+        got = zd.cpu().numpy()
+        np.testing.assert_array_equal(got, ref[rep % 4], err_msg=f"V-cycle {rep} under load")
+    torch.cuda.synchronize()
+    ns.close()
