@@ -193,3 +193,23 @@ def test_rccl_binding_selftest_single_rank(pkg):
     abi.check(h, lib.gmg_comm_selftest(h, out))
     assert out[0] == 1.5 and out[1] == 42.0
     lib.gmg_destroy(h)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), both ranks sharing the single
+    GPU of the test box over the host-staged transport: the JSON contract of the multi-rank line and the joint self-check."""
+    import subprocess
+    env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "32", "--levels", "3",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["unit"] == "DoFs/s" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["transport"] == "host" and d["config"]["degraded"] is True
+    assert d["config"]["cg_iterations"] <= 4 and d["config"]["max_abs_error_vs_exact"] < 1e-4
+    assert d["roofline"]["frac"] is None or d["roofline"]["frac"] <= 1.0
