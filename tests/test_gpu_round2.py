@@ -833,3 +833,45 @@ def test_persistent_smoothing_pass_under_uneven_load(S, po, hierarchy, monkeypat
         np.testing.assert_array_equal(got, ref[rep % 4], err_msg=f"V-cycle {rep} under load")
     torch.cuda.synchronize()
     ns.close()
+
+
+def test_offset_pattern_layout_large_level_paths(S, po, monkeypatch):
+    """Levels above ~10^5 rows take the 4-waves-per-workgroup geometry and, above 128 MB of values, non-temporal loads; the
+    small parity cases never reach those instantiations.  Variable-coefficient 96^3: SELL-O against SELL-64, bit for bit, on the
+    operator, a smoothing pass and the CG solve; linearity and symmetry of the V-cycle."""
+    import torch
+    from gridapsolvers_jl_amd import abi
+    nc, nlev = (96, 96, 96), 3
+    H = po.build_hierarchy(nc, nlev, 1, kappa=po.smooth_kappa)
+    A = H["mats"][0]
+    n = A.shape[0]
+    uex = po.nodal_values(nc, 1)
+    b = A.matvec(uex)
+    res = {}
+    for layout, flag in (("SELL-64", "0"), ("SELL-O", "1")):
+        monkeypatch.setenv("GMG_OPATTERN", flag)
+        solver = S.CGSolver(make_gmg(S, H), maxiter=30, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, A)
+        assert ns.P_ns.level_format(0)["layout"] == layout
+        v = np.random.default_rng(1).uniform(-1, 1, n)
+        y = np.zeros(n); ns.P_ns.op_apply(0, abi.OP_A, v, y)
+        xs, rs = np.zeros(n), v.copy(); ns.P_ns.smooth(0, xs, rs)
+        x = np.zeros(n); S.solve_(x, ns, b)
+        res[layout] = (y, xs, rs, x, solver.log.num_iters)
+        if layout == "SELL-O":
+            assert np.max(np.abs(x - uex)) < 1e-6
+            g = ns.P_ns
+            r1, r2 = torch.from_numpy(np.random.default_rng(2).uniform(-1, 1, n)).cuda(), torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, n)).cuda()
+            z1, z2, z3 = torch.zeros_like(r1), torch.zeros_like(r1), torch.zeros_like(r1)
+            torch.cuda.synchronize()
+            S.solve_(z1, g, r1); S.solve_(z2, g, r2)
+            r3 = (0.5 * r1 - r2).contiguous(); torch.cuda.synchronize()
+            S.solve_(z3, g, r3)
+            assert (torch.linalg.norm(z3 - (0.5 * z1 - z2)) / torch.linalg.norm(z3)).item() < 1e-12
+            a12, a21 = torch.dot(z1, r2).item(), torch.dot(r1, z2).item()
+            assert abs(a12 - a21) <= 1e-10 * max(abs(a12), abs(a21))
+        ns.P_ns.close()
+    for a, c in zip(res["SELL-64"][:4], res["SELL-O"][:4]):
+        np.testing.assert_array_equal(a, c)
+    assert res["SELL-64"][4] == res["SELL-O"][4]
+    assert max_rel(res["SELL-O"][0], A.matvec(np.random.default_rng(1).uniform(-1, 1, n))) <= 1e-13
