@@ -735,13 +735,16 @@ def test_offset_patterns_and_eager_form_with_empty_and_ragged_rows(S, po, orc, m
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("coded", ["default", "coded"])
 @pytest.mark.parametrize("nc,nlev", [((12, 12, 12), 2), ((24, 24), 3)])
-def test_patch_operator_form_matches_patch_solves(S, po, orc, hierarchy, monkeypatch, nc, nlev):
+def test_patch_operator_form_matches_patch_solves(S, po, orc, hierarchy, monkeypatch, nc, nlev, coded):
     """The additive-Schwarz operator sum_p R_p^T inv(A_pp) R_p in row-pattern form (default) against the patch-by-patch
     kernels (GMG_PATCH_OPERATOR=0) and the oracle: one application of the patch preconditioner (<= 1e-12), a V-cycle and the
     FGMRES solve (same iteration count, histories <= 1e-8).  Pre-summing the coefficients of a column over the patches changes
     the rounding order, not the operator."""
     order = 2
+    if coded == "coded":
+        monkeypatch.setenv("GMG_PAT_CODED_MIN_ROWS", "0")          # the coded shared-offset table (what the 10^8-dof levels use) for A and M
     H = hierarchy(nc, nlev, order)
     tabs = [po.vertex_star_patches(tuple(c // 2 ** l for c in nc), order) for l in range(nlev - 1)]
     b = po.dirichlet_lift_rhs(nc, order)
