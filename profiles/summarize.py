@@ -94,12 +94,15 @@ def main():
         fam = family(name)
         if fam is None:
             continue
-        key = (fam, "nt" if ", true>" in name and fam == "sell_kernel" else "")
+        # one record per (family, grid): the finest level and, when its batched variant runs on a smaller grid than the next
+        # level's (NB = 2 on 1024 workgroups), that level too; small levels (< 10^5 threads) are left out
+        if grid < 100000:
+            continue
+        key = (fam, "nt" if ", true>" in name and fam == "sell_kernel" else "", grid)
         if key not in fams:
             fams[key] = dict(grid=grid, members=[])
-        if grid == fams[key]["grid"]:
-            fams[key]["members"].append((name, avg_us, cnt))
-    for (fam, _), info in fams.items():
+        fams[key]["members"].append((name, avg_us, cnt))
+    for (fam, _, _g), info in fams.items():
         grid = info["grid"]
         tot_cnt = sum(m[2] for m in info["members"])
         avg_us = sum(m[1] * m[2] for m in info["members"]) / tot_cnt
