@@ -514,7 +514,7 @@ struct gmg_solver {
   int pat_batched = 1;  // GMG_PAT_BATCHED: the restructured sweep kernel (sells_sweep_kernel) for plain shared-offset tables
   int pat_nb = 0;       // GMG_PAT_NB: slices per batch of that kernel (0 = auto: 1, or 2 on levels with >= 200000 slices)
   int pat_small_wpb = 4;   // GMG_PAT_SMALL_WPB: waves per workgroup of sells_kernel on levels with < 8192 slices (table staging amortised)
-  int pat_small_wpb2 = 1;  // GMG_PAT_SMALL_WPB2: the same for sellp_kernel
+  int pat_small_wpb2 = 2;  // GMG_PAT_SMALL_WPB2: the same for sellp_kernel
   int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
   int64_t pat_coded_min_rows = 500000;   // GMG_PAT_CODED_MIN_ROWS
   int gj_mfma = 1;      // GMG_GJ_MFMA: trailing update of the device coarse inversion on the FP64 matrix cores
@@ -2168,7 +2168,7 @@ struct gmg_solver {
     pat_coded_min_rows = env_int("GMG_PAT_CODED_MIN_ROWS", 500000);
     pat_emit = env_int("GMG_PAT_EMIT", 1);
     pat_small_wpb = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB", 4)));
-    pat_small_wpb2 = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB2", 1)));
+    pat_small_wpb2 = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB2", 2)));
     pat_dinv = env_int("GMG_PAT_DINV", 1);
     pat_rb = env_int("GMG_PAT_RB", 3); pat_rb = pat_rb >= 9 ? 9 : (pat_rb <= 1 ? 1 : 3);
     pat_batched = env_int("GMG_PAT_BATCHED", 1);
