@@ -77,6 +77,7 @@ SYMBOLS = {
     "gmg_comm_unique_id": [C.c_char_p, C.c_char_p],
     "gmg_comm_init_rccl": [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int],
     "gmg_comm_selftest": [C.c_void_p, C.POINTER(C.c_double)],
+    "gmg_comm_latency_probe": [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)],
     "gmg_comm_init_host": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "gmg_set_partition": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_void_p],

@@ -4044,6 +4044,87 @@ int gmg_comm_selftest(gmg_handle_t h, double *out2)
   });
 }
 
+// Latency of the two communication primitives as the solver issues them (DESIGN.md section 5's model is built on these):
+//   out[0] stream time (us) of one halo exchange = ev_ready -> comm_stream: grouped ncclSend/ncclRecv of `nmsg` messages of `count`
+//          doubles each -> ev_done -> main stream, with a 1-block kernel on the main stream between exchanges (the dependent
+//          mat-vec of a latency-bound level); out[1] host time (us) to enqueue it;
+//   out[2] stream time (us) of a 1-double ncclAllReduce + the square-root kernel (PVector norm); out[3] its host enqueue time;
+//   out[4] the same exchange issued in-stream (no second stream, no events); out[5] an empty 1-block kernel (launch floor).
+// Peers: rank +- 1, +- 2, ... (ring distance) on a multi-rank communicator, the rank itself on one rank (RCCL then runs its
+// send/recv kernel without an xGMI hop: the launch + proxy floor of the path).
+int gmg_comm_latency_probe(gmg_handle_t h, int nmsg, int64_t count, int reps, double *out6)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && out6, GMG_ERR_INVALID, "null argument");
+    REQUIRE(h->comm.kind == COMM_RCCL, GMG_ERR_STATE, "RCCL communicator not initialised");
+    REQUIRE(nmsg >= 1 && nmsg <= 26 && count >= 1 && reps >= 1, GMG_ERR_INVALID, "bad probe shape");
+    const int nr = h->comm.nranks, me = h->comm.rank;
+    double *snd = nullptr, *rcv = nullptr, *sc = nullptr;
+    HIP_CHECK(hipMalloc((void **)&snd, sizeof(double) * (size_t)nmsg * (size_t)count));
+    HIP_CHECK(hipMalloc((void **)&rcv, sizeof(double) * (size_t)nmsg * (size_t)count));
+    HIP_CHECK(hipMalloc((void **)&sc, 8 * sizeof(double)));
+    HIP_CHECK(hipMemset(snd, 0, sizeof(double) * (size_t)nmsg * (size_t)count));
+    HIP_CHECK(hipMemset(sc, 0, 8 * sizeof(double)));
+    hipEvent_t t0, t1;
+    HIP_CHECK(hipEventCreate(&t0));
+    HIP_CHECK(hipEventCreate(&t1));
+    auto peer = [&](int k, bool up) {          // k-th message: ring distance k/2+1, alternating direction
+      if (nr == 1) return me;
+      const int d = (k / 2 + 1) % nr;
+      return ((k & 1) == (up ? 0 : 1)) ? (me + d) % nr : (me - d + nr) % nr;
+    };
+    auto group = [&](hipStream_t st) {
+      int rc = h->comm.api.GroupStart();
+      for (int k = 0; k < nmsg && rc == 0; ++k) {
+        rc = h->comm.api.Send(snd + (size_t)k * count, (size_t)count, kNcclDouble, peer(k, true), h->comm.comm, st);
+        if (rc == 0) rc = h->comm.api.Recv(rcv + (size_t)k * count, (size_t)count, kNcclDouble, peer(k, false), h->comm.comm, st);
+      }
+      const int rc2 = h->comm.api.GroupEnd();
+      REQUIRE(rc == 0 && rc2 == 0, GMG_ERR_COMM, std::string("latency probe send/recv: ") + h->comm.api.GetErrorString(rc ? rc : rc2));
+    };
+    auto tiny = [&]() { hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, h->stream, sc + 4, 1.0); };
+    auto timed = [&](auto &&body, double &dev_us, double &host_us) {
+      for (int w = 0; w < 3; ++w) body();                                   // warm-up (RCCL connects lazily)
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (h->comm_stream) HIP_CHECK(hipStreamSynchronize(h->comm_stream));
+      HIP_CHECK(hipEventRecord(t0, h->stream));
+      const auto c0 = std::chrono::steady_clock::now();
+      for (int r = 0; r < reps; ++r) body();
+      const auto c1 = std::chrono::steady_clock::now();
+      HIP_CHECK(hipEventRecord(t1, h->stream));
+      HIP_CHECK(hipEventSynchronize(t1));
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, t0, t1));
+      dev_us = 1e3 * (double)ms / reps;
+      host_us = std::chrono::duration<double, std::micro>(c1 - c0).count() / reps;
+    };
+    double d = 0, hst = 0;
+    timed([&] { tiny(); HIP_CHECK(hipGetLastError()); }, d, hst);
+    out6[5] = d;
+    timed([&] {
+      tiny();
+      HIP_CHECK(hipEventRecord(h->ev_ready, h->stream));
+      HIP_CHECK(hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
+      group(h->comm_stream);
+      HIP_CHECK(hipEventRecord(h->ev_done, h->comm_stream));
+      HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_done, 0));
+    }, d, hst);
+    out6[0] = d; out6[1] = hst;
+    timed([&] {
+      tiny();
+      const int rc = h->comm.api.AllReduce(sc, sc, 1, kNcclDouble, kNcclSum, h->comm.comm, h->stream);
+      REQUIRE(rc == 0, GMG_ERR_COMM, std::string("latency probe all-reduce: ") + h->comm.api.GetErrorString(rc));
+      hipLaunchKernelGGL(sqrt_inplace_kernel, dim3(1), dim3(1), 0, h->stream, sc);
+    }, d, hst);
+    out6[2] = d; out6[3] = hst;
+    timed([&] { tiny(); group(h->stream); }, d, hst);
+    out6[4] = d;
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    (void)hipFree(snd); (void)hipFree(rcv); (void)hipFree(sc);
+  });
+}
+
 int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_fn xfn, gmg_host_allreduce_fn rfn, void *ctx)
 {
   return guarded(h, [&] {

@@ -320,6 +320,196 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------
+// sell_kernel with the matrix stream kept in flight.  A lane's work is a chain  (col,val) load -> gather x[col] -> multiply-add
+// per batch of UN entries: in sell_kernel the next batch's stream loads are only issued after the current gathers have been
+// consumed, so per batch a wave exposes L_stream + L_gather and carries stream bytes in flight for L_stream of it.  Once the
+// gathered vector leaves the L2s (levels >= 256^3: L_gather roughly doubles) that share drops and with it the achieved
+// bandwidth (0.78 -> 0.64 of peak; HBM traffic stays at the algorithmic bytes, so it is latency, not re-reads).  Here the
+// stream loads of batch k+PD are issued BEFORE the gathers of batch k are waited for (loads return in order, so the wait for
+// the gathers -- vmcnt(2*UN*PD) -- leaves the younger stream loads in flight).  Same products, same left-to-right order:
+// bit-identical to sell_kernel.  Column / value indices past the slice width are clamped to its last column (masked by rowlen).
+// ---------------------------------------------------------------------------
+template <int EPI, bool ONEG, int UN, int PD, bool NT>
+__global__ __launch_bounds__(kBlock) void sell_pipe_kernel(SellArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int slice = __builtin_amdgcn_readfirstlane((int)(remap_block(blockIdx.x, gridDim.x, a.xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  if (slice >= a.nslices) return;
+  const int64_t base = a.soff[slice];
+  const int w = (int)((a.soff[slice + 1] - base) >> 6);
+  const int64_t row = (int64_t)slice * 64 + lane;
+  const bool valid = row < a.nrows;
+  const int64_t rc = valid ? row : a.nrows - 1;
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  const int32_t *cp = a.scol + base + lane;
+  const double *vp = a.sval + base + lane;
+  const int wl = w - 1;
+  int32_t c[PD + 1][UN];
+  double v[PD + 1][UN];
+  auto issue = [&](int slot, int j0) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int64_t o = (int64_t)min(j0 + u, wl) * 64;
+      if (NT) { c[slot][u] = __builtin_nontemporal_load(cp + o); v[slot][u] = __builtin_nontemporal_load(vp + o); }
+      else { c[slot][u] = cp[o]; v[slot][u] = vp[o]; }
+    }
+  };
+  // the first PD batches of the stream, then the row-wise operands (clamped addresses: no divergent loads)
+#pragma unroll
+  for (int p = 0; p < PD; ++p) issue(p, p * UN);
+  int len = a.rowlen[rc];
+  if (!valid) len = 0;
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+  if (EPI == EPI_SUB) e0 = a.y[rc];
+  else if (EPI == EPI_RESID) e0 = a.b[rc];
+  else if (EPI == EPI_ADDTO) e0 = a.x2[rc];
+  else if (EPI == EPI_SWEEP) {
+    e0 = a.b[rc];
+    e1 = ONEG ? xg[rc] : dinv[rc];
+    { const double xl = a.x2[rc]; e2 = a.x_zero ? 0.0 : xl; }
+    if (ONEG) dinv_row = dinv[rc];
+  }
+  double s = 0.0;
+  // steady state: the stream loads of batch j/UN + PD are issued unconditionally inside the loop body (a conditional issue makes
+  // the compiler wait at the join as if they had not been issued: vmcnt(UN-1) instead of vmcnt(2*UN*PD + UN-1)); drain loop after
+  auto batch = [&](int j, bool more) {
+    double g[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (dinv[c[0][u]] * xg[c[0][u]]);
+      else g[u] = xg[c[0][u]];
+    }
+    if (more) issue(PD, j + PD * UN);                      // stays in flight across the gather wait below
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const double pr = v[0][u] * g[u];
+      s = (j + u < len) ? s + pr : s;                      // masked: padding is never added
+    }
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { c[p][u] = c[p + 1][u]; v[p][u] = v[p + 1][u]; }
+    }
+  };
+  int j = 0;
+  for (; j + PD * UN < w; j += UN) batch(j, true);
+  for (; j < w; j += UN) batch(j, false);
+  if (valid) {
+    if (EPI == EPI_SET) a.y[row] = s;
+    else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+    else if (EPI == EPI_RESID) a.y[row] = e0 - s;
+    else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
+    else {
+      const double dxi = ONEG ? e1 : omega * (e1 * e0);
+      a.x2[row] = e2 + dxi;
+      const double rn = e0 - s;
+      a.y[row] = rn;
+      if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+    }
+  }
+}
+
+// Whole rows in flight: slices of width <= WMAX request every (col,val) pair of the lane's row at once, then every gather,
+// then sum left to right -- one stream latency + one gather latency per slice instead of one pair per batch, at the price of
+// ~3*WMAX registers (4 waves per SIMD at WMAX = 27).  Wider slices take the batched loop.  Bit-identical to sell_kernel.
+template <int EPI, bool ONEG, int WMAX, bool NT>
+__global__ __launch_bounds__(kBlock) void sell_row_kernel(SellArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int slice = __builtin_amdgcn_readfirstlane((int)(remap_block(blockIdx.x, gridDim.x, a.xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  if (slice >= a.nslices) return;
+  const int64_t base = a.soff[slice];
+  const int w = (int)((a.soff[slice + 1] - base) >> 6);
+  const int64_t row = (int64_t)slice * 64 + lane;
+  const bool valid = row < a.nrows;
+  const int64_t rc = valid ? row : a.nrows - 1;
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  const int32_t *cp = a.scol + base + lane;
+  const double *vp = a.sval + base + lane;
+  double s = 0.0;
+  int len;
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+  auto head = [&]() {
+    len = a.rowlen[rc];
+    if (!valid) len = 0;
+    if (EPI == EPI_SUB) e0 = a.y[rc];
+    else if (EPI == EPI_RESID) e0 = a.b[rc];
+    else if (EPI == EPI_ADDTO) e0 = a.x2[rc];
+    else if (EPI == EPI_SWEEP) {
+      e0 = a.b[rc];
+      e1 = ONEG ? xg[rc] : dinv[rc];
+      { const double xl = a.x2[rc]; e2 = a.x_zero ? 0.0 : xl; }
+      if (ONEG) dinv_row = dinv[rc];
+    }
+  };
+  if (w <= WMAX) {
+    const int wl = w - 1;
+    int32_t c[WMAX];
+    double v[WMAX], g[WMAX];
+#pragma unroll
+    for (int u = 0; u < WMAX; ++u) {
+      const int64_t o = (int64_t)min(u, wl) * 64;
+      c[u] = NT ? __builtin_nontemporal_load(cp + o) : cp[o];
+    }
+#pragma unroll
+    for (int u = 0; u < WMAX; ++u) {
+      const int64_t o = (int64_t)min(u, wl) * 64;
+      v[u] = NT ? __builtin_nontemporal_load(vp + o) : vp[o];
+    }
+    head();
+#pragma unroll
+    for (int u = 0; u < WMAX; ++u) {
+      if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (dinv[c[u]] * xg[c[u]]);
+      else g[u] = xg[c[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < WMAX; ++u) {
+      const double pr = v[u] * g[u];
+      s = (u < len) ? s + pr : s;
+    }
+  } else {
+    head();
+    constexpr int UN = 9;
+    for (int j = 0; j < w; j += UN) {
+      int32_t c[UN];
+      double v[UN], g[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int64_t o = (int64_t)min(j + u, w - 1) * 64;
+        c[u] = cp[o]; v[u] = vp[o];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (EPI == EPI_SWEEP && !ONEG) g[u] = omega * (dinv[c[u]] * xg[c[u]]);
+        else g[u] = xg[c[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const double pr = v[u] * g[u];
+        s = (j + u < len) ? s + pr : s;
+      }
+    }
+  }
+  if (valid) {
+    if (EPI == EPI_SET) a.y[row] = s;
+    else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+    else if (EPI == EPI_RESID) a.y[row] = e0 - s;
+    else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
+    else {
+      const double dxi = ONEG ? e1 : omega * (e1 * e0);
+      a.x2[row] = e2 + dxi;
+      const double rn = e0 - s;
+      a.y[row] = rn;
+      if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+    }
+  }
+}
+
 // x[byte offset]: uniform base + 32-bit lane offset (the saddr + voffset form of global_load)
 __device__ __forceinline__ double ld_off(const double *__restrict__ base, uint32_t byteoff)
 {
@@ -417,6 +607,109 @@ __global__ __launch_bounds__(kBlock) void sello_kernel(SellOArgs a)
     else g = ld_off(xg, c8);
     const double pr = v * g;
     s = (j < len) ? s + pr : s;
+  }
+  if (valid) {
+    if (EPI == EPI_SET) a.y[row] = s;
+    else if (EPI == EPI_SUB) a.y[row] = e0 - s;
+    else if (EPI == EPI_RESID) a.y[row] = e0 - s;
+    else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
+    else {
+      const double dxi = ONEG ? e1 : omega * (e1 * e0);
+      a.x2[row] = e2 + dxi;
+      const double rn = e0 - s;
+      a.y[row] = rn;
+      if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
+    }
+  }
+}
+
+// sello_kernel with the next batch (values AND gathers: the offsets come from LDS, nothing depends on the stream) requested
+// before the current batch is consumed -- see sell_pipe_kernel.  WMAX > 0: slices of width <= WMAX request their whole row.
+template <int EPI, bool ONEG, int UN, int WMAX, bool NT>
+__global__ __launch_bounds__(kBlock) void sello_pipe_kernel(SellOArgs a)
+{
+  extern __shared__ double sp_smem[];
+  int32_t *s_off = reinterpret_cast<int32_t *>(sp_smem);
+  const int tot = a.np * a.W;
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) s_off[i] = a.poff[i];
+  const int lane = threadIdx.x & 63;
+  const int slice = __builtin_amdgcn_readfirstlane((int)(remap_block(blockIdx.x, gridDim.x, a.xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const bool live = slice < a.nslices;
+  const int sc = live ? slice : a.nslices - 1;
+  const int64_t base = a.soff[sc];
+  const int w = (int)((a.soff[sc + 1] - base) >> 6);
+  const int64_t row = (int64_t)sc * 64 + lane;
+  const bool valid = live && row < a.nrows;
+  const int64_t rc = min(row, a.nrows - 1);
+  const int len = valid ? a.rowlen[rc] : 0;
+  const int pid = (int)a.rowpid[rc];
+  const uint32_t base8 = 8u * (uint32_t)(a.rowbase ? a.rowbase[rc] : (int32_t)rc);
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ dinv = a.dinv;
+  const double omega = a.omega;
+  const double *vp = a.sval + base + lane;
+  const int wl = w - 1;
+  // the value stream does not depend on the table: first batch (or the whole row) in flight while the table is staged
+  constexpr int NV = WMAX > 0 ? WMAX : UN;
+  double v0[NV];
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int64_t o = (int64_t)min(u, wl) * 64;
+    v0[u] = NT ? __builtin_nontemporal_load(vp + o) : vp[o];
+  }
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+  if (EPI == EPI_SUB) e0 = a.y[rc];
+  else if (EPI == EPI_RESID) e0 = a.b[rc];
+  else if (EPI == EPI_ADDTO) e0 = a.x2[rc];
+  else if (EPI == EPI_SWEEP) {
+    e0 = a.b[rc];
+    e1 = ONEG ? xg[rc] : dinv[rc];
+    { const double xl = a.x2[rc]; e2 = a.x_zero ? 0.0 : xl; }
+    if (ONEG) dinv_row = dinv[rc];
+  }
+  __syncthreads();
+  const int32_t *to = s_off + pid * a.W;
+  auto gat = [&](int j) -> double {
+    const uint32_t c8 = base8 + (uint32_t)((j < a.W) ? to[j] : 0);
+    if (EPI == EPI_SWEEP && !ONEG) return omega * (ld_off(dinv, c8) * ld_off(xg, c8));
+    return ld_off(xg, c8);
+  };
+  double s = 0.0;
+  if (WMAX > 0 && w <= WMAX) {
+    double g[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) g[u] = gat(min(u, wl));
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const double pr = v0[u] * g[u];
+      s = (u < len) ? s + pr : s;
+    }
+  } else {
+    double v[UN], g[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) { v[u] = v0[u]; g[u] = gat(min(u, wl)); }
+    int j = 0;
+    for (; j + UN < w; j += UN) {                            // steady state: the next batch is requested unconditionally
+      double vn[UN], gn[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int jj = min(j + UN + u, wl);
+        vn[u] = NT ? __builtin_nontemporal_load(vp + (int64_t)jj * 64) : vp[(int64_t)jj * 64];
+        gn[u] = gat(jj);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const double pr = v[u] * g[u];
+        s = (j + u < len) ? s + pr : s;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { v[u] = vn[u]; g[u] = gn[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {                           // last batch
+      const double pr = v[u] * g[u];
+      s = (j + u < len) ? s + pr : s;
+    }
   }
   if (valid) {
     if (EPI == EPI_SET) a.y[row] = s;

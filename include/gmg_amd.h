@@ -266,6 +266,12 @@ GMG_API int gmg_comm_init_rccl(gmg_handle_t h, const char *rccl_path, const char
 /* Diagnostic: all-reduce of 1.5 (-> out2[0] = 1.5*nranks) and a grouped self send/recv of
  * 42.0 (-> out2[1]) through the RCCL binding; valid on a 1-rank communicator. */
 GMG_API int gmg_comm_selftest(gmg_handle_t h, double *out2);
+/* Latency of the communication primitives exactly as the solver issues them (no reference counterpart: PartitionedArrays'
+ * consistent! / dot over MPI, PatchSolvers.jl:231, CGSolvers.jl:85): out6[0] stream time in us of one halo exchange (event
+ * hand-off to the communication stream, grouped ncclSend/ncclRecv of nmsg messages of `count` doubles, event hand-off back),
+ * out6[1] host time to enqueue it, out6[2] / out6[3] the same for a 1-double ncclAllReduce + square root, out6[4] the
+ * exchange issued in-stream, out6[5] an empty kernel.  Peers are the ring neighbours (the rank itself on one rank). */
+GMG_API int gmg_comm_latency_probe(gmg_handle_t h, int nmsg, int64_t count, int reps, double *out6);
 /* Host-staged transport through callbacks of the host language (MPI in Julia, gloo in the
  * Python tests); lets several ranks share one GPU.  Functional, not fast. */
 GMG_API int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_fn exchange,

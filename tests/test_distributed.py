@@ -192,6 +192,10 @@ def test_rccl_binding_selftest_single_rank(pkg):
     out = (C.c_double * 2)()
     abi.check(h, lib.gmg_comm_selftest(h, out))
     assert out[0] == 1.5 and out[1] == 42.0
+    # the latency probe behind DESIGN.md section 5's communication model (tools/rccl_latency.py): sane, positive stream times
+    lat = (C.c_double * 6)()
+    abi.check(h, lib.gmg_comm_latency_probe(h, 7, 1024, 20, lat))
+    assert all(0.0 < lat[i] < 5e4 for i in (0, 2, 4, 5)), list(lat)
     lib.gmg_destroy(h)
 
 
