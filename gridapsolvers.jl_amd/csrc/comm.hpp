@@ -97,6 +97,16 @@ struct HaloPlan {
   // boundary row -> its slots in the send buffer (pack fused into ghost_fix_kernel); null when some sent row has no ghost column
   int64_t *d_pk_ptr = nullptr;
   int32_t *d_pk_slot = nullptr;
+  // Overlapping layout (gmg_set_partition_overlap): the local vector holds owned and ghost entries in ONE numbering chosen by
+  // the caller (a structured box partition: the extended box in lexicographic order), the local matrix has a row for every
+  // local entry, and `depth` ghost layers are kept consistent by one exchange -- so `depth` sweeps of a distance-1 operator
+  // run between two exchanges (rows of ghost layer j are recomputed redundantly and stay exact for depth - j sweeps).
+  // Received values are scattered through rcv_idx instead of landing in a contiguous ghost segment.
+  bool ovl = false;
+  int depth = 1;
+  std::vector<int64_t> h_rcv_idx;
+  int64_t *d_rcv_idx = nullptr;
+  double *d_unpack = nullptr;                  // [n_ghost] landing buffer of the receives
   int64_t nsend() const { return snd_ptr.empty() ? 0 : snd_ptr.back(); }
 };
 
@@ -106,6 +116,13 @@ __global__ void halo_pack_kernel(int64_t n, const int64_t *__restrict__ idx, con
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) sendbuf[i] = v[idx[i]];
+}
+// v[idx[i]] = buf[i]  (overlapping layout: received ghost values into their places)
+__global__ void halo_unpack_kernel(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ buf,
+                                   double *__restrict__ v)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[idx[i]] = buf[i];
 }
 // assemble!(v) (PatchSolvers.jl:254): v[idx[i]] += buf[i] -- the ghost copies' contributions added to the owner's entry.
 // One launch per neighbour, in neighbour order: targets are unique inside a neighbour's list, so the sum order is fixed.

@@ -479,6 +479,8 @@ struct gmg_solver {
   Comm comm;
   hipStream_t comm_stream = nullptr;   // halo traffic overlapping the own x own mat-vec (RCCL only)
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  int64_t n_exchanges = 0;             // halo exchanges issued since gmg_create (gmg_get_comm_stats)
+  int64_t n_allreduces = 0;            // all-reduces issued (scalars and the replication boundary)
   int halo_fuse_pack = 1;              // GMG_HALO_FUSE_PACK: the boundary fix-up of a sweep packs the next sweep's send buffer
   int overlap = 1;                     // GMG_OVERLAP
   int host_async = 0;                  // GMG_HOST_ASYNC: run the overlapped schedule with the host transport (tests)
@@ -506,6 +508,11 @@ struct gmg_solver {
   int sell_block = 0;   // GMG_SELL_BLOCK: 0 = auto (256 threads on big levels, 64 on small ones)
   int sell_un = 6;      // GMG_SELL_UN: independent (col,val,gather) triples in flight per lane
   int nt_loads = 1;     // GMG_NT: non-temporal matrix stream
+  int nt_rowwise = 1;   // GMG_NT_ROWWISE: SELL-64 / SELL-O sweeps of big levels read r, x, 1/diag and write r, x non-temporally
+  int xcd_remap_big = 0; // GMG_XCD_REMAP_BIG: XCD-contiguous row ranges also on levels whose gathered vector exceeds the L2s (SELL-64 / SELL-O)
+  int64_t big_rows = 4000000;   // GMG_BIG_ROWS: a level is "big" above this many rows (8 B/row against 8 x 4 MB of L2)
+  int sell_defer = 1;   // GMG_SELL_DEFER: x updated every second sweep in the SELL-64 / SELL-O sweeps as well
+  bool big_level(const DevCSR &M) const { return M.nrows > big_rows; }
   int use_pattern = 1;  // GMG_PATTERN: row-pattern dictionary (SELL-P) when the matrix has few distinct rows
   int pat_un = 9;       // GMG_PAT_UN: gathers in flight per lane in sellp_kernel
   int pat_wgs = 2048;   // GMG_PAT_WGS: resident workgroups of the persistent sellp launch
@@ -520,6 +527,7 @@ struct gmg_solver {
   int gj_mfma = 1;      // GMG_GJ_MFMA: trailing update of the device coarse inversion on the FP64 matrix cores
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
+  int persist_fenced = 1; // GMG_PERSIST_FENCED: progress words published with release / polled with acquire semantics (agent scope)
   int persist_max_slices = 0;  // GMG_PERSIST_MAX_SLICES (0: what one workgroup per CU holds)
   int n_cus = 0;
   uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
@@ -1462,10 +1470,29 @@ struct gmg_solver {
     const dim3 g((M.nslices + wpb - 1) / wpb), b(64 * wpb);
     const size_t lds = (size_t)M.opat_np * M.opat_w * 4;
     const bool nt = nt_loads && (8.0 * (double)M.zpad > 128.0e6);
+    const bool huge = big_level(M);                        // see launch_sell
+    if (huge && xcd_remap_big == 0) a.xcd_remap = 0;
+    if constexpr (EPI == EPI_SWEEP && ONEG) {
+      if (sell_un < 27 && (a2.xmode != 0 || (huge && nt && nt_rowwise))) {
+#define GMG_SELLO_SWEEP(NTV)                                                                                                        \
+        do {                                                                                                                          \
+          if (a2.xmode == 1) hipLaunchKernelGGL((sello_kernel<EPI_SWEEP, true, 9, NTV, 1>), g, b, lds, stream, a);                    \
+          else if (a2.xmode == 2) hipLaunchKernelGGL((sello_kernel<EPI_SWEEP, true, 9, NTV, 2>), g, b, lds, stream, a);               \
+          else hipLaunchKernelGGL((sello_kernel<EPI_SWEEP, true, 9, NTV, 0>), g, b, lds, stream, a);                                  \
+        } while (0)
+        if (huge && nt && nt_rowwise) GMG_SELLO_SWEEP(2);
+        else if (nt) GMG_SELLO_SWEEP(1);
+        else GMG_SELLO_SWEEP(0);
+#undef GMG_SELLO_SWEEP
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
+    }
+    REQUIRE(a2.xmode == 0 || EPI != EPI_SWEEP, GMG_ERR_STATE, "deferred x update needs the default unroll of the SELL-O sweep");
 #define GMG_SELLO_LAUNCH(UNV)                                                                         \
     do {                                                                                                \
-      if (nt) hipLaunchKernelGGL((sello_kernel<EPI, ONEG, UNV, true>), g, b, lds, stream, a);            \
-      else hipLaunchKernelGGL((sello_kernel<EPI, ONEG, UNV, false>), g, b, lds, stream, a);              \
+      if (nt) hipLaunchKernelGGL((sello_kernel<EPI, ONEG, UNV, 1>), g, b, lds, stream, a);               \
+      else hipLaunchKernelGGL((sello_kernel<EPI, ONEG, UNV, 0>), g, b, lds, stream, a);                  \
     } while (0)
     if (sell_un >= 27) GMG_SELLO_LAUNCH(27);
     else if (sell_un >= 9) GMG_SELLO_LAUNCH(9);
@@ -1487,10 +1514,33 @@ struct gmg_solver {
     const int wpb = sell_block > 0 ? sell_block / 64 : (M.nslices >= 256 * 32 ? 4 : 1);
     const dim3 g((M.nslices + wpb - 1) / wpb), b(64 * wpb);
     const bool nt = nt_loads && (12.0 * (double)M.zpad > 192.0e6);   // keep cache-resident levels cacheable
+    // Levels whose gathered vector no longer fits the eight L2s (profiles/r03_tuning.md): workgroups in launch order (all XCDs
+    // stream -- and write -- inside one window of the arrays instead of eight far-apart eighths) and the once-per-sweep row-wise
+    // operands non-temporal.  Both lose 1-2 % on levels that do fit, so they switch on by size.
+    const bool huge = big_level(M);
+    if (huge && xcd_remap_big == 0) a.xcd_remap = 0;
+    if constexpr (EPI == EPI_SWEEP && ONEG) {
+      if (sell_un >= 6 && sell_un < 9 && (a2.xmode != 0 || (huge && nt && nt_rowwise))) {
+        // default unroll: the variants with the deferred x update (a2.xmode) and non-temporal row-wise operands
+#define GMG_SELL_SWEEP(NTV)                                                                                                         \
+        do {                                                                                                                          \
+          if (a2.xmode == 1) hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, NTV, 1>), g, b, 0, stream, a);                       \
+          else if (a2.xmode == 2) hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, NTV, 2>), g, b, 0, stream, a);                  \
+          else hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, NTV, 0>), g, b, 0, stream, a);                                     \
+        } while (0)
+        if (huge && nt && nt_rowwise) GMG_SELL_SWEEP(2);
+        else if (nt) GMG_SELL_SWEEP(1);
+        else GMG_SELL_SWEEP(0);
+#undef GMG_SELL_SWEEP
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
+    }
+    REQUIRE(a2.xmode == 0 || EPI != EPI_SWEEP, GMG_ERR_STATE, "deferred x update needs the default unroll of the SELL-64 sweep");
 #define GMG_SELL_LAUNCH(UNV)                                                                          \
     do {                                                                                                \
-      if (nt) hipLaunchKernelGGL((sell_kernel<EPI, ONEG, UNV, true>), g, b, 0, stream, a);               \
-      else hipLaunchKernelGGL((sell_kernel<EPI, ONEG, UNV, false>), g, b, 0, stream, a);                 \
+      if (nt) hipLaunchKernelGGL((sell_kernel<EPI, ONEG, UNV, 1>), g, b, 0, stream, a);                  \
+      else hipLaunchKernelGGL((sell_kernel<EPI, ONEG, UNV, 0>), g, b, 0, stream, a);                     \
     } while (0)
     if (sell_un >= 27) GMG_SELL_LAUNCH(27);
     else if (sell_un >= 9) GMG_SELL_LAUNCH(9);
@@ -1564,7 +1614,8 @@ struct gmg_solver {
              const double *s_old = nullptr, double *s_new = nullptr, int xmode = 0, bool prepacked = false, bool pack_next = false)
   {
     Level &L = lev[l];
-    if (comm.nranks > 1) begin_exchange(l, const_cast<double *>(s_old ? s_old : r_old), prepacked);
+    const bool halo_sweep = comm.nranks > 1 && !(L.halo.present && L.halo.ovl);   // overlapping layout: smooth() exchanges once per block of sweeps
+    if (halo_sweep) begin_exchange(l, const_cast<double *>(s_old ? s_old : r_old), prepacked);
     // HIP events around every prof_stride-th sweep launch of the profiled level: an event pair costs ~4 us of
     // stream time, timing every launch would slow the solve it measures by > 10 %
     const bool prof = (l == prof_level) && (prof_seq++ % (uint64_t)prof_stride == 0) && prof_used + 2 <= prof_ev.size();
@@ -1585,7 +1636,7 @@ struct gmg_solver {
       prof_w[prof_used / 2] = 1;
       prof_used += 2;
     }
-    if (comm.nranks > 1) finish_ghost<2>(l, s_old, r_new, S.omega, s_new, pack_next);   // distributed => one-gather sweep
+    if (halo_sweep) finish_ghost<2>(l, s_old, r_new, S.omega, s_new, pack_next);   // distributed => one-gather sweep
   }
 
   void copy(double *dst, const double *src, int64_t n)
@@ -1616,6 +1667,7 @@ struct gmg_solver {
                        (take_sqrt && !dist) ? 1 : 0);
     HIP_CHECK(hipGetLastError());
     if (!dist) return;
+    ++n_allreduces;
     if (comm.kind == COMM_RCCL) {
       const int rc = comm.api.AllReduce(d_scalars + slot, d_scalars + slot, 1, kNcclDouble, kNcclSum, comm.comm, stream);
       REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclAllReduce: ") + comm.api.GetErrorString(rc));
@@ -1646,7 +1698,8 @@ struct gmg_solver {
       hipLaunchKernelGGL(halo_pack_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ns, H.d_snd_idx, v, H.d_sendbuf);
       HIP_CHECK(hipGetLastError());
     }
-    double *ghost = v + H.n_own;
+    // own | ghost layout: received straight into the ghost segment; overlapping layout: into a landing buffer, then scattered
+    double *ghost = H.ovl ? H.d_unpack : v + H.n_own;
     if (comm.kind == COMM_RCCL) {
       int rc = comm.api.GroupStart();
       for (size_t k = 0; k < H.nbr.size() && rc == 0; ++k) {
@@ -1662,12 +1715,18 @@ struct gmg_solver {
       comm.xfn(comm.ctx, (int)H.nbr.size(), H.nbr.data(), H.h_send, H.snd_ptr.data(), H.h_recv, H.rcv_ptr.data());
       if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(ghost, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, stream));
     }
+    if (H.ovl && H.n_ghost > 0) {
+      hipLaunchKernelGGL(halo_unpack_kernel, dim3((unsigned)((H.n_ghost + 255) / 256)), dim3(256), 0, stream, H.n_ghost, H.d_rcv_idx, H.d_unpack, v);
+      HIP_CHECK(hipGetLastError());
+    }
+    ++n_exchanges;
   }
   void alloc_plan_buffers(HaloPlan &H)
   {
     H.d_snd_idx = upload(H.h_snd_idx);
     H.d_sendbuf = dvec(H.nsend());
     H.d_recvbuf = dvec(H.nsend());
+    if (H.ovl) { H.d_rcv_idx = upload(H.h_rcv_idx); H.d_unpack = dvec(H.n_ghost); }
     if (comm.kind == COMM_HOST) {
       if (!H.h_send) HIP_CHECK(hipHostMalloc((void **)&H.h_send, sizeof(double) * (size_t)std::max<int64_t>(1, H.nsend())));
       if (!H.h_recv) HIP_CHECK(hipHostMalloc((void **)&H.h_recv, sizeof(double) * (size_t)std::max<int64_t>(1, H.n_ghost)));
@@ -1679,6 +1738,7 @@ struct gmg_solver {
   {
     HaloPlan &H = lev[l].halo;
     if (comm.nranks <= 1 || !H.present || H.nbr.empty()) return;
+    REQUIRE(!H.ovl, GMG_ERR_UNSUPPORTED, "assemble! (reverse halo) is not available in the overlapping layout");
     const int64_t ns = H.nsend();
     double *ghost = v + H.n_own;
     if (comm.kind == COMM_RCCL) {
@@ -1719,6 +1779,7 @@ struct gmg_solver {
   void begin_exchange(int l, double *src, bool prepacked = false)
   {
     if (comm.nranks <= 1 || !lev[l].halo.present) return;
+    if (lev[l].halo.ovl) { exchange_on(l, src, stream, false); return; }   // overlapping layout: whole rows, nothing to overlap with
     if (overlapped() && comm.kind == COMM_RCCL) {
       HIP_CHECK(hipEventRecord(ev_ready, stream));
       HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_ready, 0));
@@ -1742,6 +1803,7 @@ struct gmg_solver {
       HIP_CHECK(hipLaunchHostFunc(comm_stream, host_exchange_trampoline, &lev[l].hostctx));
       if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(src + H.n_own, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, comm_stream));
       HIP_CHECK(hipEventRecord(ev_done, comm_stream));
+      ++n_exchanges;
     } else {
       exchange_on(l, src, stream, prepacked);
     }
@@ -1751,7 +1813,7 @@ struct gmg_solver {
   void finish_ghost(int l, const double *src, double *y, double omega = 0.0, double *s_out = nullptr, bool pack_next = false)
   {
     Level &L = lev[l];
-    if (comm.nranks <= 1 || !L.halo.present) return;
+    if (comm.nranks <= 1 || !L.halo.present || L.halo.ovl) return;
     if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
     if (!L.split || L.nbnd == 0) return;
     const bool pk = pack_next && MODE == 2 && L.halo.d_pk_ptr != nullptr;
@@ -1816,11 +1878,12 @@ struct gmg_solver {
 
   // One launch for the whole pass on small single-GPU levels in the shared-offset pattern form (see sells_smooth_kernel).
   // s_0 is in L.sbuf[0].  Returns false when the level does not qualify (the caller then runs sweep by sweep).
-  bool smooth_persistent(int l, const Smoother &S, double *x, const double *r_in, double *r_out, bool x_zero)
+  bool smooth_persistent(int l, const Smoother &S, double *x, const double *r_in, double *r_out, bool x_zero, int niter)
   {
     Level &L = lev[l];
     const DevCSR &M = L.A;
-    if (!persist || (comm.nranks > 1 && L.halo.present) || S.niter < 2) return false;   // (replicated levels have no halo)
+    // replicated levels have no halo; levels in the overlapping layout run the sweeps between two exchanges like a single-GPU level
+    if (!persist || (comm.nranks > 1 && L.halo.present && !L.halo.ovl) || niter < 2) return false;
     if (!(M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && M.pat_nruns % 3 == 0)) return false;
     const int nu = M.pat_k * M.pat_nruns;
     const size_t lds = (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16;
@@ -1859,10 +1922,10 @@ struct gmg_solver {
     a.rowpid = M.rowpid; a.tab = M.ptab; a.tab8 = M.ptab8; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
     a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl;
     a.pdinv = pat_dinv ? M.pdinv : nullptr; a.dinv = L.dinv; a.omega = S.omega;
-    a.niter = S.niter; a.x_zero = x_zero ? 1 : 0;
+    a.niter = niter; a.x_zero = x_zero ? 1 : 0;
     a.r_in = r_in; a.r_out = r_out; a.x = x; a.s_a = L.sbuf[0]; a.s_b = L.sbuf[1];
-    a.flags = L.pflags; a.epoch = L.pf_epoch; a.err = d_perr; a.halo_wg = halo;
-    L.pf_epoch += (uint32_t)S.niter;
+    a.flags = L.pflags; a.epoch = L.pf_epoch; a.err = d_perr; a.halo_wg = halo; a.fenced = persist_fenced;
+    L.pf_epoch += (uint32_t)niter;
     const dim3 g(nwg), b(64 * wpb);
     const bool td = a.pdinv != nullptr;
     const bool mk = pat_strict || !M.ptab8;
@@ -1879,16 +1942,40 @@ struct gmg_solver {
     HIP_CHECK(hipGetLastError());
     if (prof) {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
-      prof_w[prof_used / 2] = S.niter;
+      prof_w[prof_used / 2] = niter;
       prof_used += 2;
     }
     return true;
   }
+  // Runs a whole solve; if a one-launch smoothing pass timed out inside it (its workgroups were not co-resident: the GPU is shared
+  // with other persistent kernels), the handle has already switched to per-sweep launches -- restore the initial guess and run the
+  // solve again instead of failing the call.  `x_user` is only overwritten in place for single-GPU device vectors: saved first.
+  template <typename F>
+  void with_persist_retry(double *x_user, int64_t n, int memspace, F &&body)
+  {
+    const bool armed = persist != 0;
+    const bool inplace = memspace == GMG_MEM_DEVICE && comm.nranks == 1;
+    if (armed && inplace) copy(scratch_vec(6, lev[0].nvec), x_user, n);
+    try {
+      body();
+      check_persistent();
+    } catch (const GmgError &) {
+      if (!(armed && persist_tripped)) throw;
+      persist_tripped = false;
+      ++persist_retries;
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (inplace) copy(x_user, scratch_vec(6, lev[0].nvec), n);
+      body();
+    }
+  }
+  bool persist_tripped = false;
+  int64_t persist_retries = 0;
   void check_persistent()
   {
     if (!(h_perr && *h_perr)) return;
     *h_perr = 0;
     persist = 0;                                             // later solves of this handle sweep launch by launch
+    persist_tripped = true;
     throw GmgError{GMG_ERR_STATE, "one-launch smoothing pass: a neighbour wait timed out (its workgroups were not all resident -- is the GPU shared with "
                                   "other persistent kernels?); the results of this call are invalid, the handle now runs with GMG_PERSIST=0"};
   }
@@ -1909,27 +1996,43 @@ struct gmg_solver {
     if (S.kind == SM_JACOBI && one_gather()) {
       // s_0 = w*Dinv*r_in ; then each sweep: x += s_k ; r -= A s_k (in place after the
       // first sweep) ; s_{k+1} = w*Dinv*r
-      if (!(L.s0_ready && L.s0_src == r_in && L.s0_omega == S.omega)) {
-        hipLaunchKernelGGL(scaled_jacobi_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, S.omega, L.dinv, r_in, L.sbuf[0]);
-        HIP_CHECK(hipGetLastError());
-      }
-      L.s0_ready = false;
+      // Overlapping layout (gmg_set_partition_overlap): the pass runs in blocks of `depth` sweeps -- consistent!(r) on all ghost
+      // layers, s_0 from it on every local row, then `depth` sweeps over every local row with no communication (ghost layer j
+      // stays exact for depth - j sweeps; the owned rows are exact throughout).  Same arithmetic per row as on one GPU.
+      const bool ovl = comm.nranks > 1 && L.halo.present && L.halo.ovl;
       const double *cur = r_in;
       double *out = r_internal ? const_cast<double *>(r_in) : L.rbuf[0];
-      if (smooth_persistent(l, S, x, r_in, out, x_zero)) return out;
+      const int block = ovl ? std::max(1, std::min(L.halo.depth, S.niter)) : S.niter;
       // shared-offset pattern kernel: x is updated every second sweep with both increments,
       // x = (x + s_{k-1}) + s_k (the same two roundings), which saves one read+write of x per pair
-      const bool defer = pat_defer && L.A.pat_shared;
-      for (int it = 0; it < S.niter; ++it) {
-        int xmode = 0;
-        bool xz = x_zero && it == 0;
-        if (defer) {
-          if ((it & 1) == 0 && it + 1 < S.niter) xmode = 1;
-          else if (it & 1) { xmode = 2; xz = x_zero && it == 1; }
+      const bool sell64 = L.A.sell && !L.A.pat && !L.A.comp_idx && !L.A.vdict && !L.A.opat;
+      const bool defer = (pat_defer && L.A.pat_shared) ||
+                         (sell_defer && !(comm.nranks > 1 && L.split) && ((sell64 && sell_un >= 6 && sell_un < 9) || (L.A.sell && L.A.opat && sell_un < 27)));
+      for (int done = 0; done < S.niter; done += block) {
+        const int nb = std::min(block, S.niter - done);
+        const bool first = done == 0;
+        if (ovl) {
+          if (cur != out) { copy(out, cur, n); cur = out; }   // (levels >= 1 smooth in place: no copy)
+          exchange(l, out);
         }
-        const bool fp = can_fuse_pack(l);
-        sweep(l, S, x, cur, out, xz, L.sbuf[it & 1], L.sbuf[(it + 1) & 1], xmode, fp && it > 0, fp && it + 1 < S.niter);
-        cur = out;
+        if (!(first && !ovl && L.s0_ready && L.s0_src == r_in && L.s0_omega == S.omega)) {
+          hipLaunchKernelGGL(scaled_jacobi_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, S.omega, L.dinv, cur, L.sbuf[0]);
+          HIP_CHECK(hipGetLastError());
+        }
+        L.s0_ready = false;
+        const bool xz0 = x_zero && first;
+        if (smooth_persistent(l, S, x, cur, out, xz0, nb)) { cur = out; continue; }
+        for (int it = 0; it < nb; ++it) {
+          int xmode = 0;
+          bool xz = xz0 && it == 0;
+          if (defer) {
+            if ((it & 1) == 0 && it + 1 < nb) xmode = 1;
+            else if (it & 1) { xmode = 2; xz = xz0 && it == 1; }
+          }
+          const bool fp = can_fuse_pack(l);
+          sweep(l, S, x, cur, out, xz, L.sbuf[it & 1], L.sbuf[(it + 1) & 1], xmode, fp && it > 0, fp && it + 1 < nb);
+          cur = out;
+        }
       }
       return out;
     }
@@ -1968,6 +2071,7 @@ struct gmg_solver {
       hipLaunchKernelGGL(scatter_gid_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, nrows, d_rep_gid, d_rep_tmp, rH_global);
       HIP_CHECK(hipGetLastError());
     }
+    ++n_allreduces;
     if (comm.kind == COMM_RCCL) {
       const int rc = comm.api.AllReduce(rH_global, rH_global, (size_t)ng, kNcclDouble, kNcclSum, comm.comm, stream);
       REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclAllReduce(restriction): ") + comm.api.GetErrorString(rc));
@@ -2154,6 +2258,10 @@ struct gmg_solver {
     sell_block = std::min(256, env_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
     if (const char *mp = std::getenv("GMG_SELL_MAXPAD")) sell_maxpad = std::atof(mp);
     nt_loads = env_int("GMG_NT", 1);
+    nt_rowwise = env_int("GMG_NT_ROWWISE", 1);
+    xcd_remap_big = env_int("GMG_XCD_REMAP_BIG", 0);
+    big_rows = (int64_t)env_int("GMG_BIG_ROWS", 4000000);
+    sell_defer = env_int("GMG_SELL_DEFER", 1);
     use_pattern = env_int("GMG_PATTERN", 1);
     pat_un = env_int("GMG_PAT_UN", 9);
     pat_wgs = std::max(1, env_int("GMG_PAT_WGS", 2048));
@@ -2162,6 +2270,10 @@ struct gmg_solver {
     prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
     pat_defer = env_int("GMG_PAT_DEFER", 1);
     persist = env_int("GMG_PERSIST", 1);
+    // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
+    // could keep each other from becoming fully resident, so they are off unless asked for
+    if (comm.kind == COMM_HOST && !env_int("GMG_PERSIST_SHARED", 0)) persist = 0;
+    persist_fenced = env_int("GMG_PERSIST_FENCED", 1);
     pat_strict = env_int("GMG_PAT_STRICT", 1);
     gj_mfma = env_int("GMG_GJ_MFMA", 1);
     persist_max_slices = env_int("GMG_PERSIST_MAX_SLICES", 0);
@@ -2226,9 +2338,9 @@ struct gmg_solver {
       if (pat_dinv && A.pdinv) vec -= 8.0 * N;             // 1/diag from the pattern table
       if (pat_defer) vec -= 4.0 * N;                       // x touched every second sweep: (8+8+8)/2 instead of 8+8
     } else if (A.pat) mat = (A.rowbase ? 6.0 : 2.0) * N;
-    else if (A.sell && A.opat) mat = 8.0 * (double)A.zpad + (A.orowbase ? 6.0 : 2.0) * N + 4.0 * N + 8.0 * (double)A.nslices;
+    else if (A.sell && A.opat) { mat = 8.0 * (double)A.zpad + (A.orowbase ? 6.0 : 2.0) * N + 4.0 * N + 8.0 * (double)A.nslices; if (sell_defer && sell_un < 27) vec -= 4.0 * N; }
     else if (A.sell && (A.comp_idx || A.vdict)) mat = A.stream_bytes_per_nnz * (double)A.zpack + 4.0 * N + 4.0 * (double)(A.zpack / 64);
-    else if (A.sell) mat = 12.0 * (double)A.zpad + 4.0 * N + 8.0 * (double)A.nslices;
+    else if (A.sell) { mat = 12.0 * (double)A.zpad + 4.0 * N + 8.0 * (double)A.nslices; if (sell_defer && sell_un >= 6 && sell_un < 9) vec -= 4.0 * N; }
     else mat = 12.0 * (double)A.nnz + (A.ptr64 ? 8.0 : 4.0) * N;
     return mat + vec;
   }
@@ -3140,6 +3252,14 @@ void gmg_solver::setup()
     if (L.halo.present) {
       REQUIRE(comm.nranks > 1, GMG_ERR_STATE, "gmg_set_partition needs gmg_comm_init_* first");
       REQUIRE(!replicated, GMG_ERR_INVALID, "replicated levels take global operators, not a partition");
+      if (L.halo.ovl) {
+        REQUIRE(l >= 1, GMG_ERR_UNSUPPORTED, "the finest level keeps the own | ghost layout (its vectors are the caller's): gmg_set_partition");
+        REQUIRE(L.hA.nrows == L.hA.ncols && L.hA.nrows == L.halo.n_own + L.halo.n_ghost, GMG_ERR_INVALID,
+                "overlapping layout: the local matrix must be square over all local entries on level " + std::to_string(l));
+        REQUIRE(l == nlev - 1 || (L.pre.kind == SM_JACOBI && L.post.kind == SM_JACOBI), GMG_ERR_UNSUPPORTED,
+                "overlapping layout: Richardson-Jacobi smoothers only (patch smoothers need assemble!, which needs the own | ghost layout)");
+        REQUIRE(!L.has_pcorr, GMG_ERR_UNSUPPORTED, "overlapping layout: no patch-corrected prolongation");
+      } else
       REQUIRE(L.halo.n_own == L.hA.nrows && L.halo.n_own + L.halo.n_ghost == L.hA.ncols, GMG_ERR_INVALID,
               "local matrix must be n_own x (n_own+n_ghost) on level " + std::to_string(l));
     } else {
@@ -3175,7 +3295,12 @@ void gmg_solver::setup()
   init_reductions();
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
-    if (L.halo.present && comm.nranks > 1) {
+    if (L.halo.present && comm.nranks > 1 && L.halo.ovl) {
+      // overlapping layout: one square local operator over all local entries -- laid out like a single-GPU level (row patterns,
+      // shared offsets, one-launch smoothing passes all apply); ghost rows are recomputed redundantly between exchanges
+      L.split = false; L.nbnd = 0;
+      L.A = L.sA ? finish_stream(*L.sA, "level matrix") : upload_csr(L.hA);
+    } else if (L.halo.present && comm.nranks > 1) {
       REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "streamed operators are single-GPU in this round");
       // own x own / own x ghost split: A keeps the owned columns, the ghost columns of the rows
       // that have any go to a small CSR applied after the halo has arrived (finish_ghost)
@@ -3410,7 +3535,7 @@ void check_level(gmg_handle_t h, int lev, bool not_coarsest)
 }
 // exchange plan of one vector space (PartitionedArrays: assembly neighbours + local indices), validated
 void fill_plan(HaloPlan &H, const Comm &comm, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
-               const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr)
+               const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr, const int64_t *rcv_idx = nullptr, int depth = 1)
 {
   REQUIRE(n_own >= 0 && n_ghost >= 0 && nnbr >= 0, GMG_ERR_INVALID, "negative sizes");
   REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
@@ -3431,7 +3556,24 @@ void fill_plan(HaloPlan &H, const Comm &comm, int64_t n_own, int64_t n_ghost, in
   const int64_t ns = H.snd_ptr.back();
   REQUIRE(ns == 0 || snd_idx, GMG_ERR_INVALID, "null snd_idx");
   H.h_snd_idx.assign(snd_idx, snd_idx + ns);
-  for (int64_t i = 0; i < ns; ++i) REQUIRE(snd_idx[i] >= 0 && snd_idx[i] < n_own, GMG_ERR_INVALID, "snd_idx must address owned entries");
+  if (!rcv_idx) {
+    for (int64_t i = 0; i < ns; ++i) REQUIRE(snd_idx[i] >= 0 && snd_idx[i] < n_own, GMG_ERR_INVALID, "snd_idx must address owned entries");
+    return;
+  }
+  // overlapping layout: owned and ghost entries share one local numbering of n_own + n_ghost entries; every ghost entry is received
+  // exactly once, no sent entry is a ghost
+  REQUIRE(depth >= 1, GMG_ERR_INVALID, "halo depth must be >= 1");
+  const int64_t nloc = n_own + n_ghost;
+  H.ovl = true; H.depth = depth;
+  H.h_rcv_idx.assign(rcv_idx, rcv_idx + n_ghost);
+  std::vector<uint8_t> is_ghost((size_t)nloc, 0);
+  for (int64_t i = 0; i < n_ghost; ++i) {
+    REQUIRE(rcv_idx[i] >= 0 && rcv_idx[i] < nloc, GMG_ERR_INVALID, "rcv_idx out of range");
+    REQUIRE(!is_ghost[(size_t)rcv_idx[i]], GMG_ERR_INVALID, "a ghost entry is received twice");
+    is_ghost[(size_t)rcv_idx[i]] = 1;
+  }
+  for (int64_t i = 0; i < ns; ++i)
+    REQUIRE(snd_idx[i] >= 0 && snd_idx[i] < nloc && !is_ghost[(size_t)snd_idx[i]], GMG_ERR_INVALID, "snd_idx must address owned entries");
 }
 void check_ready(gmg_handle_t h)
 {
@@ -3770,15 +3912,17 @@ int gmg_apply(gmg_handle_t h, const double *b, double *x, int memspace, gmg_resu
   return guarded(h, [&] {
     check_ready(h);
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
-    const int64_t n = h->lev[0].n;
-    const double *db = h->in_vec(b, n, memspace, h->st_b);
-    const bool dist = h->comm.nranks > 1;
-    double *dx = dist ? h->cg_x : ((memspace == GMG_MEM_DEVICE) ? x : h->st_x);
-    if (h->mode == GMG_MODE_SOLVER && (memspace == GMG_MEM_HOST || dist))
-      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
-    const double last = h->gmg_solve_dev(dx, db, -1.0);
-    h->out_vec(x, dx, n, memspace);
-    h->log.export_to(res, hist, hist_cap, last);
+    h->with_persist_retry(x, h->lev[0].n, memspace, [&] {
+      const int64_t n = h->lev[0].n;
+      const double *db = h->in_vec(b, n, memspace, h->st_b);
+      const bool dist = h->comm.nranks > 1;
+      double *dx = dist ? h->cg_x : ((memspace == GMG_MEM_DEVICE) ? x : h->st_x);
+      if (h->mode == GMG_MODE_SOLVER && (memspace == GMG_MEM_HOST || dist))
+        HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
+      const double last = h->gmg_solve_dev(dx, db, -1.0);
+      h->out_vec(x, dx, n, memspace);
+      h->log.export_to(res, hist, hist_cap, last);
+    });
   });
 }
 
@@ -3790,20 +3934,22 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
-    gmg_solver &S = *h;
-    Level &L0 = S.lev[0];
-    const int64_t n = L0.n;
-    const double *db = S.in_vec(b, n, memspace, S.st_b);
-    const bool dist = S.comm.nranks > 1;
-    double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
-    if (memspace == GMG_MEM_HOST || dist)
-      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
-    ConvLog log;
-    log.configure(maxiter, atol, rtol);
-    KrylovOps ops = S.level0_ops(use_precond);
-    const double resn = cg_core(S, n, db, dx, S.cg_w, S.cg_p, S.cg_z, S.cg_r, ops, flexible != 0, log);
-    S.out_vec(x, dx, n, memspace);
-    log.export_to(res, hist, hist_cap, resn);              // :118
+    h->with_persist_retry(x, h->lev[0].n, memspace, [&] {
+      gmg_solver &S = *h;
+      Level &L0 = S.lev[0];
+      const int64_t n = L0.n;
+      const double *db = S.in_vec(b, n, memspace, S.st_b);
+      const bool dist = S.comm.nranks > 1;
+      double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
+      if (memspace == GMG_MEM_HOST || dist)
+        HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
+      ConvLog log;
+      log.configure(maxiter, atol, rtol);
+      KrylovOps ops = S.level0_ops(use_precond);
+      const double resn = cg_core(S, n, db, dx, S.cg_w, S.cg_p, S.cg_z, S.cg_r, ops, flexible != 0, log);
+      S.out_vec(x, dx, n, memspace);
+      log.export_to(res, hist, hist_cap, resn);              // :118
+    });
   });
 }
 
@@ -3825,25 +3971,27 @@ int gmg_fgmres_solve_pl(gmg_handle_t h, const double *b, double *x, int memspace
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(m0 >= 1 && m_add >= 1 && maxiter >= 0, GMG_ERR_INVALID, "bad FGMRES sizes");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
-    gmg_solver &S = *h;
-    Level &L0 = S.lev[0];
-    const int64_t n = L0.n;
-    const double *db = S.in_vec(b, n, memspace, S.st_b);
-    const bool dist = S.comm.nranks > 1;
-    const int64_t nv = L0.nvec;
-    double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
-    if (memspace == GMG_MEM_HOST || dist)
-      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
-    ConvLog log;
-    log.configure(maxiter, atol, rtol);
-    KrylovOps ops = S.level0_ops(use_precond);
-    if (use_precond_left) {
-      ops.zl = S.scratch_vec(4, nv);
-      ops.precond_left = [&S, use_precond_left](double *z, const double *r) { S.krylov_precond(use_precond_left, z, r, -1.0); };
-    }
-    const double beta = fgmres_core(S, n, nv, db, dx, S.fg_V, S.fg_Z, ops, m0, restart != 0, m_add, log);
-    S.out_vec(x, dx, n, memspace);
-    log.export_to(res, hist, hist_cap, beta);              // :197
+    h->with_persist_retry(x, h->lev[0].n, memspace, [&] {
+      gmg_solver &S = *h;
+      Level &L0 = S.lev[0];
+      const int64_t n = L0.n;
+      const double *db = S.in_vec(b, n, memspace, S.st_b);
+      const bool dist = S.comm.nranks > 1;
+      const int64_t nv = L0.nvec;
+      double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
+      if (memspace == GMG_MEM_HOST || dist)
+        HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
+      ConvLog log;
+      log.configure(maxiter, atol, rtol);
+      KrylovOps ops = S.level0_ops(use_precond);
+      if (use_precond_left) {
+        ops.zl = S.scratch_vec(4, nv);
+        ops.precond_left = [&S, use_precond_left](double *z, const double *r) { S.krylov_precond(use_precond_left, z, r, -1.0); };
+      }
+      const double beta = fgmres_core(S, n, nv, db, dx, S.fg_V, S.fg_Z, ops, m0, restart != 0, m_add, log);
+      S.out_vec(x, dx, n, memspace);
+      log.export_to(res, hist, hist_cap, beta);              // :197
+    });
   });
 }
 
@@ -3855,31 +4003,33 @@ int gmg_richardson_solve(gmg_handle_t h, const double *b, double *x, int memspac
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
-    gmg_solver &S = *h;
-    const int64_t n = S.lev[0].n;
-    const double *db = S.in_vec(b, n, memspace, S.st_b);
-    const bool dist = S.comm.nranks > 1;
-    double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
-    if (memspace == GMG_MEM_HOST || dist)
-      HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
-    double *z = S.cg_z, *r = S.cg_r;
-    ConvLog log;
-    log.configure(maxiter, atol, rtol);
-    const int grid = gmg_solver::grid_for(n);
-    S.apply_A_resid(0, dx, db, r);                         // RichardsonLinearSolvers.jl:84-85
-    double resn = S.norm(n, r);
-    bool done = log.init(resn);                            // :86
-    while (!done) {
-      const double *dir = r;
-      if (use_precond) { S.krylov_precond(use_precond, z, r, resn); dir = z; }   // :89
-      hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, omega, dir, dx);   // :90,98 x .+= w .* z
-      HIP_CHECK(hipGetLastError());
-      S.apply_A_resid(0, dx, db, r);                       // :91-92
-      resn = S.norm(n, r);
-      done = log.update(resn);                             // :93
-    }
-    S.out_vec(x, dx, n, memspace);
-    log.export_to(res, hist, hist_cap, resn);              // :95
+    h->with_persist_retry(x, h->lev[0].n, memspace, [&] {
+      gmg_solver &S = *h;
+      const int64_t n = S.lev[0].n;
+      const double *db = S.in_vec(b, n, memspace, S.st_b);
+      const bool dist = S.comm.nranks > 1;
+      double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
+      if (memspace == GMG_MEM_HOST || dist)
+        HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
+      double *z = S.cg_z, *r = S.cg_r;
+      ConvLog log;
+      log.configure(maxiter, atol, rtol);
+      const int grid = gmg_solver::grid_for(n);
+      S.apply_A_resid(0, dx, db, r);                         // RichardsonLinearSolvers.jl:84-85
+      double resn = S.norm(n, r);
+      bool done = log.init(resn);                            // :86
+      while (!done) {
+        const double *dir = r;
+        if (use_precond) { S.krylov_precond(use_precond, z, r, resn); dir = z; }   // :89
+        hipLaunchKernelGGL(axpy_kernel, dim3(grid), dim3(256), 0, S.stream, n, omega, dir, dx);   // :90,98 x .+= w .* z
+        HIP_CHECK(hipGetLastError());
+        S.apply_A_resid(0, dx, db, r);                       // :91-92
+        resn = S.norm(n, r);
+        done = log.update(resn);                             // :93
+      }
+      S.out_vec(x, dx, n, memspace);
+      log.export_to(res, hist, hist_cap, resn);              // :95
+    });
   });
 }
 
@@ -4153,6 +4303,29 @@ int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, i
     REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
     fill_plan(h->lev[lev].halo, h->comm, n_own, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr);
     h->touch();
+  });
+}
+
+int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, int64_t n_ghost, int depth, int nnbr, const int32_t *nbr_rank,
+                              const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr, const int64_t *rcv_idx)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, false);
+    REQUIRE(n_local >= 0 && n_ghost >= 0 && n_ghost <= n_local && nnbr >= 0, GMG_ERR_INVALID, "bad sizes");
+    REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
+    REQUIRE(n_ghost == 0 || rcv_idx, GMG_ERR_INVALID, "null rcv_idx");
+    static const int64_t none = 0;
+    fill_plan(h->lev[lev].halo, h->comm, n_local - n_ghost, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr, rcv_idx ? rcv_idx : &none, depth);
+    h->touch();
+  });
+}
+
+int gmg_get_comm_stats(gmg_handle_t h, int64_t *n_exchanges, int64_t *n_allreduces)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    if (n_exchanges) *n_exchanges = h->n_exchanges;
+    if (n_allreduces) *n_allreduces = h->n_allreduces;
   });
 }
 

@@ -49,6 +49,14 @@ __device__ __forceinline__ int remap_block(int b, int nb, int on)
   // Observed dispatch: workgroup b runs on XCD b % 8 (performance only, never
   // correctness).  Give XCD k the contiguous chunk [k*nb/8, (k+1)*nb/8).
   if (!on || nb < 64) return b;
+  if (on > 1) {
+    // chunked: inside every group of 8*on consecutive blocks XCD k takes the on blocks [k*on, (k+1)*on) -- each L2 still sees
+    // contiguous rows, but the eight XCDs stream from one window of 8*on blocks instead of eight far-apart eighths (HBM locality)
+    const int G = on << 3, g = b / G;
+    if ((g + 1) * G > nb) return b;                           // partial last group: identity
+    const int wi = b - g * G;
+    return g * G + (wi & 7) * on + (wi >> 3);
+  }
   const int per = nb >> 3, rem = nb & 7;
   const int xcd = b & 7, slot = b >> 3;
   // XCDs < rem own (per+1) blocks
@@ -246,7 +254,12 @@ struct SellArgs {
   double *s_out;           // ONEG sweep: s_new
 };
 
-template <int EPI, bool ONEG, int UN, bool NT>
+// NT: 0 cached matrix stream ; 1 non-temporal matrix stream ; 2 also the row-wise operands that are touched once per sweep
+// (r, x, 1/diag in; r, x out: non-temporal; s stays cacheable -- the next sweep gathers it)
+// XM (fused one-gather sweeps only): how x is updated, as in the row-pattern kernels -- 0: x += s_k ; 1: x untouched (the
+// increment is applied by the next sweep) ; 2: x = (x + s_{k-1}) + s_k with s_{k-1} read from s_out before it is overwritten:
+// the same two roundings, one read + one write of x less per pair of sweeps (writes are what this kernel pays most for).
+template <int EPI, bool ONEG, int UN, int NT, int XM = 0>
 __global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
 {
   const int lane = threadIdx.x & 63;
@@ -261,16 +274,24 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
   const double *__restrict__ dinv = a.dinv;
   const double omega = a.omega;
   // row-wise epilogue operands (coalesced), issued before the stream
-  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0, sp = 0.0;
   if (valid) {
     if (EPI == EPI_SUB) e0 = a.y[row];
     else if (EPI == EPI_RESID) e0 = a.b[row];
     else if (EPI == EPI_ADDTO) e0 = a.x2[row];
     else if (EPI == EPI_SWEEP) {
+      if (NT >= 2) {
+        e0 = __builtin_nontemporal_load(a.b + row);
+        e1 = ONEG ? xg[row] : __builtin_nontemporal_load(dinv + row);
+        if (XM != 1) e2 = a.x_zero ? 0.0 : __builtin_nontemporal_load(a.x2 + row);
+        if (ONEG) dinv_row = __builtin_nontemporal_load(dinv + row);
+      } else {
       e0 = a.b[row];
       e1 = ONEG ? xg[row] : dinv[row];
-      e2 = a.x_zero ? 0.0 : a.x2[row];
+      if (XM != 1) e2 = a.x_zero ? 0.0 : a.x2[row];
       if (ONEG) dinv_row = dinv[row];
+      }
+      if (XM == 2) sp = a.s_out[row];                        // s_{k-1}, about to be overwritten by s_{k+1}
     }
   }
   const int32_t *cp = a.scol + base + lane;
@@ -312,9 +333,10 @@ __global__ __launch_bounds__(kBlock) void sell_kernel(SellArgs a)
     else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
     else {
       const double dxi = ONEG ? e1 : omega * (e1 * e0);
-      a.x2[row] = e2 + dxi;
       const double rn = e0 - s;
-      a.y[row] = rn;
+      const double xn = XM == 2 ? (e2 + sp) + dxi : e2 + dxi;
+      if (NT >= 2) { if (XM != 1) __builtin_nontemporal_store(xn, a.x2 + row); __builtin_nontemporal_store(rn, a.y + row); }
+      else { if (XM != 1) a.x2[row] = xn; a.y[row] = rn; }
       if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
     }
   }
@@ -545,7 +567,7 @@ struct SellOArgs {
   double *s_out;
 };
 
-template <int EPI, bool ONEG, int UN, bool NT>
+template <int EPI, bool ONEG, int UN, int NT, int XM = 0>
 __global__ __launch_bounds__(kBlock) void sello_kernel(SellOArgs a)
 {
   extern __shared__ double sp_smem[];
@@ -568,15 +590,23 @@ __global__ __launch_bounds__(kBlock) void sello_kernel(SellOArgs a)
   const double *__restrict__ dinv = a.dinv;
   const double omega = a.omega;
   // row-wise epilogue operands (coalesced), requested before the stream; clamped addresses, no divergence
-  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0;
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dinv_row = 0.0, sp = 0.0;
   if (EPI == EPI_SUB) e0 = a.y[rc];
   else if (EPI == EPI_RESID) e0 = a.b[rc];
   else if (EPI == EPI_ADDTO) e0 = a.x2[rc];
   else if (EPI == EPI_SWEEP) {
+    if (NT >= 2) {
+      e0 = __builtin_nontemporal_load(a.b + rc);
+      e1 = ONEG ? xg[rc] : __builtin_nontemporal_load(dinv + rc);
+      if (XM != 1) { const double xl = __builtin_nontemporal_load(a.x2 + rc); e2 = a.x_zero ? 0.0 : xl; }
+      if (ONEG) dinv_row = __builtin_nontemporal_load(dinv + rc);
+    } else {
     e0 = a.b[rc];
     e1 = ONEG ? xg[rc] : dinv[rc];
-    { const double xl = a.x2[rc]; e2 = a.x_zero ? 0.0 : xl; }
+    if (XM != 1) { const double xl = a.x2[rc]; e2 = a.x_zero ? 0.0 : xl; }
     if (ONEG) dinv_row = dinv[rc];
+    }
+    if (XM == 2) sp = a.s_out[rc];
   }
   __syncthreads();
   const double *vp = a.sval + base + lane;
@@ -615,9 +645,10 @@ __global__ __launch_bounds__(kBlock) void sello_kernel(SellOArgs a)
     else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * s : s; a.y[row] = t; a.x2[row] = e0 + t; }
     else {
       const double dxi = ONEG ? e1 : omega * (e1 * e0);
-      a.x2[row] = e2 + dxi;
       const double rn = e0 - s;
-      a.y[row] = rn;
+      const double xn = XM == 2 ? (e2 + sp) + dxi : e2 + dxi;
+      if (NT >= 2) { if (XM != 1) __builtin_nontemporal_store(xn, a.x2 + row); __builtin_nontemporal_store(rn, a.y + row); }
+      else { if (XM != 1) a.x2[row] = xn; a.y[row] = rn; }
       if (ONEG) a.s_out[row] = omega * (dinv_row * rn);
     }
   }
@@ -1387,6 +1418,7 @@ struct SellSmoothArgs {
   uint32_t epoch;
   uint32_t *err;            // host-visible: set when a wait timed out
   int halo_wg;              // workgroup w waits for w-halo_wg .. w+halo_wg
+  int fenced;               // progress words: release store / acquire after the poll (agent scope) on top of the explicit store drain
 };
 
 __device__ __forceinline__ double ld_agent(const double *p)
@@ -1454,6 +1486,7 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
           if (++spins > (1u << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
           __builtin_amdgcn_s_sleep(1);
         }
+        if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // pairs with the neighbours' release below
       }
       __syncthreads();
     }
@@ -1504,10 +1537,16 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
     if (publish && !(DBG & 16)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: the stores have left the CU ...
       __syncthreads();
-      if (threadIdx.x == 0) __hip_atomic_store(a.flags + (size_t)w * 16, a.epoch + (uint32_t)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag
+      if (threadIdx.x == 0) {                                // ... before the flag
+        if (a.fenced) __hip_atomic_store(a.flags + (size_t)w * 16, a.epoch + (uint32_t)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(a.flags + (size_t)w * 16, a.epoch + (uint32_t)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     const double *t = sin; sin = sout; sout = const_cast<double *>(t);
   }
+  // a wait timed out somewhere (as far as this workgroup can see): the pass is void -- leave x and r as they were, the host
+  // re-runs the solve sweep by sweep (with_persist_retry)
+  if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     if (own[i]) { a.x[row[i]] = xr[i]; a.r_out[row[i]] = r[i]; }

@@ -76,12 +76,14 @@ class DistributedGMG:
     def __init__(self, cells_per_rank, nlevels, rank, world, device_id=0, transport="rccl", group=None,
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
                  gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None,
-                 smoother="jacobi"):
+                 smoother="jacobi", depth=None):
         """smoother = "jacobi": Richardson(Jacobi, niter, omega); "patch": Richardson(PatchSolver, niter, omega) with the
         vertex-star patches OWNED by this rank (partition.local_vertex_star_patches) and caller-assembled patch matrices --
         a rank's local matrix has the owned rows only, so the blocks of patches reaching into ghost dofs come from the
         driver, as the reference assembles them from the solver's weak form on the local (ghosted) mesh
-        (PatchSolvers.jl:137-150)."""
+        (PatchSolvers.jl:137-150).
+        depth: ghost layers of the OVERLAPPING layout on the partitioned levels >= 1 (int or per-level list; None / 0 = every level in
+        the own | ghost layout): one halo exchange per `depth` sweeps instead of one per sweep (gmg_set_partition_overlap)."""
         import torch.distributed as dist
         lib = abi.load()
         self._lib, self.rank, self.world = lib, rank, world
@@ -92,7 +94,8 @@ class DistributedGMG:
         # `lengths` = domain extents; the weak-scaling bench uses (px,py,pz) so that cells stay cubes
         # (an anisotropic mesh would change the iteration count with the rank grid)
         self.lengths = lengths
-        self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order, lengths, rep_from)
+        self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order, lengths, rep_from,
+                                                                  depth if smoother == "jacobi" else None)
         self.t_assembly = time.perf_counter() - t0
         self.order = order
         h = C.c_void_p()
@@ -121,9 +124,16 @@ class DistributedGMG:
                 nbr = np.ascontiguousarray(L.nbr_rank, dtype=np.int32)
                 sp, si, rp = (np.ascontiguousarray(a, dtype=np.int64) for a in (L.snd_ptr, L.snd_idx, L.rcv_ptr))
                 self._keep += [nbr, sp, si, rp]
-                abi.check(h, lib.gmg_set_partition(h, l, L.n_own, L.n_ghost, nbr.size, C.c_void_p(nbr.ctypes.data),
-                                                   C.c_void_p(sp.ctypes.data), C.c_void_p(si.ctypes.data),
-                                                   C.c_void_p(rp.ctypes.data)))
+                if L.overlap:
+                    ri = np.ascontiguousarray(L.rcv_idx, dtype=np.int64)
+                    self._keep.append(ri)
+                    abi.check(h, lib.gmg_set_partition_overlap(h, l, L.n_local, L.n_ghost, L.depth, nbr.size, C.c_void_p(nbr.ctypes.data),
+                                                               C.c_void_p(sp.ctypes.data), C.c_void_p(si.ctypes.data),
+                                                               C.c_void_p(rp.ctypes.data), C.c_void_p(ri.ctypes.data)))
+                else:
+                    abi.check(h, lib.gmg_set_partition(h, l, L.n_own, L.n_ghost, nbr.size, C.c_void_p(nbr.ctypes.data),
+                                                       C.c_void_p(sp.ctypes.data), C.c_void_p(si.ctypes.data),
+                                                       C.c_void_p(rp.ctypes.data)))
             self._set(lib.gmg_set_matrix, l, L.A)
             if l < nlevels - 1:
                 self._set(lib.gmg_set_prolongation, l, L.P)
@@ -241,6 +251,12 @@ class DistributedGMG:
         abi.check(self.h, self._lib.gmg_get_kernel_stats(self.h, C.byref(st)))
         return dict(launches=st.launches, total_ms=st.total_ms, alg_bytes=st.alg_bytes, rows=st.rows, nnz=st.nnz,
                     layout_bytes=st.layout_bytes)
+
+    def comm_stats(self):
+        """(halo exchanges, all-reduces) this rank's handle has issued so far"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        abi.check(self.h, self._lib.gmg_get_comm_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def close(self):
         if getattr(self, "h", None):

@@ -62,6 +62,13 @@ class LocalLevel:
         self.own_gid = None      # global lexicographic free-dof id of every owned dof
         self.ghost_gid = None
         self.replicated = False
+        # overlapping layout (gmg_set_partition_overlap): one local numbering = the box extended by `depth` node layers, lexicographic
+        self.overlap = False
+        self.depth = 0
+        self.n_local = 0
+        self.rcv_idx = np.zeros(0, np.int64)
+        self.own_idx = None      # local ids of the owned entries (ascending global id)
+        self.local_gid = None    # global id of every local entry
 
 
 def _axis_ranges(ncell_global, order, nparts, coord):
@@ -171,6 +178,78 @@ class _LevelGeom:
         return po.CSR((M.shape[0], self.n_own + self.n_ghost), M.ptr, np.take(e2l, M.idx), M.val)
 
 
+class _OverlapGeom:
+    """One level on one rank in the overlapping layout: the owned node box extended by `depth` layers per direction (clipped at the
+    Dirichlet boundary), numbered lexicographically (x fastest) -- owned and ghost entries interleaved.  Exact rows exist for
+    every local entry except the outermost layer, so `depth` sweeps of the 27-point operator can run between two exchanges."""
+
+    def __init__(self, cells_global, grid, rank, d, depth):
+        self.cells, self.grid, self.rank, self.d, self.depth = cells_global, grid, rank, d, int(depth)
+        co = _coords(rank, grid)
+        self.rng = []
+        for k in range(3):
+            if k < d:
+                lo, hi, _, _ = _axis_ranges(cells_global[k], 1, grid[k], co[k])
+                nlast = cells_global[k] - 1
+                self.rng.append((lo, hi, max(lo - depth, 1), min(hi + depth, nlast)))
+            else:
+                self.rng.append((0, 0, 0, 0))
+        self.nfree = [cells_global[k] - 1 if k < d else 1 for k in range(3)]
+        self.ext_shape = [r[3] - r[2] + 1 for r in self.rng]
+        self.own_shape = [r[1] - r[0] + 1 for r in self.rng]
+        self.n_local = int(np.prod(self.ext_shape))
+        ex = [np.arange(r[2], r[3] + 1) for r in self.rng]
+        Z, Y, X = np.meshgrid(ex[2], ex[1], ex[0], indexing="ij")
+        own = ((X >= self.rng[0][0]) & (X <= self.rng[0][1]) & (Y >= self.rng[1][0]) & (Y <= self.rng[1][1])
+               & (Z >= self.rng[2][0]) & (Z <= self.rng[2][1])).reshape(-1)
+        off = [1 if k < d else 0 for k in range(3)]
+        self.gid = ((X - off[0]) + self.nfree[0] * ((Y - off[1]) + self.nfree[1] * (Z - off[2]))).reshape(-1).astype(np.int64)
+        self.is_own = own
+        self.own_idx = np.nonzero(own)[0].astype(np.int64)
+        self.n_own = self.own_idx.size
+        self.own_gid = self.gid[self.own_idx]
+
+    def _sub_box(self, box):
+        """local ids (lexicographic) of the global node box [(lo,hi)]*3 intersected with this rank's extended box"""
+        sub = []
+        for k in range(3):
+            if k >= self.d:
+                sub.append(np.zeros(1, dtype=np.int64)); continue
+            a, b = max(box[k][0], self.rng[k][2]), min(box[k][1], self.rng[k][3])
+            sub.append(np.arange(a, b + 1, dtype=np.int64) - self.rng[k][2] if b >= a else np.zeros(0, dtype=np.int64))
+        ex, ey = self.ext_shape[0], self.ext_shape[1]
+        return (sub[2][:, None, None] * (ey * ex) + sub[1][None, :, None] * ex + sub[0][None, None, :]).reshape(-1)
+
+    def plan(self):
+        """(nbr, snd_ptr, snd_idx, rcv_ptr, rcv_idx): with rank q I exchange  my owned box ∩ q's extended box  (sent) and
+        q's owned box ∩ my extended box  (received), both enumerated lexicographically = ascending global id on either side."""
+        grid, d = self.grid, self.d
+        nranks = int(np.prod(grid))
+        nbr, snd_ptr, rcv_ptr, snd, rcv = [], [0], [0], [], []
+        for q in range(nranks):
+            if q == self.rank:
+                continue
+            qc = _coords(q, grid)
+            q_own, q_ext = [], []
+            for k in range(3):
+                if k >= d:
+                    q_own.append((0, 0)); q_ext.append((0, 0)); continue
+                lo, hi, _, _ = _axis_ranges(self.cells[k], 1, grid[k], qc[k])
+                q_own.append((lo, hi)); q_ext.append((max(lo - self.depth, 1), min(hi + self.depth, self.cells[k] - 1)))
+            my_own = [(self.rng[k][0], self.rng[k][1]) for k in range(3)]
+            s_box = [(max(my_own[k][0], q_ext[k][0]), min(my_own[k][1], q_ext[k][1])) for k in range(3)]
+            sidx = self._sub_box(s_box)
+            ridx = self._sub_box(q_own)
+            if sidx.size == 0 and ridx.size == 0:
+                continue
+            nbr.append(q); snd.append(sidx); rcv.append(ridx)
+            snd_ptr.append(snd_ptr[-1] + sidx.size); rcv_ptr.append(rcv_ptr[-1] + ridx.size)
+        rcv_idx = np.concatenate(rcv).astype(np.int64) if rcv else np.zeros(0, np.int64)
+        assert rcv_idx.size == self.n_local - self.n_own and not self.is_own[rcv_idx].any(), "every ghost must be received from exactly one neighbour"
+        return (np.asarray(nbr, dtype=np.int32), np.asarray(snd_ptr, dtype=np.int64),
+                np.concatenate(snd).astype(np.int64) if snd else np.zeros(0, np.int64), np.asarray(rcv_ptr, dtype=np.int64), rcv_idx)
+
+
 def local_vertex_star_patches(cells_global, order, grid, rank):
     """Vertex-star patches OWNED by `rank` on one level, for the distributed patch smoother (PatchSolvers.jl:227-258).
 
@@ -263,12 +342,27 @@ def _exchange_plan(me):
             np.asarray(rcv_ptr, dtype=np.int64))
 
 
-def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None, rep_from=None):
+def _restr_tables_ext(nc_coarse_global, order, c_elo, c_ehi, clo, chi, felo, fehi, active):
+    """1-D restriction rows for the coarse EXTENDED range c_elo..c_ehi (overlapping layout): the rows of owned coarse nodes
+    clo..chi are complete, the rows of ghost coarse nodes are empty (their residual arrives with the next exchange)."""
+    if not active:
+        return 1, np.zeros((1, 1), dtype=np.int64), np.ones((1, 1))
+    n, c, v = _restr_tables_local(nc_coarse_global, order, c_elo, c_ehi, felo, fehi, active)
+    rows = np.arange(c_elo, c_ehi + 1)
+    ghost = (rows < clo) | (rows > chi)
+    c = c.copy()
+    c[ghost, :] = -1
+    return n, c, v
+
+
+def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None, rep_from=None, depth=None):
     """Local operators of `rank` for every level.
 
     Levels >= rep_from are REPLICATED (global operators on every rank, no halo); by default only the
-    coarsest level is.  Returns dict(levels=[LocalLevel...], rep_from, rep_gid (global ids, in level
-    rep_from numbering, of the rows this rank's boundary restriction produces), cells, grid)."""
+    coarsest level is.  `depth`: None / 0 = every partitioned level in the own | ghost layout (one exchange per mat-vec); an int or a
+    per-level list = ghost layers of the OVERLAPPING layout on the partitioned levels >= 1 (`LocalLevel.overlap`: one local numbering
+    over the extended box, square local matrix, one exchange per `depth` sweeps; Q1 only).  Returns dict(levels=[LocalLevel...],
+    rep_from, rep_gid (global ids, in level rep_from numbering, of the rows this rank's boundary restriction produces), cells, grid)."""
     nc = tuple(int(c) for c in cells_global_fine)
     d = len(nc)
     nc3 = nc + (1,) * (3 - d)
@@ -280,6 +374,15 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
         rep_from = nlevels          # nothing to replicate
     if not (1 <= rep_from <= nlevels):
         raise ValueError("rep_from must be in 1..nlevels")
+    if depth is None:
+        depth = 0
+    depths = [int(depth)] * nlevels if np.isscalar(depth) else [int(v) for v in depth] + [0] * (nlevels - len(depth))
+    depths[0] = 0                    # the finest level's vectors are the caller's: own | ghost
+    for l in range(nlevels):
+        if l >= rep_from or nranks == 1:
+            depths[l] = 0
+    if any(depths) and order != 1:
+        raise ValueError("the overlapping layout is implemented for Q1 hierarchies")
     cells = [tuple(c // (2 ** l) for c in nc3[:d]) + (1,) * (3 - d) for l in range(nlevels)]
     for l in range(nlevels):
         for k in range(d):
@@ -290,10 +393,34 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
     Ls = po._lengths(lengths, d)
     ngeom = min(rep_from + 1, nlevels)
     geoms = [_LevelGeom(cells[l], order, grid, rank, d) for l in range(ngeom)]
+    ogeoms = [_OverlapGeom(cells[l], grid, rank, d, depths[l]) if depths[l] > 0 else None for l in range(nlevels)]
+
+    def fine_cols(l):
+        """(elo, ehi) per axis of the column numbering of level l's vectors + the remap to apply afterwards (None: lexicographic as is)"""
+        if ogeoms[l] is not None:
+            return [(ogeoms[l].rng[k][2], ogeoms[l].rng[k][3]) for k in range(3)], None
+        return [(geoms[l].rng[k][2], geoms[l].rng[k][3]) for k in range(3)], geoms[l].remap
+
     levels = []
     for l in range(nlevels):
         L = LocalLevel()
-        if l < rep_from:
+        if l < rep_from and ogeoms[l] is not None:
+            og = ogeoms[l]
+            tabs = [_axis_tables_local(cells[l][k], order, og.rng[k][2], og.rng[k][3], og.rng[k][2], og.rng[k][3], k < d, Ls[k]) for k in range(3)]
+            ncols = [t[0] for t in tabs]
+            cols = [t[1] for t in tabs]
+            K = [t[2] for t in tabs]
+            M = [t[3] for t in tabs]
+            terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
+            if d == 3:
+                terms.append((M[0], M[1], K[2]))
+            L.A = po._tensor_csr(cols, terms, ncols)
+            L.overlap, L.depth, L.n_local = True, og.depth, og.n_local
+            L.n_own, L.n_ghost = og.n_own, og.n_local - og.n_own
+            L.own_idx, L.local_gid, L.own_gid = og.own_idx, og.gid, og.own_gid
+            L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr, L.rcv_idx = og.plan()
+            L.ghost_gid = og.gid[L.rcv_idx]
+        elif l < rep_from:
             g = geoms[l]
             tabs = [_axis_tables_local(cells[l][k], order, *g.rng[k], k < d, Ls[k]) for k in range(3)]
             ncols = [t[0] for t in tabs]
@@ -315,25 +442,34 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
         levels.append(L)
     rep_gid = np.zeros(0, dtype=np.int64)
     for l in range(nlevels - 1):
-        if l + 1 < rep_from:                      # both levels partitioned
+        if l + 1 <= rep_from and l < rep_from:    # fine level partitioned
             gf, gc = geoms[l], geoms[l + 1]
-            pt = [_interp_tables_local(cells[l + 1][k], order, gf.rng[k][0], gf.rng[k][1], gc.rng[k][2], gc.rng[k][3], k < d)
-                  for k in range(3)]
-            levels[l].P = gc.remap(po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt]))
-            rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], gf.rng[k][2], gf.rng[k][3], k < d)
-                  for k in range(3)]
-            levels[l].R = gf.remap(po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt]))
-        elif l + 1 == rep_from:                   # boundary: fine partitioned, coarse replicated
-            gf, gc = geoms[l], geoms[l + 1]
-            last = [order * cells[l + 1][k] - 1 for k in range(3)]
-            pt = [_interp_tables_local(cells[l + 1][k], order, gf.rng[k][0], gf.rng[k][1], 1, last[k], k < d) for k in range(3)]
-            levels[l].P = po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt])   # global coarse columns
-            rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], gf.rng[k][2], gf.rng[k][3], k < d)
-                  for k in range(3)]
-            levels[l].R = gf.remap(po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt]))
-            rep_gid = gc.own_gid
+            of, oc = ogeoms[l], ogeoms[l + 1] if l + 1 < rep_from else None
+            # rows of P: the fine level's matrix rows (owned rows, or every local entry in the overlapping layout)
+            frows = [(of.rng[k][2], of.rng[k][3]) if of is not None else (gf.rng[k][0], gf.rng[k][1]) for k in range(3)]
+            fcols, fremap = fine_cols(l)
+            if l + 1 < rep_from:                  # coarse level partitioned too
+                ccols, cremap = fine_cols(l + 1)
+                pt = [_interp_tables_local(cells[l + 1][k], order, frows[k][0], frows[k][1], ccols[k][0], ccols[k][1], k < d) for k in range(3)]
+                Pm = po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt])
+                levels[l].P = cremap(Pm) if cremap is not None else Pm
+                if oc is not None:
+                    rt = [_restr_tables_ext(cells[l + 1][k], order, oc.rng[k][2], oc.rng[k][3], oc.rng[k][0], oc.rng[k][1],
+                                            fcols[k][0], fcols[k][1], k < d) for k in range(3)]
+                else:
+                    rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], fcols[k][0], fcols[k][1], k < d) for k in range(3)]
+                Rm = po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt])
+                levels[l].R = fremap(Rm) if fremap is not None else Rm
+            else:                                 # boundary: fine partitioned, coarse replicated
+                last = [order * cells[l + 1][k] - 1 for k in range(3)]
+                pt = [_interp_tables_local(cells[l + 1][k], order, frows[k][0], frows[k][1], 1, last[k], k < d) for k in range(3)]
+                levels[l].P = po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt])   # global coarse columns
+                rt = [_restr_tables_local(cells[l + 1][k], order, gc.rng[k][0], gc.rng[k][1], fcols[k][0], fcols[k][1], k < d) for k in range(3)]
+                Rm = po._tensor_csr([t[1] for t in rt], [tuple(t[2] for t in rt)], [t[0] for t in rt])
+                levels[l].R = fremap(Rm) if fremap is not None else Rm
+                rep_gid = gc.own_gid
         else:                                     # both replicated: global transfer operators
             levels[l].P = po.prolongation(cells[l + 1][:d], order)
             levels[l].R = levels[l].P.transpose()
     return dict(levels=levels, rep_from=rep_from, rep_gid=np.ascontiguousarray(rep_gid, dtype=np.int64),
-                cells=[c[:d] for c in cells], grid=grid[:d], order=order, rank=rank, nranks=nranks)
+                cells=[c[:d] for c in cells], grid=grid[:d], order=order, rank=rank, nranks=nranks, depths=depths)

@@ -281,6 +281,21 @@ GMG_API int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_ex
 GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, int nnbr,
                               const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
                               const int64_t *rcv_ptr);
+/* The same for a level in the OVERLAPPING layout: owned and ghost entries share ONE local numbering of n_local entries chosen by the
+ * caller (a structured box partition: the box extended by `depth` node layers, lexicographic), the local matrix is square over all of
+ * them (rows of ghost entries are the true global rows restricted to the local columns -- exact except on the outermost layer), and
+ * one exchange makes `depth` layers consistent.  A smoothing pass of Richardson(Jacobi) then communicates once per `depth`
+ * sweeps instead of once per sweep: ghost layer j is recomputed redundantly and stays exact for depth - j sweeps, owned rows are
+ * exact throughout and are summed in the order of a single-GPU run.  Transfers: P_lev has a row per local entry of level lev, R_lev's
+ * rows of non-owned coarse entries are empty.  Levels >= 1 with Jacobi smoothers; the finest level keeps gmg_set_partition.
+ * snd_idx / rcv_idx: local ids (0-based) sent to / received from each neighbour, both sides enumerating in the same (global) order.
+ * Reference analogue: consistent!(::PVector) once per mul! (RichardsonSmoothers.jl:94 through PartitionedArrays) -- here once per
+ * `depth` applications. */
+GMG_API int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, int64_t n_ghost, int depth, int nnbr,
+                                      const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
+                                      const int64_t *rcv_ptr, const int64_t *rcv_idx);
+/* Halo exchanges and all-reduces this handle has issued since gmg_create (either may be NULL). */
+GMG_API int gmg_get_comm_stats(gmg_handle_t h, int64_t *n_exchanges, int64_t *n_allreduces);
 /* Levels >= lev are REPLICATED: every rank passes the GLOBAL operators of those levels
  * (gmg_set_matrix / _prolongation / _restriction, no gmg_set_partition) and computes them
  * redundantly -- no halo traffic where the level is tiny.  Across the boundary, P_{lev-1} has

@@ -26,12 +26,31 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
     A = [L.A.to_scipy() for L in levels]
     P = [L.P.to_scipy() for L in levels[:-1]]
     R = [L.R.to_scipy() for L in levels[:-1]]
-    dinv = [1.0 / A[l].diagonal()[: levels[l].n_own] for l in range(nlev - 1)]   # own x own diagonal
+    dinv = [1.0 / A[l].diagonal() if levels[l].overlap else 1.0 / A[l].diagonal()[: levels[l].n_own] for l in range(nlev - 1)]   # own x own diagonal (overlapping layout: every local row)
+    stats = {"exchanges": 0}
     rep_from, rep_gid = local["rep_from"], local["rep_gid"]
     Gc = A[nlev - 1].tocsc()                    # coarsest level is always replicated (global matrix)
 
     def exchange(l, v):
         L = levels[l]
+        if L.nbr_rank.size:
+            stats["exchanges"] += 1
+        if L.overlap:                                # one local numbering: scatter through rcv_idx
+            ops, keep = [], []
+            for k, q in enumerate(L.nbr_rank):
+                r0, r1 = L.rcv_ptr[k], L.rcv_ptr[k + 1]
+                if r1 > r0:
+                    t = torch.zeros(int(r1 - r0), dtype=torch.float64); keep.append((t, r0, r1))
+                    ops.append(dist.P2POp(dist.irecv, t, int(q)))
+                sidx = L.snd_idx[L.snd_ptr[k]:L.snd_ptr[k + 1]]
+                if sidx.size:
+                    ops.append(dist.P2POp(dist.isend, torch.from_numpy(v[sidx].copy()), int(q)))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for t, r0, r1 in keep:
+                v[L.rcv_idx[r0:r1]] = t.numpy()
+            return
         ops, keep = [], []
         for k, q in enumerate(L.nbr_rank):
             r0, r1 = L.rcv_ptr[k], L.rcv_ptr[k + 1]
@@ -75,6 +94,17 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
 
     def smooth(l, x, r):
         n = levels[l].n_own
+        if levels[l].overlap:
+            # blocks of `depth` sweeps between two exchanges: consistent!(r) on every ghost layer, then every local row is swept
+            # (ghost layer j stays exact for depth - j sweeps, the owned rows throughout)
+            k = max(1, min(levels[l].depth, niter))
+            for blk in range(0, niter, k):
+                exchange(l, r)
+                for _ in range(min(k, niter - blk)):
+                    dx = omega * (dinv[l] * r)
+                    x += dx
+                    r -= A[l] @ dx
+            return
         if patches is not None:
             pp, pl, Binv = patches[l]
             for _ in range(niter):
@@ -111,15 +141,23 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
             full[torch.from_numpy(rep_gid)] = torch.from_numpy(R[l] @ r)
             dist.all_reduce(full)
             rH[:] = full.numpy()
+        elif levels[l + 1].overlap:
+            rH[:] = R[l] @ r                     # rows of ghost coarse entries are empty
         else:
             rH[: levels[l + 1].n_own] = R[l] @ r
         dxH = vec(l + 1)
         cycle(l + 1, dxH, rH)
         exchange(l + 1, dxH)
-        dx = vec(l); dx[:n] = P[l] @ dxH
-        x[:n] += dx[:n]
-        exchange(l, dx)
-        r[:n] -= A[l] @ dx
+        if levels[l].overlap:                    # every local row (ghost rows are fixed by the exchange below)
+            dx = P[l] @ dxH
+            x += dx
+            exchange(l, dx)
+            r -= A[l] @ dx
+        else:
+            dx = vec(l); dx[:n] = P[l] @ dxH
+            x[:n] += dx[:n]
+            exchange(l, dx)
+            r[:n] -= A[l] @ dx
         smooth(l, x, r)
 
     n = levels[0].n_own
@@ -142,6 +180,7 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
         r[:n] -= alpha * w
         res = np.sqrt(gdot(r[:n], r[:n])); hist.append(res); it += 1
         done = (it >= maxiter) or (res / hist[0] < rtol) or (res < atol)
+    numpy_distributed_cg.last_exchanges = stats["exchanges"]
     return x[:n].copy(), it, np.array(hist)
 
 
@@ -227,11 +266,12 @@ def main():
     order = int(os.environ.get("GMG_TEST_ORDER", "1"))
     smoother = os.environ.get("GMG_TEST_SMOOTHER", "jacobi")
     p_niter, p_omega = 4, 0.2
+    depth = int(os.environ.get("GMG_TEST_DEPTH", "0"))      # > 0: partitioned levels >= 1 in the overlapping layout with that many ghost layers
     verdict = {}
     if mode == "gpu_block":
         pass
     elif mode == "numpy":
-        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from)
+        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from, depth)
         b = po.dirichlet_lift_rhs(cg, order)[local["levels"][0].own_gid]
         patches = None
         if smoother == "patch":
@@ -250,6 +290,7 @@ def main():
             x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol, p_niter, p_omega, patches)
         else:
             x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol)
+            verdict["exchanges"] = int(numpy_distributed_cg.last_exchanges)
         gid = local["levels"][0].own_gid
     else:
         ndev = torch.cuda.device_count()
@@ -257,10 +298,13 @@ def main():
         torch.cuda.set_device(dev)
         g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=rep_from,
                                     order=order, smoother=smoother, niter=(p_niter if smoother == "patch" else 10),
-                                    omega=(p_omega if smoother == "patch" else 2.0 / 3.0))
+                                    omega=(p_omega if smoother == "patch" else 2.0 / 3.0), depth=depth)
         b = g.rhs_lin()
         x = np.zeros(g.n_own)
+        ex0 = g.comm_stats()[0]
         log = g.cg_solve(b, x, maxiter, atol, rtol)
+        verdict["exchanges"] = int(g.comm_stats()[0] - ex0)
+        verdict["x_sha"] = __import__("hashlib").sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
         nit, hist = log.num_iters, log.residuals[: log.num_iters + 1].copy()
         # also exercise device-pointer vectors + FGMRES
         xd = torch.zeros(g.n_own, dtype=torch.float64, device="cuda"); bd = torch.from_numpy(b).cuda(); torch.cuda.synchronize()

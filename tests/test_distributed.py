@@ -54,6 +54,68 @@ def test_partitioned_cg_gmg_numpy_gloo(world, cells, nlev, rep, tmp_path):
     _check(_launch("numpy", world, cells, nlev, tmp_path, rep_from=rep))
 
 
+@pytest.mark.parametrize("world,cells,nlev,rep,depth", [(2, (16, 16, 16), 3, 2, 2), (8, (8, 8, 8), 3, 2, 2), (4, (16, 16), 4, 3, 3),
+                                                          (2, (16, 16, 16), 3, 2, 10)])
+def test_overlapping_layout_numpy_gloo(world, cells, nlev, rep, depth, tmp_path):
+    """Partitioned levels >= 1 in the overlapping layout (gmg_set_partition_overlap): `depth` ghost layers, one exchange per
+    `depth` sweeps, ghost rows recomputed redundantly.  Same iteration count and history as the serial oracle, and fewer halo
+    exchanges than the own | ghost schedule by the expected amount."""
+    v0 = _launch("numpy", world, cells, nlev, tmp_path, rep_from=rep)
+    v = _launch("numpy", world, cells, nlev, tmp_path, rep_from=rep, extra_env={"GMG_TEST_DEPTH": str(depth)})
+    _check(v0); _check(v)
+    nov = rep - 1                                            # levels 1 .. rep-1 are in the overlapping layout
+    per_pass0, per_pass = 10, -(-10 // depth)
+    saved = v["iters"] * nov * 2 * (per_pass0 - per_pass)    # two smoothing passes per level and V-cycle, one V-cycle per CG iteration
+    assert v0["exchanges"] - v["exchanges"] == saved, (v0["exchanges"], v["exchanges"], saved)
+
+
+def test_overlapping_layout_operators_match_global(po, pkg):
+    """Local operators of the overlapping layout: owned rows of A / P / R reproduce the global mat-vecs, ghost rows of R are empty,
+    both sides of every exchange enumerate the same global ids, every ghost is received exactly once."""
+    from gridapsolvers_jl_amd import partition as pa
+    for nc, nlev, nranks, rep, depth in [((16, 16, 16), 3, 8, 2, 2), ((16, 16, 16), 3, 2, 2, 3), ((32, 32), 4, 4, 3, 2)]:
+        grid = pa.rank_grid(nranks, len(nc))
+        Hg = po.build_hierarchy(nc, nlev, 1)
+        locs = [pa.build_local_hierarchy(nc, nlev, grid, r, 1, None, rep, depth) for r in range(nranks)]
+        assert any(L.overlap for L in locs[0]["levels"]) and not locs[0]["levels"][0].overlap
+        for l in range(nlev):
+            N = Hg["mats"][l].shape[0]
+            x = np.random.default_rng(l).uniform(-1, 1, N)
+            yg = Hg["mats"][l].matvec(x)
+            owned = np.zeros(N, dtype=int)
+
+            def loc_vec(L, v):
+                return v[L.local_gid] if L.overlap else (v if L.replicated else np.concatenate([v[L.own_gid], v[L.ghost_gid]]))
+            for r in range(nranks):
+                L = locs[r]["levels"][l]
+                if L.replicated:
+                    continue
+                owned[L.own_gid] += 1
+                y = L.A.matvec(loc_vec(L, x))
+                assert np.abs((y[L.own_idx] if L.overlap else y) - yg[L.own_gid]).max() < 1e-13
+                if L.overlap:
+                    assert L.A.shape == (L.n_local, L.n_local) and np.array_equal(np.sort(np.concatenate([L.own_idx, L.rcv_idx])), np.arange(L.n_local))
+                    for k, q in enumerate(L.nbr_rank):
+                        Lq = locs[q]["levels"][l]
+                        kk = list(Lq.nbr_rank).index(r)
+                        assert np.array_equal(L.local_gid[L.snd_idx[L.snd_ptr[k]:L.snd_ptr[k + 1]]], Lq.local_gid[Lq.rcv_idx[Lq.rcv_ptr[kk]:Lq.rcv_ptr[kk + 1]]])
+                if l < nlev - 1:
+                    Lc = locs[r]["levels"][l + 1]
+                    xc = np.random.default_rng(9).uniform(-1, 1, Hg["mats"][l + 1].shape[0])
+                    yp, ypg = L.P.matvec(loc_vec(Lc, xc)), Hg["prolongations"][l].matvec(xc)
+                    assert np.abs((yp[L.own_idx] if L.overlap else yp) - ypg[L.own_gid]).max() < 1e-14
+                    yr, yrg = L.R.matvec(loc_vec(L, x)), Hg["restrictions"][l].matvec(x)
+                    if Lc.overlap:
+                        assert np.abs(yr[Lc.own_idx] - yrg[Lc.own_gid]).max() < 1e-13
+                        assert np.abs(np.delete(yr, Lc.own_idx)).max(initial=0.0) == 0.0
+                    elif Lc.replicated:
+                        assert np.abs(yr - yrg[locs[r]["rep_gid"]]).max() < 1e-13
+                    else:
+                        assert np.abs(yr - yrg[Lc.own_gid]).max() < 1e-13
+            if not locs[0]["levels"][l].replicated:
+                assert (owned == 1).all()
+
+
 def test_partition_operators_match_global(po, pkg):
     """Local operators / exchange plans reproduce the global mat-vecs on every level (no processes)."""
     from gridapsolvers_jl_amd import partition as pa
@@ -140,6 +202,28 @@ def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_p
     v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep)
     _check(v)
     assert v["fgmres_iters"] <= v["iters"] + 1 and v["fgmres_vs_cg"] < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cells,nlev,rep", [(2, (16, 16, 16), 4, 3), (8, (8, 8, 8), 3, 2), (4, (32, 32), 4, 3)])
+def test_overlapping_layout_on_gpu_host_transport(world, cells, nlev, rep, tmp_path):
+    """The real library with levels >= 1 in the overlapping layout (several ranks on one GPU, host transport): iteration counts
+    and histories of the serial oracle; halo exchanges per solve drop by the expected amount; and because owned rows are summed
+    in the single-GPU order whatever the depth, solutions computed with different depths are IDENTICAL bit for bit -- with
+    the sweeps of a block run as one launch (sells_smooth_kernel between two exchanges) or launch by launch."""
+    env = {"GMG_PERSIST_SHARED": "1"}
+    v0 = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep)
+    vs = {d: _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env=dict(env, GMG_TEST_DEPTH=str(d))) for d in (1, 2, 5)}
+    vl = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env={"GMG_TEST_DEPTH": "5", "GMG_PERSIST": "0"})
+    _check(v0)
+    for v in list(vs.values()) + [vl]:
+        _check(v)
+        assert v["iters"] == v0["iters"]
+    assert vs[1]["x_sha"] == vs[2]["x_sha"] == vs[5]["x_sha"] == vl["x_sha"]
+    nov = rep - 1
+    assert vs[1]["exchanges"] == v0["exchanges"]                    # depth 1: the same count, whole rows in one kernel
+    for d in (2, 5):
+        assert v0["exchanges"] - vs[d]["exchanges"] == v0["iters"] * nov * 2 * (10 - -(-10 // d)), (v0["exchanges"], vs[d]["exchanges"])
 
 
 @pytest.mark.gpu

@@ -58,6 +58,108 @@ __global__ void cmp_kernel(int64_t n, const double *a, const double *b, unsigned
     if (__double_as_longlong(a[i]) != __double_as_longlong(b[i])) atomicAdd(ndiff, 1ull);
 }
 
+// ---- ablations of the generic sweep (wrong results by design) ----
+// MODE 0: stream only (col,val in the SELL layout, 4 B + 8 B per lane) ; 1: + gathers that always hit (col & 1023)
+// 2: + row-wise operand loads and the three stores ; 3: loads only ; 4: stores only ; 5: as 2, non-temporal stores ;
+// 6: as 2, non-temporal loads and stores ; 7: as 2 but one store (r) ; 8: as 2, stores of a slice issued by ... (unused)
+template <int MODE, int UN>
+__global__ __launch_bounds__(256) void abl_kernel(SellArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int slice = __builtin_amdgcn_readfirstlane((int)(remap_block(blockIdx.x, gridDim.x, a.xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  if (slice >= a.nslices) return;
+  const int64_t base = a.soff[slice];
+  const int w = (int)((a.soff[slice + 1] - base) >> 6);
+  const int64_t row = min((int64_t)slice * 64 + lane, a.nrows - 1);
+  const int32_t *cp = a.scol + base + lane;
+  const double *vp = a.sval + base + lane;
+  constexpr bool LD = MODE == 2 || MODE == 3 || MODE == 5 || MODE == 6 || MODE == 7;
+  constexpr bool ST = MODE == 2 || MODE == 4 || MODE == 5 || MODE == 6 || MODE == 7;
+  constexpr bool NTL = MODE == 6, NTS = MODE == 5 || MODE == 6;
+  double e0 = 0.0, e1 = 0.0, e2 = 0.0, dr = 0.0;
+  if (LD) {
+    if (NTL) { e0 = __builtin_nontemporal_load(a.b + row); e1 = a.x[row]; e2 = __builtin_nontemporal_load(a.x2 + row); dr = __builtin_nontemporal_load(a.dinv + row); }
+    else { e0 = a.b[row]; e1 = a.x[row]; e2 = a.x2[row]; dr = a.dinv[row]; }
+  }
+  double s = 0.0;
+  for (int j = 0; j + UN <= w; j += UN) {
+    int32_t c[UN]; double v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) { c[u] = __builtin_nontemporal_load(cp + (int64_t)(j + u) * 64); v[u] = __builtin_nontemporal_load(vp + (int64_t)(j + u) * 64); }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) s += v[u] * (MODE >= 1 ? a.x[c[u] & 1023] : (double)c[u]);
+  }
+  if (ST) {
+    const double rn = e0 - s;
+    if (NTS) { __builtin_nontemporal_store(e2 + e1, a.x2 + row); __builtin_nontemporal_store(rn, a.y + row); a.s_out[row] = a.omega * (dr * rn); }
+    else if (MODE == 7) a.y[row] = rn + e2 + e1 + dr;
+    else { a.x2[row] = e2 + e1; a.y[row] = rn; a.s_out[row] = a.omega * (dr * rn); }
+  } else if (s + e0 + e1 + e2 + dr == 1.2345e300) a.y[row] = s;
+}
+// ---- candidate: NB consecutive slices per wave, all stores after the last slice's loads (bit-identical to sell_kernel) ----
+template <int NB, int UN>
+__global__ __launch_bounds__(256) void sell_multi_kernel(SellArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(remap_block(blockIdx.x, gridDim.x, a.xcd_remap) * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  const int slice0 = wv * NB;
+  if (slice0 >= a.nslices) return;
+  const double *__restrict__ xg = a.x;
+  const double omega = a.omega;
+  double xn[NB], rn[NB], sn[NB];
+  int64_t rows[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int slice = min(slice0 + i, a.nslices - 1);
+    const int64_t base = a.soff[slice];
+    const int w = (int)((a.soff[slice + 1] - base) >> 6);
+    const int64_t row = (int64_t)slice * 64 + lane;
+    const int64_t rc = min(row, a.nrows - 1);
+    rows[i] = (slice0 + i < a.nslices && row < a.nrows) ? row : -1;
+    int len = a.rowlen[rc];
+    if (rows[i] < 0) len = 0;
+    const double e0 = a.b[rc], e1 = xg[rc], dinv_row = a.dinv[rc];
+    double e2 = a.x2[rc];
+    if (a.x_zero) e2 = 0.0;
+    const int32_t *cp = a.scol + base + lane;
+    const double *vp = a.sval + base + lane;
+    double s = 0.0;
+    int j = 0;
+    for (; j + UN <= w; j += UN) {
+      int32_t c[UN]; double v[UN], g[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { c[u] = __builtin_nontemporal_load(cp + (int64_t)(j + u) * 64); v[u] = __builtin_nontemporal_load(vp + (int64_t)(j + u) * 64); }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) g[u] = xg[c[u]];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) { const double pr = v[u] * g[u]; s = (j + u < len) ? s + pr : s; }
+    }
+    for (; j < w; ++j) {
+      const int32_t c = cp[(int64_t)j * 64]; const double v = vp[(int64_t)j * 64];
+      const double pr = v * xg[c]; s = (j < len) ? s + pr : s;
+    }
+    xn[i] = e2 + e1;
+    rn[i] = e0 - s;
+    sn[i] = omega * (dinv_row * rn[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (rows[i] >= 0) { a.x2[rows[i]] = xn[i]; a.y[rows[i]] = rn[i]; a.s_out[rows[i]] = sn[i]; }
+}
+
+// flat 16 B/lane read of nbytes (the same arrays as one stream)
+__global__ __launch_bounds__(256) void flat_read_kernel(int64_t n2, const double *__restrict__ src, double *__restrict__ sink)
+{
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 *s2 = reinterpret_cast<const d2 *>(src);
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    const d2 v = __builtin_nontemporal_load(s2 + i);
+    acc += v.x + v.y;
+  }
+  if (acc == 1.2345e300) sink[0] = acc;
+}
+
 template <typename F> float time_it(F f, int reps)
 {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -152,7 +254,53 @@ int main(int argc, char **argv)
   RUN("sello_pipe<UN=9>", B8, 4, 0, hipLaunchKernelGGL((sello_pipe_kernel<EPI_SWEEP, true, 9, 0, true>), g, b, lds, 0, o))
   RUN("sello_pipe<row 27>", B8, 4, 1, hipLaunchKernelGGL((sello_pipe_kernel<EPI_SWEEP, true, 9, 27, true>), g, b, lds, 0, o))
   RUN("sello_pipe<row 27>", B8, 2, 1, hipLaunchKernelGGL((sello_pipe_kernel<EPI_SWEEP, true, 9, 27, true>), g, b, lds, 0, o))
-  RUN("sello_pipe<row 27>", B8, 8, 1, hipLaunchKernelGGL((sello_pipe_kernel<EPI_SWEEP, true, 9, 27, true>), g, b, lds, 0, o))
   RUN("sello_pipe<row 27> cached stream", B8, 4, 1, hipLaunchKernelGGL((sello_pipe_kernel<EPI_SWEEP, true, 9, 27, false>), g, b, lds, 0, o))
+  // ---- ceilings and ablations over the same footprint ----
+  have_ref = false;
+  const double Bs = 12.0 * 27.0 * 64.0 * nsl;
+  double *cpy; CK(hipMalloc(&cpy, zpad * 4));
+  { float t = time_it([&] { hipLaunchKernelGGL(flat_read_kernel, dim3(256 * 16), dim3(256), 0, 0, zpad / 2, sval, ref); }, reps);
+    printf("  flat 16 B/lane read of sval (%.0f MB), 4096 wgs              : %8.1f us  %6.0f GB/s\n", 8.0 * zpad / 1e6, t * 1e3, 8.0 * zpad / t / 1e6); }
+  { float t = time_it([&] { hipLaunchKernelGGL(flat_read_kernel, dim3(256 * 64), dim3(256), 0, 0, zpad / 2, sval, ref); }, reps);
+    printf("  flat 16 B/lane read of sval (%.0f MB), 16384 wgs             : %8.1f us  %6.0f GB/s\n", 8.0 * zpad / 1e6, t * 1e3, 8.0 * zpad / t / 1e6); }
+  { float t = time_it([&] { hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 16), dim3(256), 0, 0, zpad / 4, sval, cpy); }, reps);
+    printf("  16 B/lane copy of half of sval (%.0f MB read + written)      : %8.1f us  %6.0f GB/s\n", 8.0 * zpad / 1e6, t * 1e3, 8.0 * zpad / t / 1e6); }
+  RUN("ablation: stream only (SELL layout, UN=6)", Bs, 4, 1, hipLaunchKernelGGL((abl_kernel<0, 6>), g, b, 0, 0, a))
+  RUN("ablation: stream only (SELL layout, UN=6)", Bs, 4, 0, hipLaunchKernelGGL((abl_kernel<0, 6>), g, b, 0, 0, a))
+  RUN("ablation: stream only (SELL layout, UN=9)", Bs, 4, 0, hipLaunchKernelGGL((abl_kernel<0, 9>), g, b, 0, 0, a))
+  RUN("ablation: stream + always-hit gathers", Bs, 4, 1, hipLaunchKernelGGL((abl_kernel<1, 6>), g, b, 0, 0, a))
+  RUN("ablation: stream + always-hit gathers", Bs, 4, 0, hipLaunchKernelGGL((abl_kernel<1, 6>), g, b, 0, 0, a))
+  RUN("ablation 2: stream + hit gathers + row loads + 3 stores", B12, 4, 0, hipLaunchKernelGGL((abl_kernel<2, 6>), g, b, 0, 0, a))
+  RUN("ablation 3: ... row loads only", B12, 4, 0, hipLaunchKernelGGL((abl_kernel<3, 6>), g, b, 0, 0, a))
+  RUN("ablation 4: ... stores only", B12, 4, 0, hipLaunchKernelGGL((abl_kernel<4, 6>), g, b, 0, 0, a))
+  RUN("ablation 5: ... loads + nt stores (x, r)", B12, 4, 0, hipLaunchKernelGGL((abl_kernel<5, 6>), g, b, 0, 0, a))
+  RUN("ablation 6: ... nt loads + nt stores", B12, 4, 0, hipLaunchKernelGGL((abl_kernel<6, 6>), g, b, 0, 0, a))
+  RUN("ablation 7: ... loads + ONE store", B12, 4, 0, hipLaunchKernelGGL((abl_kernel<7, 6>), g, b, 0, 0, a))
+  have_ref = true;
+#define RUNM(NBV, UNV, WPB, REMAP)                                                                                     \
+  { a.xcd_remap = REMAP; const int64_t nw = (nsl + (NBV) - 1) / (NBV); const dim3 g((unsigned)((nw + (WPB) - 1) / (WPB))), b(64 * (WPB)); \
+    CK(hipMemset(r2, 0, nrows * 8));                                                                                   \
+    float t = time_it([&] { hipLaunchKernelGGL((sell_multi_kernel<NBV, UNV>), g, b, 0, 0, a); }, reps); CK(hipGetLastError()); \
+    printf("  sell_multi<NB=%d,UN=%d>                                     wpb %d remap %d : %8.1f us  %6.0f GB/s  frac %.3f\n", NBV, UNV, WPB, REMAP, t * 1e3, B12 / t / 1e6, B12 / t / 1e6 / 8000.0); \
+    check("sell_multi"); }
+  RUNM(1, 6, 4, 0) RUNM(2, 6, 4, 0) RUNM(4, 6, 4, 0) RUNM(8, 6, 4, 0) RUNM(16, 6, 4, 0)
+  RUNM(2, 9, 4, 0) RUNM(4, 9, 4, 0) RUNM(4, 6, 4, 1) RUNM(4, 6, 2, 0) RUNM(4, 6, 1, 0) RUNM(8, 6, 1, 0)
+  RUN("sell_kernel<UN=6,NT=1>", B12, 4, 0, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, 1>), g, b, 0, 0, a))
+  RUN("sell_kernel<UN=6,NT=2> (nt row operands + stores)", B12, 4, 0, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, 2>), g, b, 0, 0, a))
+  RUN("sell_kernel<UN=6,NT=2> (nt row operands + stores)", B12, 4, 1, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, 2>), g, b, 0, 0, a))
+  // ---- XCD chunk size (blocks of 256 rows per XCD inside a window of 8 chunks) ----
+  have_ref = true;
+  for (int C : {0, 256, 1}) {
+    char nm[96]; snprintf(nm, sizeof nm, "sell_kernel<UN=6>, XCD chunk %d blocks", C);
+    RUN(nm, B12, 4, C, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, true>), g, b, 0, 0, a))
+  }
+  for (int C : {0, 1}) {
+    char nm[96]; snprintf(nm, sizeof nm, "sell_pipe<UN=9,PD=1>, XCD chunk %d blocks", C);
+    RUN(nm, B12, 4, C, hipLaunchKernelGGL((sell_pipe_kernel<EPI_SWEEP, true, 9, 1, true>), g, b, 0, 0, a))
+  }
+  for (int C : {0, 1}) {
+    char nm[96]; snprintf(nm, sizeof nm, "sello_kernel<UN=9>, XCD chunk %d blocks", C);
+    RUN(nm, B8, 4, C, hipLaunchKernelGGL((sello_kernel<EPI_SWEEP, true, 9, true>), g, b, lds, 0, o))
+  }
   return 0;
 }

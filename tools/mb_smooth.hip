@@ -87,7 +87,10 @@ int main(int argc, char **argv)
     uint32_t e = 0; CK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));                                            \
     printf("%-58s %8.2f us per launch  %6.2f us per sweep%s\n", label, ms * 1e3, ms * 1e3 / niter, e ? "  (TIMEOUT FLAG SET)" : ""); \
   } while (0)
-  RUN(0, "product kernel");
+  RUN(0, "product kernel (relaxed progress words)");
+  a.fenced = 1;
+  RUN(0, "product kernel, release / acquire progress words");
+  a.fenced = 0;
   RUN(1, "- neighbour waits");
   RUN(1 | 16, "- waits - store drain / flag publish");
   RUN(2, "plain gather loads (stale L1 allowed)");
