@@ -88,6 +88,7 @@ SYMBOLS = {
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
     "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],
     "gmg_model_bytes": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "gmg_sweep_signature": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "gmg_level_format": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                          C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gmg_device_bytes": [C.c_void_p, C.POINTER(C.c_int64)],

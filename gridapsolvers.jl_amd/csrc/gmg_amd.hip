@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -257,6 +258,17 @@ struct DevCSR {
   uint16_t *orowpid = nullptr;
   int32_t *orowbase = nullptr, *opoff = nullptr;
   int opat_np = 0, opat_w = 0;
+  // kernel + template arguments of the fused sweep last launched on this operator (x-update variant excluded): bench.py only
+  // attaches committed PMC traffic to a kernel whose signature matches the profiled one (gmg_sweep_signature)
+  mutable char sweep_sig[112] = {0};
+  void note_sweep(const char *fmt, ...) const __attribute__((format(printf, 2, 3)))
+  {
+    if (sweep_sig[0]) return;
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(sweep_sig, sizeof(sweep_sig), fmt, ap);
+    va_end(ap);
+  }
   bool present() const { return rowptr != nullptr; }
 };
 
@@ -527,9 +539,10 @@ struct gmg_solver {
   int gj_mfma = 1;      // GMG_GJ_MFMA: trailing update of the device coarse inversion on the FP64 matrix cores
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
-  int persist_fenced = 1; // GMG_PERSIST_FENCED: progress words published with release / polled with acquire semantics (agent scope)
+  int persist_fenced = 0; // GMG_PERSIST_FENCED: progress words published with release / polled with acquire semantics (agent scope)
   int persist_max_slices = 0;  // GMG_PERSIST_MAX_SLICES (0: what one workgroup per CU holds)
   int n_cus = 0;
+  uint32_t *d_perr_dev = nullptr;                  // device-memory twin (the kernel's end-of-pass check)
   uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
   int pat_dinv = 1;     // GMG_PAT_DINV: Jacobi inverse diagonal from the pattern table instead of its vector
@@ -606,6 +619,7 @@ struct gmg_solver {
   {
     for (void *p : allocs) (void)hipFree(p);
     allocs.clear();
+    d_perr_dev = nullptr;
     dev_bytes = 0;
     for (auto &L : lev) {
       L.A = DevCSR(); L.P = DevCSR(); L.R = DevCSR(); L.G = DevCSR();
@@ -1221,12 +1235,14 @@ struct gmg_solver {
           else hipLaunchKernelGGL((sells_sweep_kernel<XMV, NBV, false, false>), g2, b, lds2, stream, a);         \
         }                                                                                                        \
       } while (0)
+      M.note_sweep("sells_sweep_kernel<XM=*,NB=%d,TD=%d,MK=%d> wgs=%d wpb=%d", nb >= 2 ? 2 : 1, td ? 1 : 0, mk ? 1 : 0, wg2, wpb);
       if (nb >= 2) { if (a.xmode == 0) GMG_SWEEP_LAUNCH(0, 2); else if (a.xmode == 1) GMG_SWEEP_LAUNCH(1, 2); else GMG_SWEEP_LAUNCH(2, 2); }
       else { if (a.xmode == 0) GMG_SWEEP_LAUNCH(0, 1); else if (a.xmode == 1) GMG_SWEEP_LAUNCH(1, 1); else GMG_SWEEP_LAUNCH(2, 1); }
 #undef GMG_SWEEP_LAUNCH
       HIP_CHECK(hipGetLastError());
       return;
     }
+    if (EPI == EPI_SWEEP) M.note_sweep("sells_kernel<EPI_SWEEP,%s,RB=%d,K=%d,VD=%d> wgs=%d wpb=%d", ONEG ? "ONEG" : "2G", M.pat_coded ? M.pat_k : pat_rb, M.pat_k, M.pat_coded ? 1 : 0, nwg, wpb);
     if (M.pat_coded && M.pat_k == 5) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true>), g, b, lds, stream, a);
     else if (M.pat_coded) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3, 3, true>), g, b, lds, stream, a);
     else if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), g, b, lds, stream, a);
@@ -1480,6 +1496,7 @@ struct gmg_solver {
           else if (a2.xmode == 2) hipLaunchKernelGGL((sello_kernel<EPI_SWEEP, true, 9, NTV, 2>), g, b, lds, stream, a);               \
           else hipLaunchKernelGGL((sello_kernel<EPI_SWEEP, true, 9, NTV, 0>), g, b, lds, stream, a);                                  \
         } while (0)
+        M.note_sweep("sello_kernel<EPI_SWEEP,ONEG,UN=9,NT=%d,XM=*> wpb=%d remap=%d", (huge && nt && nt_rowwise) ? 2 : (nt ? 1 : 0), wpb, a.xcd_remap);
         if (huge && nt && nt_rowwise) GMG_SELLO_SWEEP(2);
         else if (nt) GMG_SELLO_SWEEP(1);
         else GMG_SELLO_SWEEP(0);
@@ -1494,6 +1511,7 @@ struct gmg_solver {
       if (nt) hipLaunchKernelGGL((sello_kernel<EPI, ONEG, UNV, 1>), g, b, lds, stream, a);               \
       else hipLaunchKernelGGL((sello_kernel<EPI, ONEG, UNV, 0>), g, b, lds, stream, a);                  \
     } while (0)
+    if (EPI == EPI_SWEEP) M.note_sweep("sello_kernel<EPI_SWEEP,%s,UN=%d,NT=%d,XM=0> wpb=%d remap=%d", ONEG ? "ONEG" : "2G", sell_un >= 27 ? 27 : sell_un >= 9 ? 9 : 3, nt ? 1 : 0, wpb, a.xcd_remap);
     if (sell_un >= 27) GMG_SELLO_LAUNCH(27);
     else if (sell_un >= 9) GMG_SELLO_LAUNCH(9);
     else GMG_SELLO_LAUNCH(3);
@@ -1528,6 +1546,7 @@ struct gmg_solver {
           else if (a2.xmode == 2) hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, NTV, 2>), g, b, 0, stream, a);                  \
           else hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, NTV, 0>), g, b, 0, stream, a);                                     \
         } while (0)
+        M.note_sweep("sell_kernel<EPI_SWEEP,ONEG,UN=6,NT=%d,XM=*> wpb=%d remap=%d", (huge && nt && nt_rowwise) ? 2 : (nt ? 1 : 0), wpb, a.xcd_remap);
         if (huge && nt && nt_rowwise) GMG_SELL_SWEEP(2);
         else if (nt) GMG_SELL_SWEEP(1);
         else GMG_SELL_SWEEP(0);
@@ -1542,6 +1561,7 @@ struct gmg_solver {
       if (nt) hipLaunchKernelGGL((sell_kernel<EPI, ONEG, UNV, 1>), g, b, 0, stream, a);                  \
       else hipLaunchKernelGGL((sell_kernel<EPI, ONEG, UNV, 0>), g, b, 0, stream, a);                     \
     } while (0)
+    if (EPI == EPI_SWEEP) M.note_sweep("sell_kernel<EPI_SWEEP,%s,UN=%d,NT=%d,XM=0> wpb=%d remap=%d", ONEG ? "ONEG" : "2G", sell_un, nt ? 1 : 0, wpb, a.xcd_remap);
     if (sell_un >= 27) GMG_SELL_LAUNCH(27);
     else if (sell_un >= 9) GMG_SELL_LAUNCH(9);
     else if (sell_un >= 6) GMG_SELL_LAUNCH(6);
@@ -1917,6 +1937,10 @@ struct gmg_solver {
       *h_perr = 0;
       HIP_CHECK(hipHostGetDevicePointer((void **)&d_perr, h_perr, 0));
     }
+    if (!d_perr_dev) {                                       // (released with the other device arrays by free_all)
+      d_perr_dev = dalloc<uint32_t>(16);
+      HIP_CHECK(hipMemsetAsync(d_perr_dev, 0, 64, stream));
+    }
     SellSmoothArgs a;
     std::memset(&a, 0, sizeof(a));
     a.rowpid = M.rowpid; a.tab = M.ptab; a.tab8 = M.ptab8; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
@@ -1924,7 +1948,7 @@ struct gmg_solver {
     a.pdinv = pat_dinv ? M.pdinv : nullptr; a.dinv = L.dinv; a.omega = S.omega;
     a.niter = niter; a.x_zero = x_zero ? 1 : 0;
     a.r_in = r_in; a.r_out = r_out; a.x = x; a.s_a = L.sbuf[0]; a.s_b = L.sbuf[1];
-    a.flags = L.pflags; a.epoch = L.pf_epoch; a.err = d_perr; a.halo_wg = halo; a.fenced = persist_fenced;
+    a.flags = L.pflags; a.epoch = L.pf_epoch; a.err = d_perr; a.err_dev = d_perr_dev; a.halo_wg = halo; a.fenced = persist_fenced;
     L.pf_epoch += (uint32_t)niter;
     const dim3 g(nwg), b(64 * wpb);
     const bool td = a.pdinv != nullptr;
@@ -2273,7 +2297,11 @@ struct gmg_solver {
     // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
     // could keep each other from becoming fully resident, so they are off unless asked for
     if (comm.kind == COMM_HOST && !env_int("GMG_PERSIST_SHARED", 0)) persist = 0;
-    persist_fenced = env_int("GMG_PERSIST_FENCED", 1);
+    // release / acquire on the progress words costs 2.4 us per sweep (43 -> 68 us per pass of 10 on 63^3 rows, profiles/r03_mb_smooth.txt)
+    // and adds nothing the explicit ordering does not already give: every datum that crosses workgroups moves with agent-scope
+    // (sc1) atomics, the publishing lane stores the word after the workgroup's s_waitcnt vmcnt(0) + barrier, the polling lanes read
+    // it with agent-scope loads and a barrier precedes the gathers.  Off by default, kept as a switch.
+    persist_fenced = env_int("GMG_PERSIST_FENCED", 0);
     pat_strict = env_int("GMG_PAT_STRICT", 1);
     gj_mfma = env_int("GMG_GJ_MFMA", 1);
     persist_max_slices = env_int("GMG_PERSIST_MAX_SLICES", 0);
@@ -4402,6 +4430,16 @@ int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes)
     BV += 8.0 * NL * NL + 16.0 * NL;
     if (vcycle_bytes) *vcycle_bytes = BV;
     if (cg_iter_bytes) *cg_iter_bytes = BV + 12.0 * (double)h->lev[0].A.nnz + 132.0 * (double)h->lev[0].n;
+  });
+}
+
+int gmg_sweep_signature(gmg_handle_t h, int lev, char *buf, int cap)
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    check_level(h, lev, false);
+    REQUIRE(buf && cap > 0, GMG_ERR_INVALID, "null buffer");
+    std::snprintf(buf, (size_t)cap, "%s", h->lev[lev].A.sweep_sig);
   });
 }
 

@@ -1419,6 +1419,7 @@ struct SellSmoothArgs {
   uint32_t *err;            // host-visible: set when a wait timed out
   int halo_wg;              // workgroup w waits for w-halo_wg .. w+halo_wg
   int fenced;               // progress words: release store / acquire after the poll (agent scope) on top of the explicit store drain
+  uint32_t *err_dev;        // device-memory twin of *err (read at the end of the pass: a host-mapped word would cost a PCIe round trip)
 };
 
 __device__ __forceinline__ double ld_agent(const double *p)
@@ -1483,7 +1484,11 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
         const uint32_t want = a.epoch + (uint32_t)k;
         unsigned spins = 0;
         while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-          if (++spins > (1u << 22)) { __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+          if (++spins > (1u << 22)) {
+            __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (a.err_dev) __hip_atomic_store(a.err_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
         }
         if (a.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // pairs with the neighbours' release below
@@ -1546,7 +1551,7 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
   }
   // a wait timed out somewhere (as far as this workgroup can see): the pass is void -- leave x and r as they were, the host
   // re-runs the solve sweep by sweep (with_persist_retry)
-  if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+  if (a.err_dev && __hip_atomic_load(a.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     if (own[i]) { a.x[row[i]] = xr[i]; a.r_out[row[i]] = r[i]; }

@@ -270,6 +270,63 @@ class DistributedGMG:
             pass
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# Communication model of a partitioned V-cycle: which levels to replicate, how many ghost layers the others carry
+# ---------------------------------------------------------------------------------------------------------------------------
+# Measured on MI355X (profiles/r03_rccl_latency.json, tools/rccl_latency.py; RCCL 2.26 self send/recv, 7 messages): one halo
+# exchange costs 28-42 us of stream time issued in-stream and 51-63 us with the event hand-off to a second stream; the host needs
+# 23-36 us to enqueue it.  A 1-double all-reduce + sqrt: 5-6 us on one rank.  Sweep kernels: 11.3 ns per 1000 rows (row-pattern
+# layout, profiles/r02b_kernel_stats.txt) with a floor of 4.4 us + 1.5 us of dependent-launch gap per launch; a whole block of k
+# sweeps as ONE launch (<= 5.08e5 rows: sells_smooth_kernel): 2.8 us + 6.0e-6 us per row per sweep (profiles/r02_tuning.md section 6).
+MODEL = dict(exchange_us=40.0, exchange_overlapped_us=60.0, link_GBs=50.0, sweep_ns_per_krow=11.3, launch_floor_us=5.9,
+             one_launch_rows=507904, one_launch_base_us=2.8, one_launch_us_per_row=6.0e-6, allreduce_us=30.0, allreduce_GBs=50.0)
+
+
+def _pass_us(n_own_cells, depth, niter, m=MODEL):
+    """modelled time of one smoothing pass of `niter` sweeps on a level with n_own_cells^3 owned cells per rank and `depth` ghost
+    layers (0 = own | ghost layout with the exchange overlapped with the own x own kernel)"""
+    c = n_own_cells
+    if depth == 0:
+        t_sweep = max(m["launch_floor_us"], c ** 3 * m["sweep_ns_per_krow"] * 1e-6)
+        return niter * (max(t_sweep, m["exchange_overlapped_us"]) + 3.0)           # + boundary fix-up launch
+    rows = (c + 2 * depth) ** 3
+    nblk = -(-niter // depth)
+    msg_us = depth * c * c * 8.0 / (m["link_GBs"] * 1e3)                            # one face, `depth` layers
+    if rows <= m["one_launch_rows"]:
+        t_sweeps = nblk * m["one_launch_base_us"] + niter * (m["one_launch_base_us"] + rows * m["one_launch_us_per_row"])
+    else:
+        t_sweeps = niter * max(m["launch_floor_us"], rows * m["sweep_ns_per_krow"] * 1e-6)
+    return t_sweeps + nblk * (m["exchange_us"] + msg_us + 4.0)                      # + scaled-Jacobi launch per block
+
+
+def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, depth_choices=(0, 1, 2, 3, 5, 10)):
+    """(rep_from, depths, table): replicate every level whose GLOBAL size is <= rep_rows dofs (latency-bound: redundant compute beats
+    any exchange); give every other level >= 1 the halo depth that minimises the modelled smoothing-pass time.  The finest level
+    keeps the own | ghost layout (its own x own kernel hides the exchange)."""
+    grid = pa.rank_grid(world, 3)
+    rep_from = nlevels - 1
+    for l in range(1, nlevels):
+        if po.level_sizes(tuple(cells_per_rank * g // 2 ** l for g in grid), 1) <= rep_rows:
+            rep_from = l
+            break
+    depths, table = [0] * nlevels, []
+    for l in range(nlevels):
+        c = cells_per_rank // 2 ** l
+        if l >= rep_from or world == 1:
+            table.append(dict(level=l, cells_per_rank=c, layout="replicated" if world > 1 else "single GPU"))
+            continue
+        cand = {k: _pass_us(c, k, niter) for k in depth_choices if k == 0 or (l >= 1 and k <= niter and c >= 2)}
+        best = 0 if l == 0 else min(cand, key=cand.get)
+        depths[l] = best
+        table.append(dict(level=l, cells_per_rank=c, layout="own|ghost, exchange overlapped" if best == 0 else f"overlapping, depth {best}",
+                          modelled_pass_us={str(k): round(v, 1) for k, v in cand.items()},
+                          exchanges_per_pass=niter if best == 0 else -(-niter // best)))
+    env = os.environ.get("GMG_HALO_DEPTH")
+    if env is not None:
+        depths = [0] + [int(env) if l < rep_from else 0 for l in range(1, nlevels)]
+    return rep_from, depths, table
+
+
 def run_bench(args, rank, world, local_rank):
     """bench.py --gpus N (N > 1): weak scaling, `cells` cells per direction per GPU."""
     import torch
@@ -284,12 +341,7 @@ def run_bench(args, rank, world, local_rank):
     # replicate every level whose GLOBAL size is small (<= 4e5 dofs: at config 4 that is the 72^3 level, 3.6e5 dofs):
     # those levels are latency bound -- a sweep takes 5-7 us, a grouped RCCL send/recv tens of us -- so computing them
     # redundantly on every GPU is cheaper than a halo exchange per sweep
-    grid3 = pa.rank_grid(world, 3)
-    rep_from = nlev - 1
-    for l in range(1, nlev):
-        if po.level_sizes(tuple(args.cells * g // 2 ** l for g in grid3), 1) <= 400000:
-            rep_from = l
-            break
+    rep_from, depths, plan_table = plan_partition(args.cells, nlev, world)
     rdev0 = "cpu" if dist.get_backend() == "gloo" else "cuda"
 
     def all_ok(ok):
@@ -316,7 +368,7 @@ def run_bench(args, rank, world, local_rank):
             transport = "host"
     if transport != "host":
         try:
-            g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from)
+            g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from, depth=depths)
         except Exception as e:
             err = e
         if not all_ok(g is not None):
@@ -334,7 +386,7 @@ def run_bench(args, rank, world, local_rank):
             transport = "host"
     if transport == "host":
         group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
-        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths, rep_from=rep_from)
+        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths, rep_from=rep_from, depth=depths)
     b = g.rhs_lin()
     bd = torch.from_numpy(b).cuda()
     xd = torch.zeros(g.n_own, dtype=torch.float64, device="cuda")
@@ -358,62 +410,118 @@ def run_bench(args, rank, world, local_rank):
             print("[bench] overlapped halo exchange gave a wrong solution; retrying with GMG_OVERLAP=0", flush=True, file=sys.stderr)
         os.environ["GMG_OVERLAP"] = "0"
         g.close()
-        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from)
+        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from, depth=depths)
         overlap_note = "in-stream halo exchange (overlap disabled after a failed self-check)"
         degraded = True
         if not sane():
             raise RuntimeError("distributed solve does not reproduce the analytic solution")
 
-    def step():
-        xd.zero_()
-        torch.cuda.synchronize()
-        return g.cg_solve(bd, xd, maxiter, atol, rtol)
-
-    for _ in range(args.warmup):
-        log = step()
-    g.profile(0, True)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        log = step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    st = g.kernel_stats()
     rdev = "cpu" if dist.get_backend() == "gloo" else "cuda"
-    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    err = torch.tensor([float(np.max(np.abs(xd.cpu().numpy() - g.exact_own())))], dtype=torch.float64, device=rdev)
-    dist.all_reduce(err, op=dist.ReduceOp.MAX)
-    avg_ms = st["total_ms"] / max(st["launches"], 1)
+
+    def timed(gh, steps, warmup):
+        """`steps` timed solves of handle gh (barrier + synchronize on both sides, max over ranks)"""
+        def step():
+            xd.zero_()
+            torch.cuda.synchronize()
+            return gh.cg_solve(bd, xd, maxiter, atol, rtol)
+        for _ in range(warmup):
+            lg = step()
+        gh.profile(0, True)
+        ex0, ar0 = gh.comm_stats()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lg = step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        ex1, ar1 = gh.comm_stats()
+        st = gh.kernel_stats()
+        gh.profile(0, False)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        e = torch.tensor([float(np.max(np.abs(xd.cpu().numpy() - gh.exact_own())))], dtype=torch.float64, device=rdev)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        avg_ms = st["total_ms"] / max(st["launches"], 1)
+        return dict(dt=float(tmax.item()), steps=steps, iters=int(lg.num_iters), err=float(e.item()), st=st, avg_ms=avg_ms,
+                    exchanges_per_solve=(ex1 - ex0) / steps, allreduces_per_solve=(ar1 - ar0) / steps)
+
+    n = g.n_global
+    D = timed(g, args.steps, args.warmup)
+    st, avg_ms = D["st"], D["avg_ms"]
     achieved = st["alg_bytes"] / (avg_ms * 1e-3) / 1e9 if st["launches"] else None
     layout_GBs = st["layout_bytes"] / (avg_ms * 1e-3) / 1e9 if st["launches"] else None
-    n = g.n_global
-    return {
+    setup_s, asm_s, rep_lvl = g.t_setup, g.t_assembly, int(g.local["rep_from"])
+    grid_s, cg_s = "x".join(map(str, g.grid)), "x".join(map(str, g.cells_global))
+    out = {
         "metric": "DoFs/sec, CG+GMG V-cycle on 3D Poisson Q1",
-        "value": n * args.steps / dt, "unit": "DoFs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "value": n * D["steps"] / D["dt"], "unit": "DoFs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": D["dt"] / D["steps"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "headline_leg": "default",
+        "legs": "default (`value`, `roofline`): storage layout chosen by gmg_setup (row patterns on this constant-coefficient operator); "
+                "generic (`value_generic`, `roofline_generic`): the same partitioned problem with the 12 B/nnz stream SURVEY 8(d) models.  "
+                "The single-GPU figure to hold these against is `weak_scaling_ref` of the N = 1 line (the same per-GPU problem on one GPU).",
         "config": {
-            "workload": f"3D Poisson Q1, {args.cells}^3 cells per GPU on a {'x'.join(map(str, g.grid))} GPU grid "
-                        f"(global {'x'.join(map(str, g.cells_global))} cells on (0,{'x'.join(str(int(v)) for v in lengths)}): cubic cells), {nlev}-level GMG V-cycle, "
+            "workload": f"3D Poisson Q1, {args.cells}^3 cells per GPU on a {grid_s} GPU grid "
+                        f"(global {cg_s} cells on (0,{'x'.join(str(int(v)) for v in lengths)}): cubic cells), {nlev}-level GMG V-cycle, "
                         f"Richardson(Jacobi,10,2/3), CG rtol={rtol:g}, rhs = u=x1+x2 Dirichlet lift; row partition + "
                         f"halo exchange + scalar all-reduce ({transport}; {overlap_note})",
-            "dofs": n, "dofs_per_gpu": g.n_own, "levels": nlev, "cg_iterations": int(log.num_iters),
-            "transport": transport, "degraded": bool(degraded), "replicated_from_level": int(g.local["rep_from"]), "max_abs_error_vs_exact": float(err.item()),
-            "setup_s": g.t_setup, "assembly_s": g.t_assembly,
+            "dofs": n, "dofs_per_gpu": g.n_own, "levels": nlev, "cg_iterations": D["iters"],
+            "transport": transport, "degraded": bool(degraded), "replicated_from_level": rep_lvl, "max_abs_error_vs_exact": D["err"],
+            "halo_depths": depths, "partition_plan": plan_table, "communication_model": MODEL,
+            "halo_exchanges_per_solve": D["exchanges_per_solve"], "allreduces_per_solve": D["allreduces_per_solve"],
+            "setup_s": setup_s, "assembly_s": asm_s,
         },
         # the local operators are constant-coefficient here, so the own x own kernel runs the row-pattern layout: its honest
-        # figure is bytes-actually-moved / time (layout_bytes), not the 12 B/nnz model (which gives > 1; see bench.py N=1 `roofline`)
-        "roofline": {"bound": "hbm", "kernel": "fused Richardson-Jacobi sweep, own x own part (rank 0, finest level)",
+        # figure is bytes-actually-moved / time (layout_bytes), not the 12 B/nnz model (which gives > 1; see `roofline_generic`)
+        "roofline": {"leg": "default", "leg_value": n * D["steps"] / D["dt"], "leg_ms_per_step": D["dt"] / D["steps"] * 1e3,
+                     "bound": "hbm", "kernel": "fused Richardson-Jacobi sweep, own x own part (rank 0, finest level)",
                      "achieved": layout_GBs, "peak": 8000.0, "unit": "GB/s",
                      "frac": (layout_GBs / 8000.0) if layout_GBs else None, "traffic": None,
                      "bytes_model": "gmg_kernel_stats.layout_bytes (matrix stream as stored + row-wise vectors, each once)",
                      "bytes_per_launch": st["layout_bytes"], "model_12B_per_nnz_GBs": achieved,
                      "avg_launch_ms": avg_ms, "launches_timed": st["launches"]},
     }
+    # ---- generic leg: the same partitioned problem on the plain 12 B/nnz stream (what SURVEY 8(d)'s byte model describes) ----
+    if not getattr(args, "no_generic", False):
+        g.close()
+        saved = {k: os.environ.get(k) for k in GENERIC_ENV}
+        os.environ.update(GENERIC_ENV)
+        gg = None
+        try:
+            gg = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport=transport, group=group, lengths=lengths, rep_from=rep_from, depth=depths)
+        except Exception as e:
+            err = e
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        if all_ok(gg is not None):
+            G = timed(gg, max(2, args.steps // 3), 1)
+            stg = G["st"]
+            ach = stg["alg_bytes"] / (G["avg_ms"] * 1e-3) / 1e9 if stg["launches"] else None
+            out["value_generic"] = n * G["steps"] / G["dt"]
+            out["ms_per_step_generic"] = G["dt"] / G["steps"] * 1e3
+            out["config"]["cg_iterations_generic"] = G["iters"]
+            out["roofline_generic"] = {"leg": "generic", "leg_value": out["value_generic"], "leg_ms_per_step": out["ms_per_step_generic"],
+                                       "bound": "hbm", "kernel": "sell_kernel<EPI_SWEEP,ONEG> own x own part (rank 0, finest level), 12 B/nnz (col,val) stream",
+                                       "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": (ach / 8000.0) if ach else None, "traffic": None,
+                                       "bytes_model": "SURVEY 8(d): B_sweep = 12 Z + 68 N on this rank's rows", "bytes_per_launch": stg["alg_bytes"],
+                                       "avg_launch_ms": G["avg_ms"], "launches_timed": stg["launches"]}
+            gg.close()
+        else:
+            if gg is not None:
+                gg.close()
+            out["roofline_generic"] = {"error": f"generic leg could not be set up on every rank ({err})"}
+    else:
+        g.close()
+    return out
+
+
+GENERIC_ENV = {"GMG_VDICT": "0", "GMG_IDX16": "0", "GMG_PATTERN": "0", "GMG_OPATTERN": "0"}
 
 
 class DistributedBlockSolver:

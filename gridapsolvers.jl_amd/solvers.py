@@ -564,6 +564,11 @@ class GMGNumericalSetup:
         return dict(layout=("CSR-stream", "SELL-64", "SELL-P", "SELL-O")[a.value], row_patterns=(a.value == 2),
                     value_dictionary=bool(b.value), idx16=bool(c.value), stream_bytes_per_nnz=d.value, padding=e.value)
 
+    def sweep_signature(self, lev=0):
+        buf = C.create_string_buffer(128)
+        abi.check(self.h, self._lib.gmg_sweep_signature(self.h, lev, buf, 128))
+        return buf.value.decode()
+
     def device_bytes(self):
         v = C.c_int64(0)
         abi.check(self.h, self._lib.gmg_device_bytes(self.h, C.byref(v)))

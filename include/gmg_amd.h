@@ -317,6 +317,9 @@ GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_ite
 /* Storage chosen for A_lev at setup: *sell = 0 CSR-stream, 1 SELL-64 / SELL-C, 2 SELL-P (row-pattern
  * dictionary), 3 SELL-O (SELL-64 value stream, column offsets from an offset-pattern table); 8-bit value dictionary, 16-bit column offsets, bytes of matrix stream per stored nonzero,
  * padding factor. */
+/* Kernel + template arguments + launch geometry of the fused sweep last launched on level lev ("" before the first sweep):
+ * committed counter measurements (profiles/traffic_latest.json) are only attached to a bench line whose sweep has this signature. */
+GMG_API int gmg_sweep_signature(gmg_handle_t h, int lev, char *buf, int cap);
 GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
                              double *stream_bytes_per_nnz, double *padding);
 /* Measured streaming ceiling: a 16 B/lane copy kernel over nbytes (read) + nbytes (write), reps launches timed with HIP

@@ -331,6 +331,7 @@ def main():
         xg = np.zeros_like(xo)
         for gidq, xq, _, _ in parts:
             xg[gidq] = xq
+        np.save(out + ".x.npy", xg)
         verdict.update(iters=int(nit), iters_oracle=int(nit_o), iters_all_equal=all(p[2] == nit for p in parts),
                        rel_err=float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)),
                        hist_dev=float(np.max(np.abs(np.array(hist) - hist_o) / hist_o)) if len(hist) == len(hist_o) else 1.0,

@@ -39,7 +39,10 @@ def _launch(mode, world, cells, nlev, tmp_path, transport="host", timeout=600, r
             if p.poll() is None:
                 p.kill()
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    return json.load(open(out))
+    v = json.load(open(out))
+    if os.path.exists(out + ".x.npy"):
+        v["x"] = np.load(out + ".x.npy")                     # gathered solution (global numbering)
+    return v
 
 
 def _check(v):
@@ -208,9 +211,10 @@ def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_p
 @pytest.mark.parametrize("world,cells,nlev,rep", [(2, (16, 16, 16), 4, 3), (8, (8, 8, 8), 3, 2), (4, (32, 32), 4, 3)])
 def test_overlapping_layout_on_gpu_host_transport(world, cells, nlev, rep, tmp_path):
     """The real library with levels >= 1 in the overlapping layout (several ranks on one GPU, host transport): iteration counts
-    and histories of the serial oracle; halo exchanges per solve drop by the expected amount; and because owned rows are summed
-    in the single-GPU order whatever the depth, solutions computed with different depths are IDENTICAL bit for bit -- with
-    the sweeps of a block run as one launch (sells_smooth_kernel between two exchanges) or launch by launch."""
+    and histories of the serial oracle; halo exchanges per solve drop by the expected amount; the sweeps of a block run as one
+    launch (sells_smooth_kernel between two exchanges) or launch by launch give IDENTICAL bits; different depths agree to rounding
+    (owned rows of the level operators are summed in the same order whatever the depth, but the restriction's layout -- and with
+    it the summation tree of the CSR-stream kernel -- depends on how many empty ghost rows it carries)."""
     env = {"GMG_PERSIST_SHARED": "1"}
     v0 = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep)
     vs = {d: _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env=dict(env, GMG_TEST_DEPTH=str(d))) for d in (1, 2, 5)}
@@ -219,7 +223,10 @@ def test_overlapping_layout_on_gpu_host_transport(world, cells, nlev, rep, tmp_p
     for v in list(vs.values()) + [vl]:
         _check(v)
         assert v["iters"] == v0["iters"]
-    assert vs[1]["x_sha"] == vs[2]["x_sha"] == vs[5]["x_sha"] == vl["x_sha"]
+    assert np.array_equal(vs[5]["x"], vl["x"])
+    for d in (1, 2):
+        assert np.linalg.norm(vs[d]["x"] - vs[5]["x"]) <= 1e-13 * np.linalg.norm(vs[5]["x"])
+    assert np.linalg.norm(vs[5]["x"] - v0["x"]) <= 1e-12 * np.linalg.norm(v0["x"])
     nov = rep - 1
     assert vs[1]["exchanges"] == v0["exchanges"]                    # depth 1: the same count, whole rows in one kernel
     for d in (2, 5):

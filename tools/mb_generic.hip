@@ -285,6 +285,11 @@ int main(int argc, char **argv)
     check("sell_multi"); }
   RUNM(1, 6, 4, 0) RUNM(2, 6, 4, 0) RUNM(4, 6, 4, 0) RUNM(8, 6, 4, 0) RUNM(16, 6, 4, 0)
   RUNM(2, 9, 4, 0) RUNM(4, 9, 4, 0) RUNM(4, 6, 4, 1) RUNM(4, 6, 2, 0) RUNM(4, 6, 1, 0) RUNM(8, 6, 1, 0)
+  have_ref = false;   // (two-gather form: r ping-pong, different operands -- timing only)
+  RUN("sell_kernel<ONEG=false (gather r and 1/diag), UN=6, NT=1>", B12, 4, 0, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, false, 6, 1>), g, b, 0, 0, a))
+  RUN("sell_kernel<ONEG=false (gather r and 1/diag), UN=6, NT=2>", B12, 4, 0, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, false, 6, 2>), g, b, 0, 0, a))
+  have_ref = true;
+  RUN("sell_kernel<UN=6,NT=2,XM=1> (x untouched)", B12, 4, 0, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, 2, 1>), g, b, 0, 0, a))
   RUN("sell_kernel<UN=6,NT=1>", B12, 4, 0, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, 1>), g, b, 0, 0, a))
   RUN("sell_kernel<UN=6,NT=2> (nt row operands + stores)", B12, 4, 0, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, 2>), g, b, 0, 0, a))
   RUN("sell_kernel<UN=6,NT=2> (nt row operands + stores)", B12, 4, 1, hipLaunchKernelGGL((sell_kernel<EPI_SWEEP, true, 6, 2>), g, b, 0, 0, a))
