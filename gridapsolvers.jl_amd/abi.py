@@ -40,6 +40,7 @@ SYMBOLS = {
                        C.c_int, C.c_int, C.c_int],
     "gmg_set_operator_rows": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_int, C.c_int],
+    "gmg_set_operator_rows_repeat": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64],
     "gmg_update_values": [C.c_void_p, C.c_int, C.c_void_p],
     "gmg_set_prolongation": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int, C.c_int, C.c_int],

@@ -360,6 +360,11 @@ int gmg_block_destroy(gmg_block_handle_t h)
     if (P.h_recv) (void)hipHostFree(P.h_recv);
   }
   if (h->eng.comm.kind == COMM_RCCL && h->eng.comm.comm) (void)h->eng.comm.api.CommDestroy(h->eng.comm.comm);
+  if (h->eng.comm_stream) (void)hipStreamSynchronize(h->eng.comm_stream);   // created by gmg_block_comm_init_* on the engine
+  if (h->eng.ev_ready) (void)hipEventDestroy(h->eng.ev_ready);
+  if (h->eng.ev_done) (void)hipEventDestroy(h->eng.ev_done);
+  if (h->eng.comm_stream) (void)hipStreamDestroy(h->eng.comm_stream);
+  if (h->eng.h_rep_full) (void)hipHostFree(h->eng.h_rep_full);
   if (h->eng.h_scalars) (void)hipHostFree(h->eng.h_scalars);
   if (h->eng.own_stream) (void)hipStreamDestroy(h->eng.own_stream);
   delete h;

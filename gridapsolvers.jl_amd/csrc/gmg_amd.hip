@@ -819,7 +819,8 @@ struct gmg_solver {
       }
     return true;
   }
-  int pat_un_eff() const { return pat_un >= 27 ? 27 : pat_un >= 14 ? 14 : pat_un >= 9 ? 9 : pat_un >= 6 ? 6 : 3; }
+  static int pat_un_of(int u) { return u >= 27 ? 27 : u >= 14 ? 14 : u >= 9 ? 9 : u >= 6 ? 6 : 3; }
+  int pat_un_eff() const { return pat_un_of(pat_un); }
   bool build_pattern(const HostCSR &H, DevCSR &D)
   {
     // byte offsets into the gathered vector are 32-bit: ncols * 8 < 2^31
@@ -1028,7 +1029,7 @@ struct gmg_solver {
     } catch (const GmgError &) {
       return false;
     }
-    const int un = 9;                                        // table stride granularity of the default pattern kernel
+    const int un = pat_un_of(env_int("GMG_PAT_UN", 9));      // table stride granularity of the pattern kernel, as finish_stream will see it (read_tuning has not run yet)
     const int64_t W = (std::max<int64_t>(S->wmax, 1) + un - 1) / un * un;
     const bool generic = (int64_t)(S->len.size() + 1) * (12 * W + 4) <= 48 * 1024;
     if (!generic) return false;                              // wide / many patterns: let the general path pick the layout
@@ -1928,6 +1929,7 @@ struct gmg_solver {
     const int nwg = (nsl + wpb * ns - 1) / (wpb * ns);
     if (nwg > n_cus) return false;
     if (!L.pflags || L.pf_nwg < nwg) {
+      if (L.pflags) { HIP_CHECK(hipStreamSynchronize(stream)); release(L.pflags, (size_t)L.pf_nwg * 16); }
       L.pflags = dalloc<uint32_t>((size_t)nwg * 16);
       HIP_CHECK(hipMemsetAsync(L.pflags, 0, sizeof(uint32_t) * (size_t)nwg * 16, stream));
       L.pf_nwg = nwg; L.pf_epoch = 1;
@@ -3166,7 +3168,14 @@ double *gmg_solver::build_dense_inverse(const HostCSR &A, const std::string &wha
   if (n > env_int("GMG_COARSE_HOST_MAX", 1500)) {
     REQUIRE((double)n * n * 8.0 <= 64.0e9, GMG_ERR_UNSUPPORTED,
             what + " has " + std::to_string(n) + " dofs: its dense inverse would not fit; add multigrid levels");
-    return build_coarse_device(A, what);
+    // the device inversion does not pivot and verifies its result: a matrix that needs pivoting is rejected there -- within
+    // reach of the host's pivoted banded LU (seconds up to ~6000 dofs) take that instead of failing the setup
+    if (n > env_int("GMG_COARSE_HOST_FALLBACK_MAX", 6000)) return build_coarse_device(A, what);
+    try {
+      return build_coarse_device(A, what);
+    } catch (const GmgError &e) {
+      if (e.code != GMG_ERR_SINGULAR) throw;
+    }
   }
   BandLU lu;
   REQUIRE(lu.factor(A), GMG_ERR_SINGULAR, what + " is singular");
@@ -3261,6 +3270,17 @@ void gmg_solver::setup()
     std::fprintf(stderr, "[gmg_setup] level %d %-28s %8.1f ms\n", l, what, std::chrono::duration<double, std::milli>(now - t_last).count());
     t_last = now;
   };
+  // patch smoothers / patch corrections with patches of more than 64 dofs take their blocks from the level's CSR (one thread block
+  // per patch): a level kept in row-pattern form only gets its rows back
+  for (int l = 0; l < nlev - 1; ++l) {
+    Level &L = lev[l];
+    if (!(L.sA && L.sA->complete())) continue;
+    int64_t big = 0;
+    for (const Smoother *sp : {&L.pre, &L.post, &L.pcorr})
+      if (sp->kind == SM_PATCH && sp->tab && !sp->tab->has_blocks)
+        for (size_t q = 0; q + 1 < sp->tab->pptr.size(); ++q) big = std::max(big, sp->tab->pptr[q + 1] - sp->tab->pptr[q]);
+    if (big > 64) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
+  }
   if (comm.nranks > 1) {
     // operators handed over BEFORE the communicator was initialised may sit in the (single-GPU) row-pattern-only form: the
     // distributed setup splits own / ghost columns on the CSR, so give them their rows back
@@ -3718,14 +3738,79 @@ int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, 
   });
 }
 
+// Structured operators repeat themselves: on a uniform mesh all interior node planes of a level carry the same rows up to a
+// shift of the column indices.  After a block of rows has been handed over (gmg_set_operator_rows), this call appends `count`
+// further copies of the LAST `nrows_block` rows, copy k with every column index shifted by k * col_shift -- no arrays, no hashing
+// (the copies have the pattern ids of the block).  Level matrices keep their offsets relative to the row index, so there
+// col_shift must equal nrows_block.  BASELINE config 3 at 256^3: 511 planes of 2.6e5 rows x 125 entries each, 7 distinct ones.
+int gmg_set_operator_rows_repeat(gmg_handle_t h, int lev, int op, int64_t nrows_block, int64_t count, int64_t col_shift)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, op != GMG_OP_A);
+    REQUIRE(op == GMG_OP_A || op == GMG_OP_P || op == GMG_OP_R, GMG_ERR_INVALID, "unknown operator");
+    Level &L = h->lev[lev];
+    std::shared_ptr<PatStream> &S = op == GMG_OP_A ? L.sA : op == GMG_OP_P ? L.sP : L.sR;
+    bool &has = op == GMG_OP_A ? L.hasA : op == GMG_OP_P ? L.hasP : L.hasR;
+    REQUIRE(S && !S->complete(), GMG_ERR_STATE, "no row stream in progress (gmg_set_operator_rows first)");
+    PatStream &P = *S;
+    REQUIRE(nrows_block >= 1 && count >= 1 && nrows_block <= P.rows_seen, GMG_ERR_INVALID, "the repeated block must lie inside the rows already handed over");
+    REQUIRE(P.rows_seen + nrows_block * count <= P.nrows, GMG_ERR_INVALID, "repeated rows exceed the operator");
+    REQUIRE(P.mode == 1 || col_shift == nrows_block, GMG_ERR_INVALID, "level matrix: a repeated block shifts its columns by its own height");
+    const int64_t r0 = P.rows_seen - nrows_block;
+    // column range and nonzeros of the block (from the pattern table)
+    int64_t cmin = P.ncols, cmax = -1, bnnz = 0;
+    for (int64_t i = r0; i < P.rows_seen; ++i) {
+      const int32_t q = P.rowpid[(size_t)i];
+      const int32_t len = P.len[(size_t)q];
+      if (len == 0) continue;
+      const int64_t ref = P.mode == 0 ? i : (int64_t)P.rowbase[(size_t)i];
+      cmin = std::min(cmin, ref + P.off[(size_t)P.start[(size_t)q]]);
+      cmax = std::max(cmax, ref + P.off[(size_t)P.start[(size_t)q] + len - 1]);
+      bnnz += len;
+    }
+    if (cmax >= 0)
+      REQUIRE(cmin + std::min<int64_t>(col_shift, col_shift * count) >= 0 && cmax + std::max<int64_t>(col_shift, col_shift * count) < P.ncols,
+              GMG_ERR_INVALID, "repeated rows reach outside the column range");
+    const int64_t n_new = nrows_block * count;
+    P.rowpid.resize((size_t)(P.rows_seen + n_new));
+    if (P.mode == 1) P.rowbase.resize((size_t)(P.rows_seen + n_new));
+    parallel_for(n_new, [&](int64_t t) {
+      const int64_t k = t / nrows_block + 1, j = t % nrows_block;
+      P.rowpid[(size_t)(P.rows_seen + t)] = P.rowpid[(size_t)(r0 + j)];
+      if (P.mode == 1) P.rowbase[(size_t)(P.rows_seen + t)] = (int32_t)((int64_t)P.rowbase[(size_t)(r0 + j)] + k * col_shift);
+    });
+    P.nnz += bnnz * count;
+    P.rows_seen += n_new;
+    if (P.complete()) has = true;
+  });
+}
+
 int gmg_update_values(gmg_handle_t h, int lev, const double *val)
 {
   return guarded(h, [&] {
     check_level(h, lev, false);
     Level &L = h->lev[lev];
     REQUIRE(L.hasA, GMG_ERR_STATE, "no matrix set on this level");
-    REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "this level is held in row-pattern form only (no CSR copy): pass the new matrix whole (gmg_set_matrix) or stream it again");
     REQUIRE(val, GMG_ERR_INVALID, "null values");
+    if (L.sA) {
+      // The level is held in row-pattern form only (no CSR copy: structured operators handed over whole, or streamed).  The
+      // pattern ids depend on the values, so the rows are rebuilt from the pattern form with the new values and hashed again
+      // (numerical_setup! keeps working on every level; a fresh gmg_set_matrix costs the same).
+      REQUIRE(L.sA->complete(), GMG_ERR_STATE, "row stream incomplete");
+      HostCSR S = gmg_solver::expand_stream(*L.sA);
+      const int64_t nnz = S.nnz();
+      std::memcpy(S.val.data(), val, sizeof(double) * (size_t)nnz);
+      std::shared_ptr<PatStream> N;
+      bool eager = false;
+      if (nnz < (int64_t)INT32_MAX) {
+        std::vector<int32_t> p32(S.ptr.begin(), S.ptr.end());
+        eager = h->try_eager_pattern(N, 0, S.nrows, S.ncols, nnz, p32.data(), S.col.data(), S.val.data(), GMG_CSR, 0, 4);
+      }
+      if (eager) L.sA = N;                                  // (hA keeps the shape only)
+      else { L.hA = std::move(S); L.sA.reset(); }
+      h->touch();
+      return;
+    }
     // values are given in the 0-based CSR order held by the handle
     std::memcpy(L.hA.val.data(), val, sizeof(double) * (size_t)L.hA.nnz());
     L.values_dirty = true;

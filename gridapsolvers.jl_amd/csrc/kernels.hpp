@@ -1278,7 +1278,9 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 //   sweep -- so halving the entry halves that.  Bit-identical for finite vectors (a +-0.0 term never changes a sum that
 //   started from +0.0); with a non-finite entry in s the rows whose zero-padded taps touch it turn NaN one application
 //   earlier than in the reference -- the iteration is lost either way (every dot product is NaN).  GMG_PAT_STRICT=1 = MK.
-template <int XM, int NB, bool TD, bool MK>
+// NT = 1 (levels whose vectors no longer fit the L2s): the operands touched once per sweep -- pattern id, r in / out, x, 1/diag --
+//   move with non-temporal loads / stores; s stays cacheable (this sweep gathers s_k, the next one s_{k+1}).
+template <int XM, int NB, bool TD, bool MK, int NT = 0>
 __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
 {
   constexpr int K = 3, ROWS = 65 - K, RB = 3;
@@ -1312,13 +1314,13 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
       const int slice = min(sb + i * wpb, s_end - 1);        // a short last batch re-reads its last slice (results unused)
       row[i] = slice * ROWS + lane;
       const int rc = min(row[i], lastrow);
-      pid[i] = (int)a.rowpid[rc];
-      e0[i] = a.b[rc];
+      pid[i] = NT ? (int)__builtin_nontemporal_load(a.rowpid + rc) : (int)a.rowpid[rc];
+      e0[i] = NT ? __builtin_nontemporal_load(a.b + rc) : a.b[rc];
       e1[i] = xg[rc];
       e2[i] = 0.0; sp[i] = 0.0; dr[i] = 0.0;
-      if (XM != 1) { const double xl = a.x2[rc]; e2[i] = xz ? 0.0 : xl; }
+      if (XM != 1) { const double xl = NT ? __builtin_nontemporal_load(a.x2 + rc) : a.x2[rc]; e2[i] = xz ? 0.0 : xl; }
       if (XM == 2) sp[i] = a.s_out[rc];
-      if (!TD) dr[i] = a.dinv[rc];
+      if (!TD) dr[i] = NT ? __builtin_nontemporal_load(a.dinv + rc) : a.dinv[rc];
 #pragma unroll
       for (int q = 0; q < RB; ++q) A[i][q] = ld_off(xg, 8u * (uint32_t)min(max(row[i] + a.run_off[q], 0), last));
     }
@@ -1369,10 +1371,16 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
       if (sb + i * wpb < s_end && lane < ROWS && row[i] <= lastrow) {
         const int r = row[i];
         const double dinv_row = TD ? s_dinv[pid[i]] : dr[i];
-        if (XM == 0) a.x2[r] = e2[i] + e1[i];
-        else if (XM == 2) a.x2[r] = (e2[i] + sp[i]) + e1[i];
         const double rn = e0[i] - acc[i];
-        a.y[r] = rn;
+        if (NT) {
+          if (XM == 0) __builtin_nontemporal_store(e2[i] + e1[i], a.x2 + r);
+          else if (XM == 2) __builtin_nontemporal_store((e2[i] + sp[i]) + e1[i], a.x2 + r);
+          __builtin_nontemporal_store(rn, a.y + r);
+        } else {
+          if (XM == 0) a.x2[r] = e2[i] + e1[i];
+          else if (XM == 2) a.x2[r] = (e2[i] + sp[i]) + e1[i];
+          a.y[r] = rn;
+        }
         a.s_out[r] = omega * (dinv_row * rn);
       }
     }

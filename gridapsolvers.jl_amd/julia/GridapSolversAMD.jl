@@ -79,12 +79,14 @@ struct HipPatchProlongation{M}
   patches :: PatchTable
 end
 
-struct HipGMGLinearSolver{A,B,C,D,E} <: Gridap.Algebra.LinearSolver
+struct HipGMGLinearSolver{A,B,C,D,E,F} <: Gridap.Algebra.LinearSolver
   smatrices      :: A
   interp         :: B           # explicit sparse prolongations, level l+1 -> l
   restrict       :: C           # explicit sparse restrictions or nothing (=> P^T on the device)
   pre_smoothers  :: D
   post_smoothers :: E
+  coarsest_solver :: F          # GMGLinearSolvers.jl:54: LUSolver() (dense inverse on the device), CGSolver(JacobiLinearSolver())
+                                # (device CG), anything else runs on the host through a callback (set_coarsest_solver!)
   mode           :: Symbol
   cycle_type     :: Symbol
   log            :: ConvergenceLog{Float64}
@@ -96,6 +98,7 @@ function HipGMGLinearSolver(
   smatrices::AbstractArray{<:AbstractMatrix}, interp::AbstractArray, restrict = nothing;
   pre_smoothers  = fill(RichardsonSmoother(JacobiLinearSolver(),10),length(smatrices)-1),
   post_smoothers = pre_smoothers,
+  coarsest_solver = Gridap.Algebra.LUSolver(),
   mode = :preconditioner, cycle_type = :v_cycle,
   maxiter = 100, atol = 1.0e-14, rtol = 1.0e-08, verbose = false, device = 0,
 )
@@ -106,7 +109,7 @@ function HipGMGLinearSolver(
   @assert cycle_type ∈ [:v_cycle,:w_cycle,:f_cycle]
   tols = SolverTolerances{Float64}(;maxiter=maxiter,atol=atol,rtol=rtol)
   log  = ConvergenceLog("GMG-MI355X",tols;verbose=verbose)
-  return HipGMGLinearSolver(smatrices,interp,restrict,pre_smoothers,post_smoothers,mode,cycle_type,log,device)
+  return HipGMGLinearSolver(smatrices,interp,restrict,pre_smoothers,post_smoothers,coarsest_solver,mode,cycle_type,log,device)
 end
 
 struct HipGMGSymbolicSetup{A} <: Gridap.Algebra.SymbolicSetup
@@ -223,7 +226,11 @@ function Gridap.Algebra.numerical_setup(ss::HipGMGSymbolicSetup, mat::AbstractMa
   cycle = s.cycle_type == :v_cycle ? 0 : (s.cycle_type == :w_cycle ? 1 : 2)
   check(h, ccall((:gmg_set_options, libgmgamd), Cint, (Ptr{Cvoid},Cint,Cint,Cint,Float64,Float64),
                  h, mode, cycle, tols.maxiter, tols.atol, tols.rtol))
-  check(h, ccall((:gmg_setup, libgmgamd), Cint, (Ptr{Cvoid},), h))
+  if s.coarsest_solver isa Gridap.Algebra.LUSolver          # the default: one setup, dense inverse of the coarsest matrix on the device
+    check(h, ccall((:gmg_setup, libgmgamd), Cint, (Ptr{Cvoid},), h))
+  else                                                      # GMGLinearSolvers.jl:423-434: the caller's coarsest solver (sets up the handle itself)
+    set_coarsest_solver!(ns, s.coarsest_solver, s.smatrices[nlev])
+  end
   return ns
 end
 

@@ -67,12 +67,20 @@ class StreamedCSR:
     gmg_set_operator_rows and drops it, so the host never holds more than one block -- the driver-side counterpart of an
     assembler that emits the matrix slab by slab."""
 
-    def __init__(self, shape, blocks_fn):
+    def __init__(self, shape, blocks_fn, plan_fn=None):
         self.shape = (int(shape[0]), int(shape[1]))
         self._fn = blocks_fn
+        self._plan = plan_fn
 
     def row_blocks(self):
         return self._fn()
+
+    def row_plan(self):
+        """("block", row0, CSR) items, and ("repeat", nrows_block, count, col_shift) where the last nrows_block rows recur `count`
+        more times with their columns shifted (gmg_set_operator_rows_repeat): what a structured-mesh assembler knows for free."""
+        if self._plan is not None:
+            return self._plan()
+        return (("block", row0, B) for row0, B in self._fn())
 
     def materialize(self):
         """the whole operator as one CSR (tests / small sizes)"""
@@ -226,6 +234,59 @@ def _tensor_csr_blocks(axes, terms, ncols_axes, raw=False):
             yield z * ny * nx, CSR((ny * nx, ncx * ncy * ncz), ptr, idx, val)
 
 
+def _tensor_csr_plan(axes, terms, ncols_axes):
+    """`_tensor_csr_blocks` with the repetition made explicit: yields ("block", row0, CSR) for the planes that have to be
+    handed over as arrays and ("repeat", nrows_block, count, col_shift) for runs of planes that recur with period 1, 2 or 4
+    planes up to a constant column shift (all interior planes of a uniform mesh)."""
+    cx, cy, cz = axes
+    nx, ny, nz = cx.shape[0], cy.shape[0], cz.shape[0]
+    ncx, ncy, ncz = ncols_axes
+    mz = cz >= 0
+    keys, firsts = [], []
+    for z in range(nz):
+        valid = np.nonzero(mz[z])[0]
+        first = int(cz[z, valid[0]]) if valid.size else 0
+        keys.append((tuple(np.where(mz[z], cz[z] - first, -1).tolist()),) + tuple(tuple(t[2][z].tolist()) for t in terms))
+        firsts.append(first)
+    blocks = _tensor_csr_blocks(axes, terms, ncols_axes)
+    pending = {}                                              # planes generated by the block iterator but not consumed (it is sequential)
+
+    def take(z):
+        while z not in pending:
+            row0, B = next(blocks)
+            pending[row0 // (ny * nx)] = B
+        return pending.pop(z)
+
+    z = 0
+    skipped = set()
+    while z < nz:
+        done = False
+        for p in (1, 2, 4):
+            if z < p or z + p > nz:
+                continue
+            delta = firsts[z] - firsts[z - p]
+            count = 0
+            while z + (count + 1) * p <= nz and all(keys[z + count * p + t] == keys[z - p + t] and
+                                                    firsts[z + count * p + t] - firsts[z - p + t] == delta * (count + 1) for t in range(p)):
+                count += 1
+            if count >= 1 and delta >= 0:
+                yield ("repeat", p * ny * nx, count, delta * ncy * ncx)
+                for t in range(count * p):
+                    skipped.add(z + t)
+                z += count * p
+                done = True
+                break
+        if done:
+            continue
+        # materialise plane z (consuming and dropping the skipped planes the sequential block iterator has to pass)
+        for zz in sorted(skipped):
+            if zz < z:
+                take(zz)
+        skipped = {q for q in skipped if q > z}
+        yield ("block", z * ny * nx, take(z))
+        z += 1
+
+
 def _dims(ncells):
     nc = tuple(int(c) for c in ncells)
     if len(nc) not in (2, 3):
@@ -339,9 +400,9 @@ def poisson_matrix_stream(ncells, order=1, lengths=None) -> StreamedCSR:
         terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
         if d == 3:
             terms.append((M[0], M[1], K[2]))
-        return _tensor_csr_blocks([t[1] for t in tabs], terms, [t[0] for t in tabs])
+        return [t[1] for t in tabs], terms, [t[0] for t in tabs]
     n = level_sizes(ncells, order)
-    return StreamedCSR((n, n), blocks)
+    return StreamedCSR((n, n), lambda: _tensor_csr_blocks(*blocks()), lambda: _tensor_csr_plan(*blocks()))
 
 
 def _interp_1d(nc_coarse, order):
@@ -413,10 +474,11 @@ def prolongation_stream(ncells_coarse, order=1) -> StreamedCSR:
     """`prolongation` as a row-block stream."""
     nc = tuple(int(c) for c in ncells_coarse)
 
-    def blocks():
+    def args():
         cols, vals, ncols = _transfer_tables(nc, order, False)
-        return _tensor_csr_blocks(cols, [tuple(vals)], ncols)
-    return StreamedCSR((level_sizes(tuple(2 * c for c in nc), order), level_sizes(nc, order)), blocks)
+        return cols, [tuple(vals)], ncols
+    return StreamedCSR((level_sizes(tuple(2 * c for c in nc), order), level_sizes(nc, order)), lambda: _tensor_csr_blocks(*args()),
+                       lambda: _tensor_csr_plan(*args()))
 
 
 def restriction_stream(ncells_coarse, order=1) -> StreamedCSR:
@@ -424,10 +486,11 @@ def restriction_stream(ncells_coarse, order=1) -> StreamedCSR:
     entries are the very numbers of `prolongation(...).transpose()`."""
     nc = tuple(int(c) for c in ncells_coarse)
 
-    def blocks():
+    def args():
         cols, vals, ncols = _transfer_tables(nc, order, True)
-        return _tensor_csr_blocks(cols, [tuple(vals)], ncols)
-    return StreamedCSR((level_sizes(nc, order), level_sizes(tuple(2 * c for c in nc), order)), blocks)
+        return cols, [tuple(vals)], ncols
+    return StreamedCSR((level_sizes(nc, order), level_sizes(tuple(2 * c for c in nc), order)), lambda: _tensor_csr_blocks(*args()),
+                       lambda: _tensor_csr_plan(*args()))
 
 
 def _apply_axes(G, mats):

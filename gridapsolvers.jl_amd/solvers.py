@@ -26,6 +26,7 @@ All arithmetic happens in libgmgamd.so on the GPU.  Vectors may be numpy arrays
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -317,7 +318,16 @@ def _set_op(fn, h, lev, M):
         lib = abi.load()
         op = {"gmg_set_matrix": abi.OP_A, "gmg_set_prolongation": abi.OP_P, "gmg_set_restriction": abi.OP_R}[fn.__name__]
         seen = 0
-        for row0, B in M.row_blocks():
+        plan = M.row_plan() if (hasattr(M, "row_plan") and os.environ.get("GMG_STREAM_REPEAT", "1") != "0") else (("block", r0, B) for r0, B in M.row_blocks())
+        for item in plan:
+            if item[0] == "repeat":                         # the last nrows_block rows recur: no arrays, nothing hashed
+                _, nrb, count, cshift = item
+                abi.check(h, lib.gmg_set_operator_rows_repeat(h, lev, op, nrb, count, cshift))
+                seen += nrb * count
+                continue
+            _, row0, B = item
+            if row0 != seen:
+                raise ValueError("row-block stream out of order")
             ptr = np.ascontiguousarray(B.ptr, dtype=np.int64)
             idx = np.ascontiguousarray(B.idx, dtype=np.int64)
             val = np.ascontiguousarray(B.val, dtype=np.float64)

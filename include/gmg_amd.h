@@ -109,6 +109,11 @@ GMG_API int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols
 GMG_API int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, int64_t ncols, int64_t row0,
                                   int64_t nrows_block, const void *ptr, const void *idx, const double *val,
                                   int index_base, int index_bytes);
+/* Structured operators: append `count` further copies of the LAST nrows_block rows handed over, copy k with all its column
+ * indices shifted by k * col_shift (uniform meshes: every interior node plane repeats the previous one).  No arrays cross the
+ * boundary and nothing is hashed again; for level matrices col_shift must equal nrows_block.  No reference counterpart (the
+ * reference assembles every row, GMGLinearSolvers.jl:342-353). */
+GMG_API int gmg_set_operator_rows_repeat(gmg_handle_t h, int lev, int op, int64_t nrows_block, int64_t count, int64_t col_shift);
 /* numerical_setup!(ns,A): same pattern, new values in the handle's 0-based CSR order (GMGLinearSolvers.jl:249-297;
  * JacobiLinearSolvers.jl:25-27), any level.  Requires gmg_setup to be called again; when nothing but values changed
  * since the last setup and the refreshed levels are stored with explicit values (SELL-64 / CSR-stream: what

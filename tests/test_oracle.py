@@ -535,3 +535,28 @@ def test_twin_fgmres_left_preconditioner(po, orc):
     assert nit == nt
     np.testing.assert_allclose(hist, ht, rtol=1e-6, atol=1e-15 * hist[0])
     assert np.linalg.norm(xo - xt) <= 1e-8 * np.linalg.norm(xt)
+
+
+# ---------------------------------------------------------------- the reference's restriction is P^T only to ~1e-6 (CG mass solve)
+@pytest.mark.parametrize("nc,nlev,order,krylov", [((64, 64), 3, 1, "cg"), ((16, 16, 16), 3, 1, "cg"), ((8, 8, 8), 2, 2, "fgmres")])
+def test_inexact_restriction_does_not_change_iteration_counts(po, orc, nc, nlev, order, krylov):
+    """test/LinearSolvers/GMGTests.jl:66-74 builds `restrict` with CGSolver(JacobiLinearSolver()) (rtol 1e-6) as the mass solver of
+    the dual projection (GridTransferOperators.jl:536-547): the reference's R is P^T (1 + O(1e-6)).  With R perturbed by that
+    much the oracle's iteration counts are unchanged and its residual histories move by <= 1e-5 relative (3 eps, linear)."""
+    H = po.build_hierarchy(nc, nlev, order)
+    b = po.dirichlet_lift_rhs(nc, order)
+    out = []
+    for eps in (0.0, 1e-6):
+        rng = np.random.default_rng(11)
+        Rs = [po.CSR(R.shape, R.ptr, R.idx, R.val * (1.0 + eps * rng.uniform(-1, 1, R.val.size))) for R in H["restrictions"]]
+        if krylov == "cg":
+            go = orc.GMG(H["mats"], H["prolongations"], Rs, maxiter=1)
+            x, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
+        else:
+            tabs = [po.vertex_star_patches(c, order) for c in H["ncells"][:-1]]
+            go = orc.GMG(H["mats"], H["prolongations"], Rs, pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in tabs], maxiter=1)
+            x, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-6)
+        out.append((nit, hist, x))
+    assert out[0][0] == out[1][0]
+    assert np.max(np.abs(out[1][1] - out[0][1]) / out[0][1]) <= 1e-5
+    assert np.linalg.norm(out[1][2] - out[0][2]) <= 1e-10 * np.linalg.norm(out[0][2])

@@ -80,12 +80,12 @@ int main(int argc, char **argv)
       hipLaunchKernelGGL((sells_kernel<EPI_SWEEP, true, 3, 3, false, 15>), dim3(g2), dim3(64 * wpbv), lds, 0, b); }, 30);
     printf("waves/wg %d workgroups %6d : product %7.2f us   skeleton %7.2f us\n", wpbv, g2, t0 * 1e3 / 2, t1 * 1e3 / 2);
   }
-#define RUNB(NBV, wpbv, wg) { const int g2 = std::min((a.nslices + wpbv - 1) / wpbv, wg); \
-    float t = time_it([&] { SellSArgs b = a; b.x = s0; b.s_out = s1; b.b = r; b.y = r; b.x2 = x; b.xmode = 1; \
-      hipLaunchKernelGGL((sells_sweep_kernel<1, NBV, true>), dim3(g2), dim3(64 * wpbv), lds16, 0, b); b.x = s1; b.s_out = s0; b.xmode = 2; \
-      hipLaunchKernelGGL((sells_sweep_kernel<2, NBV, true>), dim3(g2), dim3(64 * wpbv), lds16, 0, b); }, 30); \
-    printf("batched sweep NB=%d waves/wg %d workgroups %6d : %7.2f us\n", NBV, wpbv, g2, t * 1e3 / 2); }
-  for (int wg : {1024, 2048, 4096}) { RUNB(1, 4, wg) RUNB(2, 4, wg) RUNB(1, 2, wg) }
+#define RUNB(NBV, wpbv, wg, NTV, REMAP) { const int g2 = std::min((a.nslices + wpbv - 1) / wpbv, wg); \
+    SellSArgs b = a; b.xcd_remap = REMAP; b.b = r; b.y = r; b.x2 = x; float t = time_it([&] { b.x = s0; b.s_out = s1; b.xmode = 1; \
+      hipLaunchKernelGGL((sells_sweep_kernel<1, NBV, true, true, NTV>), dim3(g2), dim3(64 * wpbv), lds16, 0, b); b.x = s1; b.s_out = s0; b.xmode = 2; \
+      hipLaunchKernelGGL((sells_sweep_kernel<2, NBV, true, true, NTV>), dim3(g2), dim3(64 * wpbv), lds16, 0, b); }, 30); \
+    printf("sells_sweep_kernel NB=%d wpb=%d wgs=%d nt=%d remap=%d : %8.2f us per sweep (pair average)\n", NBV, wpbv, g2, NTV, REMAP, t * 1e3 / 2); }
+  for (int wg : {1024, 2048, 4096}) { RUNB(1, 4, wg, 0, 1) RUNB(2, 4, wg, 0, 1) RUNB(2, 4, wg, 1, 1) RUNB(2, 4, wg, 0, 0) RUNB(2, 4, wg, 1, 0) RUNB(1, 4, wg, 1, 0) }
   RUN(0, "product kernel")
   RUN(1, "- high-word mask")
   RUN(2, "- LDS coefficient reads")
