@@ -2178,7 +2178,7 @@ struct gmg_solver {
       if (L.has_pcorr) {
         // PatchProlongationOperator: dxh = P dxH - sum_p A_pp^-1 (A P dxH)_p  (PatchTransferOperators.jl:153-172)
         spmv_set(L.P, C.x, L.dx);
-        if (L.hasG) spmv_set(L.G, L.dx, L.ptmp);           // rhs(uH,v_i) with the caller's rhs form
+        if (L.hasG) { exchange(l, L.dx); spmv_set(L.G, L.dx, L.ptmp); }   // rhs(uH,v_i) with the caller's rhs form (consistent!(dxh) first when distributed)
         else apply_A_set(l, L.dx, L.ptmp);
         patch_precond(L, L.pcorr, L.ptmp, 1.0, false, L.pcor, nullptr);
         hipLaunchKernelGGL(prolong_correct_kernel, dim3(grid_for(L.n)), dim3(256), 0, stream, L.n, L.pcor, L.dx, x);
@@ -2565,6 +2565,15 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
 {
   REQUIRE(S.tab, GMG_ERR_INVALID, "patch tables missing");
   const Smoother::Tables &T = *S.tab;
+  const bool bp_timing = env_int("GMG_SETUP_TIMING", 0) != 0;
+  auto bp_last = std::chrono::steady_clock::now();
+  auto bp_lap = [&](const char *what) {
+    if (!bp_timing) return;
+    (void)hipStreamSynchronize(stream);
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[gmg_setup]   patch tables: %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - bp_last).count());
+    bp_last = now;
+  };
   const int64_t npatch = (int64_t)T.pptr.size() - 1;
   REQUIRE(npatch >= 0, GMG_ERR_INVALID, "patch_ptr missing");
   S.npatch = npatch;
@@ -2580,8 +2589,15 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
   const int64_t ndof_entries = T.pptr[npatch];
   const int64_t nloc = L.nvec;                              // patches of a distributed level reach into the ghost dofs (own | ghost numbering)
   REQUIRE((int64_t)T.prow.size() == ndof_entries && (int64_t)pcolv.size() == ndof_entries, GMG_ERR_INVALID, "patch tables have the wrong length");
-  for (int64_t q = 0; q < ndof_entries; ++q)
-    REQUIRE(T.prow[q] >= 0 && T.prow[q] < nloc && pcolv[q] >= 0 && pcolv[q] < nloc, GMG_ERR_INVALID, "patch dof out of range");
+  {
+    std::atomic<int> oob(0);
+    parallel_chunks(64, [&](int64_t t) {
+      const int64_t per = (ndof_entries + 63) / 64;
+      for (int64_t q = t * per; q < std::min(ndof_entries, (t + 1) * per); ++q)
+        if (!(T.prow[q] >= 0 && T.prow[q] < nloc && pcolv[q] >= 0 && pcolv[q] < nloc)) { oob.store(1); return; }
+    });
+    REQUIRE(oob.load() == 0, GMG_ERR_INVALID, "patch dof out of range");
+  }
   if (T.has_blocks) REQUIRE((int64_t)T.blocks.size() == boff[npatch], GMG_ERR_INVALID, "patch blocks have the wrong total size");
   S.max_np = max_np;
   if (blocks_only) {
@@ -2598,6 +2614,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
   S.d_pdofs = upload(T.prow);
   S.d_pcol = T.pcol.empty() ? S.d_pdofs : upload(T.pcol);
   }
+  bp_lap("validation + upload");
   int32_t *d_pcol = S.d_pcol;
   // dof -> contribution slots, ascending patch order (= reference loop order PatchSolvers.jl:288).  Built at the first setup;
   // again after a value refresh when the row-pattern form of the patch operator (which had released these buffers) can no
@@ -2819,11 +2836,14 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
     return true;
   };
   if (!(want_dedup && build_blocks(true))) build_blocks(false);
+  bp_lap("inverse blocks + de-duplication");
   if (S.dedup) release(S.d_boff, (size_t)npatch + 1);        // the de-duplicated solve addresses blocks through ublock / uboff
   S.built = true;
   build_patch_operator(L, S);
   S.h_ublock.clear(); S.h_ublock.shrink_to_fit(); S.h_uboff.clear();
+  bp_lap("patch operator");
   if (!S.use_M && !S.d_contrib) make_incidence();           // (value refresh: the patch-by-patch kernels are needed again)
+  bp_lap("incidence lists");
 }
 
 // ----------------------------------------------------------------------------
@@ -3420,10 +3440,16 @@ void gmg_solver::setup()
       const bool need_diag = (L.pre.kind == SM_JACOBI) || (L.post.kind == SM_JACOBI);
       REQUIRE(!(need_diag && nzero > 0), GMG_ERR_SINGULAR, "zero diagonal entry on level " + std::to_string(l));
       if (L.has_pcorr) {
-        REQUIRE(comm.nranks == 1, GMG_ERR_UNSUPPORTED, "patch-corrected prolongation is single-GPU in this round");
+        if (comm.nranks > 1 && L.halo.present) {
+          // distributed (PatchTransferOperators.jl:153-172 on PVectors): the correction patches (coarse-cell interiors) must lie
+          // inside the owned dofs -- their blocks are then rows / columns of the own x own part of the local matrix
+          REQUIRE(L.pcorr.tab && !L.pcorr.tab->has_blocks, GMG_ERR_UNSUPPORTED, "distributed patch prolongation: blocks come from the level matrix");
+          for (int32_t q : L.pcorr.tab->prow) REQUIRE(q < L.n, GMG_ERR_UNSUPPORTED, "distributed patch prolongation: every patch dof must be owned by this rank");
+          for (int32_t q : L.pcorr.tab->pcol) REQUIRE(q < L.n, GMG_ERR_UNSUPPORTED, "distributed patch prolongation: every patch dof must be owned by this rank");
+        }
         build_patch(L, L.pcorr);
         if (L.hasG) {
-          REQUIRE(L.hG.nrows == L.n && L.hG.ncols == L.n, GMG_ERR_INVALID, "rhs operator of the prolongation correction has the wrong shape");
+          REQUIRE(L.hG.nrows == L.n && L.hG.ncols == L.nvec, GMG_ERR_INVALID, "rhs operator of the prolongation correction has the wrong shape");
           L.G = upload_csr(L.hG);
           drop_csr_stream(L.G);
         }
@@ -3951,7 +3977,10 @@ int gmg_set_prolongation_patch_correction_rhs(gmg_handle_t h, int lev, int64_t n
 {
   return guarded(h, [&] {
     check_level(h, lev, true);
-    h->lev[lev].hG = convert_input(n, n, nnz, ptr, idx, val, layout, index_base, index_bytes);
+    // distributed level (gmg_set_partition first): this rank's rows, [own | ghost] columns
+    const HaloPlan &Hp = h->lev[lev].halo;
+    const int64_t ncols = (h->comm.nranks > 1 && Hp.present && !Hp.ovl) ? Hp.n_own + Hp.n_ghost : n;
+    h->lev[lev].hG = convert_input(n, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
     h->lev[lev].hasG = true;
     h->touch();
   });

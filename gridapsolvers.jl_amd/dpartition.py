@@ -1,0 +1,133 @@
+"""Row partition of ARBITRARY global operators by dof -> owner maps (multi-GPU).
+
+`partition.py` builds the local operators of the structured Poisson hierarchy analytically (nothing of global size is ever
+formed: 576^3 nodes on 8 GPUs).  This module is its general counterpart for operators that exist as global sparse matrices at
+driver scale -- the vector-valued Q2 / discontinuous-P1 Stokes blocks of test/Applications/mpi/StokesGMG.jl, their velocity
+hierarchy, transfer operators and patch tables: what GridapDistributed + PartitionedArrays give the reference, in the same
+conventions (JacobiLinearSolvers.jl:29-56, PatchSolvers.jl:227-258):
+
+  * every vector SPACE has an owner per dof; rank r's local numbering is [own (ascending global id) | ghost (by owner, then id)];
+  * an operator's local part has the rows its row space owns on r and the columns of its column space in local numbering;
+  * the ghosts of a space on r are the columns any of r's operator rows reference plus the dofs its owned patches touch;
+  * exchange plans list, per neighbour, the owned entries to send (ascending global id -- the order the neighbour stores them in).
+
+Host-side numpy / scipy only; nothing here is on the timed path."""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import poisson as po
+
+__all__ = ["Space", "partition_spaces", "local_operator", "local_patches"]
+
+
+class Space:
+    """One vector space on every rank: owner per global dof, then (after `partition_spaces`) per rank the own / ghost global ids,
+    the global -> local map and the exchange plan."""
+
+    def __init__(self, name, owner, nranks):
+        self.name = name
+        self.owner = np.asarray(owner, dtype=np.int64)
+        self.n = self.owner.size
+        self.nranks = int(nranks)
+        assert self.owner.min(initial=0) >= 0 and self.owner.max(initial=0) < nranks
+        self.own = [np.nonzero(self.owner == r)[0].astype(np.int64) for r in range(nranks)]
+        self.need = [set() for _ in range(nranks)]          # ghost candidates collected from operators / patches
+        self.ghost = None
+
+    def require(self, rank, gids):
+        g = np.asarray(gids, dtype=np.int64)
+        self.need[rank].update(g[self.owner[g] != rank].tolist())
+
+    def finalize(self):
+        self.ghost, self.g2l, self.plan = [], [], []
+        for r in range(self.nranks):
+            g = np.array(sorted(self.need[r]), dtype=np.int64)
+            order = np.lexsort((g, self.owner[g])) if g.size else np.zeros(0, dtype=np.int64)
+            g = g[order]
+            self.ghost.append(g)
+            m = -np.ones(self.n, dtype=np.int64)
+            m[self.own[r]] = np.arange(self.own[r].size)
+            m[g] = self.own[r].size + np.arange(g.size)
+            self.g2l.append(m)
+        for r in range(self.nranks):
+            nbr, snd_ptr, rcv_ptr, snd = [], [0], [0], []
+            for q in range(self.nranks):
+                if q == r:
+                    continue
+                mine_at_q = self.ghost[q][self.owner[self.ghost[q]] == r]       # ascending id: q stores them in this order
+                n_rcv = int(np.count_nonzero(self.owner[self.ghost[r]] == q))
+                if mine_at_q.size == 0 and n_rcv == 0:
+                    continue
+                nbr.append(q)
+                snd.append(self.g2l[r][mine_at_q])
+                snd_ptr.append(snd_ptr[-1] + mine_at_q.size)
+                rcv_ptr.append(rcv_ptr[-1] + n_rcv)
+            assert rcv_ptr[-1] == self.ghost[r].size
+            self.plan.append(dict(nbr_rank=np.asarray(nbr, dtype=np.int32), snd_ptr=np.asarray(snd_ptr, dtype=np.int64),
+                                  snd_idx=np.concatenate(snd).astype(np.int64) if snd else np.zeros(0, np.int64),
+                                  rcv_ptr=np.asarray(rcv_ptr, dtype=np.int64)))
+
+    # views a rank works with
+    def n_own(self, r):
+        return int(self.own[r].size)
+
+    def n_ghost(self, r):
+        return int(self.ghost[r].size)
+
+    def local_gid(self, r):
+        return np.concatenate([self.own[r], self.ghost[r]])
+
+
+def partition_spaces(spaces, operators, patches=()):
+    """Collect the ghosts every rank needs and freeze the local numberings.
+
+    spaces    : list of Space
+    operators : list of (A_global (scipy sparse), row_space, col_space)
+    patches   : list of (patch_ptr, patch_dofs (global ids), space, patch_owner[npatch])"""
+    for A, rs, cs in operators:
+        A = A.tocsr()
+        for r in range(rs.nranks):
+            rows = rs.own[r]
+            if rows.size:
+                cs.require(r, A[rows].indices)
+    for pp, pd, spc, powner in patches:
+        for r in range(spc.nranks):
+            mine = np.nonzero(powner == r)[0]
+            if mine.size:
+                cs_ = np.concatenate([pd[pp[p]:pp[p + 1]] for p in mine]) if mine.size else np.zeros(0, np.int64)
+                spc.require(r, cs_)
+    for s in spaces:
+        s.finalize()
+
+
+def local_operator(A, rs, cs, rank):
+    """Rows rs owns on `rank`, columns in cs's [own | ghost] numbering (ascending column order per row, the order a sequential
+    mat-vec sums in -- ghosts come after the owned columns)."""
+    A = A.tocsr()
+    L = A[rs.own[rank]].tocoo()
+    cols = cs.g2l[rank][L.col]
+    assert (cols >= 0).all(), "operator references a dof that is neither owned nor ghost"
+    M = sp.csr_matrix((L.data, (L.row, cols)), shape=(rs.n_own(rank), cs.n_own(rank) + cs.n_ghost(rank)))
+    M.sort_indices()
+    return po.CSR(M.shape, M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data)
+
+
+def local_patches(pp, pd, spc, powner, rank, A_global=None):
+    """Patches owned by `rank` in local numbering, in the serial order; with A_global also their dense matrices (column-major,
+    concatenated: gmg_set_smoother_patch_matrices -- a rank's local rows cannot supply the blocks of ghost-reaching patches)."""
+    mine = np.nonzero(powner == rank)[0]
+    ptr = np.zeros(mine.size + 1, dtype=np.int64)
+    loc, glob, blocks = [], [], []
+    Ag = A_global.tocsr() if A_global is not None else None
+    for k, p in enumerate(mine):
+        g = pd[pp[p]:pp[p + 1]].astype(np.int64)
+        l = spc.g2l[rank][g]
+        assert (l >= 0).all()
+        loc.append(l); glob.append(g)
+        ptr[k + 1] = ptr[k] + g.size
+        if Ag is not None:
+            blocks.append(Ag[g][:, g].toarray().reshape(-1, order="F"))
+    cat = (lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt))
+    return ptr, cat(loc, np.int64), cat(glob, np.int64), (cat(blocks, np.float64) if Ag is not None else None)

@@ -76,12 +76,18 @@ class DistributedGMG:
     def __init__(self, cells_per_rank, nlevels, rank, world, device_id=0, transport="rccl", group=None,
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
                  gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None,
-                 smoother="jacobi", depth=None):
+                 smoother="jacobi", depth=None, patch_tables=None, pcorr_tables=None, cells_global=None):
         """smoother = "jacobi": Richardson(Jacobi, niter, omega); "patch": Richardson(PatchSolver, niter, omega) with the
         vertex-star patches OWNED by this rank (partition.local_vertex_star_patches) and caller-assembled patch matrices --
         a rank's local matrix has the owned rows only, so the blocks of patches reaching into ghost dofs come from the
         driver, as the reference assembles them from the solver's weak form on the local (ghosted) mesh
         (PatchSolvers.jl:137-150).
+        local_hierarchy: ready-made local operators (dict like partition.build_local_hierarchy's: levels = objects with A, P, R, n_own,
+        n_ghost, nbr_rank, snd_ptr, snd_idx, rcv_ptr, replicated; rep_from; rep_gid) -- e.g. from dpartition for the vector-valued
+        Stokes velocity hierarchy; then patch_tables[l] = (patch_ptr, dofs, blocks) supplies the smoother's patches per level
+        (local numbering + caller-assembled matrices on partitioned levels, global numbering and blocks=None on replicated ones)
+        and pcorr_tables[l] = (patch_ptr, local dofs, G_local or None) a patch-corrected prolongation
+        (PatchProlongationOperator, PatchTransferOperators.jl:153-172) with its rhs form.
         depth: ghost layers of the OVERLAPPING layout on the partitioned levels >= 1 (int or per-level list; None / 0 = every level in
         the own | ghost layout): one halo exchange per `depth` sweeps instead of one per sweep (gmg_set_partition_overlap)."""
         import torch.distributed as dist
@@ -89,7 +95,8 @@ class DistributedGMG:
         self._lib, self.rank, self.world = lib, rank, world
         d = len(cells_per_rank)
         self.grid = pa.rank_grid(world, d)
-        self.cells_global = pa.global_cells(cells_per_rank, self.grid)
+        self.cells_global = tuple(cells_global) if cells_global is not None else pa.global_cells(cells_per_rank, self.grid)
+        self._patch_tables, self._pcorr_tables = patch_tables, pcorr_tables
         t0 = time.perf_counter()
         # `lengths` = domain extents; the weak-scaling bench uses (px,py,pz) so that cells stay cubes
         # (an anisotropic mesh would change the iteration count with the rank grid)
@@ -121,6 +128,8 @@ class DistributedGMG:
         levels = self.local["levels"]
         for l, L in enumerate(levels):
             if world > 1 and not L.replicated:
+                if not hasattr(L, "overlap"):
+                    L.overlap = False
                 nbr = np.ascontiguousarray(L.nbr_rank, dtype=np.int32)
                 sp, si, rp = (np.ascontiguousarray(a, dtype=np.int64) for a in (L.snd_ptr, L.snd_idx, L.rcv_ptr))
                 self._keep += [nbr, sp, si, rp]
@@ -142,6 +151,16 @@ class DistributedGMG:
                     self._set_patch_smoother(l, L, niter, omega)
                 else:
                     abi.check(h, lib.gmg_set_smoother_jacobi(h, l, abi.PRE_AND_POST, niter, omega))
+                if pcorr_tables is not None and pcorr_tables[l] is not None:
+                    pp, pl, G = pcorr_tables[l]
+                    pp64, pl64 = np.ascontiguousarray(pp, dtype=np.int64), np.ascontiguousarray(pl, dtype=np.int64)
+                    self._keep += [pp64, pl64]
+                    abi.check(h, lib.gmg_set_prolongation_patch_correction(h, l, abi.PATCH_LU, pp64.size - 1, C.c_void_p(pp64.ctypes.data),
+                                                                           C.c_void_p(pl64.ctypes.data), 0, 8))
+                    if G is not None:
+                        gp, gi = np.ascontiguousarray(G.ptr, dtype=np.int64), np.ascontiguousarray(G.idx, dtype=np.int64)
+                        abi.check(h, lib.gmg_set_prolongation_patch_correction_rhs(h, l, G.shape[0], G.nnz, C.c_void_p(gp.ctypes.data),
+                                                                                   C.c_void_p(gi.ctypes.data), C.c_void_p(G.val.ctypes.data), abi.CSR, 0, 8))
         if world > 1:
             gid = self.local["rep_gid"]
             self._keep.append(gid)
@@ -153,11 +172,25 @@ class DistributedGMG:
         abi.check(h, lib.gmg_setup(h))
         self.t_setup = time.perf_counter() - t0
         self.n_own = levels[0].n_own
-        self.n_global = po.level_sizes(self.cells_global, order)
+        self.n_global = po.level_sizes(self.cells_global, order) if local_hierarchy is None else None
         self.nnz_local = levels[0].A.nnz
 
     def _set_patch_smoother(self, l, L, niter, omega):
         lib, h = self._lib, self.h
+        if self._patch_tables is not None:                   # caller-made tables (generic hierarchies, e.g. the Stokes velocity block)
+            pp, pd, blocks = self._patch_tables[l]
+            pp64, pd64 = np.ascontiguousarray(pp, dtype=np.int64), np.ascontiguousarray(pd, dtype=np.int64)
+            self._keep += [pp64, pd64]
+            if blocks is None:
+                abi.check(h, lib.gmg_set_smoother_patch(h, l, abi.PRE_AND_POST, niter, omega, abi.PATCH_LU, pp64.size - 1,
+                                                        C.c_void_p(pp64.ctypes.data), C.c_void_p(pd64.ctypes.data), 0, 8))
+            else:
+                blocks = np.ascontiguousarray(blocks)
+                self._keep.append(blocks)
+                abi.check(h, lib.gmg_set_smoother_patch_matrices(h, l, abi.PRE_AND_POST, niter, omega, abi.PATCH_LU, pp64.size - 1,
+                                                                 C.c_void_p(pp64.ctypes.data), C.c_void_p(pd64.ctypes.data), None, 0, 8,
+                                                                 C.c_void_p(blocks.ctypes.data), 0, None))
+            return
         cells_l = self.local["cells"][l]
         if L.replicated or self.world == 1:
             pp, pd = po.vertex_star_patches(cells_l, self.order)
@@ -304,6 +337,7 @@ def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, de
     any exchange); give every other level >= 1 the halo depth that minimises the modelled smoothing-pass time.  The finest level
     keeps the own | ghost layout (its own x own kernel hides the exchange)."""
     grid = pa.rank_grid(world, 3)
+    rep_rows = int(os.environ.get("GMG_REP_ROWS", rep_rows))
     rep_from = nlevels - 1
     for l in range(1, nlevels):
         if po.level_sizes(tuple(cells_per_rank * g // 2 ** l for g in grid), 1) <= rep_rows:

@@ -197,17 +197,18 @@ def _tensor_csr(axes, terms, ncols_axes):
     return CSR((nx * ny * nz, ncx * ncy * ncz), ptr, idx, val)
 
 
-def _tensor_csr_blocks(axes, terms, ncols_axes, raw=False):
-    """The same operator as `_tensor_csr`, one z-plane of rows at a time: yields (row0, CSR block).  Values are formed by
-    the same products and sums (bit-identical to `_tensor_csr`).  Planes whose 1-D z-rows agree up to a shift of the
-    column index (all interior planes of a uniform mesh, period `order`) reuse the first such plane's arrays: the
-    columns get a constant added, the values are the very same array."""
+def _plane_maker(axes, terms, ncols_axes):
+    """plane(z) -> (ptr, idx, val) of one z-plane of rows of  sum_t Z_t (x) Y_t (x) X_t  (random access).  Values are formed by the
+    same products and sums as one big tensor product would.  Planes whose 1-D z-rows agree up to a shift of the column index
+    (all interior planes of a uniform mesh, period `order`) reuse the first such plane's arrays: the columns get a constant
+    added, the values are the very same array."""
     cx, cy, cz = axes
     nx, ny, nz = cx.shape[0], cy.shape[0], cz.shape[0]
     ncx, ncy, ncz = ncols_axes
     mx, my, mz = cx >= 0, cy >= 0, cz >= 0
     cache = {}
-    for z in range(nz):
+
+    def plane(z):
         valid = np.nonzero(mz[z])[0]
         first = int(cz[z, valid[0]]) if valid.size else 0
         key = (tuple(np.where(mz[z], cz[z] - first, -1).tolist()),) + tuple(tuple(t[2][z].tolist()) for t in terms)
@@ -228,6 +229,18 @@ def _tensor_csr_blocks(axes, terms, ncols_axes, raw=False):
                 cache[key] = hit
         f0, ptr, idx0, val = hit
         idx = idx0 + (first - f0) * (ncy * ncx) if first != f0 else idx0
+        return ptr, idx, val
+    return plane
+
+
+def _tensor_csr_blocks(axes, terms, ncols_axes, raw=False):
+    """The same operator as `_tensor_csr`, one z-plane of rows at a time: yields (row0, CSR block) (bit-identical values)."""
+    cx, cy, cz = axes
+    nx, ny, nz = cx.shape[0], cy.shape[0], cz.shape[0]
+    ncx, ncy, ncz = ncols_axes
+    plane = _plane_maker(axes, terms, ncols_axes)
+    for z in range(nz):
+        ptr, idx, val = plane(z)
         if raw:
             yield z * ny * nx, (ptr, idx, val)
         else:
@@ -248,17 +261,8 @@ def _tensor_csr_plan(axes, terms, ncols_axes):
         first = int(cz[z, valid[0]]) if valid.size else 0
         keys.append((tuple(np.where(mz[z], cz[z] - first, -1).tolist()),) + tuple(tuple(t[2][z].tolist()) for t in terms))
         firsts.append(first)
-    blocks = _tensor_csr_blocks(axes, terms, ncols_axes)
-    pending = {}                                              # planes generated by the block iterator but not consumed (it is sequential)
-
-    def take(z):
-        while z not in pending:
-            row0, B = next(blocks)
-            pending[row0 // (ny * nx)] = B
-        return pending.pop(z)
-
+    plane = _plane_maker(axes, terms, ncols_axes)               # random access: repeated planes are never generated
     z = 0
-    skipped = set()
     while z < nz:
         done = False
         for p in (1, 2, 4):
@@ -271,19 +275,13 @@ def _tensor_csr_plan(axes, terms, ncols_axes):
                 count += 1
             if count >= 1 and delta >= 0:
                 yield ("repeat", p * ny * nx, count, delta * ncy * ncx)
-                for t in range(count * p):
-                    skipped.add(z + t)
                 z += count * p
                 done = True
                 break
         if done:
             continue
-        # materialise plane z (consuming and dropping the skipped planes the sequential block iterator has to pass)
-        for zz in sorted(skipped):
-            if zz < z:
-                take(zz)
-        skipped = {q for q in skipped if q > z}
-        yield ("block", z * ny * nx, take(z))
+        ptr, idx, val = plane(z)
+        yield ("block", z * ny * nx, CSR((ny * nx, ncx * ncy * ncz), ptr, idx, val))
         z += 1
 
 

@@ -150,3 +150,34 @@ def velocity_hierarchy(n, nlevels, alpha=1.0e3):
     interior = [_vector_table(*po.coarse_cell_interior_patches((cells[l + 1],) * 2, 2)) for l in range(nlevels - 1)]
     return dict(mats=mats, prolongations=Ps, restrictions=Rs, star_patches=star, interior_patches=interior, graddiv=Gs[:-1],
                 ncells=cells)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# distributed runs (test/Applications/mpi/StokesGMG.jl:5-12): who owns which dof
+# ----------------------------------------------------------------------------------------------------------------------
+def velocity_owner(ncells, grid):
+    """Owner rank of every FREE velocity dof of the n x n-cell Q2 space (dof = 2 * free node + component, free nodes
+    lexicographic): a node goes with the cell box of the px x py rank grid it lies in, interface nodes with the upper box's lower
+    neighbour -- i.e. node i in 1..2n-1 belongs to box min((i-1) // (2n/px), px-1), the rule of partition._LevelGeom."""
+    n, (px, py) = int(ncells), tuple(grid)[:2]
+    nn = 2 * n + 1
+    i = np.arange(1, nn - 1)
+    ox = np.minimum((i - 1) // (2 * n // px), px - 1)
+    oy = np.minimum((i - 1) // (2 * n // py), py - 1)
+    node_owner = (oy[:, None] * px + ox[None, :]).reshape(-1)
+    return np.repeat(node_owner, 2)
+
+
+def pressure_owner(ncells, grid):
+    """Owner of every kept pressure dof (3 per cell, the last dof of the last cell removed by the zero-mean constraint): its cell's box"""
+    n, (px, py) = int(ncells), tuple(grid)[:2]
+    c = np.arange(n)
+    cell_owner = (np.minimum(c // (n // py), py - 1)[:, None] * px + np.minimum(c // (n // px), px - 1)[None, :]).reshape(-1)
+    return np.repeat(cell_owner, 3)[: 3 * n * n - 1]
+
+
+def patch_owner(pp, pd, dof_owner):
+    """Every patch belongs to exactly one rank: the owner of its first (smallest) dof; empty patches to rank 0"""
+    first = np.where(pp[1:] > pp[:-1], pd[np.minimum(pp[:-1], max(pd.size - 1, 0))], 0) if pd.size else np.zeros(pp.size - 1, dtype=np.int64)
+    own = dof_owner[first.astype(np.int64)] if pd.size else np.zeros(pp.size - 1, dtype=np.int64)
+    return np.where(pp[1:] > pp[:-1], own, 0).astype(np.int64)

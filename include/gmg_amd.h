@@ -168,7 +168,8 @@ GMG_API int gmg_set_prolongation_patch_correction(gmg_handle_t h, int lev, int k
 /* rhs form of that correction when it differs from the level operator: PatchProlongationOperator(lev,sh,ptopo,lhs,rhs)
  * solves lhs(u_i,v_i) = rhs(uH,v_i) (PatchTransferOperators.jl:30-50); the Stokes application passes lhs = the velocity
  * form and rhs = the grad-div term only (test/Applications/StokesGMG.jl:125-127).  G = the assembled rhs form on level lev
- * (square, same format options as gmg_set_matrix); lhs patch blocks: A[p,p], or the caller's via the patch tables. */
+ * (square, same format options as gmg_set_matrix); lhs patch blocks: A[p,p], or the caller's via the patch tables.   On a distributed level (gmg_set_partition first) the matrix holds this rank's rows
+ * with [own | ghost] columns, and every correction patch must lie inside the owned dofs (coarse-cell interiors do). */
 GMG_API int gmg_set_prolongation_patch_correction_rhs(gmg_handle_t h, int lev, int64_t n, int64_t nnz, const void *ptr,
                                                       const void *idx, const double *val, int layout, int index_base,
                                                       int index_bytes);

@@ -7,7 +7,7 @@ ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-weak-ref $*"
 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/trace.log 2>&1
 timeout -k 5 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/fetch.log 2>&1
 timeout -k 5 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/write.log 2>&1

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--cmd", default="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
     ap.add_argument("--no-latest", action="store_true")
+    ap.add_argument("--bench-log", default=None, help="stdout of the profiled bench.py run (default: <src>/trace.log): its JSON line supplies the sweep signatures")
     a = ap.parse_args()
     src, out = a.src, a.out
     lines = []
@@ -124,8 +125,26 @@ def main():
             tl.append(f"  HBM traffic per launch = {ffac:.3f}*FETCH + {wfac:.3f}*WRITE = {fb/1e6:.1f} MB + {wb/1e6:.1f} MB = {(fb+wb)/1e6:.1f} MB "
                       f"-> {(fb+wb)/avg_us/1e3:.0f} GB/s at the kernel-trace duration")
         recs.append(rec)
+    # sweep signatures as the library reported them in the profiled run (gmg_sweep_signature, printed by bench.py), and the sha of
+    # the kernel source: bench.py attaches these measurements only to runs of the same kernels
+    sigs = {}
+    try:
+        blog = a.bench_log or os.path.join(src, "trace.log")
+        line = [ln for ln in open(blog).read().splitlines() if ln.startswith("{") and '"roofline"' in ln][-1]
+        bj = json.loads(line)
+        for fam_leg, blk in (("generic", bj.get("roofline")), ("default", bj.get("roofline_compressed")),
+                             ("varcoef", (bj.get("variable_coefficient") or {}).get("roofline"))):
+            if blk and blk.get("sweep_signature"):
+                sigs[blk["sweep_signature"].split("<")[0].replace("sells_sweep_kernel", "sells_kernel")] = blk["sweep_signature"]
+    except Exception as e:
+        tl.append(f"# (no sweep signatures: {e})")
+    for rec in recs:
+        rec["signature"] = sigs.get(rec["family"])
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = hashlib.sha256(open(os.path.join(root, "gridapsolvers.jl_amd", "csrc", "kernels.hpp"), "rb").read()).hexdigest()[:16]
     recs.sort(key=lambda r: -r["avg_us_kernel_trace"])      # per family the finest level (the slowest launch) comes first: bench.py takes the first match
-    res = dict(tag=os.path.basename(out), command=a.cmd, calibration=cal, kernels=recs)
+    res = dict(tag=os.path.basename(out), command=a.cmd, calibration=cal, kernels_hpp_sha=sha, kernels=recs)
     open(out + "_hbm_traffic.txt", "w").write("\n".join(tl) + "\n")
     json.dump(res, open(out + "_hbm_traffic.json", "w"), indent=1)
     if not a.no_latest:

@@ -248,6 +248,122 @@ def block_mode(cells, nlev, out, transport, rank, world, dist, torch, pkg, po, p
     dist.destroy_process_group()
 
 
+def stokes_mode(n, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, multigpu):
+    """test/Applications/mpi/StokesGMG.jl:5-12 on the synthesised lid-driven cavity (stokes.py): vector-valued Q2 velocity and
+    discontinuous P1 pressure partitioned by cell boxes (dpartition.py), distributed velocity GMG(maxiter=4) with owned
+    vertex-star patch smoothers (caller-assembled patch matrices, assemble!) and the patch-corrected prolongation with the
+    grad-div rhs form, CG-Jacobi pressure block, upper block-triangular preconditioner, FGMRES(20) -- against the serial oracle."""
+    from gridapsolvers_jl_amd import stokes as st, dpartition as dp
+    alpha = 1.0e3
+    ndev = torch.cuda.device_count()
+    dev = rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
+    grid = pa.rank_grid(world, 2)
+    sysd, Hv = st.stokes_system(n, alpha), st.velocity_hierarchy(n, nlev, alpha)
+    cells, npart = Hv["ncells"], nlev - 1                        # levels 0 .. nlev-2 partitioned, the coarsest replicated
+    V = [dp.Space(f"v{l}", st.velocity_owner(cells[l], grid), world) for l in range(nlev)]
+    Pq = dp.Space("p", st.pressure_owner(n, grid), world)
+    A = sysd["A"]
+    sc = lambda M: M.to_scipy()
+    ops = [(sc(A[0][0]), V[0], V[0]), (sc(A[0][1]), V[0], Pq), (sc(A[1][0]), Pq, V[0]), (sc(sysd["Mp_scaled"]), Pq, Pq)]
+    pats, star_own, int_own = [], [], []
+    for l in range(npart):
+        ops += [(sc(Hv["mats"][l]), V[l], V[l]), (sc(Hv["graddiv"][l]), V[l], V[l]), (sc(Hv["restrictions"][l]), V[l + 1], V[l])]
+        if l + 1 < npart:
+            ops.append((sc(Hv["prolongations"][l]), V[l], V[l + 1]))
+        star_own.append(st.patch_owner(*Hv["star_patches"][l], V[l].owner))
+        int_own.append(st.patch_owner(*Hv["interior_patches"][l], V[l].owner))
+        pats += [(*Hv["star_patches"][l], V[l], star_own[l]), (*Hv["interior_patches"][l], V[l], int_own[l])]
+    dp.partition_spaces(V + [Pq], ops, pats)
+
+    class LL:
+        overlap = False
+
+    def plan_of(obj, S):
+        pl = S.plan[rank]
+        obj.n_own, obj.n_ghost = S.n_own(rank), S.n_ghost(rank)
+        obj.nbr_rank, obj.snd_ptr, obj.snd_idx, obj.rcv_ptr = pl["nbr_rank"], pl["snd_ptr"], pl["snd_idx"], pl["rcv_ptr"]
+    levels, ptabs, ctabs = [], [], []
+    rep_gid = np.zeros(0, dtype=np.int64)
+    for l in range(nlev):
+        L = LL()
+        if l < npart:
+            plan_of(L, V[l])
+            L.replicated = False
+            L.A = dp.local_operator(sc(Hv["mats"][l]), V[l], V[l], rank)
+            if l + 1 < npart:
+                L.P = dp.local_operator(sc(Hv["prolongations"][l]), V[l], V[l + 1], rank)
+                L.R = dp.local_operator(sc(Hv["restrictions"][l]), V[l + 1], V[l], rank)
+            else:                                               # boundary to the replicated level: global coarse columns, this rank's coarse rows
+                Pg = sc(Hv["prolongations"][l]).tocsr()[V[l].own[rank]]
+                Pg.sort_indices()
+                L.P = po.CSR(Pg.shape, Pg.indptr.astype(np.int64), Pg.indices.astype(np.int32), Pg.data)
+                L.R = dp.local_operator(sc(Hv["restrictions"][l]), V[l + 1], V[l], rank)
+                rep_gid = V[l + 1].own[rank]
+            ptr, loc, _g, blocks = dp.local_patches(*Hv["star_patches"][l], V[l], star_own[l], rank, sc(Hv["mats"][l]))
+            ptabs.append((ptr, loc, blocks))
+            cptr, cloc, _cg, _ = dp.local_patches(*Hv["interior_patches"][l], V[l], int_own[l], rank)
+            ctabs.append((cptr, cloc, dp.local_operator(sc(Hv["graddiv"][l]), V[l], V[l], rank)))
+        else:
+            L.replicated = True
+            L.A = Hv["mats"][l]
+            L.n_own, L.n_ghost = L.A.shape[0], 0
+            ptabs.append(None); ctabs.append(None)
+        levels.append(L)
+    local = dict(levels=levels, rep_from=npart, rep_gid=np.ascontiguousarray(rep_gid, dtype=np.int64), cells=[(c, c) for c in cells],
+                 grid=grid, order=2, rank=rank, nranks=world)
+    g = multigpu.DistributedGMG((n // grid[0], n // grid[1]), nlev, rank, world, device_id=dev, transport=transport, order=2, niter=10, omega=0.2,
+                                gmg_maxiter=4, gmg_rtol=1e-8, local_hierarchy=local, smoother="patch", patch_tables=ptabs, pcorr_tables=ctabs,
+                                cells_global=(n, n))
+    nu, npp = sysd["sizes"]
+    # (1) the distributed velocity GMG alone
+    rg = np.random.default_rng(2).uniform(-1, 1, nu)
+    z = np.zeros(V[0].n_own(rank))
+    glog = g.apply(np.ascontiguousarray(rg[V[0].own[rank]]), z, maxiter=4)
+    # (2) the whole solve
+    lev1 = LL(); plan_of(lev1, Pq)
+    A01 = dp.local_operator(sc(A[0][1]), V[0], Pq, rank)
+    A10 = dp.local_operator(sc(A[1][0]), Pq, V[0], rank)
+    M11 = dp.local_operator(sc(sysd["Mp_scaled"]), Pq, Pq, rank)
+    blk = multigpu.DistributedBlockSolver(g, A01, A10, M11, levels[0], lev1, A11=None, coeffs=((1.0, 1.0), (0.0, 1.0)), half="upper", cg=(20, 1e-14, 1e-6))
+    bg = sysd["b"]
+    b = np.concatenate([bg[:nu][V[0].own[rank]], bg[nu:][Pq.own[rank]]])
+    x = np.zeros_like(b)
+    log = blk.fgmres_solve(b, x, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+    parts = [None] * world
+    dist.all_gather_object(parts, (V[0].own[rank], Pq.own[rank], x, z, int(log.num_iters), log.residuals[: log.num_iters + 1].tolist(), int(glog.num_iters)))
+    if rank == 0:
+        orc = entry.import_oracle()
+        osm = [orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in Hv["star_patches"]]
+
+        def make_go():
+            return orc.GMG(Hv["mats"], Hv["prolongations"], Hv["restrictions"], pre_smoothers=osm, maxiter=4, rtol=1e-8,
+                           prolongation_patches=[(orc.PATCH, *Hv["interior_patches"][l], Hv["graddiv"][l]) for l in range(nlev - 1)])
+        zo, nit_g, _, _ = make_go().solve(rg)
+        Po = orc.BlockPreconditioner([nu, npp], [make_go(), (orc.BD_CG_JACOBI, sysd["Mp_scaled"], 20, 1e-14, 1e-6)],
+                                     {(0, 1): (A[0][1], 1.0), (1, 0): (A[1][0], 0.0)}, orc.UPPER)
+        K = sysd["K"]
+        Kc = po.CSR(K.shape, K.indptr, K.indices, K.data)
+        xo, nit, flag, hist = orc.fgmres_solve(Kc, bg, Pr=Po, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+        xg, zg = np.zeros(nu + npp), np.zeros(nu)
+        for vo, pown, xq, zq, _, _, _ in parts:
+            xg[vo] = xq[: vo.size]; xg[nu + pown] = xq[vo.size:]
+            zg[vo] = zq
+        hist_d = np.array(parts[0][5])
+        verdict = dict(iters=int(parts[0][4]), iters_oracle=int(nit), iters_all_equal=all(p[4] == parts[0][4] for p in parts),
+                       gmg_iters=int(parts[0][6]), gmg_iters_oracle=int(nit_g),
+                       gmg_rel_err=float(np.linalg.norm(zg - zo) / np.linalg.norm(zo)),
+                       rel_err=float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)),
+                       hist_dev=float(np.max(np.abs(hist_d - hist) / hist[0])) if len(hist_d) == len(hist) else 1.0,
+                       true_residual=float(np.linalg.norm(K @ xg - bg)), div_residual=float(np.linalg.norm(sc(A[1][0]) @ xg[:nu] - bg[nu:])),
+                       umax=float(xg[:nu].max()), world=world, grid=list(grid), mode="gpu_stokes",
+                       ghosts=[int(V[0].n_ghost(0)), int(Pq.n_ghost(0))])
+        json.dump(verdict, open(out, "w"))
+    dist.barrier()
+    blk.close(); g.close()
+    dist.destroy_process_group()
+
+
 def main():
     mode, cells, nlev, out = sys.argv[1], tuple(int(c) for c in sys.argv[2].split("x")), int(sys.argv[3]), sys.argv[4]
     transport = sys.argv[5] if len(sys.argv) > 5 else "host"
@@ -268,6 +384,8 @@ def main():
     p_niter, p_omega = 4, 0.2
     depth = int(os.environ.get("GMG_TEST_DEPTH", "0"))      # > 0: partitioned levels >= 1 in the overlapping layout with that many ghost layers
     verdict = {}
+    if mode == "gpu_stokes":
+        return stokes_mode(cells[0], nlev, out, transport, rank, world, dist, torch, pkg, po, pa, multigpu)
     if mode == "gpu_block":
         pass
     elif mode == "numpy":

@@ -291,6 +291,25 @@ def test_rccl_binding_selftest_single_rank(pkg):
 
 
 @pytest.mark.gpu
+def test_bench_multi_rank_path_with_overlapping_levels(tmp_path):
+    """`bench.py --gpus 2` with the planner forced to keep level 1 partitioned in the overlapping layout (depth 5): the N > 1 line
+    carries both legs, the partition plan and the per-solve exchange counts."""
+    import subprocess
+    env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1",
+               GMG_REP_ROWS="3000", GMG_HALO_DEPTH="5")
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "32", "--levels", "4",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["headline_leg"] == "default" and d["roofline"]["leg"] == "default" and d["roofline_generic"]["leg"] == "generic"
+    assert d["config"]["halo_depths"][:3] == [0, 5, 0] and d["config"]["replicated_from_level"] == 2
+    assert d["config"]["cg_iterations"] == d["config"]["cg_iterations_generic"] <= 4 and d["config"]["max_abs_error_vs_exact"] < 1e-4
+    assert d["value_generic"] > 0 and d["config"]["halo_exchanges_per_solve"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(tmp_path):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), both ranks sharing the single
     GPU of the test box over the host-staged transport: the JSON contract of the multi-rank line and the joint self-check."""
@@ -308,3 +327,58 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(tmp_path):
     assert d["config"]["transport"] == "host" and d["config"]["degraded"] is True
     assert d["config"]["cg_iterations"] <= 4 and d["config"]["max_abs_error_vs_exact"] < 1e-4
     assert d["roofline"]["frac"] is None or d["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,nlev", [(2, 8, 2), (4, 16, 3), (2, 16, 3)])
+def test_distributed_real_stokes_on_gpu_host_transport(world, n, nlev, tmp_path):
+    """BASELINE configs[4] in its multi-rank form (test/Applications/mpi/StokesGMG.jl:5-12): the lid-driven-cavity Q2 / P1disc
+    system partitioned by cell boxes over `world` ranks (all on the one GPU of the test box, host transport) -- vector-valued
+    velocity hierarchy with owned vertex-star patch smoothers and the DISTRIBUTED patch-corrected prolongation, CG-Jacobi
+    pressure block, upper block-triangular preconditioner, FGMRES(20): iteration counts equal the serial oracle's, solution
+    <= 1e-6, true residual < 1e-7 (StokesGMG.jl:166), discretely divergence-free."""
+    v = _launch("gpu_stokes", world, (n, n), nlev, tmp_path, transport="host")
+    assert v["gmg_iters"] == v["gmg_iters_oracle"] and v["gmg_rel_err"] < 1e-8, v
+    assert v["iters"] == v["iters_oracle"] and v["iters_all_equal"], v
+    assert v["rel_err"] < 1e-6 and v["hist_dev"] < 1e-6, v
+    assert v["true_residual"] < 1e-7 and v["div_residual"] < 1e-7 and v["umax"] > 0.3, v
+    assert v["ghosts"][0] > 0 and v["ghosts"][1] > 0
+
+
+def test_generic_partitioner_reproduces_the_stokes_operators(po, pkg):
+    """dpartition.py on the Q2 / P1disc Stokes blocks and the velocity hierarchy: local operators reproduce the global mat-vecs,
+    every dof has exactly one owner, both sides of every exchange agree, owned patches cover the serial patch set exactly once."""
+    from gridapsolvers_jl_amd import stokes as st, dpartition as dp, partition as pa
+    n, nlev, nranks = 8, 2, 4
+    grid = pa.rank_grid(nranks, 2)
+    sysd, Hv = st.stokes_system(n), st.velocity_hierarchy(n, nlev)
+    V = [dp.Space(f"v{l}", st.velocity_owner(Hv["ncells"][l], grid), nranks) for l in range(nlev)]
+    Pq = dp.Space("p", st.pressure_owner(n, grid), nranks)
+    A = sysd["A"]
+    ops = [(A[0][0].to_scipy(), V[0], V[0]), (A[0][1].to_scipy(), V[0], Pq), (A[1][0].to_scipy(), Pq, V[0]),
+           (Hv["restrictions"][0].to_scipy(), V[1], V[0]), (Hv["graddiv"][0].to_scipy(), V[0], V[0])]
+    pp, pd = Hv["star_patches"][0]
+    powner = st.patch_owner(pp, pd, V[0].owner)
+    dp.partition_spaces(V + [Pq], ops, [(pp, pd, V[0], powner)])
+    rng = np.random.default_rng(0)
+    for M, rs, cs in ops:
+        x = rng.uniform(-1, 1, cs.n)
+        y = M @ x
+        for r in range(nranks):
+            Ml = dp.local_operator(M, rs, cs, r)
+            assert np.abs(Ml.matvec(x[cs.local_gid(r)]) - y[rs.own[r]]).max() < 1e-11
+    for S_ in V + [Pq]:
+        assert sum(S_.n_own(r) for r in range(nranks)) == S_.n
+        for r in range(nranks):
+            pl = S_.plan[r]
+            for k, q in enumerate(pl["nbr_rank"]):
+                plq = S_.plan[q]
+                kk = list(plq["nbr_rank"]).index(r)
+                sent = S_.own[r][pl["snd_idx"][pl["snd_ptr"][k]:pl["snd_ptr"][k + 1]]]
+                assert np.array_equal(sent, S_.ghost[q][plq["rcv_ptr"][kk]:plq["rcv_ptr"][kk + 1]])
+    got = []
+    for r in range(nranks):
+        ptr, loc, glob, blocks = dp.local_patches(pp, pd, V[0], powner, r, Hv["mats"][0].to_scipy())
+        assert np.array_equal(V[0].local_gid(r)[loc], glob) and blocks.size == int(((ptr[1:] - ptr[:-1]) ** 2).sum())
+        got += [tuple(glob[ptr[p]:ptr[p + 1]]) for p in range(ptr.size - 1) if ptr[p + 1] > ptr[p]]
+    assert sorted(got) == sorted(tuple(pd[pp[p]:pp[p + 1]]) for p in range(pp.size - 1) if pp[p + 1] > pp[p])

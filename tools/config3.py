@@ -28,6 +28,7 @@ ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--stream-min-rows", type=int, default=1000000)
 ap.add_argument("--no-l2", action="store_true")
+ap.add_argument("--profile", action="store_true", help="cProfile of numerical_setup (top 30 by cumulative time, stderr)")
 a = ap.parse_args()
 
 pkg = entry.import_package()
@@ -51,7 +52,14 @@ gmg = S.GMGLinearSolver(H["mats"], H["prolongations"], H["restrictions"], pre_sm
 solver = S.FGMRESSolver(5, gmg, maxiter=20, atol=1e-14, rtol=1e-6)
 os.environ.setdefault("GMG_SETUP_TIMING", "1")
 t0 = time.time()
-ns = S.numerical_setup(S.symbolic_setup(solver, H["mats"][0]), H["mats"][0])
+if a.profile:
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    ns = pr.runcall(S.numerical_setup, S.symbolic_setup(solver, H["mats"][0]), H["mats"][0])
+    pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(30)
+else:
+    ns = S.numerical_setup(S.symbolic_setup(solver, H["mats"][0]), H["mats"][0])
 t_setup = time.time() - t0
 del sm, gmg.pre_smoothers[:], gmg.post_smoothers[:]
 bd = torch.from_numpy(b).cuda()
