@@ -47,7 +47,8 @@ struct gmg_block_solver {
   // x_j with its ghost entries filled (consistent!): own part copied into the work vector, halo exchanged
   const double *with_ghosts(int j, const double *xj)
   {
-    if (!distributed() || (size_t)j >= plan.size() || !plan[j].present || plan[j].n_ghost == 0) return xj;
+    // (a rank without ghosts of its own may still have to SEND: discontinuous pressure spaces -- only "no neighbours" skips the exchange)
+    if (!distributed() || (size_t)j >= plan.size() || !plan[j].present || plan[j].nbr.empty()) return xj;
     eng.copy(xg[j], xj, bsize(j));
     eng.exchange_plan(plan[j], xg[j], eng.stream);
     return xg[j];

@@ -3916,7 +3916,7 @@ static Smoother make_patch_smoother(int niter, double omega, int kind, int64_t n
   for (int64_t p = 0; p < npatch; ++p) REQUIRE(T.pptr[p] <= T.pptr[p + 1], GMG_ERR_INVALID, "patch_ptr not monotone");
   const int64_t tot = T.pptr[npatch];
   T.prow.resize((size_t)tot);
-  for (int64_t q = 0; q < tot; ++q) T.prow[q] = (int32_t)(read_index(patch_rows, q, index_bytes) - index_base);
+  parallel_for(tot, [&](int64_t q) { T.prow[(size_t)q] = (int32_t)(read_index(patch_rows, q, index_bytes) - index_base); });
   if (patch_cols && patch_cols != patch_rows) {
     T.pcol.resize((size_t)tot);
     bool same = true;

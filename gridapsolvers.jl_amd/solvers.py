@@ -444,7 +444,15 @@ class GMGNumericalSetup:
             abi.check(h, lib.gmg_set_smoother_jacobi(h, l, which, sm.niter, sm.omega))
         else:
             M = sm.M
-            pp, pd = M.patch_ptr, M.patch_dofs.astype(np.int64)
+            pp = M.patch_ptr
+            if M.patch_cols is None and M.patch_mats is None and M.factors is None:
+                if M.patch_dofs.dtype == np.int32 and int(pp[-1]) < 2 ** 31 - 1:
+                    # int32 tables as they are (1.7e7 vertex-star patches of a 256^3 Q2 level: 4.6e8 entries), the short pointer array narrowed
+                    pp32, pd = np.ascontiguousarray(pp, dtype=np.int32), np.ascontiguousarray(M.patch_dofs)
+                    abi.check(h, lib.gmg_set_smoother_patch(h, l, which, sm.niter, sm.omega, M.kind, pp.size - 1,
+                                                            C.c_void_p(pp32.ctypes.data), C.c_void_p(pd.ctypes.data), 0, 4))
+                    return
+            pp, pd = np.ascontiguousarray(pp, dtype=np.int64), M.patch_dofs.astype(np.int64)
             if M.patch_cols is None and M.patch_mats is None and M.factors is None:
                 abi.check(h, lib.gmg_set_smoother_patch(h, l, which, sm.niter, sm.omega, M.kind, pp.size - 1,
                                                         C.c_void_p(pp.ctypes.data), C.c_void_p(pd.ctypes.data), 0, 8))

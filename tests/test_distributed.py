@@ -29,15 +29,20 @@ def _launch(mode, world, cells, nlev, tmp_path, transport="host", timeout=600, r
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode,
                                        "x".join(map(str, cells)), str(nlev), out, transport, str(rep_from)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    import time as _time
     logs = []
-    try:
-        for p in procs:
-            o, _ = p.communicate(timeout=timeout)
-            logs.append(o.decode(errors="replace")[-2000:])
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    t_end = _time.time() + timeout
+    # a rank that dies leaves the others blocked in a collective: stop waiting as soon as one has failed
+    while _time.time() < t_end and any(p.poll() is None for p in procs) and not any(p.poll() not in (None, 0) for p in procs):
+        _time.sleep(0.2)
+    if any(p.poll() not in (None, 0) for p in procs):
+        _time.sleep(2.0)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+    for r, p in enumerate(procs):
+        o, _ = p.communicate()
+        logs.append(f"---- rank {r} (rc {p.returncode}) ----\n" + o.decode(errors="replace")[-3000:])
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
     v = json.load(open(out))
     if os.path.exists(out + ".x.npy"):
