@@ -3608,14 +3608,23 @@ void check_level(gmg_handle_t h, int lev, bool not_coarsest)
   if (not_coarsest) REQUIRE(lev < h->nlev - 1, GMG_ERR_INVALID, "level must not be the coarsest");
 }
 // exchange plan of one vector space (PartitionedArrays: assembly neighbours + local indices), validated
+void fill_plan_checked(HaloPlan &H, const Comm &comm, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
+                       const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr, const int64_t *rcv_idx, int depth);
+// the plan is built aside and replaces the level's only when every check has passed (a rejected call leaves no half-filled plan)
 void fill_plan(HaloPlan &H, const Comm &comm, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
                const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr, const int64_t *rcv_idx = nullptr, int depth = 1)
 {
+  HaloPlan T;
+  fill_plan_checked(T, comm, n_own, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr, rcv_idx, depth);
+  if (H.h_send) (void)hipHostFree(H.h_send);               // pinned buffers of the plan that is replaced
+  if (H.h_recv) (void)hipHostFree(H.h_recv);
+  H = std::move(T);
+}
+void fill_plan_checked(HaloPlan &H, const Comm &comm, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
+                       const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr, const int64_t *rcv_idx, int depth)
+{
   REQUIRE(n_own >= 0 && n_ghost >= 0 && nnbr >= 0, GMG_ERR_INVALID, "negative sizes");
   REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
-  double *hs = H.h_send, *hr = H.h_recv;                   // pinned buffers survive a re-plan only if sizes allow: drop them
-  if (hs) (void)hipHostFree(hs);
-  if (hr) (void)hipHostFree(hr);
   H = HaloPlan();
   H.present = true; H.n_own = n_own; H.n_ghost = n_ghost;
   H.nbr.assign(nbr_rank, nbr_rank + nnbr);

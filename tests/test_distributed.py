@@ -335,7 +335,7 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,nlev", [(2, 8, 2), (4, 16, 3), (2, 16, 3)])
+@pytest.mark.parametrize("world,n,nlev", [(2, 8, 2), (4, 16, 3), (2, 16, 3), (8, 16, 3)])
 def test_distributed_real_stokes_on_gpu_host_transport(world, n, nlev, tmp_path):
     """BASELINE configs[4] in its multi-rank form (test/Applications/mpi/StokesGMG.jl:5-12): the lid-driven-cavity Q2 / P1disc
     system partitioned by cell boxes over `world` ranks (all on the one GPU of the test box, host transport) -- vector-valued

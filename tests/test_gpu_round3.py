@@ -141,3 +141,36 @@ def test_config3_q2_128cubed_properties(S, po):
     assert np.max(np.abs(x - po.nodal_values(nc, order))) < 1e-5
     assert ns.P_ns.level_format(0)["row_patterns"] and ns.P_ns.device_bytes() < 8e9
     assert t_setup < 60.0, t_setup
+
+
+# ---------------------------------------------------------------- structured row streams: declared repetitions
+@pytest.mark.parametrize("order,nc", [(1, (24, 24, 24)), (2, (12, 12, 12))])
+def test_repeated_row_blocks_equal_the_sent_ones(S, po, order, nc, monkeypatch):
+    """gmg_set_operator_rows_repeat: a hierarchy whose operators are streamed with the recurring node planes DECLARED (no arrays,
+    nothing hashed) gives bit-identical operator applications and CG+GMG solves to the same stream with every plane sent, and to
+    the whole matrices handed over at once."""
+    from gridapsolvers_jl_amd import abi
+    nlev = 2
+    Hs = po.build_hierarchy(nc, nlev, order, stream_min_rows=5000)
+    Hw = po.build_hierarchy(nc, nlev, order)
+    assert hasattr(Hs["mats"][0], "row_plan") and any(it[0] == "repeat" for it in Hs["mats"][0].row_plan())
+    b = po.dirichlet_lift_rhs(nc, order)
+    xin = np.random.default_rng(3).uniform(-1, 1, b.size)
+    out = {}
+    for tag, H, rep in (("repeat", Hs, "1"), ("sent", Hs, "0"), ("whole", Hw, "1")):
+        monkeypatch.setenv("GMG_STREAM_REPEAT", rep)
+        solver = S.CGSolver(make_gmg(S, H), maxiter=30, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        y = np.zeros_like(b)
+        ns.P_ns.op_apply(0, abi.OP_A, xin, y)
+        yc = np.zeros(Hw["mats"][1].shape[0])
+        ns.P_ns.op_apply(0, abi.OP_R, xin, yc)
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        out[tag] = (y, yc, x, solver.log.num_iters)
+        ns.P_ns.close()
+    for tag in ("sent", "whole"):
+        assert np.array_equal(out["repeat"][0], out[tag][0]) and np.array_equal(out["repeat"][1], out[tag][1])
+        assert out["repeat"][3] == out[tag][3]
+    assert np.array_equal(out["repeat"][2], out["sent"][2])
+    assert rel_err(out["repeat"][2], out["whole"][2]) <= 1e-12
