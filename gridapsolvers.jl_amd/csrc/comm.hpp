@@ -173,6 +173,8 @@ __global__ void sqrt_inplace_kernel(double *v) { v[0] = sqrt(v[0]); }
 //   MODE 0: y[row] += g                         (y = A x)
 //   MODE 1: y[row] -= g                         (y -= A x ; y = b - A x)
 //   MODE 2: y[row] -= g ; s[row] = omega*(dinv[row]*y[row])   (fused sweep: r and s = w*Dinv*r)
+//   MODE 3: g = sum_k val[k] * (omega*(du*v[col[k]])) ; y[row] -= g   (the sweep that gathers r itself, uniform 1/diag du:
+//           sells_rsweep_kernel; the send buffer then carries the new r of the boundary rows)
 // The owned-column part ran while the exchange was in flight (own x own / own x ghost split of
 // the local matrix, the standard PartitionedArrays-style overlap).
 // pk_ptr / pk_slot / sendbuf (MODE 2, optional): the boundary rows are exactly the rows the neighbours need, so the
@@ -183,16 +185,23 @@ __global__ void ghost_fix_kernel(int64_t nb, const int32_t *__restrict__ rows, c
                                  const int32_t *__restrict__ col, const double *__restrict__ val,
                                  const double *__restrict__ v, double *__restrict__ y, const double *__restrict__ dinv,
                                  double omega, double *__restrict__ s_out, const int64_t *__restrict__ pk_ptr = nullptr,
-                                 const int32_t *__restrict__ pk_slot = nullptr, double *__restrict__ sendbuf = nullptr)
+                                 const int32_t *__restrict__ pk_slot = nullptr, double *__restrict__ sendbuf = nullptr, double du = 0.0)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
   double g = 0.0;
+  if (MODE == 3) { for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) g += val[k] * (omega * (du * v[col[k]])); }
+  else
   for (int64_t k = ptr[i]; k < ptr[i + 1]; ++k) g += val[k] * v[col[k]];
   const int32_t row = rows[i];
   if (MODE == 0) y[row] = y[row] + g;
   else if (MODE == 1) y[row] = y[row] - g;
-  else {
+  else if (MODE == 3) {
+    const double rn = y[row] - g;
+    y[row] = rn;
+    if (pk_ptr)
+      for (int64_t k = pk_ptr[i]; k < pk_ptr[i + 1]; ++k) sendbuf[pk_slot[k]] = rn;
+  } else {
     const double rn = y[row] - g;
     y[row] = rn;
     const double sn = omega * (dinv[row] * rn);

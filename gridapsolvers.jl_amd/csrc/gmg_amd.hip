@@ -247,6 +247,8 @@ struct DevCSR {
   int32_t *prun = nullptr;
   int pat_nruns = 0, pat_minoff = 0, pat_maxoff = 0;
   double *pdinv = nullptr;      // [np] 1/diag per pattern (nullptr: some pattern has no diagonal entry)
+  double pdinv_u = 0.0;         // that number
+  bool pdinv_uniform = false;   // every pattern has the same 1/diag, bit for bit (constant-coefficient operator on a uniform mesh): sells_rsweep_kernel
   bool pat_generic = false;     // the per-lane-offset table (sellp_kernel) fits LDS
   int pat_k = 3;                // offsets per run of the shared form
   bool pat_coded = false;       // shared form with one-byte value codes + dictionary
@@ -544,6 +546,7 @@ struct gmg_solver {
   int n_cus = 0;
   uint32_t *d_perr_dev = nullptr;                  // device-memory twin (the kernel's end-of-pass check)
   uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
+  int pat_rsweep = 1;   // GMG_PAT_RSWEEP: sweeps of uniform-diagonal row-pattern levels gather r itself (no s vector: sells_rsweep_kernel)
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
   int pat_dinv = 1;     // GMG_PAT_DINV: Jacobi inverse diagonal from the pattern table instead of its vector
   int pat_shared = 1;   // GMG_PAT_SHARED: shared-offset (stencil) form when the offsets are row-relative
@@ -1088,7 +1091,12 @@ struct gmg_solver {
           if (P.off[P.start[p] + j] == 0) { double v; std::memcpy(&v, &P.val[P.start[p] + j], 8); pd[p] = 1.0 / v; f = true; }
         all = f;
       }
-      if (all) D.pdinv = upload(pd);
+      if (all) {
+        D.pdinv = upload(pd);
+        D.pdinv_u = np >= 1 ? pd[0] : 0.0;
+        D.pdinv_uniform = np >= 1;
+        for (int p = 1; p < np; ++p) D.pdinv_uniform = D.pdinv_uniform && std::memcmp(&pd[p], &pd[0], 8) == 0;
+      }
     }
     upload_pattern(D, P.nrows, P.rowpid, P.rowbase, plen, poff, pval, W, generic, true);
     return D;                                                // P keeps its per-row ids (2-6 B/row): gmg_setup may run again
@@ -1169,7 +1177,12 @@ struct gmg_solver {
             if (poff8[(size_t)p * W + j] == 0) { pd[p] = 1.0 / pval[(size_t)p * W + j]; found = true; }
           all = found;
         }
-        if (all) D.pdinv = upload(pd);
+        if (all) {
+          D.pdinv = upload(pd);
+          D.pdinv_u = np >= 2 ? pd[0] : 0.0;
+          D.pdinv_uniform = np >= 2;                         // (the last pattern is the empty one)
+          for (int p = 1; p < np - 1; ++p) D.pdinv_uniform = D.pdinv_uniform && std::memcmp(&pd[p], &pd[0], 8) == 0;
+        }
       }
       if (c.coded) {
         if (nruns > 32) continue;                           // run masks are 32-bit
@@ -1629,6 +1642,69 @@ struct gmg_solver {
     launch_stream1<EPI_ADDTO, false, false>(M, a);
   }
   bool one_gather() const { return one_gather_sweep != 0; }
+  // levels whose fused sweeps gather r itself (uniform 1/diag, plain shared-offset table): see sells_rsweep_kernel
+  bool rsweep_level(const Level &L) const
+  {
+    const DevCSR &M = L.A;
+    if (!(pat_rsweep && one_gather_sweep && pat_dinv && M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && pat_rb == 3 && pat_batched)) return false;
+    if (M.pat_nruns % 3 != 0 || !M.pdinv || !M.pdinv_uniform || !L.rbuf[0] || !L.rbuf[1]) return false;
+    const int nu = M.pat_k * M.pat_nruns;
+    return (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16 <= 64 * 1024;
+  }
+  void launch_rsweep(const DevCSR &M, const double *r_cur, double *r_next, const double *r_prev, double *x, bool x_zero, double omega, int xmode)
+  {
+    SellSArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rowpid = M.rowpid; a.tab = M.ptab; a.tab8 = M.ptab8; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
+    a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff; a.xmode = xmode; a.pdinv = M.pdinv;
+    const int rows = 65 - M.pat_k;
+    const int nsl = (int)((M.nrows + rows - 1) / rows);
+    a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl; a.xcd_remap = xcd_remap;
+    a.x_zero = x_zero ? 1 : 0; a.x = r_cur; a.omega = omega; a.y = r_next; a.b = r_cur; a.x2 = x; a.s_out = const_cast<double *>(r_prev);
+    const int wpb = sell_block > 0 ? sell_block / 64 : (nsl >= 256 * 32 ? 4 : pat_small_wpb);
+    const int nu = M.pat_k * M.pat_nruns;
+    const int nb = pat_nb > 0 ? pat_nb : (nsl >= 200000 ? 2 : 1);
+    const int wg2 = std::max(1, std::min((nsl + wpb - 1) / wpb, nb >= 2 && pat_wgs == 2048 ? 1024 : pat_wgs));
+    const dim3 g2(wg2), b(64 * wpb);
+    const size_t lds2 = (size_t)M.pat_np * nu * 16 + 16;
+    const bool mk = pat_strict || !M.ptab8;
+    M.note_sweep("sells_rsweep_kernel<XM=*,NB=%d,MK=%d> wgs=%d wpb=%d", nb >= 2 ? 2 : 1, mk ? 1 : 0, wg2, wpb);
+#define GMG_RSWEEP_LAUNCH(XMV, NBV)                                                                            \
+    do {                                                                                                         \
+      if (mk) hipLaunchKernelGGL((sells_rsweep_kernel<XMV, NBV, true>), g2, b, lds2, stream, a);                 \
+      else hipLaunchKernelGGL((sells_rsweep_kernel<XMV, NBV, false>), g2, b, lds2, stream, a);                   \
+    } while (0)
+    if (nb >= 2) { if (xmode == 0) GMG_RSWEEP_LAUNCH(0, 2); else if (xmode == 1) GMG_RSWEEP_LAUNCH(1, 2); else GMG_RSWEEP_LAUNCH(2, 2); }
+    else { if (xmode == 0) GMG_RSWEEP_LAUNCH(0, 1); else if (xmode == 1) GMG_RSWEEP_LAUNCH(1, 1); else GMG_RSWEEP_LAUNCH(2, 1); }
+#undef GMG_RSWEEP_LAUNCH
+    HIP_CHECK(hipGetLastError());
+  }
+  // one sweep of that form: x (+)= s_k ; r_{k+1} = r_k - A s_k with s_k = omega*(d*r_k) formed from the gathered r_k
+  void rsweep(int l, const Smoother &S, double *x, const double *r_cur, double *r_next, const double *r_prev, bool x_zero, int xmode,
+              bool prepacked, bool pack_next)
+  {
+    Level &L = lev[l];
+    const bool halo_sweep = comm.nranks > 1 && L.halo.present && !L.halo.ovl;
+    if (halo_sweep) begin_exchange(l, const_cast<double *>(r_cur), prepacked);     // the ghosts of r_k
+    const bool prof = (l == prof_level) && (prof_seq++ % (uint64_t)prof_stride == 0) && prof_used + 2 <= prof_ev.size();
+    if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
+    launch_rsweep(L.A, r_cur, r_next, r_prev, x, x_zero, S.omega, xmode);
+    if (prof) {
+      HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
+      prof_w[prof_used / 2] = 1;
+      prof_used += 2;
+    }
+    if (halo_sweep) {
+      if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
+      if (L.split && L.nbnd > 0) {
+        const bool pk = pack_next && L.halo.d_pk_ptr != nullptr;
+        hipLaunchKernelGGL((ghost_fix_kernel<3>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
+                           L.gh_ptr, L.gh_col, L.gh_val, r_cur, r_next, (const double *)nullptr, S.omega, (double *)nullptr,
+                           pk ? L.halo.d_pk_ptr : nullptr, pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr, L.A.pdinv_u);
+        HIP_CHECK(hipGetLastError());
+      }
+    }
+  }
   // fused Richardson-Jacobi sweep: x += w*Dinv*r_old ; r_new = r_old - A*(w*Dinv*r_old)
   // one-gather form: s_old = w*Dinv*r_old is an input, s_new = w*Dinv*r_new an output.
   void sweep(int l, const Smoother &S, double *x, const double *r_old, double *r_new, bool x_zero,
@@ -1863,9 +1939,13 @@ struct gmg_solver {
     spmv_sub(L.A, x, y);
     finish_ghost<1>(l, x, y);
   }
-  bool emits_s0(const Level &L, const Smoother &S, const DevCSR &producer) const
+  bool emits_s0(const Level &L, const Smoother &S, const DevCSR &producer)
   {
-    return pat_emit && comm.nranks == 1 && producer.pat && S.kind == SM_JACOBI && one_gather() && S.niter > 0 && L.sbuf[0] != nullptr && L.dinv != nullptr;
+    if (!(pat_emit && comm.nranks == 1 && producer.pat && S.kind == SM_JACOBI && one_gather() && S.niter > 0 && L.sbuf[0] != nullptr && L.dinv != nullptr)) return false;
+    // levels whose sweeps gather r itself have no use for s_0 -- unless the pass runs as one launch (small levels), which starts from it
+    const int l = (int)(&L - &lev[0]);
+    if (rsweep_level(L) && !smooth_persistent(l, S, nullptr, nullptr, nullptr, false, S.niter, true)) return false;
+    return true;
   }
   void apply_A_resid(int l, double *x, const double *b, double *y)
   {
@@ -1899,7 +1979,8 @@ struct gmg_solver {
 
   // One launch for the whole pass on small single-GPU levels in the shared-offset pattern form (see sells_smooth_kernel).
   // s_0 is in L.sbuf[0].  Returns false when the level does not qualify (the caller then runs sweep by sweep).
-  bool smooth_persistent(int l, const Smoother &S, double *x, const double *r_in, double *r_out, bool x_zero, int niter)
+  // dry = true: only answer whether the pass WOULD run as one launch (nothing is allocated or launched)
+  bool smooth_persistent(int l, const Smoother &S, double *x, const double *r_in, double *r_out, bool x_zero, int niter, bool dry = false)
   {
     Level &L = lev[l];
     const DevCSR &M = L.A;
@@ -1928,6 +2009,7 @@ struct gmg_solver {
     if (2 * halo + 1 > 64) return false;
     const int nwg = (nsl + wpb * ns - 1) / (wpb * ns);
     if (nwg > n_cus) return false;
+    if (dry) return true;
     if (!L.pflags || L.pf_nwg < nwg) {
       if (L.pflags) { HIP_CHECK(hipStreamSynchronize(stream)); release(L.pflags, (size_t)L.pf_nwg * 16); }
       L.pflags = dalloc<uint32_t>((size_t)nwg * 16);
@@ -2031,6 +2113,7 @@ struct gmg_solver {
       const int block = ovl ? std::max(1, std::min(L.halo.depth, S.niter)) : S.niter;
       // shared-offset pattern kernel: x is updated every second sweep with both increments,
       // x = (x + s_{k-1}) + s_k (the same two roundings), which saves one read+write of x per pair
+      const bool rsw = pat_defer && rsweep_level(L);
       const bool sell64 = L.A.sell && !L.A.pat && !L.A.comp_idx && !L.A.vdict && !L.A.opat;
       const bool defer = (pat_defer && L.A.pat_shared) ||
                          (sell_defer && !(comm.nranks > 1 && L.split) && ((sell64 && sell_un >= 6 && sell_un < 9) || (L.A.sell && L.A.opat && sell_un < 27)));
@@ -2041,13 +2124,37 @@ struct gmg_solver {
           if (cur != out) { copy(out, cur, n); cur = out; }   // (levels >= 1 smooth in place: no copy)
           exchange(l, out);
         }
+        const bool xz0 = x_zero && first;
+        const bool one_launch = smooth_persistent(l, S, x, cur, out, xz0, nb, true);
+        if (rsw && !one_launch) {
+          // sweeps that gather r itself (uniform 1/diag): no s vector, no scaled-Jacobi launch; r ping-pongs between the level's
+          // two residual buffers (the gathers read r_k while the rows write r_{k+1}), the result is wherever the last sweep wrote
+          L.s0_ready = false;
+          const double *prev = nullptr;
+          if (comm.nranks > 1 && L.halo.present && !L.halo.ovl && cur != L.rbuf[0] && cur != L.rbuf[1]) {
+            copy(L.rbuf[0], cur, n);                           // the exchange writes the ghost entries of r_k: never into a caller's vector
+            cur = L.rbuf[0];
+          }
+          for (int it = 0; it < nb; ++it) {
+            int xmode = 0;
+            bool xz = xz0 && it == 0;
+            if ((it & 1) == 0 && it + 1 < nb) xmode = 1;
+            else if (it & 1) { xmode = 2; xz = xz0 && it == 1; }
+            double *next = (cur == L.rbuf[0]) ? L.rbuf[1] : L.rbuf[0];
+            const bool fp = can_fuse_pack(l);
+            rsweep(l, S, x, cur, next, prev, xz, xmode, fp && it > 0, fp && it + 1 < nb);
+            prev = cur;
+            cur = next;
+          }
+          out = const_cast<double *>(cur);
+          continue;
+        }
         if (!(first && !ovl && L.s0_ready && L.s0_src == r_in && L.s0_omega == S.omega)) {
           hipLaunchKernelGGL(scaled_jacobi_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, S.omega, L.dinv, cur, L.sbuf[0]);
           HIP_CHECK(hipGetLastError());
         }
         L.s0_ready = false;
-        const bool xz0 = x_zero && first;
-        if (smooth_persistent(l, S, x, cur, out, xz0, nb)) { cur = out; continue; }
+        if (one_launch && smooth_persistent(l, S, x, cur, out, xz0, nb)) { cur = out; continue; }
         for (int it = 0; it < nb; ++it) {
           int xmode = 0;
           bool xz = xz0 && it == 0;
@@ -2295,6 +2402,7 @@ struct gmg_solver {
     halo_fuse_pack = env_int("GMG_HALO_FUSE_PACK", 1);
     prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
     pat_defer = env_int("GMG_PAT_DEFER", 1);
+    pat_rsweep = env_int("GMG_PAT_RSWEEP", 1);
     persist = env_int("GMG_PERSIST", 1);
     // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
     // could keep each other from becoming fully resident, so they are off unless asked for
@@ -2367,6 +2475,7 @@ struct gmg_solver {
       mat = 2.0 * N;                                       // 16-bit pattern id per row; the table lives in LDS
       if (pat_dinv && A.pdinv) vec -= 8.0 * N;             // 1/diag from the pattern table
       if (pat_defer) vec -= 4.0 * N;                       // x touched every second sweep: (8+8+8)/2 instead of 8+8
+      if (pat_defer && rsweep_level(L)) vec = 28.0 * N;    // sells_rsweep_kernel: r in + r out, (x in + x out + r_prev) every second sweep; no s, no 1/diag
     } else if (A.pat) mat = (A.rowbase ? 6.0 : 2.0) * N;
     else if (A.sell && A.opat) { mat = 8.0 * (double)A.zpad + (A.orowbase ? 6.0 : 2.0) * N + 4.0 * N + 8.0 * (double)A.nslices; if (sell_defer && sell_un < 27) vec -= 4.0 * N; }
     else if (A.sell && (A.comp_idx || A.vdict)) mat = A.stream_bytes_per_nnz * (double)A.zpack + 4.0 * N + 4.0 * (double)(A.zpack / 64);

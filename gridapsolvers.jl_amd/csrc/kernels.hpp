@@ -1390,6 +1390,110 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// The same sweep WITHOUT the s vector, for operators whose rows all carry the same diagonal (constant-coefficient operators on
+// uniform meshes: every free node sees the same cells, so 1/diag is ONE number d).  s_k = omega*(d*r_k) is then a function of the
+// gathered value alone: the kernel gathers r_k itself and forms s once per LOADED value -- before the DPP shifts hand it to the
+// neighbouring lanes --, two multiplies per run and lane, the very two roundings of RichardsonSmoothers.jl:91-92 /
+// JacobiLinearSolvers.jl:45.  Gone: the s store and the s load of every row and sweep, the scaled-Jacobi launch in front of every
+// pass, and the ping-pong of s (r ping-pongs instead: the gathers read r_k while the rows write r_{k+1}).  Per row and sweep
+// 2 + 8 B read and 8 B written when x is untouched (XM = 1), + 16 B + 8 B when it is (XM = 2): 30 B on average against 46 B --
+// and 12 B instead of 20 B of WRITES, which is what this kernel pays most for once the level has left the caches
+// (profiles/r03_tuning.md).  Same products, same order, same roundings as sells_sweep_kernel: bit-identical (tested).
+//   a.x = r_k (gathered, incl. the row's own value) ; a.y = r_{k+1} ; a.s_out = r_{k-1} (XM = 2 only; may be a.y) ; a.pdinv[0] = d
+// ---------------------------------------------------------------------------
+template <int XM, int NB, bool MK, int NT = 0>
+__global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
+{
+  constexpr int K = 3, ROWS = 65 - K, RB = 3;
+  extern __shared__ double sp_smem[];
+  const int nu = K * a.nruns;
+  const int tot = a.np * nu;
+  PatEntry *s_tab = reinterpret_cast<PatEntry *>(sp_smem);
+  double *s_tab8 = sp_smem;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int nwg = gridDim.x;
+  const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
+  const int chunk_lo = a.nslices / nwg, chunk_rem = a.nslices % nwg;
+  const int s_begin = blk * chunk_lo + min(blk, chunk_rem);
+  const int s_end = s_begin + chunk_lo + (blk < chunk_rem ? 1 : 0);
+  const double *__restrict__ rg = a.x;
+  const double omega = a.omega;
+  const double du = a.pdinv[0];                              // the one 1/diag (uniform: scalar load)
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  const bool xz = a.x_zero != 0;
+  int pid[NB], row[NB];
+  double e0[NB], e2[NB], rp[NB], A[NB][RB], acc[NB];
+  auto load_batch = [&](int sb) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int slice = min(sb + i * wpb, s_end - 1);
+      row[i] = slice * ROWS + lane;
+      const int rc = min(row[i], lastrow);
+      pid[i] = NT ? (int)__builtin_nontemporal_load(a.rowpid + rc) : (int)a.rowpid[rc];
+      e0[i] = rg[rc];
+      e2[i] = 0.0; rp[i] = 0.0;
+      if (XM != 1) { const double xl = NT ? __builtin_nontemporal_load(a.x2 + rc) : a.x2[rc]; e2[i] = xz ? 0.0 : xl; }
+      if (XM == 2) rp[i] = a.s_out[rc];                      // r_{k-1} of the row, read before this sweep overwrites it
+#pragma unroll
+      for (int q = 0; q < RB; ++q) A[i][q] = ld_off(rg, 8u * (uint32_t)min(max(row[i] + a.run_off[q], 0), last));
+    }
+  };
+  int sb = s_begin + wave;
+  if (sb < s_end) load_batch(sb);
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i]; }
+  else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
+  __syncthreads();
+  while (sb < s_end) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const PatEntry *te = s_tab + pid[i] * nu;
+      const double *tv = s_tab8 + pid[i] * nu;
+      double s = 0.0;
+      for (int r0 = 0; r0 < a.nruns; r0 += RB) {
+        double cur[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) cur[q] = omega * (du * A[i][q]);   // s = omega*(Dinv*r): once per loaded value
+        if (r0 + RB < a.nruns) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) A[i][q] = ld_off(rg, 8u * (uint32_t)min(max(row[i] + a.run_off[r0 + RB + q], 0), last));
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          double c = cur[q];
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) c = wave_shl1(c);
+            const int j = (r0 + q) * K + t;
+            if (MK) {
+              const PatEntry en = te[j];
+              const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
+              s = s + en.v * g;
+            } else
+              s = s + tv[j] * c;
+          }
+        }
+      }
+      acc[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (sb + i * wpb < s_end && lane < ROWS && row[i] <= lastrow) {
+        const int r = row[i];
+        const double rn = e0[i] - acc[i];
+        const double sk = omega * (du * e0[i]);              // the row's own s_k
+        if (XM == 0) { const double xn = e2[i] + sk; if (NT) __builtin_nontemporal_store(xn, a.x2 + r); else a.x2[r] = xn; }
+        else if (XM == 2) { const double xn = (e2[i] + omega * (du * rp[i])) + sk; if (NT) __builtin_nontemporal_store(xn, a.x2 + r); else a.x2[r] = xn; }
+        a.y[r] = rn;
+      }
+    }
+    sb += wpb * NB;
+    if (sb < s_end) load_batch(sb);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // A whole Richardson-Jacobi smoothing pass (niter sweeps) of a SMALL level in ONE launch.
 //
 // On levels of a few 10^4 .. 10^5 rows a sweep kernel runs 4.6-5.9 us + ~1.5 us of dependent-launch gap against
