@@ -174,3 +174,48 @@ def test_repeated_row_blocks_equal_the_sent_ones(S, po, order, nc, monkeypatch):
         assert out["repeat"][3] == out[tag][3]
     assert np.array_equal(out["repeat"][2], out["sent"][2])
     assert rel_err(out["repeat"][2], out["whole"][2]) <= 1e-12
+
+
+# ---------------------------------------------------------------- the row-pattern sweep that gathers r itself (no s vector)
+@pytest.mark.parametrize("nc,nlev,niter", [((32, 32, 32), 3, 10), ((48, 32, 16), 2, 5), ((96, 96), 3, 1), ((24, 24, 24), 2, 2)])
+def test_r_gather_sweep_is_bitwise_the_s_sweep(S, po, orc, monkeypatch, nc, nlev, niter):
+    """sells_rsweep_kernel (uniform 1/diag: s_k = omega*(d*r_k) formed from the gathered r_k, r ping-pong, no s vector, no
+    scaled-Jacobi launch) against the sweep that gathers a stored s (GMG_PAT_RSWEEP=0): smoothing passes with x given and from
+    x = 0, odd and even sweep counts (the deferred x update ends differently), chained passes, V-cycles and a CG solve agree to
+    the last bit; and against the oracle to its usual tolerance.  GMG_PERSIST=0 keeps the small test levels on the per-sweep path."""
+    monkeypatch.setenv("GMG_PERSIST", "0")
+    H = po.build_hierarchy(nc, nlev, 1)
+    n = H["mats"][0].shape[0]
+    b = po.dirichlet_lift_rhs(nc, 1)
+    res = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GMG_PAT_RSWEEP", flag)
+        solver = S.CGSolver(make_gmg(S, H, pre_smoothers=jac(S, nlev, niter)), maxiter=40, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        assert ns.P_ns.level_format(0)["row_patterns"]
+        out = []
+        for l in range(nlev - 1):
+            nl = H["mats"][l].shape[0]
+            x, r = np.random.default_rng(3 + l).uniform(-1, 1, nl), np.random.default_rng(50 + l).uniform(-1, 1, nl)
+            for _ in range(3):
+                ns.P_ns.smooth(l, x, r)
+            out += [x, r]
+        z = np.zeros(n)
+        for rep in range(3):
+            S.solve_(z, ns.P_ns, np.random.default_rng(100 + rep).uniform(-1, 1, n))
+            out.append(z.copy())
+        x = np.zeros(n)
+        S.solve_(x, ns, b)
+        out += [x, solver.log.residuals[: solver.log.num_iters + 1].copy()]
+        sig = ns.P_ns.sweep_signature(0)
+        assert ("sells_rsweep_kernel" in sig) == (flag == "1"), sig
+        res[flag] = out
+        ns.P_ns.close()
+    for a, c in zip(res["0"], res["1"]):
+        np.testing.assert_array_equal(a, c)
+    sm = [orc.Smoother(orc.JACOBI, niter, 2.0 / 3.0)] * (nlev - 1)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=sm, maxiter=1)
+    xo, nit, flag_o, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=40, atol=1e-14, rtol=1e-8)
+    assert len(res["1"][-1]) == nit + 1
+    np.testing.assert_allclose(res["1"][-1], hist, rtol=TOL_HIST)
+    assert rel_err(res["1"][-2], xo) <= 1e-10
