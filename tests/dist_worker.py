@@ -364,6 +364,79 @@ def stokes_mode(n, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, 
     dist.destroy_process_group()
 
 
+def stokes_matvec_mode(n, nlev, out, rank, world, dist, torch, pkg, po, pa):
+    """CPU / gloo: the partitioned Q2 / P1disc Stokes block system applied with real neighbour exchanges -- every rank holds its
+    rows of the four blocks in [own | ghost] column numbering (dpartition.py), makes its ghosts consistent (consistent!) through
+    the exchange plans and applies its rows; the gathered result must be K x.  Also the reverse halo (assemble!) on the velocity
+    space: ghost contributions added to their owners reproduce a global scatter-add."""
+    from gridapsolvers_jl_amd import stokes as st, dpartition as dp
+    grid = pa.rank_grid(world, 2)
+    sysd, Hv = st.stokes_system(n), st.velocity_hierarchy(n, nlev)
+    V0 = dp.Space("v0", st.velocity_owner(n, grid), world)
+    Pq = dp.Space("p", st.pressure_owner(n, grid), world)
+    A = sysd["A"]
+    sc = lambda M: M.to_scipy()
+    ops = [(sc(A[0][0]), V0, V0), (sc(A[0][1]), V0, Pq), (sc(A[1][0]), Pq, V0)]
+    pp, pd = Hv["star_patches"][0]
+    dp.partition_spaces([V0, Pq], ops, [(pp, pd, V0, st.patch_owner(pp, pd, V0.owner))])
+
+    def exchange(S, v):
+        pl = S.plan[rank]
+        reqs, keep = [], []
+        for k, q in enumerate(pl["nbr_rank"]):
+            r0, r1 = pl["rcv_ptr"][k], pl["rcv_ptr"][k + 1]
+            if r1 > r0:
+                t = torch.zeros(int(r1 - r0), dtype=torch.float64); keep.append((t, r0, r1))
+                reqs.append(dist.P2POp(dist.irecv, t, int(q)))
+            sidx = pl["snd_idx"][pl["snd_ptr"][k]:pl["snd_ptr"][k + 1]]
+            if sidx.size:
+                reqs.append(dist.P2POp(dist.isend, torch.from_numpy(v[sidx].copy()), int(q)))
+        if reqs:
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+        for t, r0, r1 in keep:
+            v[S.n_own(rank) + r0: S.n_own(rank) + r1] = t.numpy()
+
+    def assemble(S, v):
+        pl = S.plan[rank]
+        reqs, keep = [], []
+        for k, q in enumerate(pl["nbr_rank"]):
+            s0, s1 = pl["snd_ptr"][k], pl["snd_ptr"][k + 1]
+            if s1 > s0:
+                t = torch.zeros(int(s1 - s0), dtype=torch.float64); keep.append((t, s0, s1))
+                reqs.append(dist.P2POp(dist.irecv, t, int(q)))
+            r0, r1 = pl["rcv_ptr"][k], pl["rcv_ptr"][k + 1]
+            if r1 > r0:
+                reqs.append(dist.P2POp(dist.isend, torch.from_numpy(v[S.n_own(rank) + r0: S.n_own(rank) + r1].copy()), int(q)))
+        if reqs:
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+        for t, s0, s1 in keep:
+            np.add.at(v, pl["snd_idx"][s0:s1], t.numpy())
+    nu, npp = sysd["sizes"]
+    xg = np.random.default_rng(4).uniform(-1, 1, nu + npp)
+    xu = np.zeros(V0.n_own(rank) + V0.n_ghost(rank)); xu[: V0.n_own(rank)] = xg[:nu][V0.own[rank]]
+    xp = np.zeros(Pq.n_own(rank) + Pq.n_ghost(rank)); xp[: Pq.n_own(rank)] = xg[nu:][Pq.own[rank]]
+    exchange(V0, xu); exchange(Pq, xp)
+    yu = dp.local_operator(sc(A[0][0]), V0, V0, rank).matvec(xu) + dp.local_operator(sc(A[0][1]), V0, Pq, rank).matvec(xp)
+    yp = dp.local_operator(sc(A[1][0]), Pq, V0, rank).matvec(xu)
+    # assemble!: every rank adds 1 + rank to all its local velocity entries; owners must end up with the sum over the ranks that see the dof
+    w = np.full(V0.n_own(rank) + V0.n_ghost(rank), 1.0 + rank)
+    assemble(V0, w)
+    parts = [None] * world
+    dist.all_gather_object(parts, (V0.own[rank], Pq.own[rank], yu, yp, w[: V0.n_own(rank)], V0.local_gid(rank)))
+    if rank == 0:
+        yg, wg, expect = np.zeros(nu + npp), np.zeros(nu), np.zeros(nu)
+        for r, (vo, pown, a, b_, ww, lg) in enumerate(parts):
+            yg[vo] = a; yg[nu + pown] = b_; wg[vo] = ww
+            np.add.at(expect, lg, 1.0 + r)
+        ref = sysd["K"] @ xg
+        json.dump(dict(matvec_err=float(np.abs(yg - ref).max() / np.abs(ref).max()), assemble_err=float(np.abs(wg - expect).max()),
+                       world=world, ghosts=[int(V0.n_ghost(0)), int(Pq.n_ghost(0))], mode="numpy_stokes"), open(out, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     mode, cells, nlev, out = sys.argv[1], tuple(int(c) for c in sys.argv[2].split("x")), int(sys.argv[3]), sys.argv[4]
     transport = sys.argv[5] if len(sys.argv) > 5 else "host"
@@ -384,6 +457,8 @@ def main():
     p_niter, p_omega = 4, 0.2
     depth = int(os.environ.get("GMG_TEST_DEPTH", "0"))      # > 0: partitioned levels >= 1 in the overlapping layout with that many ghost layers
     verdict = {}
+    if mode == "numpy_stokes":
+        return stokes_matvec_mode(cells[0], nlev, out, rank, world, dist, torch, pkg, po, pa)
     if mode == "gpu_stokes":
         return stokes_mode(cells[0], nlev, out, transport, rank, world, dist, torch, pkg, po, pa, multigpu)
     if mode == "gpu_block":

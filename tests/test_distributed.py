@@ -387,3 +387,13 @@ def test_generic_partitioner_reproduces_the_stokes_operators(po, pkg):
         assert np.array_equal(V[0].local_gid(r)[loc], glob) and blocks.size == int(((ptr[1:] - ptr[:-1]) ** 2).sum())
         got += [tuple(glob[ptr[p]:ptr[p + 1]]) for p in range(ptr.size - 1) if ptr[p + 1] > ptr[p]]
     assert sorted(got) == sorted(tuple(pd[pp[p]:pp[p + 1]]) for p in range(pp.size - 1) if pp[p + 1] > pp[p])
+
+
+@pytest.mark.parametrize("world,n", [(2, 8), (4, 8), (8, 16)])
+def test_partitioned_stokes_system_numpy_gloo(world, n, tmp_path):
+    """The partitioned Q2 / P1disc block system over gloo (CPU): consistent! of both spaces through the generic partitioner's
+    exchange plans, then every rank's rows -- the gathered product equals K x; and assemble! (reverse halo add) on the velocity
+    space equals a global scatter-add.  Ranks without pressure ghosts still send (discontinuous pressure)."""
+    v = _launch("numpy_stokes", world, (n, n), 2, tmp_path)
+    assert v["matvec_err"] < 1e-13 and v["assemble_err"] == 0.0, v
+    assert v["ghosts"][0] > 0
