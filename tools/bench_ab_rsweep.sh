@@ -2,7 +2,7 @@
 # A/B of the r-gather row-pattern sweep (sells_rsweep_kernel, GMG_PAT_RSWEEP) on one box: bench.py at $1^3 cells, $2 levels
 C=${1:-128}; L=${2:-4}; OUT=${3:-gpurun_out/r03n}
 mkdir -p $OUT
-for rep in 1 2; do for cfg in "new:GMG_NONE=0" "old:GMG_PAT_RSWEEP=0"; do
+for rep in 1 2; do for cfg in "new:GMG_NONE=0" "old:${OLD_ENV:-GMG_PAT_RSWEEP=0}"; do
   tag=${cfg%%:*}; envs=${cfg#*:}
   env $envs timeout 900 python bench.py --cells $C --levels $L --no-cpu-baseline --no-varcoef --no-weak-ref --steps 8 --warmup 2 2>$OUT/rs_${C}_${tag}_$rep.err > $OUT/rs_${C}_${tag}_$rep.json < /dev/null
   python - <<PY
