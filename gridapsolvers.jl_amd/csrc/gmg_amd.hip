@@ -2762,8 +2762,9 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
       S.d_inc = upload(inc);
     }
   };
-  if (!blocks_only) make_incidence();
-  if (npatch == 0 || max_np == 0) { S.built = true; return; }
+  // (built after the blocks, and only when the patch-by-patch kernels will run: the row-pattern form of the additive-Schwarz
+  // operator needs none of it, and at 4.6 x 10^8 patch entries the lists take 2.8 s of host time)
+  if (npatch == 0 || max_np == 0) { if (!blocks_only) make_incidence(); S.built = true; return; }
 
   // ---- inverse blocks, built in batches (bounded scratch) and de-duplicated on the fly -------------------------------
   // Block sources: caller's lu! factors (inverted on the host exactly as ldiv! would solve against the identity), caller's
@@ -2944,7 +2945,145 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
     HIP_CHECK(hipStreamSynchronize(stream));
     return true;
   };
-  if (!(want_dedup && build_blocks(true))) build_blocks(false);
+  // Row-pattern sources: group the patches by the SIGNATURE of their source block first (kernels.hpp: patch_sig_hash_kernel) and
+  // invert one representative per group -- the groups' inverses are then de-duplicated bitwise exactly as above, so block ids and
+  // stores come out as the batch-by-batch path gives them (that one inverts every patch: 5.1 s of the 8.2 s level-0 setup of
+  // BASELINE config 3, this one 64 of 1.7 x 10^7).  Returns false when the signatures do not repeat (or a hash collided).
+  auto bp_sub = std::chrono::steady_clock::now();
+  auto build_blocks_by_source = [&]() -> bool {
+    DevTmp tmp;
+    auto sub = [&](const char *what) { if (bp_timing) { (void)hipStreamSynchronize(stream); const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[gmg_setup]     source de-duplication: %-24s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - bp_sub).count()); bp_sub = now; } };
+    PatchSrc src;
+    std::memset(&src, 0, sizeof(src));
+    src.rowpid = L.A.rowpid; src.rowbase = L.A.rowbase; src.plen = L.A.plen; src.poff8 = L.A.ppoff; src.pval = L.A.ppval; src.W = L.A.pat_w;
+    unsigned long long *d_hash = (unsigned long long *)tmp.get(sizeof(unsigned long long) * (size_t)npatch);
+    hipLaunchKernelGGL(patch_sig_hash_kernel, dim3((unsigned)((npatch + 3) / 4)), dim3(256), 0, stream, npatch, S.d_pptr, S.d_pdofs, d_pcol, src, d_hash);
+    HIP_CHECK(hipGetLastError());
+    std::vector<unsigned long long> hash((size_t)npatch);
+    HIP_CHECK(hipMemcpyAsync(hash.data(), d_hash, sizeof(unsigned long long) * (size_t)npatch, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    tmp.drop(d_hash);
+    sub("signature hashes");
+    // groups numbered by first appearance: per chunk the distinct hashes with their first patch, merged in chunk order
+    const int64_t NT = std::max<int64_t>(1, std::min<int64_t>(64, npatch / 65536));
+    const int64_t chunk = (npatch + NT - 1) / NT;
+    std::vector<std::vector<std::pair<unsigned long long, int64_t>>> firsts((size_t)NT);
+    parallel_chunks(NT, [&](int64_t t) {
+      std::unordered_map<unsigned long long, char> seen;
+      unsigned long long last = 0; bool have = false;
+      for (int64_t pp = t * chunk; pp < std::min(npatch, (t + 1) * chunk); ++pp) {
+        const unsigned long long h = hash[(size_t)pp];
+        if (have && h == last) continue;
+        last = h; have = true;
+        if (seen.emplace(h, 0).second) firsts[(size_t)t].emplace_back(h, pp);
+      }
+    });
+    std::unordered_map<unsigned long long, int32_t> gid;
+    std::vector<int64_t> rep;                                // group -> first patch
+    for (int64_t t = 0; t < NT; ++t)
+      for (const auto &f : firsts[(size_t)t])
+        if (gid.emplace(f.first, (int32_t)rep.size()).second) rep.push_back(f.second);
+    const int64_t ngrp = (int64_t)rep.size();
+    if (ngrp * 4 > npatch) return false;
+    std::vector<int32_t> grp((size_t)npatch);
+    parallel_chunks(NT, [&](int64_t t) {
+      unsigned long long last = 0; int32_t lastg = -1;
+      for (int64_t pp = t * chunk; pp < std::min(npatch, (t + 1) * chunk); ++pp) {
+        const unsigned long long h = hash[(size_t)pp];
+        if (lastg < 0 || h != last) { last = h; lastg = gid.find(h)->second; }
+        grp[(size_t)pp] = lastg;
+      }
+    });
+    hash.clear(); hash.shrink_to_fit();
+    sub("grouping (host)");
+    // exact check of every patch against its group's representative
+    int32_t *d_grp = (int32_t *)tmp.get(sizeof(int32_t) * (size_t)npatch);
+    int64_t *d_replist = (int64_t *)tmp.get(sizeof(int64_t) * (size_t)ngrp);
+    int *d_nmis = (int *)tmp.get(sizeof(int));
+    HIP_CHECK(hipMemsetAsync(d_nmis, 0, sizeof(int), stream));
+    HIP_CHECK(hipMemsetAsync(d_nsing, 0, sizeof(int), stream));
+    HIP_CHECK(hipMemcpyAsync(d_grp, grp.data(), sizeof(int32_t) * (size_t)npatch, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(d_replist, rep.data(), sizeof(int64_t) * (size_t)ngrp, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(patch_sig_verify_kernel, dim3((unsigned)((npatch + 3) / 4)), dim3(256), 0, stream, npatch, S.d_pptr, S.d_pdofs, d_pcol, src, d_grp, d_replist, d_nmis);
+    HIP_CHECK(hipGetLastError());
+    // the representatives' inverses, compact: group g at roff[g]
+    std::vector<int64_t> rpptr((size_t)ngrp + 1, 0), roff((size_t)ngrp + 1, 0);
+    for (int64_t g = 0; g < ngrp; ++g) {
+      const int64_t np = T.pptr[(size_t)rep[(size_t)g] + 1] - T.pptr[(size_t)rep[(size_t)g]];
+      rpptr[(size_t)g + 1] = rpptr[(size_t)g] + np;
+      roff[(size_t)g + 1] = roff[(size_t)g] + np * np;
+    }
+    double *d_rinv = (double *)tmp.get(sizeof(double) * (size_t)std::max<int64_t>(1, roff[(size_t)ngrp]));
+    int64_t *d_rpptr = (int64_t *)tmp.get(sizeof(int64_t) * ((size_t)ngrp + 1));
+    int64_t *d_roff = (int64_t *)tmp.get(sizeof(int64_t) * ((size_t)ngrp + 1));
+    HIP_CHECK(hipMemcpyAsync(d_rpptr, rpptr.data(), sizeof(int64_t) * ((size_t)ngrp + 1), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(d_roff, roff.data(), sizeof(int64_t) * ((size_t)ngrp + 1), hipMemcpyHostToDevice, stream));
+    {
+      const size_t lds = 2 * per * sizeof(double) + (size_t)max_np * sizeof(int32_t) + 8;
+      hipLaunchKernelGGL((patch_invert_kernel<PSRC_PATTERN>), dim3((unsigned)ngrp), dim3(64), lds, stream, ngrp, S.d_pptr, S.d_pdofs, d_pcol, S.d_boff, (int64_t)0, src,
+                         pivoting, d_rinv, max_np, d_nsing, d_replist, d_roff);
+      HIP_CHECK(hipGetLastError());
+    }
+    // second stage: groups with bitwise equal inverses share one stored block (ids by first appearance, as the batch path numbers them)
+    unsigned long long *d_ghash = (unsigned long long *)tmp.get(sizeof(unsigned long long) * (size_t)ngrp);
+    hipLaunchKernelGGL(block_hash_kernel, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, stream, ngrp, d_rpptr, d_roff, d_rinv, d_ghash);
+    HIP_CHECK(hipGetLastError());
+    std::vector<unsigned long long> ghash((size_t)ngrp);
+    int nsing = 0, nmis = 0;
+    HIP_CHECK(hipMemcpyAsync(ghash.data(), d_ghash, sizeof(unsigned long long) * (size_t)ngrp, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&nsing, d_nsing, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(&nmis, d_nmis, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    REQUIRE(nsing == 0, GMG_ERR_SINGULAR, "singular patch block (BlockJacobiSolvers.jl:163 'Factorization failed')");
+    if (nmis != 0) return false;
+    sub("verify + invert groups");
+    std::unordered_map<unsigned long long, int32_t> uniq;
+    std::vector<int64_t> uboff(1, 0), usrc, goff((size_t)ngrp);
+    std::vector<int32_t> uid((size_t)ngrp);
+    for (int64_t g = 0; g < ngrp; ++g) {
+      const int64_t len = roff[(size_t)g + 1] - roff[(size_t)g];
+      auto it = uniq.find(ghash[(size_t)g]);
+      if (it == uniq.end()) {
+        it = uniq.emplace(ghash[(size_t)g], (int32_t)(uboff.size() - 1)).first;
+        usrc.push_back(roff[(size_t)g]);
+        uboff.push_back(uboff.back() + len);
+      }
+      uid[(size_t)g] = it->second;
+      goff[(size_t)g] = uboff[(size_t)it->second];
+    }
+    const int64_t nu = (int64_t)uboff.size() - 1;
+    double *d_ustore = (double *)tmp.get(sizeof(double) * (size_t)std::max<int64_t>(1, uboff.back()));
+    for (int64_t u = 0; u < nu; ++u)
+      HIP_CHECK(hipMemcpyAsync(d_ustore + uboff[(size_t)u], d_rinv + usrc[(size_t)u], sizeof(double) * (size_t)(uboff[(size_t)u + 1] - uboff[(size_t)u]), hipMemcpyDeviceToDevice, stream));
+    int64_t *d_goff = (int64_t *)tmp.get(sizeof(int64_t) * (size_t)ngrp);
+    HIP_CHECK(hipMemcpyAsync(d_goff, goff.data(), sizeof(int64_t) * (size_t)ngrp, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(block_verify_store_kernel, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, stream, ngrp, d_rpptr, d_roff, d_rinv, d_ustore, d_goff, d_nmis);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(&nmis, d_nmis, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (nmis != 0) return false;
+    std::vector<int32_t> ublock((size_t)npatch);
+    parallel_chunks(NT, [&](int64_t t) {
+      for (int64_t pp = t * chunk; pp < std::min(npatch, (t + 1) * chunk); ++pp) ublock[(size_t)pp] = uid[(size_t)grp[(size_t)pp]];
+    });
+    sub("second stage + block ids");
+    S.d_uboff = upload(uboff); S.n_uboff = (int64_t)uboff.size();
+    S.d_ubinv = dalloc<double>((size_t)uboff.back()); S.n_ubinv = uboff.back();
+    HIP_CHECK(hipMemcpyAsync(S.d_ubinv, d_ustore, sizeof(double) * (size_t)uboff.back(), hipMemcpyDeviceToDevice, stream));
+    S.d_ublock = upload(ublock);
+    S.h_ublock = std::move(ublock); S.h_uboff = uboff;
+    S.nuniq = nu;
+    S.dedup = true;
+    HIP_CHECK(hipStreamSynchronize(stream));
+    sub("uploads");
+    if (bp_timing) std::fprintf(stderr, "[gmg_setup]   patch tables: %lld source signatures, %lld distinct inverse blocks of %lld patches\n", (long long)ngrp, (long long)nu, (long long)npatch);
+    return true;
+  };
+  const bool by_source = want_dedup && from_pattern && wave_kernel && env_int("GMG_PATCH_SOURCE_DEDUP", 1);
+  bp_lap("block offsets");
+  bp_sub = std::chrono::steady_clock::now();
+  if (!(by_source && build_blocks_by_source()))
+    if (!(want_dedup && build_blocks(true))) build_blocks(false);
   bp_lap("inverse blocks + de-duplication");
   if (S.dedup) release(S.d_boff, (size_t)npatch + 1);        // the de-duplicated solve addresses blocks through ublock / uboff
   S.built = true;
@@ -3334,25 +3473,47 @@ double *gmg_solver::build_coarse_device(const HostCSR &A, const std::string &wha
   const int n = (int)A.nrows;
   const size_t mark = allocs.size();
   const int64_t bytes0 = dev_bytes;
+  // large levels: 64-wide panels on a padded leading dimension (half the passes over the matrix, aligned 128-byte row
+  // segments), compacted into the n x n result at the end; small ones: 32-wide panels in place
+  const bool wide = gj_mfma && n >= env_int("GMG_GJ_WIDE_MIN", 4096);
+  const int64_t lda = wide ? (((int64_t)n + 127) / 128) * 128 : n;        // whole tiles: the update kernel loads unconditionally
+  const int64_t nr = wide ? (((int64_t)n + 127) / 128) * 128 : n;
   double *D = dalloc<double>((size_t)n * n);
   const int64_t bytesD = dev_bytes - bytes0;
-  HIP_CHECK(hipMemsetAsync(D, 0, sizeof(double) * (size_t)n * n, stream));
+  double *W = wide ? dalloc<double>((size_t)nr * lda) : D;
+  HIP_CHECK(hipMemsetAsync(W, 0, sizeof(double) * (size_t)nr * lda, stream));
   int64_t *d_ptr = upload(A.ptr);
   int32_t *d_col = upload(A.col);
   double *d_val = upload(A.val);
-  hipLaunchKernelGGL((densify_kernel<int64_t>), dim3((n + 255) / 256), dim3(256), 0, stream, (int64_t)n, d_ptr, d_col, d_val, D);
+  hipLaunchKernelGGL((densify_ld_kernel<int64_t>), dim3((n + 255) / 256), dim3(256), 0, stream, (int64_t)n, lda, d_ptr, d_col, d_val, W);
   HIP_CHECK(hipGetLastError());
-  double *Pinv = dvec(GJ_B * GJ_B), *R = dvec((int64_t)GJ_B * n), *C = dvec((int64_t)GJ_B * n), *Cp = dvec((int64_t)GJ_B * n);
   int *d_bad = dalloc<int>(1);
   HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
-  const dim3 tiles((n + 63) / 64, (n + 63) / 64);
-  for (int k0 = 0; k0 < n; k0 += GJ_B) {
-    const int b = std::min(GJ_B, n - k0);
-    hipLaunchKernelGGL(gj_diag_kernel, dim3(1), dim3(GJ_B * GJ_B), 0, stream, n, k0, b, D, Pinv, d_bad);
-    hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)(((int64_t)n * b + 255) / 256)), dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
-    if (gj_mfma) hipLaunchKernelGGL(gj_update_mfma_kernel, tiles, dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
-    else hipLaunchKernelGGL(gj_update_kernel, tiles, dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
-    HIP_CHECK(hipGetLastError());
+  if (wide) {
+    double *Pinv = dvec(GJ_W * GJ_W), *R = dvec((int64_t)GJ_W * lda), *C = dvec((int64_t)GJ_W * nr), *Cp = dvec((int64_t)GJ_W * nr);
+    constexpr int GJ_RT = 4;                                 // 64 x 64 per wave, 128 x 128 per workgroup
+    const int64_t nst = (int64_t)(((n + 127) / 128 + GJ_SX - 1) / GJ_SX) * ((n + 1023) / 1024);
+    const dim3 tiles((unsigned)(((nst + 7) / 8) * 8 * GJ_SX * (1024 / (32 * GJ_RT))));
+    for (int k0 = 0; k0 < n; k0 += GJ_W) {
+      const int b = std::min(GJ_W, n - k0);
+      hipLaunchKernelGGL(gj_diag64_kernel, dim3(1), dim3(1024), 0, stream, n, lda, k0, b, W, Pinv, d_bad);
+      hipLaunchKernelGGL(gj_panel_rows_kernel, dim3((n + 63) / 64, 4), dim3(64), 0, stream, n, lda, k0, b, W, Pinv, R);
+      hipLaunchKernelGGL(gj_panel_cols_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, n, lda, k0, b, W, Pinv, C, Cp);
+      hipLaunchKernelGGL((gj_update64_kernel<GJ_RT>), tiles, dim3(256), 0, stream, n, lda, k0, b, W, Pinv, R, C, Cp);
+      HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipMemcpy2DAsync(D, sizeof(double) * (size_t)n, W, sizeof(double) * (size_t)lda, sizeof(double) * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, stream));
+  } else {
+    double *Pinv = dvec(GJ_B * GJ_B), *R = dvec((int64_t)GJ_B * n), *C = dvec((int64_t)GJ_B * n), *Cp = dvec((int64_t)GJ_B * n);
+    const dim3 tiles((n + 63) / 64, (n + 63) / 64);
+    for (int k0 = 0; k0 < n; k0 += GJ_B) {
+      const int b = std::min(GJ_B, n - k0);
+      hipLaunchKernelGGL(gj_diag_kernel, dim3(1), dim3(GJ_B * GJ_B), 0, stream, n, k0, b, D, Pinv, d_bad);
+      hipLaunchKernelGGL(gj_panels_kernel, dim3((unsigned)(((int64_t)n * b + 255) / 256)), dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
+      if (gj_mfma) hipLaunchKernelGGL(gj_update_mfma_kernel, tiles, dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
+      else hipLaunchKernelGGL(gj_update_kernel, tiles, dim3(256), 0, stream, n, k0, b, D, Pinv, R, C, Cp);
+      HIP_CHECK(hipGetLastError());
+    }
   }
   int bad = 0;
   HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream));

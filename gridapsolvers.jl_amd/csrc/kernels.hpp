@@ -2050,6 +2050,192 @@ __global__ __launch_bounds__(256) void gj_update_mfma_kernel(int n, int k0, int 
 }
 
 // ---------------------------------------------------------------------------
+// The same inversion with 64-wide panels for LARGE coarsest levels (tens of thousands of dofs: the 31^3-node coarsest level
+// of BASELINE config 3 is a 7.1 GB dense inverse).  A pass over the matrix is bound by HBM (read + write of n^2 doubles), so
+// the panel width sets the number of passes; 64 columns cost 16 v_mfma_f64_16x16x4_f64 per 16 x 16 tile, still far below the
+// time the tile's 4 KB take to stream.  The matrix is held with a leading dimension lda (a multiple of 16: every 16-double
+// row segment a wave touches is one aligned 128-byte line; n itself is usually odd), R shares it, C / Cp are n x 64; all of
+// them padded with zeros to whole 64 x 128 tiles.
+//   gj_diag64_kernel     Pinv = A[K,K]^-1, one workgroup of 1024 threads, Gauss-Jordan in LDS (64 KB)
+//   gj_panel_rows_kernel R = Pinv * A[K,:]                 (thread = column, 16 rows of R per thread, Pinv uniform)
+//   gj_panel_cols_kernel C = A[:,K] ; Cp = -C * Pinv       (wave = 16 rows of A, lane = column of the panel)
+//   gj_update64_kernel   A -= C * R off the panel; panel rows / columns / block replaced as in gj_update_kernel.
+//                        A wave owns 32 rows x 64 columns (2 x 4 MFMA tiles: the C operand stays in registers for the four
+//                        column tiles), a workgroup 64 x 128.  k index of MFMA step s in lane group g (= lane / 16): 16 g + s,
+//                        so a lane's C operands are 16 consecutive doubles.
+// ---------------------------------------------------------------------------
+constexpr int GJ_W = 64;
+constexpr int GJ_SX = 8;                                     // super-tile of gj_update64_kernel: 8 workgroup tiles of 128 columns (x 1024 rows)
+
+__global__ __launch_bounds__(1024) void gj_diag64_kernel(int n, int64_t lda, int k0, int b, const double *__restrict__ A,
+                                                         double *__restrict__ Pinv, int *__restrict__ bad)
+{
+  __shared__ double M[GJ_W][GJ_W], X[GJ_W][GJ_W];
+  const int r0 = threadIdx.x >> 6, c = threadIdx.x & 63;     // rows r0 + 16 q of column c (r0 is uniform in a wave)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = r0 + 16 * q;
+    M[r][c] = (r < b && c < b) ? A[(size_t)(k0 + r) * lda + k0 + c] : (r == c ? 1.0 : 0.0);
+    X[r][c] = (r == c) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < GJ_W; ++j) {
+    const double d = M[j][j];
+    const double mjc = M[j][c] / d, xjc = X[j][c] / d;
+    double f[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[q] = M[r0 + 16 * q][j];
+    __syncthreads();
+    if (d == 0.0) { if (threadIdx.x == 0) atomicAdd(bad, 1); return; }   // uniform
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + 16 * q;
+      if (r == j) { M[j][c] = mjc; X[j][c] = xjc; }
+      else { M[r][c] -= f[q] * mjc; X[r][c] -= f[q] * xjc; }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = r0 + 16 * q;
+    if (r < b && c < b) Pinv[r * GJ_W + c] = X[r][c];
+  }
+}
+
+// R[t][j] = sum_u Pinv[t][u] * A[k0 + u][j]: blockIdx.y picks 16 rows t of R, a thread one column j
+__global__ __launch_bounds__(64) void gj_panel_rows_kernel(int n, int64_t lda, int k0, int b, const double *__restrict__ A,
+                                                           const double *__restrict__ Pinv, double *__restrict__ R)
+{
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int t0 = blockIdx.y * 16;
+  if (j >= n) return;
+  double acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+  for (int u = 0; u < b; ++u) {
+    const double a = A[(size_t)(k0 + u) * lda + j];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] += Pinv[(t0 + t) * GJ_W + u] * a;   // uniform address: scalar loads
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) R[(size_t)(t0 + t) * lda + j] = (t0 + t < b) ? acc[t] : 0.0;   // rows >= b: zeros (the update reads all 64)
+}
+
+// C[i][t] = A[i][k0 + t] ; Cp[i][t] = -sum_u C[i][u] * Pinv[u][t]: a wave takes 16 rows, lane = t
+__global__ __launch_bounds__(256) void gj_panel_cols_kernel(int n, int64_t lda, int k0, int b, const double *__restrict__ A,
+                                                            const double *__restrict__ Pinv, double *__restrict__ C,
+                                                            double *__restrict__ Cp)
+{
+  __shared__ double sC[4][GJ_W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = (blockIdx.x * 4 + wave) * 16;
+  for (int q = 0; q < 16; ++q) {
+    const int i = i0 + q;
+    if (i >= n) break;                                       // uniform in the wave
+    const double v = (lane < b) ? A[(size_t)i * lda + k0 + lane] : 0.0;
+    sC[wave][lane] = v;
+    __builtin_amdgcn_wave_barrier();
+    double sp = 0.0;
+    if (lane < b)
+      for (int u = 0; u < b; ++u) sp += sC[wave][u] * Pinv[u * GJ_W + lane];
+    C[(size_t)i * GJ_W + lane] = v;
+    Cp[(size_t)i * GJ_W + lane] = -sp;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int RT>                                            // a wave owns 16 RT rows x 64 columns, a workgroup 32 RT x 128
+__global__ __launch_bounds__(256) void gj_update64_kernel(int n, int64_t lda, int k0, int b, double *__restrict__ A,
+                                                          const double *__restrict__ Pinv, const double *__restrict__ R,
+                                                          const double *__restrict__ C, const double *__restrict__ Cp)
+{
+  // Every buffer is padded with zeros to whole tiles (lda a multiple of 128, rows of A / C / Cp a multiple of 128, R rows >= b and
+  // C columns >= b zero): no load of the hot path is conditional -- a conditional load is a branch, and the compiler then waits for
+  // each operand before the MFMA that uses it (64 serialised L2 round trips per wave: 8.5 ms per pass instead of 4.5).
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int WR = 32 * RT;                                // rows of a workgroup tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // Workgroups are dealt to the eight XCDs round-robin; each XCD walks its own contiguous share of the super-tiles (GJ_SX x
+  // 1024 / WR workgroup tiles = 1024 x 1024 entries: the 512 KB of C rows and 512 KB of R columns they share stay in that XCD's L2).
+  constexpr int SY = 1024 / WR;
+  const int nbx = (n + 127) / 128, nby = (n + WR - 1) / WR;
+  const int nsx = (nbx + GJ_SX - 1) / GJ_SX;
+  const int64_t per_xcd = (int64_t)gridDim.x / 8;            // the launcher rounds the grid up to a multiple of 8 super-tiles
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int st = (int)(L / (GJ_SX * SY)), in = (int)(L % (GJ_SX * SY));
+  const int bx = (st % nsx) * GJ_SX + in % GJ_SX, by = (st / nsx) * SY + in / GJ_SX;
+  if (bx >= nbx || by >= nby) return;
+  const int ti = by * WR + (wave >> 1) * (16 * RT);
+  const int tj = bx * 128 + (wave & 1) * 64;
+  const int lr = lane & 15, lk = lane >> 4;
+  // A-operands: C[ti + 16 rt + lr][16 lk + s]
+  double ca[RT][16];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const d4 *src = reinterpret_cast<const d4 *>(C + (size_t)(ti + 16 * rt + lr) * GJ_W + 16 * lk);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const d4 x = src[v];
+      ca[rt][4 * v + 0] = x[0]; ca[rt][4 * v + 1] = x[1]; ca[rt][4 * v + 2] = x[2]; ca[rt][4 * v + 3] = x[3];
+    }
+  }
+  const bool panel = (ti < k0 + b && ti + 16 * RT > k0) || (tj < k0 + b && tj + 64 > k0);   // uniform in the wave
+  double *Aw = A + (size_t)(ti + lk) * lda + tj + lr;         // register (rt, a) of column tile c: Aw[(16 rt + 4 a) * lda + 16 c]
+  const double *Rw = R + (size_t)(16 * lk) * lda + tj + lr;   // step s of column tile c: Rw[s * lda + 16 c]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double av[RT][4], rb[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) rb[s] = Rw[(size_t)s * lda + 16 * c];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[rt][a] = Aw[(size_t)(16 * rt + 4 * a) * lda + 16 * c];   // f64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15
+    d4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[rt][s], rb[s], acc[rt], 0, 0, 0);
+    if (!panel) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) Aw[(size_t)(16 * rt + 4 * a) * lda + 16 * c] = av[rt][a] - acc[rt][a];
+    } else {
+      const int j = tj + 16 * c + lr;
+      if (j >= n) continue;
+      const bool jK = j >= k0 && j < k0 + b;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int i = ti + 16 * rt + lk + 4 * a;
+          if (i >= n) continue;
+          const bool iK = i >= k0 && i < k0 + b;
+          double v;
+          if (iK && jK) v = Pinv[(i - k0) * GJ_W + (j - k0)];
+          else if (iK) v = R[(size_t)(i - k0) * lda + j];
+          else if (jK) v = Cp[(size_t)i * GJ_W + (j - k0)];
+          else v = av[rt][a] - acc[rt][a];
+          A[(size_t)i * lda + j] = v;
+        }
+    }
+  }
+}
+
+// densify into a padded leading dimension: D[i * lda + col] += val
+template <typename PtrT>
+__global__ void densify_ld_kernel(int64_t n, int64_t lda, const PtrT *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                  const double *__restrict__ val, double *__restrict__ D)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (PtrT k = rowptr[i]; k < rowptr[i + 1]; ++k) D[(size_t)i * lda + col[k]] += val[k];
+}
+
+// ---------------------------------------------------------------------------
 // K9/K10: patch smoother.
 //  setup : extract A[p,p] (BlockJacobiSolvers.jl:160), factorise (LU with partial
 //          pivoting = PatchSolvers.jl:176 lu!, or NoPivot = BlockJacobiSolvers.jl:162)
@@ -2143,11 +2329,13 @@ __global__ __launch_bounds__(64) void patch_invert_kernel(int64_t npatch, const 
                                                           const int32_t *__restrict__ prow, const int32_t *__restrict__ pcol,
                                                           const int64_t *__restrict__ boff, int64_t boff0, PatchSrc src,
                                                           int pivoting, double *__restrict__ binv, int max_np,
-                                                          int *__restrict__ nsing)
+                                                          int *__restrict__ nsing, const int64_t *__restrict__ plist = nullptr,
+                                                          const int64_t *__restrict__ ooff = nullptr)
 {
+  // plist: invert the listed patches only (representatives of the source de-duplication), block k of the list to binv[ooff[k]]
   extern __shared__ double pi_smem[];
-  const int64_t p = blockIdx.x;
-  if (p >= npatch) return;
+  if ((int64_t)blockIdx.x >= npatch) return;
+  const int64_t p = plist ? plist[blockIdx.x] : (int64_t)blockIdx.x;
   const int64_t q0 = pptr[p];
   const int np = (int)(pptr[p + 1] - q0);
   if (np == 0) return;
@@ -2236,8 +2424,60 @@ __global__ __launch_bounds__(64) void patch_invert_kernel(int64_t npatch, const 
       X[j * np + c] = sacc / d;
     }
   __syncthreads();
-  double *out = binv + (boff[p] - boff0);
+  double *out = plist ? binv + ooff[blockIdx.x] : binv + (boff[p] - boff0);
   for (int e = lane; e < np * np; e += 64) out[e] = X[e];
+}
+
+// ---- source de-duplication of patch blocks taken from a row-pattern operator ---------------------------------------------
+// A[rows_p, cols_p] gathered from the pattern form is a function of (n_p; per row r: pattern id of the row, its base column
+// relative to cols_p[0]; per column c: cols_p[c] - cols_p[0]) -- patch_invert_kernel<PSRC_PATTERN> reads nothing else.  Patches
+// with equal signatures therefore have bitwise equal blocks and bitwise equal inverses: only one per signature is inverted
+// (64 of 1.7 x 10^7 on the uniform Q2 mesh of BASELINE config 3).  Hash per patch (wave = patch, lane = row) ...
+__device__ __forceinline__ unsigned long long patch_sig_word(int r, int pid, int32_t dbase, int32_t dcol)
+{
+  unsigned long long a = (unsigned long long)(unsigned)pid * 0x9E3779B97F4A7C15ull ^ (unsigned long long)(uint32_t)dbase * 0xC2B2AE3D27D4EB4Full ^
+                         (((unsigned long long)(uint32_t)dcol << 32) | (unsigned)r) * 0x165667B19E3779F9ull;
+  a ^= a >> 29; a *= 0xBF58476D1CE4E5B9ull; a ^= a >> 32;
+  return a;
+}
+__global__ __launch_bounds__(256) void patch_sig_hash_kernel(int64_t npatch, const int64_t *__restrict__ pptr, const int32_t *__restrict__ prow,
+                                                             const int32_t *__restrict__ pcol, PatchSrc src, unsigned long long *__restrict__ hash)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= npatch) return;
+  const int64_t q0 = pptr[p];
+  const int np = (int)(pptr[p + 1] - q0);
+  unsigned long long h = 0;
+  if (lane < np) {
+    const int32_t ref = pcol[q0];
+    const int32_t gr = prow[q0 + lane];
+    h = patch_sig_word(lane, src.rowpid[gr], (src.rowbase ? src.rowbase[gr] : gr) - ref, pcol[q0 + lane] - ref);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+  if (lane == 0) hash[p] = h ^ ((unsigned long long)np * 0xD6E8FEB86659FD93ull);
+}
+// ... and the exact comparison of every patch with the representative of its group (rep[g] = patch index): hash collisions -> mismatch
+__global__ __launch_bounds__(256) void patch_sig_verify_kernel(int64_t npatch, const int64_t *__restrict__ pptr, const int32_t *__restrict__ prow,
+                                                               const int32_t *__restrict__ pcol, PatchSrc src, const int32_t *__restrict__ grp,
+                                                               const int64_t *__restrict__ rep, int *__restrict__ nmis)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= npatch) return;
+  const int64_t q = rep[grp[p]];
+  if (q == p) return;
+  const int64_t q0 = pptr[p], r0 = pptr[q];
+  const int np = (int)(pptr[p + 1] - q0);
+  bool same = (int)(pptr[q + 1] - r0) == np;
+  if (same && lane < np) {
+    const int32_t ref = pcol[q0], rref = pcol[r0];
+    const int32_t gr = prow[q0 + lane], rgr = prow[r0 + lane];
+    same = src.rowpid[gr] == src.rowpid[rgr] && (src.rowbase ? src.rowbase[gr] : gr) - ref == (src.rowbase ? src.rowbase[rgr] : rgr) - rref &&
+           pcol[q0 + lane] - ref == pcol[r0 + lane] - rref;
+  }
+  if (__any(!same) && lane == 0) atomicAdd(nmis, 1);
 }
 
 // CSR -> SELL-64 on the device (setup): one wave per slice, lane = row; entry j of the slice's rows goes to

@@ -219,3 +219,62 @@ def test_r_gather_sweep_is_bitwise_the_s_sweep(S, po, orc, monkeypatch, nc, nlev
     assert len(res["1"][-1]) == nit + 1
     np.testing.assert_allclose(res["1"][-1], hist, rtol=TOL_HIST)
     assert rel_err(res["1"][-2], xo) <= 1e-10
+
+
+# ---------------------------------------------------------------- dense inverse of a large coarsest level: 64-wide panels
+@pytest.mark.parametrize("cells,last_panel", [(26, "full"), (28, "ragged")])
+def test_wide_panel_coarse_inverse(S, po, orc, monkeypatch, cells, last_panel):
+    """Coarsest levels of >= 4096 dofs (BASELINE config 3: 29 791) are inverted with 64-wide Gauss-Jordan panels on a zero-padded
+    leading dimension (`gj_update64_kernel`); GMG_GJ_WIDE_MIN pulls a 12^3 / 13^3-node coarsest level (1 728 = 27 full panels,
+    2 197 = 34 panels + 21 columns) into that path.  LUSolver() on the coarsest level (GMGLinearSolvers.jl:54): same iterations
+    as the oracle's exact LU, history <= 1e-8, solution <= 1e-10; and equal to the 32-wide path to rounding."""
+    nc = (cells,) * 3
+    H = po.build_hierarchy(nc, 2, 1)
+    assert H["mats"][-1].shape[0] == (cells // 2 - 1) ** 3
+    b = po.dirichlet_lift_rhs(nc, 1)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-8)
+    xs = {}
+    for wide_min in ("1024", "100000000"):
+        monkeypatch.setenv("GMG_GJ_WIDE_MIN", wide_min)
+        solver = S.CGSolver(make_gmg(S, H), maxiter=20, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        assert solver.log.num_iters == nit and solver.log.flag == flag
+        np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=TOL_HIST)
+        assert rel_err(x, xo) <= 1e-10
+        xs[wide_min] = x
+        ns.P_ns.close()
+    assert rel_err(xs["1024"], xs["100000000"]) <= 1e-13
+
+
+# ---------------------------------------------------------------- patch blocks of streamed operators: de-duplicated before the inversion
+@pytest.mark.parametrize("nc", [(16, 16, 16), (20, 12, 8)])
+def test_source_deduplication_of_patch_blocks_is_bitwise_the_batch_path(S, po, orc, monkeypatch, nc):
+    """Patch smoothers on levels held in row-pattern form: the patches are grouped by the signature of their source block and one per
+    group is inverted (`patch_sig_hash_kernel`, GMG_PATCH_SOURCE_DEDUP) instead of every patch (BlockJacobiSolvers.jl:160-163 inverts
+    every block; equal sources give equal bits).  Same distinct blocks, same solution bits as the invert-everything path, and the
+    oracle's iterations / history / solution."""
+    order, nlev = 2, 2
+    H = po.build_hierarchy(nc, nlev, order, stream_min_rows=5000)
+    assert hasattr(H["mats"][0], "row_blocks")
+    b = po.dirichlet_lift_rhs(nc, order)
+    tabs = [po.vertex_star_patches(c, order) for c in H["ncells"][:-1]]
+    Hw = po.build_hierarchy(nc, nlev, order)
+    go = orc.GMG(Hw["mats"], Hw["prolongations"], Hw["restrictions"], pre_smoothers=[orc.Smoother(orc.PATCH, 5, 0.2, pp, pd) for pp, pd in tabs], maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(Hw["mats"][0], b, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-8)
+    xs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GMG_PATCH_SOURCE_DEDUP", mode)
+        sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 5, 0.2) for pp, pd in tabs]
+        solver = S.FGMRESSolver(5, make_gmg(S, H, pre_smoothers=sm), maxiter=20, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        assert solver.log.num_iters == nit and solver.log.flag == flag
+        np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-6)
+        assert rel_err(x, xo) <= 1e-9
+        xs[mode] = x
+        ns.P_ns.close()
+    assert np.array_equal(xs["1"], xs["0"])

@@ -6,12 +6,12 @@ import pytest
 
 def _expand_plan(po, M):
     """materialise a StreamedCSR from its plan, expanding ("repeat", nrows_block, count, col_shift) items as the library does"""
-    ptrs, idxs, vals, base, nblk, nrep = [np.zeros(1, dtype=np.int64)], [], [], 0, 0, 0
+    ptrs, idxs, vals, base, nblk, nrep, nsent = [np.zeros(1, dtype=np.int64)], [], [], 0, 0, 0, 0
     for it in M.row_plan():
         if it[0] == "block":
             _, row0, B = it
             assert row0 == sum(p.size for p in ptrs) - 1
-            ptrs.append(B.ptr[1:] + base); idxs.append(B.idx.astype(np.int64)); vals.append(B.val); base += B.nnz; nblk += 1
+            ptrs.append(B.ptr[1:] + base); idxs.append(B.idx.astype(np.int64)); vals.append(B.val); base += B.nnz; nblk += 1; nsent += B.shape[0]
         else:
             _, nrb, count, cs = it
             P, I, V = np.concatenate(ptrs), np.concatenate(idxs), np.concatenate(vals)
@@ -21,24 +21,24 @@ def _expand_plan(po, M):
             for k in range(1, count + 1):
                 ptrs.append(bp[1:] + base); idxs.append(bi + k * cs); vals.append(bv); base += bv.size
             nrep += count
-    return po.CSR(M.shape, np.concatenate(ptrs), np.concatenate(idxs), np.concatenate(vals)), nblk, nrep
+    return po.CSR(M.shape, np.concatenate(ptrs), np.concatenate(idxs), np.concatenate(vals)), nblk, nrep, nsent
 
 
 @pytest.mark.parametrize("nc,order", [((8, 8, 8), 2), ((16, 16, 16), 1), ((12, 8, 10), 2), ((16, 16), 2), ((32, 32, 32), 1)])
 def test_row_stream_plan_reproduces_the_operators(po, nc, order):
     """poisson.*_stream().row_plan(): blocks + declared repetitions (gmg_set_operator_rows_repeat) expand to exactly the
     operator `materialize()` gives and the whole-matrix generator gives -- same pointers, columns and value bits; on 3-D meshes
-    most planes are declared, not generated."""
+    most planes are declared, not generated, and of the planes that are sent most grid lines."""
     half = tuple(c // 2 for c in nc)
     for M, whole in ((po.poisson_matrix_stream(nc, order), po.poisson_matrix(nc, order)),
                      (po.prolongation_stream(half, order), po.prolongation(half, order)),
                      (po.restriction_stream(half, order), po.prolongation(half, order).transpose())):
-        E, nblk, nrep = _expand_plan(po, M)
+        E, nblk, nrep, nsent = _expand_plan(po, M)
         F = M.materialize()
         assert np.array_equal(E.ptr, F.ptr) and np.array_equal(E.idx, F.idx) and np.array_equal(E.val, F.val)
         assert np.array_equal(F.ptr, whole.ptr) and np.array_equal(F.idx, whole.idx) and np.allclose(F.val, whole.val, rtol=0, atol=0)
         if len(nc) == 3 and min(nc) >= 16:
-            assert nrep > 0 and nblk <= 12
+            assert nrep > 0 and nblk <= 12 * 12 and nsent <= 12 * 12 * max(order * c for c in nc), (nblk, nrep, nsent)
 
 
 def test_partition_planner(pkg):
