@@ -255,6 +255,11 @@ struct DevCSR {
   uint8_t *pcodes = nullptr;
   double *pdict = nullptr;
   uint32_t *prunmask = nullptr;
+  // per-workgroup value tables of the coded form (sells_kernel<..., WL>): pattern lists of the launch geometry they were built for
+  mutable int wl_state = 0;     // 0 not looked at, 1 in use, 2 not applicable (too many patterns in one chunk / switched off)
+  mutable int wl_nwg = 0, wl_wpb = 0, wl_max = 0;
+  mutable uint16_t *wl_pids = nullptr;
+  mutable int32_t *wl_cnt = nullptr;
   // offset-pattern layout (SELL-O): SELL-64 value stream + a 16-bit offset-pattern id per row, no column stream
   bool opat = false;
   uint16_t *orowpid = nullptr;
@@ -539,6 +544,7 @@ struct gmg_solver {
   int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
   int64_t pat_coded_min_rows = 500000;   // GMG_PAT_CODED_MIN_ROWS
   int gj_mfma = 1;      // GMG_GJ_MFMA: trailing update of the device coarse inversion on the FP64 matrix cores
+  int pat_wide = 1;     // GMG_PAT_WIDE: coded (wide-row) operators decode the patterns of each workgroup's chunk into a plain LDS value table
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
   int persist_fenced = 0; // GMG_PERSIST_FENCED: progress words published with release / polled with acquire semantics (agent scope)
@@ -1211,6 +1217,38 @@ struct gmg_solver {
       return;
     }
   }
+  static constexpr int kWideStride = 64;                     // patterns per chunk the lists hold
+  // which patterns every chunk of the launch geometry (nwg workgroups of wpb waves) touches; false: the coded kernel stays
+  bool prepare_wide(const DevCSR &M, int nwg, int wpb, int nsl, int rows)
+  {
+    if (M.wl_state != 0 && M.wl_nwg == nwg && M.wl_wpb == wpb) return M.wl_state == 1;
+    if (M.wl_state == 1) { HIP_CHECK(hipStreamSynchronize(stream)); release(M.wl_pids, (size_t)M.wl_nwg * kWideStride); release(M.wl_cnt, (size_t)M.wl_nwg); }
+    M.wl_state = 2; M.wl_nwg = nwg; M.wl_wpb = wpb; M.wl_max = 0;
+    if (!pat_wide || !M.pat_coded || M.pat_np > 4096 || M.pat_np < 2 || !M.rowpid || !M.pcodes || !M.pdict || !M.prunmask) return false;
+    uint16_t *pids = dalloc<uint16_t>((size_t)nwg * kWideStride);
+    int32_t *cnt = dalloc<int32_t>((size_t)nwg);
+    hipLaunchKernelGGL(sellw_chunk_patterns_kernel, dim3(nwg), dim3(256), 0, stream, M.rowpid, M.nrows, nsl, rows, M.pat_np, kWideStride, pids, cnt);
+    HIP_CHECK(hipGetLastError());
+    std::vector<int32_t> h((size_t)nwg);
+    HIP_CHECK(hipMemcpyAsync(h.data(), cnt, sizeof(int32_t) * (size_t)nwg, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const int lmax = *std::max_element(h.begin(), h.end());
+    const int nu = M.pat_k * M.pat_nruns;
+    if (env_int("GMG_SETUP_TIMING", 0))
+      std::fprintf(stderr, "[gmg] wide-row tables: %lld rows, %d patterns x %d entries, %d workgroups, at most %d patterns per chunk -> %zu B of LDS\n", (long long)M.nrows, M.pat_np, nu, nwg, lmax, wide_lds(M, std::min(lmax, 255)));
+    if (lmax > kWideStride || lmax > 255 || wide_lds(M, lmax) > (size_t)env_int("GMG_PAT_WIDE_LDS", 72 * 1024)) {
+      release(pids, (size_t)nwg * kWideStride); release(cnt, (size_t)nwg);
+      return false;
+    }
+    (void)nu;
+    M.wl_pids = pids; M.wl_cnt = cnt; M.wl_max = lmax; M.wl_state = 1;
+    return true;
+  }
+  static size_t wide_lds(const DevCSR &M, int lmax)
+  {
+    const size_t nu = (size_t)M.pat_k * M.pat_nruns;
+    return (size_t)lmax * (nu + M.pat_k) * 8 + (size_t)lmax * 12 + (size_t)M.pat_np + 16;
+  }
   template <int EPI, bool ONEG>
   void launch_sells(const DevCSR &M, const StreamArgs2 &a2)
   {
@@ -1257,6 +1295,16 @@ struct gmg_solver {
       return;
     }
     if (EPI == EPI_SWEEP) M.note_sweep("sells_kernel<EPI_SWEEP,%s,RB=%d,K=%d,VD=%d> wgs=%d wpb=%d", ONEG ? "ONEG" : "2G", M.pat_coded ? M.pat_k : pat_rb, M.pat_k, M.pat_coded ? 1 : 0, nwg, wpb);
+    if (M.pat_coded && M.pat_k == 5 && prepare_wide(M, nwg, wpb, nsl, rows)) {
+      a.wl_pids = M.wl_pids; a.wl_cnt = M.wl_cnt; a.wl_stride = kWideStride; a.wl_max = M.wl_max;
+      const size_t ldsw = wide_lds(M, M.wl_max);
+      static bool attr_set = false;                         // per instantiation: LDS beyond the 64 KB default
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_kernel<EPI, ONEG, 5, 5, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true, 0, true>), g, b, ldsw, stream, a);
+    } else
     if (M.pat_coded && M.pat_k == 5) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true>), g, b, lds, stream, a);
     else if (M.pat_coded) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 3, 3, true>), g, b, lds, stream, a);
     else if (pat_rb == 9) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 9>), g, b, lds, stream, a);
@@ -2413,6 +2461,7 @@ struct gmg_solver {
     // it with agent-scope loads and a barrier precedes the gathers.  Off by default, kept as a switch.
     persist_fenced = env_int("GMG_PERSIST_FENCED", 0);
     pat_strict = env_int("GMG_PAT_STRICT", 1);
+    pat_wide = env_int("GMG_PAT_WIDE", 1);
     gj_mfma = env_int("GMG_GJ_MFMA", 1);
     persist_max_slices = env_int("GMG_PERSIST_MAX_SLICES", 0);
     pat_coded_min_rows = env_int("GMG_PAT_CODED_MIN_ROWS", 500000);
@@ -3118,6 +3167,7 @@ void gmg_solver::free_pattern(DevCSR &M)
   release(M.plen, (size_t)1); release(M.ppoff, (size_t)1); release(M.ppval, (size_t)1);
   release(M.ptab, (size_t)1); release(M.ptab8, (size_t)1); release(M.prun, (size_t)1); release(M.pdinv, (size_t)1);
   release(M.pcodes, (size_t)1); release(M.pdict, (size_t)1); release(M.prunmask, (size_t)1);
+  if (M.wl_state == 1) { release(M.wl_pids, (size_t)1); release(M.wl_cnt, (size_t)1); }
   M = DevCSR();
 }
 

@@ -1078,6 +1078,10 @@ struct SellSArgs {
   const double *b;
   double *x2;
   double *s_out;
+  // wide rows, per-workgroup value tables (sells_kernel<..., WL = true>): the patterns chunk c of the launch geometry uses
+  const uint16_t *wl_pids;  // [nwg * wl_stride] pattern ids, ascending
+  const int32_t *wl_cnt;    // [nwg]
+  int wl_stride, wl_max;    // list stride; largest list of the launch (sizes the LDS table)
 };
 
 // lane i <- lane i+1 ; lane 63 <- 0 (bound_ctrl: no separate initialisation of the destination)
@@ -1101,9 +1105,19 @@ __device__ __forceinline__ double bcast_lane(double v, int l)
 constexpr int kSellsRows = 62;
 // DBG (tools/mb_sells.hip only; the library instantiates DBG = 0): timing ablations that drop one ingredient each --
 // bit0 no high-word mask, bit1 coefficients not read from LDS, bit2 no DPP shifts, bit3 no gathers.  Wrong results by design.
-template <int EPI, bool ONEG, int RB, int K = 3, bool VD = false, int DBG = 0>
+// WL (coded tables only): wide rows -- Q2 stiffness and additive-Schwarz operators, 125 entries per row -- spend their time on
+// instruction issue, not on bytes: per entry the coded form pays a code read, a dictionary read, a compare + select for the mask
+// and the address arithmetic of both (8 vector instructions + 2 LDS reads).  A workgroup's chunk of consecutive rows uses only a
+// few of the patterns (6 x <= 4 x <= 2 of the 217 of a Q2 operator), so each workgroup decodes THOSE into a plain value table of
+// its own (list prepared once per launch geometry: sellw_chunk_patterns_kernel) and an entry costs one LDS read, a multiply and
+// an add.  Absent entries hold 0.0 and are NOT masked: with finite gathered values the products are exact zeros, which leave every
+// partial sum unchanged (a sum that starts at +0.0 never becomes -0.0) -- bit-identical to the masked form; a batch of runs whose
+// gathered values are not all finite takes the masked path with the codes read from global memory, so a non-finite entry of x
+// still reaches exactly the rows that store a coefficient for it.
+template <int EPI, bool ONEG, int RB, int K = 3, bool VD = false, int DBG = 0, bool WL = false>
 __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 {
+  static_assert(!WL || VD, "per-workgroup value tables are built from the coded form");
   constexpr int ROWS = 65 - K;
   extern __shared__ double sp_smem[];
   const int nu = K * a.nruns;
@@ -1151,19 +1165,172 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
       if (!tab_dinv) dr_n = dinv[row];
     }
   };
-  double *s_dinv = VD ? sp_smem + 256 + ((tot + 7) >> 3) : reinterpret_cast<double *>(s_msk + tot + (tot & 1));   // [np]
-  uint32_t *s_rmask = reinterpret_cast<uint32_t *>(s_dinv + a.np);                                                 // [np] (coded form)
-  if (VD) {
+  // WL: [wl_max * (nu + K)] values, the last run of every pattern all zeros (the multiply code is branch-free: a batch's missing
+  // runs use it) | [wl_max] 1/diag | [wl_max] run masks | [np] pattern id -> local id
+  double *s_dinv = WL ? sp_smem + (size_t)a.wl_max * (nu + K) : VD ? sp_smem + 256 + ((tot + 7) >> 3) : reinterpret_cast<double *>(s_msk + tot + (tot & 1));   // [np]
+  uint32_t *s_rmask = reinterpret_cast<uint32_t *>(s_dinv + (WL ? a.wl_max : a.np));                               // [np] (coded form)
+  uint8_t *s_map = reinterpret_cast<uint8_t *>(s_rmask + (WL ? a.wl_max : 0));
+  if (WL) {
+    const int lnp = a.wl_cnt[blk];
+    const uint16_t *mine = a.wl_pids + (size_t)blk * a.wl_stride;
+    for (int i = threadIdx.x; i < lnp; i += blockDim.x) {
+      const int p = mine[i];
+      s_map[p] = (uint8_t)i;
+      s_rmask[i] = a.runmask[p];
+      if (EPI == EPI_SWEEP && tab_dinv) s_dinv[i] = a.pdinv[p];
+    }
+    for (int i = threadIdx.x; i < lnp * (nu + K); i += blockDim.x) {
+      const int l = i / (nu + K), e = i - l * (nu + K);
+      sp_smem[i] = e < nu ? a.dict[a.codes[(size_t)mine[l] * nu + e]] : 0.0;
+    }
+  } else if (VD) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) sp_smem[i] = a.dict[i];
     uint8_t *wc = reinterpret_cast<uint8_t *>(sp_smem + 256);
     for (int i = threadIdx.x; i < tot; i += blockDim.x) wc[i] = a.codes[i];
     for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_rmask[i] = a.runmask[i];
   } else
   for (int i = threadIdx.x; i < tot; i += blockDim.x) { s_val[i] = a.tab[i].v; s_msk[i] = a.tab[i].m; }
-  if (EPI == EPI_SWEEP && tab_dinv)
+  if (!WL && EPI == EPI_SWEEP && tab_dinv)
     for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
   __syncthreads();
 
+  if constexpr (WL) {
+    // Batches of WB runs flow through a two-deep pipeline that runs ACROSS the slices of the wave: while batch k is multiplied the
+    // gathers of batch k + 1 are in flight, and when batch k is the last of its slice, batch k + 1 is the first of the next one
+    // (set up -- pattern ids -> local ids -> wave-OR of the run masks, row-wise operands requested -- before batch k is waited
+    // for).  Every batch issues exactly WB gathers (missing runs re-read run 0 and meet the zero run of the table) and each path has
+    // its own copy of the multiply code, so the waits are static vmcnt(#loads issued since).  Measured alternatives
+    // (profiles/r03_tuning.md section 8): 10 runs per batch (twice the registers: two waves per SIMD instead of four) and a
+    // three-slice pipeline with a register pair per run (two waves per SIMD) are both slower.
+    constexpr int WB = 5;
+    struct Ctx { int row0, gpid, lid; double e0, e1, e2, sp, dr; };
+    auto epilogue = [&](const Ctx &c, double sum) {
+      const int64_t row = (int64_t)c.row0 + lane;
+      if (!(lane < ROWS && row < a.nrows)) return;
+      if (EPI == EPI_SET) { a.y[row] = sum; if (a.s_out) a.s_out[row] = omega * (dinv[row] * sum); }
+      else if (EPI == EPI_SUB) { const double yn = c.e0 - sum; a.y[row] = yn; if (a.s_out) a.s_out[row] = omega * (dinv[row] * yn); }
+      else if (EPI == EPI_RESID) a.y[row] = c.e0 - sum;
+      else if (EPI == EPI_ADDTO) { const double t = a.omega != 0.0 ? a.omega * sum : sum; a.y[row] = t; a.x2[row] = c.e0 + t; }
+      else {
+        if (xmode == 0) a.x2[row] = c.e2 + c.e1;
+        else if (xmode == 2) a.x2[row] = (c.e2 + c.sp) + c.e1;
+        const double rn = c.e0 - sum;
+        a.y[row] = rn;
+        a.s_out[row] = omega * (((EPI == EPI_SWEEP && tab_dinv) ? s_dinv[c.lid] : c.dr) * rn);
+      }
+    };
+    int is = s_begin + wave;                                 // slice on the issue side
+    if (is >= s_end) return;
+    int pid_next = (int)a.rowpid[min((int64_t)is * ROWS + lane, lastrow)];
+    // run offsets: lane r of a register holds run_off[r] (nruns <= 32), read with v_readlane -- a scalar load per run put a
+    // constant-cache round trip in front of every batch of gathers
+    const int voff = a.run_off[min(lane, a.nruns - 1)];
+    uint32_t iM = 0;
+    Ctx nc;
+    auto setup = [&]() {                                     // slice `is`
+      const int64_t row = (int64_t)is * ROWS + lane;
+      nc.row0 = is * ROWS;
+      nc.gpid = (lane < ROWS && row <= lastrow) ? pid_next : a.np - 1;
+      nc.lid = (int)s_map[nc.gpid];
+      uint32_t m = s_rmask[nc.lid];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m |= (uint32_t)__shfl_xor((int)m, o);
+      iM = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+      const int64_t r = min(row, lastrow);
+      nc.e0 = nc.e1 = nc.e2 = nc.sp = nc.dr = 0.0;
+      if (EPI == EPI_SUB) nc.e0 = a.y[r];
+      else if (EPI == EPI_RESID) nc.e0 = a.b[r];
+      else if (EPI == EPI_ADDTO) nc.e0 = a.x2[r];
+      else if (EPI == EPI_SWEEP) {
+        nc.e0 = a.b[r];
+        nc.e1 = xg[r];
+        if (xmode != 1) { const double xl = a.x2[r]; nc.e2 = xzero ? 0.0 : xl; }
+        if (xmode == 2) nc.sp = a.s_out[r];
+        if (!tab_dinv) nc.dr = dinv[r];
+      }
+      pid_next = (int)a.rowpid[min((int64_t)min(is + wpb, s_end - 1) * ROWS + lane, lastrow)];
+    };
+    auto take = [&](int (&rr)[WB]) {
+#pragma unroll
+      for (int q = 0; q < WB; ++q) { rr[q] = iM ? (int)__builtin_ctz(iM) : -1; iM &= iM - 1; }
+      return iM == 0;
+    };
+    auto issue = [&](const int (&rr)[WB], double (&G)[WB]) {
+      const int row = nc.row0 + lane;
+#pragma unroll
+      for (int q = 0; q < WB; ++q) {
+        const int o = __builtin_amdgcn_readlane(voff, __builtin_amdgcn_readfirstlane(max(rr[q], 0)));
+        G[q] = ld_off(xg, 8u * (uint32_t)min(max(row + o, 0), last));
+      }
+    };
+    double sum = 0.0;
+    auto consume = [&](const int (&rr)[WB], const double (&G)[WB], const Ctx &c) {
+      const double *tv = sp_smem + c.lid * (nu + K);
+      bool fin = true;
+#pragma unroll
+      for (int q = 0; q < WB; ++q) fin = fin && __builtin_isfinite(G[q]);
+      if (__all(fin)) {
+        // five runs at a time: their 5 x K coefficients first, no branch in between (a branch per run made the compiler wait for each
+        // run's LDS reads right where it issued them); missing runs take the zero run -- exact zero products, the sum does not move
+#pragma unroll
+        for (int h = 0; h < WB; h += 5) {
+          if (rr[h] < 0) break;                              // uniform: the batch's runs are packed to the front
+          double cf[5][K];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            const double *tr = tv + (rr[h + q] >= 0 ? rr[h + q] : a.nruns) * K;
+#pragma unroll
+            for (int t = 0; t < K; ++t) cf[q][t] = tr[t];
+          }
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            double cur = G[h + q];
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+              if (t > 0) cur = wave_shl1(cur);
+              sum = sum + cf[q][t] * cur;
+            }
+          }
+        }
+      } else {                                               // a non-finite value in reach: masked products, codes from global memory
+        const uint8_t *gc = a.codes + (size_t)c.gpid * nu;
+#pragma unroll 1
+        for (int q = 0; q < WB; ++q) {
+          if (rr[q] < 0) continue;
+          double cur = G[q];
+#pragma unroll 1
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) cur = wave_shl1(cur);
+            const int code = gc[rr[q] * K + t];
+            const double gv = __hiloint2double(__double2hiint(cur) & ((code == 255) ? 0 : -1), __double2loint(cur));
+            sum = sum + tv[rr[q] * K + t] * gv;
+          }
+        }
+      }
+    };
+    int r0[WB], r1[WB];
+    double G0[WB], G1[WB];
+    bool l0, l1;                                             // the batch is the last of its slice
+    setup();
+    Ctx cc = nc;                                             // slice on the multiply side
+    l0 = take(r0);
+    issue(r0, G0);
+    for (;;) {
+      if (!l0) { l1 = take(r1); issue(r1, G1); consume(r0, G0, cc); }
+      else {
+        is += wpb;
+        if (is < s_end) { setup(); l1 = take(r1); issue(r1, G1); consume(r0, G0, cc); epilogue(cc, sum); sum = 0.0; cc = nc; }
+        else { consume(r0, G0, cc); epilogue(cc, sum); break; }
+      }
+      if (!l1) { l0 = take(r0); issue(r0, G0); consume(r1, G1, cc); }
+      else {
+        is += wpb;
+        if (is < s_end) { setup(); l0 = take(r0); issue(r0, G0); consume(r1, G1, cc); epilogue(cc, sum); sum = 0.0; cc = nc; }
+        else { consume(r1, G1, cc); epilogue(cc, sum); break; }
+      }
+    }
+    return;
+  }
   // coded form: the run mask of a slice hangs off its pattern ids (load -> LDS -> wave OR -> gathers), so the ids alone
   // are requested one slice ahead
   int pid_ahead = a.np - 1;
@@ -1210,6 +1377,7 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 #pragma unroll
         for (int q = 0; q < RB; ++q)
           if (rr[q] >= 0) A[q] = ld_off(xg, 8u * (uint32_t)min(max((int)row + a.run_off[rr[q]], 0), last));
+        {
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
           if (rr[q] < 0) continue;
@@ -1221,6 +1389,7 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
             const double g = __hiloint2double(__double2hiint(cur) & ((code == 255) ? 0 : -1), __double2loint(cur));
             s = s + sp_smem[code] * g;
           }
+        }
         }
       }
     } else {
@@ -1257,6 +1426,37 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
         a.s_out[row] = omega * (dinv_row * rn);
       }
     }
+  }
+}
+
+// The patterns each chunk of sells_kernel's launch geometry uses (chunk c = the slices workgroup c walks after the XCD remap):
+// ids ascending, the empty pattern np - 1 always among them (halo lanes and rows past the end take it).  cnt[c] may exceed
+// `stride` (then the list is truncated and the caller does not use the per-workgroup tables).
+__global__ __launch_bounds__(256) void sellw_chunk_patterns_kernel(const uint16_t *__restrict__ rowpid, int64_t nrows, int nslices, int rows_per_slice,
+                                                                    int np, int stride, uint16_t *__restrict__ pids, int32_t *__restrict__ cnt)
+{
+  __shared__ uint32_t bits[128];                             // np <= 4096
+  const int nwg = gridDim.x, blk = blockIdx.x;
+  const int chunk_lo = nslices / nwg, chunk_rem = nslices % nwg;
+  const int s_begin = blk * chunk_lo + min(blk, chunk_rem);
+  const int s_end = s_begin + chunk_lo + (blk < chunk_rem ? 1 : 0);
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) bits[i] = 0u;
+  __syncthreads();
+  const int64_t r0 = (int64_t)s_begin * rows_per_slice, r1 = min(nrows, (int64_t)s_end * rows_per_slice);
+  for (int64_t i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+    const int p = rowpid[i];
+    atomicOr(&bits[p >> 5], 1u << (p & 31));
+  }
+  if (threadIdx.x == 0) atomicOr(&bits[(np - 1) >> 5], 1u << ((np - 1) & 31));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < (np + 31) / 32; ++w)
+      for (uint32_t m = bits[w]; m; m &= m - 1) {
+        if (c < stride) pids[(size_t)blk * stride + c] = (uint16_t)(w * 32 + __builtin_ctz(m));
+        ++c;
+      }
+    cnt[blk] = c;
   }
 }
 

@@ -278,3 +278,46 @@ def test_source_deduplication_of_patch_blocks_is_bitwise_the_batch_path(S, po, o
         xs[mode] = x
         ns.P_ns.close()
     assert np.array_equal(xs["1"], xs["0"])
+
+
+# ---------------------------------------------------------------- wide rows: per-workgroup value tables of the coded form
+@pytest.mark.parametrize("nc", [(16, 16, 16), (24, 10, 12)])
+def test_wide_row_tables_are_bitwise_the_coded_kernel(S, po, orc, monkeypatch, nc):
+    """Q2 operators in the coded row-pattern form (125 entries per row): every workgroup decodes the patterns its chunk uses into a
+    plain LDS value table (`sells_kernel<..., WL>`, GMG_PAT_WIDE) and multiplies unmasked.  mul!(y, A, x) equals the oracle's
+    sequential row sums bit for bit, an Inf in x reaches exactly the rows that store a coefficient for it (the kernel takes its
+    masked path for batches with a non-finite value), and a patch-smoothed FGMRES solve gives the same bits with and without."""
+    from gridapsolvers_jl_amd import abi
+    monkeypatch.setenv("GMG_PAT_CODED_MIN_ROWS", "0")               # the coded shared-offset table (what the 10^8-dof levels use) for A and M
+    order, nlev = 2, 2
+    H = po.build_hierarchy(nc, nlev, order, stream_min_rows=5000)
+    Hw = po.build_hierarchy(nc, nlev, order)
+    A = Hw["mats"][0]
+    b = po.dirichlet_lift_rhs(nc, order)
+    tabs = [po.vertex_star_patches(c, order) for c in H["ncells"][:-1]]
+    x = np.random.default_rng(11).uniform(-1, 1, A.shape[0])
+    k = A.shape[0] // 2 + 3
+    xi = x.copy(); xi[k] = np.inf
+    As = A.to_scipy().tocsc()
+    touched = np.zeros(A.shape[0], dtype=bool)
+    touched[As.indices[As.indptr[k]:As.indptr[k + 1]]] = True
+    sols = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GMG_PAT_WIDE", mode)
+        sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 5, 0.2) for pp, pd in tabs]
+        solver = S.FGMRESSolver(5, make_gmg(S, H, pre_smoothers=sm), maxiter=20, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        fmt = ns.P_ns.level_format(0)
+        assert fmt["row_patterns"], fmt
+        y = np.zeros_like(x)
+        ns.P_ns.op_apply(0, abi.OP_A, x, y)
+        assert np.array_equal(y, orc.spmv(A, x))
+        yi = np.zeros_like(x)
+        ns.P_ns.op_apply(0, abi.OP_A, xi, yi)
+        assert np.all(np.isfinite(yi[~touched])) and not np.any(np.isfinite(yi[touched]))
+        assert np.array_equal(yi[~touched], y[~touched])
+        xs = np.zeros_like(b)
+        S.solve_(xs, ns, b)
+        sols[mode] = (xs, solver.log.num_iters, np.array(solver.log.residuals[: solver.log.num_iters + 1]))
+        ns.P_ns.close()
+    assert sols["1"][1] == sols["0"][1] and np.array_equal(sols["1"][2], sols["0"][2]) and np.array_equal(sols["1"][0], sols["0"][0])

@@ -99,6 +99,28 @@ __global__ __launch_bounds__(256) void fma_rate_kernel(int iters, double *__rest
   if (t == 12345.678) sink[0] = t;
 }
 
+// v_mul_f64 / v_add_f64 rates (the sparse kernels multiply and add separately: -ffp-contract=off, the reference's roundings)
+template <int MODE>   // 0: 16 independent mul chains, 1: 16 independent add chains, 2: mul feeding ONE dependent add chain (a row sum)
+__global__ __launch_bounds__(256) void muladd_rate_kernel(int iters, double *__restrict__ sink)
+{
+  double acc[16];
+  for (int q = 0; q < 16; ++q) acc[q] = 1.0 + q * 1e-3;
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
+  double sum = 0.0;
+  for (int it = 0; it < iters; ++it)
+#pragma unroll
+    for (int s = 0; s < 128; ++s)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (MODE == 0) acc[q] = acc[q] * a;
+        else if (MODE == 1) acc[q] = acc[q] + b;
+        else { sum = sum + acc[q] * a; }
+      }
+  double t = sum;
+  for (int q = 0; q < 16; ++q) t += acc[q];
+  if (t == 12345.678) sink[0] = t;
+}
+
 int main(int argc, char **argv)
 {
   const int n = argc > 1 ? atoi(argv[1]) : 29791;
@@ -150,6 +172,12 @@ int main(int argc, char **argv)
     printf("v_mfma_f64_16x16x4, 8 chains / wave    %8.3f ms  %6.1f TFLOP/s\n", t, fl / t / 1e9);
     t = time_it([&] { hipLaunchKernelGGL(fma_rate_kernel, dim3(256 * 16), dim3(256), 0, 0, iters, sink); });
     printf("v_fma_f64, 16 chains / lane            %8.3f ms  %6.1f TFLOP/s\n", t, fl / t / 1e9);
+    t = time_it([&] { hipLaunchKernelGGL((muladd_rate_kernel<0>), dim3(256 * 16), dim3(256), 0, 0, iters, sink); });
+    printf("v_mul_f64, 16 chains / lane            %8.3f ms  %6.1f Tinstr-lanes/s (x 1e12)\n", t, fl / 2 / t / 1e9);
+    t = time_it([&] { hipLaunchKernelGGL((muladd_rate_kernel<1>), dim3(256 * 16), dim3(256), 0, 0, iters, sink); });
+    printf("v_add_f64, 16 chains / lane            %8.3f ms  %6.1f\n", t, fl / 2 / t / 1e9);
+    t = time_it([&] { hipLaunchKernelGGL((muladd_rate_kernel<2>), dim3(256 * 16), dim3(256), 0, 0, iters, sink); });
+    printf("mul + dependent add (one row sum)      %8.3f ms  %6.1f pairs\n", t, fl / 2 / t / 1e9);
   }
   return 0;
 }
