@@ -3189,13 +3189,30 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   // slot -> patch, dof -> slots in ascending patch order
   std::vector<int32_t> s2p((size_t)ne);
   parallel_for(npatch, [&](int64_t p) { for (int64_t q = T.pptr[p]; q < T.pptr[p + 1]; ++q) s2p[(size_t)q] = (int32_t)p; });
+  // (counting sort over 4.6e8 slots at 256^3 Q2: counted and scattered by all cores with relaxed atomic increments, then every
+  // dof's short list is sorted back into ascending slot = patch order -- the result does not depend on the interleaving)
   std::vector<int64_t> iptr((size_t)n + 1, 0);
   std::vector<int32_t> inc((size_t)ne);
-  for (int64_t q = 0; q < ne; ++q) iptr[(size_t)T.prow[(size_t)q] + 1]++;
-  for (int64_t i = 0; i < n; ++i) iptr[(size_t)i + 1] += iptr[(size_t)i];
   {
+    const int64_t TQ = std::max<int64_t>(1, std::min<int64_t>(64, ne / (1 << 20)));
+    const int64_t perq = (ne + TQ - 1) / TQ;
+    parallel_chunks(TQ, [&](int64_t t) {
+      for (int64_t q = t * perq; q < std::min(ne, (t + 1) * perq); ++q) __atomic_fetch_add(&iptr[(size_t)T.prow[(size_t)q] + 1], (int64_t)1, __ATOMIC_RELAXED);
+    });
+    for (int64_t i = 0; i < n; ++i) iptr[(size_t)i + 1] += iptr[(size_t)i];
     std::vector<int64_t> fill(iptr.begin(), iptr.end() - 1);
-    for (int64_t q = 0; q < ne; ++q) inc[(size_t)fill[(size_t)T.prow[(size_t)q]]++] = (int32_t)q;
+    parallel_chunks(TQ, [&](int64_t t) {
+      for (int64_t q = t * perq; q < std::min(ne, (t + 1) * perq); ++q)
+        inc[(size_t)__atomic_fetch_add(&fill[(size_t)T.prow[(size_t)q]], (int64_t)1, __ATOMIC_RELAXED)] = (int32_t)q;
+    });
+    const int64_t TD = std::max<int64_t>(1, std::min<int64_t>(64, n / (1 << 18)));
+    const int64_t perd = (n + TD - 1) / TD;
+    parallel_chunks(TD, [&](int64_t t) {
+      for (int64_t i = t * perd; i < std::min(n, (t + 1) * perd); ++i) {
+        int32_t *lo = inc.data() + iptr[(size_t)i], *hi = inc.data() + iptr[(size_t)i + 1];
+        if (hi - lo > 1) std::sort(lo, hi);
+      }
+    });
   }
   // exact numbering of integer sequences: ids by first appearance (two parallel passes + a short sequential one)
   auto sequence_ids = [&](int64_t nitems, auto len, auto word, std::vector<int32_t> &ids, std::vector<int64_t> &rep, int max_ids) -> bool {
@@ -3319,7 +3336,17 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   }
   P.rowpid.resize((size_t)n);
   parallel_for(n, [&](int64_t i) { P.rowpid[(size_t)i] = (uint16_t)sig[(size_t)i]; });
-  for (int64_t i = 0; i < n; ++i) P.nnz += P.len[(size_t)sig[(size_t)i]];
+  {
+    const int64_t TN = std::max<int64_t>(1, std::min<int64_t>(64, n / (1 << 18)));
+    const int64_t pern = (n + TN - 1) / TN;
+    std::vector<int64_t> part((size_t)TN, 0);
+    parallel_chunks(TN, [&](int64_t t) {
+      int64_t c = 0;
+      for (int64_t i = t * pern; i < std::min(n, (t + 1) * pern); ++i) c += P.len[(size_t)sig[(size_t)i]];
+      part[(size_t)t] = c;
+    });
+    for (int64_t c : part) P.nnz += c;
+  }
   P.rows_seen = n;
   if (P.nnz <= 0) return;
   try {
