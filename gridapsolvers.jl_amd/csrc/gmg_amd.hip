@@ -257,7 +257,7 @@ struct DevCSR {
   uint32_t *prunmask = nullptr;
   // per-workgroup value tables of the coded form (sells_kernel<..., WL>): pattern lists of the launch geometry they were built for
   mutable int wl_state = 0;     // 0 not looked at, 1 in use, 2 not applicable (too many patterns in one chunk / switched off)
-  mutable int wl_nwg = 0, wl_wpb = 0, wl_max = 0;
+  mutable int wl_req = 0, wl_nwg = 0, wl_wpb = 0, wl_max = 0;   // requested / launched workgroups
   mutable uint16_t *wl_pids = nullptr;
   mutable int32_t *wl_cnt = nullptr;
   // offset-pattern layout (SELL-O): SELL-64 value stream + a 16-bit offset-pattern id per row, no column stream
@@ -1218,31 +1218,46 @@ struct gmg_solver {
     }
   }
   static constexpr int kWideStride = 64;                     // patterns per chunk the lists hold
-  // which patterns every chunk of the launch geometry (nwg workgroups of wpb waves) touches; false: the coded kernel stays
-  bool prepare_wide(const DevCSR &M, int nwg, int wpb, int nsl, int rows)
+  // which patterns every chunk of the launch geometry touches.  Returns the number of workgroups to launch (0: the coded kernel
+  // stays): the requested count, or -- when the tables let fewer workgroups be resident than that -- a whole number of resident
+  // rounds (3 workgroups per CU fit with the 51 KB of a Q2 stiffness matrix: 2048 workgroups would run 3 + 3 + 2 per CU, the last
+  // round a third empty; 1536 run 3 + 3).
+  int prepare_wide(const DevCSR &M, int nwg_req, int wpb, int nsl, int rows)
   {
-    if (M.wl_state != 0 && M.wl_nwg == nwg && M.wl_wpb == wpb) return M.wl_state == 1;
+    if (M.wl_state != 0 && M.wl_req == nwg_req && M.wl_wpb == wpb) return M.wl_state == 1 ? M.wl_nwg : 0;
     if (M.wl_state == 1) { HIP_CHECK(hipStreamSynchronize(stream)); release(M.wl_pids, (size_t)M.wl_nwg * kWideStride); release(M.wl_cnt, (size_t)M.wl_nwg); }
-    M.wl_state = 2; M.wl_nwg = nwg; M.wl_wpb = wpb; M.wl_max = 0;
-    if (!pat_wide || !M.pat_coded || M.pat_np > 4096 || M.pat_np < 2 || !M.rowpid || !M.pcodes || !M.pdict || !M.prunmask) return false;
-    uint16_t *pids = dalloc<uint16_t>((size_t)nwg * kWideStride);
-    int32_t *cnt = dalloc<int32_t>((size_t)nwg);
-    hipLaunchKernelGGL(sellw_chunk_patterns_kernel, dim3(nwg), dim3(256), 0, stream, M.rowpid, M.nrows, nsl, rows, M.pat_np, kWideStride, pids, cnt);
-    HIP_CHECK(hipGetLastError());
-    std::vector<int32_t> h((size_t)nwg);
-    HIP_CHECK(hipMemcpyAsync(h.data(), cnt, sizeof(int32_t) * (size_t)nwg, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    const int lmax = *std::max_element(h.begin(), h.end());
-    const int nu = M.pat_k * M.pat_nruns;
-    if (env_int("GMG_SETUP_TIMING", 0))
-      std::fprintf(stderr, "[gmg] wide-row tables: %lld rows, %d patterns x %d entries, %d workgroups, at most %d patterns per chunk -> %zu B of LDS\n", (long long)M.nrows, M.pat_np, nu, nwg, lmax, wide_lds(M, std::min(lmax, 255)));
-    if (lmax > kWideStride || lmax > 255 || wide_lds(M, lmax) > (size_t)env_int("GMG_PAT_WIDE_LDS", 72 * 1024)) {
-      release(pids, (size_t)nwg * kWideStride); release(cnt, (size_t)nwg);
-      return false;
+    M.wl_state = 2; M.wl_req = nwg_req; M.wl_nwg = 0; M.wl_wpb = wpb; M.wl_max = 0;
+    if (!pat_wide || !M.pat_coded || M.pat_np > 4096 || M.pat_np < 2 || !M.rowpid || !M.pcodes || !M.pdict || !M.prunmask) return 0;
+    const size_t lds_cap = (size_t)env_int("GMG_PAT_WIDE_LDS", 72 * 1024);
+    int nwg = nwg_req;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      uint16_t *pids = dalloc<uint16_t>((size_t)nwg * kWideStride);
+      int32_t *cnt = dalloc<int32_t>((size_t)nwg);
+      hipLaunchKernelGGL(sellw_chunk_patterns_kernel, dim3(nwg), dim3(256), 0, stream, M.rowpid, M.nrows, nsl, rows, M.pat_np, kWideStride, pids, cnt);
+      HIP_CHECK(hipGetLastError());
+      std::vector<int32_t> h((size_t)nwg);
+      HIP_CHECK(hipMemcpyAsync(h.data(), cnt, sizeof(int32_t) * (size_t)nwg, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      const int lmax = *std::max_element(h.begin(), h.end());
+      const bool ok = lmax <= kWideStride && lmax <= 255 && wide_lds(M, lmax) <= lds_cap;
+      // resident workgroups per CU: LDS (160 KB) and registers (128 per lane: 4 waves per SIMD)
+      const int per_cu = ok ? (int)std::min<size_t>((size_t)(160 * 1024) / (wide_lds(M, lmax) + 512), (size_t)std::max(1, 16 / wpb)) : 0;
+      const int resident = per_cu * 256;
+      if (env_int("GMG_SETUP_TIMING", 0))
+        std::fprintf(stderr, "[gmg] wide-row tables: %lld rows, %d patterns x %d entries, %d workgroups, at most %d patterns per chunk -> %zu B of LDS, %d workgroups per CU\n",
+                     (long long)M.nrows, M.pat_np, M.pat_k * M.pat_nruns, nwg, lmax, wide_lds(M, std::min(lmax, 255)), per_cu);
+      if (!ok) { release(pids, (size_t)nwg * kWideStride); release(cnt, (size_t)nwg); return 0; }
+      const int rounds = resident > 0 ? nwg / resident : 0;
+      if (attempt == 0 && env_int("GMG_PAT_WIDE_ROUNDS", 1) && rounds >= 1 && nwg % resident != 0) {
+        // not a whole number of rounds: take the whole rounds below the request and list the patterns of THAT geometry
+        release(pids, (size_t)nwg * kWideStride); release(cnt, (size_t)nwg);
+        nwg = rounds * resident;
+        continue;
+      }
+      M.wl_pids = pids; M.wl_cnt = cnt; M.wl_max = lmax; M.wl_nwg = nwg; M.wl_state = 1;
+      return nwg;
     }
-    (void)nu;
-    M.wl_pids = pids; M.wl_cnt = cnt; M.wl_max = lmax; M.wl_state = 1;
-    return true;
+    return 0;
   }
   static size_t wide_lds(const DevCSR &M, int lmax)
   {
@@ -1295,7 +1310,9 @@ struct gmg_solver {
       return;
     }
     if (EPI == EPI_SWEEP) M.note_sweep("sells_kernel<EPI_SWEEP,%s,RB=%d,K=%d,VD=%d> wgs=%d wpb=%d", ONEG ? "ONEG" : "2G", M.pat_coded ? M.pat_k : pat_rb, M.pat_k, M.pat_coded ? 1 : 0, nwg, wpb);
-    if (M.pat_coded && M.pat_k == 5 && prepare_wide(M, nwg, wpb, nsl, rows)) {
+    const int nwg_wide = (M.pat_coded && M.pat_k == 5) ? prepare_wide(M, nwg, wpb, nsl, rows) : 0;
+    if (nwg_wide > 0) {
+      const dim3 g(nwg_wide);
       a.wl_pids = M.wl_pids; a.wl_cnt = M.wl_cnt; a.wl_stride = kWideStride; a.wl_max = M.wl_max;
       const size_t ldsw = wide_lds(M, M.wl_max);
       static bool attr_set = false;                         // per instantiation: LDS beyond the 64 KB default
@@ -1303,6 +1320,8 @@ struct gmg_solver {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_kernel<EPI, ONEG, 5, 5, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
       }
+      if (env_int("GMG_DBG_NOGATHER", 0)) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true, 8, true>), g, b, ldsw, stream, a);   // timing ablation only
+      else
       hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true, 0, true>), g, b, ldsw, stream, a);
     } else
     if (M.pat_coded && M.pat_k == 5) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true>), g, b, lds, stream, a);

@@ -1260,6 +1260,8 @@ __global__ __launch_bounds__(kBlock) void sells_kernel(SellSArgs a)
 #pragma unroll
       for (int q = 0; q < WB; ++q) {
         const int o = __builtin_amdgcn_readlane(voff, __builtin_amdgcn_readfirstlane(max(rr[q], 0)));
+        if (DBG & 8) G[q] = (double)(o + lane);              // timing ablation: no gathers (wrong results)
+        else
         G[q] = ld_off(xg, 8u * (uint32_t)min(max(row + o, 0), last));
       }
     };
