@@ -1661,19 +1661,37 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
 #pragma unroll
           for (int q = 0; q < RB; ++q) A[i][q] = ld_off(rg, 8u * (uint32_t)min(max(row[i] + a.run_off[r0 + RB + q], 0), last));
         }
+        // MK (strict masks): absent entries hold 0.0, so with finite values in every lane of the three windows the products are
+        // exact zeros and leave the partial sums as they are -- the mask is only applied (27 v_and + 27 mask reads per slice)
+        // when a window holds a non-finite value, which must reach exactly the rows that store a coefficient for it
+        bool fin = true;
+        if (MK) {
 #pragma unroll
-        for (int q = 0; q < RB; ++q) {
-          double c = cur[q];
+          for (int q = 0; q < RB; ++q) fin = fin && __builtin_isfinite(cur[q]);
+          fin = __all(fin);
+        }
+        if (MK && !fin) {
 #pragma unroll
-          for (int t = 0; t < K; ++t) {
-            if (t > 0) c = wave_shl1(c);
-            const int j = (r0 + q) * K + t;
-            if (MK) {
-              const PatEntry en = te[j];
+          for (int q = 0; q < RB; ++q) {
+            double c = cur[q];
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+              if (t > 0) c = wave_shl1(c);
+              const PatEntry en = te[(r0 + q) * K + t];
               const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
               s = s + en.v * g;
-            } else
-              s = s + tv[j] * c;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            double c = cur[q];
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+              if (t > 0) c = wave_shl1(c);
+              const int j = (r0 + q) * K + t;
+              s = s + (MK ? te[j].v : tv[j]) * c;
+            }
           }
         }
       }

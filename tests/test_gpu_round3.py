@@ -321,3 +321,33 @@ def test_wide_row_tables_are_bitwise_the_coded_kernel(S, po, orc, monkeypatch, n
         sols[mode] = (xs, solver.log.num_iters, np.array(solver.log.residuals[: solver.log.num_iters + 1]))
         ns.P_ns.close()
     assert sols["1"][1] == sols["0"][1] and np.array_equal(sols["1"][2], sols["0"][2]) and np.array_equal(sols["1"][0], sols["0"][0])
+
+
+# ---------------------------------------------------------------- strict masks only where a non-finite value is in reach
+@pytest.mark.parametrize("persist", ["0", "1"])
+@pytest.mark.parametrize("niter", [1, 3])
+def test_sweeps_confine_non_finite_values_like_the_reference(S, po, orc, monkeypatch, persist, niter):
+    """The r-gather sweep multiplies unmasked when every value of a batch of windows is finite (absent entries hold 0.0: exact zero
+    products) and applies the per-entry masks otherwise.  RichardsonSmoothers.jl:84-98 with an Inf in r: the non-finite entries of x
+    and r are exactly the ones the oracle's row sums give (two hops per sweep), every other entry is bit-identical to it -- with
+    per-sweep launches (GMG_PERSIST=0: sells_rsweep_kernel) and in the one-launch pass."""
+    monkeypatch.setenv("GMG_PERSIST", persist)
+    nc, nlev = (24, 20, 16), 2
+    H = po.build_hierarchy(nc, nlev, 1)
+    sm = [S.RichardsonSmoother(S.JacobiLinearSolver(), niter, 2.0 / 3.0)] * (nlev - 1)
+    ns = setup(S, make_gmg(S, H, pre_smoothers=sm), H["mats"][0])
+    assert ns.level_format(0)["row_patterns"]
+    go = orc.GMG(H["mats"], H["prolongations"], pre_smoothers=[orc.Smoother(orc.JACOBI, niter, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
+    n = H["mats"][0].shape[0]
+    rng = np.random.default_rng(5)
+    for k, bad in ((n // 2 + 7, np.inf), (3, -np.inf), (n - 2, np.nan)):
+        x0, r0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        r0[k] = bad
+        x, r = x0.copy(), r0.copy()
+        ns.smooth(0, x, r)
+        xo, ro = go.smooth(0, x0, r0)
+        fx, fr = np.isfinite(xo), np.isfinite(ro)
+        assert np.array_equal(np.isfinite(x), fx) and np.array_equal(np.isfinite(r), fr)
+        assert 0 < np.count_nonzero(~fr) < n // 4
+        assert np.array_equal(x[fx], xo[fx]) and np.array_equal(r[fr], ro[fr])
+    ns.close()
