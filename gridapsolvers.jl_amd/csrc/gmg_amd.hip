@@ -1715,6 +1715,7 @@ struct gmg_solver {
     const DevCSR &M = L.A;
     if (!(pat_rsweep && one_gather_sweep && pat_dinv && M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && pat_rb == 3 && pat_batched)) return false;
     if (M.pat_nruns % 3 != 0 || !M.pdinv || !M.pdinv_uniform || !L.rbuf[0] || !L.rbuf[1]) return false;
+    if (M.ncols >= (int64_t)(1 << 28) || M.nrows >= (int64_t)(1 << 28)) return false;      // signed 32-bit byte offsets in the gathers
     const int nu = M.pat_k * M.pat_nruns;
     return (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16 <= 64 * 1024;
   }

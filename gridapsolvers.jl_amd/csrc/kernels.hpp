@@ -1603,6 +1603,14 @@ __global__ __launch_bounds__(kBlock) void sells_sweep_kernel(SellSArgs a)
 // (profiles/r03_tuning.md).  Same products, same order, same roundings as sells_sweep_kernel: bit-identical (tested).
 //   a.x = r_k (gathered, incl. the row's own value) ; a.y = r_{k+1} ; a.s_out = r_{k-1} (XM = 2 only; may be a.y) ; a.pdinv[0] = d
 // ---------------------------------------------------------------------------
+// clamp(x, 0, hi) in one instruction (the compiler emits v_max + v_min for min(max(x, 0), hi) with a run-time bound)
+__device__ __forceinline__ int clamp0_med3(int x, int hi)
+{
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+  return r;
+}
+
 template <int XM, int NB, bool MK, int NT = 0>
 __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
 {
@@ -1622,7 +1630,7 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
   const double *__restrict__ rg = a.x;
   const double omega = a.omega;
   const double du = a.pdinv[0];                              // the one 1/diag (uniform: scalar load)
-  const int last = (int)a.ncols - 1;
+  const int last8 = 8 * ((int)a.ncols - 1);
   const int lastrow = (int)a.nrows - 1;
   const bool xz = a.x_zero != 0;
   int pid[NB], row[NB];
@@ -1639,7 +1647,7 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
       if (XM != 1) { const double xl = NT ? __builtin_nontemporal_load(a.x2 + rc) : a.x2[rc]; e2[i] = xz ? 0.0 : xl; }
       if (XM == 2) rp[i] = a.s_out[rc];                      // r_{k-1} of the row, read before this sweep overwrites it
 #pragma unroll
-      for (int q = 0; q < RB; ++q) A[i][q] = ld_off(rg, 8u * (uint32_t)min(max(row[i] + a.run_off[q], 0), last));
+      for (int q = 0; q < RB; ++q) A[i][q] = ld_off(rg, (uint32_t)clamp0_med3(8 * row[i] + 8 * a.run_off[q], last8));   // byte offsets: add + clamp (ncols < 2^28)
     }
   };
   int sb = s_begin + wave;
@@ -1659,7 +1667,7 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
         for (int q = 0; q < RB; ++q) cur[q] = omega * (du * A[i][q]);   // s = omega*(Dinv*r): once per loaded value
         if (r0 + RB < a.nruns) {
 #pragma unroll
-          for (int q = 0; q < RB; ++q) A[i][q] = ld_off(rg, 8u * (uint32_t)min(max(row[i] + a.run_off[r0 + RB + q], 0), last));
+          for (int q = 0; q < RB; ++q) A[i][q] = ld_off(rg, (uint32_t)clamp0_med3(8 * row[i] + 8 * a.run_off[r0 + RB + q], last8));
         }
         // MK (strict masks): absent entries hold 0.0, so with finite values in every lane of the three windows the products are
         // exact zeros and leave the partial sums as they are -- the mask is only applied (27 v_and + 27 mask reads per slice)
