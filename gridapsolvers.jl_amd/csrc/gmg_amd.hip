@@ -256,6 +256,7 @@ struct DevCSR {
   double *pdict = nullptr;
   uint32_t *prunmask = nullptr;
   // per-workgroup value tables of the coded form (sells_kernel<..., WL>): pattern lists of the launch geometry they were built for
+  mutable std::vector<int32_t> h_run_off;   // host copy of prun (tile sweep geometry), fetched on first use
   mutable int wl_state = 0;     // 0 not looked at, 1 in use, 2 not applicable (too many patterns in one chunk / switched off)
   mutable int wl_req = 0, wl_nwg = 0, wl_wpb = 0, wl_max = 0;   // requested / launched workgroups
   mutable uint16_t *wl_pids = nullptr;
@@ -544,6 +545,8 @@ struct gmg_solver {
   int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
   int64_t pat_coded_min_rows = 500000;   // GMG_PAT_CODED_MIN_ROWS
   int gj_mfma = 1;      // GMG_GJ_MFMA: trailing update of the device coarse inversion on the FP64 matrix cores
+  int pat_tile = 1;     // GMG_PAT_TILE: r-gather sweeps share their gathers through LDS (sells_tsweep_kernel): 0 never, 1 on levels of >= GMG_PAT_TILE_ROWS rows, 2 wherever it applies
+  int64_t pat_tile_rows = 6000000;
   int pat_wide = 1;     // GMG_PAT_WIDE: coded (wide-row) operators decode the patterns of each workgroup's chunk into a plain LDS value table
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
@@ -1719,6 +1722,84 @@ struct gmg_solver {
     const int nu = M.pat_k * M.pat_nruns;
     return (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16 <= 64 * 1024;
   }
+  // the tile form of that sweep (kernels.hpp: sells_tsweep_kernel): segments of r a tile of T slices needs, merged over the runs
+  bool launch_tsweep(const DevCSR &M, const SellSArgs &a, int nsl)
+  {
+    constexpr int WPB = 16, ROWS = 62, TMAX = 3 * WPB;
+    if (M.pat_nruns > 32 || nsl < env_int("GMG_PAT_TILE_MIN", 512)) return false;
+    std::vector<int32_t> &off = M.h_run_off;
+    if (off.empty()) {
+      off.resize((size_t)M.pat_nruns);
+      HIP_CHECK(hipMemcpyAsync(off.data(), M.prun, sizeof(int32_t) * (size_t)M.pat_nruns, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    const bool mk = pat_strict || !M.ptab8;
+    const int nu = M.pat_k * M.pat_nruns;
+    const size_t lds_cap = (size_t)env_int("GMG_PAT_TILE_LDS", 78 * 1024);      // two workgroups of 16 waves per CU
+    std::vector<int> order((size_t)M.pat_nruns);
+    for (int r = 0; r < M.pat_nruns; ++r) order[(size_t)r] = r;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return off[(size_t)x] < off[(size_t)y]; });
+    // segments of r a tile of T slices needs: the runs' stretches [off, off + 62 T + 2), merged where they overlap or touch
+    auto geometry = [&](int T, SellTile &tl) -> size_t {
+      std::memset(&tl, 0, sizeof(tl));
+      tl.T = T;
+      const int RT = ROWS * T;
+      int nseg = 0;
+      int64_t elems = 0;
+      for (int k = 0; k < M.pat_nruns; ++k) {
+        const int r = order[(size_t)k];
+        const int64_t lo = off[(size_t)r], hi = (int64_t)off[(size_t)r] + RT + 2;
+        if (nseg > 0 && lo <= (int64_t)tl.seg_off[nseg - 1] + tl.seg_len[nseg - 1])
+          tl.seg_len[nseg - 1] = (int)std::max<int64_t>(tl.seg_len[nseg - 1], hi - tl.seg_off[nseg - 1]);
+        else {
+          if (nseg == 12) return 0;
+          tl.seg_off[nseg] = (int)lo; tl.seg_len[nseg] = (int)(hi - lo);
+          ++nseg;
+        }
+      }
+      for (int sg = 0; sg < nseg; ++sg) { tl.seg_base[sg] = (int)elems; elems += tl.seg_len[sg]; }
+      for (int r = 0; r < M.pat_nruns; ++r) {
+        int sg = 0;
+        while (!(off[(size_t)r] >= tl.seg_off[sg] && (int64_t)off[(size_t)r] + RT + 2 <= (int64_t)tl.seg_off[sg] + tl.seg_len[sg])) ++sg;
+        tl.run_lds[r] = tl.seg_base[sg] + (off[(size_t)r] - tl.seg_off[sg]);
+      }
+      tl.nseg = nseg; tl.elems = (int)elems;
+      return (size_t)M.pat_np * nu * (mk ? 16 : 8) + (size_t)elems * 8 + 16;
+    };
+    // the largest tile that fits the LDS budget, then the tile size that fills whole rounds of the resident workgroups
+    SellTile tl;
+    int tmax = env_int("GMG_PAT_TILE_T", TMAX);
+    tmax = std::max(WPB, std::min(tmax, TMAX));
+    size_t lds = 0;
+    for (; tmax >= WPB; --tmax) { lds = geometry(tmax, tl); if (lds != 0 && lds <= lds_cap) break; }
+    if (tmax < WPB) return false;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (size_t)(160 * 1024) / (lds + 512)));
+    const int resident = per_cu * 256;
+    const int rounds = (nsl + resident * tmax - 1) / (resident * tmax);
+    const int T = std::max(WPB, (nsl + rounds * resident - 1) / (rounds * resident));
+    lds = geometry(T, tl);
+    if (lds == 0 || lds > lds_cap) return false;
+    const int ntiles = (nsl + T - 1) / T;
+    const int nwg = std::max(8, (std::min(ntiles, resident) / 8) * 8);          // a multiple of 8: one share per XCD
+    const dim3 g(nwg), b(64 * WPB);
+    M.note_sweep("sells_tsweep_kernel<XM=*,MK=%d,WPB=%d> T=%d tiles=%d wgs=%d segs=%d", mk ? 1 : 0, WPB, T, ntiles, nwg, tl.nseg);
+#define GMG_TSWEEP_LAUNCH(XMV)                                                                                      \
+    do {                                                                                                              \
+      if (mk) {                                                                                                       \
+        static bool attr = false;                                                                                     \
+        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, true, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((sells_tsweep_kernel<XMV, true, WPB>), g, b, lds, stream, a, tl);                          \
+      } else {                                                                                                        \
+        static bool attr = false;                                                                                     \
+        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, false, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((sells_tsweep_kernel<XMV, false, WPB>), g, b, lds, stream, a, tl);                         \
+      }                                                                                                               \
+    } while (0)
+    if (a.xmode == 0) GMG_TSWEEP_LAUNCH(0); else if (a.xmode == 1) GMG_TSWEEP_LAUNCH(1); else GMG_TSWEEP_LAUNCH(2);
+#undef GMG_TSWEEP_LAUNCH
+    HIP_CHECK(hipGetLastError());
+    return true;
+  }
   void launch_rsweep(const DevCSR &M, const double *r_cur, double *r_next, const double *r_prev, double *x, bool x_zero, double omega, int xmode)
   {
     SellSArgs a;
@@ -1729,6 +1810,7 @@ struct gmg_solver {
     const int nsl = (int)((M.nrows + rows - 1) / rows);
     a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl; a.xcd_remap = xcd_remap;
     a.x_zero = x_zero ? 1 : 0; a.x = r_cur; a.omega = omega; a.y = r_next; a.b = r_cur; a.x2 = x; a.s_out = const_cast<double *>(r_prev);
+    if ((pat_tile >= 2 || (pat_tile == 1 && M.nrows >= pat_tile_rows)) && launch_tsweep(M, a, nsl)) return;
     const int wpb = sell_block > 0 ? sell_block / 64 : (nsl >= 256 * 32 ? 4 : pat_small_wpb);
     const int nu = M.pat_k * M.pat_nruns;
     const int nb = pat_nb > 0 ? pat_nb : (nsl >= 200000 ? 2 : 1);
@@ -2482,6 +2564,8 @@ struct gmg_solver {
     persist_fenced = env_int("GMG_PERSIST_FENCED", 0);
     pat_strict = env_int("GMG_PAT_STRICT", 1);
     pat_wide = env_int("GMG_PAT_WIDE", 1);
+    pat_tile = env_int("GMG_PAT_TILE", 1);
+    pat_tile_rows = env_int("GMG_PAT_TILE_ROWS", 6000000);
     gj_mfma = env_int("GMG_GJ_MFMA", 1);
     persist_max_slices = env_int("GMG_PERSIST_MAX_SLICES", 0);
     pat_coded_min_rows = env_int("GMG_PAT_CODED_MIN_ROWS", 500000);

@@ -1722,6 +1722,136 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// The r-gather sweep with the gathers shared through LDS ("tile sweep").  sells_rsweep_kernel fetches every r value nine times out of
+// L2 (once per run: 3 x 3 neighbouring grid lines; only the three taps of a run are shared inside the wave) -- at 128^3 that is
+// 150 MB of L2 -> L1 traffic per sweep on top of the 61 MB the sweep has to move, and neither fewer instructions nor another launch
+// geometry changes its 21-22 us (profiles/r03_tuning.md section 10).  Here a workgroup of WPB waves takes TILES of T <= 3 WPB
+// consecutive slices (62 T rows; T is chosen by the launcher so that the tiles fill whole rounds of resident workgroups).  The windows of all slices of a tile for one run are one contiguous stretch of r (62 T + 2 values),
+// and the stretches of runs whose offsets differ by less than that -- the three lines of a plane -- overlap: the host merges them
+// into segments (SellTile), the workgroup loads each segment ONCE, coalesced, converts it (s = omega*(d*r): two multiplies per loaded
+// value instead of per gathered value) and keeps it in LDS; a slice then reads its nine windows from LDS.  2.7 x fewer values fetched
+// at 128^3, none of them a gather.  Same taps in the same order on the same values: bit-identical to sells_rsweep_kernel.
+// ---------------------------------------------------------------------------
+struct SellTile {
+  int T;                    // slices per tile
+  int nseg;                 // merged stretches of r per tile
+  int seg_off[12];          // first column of the stretch relative to the tile's first row
+  int seg_len[12];
+  int seg_base[12];         // its place in the LDS staging array (elements)
+  int run_lds[32];          // window of run r for the tile's first slice: staging index of its lane 0
+  int elems;                // staged values per tile
+};
+
+template <int XM, bool MK, int WPB>
+__global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, SellTile tl)
+{
+  constexpr int K = 3, ROWS = 65 - K, RB = 3, SPW = 3;       // T <= SPW * WPB slices per tile: slice j of the tile belongs to wave j % WPB
+  const int T = tl.T;
+  extern __shared__ double sp_smem[];
+  const int nu = K * a.nruns;
+  const int tot = a.np * nu;
+  PatEntry *s_tab = reinterpret_cast<PatEntry *>(sp_smem);
+  double *s_tab8 = sp_smem;
+  double *s_stage = sp_smem + (MK ? 2 : 1) * (size_t)tot;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntiles = (a.nslices + T - 1) / T;
+  const double *__restrict__ rg = a.x;
+  const double omega = a.omega;
+  const double du = a.pdinv[0];
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  const bool xz = a.x_zero != 0;
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i]; }
+  else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
+  // (requesting the next tile's stretches and row-wise operands a tile ahead was tried: the registers it takes leave ONE workgroup
+  // per CU instead of two, and the sweep got slower -- 223 instead of 210 us at 288^3; two resident workgroups overlap their phases)
+  // Workgroups are dealt to the eight XCDs round-robin; each XCD walks its own contiguous eighth of the tiles with all its workgroups
+  // side by side, so the stretches of the planes above and below (the own stretches of tiles one plane away) are in that XCD's L2.
+  // gridDim.x is a multiple of 8.
+  const int wpx = gridDim.x >> 3, xcd = blockIdx.x & 7, wq = blockIdx.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  const int t_hi = min(ntiles, (xcd + 1) * tpx);
+  for (int tile = xcd * tpx + wq; tile < t_hi; tile += wpx) {
+    const int ts = tile * T;                                 // first slice of the tile
+    const int R0 = ts * ROWS;
+    // row-wise operands of this wave's slices: requested before the staging loads, used after the taps
+    int pid[SPW], row[SPW];
+    bool live[SPW];
+    double e0[SPW], e2[SPW], rp[SPW];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      const int slice = ts + wave + i * WPB;
+      live[i] = wave + i * WPB < T && slice < a.nslices;
+      row[i] = min(slice, a.nslices - 1) * ROWS + lane;
+      const int rc = min(row[i], lastrow);
+      pid[i] = (int)a.rowpid[rc];
+      e0[i] = rg[rc];
+      e2[i] = 0.0; rp[i] = 0.0;
+      if (XM != 1) { const double xl = a.x2[rc]; e2[i] = xz ? 0.0 : xl; }
+      if (XM == 2) rp[i] = a.s_out[rc];
+    }
+    __syncthreads();                                         // the previous tile's windows have been read (first tile: the table is complete)
+    for (int sg = 0; sg < tl.nseg; ++sg) {
+      const int c0 = R0 + tl.seg_off[sg];
+      double *dst = s_stage + tl.seg_base[sg];
+      for (int p = threadIdx.x; p < tl.seg_len[sg]; p += blockDim.x) dst[p] = omega * (du * rg[min(max(c0 + p, 0), last)]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      if (!live[i]) continue;                                // uniform in the wave
+      const int rel = (wave + i * WPB) * ROWS + lane;
+      const PatEntry *te = s_tab + pid[i] * nu;
+      const double *tv = s_tab8 + pid[i] * nu;
+      double s = 0.0;
+      for (int r0 = 0; r0 < a.nruns; r0 += RB) {
+        double cur[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) cur[q] = s_stage[tl.run_lds[r0 + q] + rel];
+        bool fin = true;
+        if (MK) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) fin = fin && __builtin_isfinite(cur[q]);
+          fin = __all(fin);
+        }
+        if (MK && !fin) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            double c = cur[q];
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+              if (t > 0) c = wave_shl1(c);
+              const PatEntry en = te[(r0 + q) * K + t];
+              const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
+              s = s + en.v * g;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            double c = cur[q];
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+              if (t > 0) c = wave_shl1(c);
+              const int j = (r0 + q) * K + t;
+              s = s + (MK ? te[j].v : tv[j]) * c;
+            }
+          }
+        }
+      }
+      if (lane < ROWS && row[i] <= lastrow) {
+        const int r = row[i];
+        const double rn = e0[i] - s;
+        const double sk = omega * (du * e0[i]);              // the row's own s_k
+        if (XM == 0) a.x2[r] = e2[i] + sk;
+        else if (XM == 2) a.x2[r] = (e2[i] + omega * (du * rp[i])) + sk;
+        a.y[r] = rn;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // A whole Richardson-Jacobi smoothing pass (niter sweeps) of a SMALL level in ONE launch.
 //
 // On levels of a few 10^4 .. 10^5 rows a sweep kernel runs 4.6-5.9 us + ~1.5 us of dependent-launch gap against

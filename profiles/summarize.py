@@ -26,7 +26,7 @@ def db(path):
 
 
 def family(name):
-    if "gmg::sells_sweep_kernel<" in name or "gmg::sells_rsweep_kernel<" in name:   # the fused sweeps on the shared-offset pattern table (XM = 0/1/2 variants)
+    if "gmg::sells_sweep_kernel<" in name or "gmg::sells_rsweep_kernel<" in name or "gmg::sells_tsweep_kernel<" in name:   # the fused sweeps on the shared-offset pattern table (XM = 0/1/2 variants)
         return "sells_kernel"
     for fam in ("sells_kernel", "sellp_kernel", "sellc_kernel", "sello_kernel", "sell_kernel", "csr_stream1_kernel"):
         if "gmg::" + fam + "<" in name:
@@ -86,7 +86,7 @@ def main():
 
     # ---- finest-level fused sweeps (EPI_SWEEP = 3 kernels and the sells_sweep_kernel variants): largest grid per family;
     #      variants of one family at that grid (x updated every second sweep) are averaged, weighted by launches ----
-    sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%_kernel<3,%' or name like '%sells_sweep_kernel<%' or name like '%sells_rsweep_kernel<%' "
+    sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%_kernel<3,%' or name like '%sells_sweep_kernel<%' or name like '%sells_rsweep_kernel<%' or name like '%sells_tsweep_kernel<%' "
                      "group by name, grid_x order by grid_x desc").fetchall()
     recs = []
     nrows = (a.cells - 1) ** 3
