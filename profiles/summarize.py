@@ -99,7 +99,7 @@ def main():
         # level's (NB = 2 on 1024 workgroups), that level too; small levels (< 10^5 threads) are left out
         if grid < 100000:
             continue
-        key = (fam, "nt" if ", true>" in name and fam == "sell_kernel" else "", grid)
+        key = (fam, "tile" if "sells_tsweep_kernel<" in name else ("nt" if ", true>" in name and fam == "sell_kernel" else ""), grid)   # (the tile sweep of the finest level and the gather sweep of the next one can share a grid size)
         if key not in fams:
             fams[key] = dict(grid=grid, members=[])
         fams[key]["members"].append((name, avg_us, cnt))
@@ -135,7 +135,7 @@ def main():
         for fam_leg, blk in (("generic", bj.get("roofline")), ("default", bj.get("roofline_compressed")),
                              ("varcoef", (bj.get("variable_coefficient") or {}).get("roofline"))):
             if blk and blk.get("sweep_signature"):
-                sigs[blk["sweep_signature"].split("<")[0].replace("sells_sweep_kernel", "sells_kernel").replace("sells_rsweep_kernel", "sells_kernel")] = blk["sweep_signature"]
+                sigs[blk["sweep_signature"].split("<")[0].replace("sells_sweep_kernel", "sells_kernel").replace("sells_rsweep_kernel", "sells_kernel").replace("sells_tsweep_kernel", "sells_kernel")] = blk["sweep_signature"]
     except Exception as e:
         tl.append(f"# (no sweep signatures: {e})")
     for rec in recs:
