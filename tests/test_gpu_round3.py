@@ -208,7 +208,7 @@ def test_r_gather_sweep_is_bitwise_the_s_sweep(S, po, orc, monkeypatch, nc, nlev
         S.solve_(x, ns, b)
         out += [x, solver.log.residuals[: solver.log.num_iters + 1].copy()]
         sig = ns.P_ns.sweep_signature(0)
-        assert ("sells_rsweep_kernel" in sig or "sells_tsweep_kernel" in sig) == (flag == "1"), sig
+        assert any(k in sig for k in ("sells_rsweep_kernel", "sells_tsweep_kernel", "sells_tasync_kernel")) == (flag == "1"), sig
         res[flag] = out
         ns.P_ns.close()
     for a, c in zip(res["0"], res["1"]):
