@@ -3284,6 +3284,9 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   if (!env_int("GMG_PATCH_OPERATOR", 1) || !S.dedup || !T.pcol.empty() || (comm.nranks > 1 && L.halo.present) || !use_pattern || !use_sell) return;
   if (npatch < 64 || n < 64 || n >= (int64_t)(1 << 28) || S.max_np > 32 || S.h_ublock.size() != (size_t)npatch) return;
   const auto t_begin = std::chrono::steady_clock::now();
+  auto t_sub = t_begin;
+  const bool po_timing = env_int("GMG_SETUP_TIMING", 0) != 0;
+  auto sub = [&](const char *what) { if (!po_timing) return; const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[gmg_setup]     patch operator: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_sub).count()); t_sub = now; };
   const int64_t ne = T.pptr[npatch];
   if (ne >= (int64_t)INT32_MAX) return;
   // unique inverse blocks back on the host (a few KB .. MB)
@@ -3318,6 +3321,7 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
       }
     });
   }
+  sub("slot lists (counting sort)");
   // exact numbering of integer sequences: ids by first appearance (two parallel passes + a short sequential one)
   auto sequence_ids = [&](int64_t nitems, auto len, auto word, std::vector<int32_t> &ids, std::vector<int64_t> &rep, int max_ids) -> bool {
     ids.assign((size_t)nitems, -1);
@@ -3392,6 +3396,7 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   if (!sequence_ids(npatch, [&](int64_t p) { return (int)(T.pptr[p + 1] - T.pptr[p]); },
                     [&](int64_t p, int j) { return (int64_t)T.prow[(size_t)(T.pptr[p] + j)] - (int64_t)T.prow[(size_t)T.pptr[p]]; }, shape, shape_rep, 4096))
     return;
+  sub("patch shapes");
   // row signatures: (block, local row, shape, first dof - row) of every patch of the row, in patch order
   auto sig_len = [&](int64_t i) { return (int)(4 * (iptr[(size_t)i + 1] - iptr[(size_t)i])); };
   auto sig_word = [&](int64_t i, int j) -> int64_t {
@@ -3407,6 +3412,7 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   std::vector<int32_t> sig;
   std::vector<int64_t> sig_rep;
   if (!sequence_ids(n, sig_len, sig_word, sig, sig_rep, 4096)) return;
+  sub("row signatures");
   // one merged row per signature
   auto S_ = std::make_shared<PatStream>();
   PatStream &P = *S_;
@@ -3453,12 +3459,14 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   }
   P.rows_seen = n;
   if (P.nnz <= 0) return;
+  sub("merged rows + row ids");
   try {
     S.M = finish_stream(P, "patch operator");
   } catch (const GmgError &) {
     S.M = DevCSR();
     return;
   }
+  sub("device form (finish_stream)");
   S.use_M = true;
   // the patch-solve path's buffers are not needed any more
   HIP_CHECK(hipStreamSynchronize(stream));
