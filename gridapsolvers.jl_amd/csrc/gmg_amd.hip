@@ -1318,10 +1318,10 @@ struct gmg_solver {
       const dim3 g(nwg_wide);
       a.wl_pids = M.wl_pids; a.wl_cnt = M.wl_cnt; a.wl_stride = kWideStride; a.wl_max = M.wl_max;
       const size_t ldsw = wide_lds(M, M.wl_max);
-      static bool attr_set = false;                         // per instantiation: LDS beyond the 64 KB default
-      if (!attr_set) {
+      static bool attr_set[64] = {false};                   // per instantiation and device: LDS beyond the 64 KB default
+      if (!attr_set[device & 63]) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_kernel<EPI, ONEG, 5, 5, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_set = true;
+        attr_set[device & 63] = true;
       }
       if (env_int("GMG_DBG_NOGATHER", 0)) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true, 8, true>), g, b, ldsw, stream, a);   // timing ablation only
       else
@@ -1786,12 +1786,12 @@ struct gmg_solver {
 #define GMG_TSWEEP_LAUNCH(XMV)                                                                                      \
     do {                                                                                                              \
       if (mk) {                                                                                                       \
-        static bool attr = false;                                                                                     \
-        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, true, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; } \
+        static bool attr[64] = {false};                                                                               \
+        if (!attr[device & 63]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, true, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr[device & 63] = true; } \
         hipLaunchKernelGGL((sells_tsweep_kernel<XMV, true, WPB>), g, b, lds, stream, a, tl);                          \
       } else {                                                                                                        \
-        static bool attr = false;                                                                                     \
-        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, false, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr = true; } \
+        static bool attr[64] = {false};                                                                               \
+        if (!attr[device & 63]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, false, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr[device & 63] = true; } \
         hipLaunchKernelGGL((sells_tsweep_kernel<XMV, false, WPB>), g, b, lds, stream, a, tl);                         \
       }                                                                                                               \
     } while (0)
