@@ -351,3 +351,46 @@ def test_sweeps_confine_non_finite_values_like_the_reference(S, po, orc, monkeyp
         assert 0 < np.count_nonzero(~fr) < n // 4
         assert np.array_equal(x[fx], xo[fx]) and np.array_equal(r[fr], ro[fr])
     ns.close()
+
+
+# ---------------------------------------------------------------- tile sweep: the gathers of the r-gather sweep shared through LDS
+@pytest.mark.parametrize("nc,nlev,niter", [((40, 36, 28), 2, 5), ((160, 144), 2, 4), ((48, 48, 48), 3, 10)])
+def test_tile_sweep_is_bitwise_the_gather_sweep(S, po, orc, monkeypatch, nc, nlev, niter):
+    """sells_tsweep_kernel (default on levels of >= 6e6 rows; forced here with GMG_PAT_TILE=2, GMG_PAT_TILE_MIN=0): a workgroup stages the
+    merged stretches of r that a tile of consecutive slices needs in LDS once and the slices read their windows from there, instead of
+    nine gathers per slice.  Smoothing passes from x = 0 and from a given x, odd / even sweep counts, chained passes and a CG solve
+    agree bit for bit with the gather form (RichardsonSmoothers.jl:84-98), an Inf in r stays confined as in the oracle, and the
+    solve equals the oracle's."""
+    monkeypatch.setenv("GMG_PERSIST", "0")
+    monkeypatch.setenv("GMG_PAT_TILE_MIN", "0")
+    H = po.build_hierarchy(nc, nlev, 1)
+    n = H["mats"][0].shape[0]
+    b = po.dirichlet_lift_rhs(nc, 1)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("GMG_PAT_TILE", mode)
+        solver = S.CGSolver(make_gmg(S, H, pre_smoothers=jac(S, nlev, niter)), maxiter=40, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        out = []
+        x, r = np.random.default_rng(3).uniform(-1, 1, n), np.random.default_rng(50).uniform(-1, 1, n)
+        for _ in range(3):
+            ns.P_ns.smooth(0, x, r)
+        out += [x.copy(), r.copy()]
+        xi, ri = np.zeros(n), np.random.default_rng(51).uniform(-1, 1, n)
+        ri[n // 3] = np.inf
+        ns.P_ns.smooth(0, xi, ri)
+        out += [np.isfinite(xi), np.isfinite(ri), np.where(np.isfinite(xi), xi, 0.0), np.where(np.isfinite(ri), ri, 0.0)]
+        xs = np.zeros(n)
+        S.solve_(xs, ns, b)
+        out += [xs, solver.log.residuals[: solver.log.num_iters + 1].copy()]
+        sig = ns.P_ns.sweep_signature(0)
+        assert ("sells_tsweep_kernel" in sig) == (mode == "2"), sig
+        res[mode] = out
+        ns.P_ns.close()
+    for a, c in zip(res["0"], res["2"]):
+        np.testing.assert_array_equal(a, c)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, niter, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
+    xo, nit, flag_o, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=40, atol=1e-14, rtol=1e-8)
+    assert len(res["2"][-1]) == nit + 1
+    np.testing.assert_allclose(res["2"][-1], hist, rtol=TOL_HIST)
+    assert rel_err(res["2"][-2], xo) <= 1e-10
