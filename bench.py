@@ -2,27 +2,31 @@
 """bench.py -- DoFs/s of CG + GMG V-cycle on 3-D Poisson Q1 (BASELINE.json metric).
 
 A "step" is one complete `solve!(x, CGNumericalSetup, b)` (Krylov/CGSolvers.jl:73-120 with the GMG V-cycle
-preconditioner GMGLinearSolvers.jl:468-502,612-645) from x = 0 to rtol.
+preconditioner GMGLinearSolvers.jl:468-502,612-645) from x = 0 to rtol, inputs resident in HBM.
 
+The JSON line has the SAME shape at every --gpus N (key <-> leg):
+    value, ms_per_step, roofline_compressed   default leg: the product as shipped, gmg_setup picks the storage layout
+                                              (row-pattern dictionary on this constant-coefficient operator)
+    value_generic, ms_per_step_generic,       generic leg: every structure-exploiting layout off -- the 12 B/nnz (col,val)
+    roofline                                  stream SURVEY 8(d)'s byte model is written for
+    cpu_baseline                              the CPU oracle (oracle/, a cited port of the reference algorithm) on the host cores
 N = 1  BASELINE configs[1]: 128^3 cells, Q1, 4 levels, Richardson(Jacobi,10,2/3) pre = post, exact coarse solve,
        CG(maxiter=20, atol=1e-14, rtol=1e-6), rhs = the reference test problem u = x1 + x2
-       (test/LinearSolvers/GMGTests.jl:52,109-124,204-213).  Three legs, all inside this run:
-         default   the product as shipped: setup picks the storage layout (row-pattern dictionary on this
-                   constant-coefficient operator)                                   -> `value`, `roofline_compressed`
-         generic   the same problem with the lossless stream compression switched off: the 12 B/nnz (col,val)
-                   stream SURVEY 8(d)'s byte model is written for             -> `value_generic`, `roofline`
-         varcoef   a(u,v) = int kappa(x) grad u . grad v with smooth kappa: every row's values distinct, the setup
-                   keeps the 8 B/nnz value stream and finds the column structure repeating
-                   (SELL-O: offsets from a pattern table)                          -> `variable_coefficient`
+       (test/LinearSolvers/GMGTests.jl:52,109-124,204-213).  Further legs of the same run:
+         variable_coefficient   kappa(x) grad u . grad v: every row's values distinct (SELL-O: 8 B/nnz)
+         weak_scaling_ref       the per-GPU problem of the N > 1 runs (288^3, 6 levels) on this one GPU; its value is also the
+                                top-level `weak_anchor_value` -- what value / N of an N > 1 line is to be held against
+         host_io                the same solves with b / x as HOST arrays through GMG_MEM_HOST -- what the Julia binding passes --
+                                pageable, page-locked once (gmg_host_register) and with the x0_zero option; + one V-cycle per call
+                                (`precond_only`: the library as the preconditioner of a host-language Krylov loop)
+         config3                BASELINE configs[2]: Q2, vertex-star patch smoother Richardson(PatchSolver,10,0.2), FGMRES(5)
+                                (test/LinearSolvers/GMGTests.jl:18-47,119-123) at 128^3 (--config3-cells 256 for the full size)
 N > 1  BASELINE configs[3]: 288^3 cells per GPU (576^3 on 2x2x2), 6 levels, box row partition, halo exchange and
        scalar all-reduces over RCCL; launched by torch.distributed.run, or by bench.py itself when WORLD_SIZE is unset.
 
-Inputs are synthetic (generated by formula) and resident in HBM before the timed region.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--legs default,generic,varcoef,weak_ref,host_io,config3,cpu]
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-
-Prints ONE JSON line (rank 0).  `cpu_baseline` is the CPU oracle (oracle/, a cited port of the reference algorithm)
-timed in a child process on this box's host cores on the same workload."""
+Prints ONE JSON line (rank 0)."""
 from __future__ import annotations
 
 import argparse
@@ -42,7 +46,15 @@ import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 WS_CELLS, WS_LEVELS = 288, 6   # per-GPU problem of the N > 1 runs: BASELINE configs[3] = 576^3 cells on 2x2x2 GPUs, 6 levels
-GENERIC_ENV = {"GMG_VDICT": "0", "GMG_IDX16": "0", "GMG_PATTERN": "0", "GMG_OPATTERN": "0"}
+# the generic (12 B/nnz) leg: per-handle options (gmg_set_option), not environment variables
+GENERIC_OPTIONS = {"vdict": 0, "idx16": 0, "pattern": 0, "opattern": 0}
+ALL_LEGS = ("default", "generic", "varcoef", "weak_ref", "host_io", "config3", "cpu")
+LEGS_NOTE = ("same key <-> leg mapping at every --gpus N: default leg (the product as shipped: gmg_setup picks the storage layout) = `value`, "
+             "`ms_per_step`, `roofline_compressed`; generic leg (every structure-exploiting layout off: the 12 B/nnz (col,val) stream SURVEY 8(d)'s "
+             "byte model describes) = `value_generic`, `ms_per_step_generic`, `roofline`.  N = 1 runs BASELINE configs[1] (128^3) and carries the "
+             "per-GPU problem of the N > 1 runs on one GPU as `weak_anchor_value` / `weak_scaling_ref`; N > 1 runs 288^3 cells per GPU: hold "
+             "value / N against weak_anchor_value, never against the N = 1 `value`.  Further N = 1 legs: variable_coefficient, host_io "
+             "(`value_host_io`: b / x as host arrays through GMG_MEM_HOST, the Julia binding's path), config3 (Q2 + patch smoother + FGMRES).")
 
 
 def parse():
@@ -52,16 +64,32 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=None, help="cells per direction per GPU (default: 128 at N=1, 288 at N>1)")
     ap.add_argument("--levels", type=int, default=None, help="GMG levels (default: 4 at N=1, 6 at N>1)")
+    ap.add_argument("--legs", default="all", help="comma list of " + ",".join(ALL_LEGS) + " (default: all; `default` always runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-varcoef", action="store_true", help="skip the variable-coefficient leg")
     ap.add_argument("--no-weak-ref", action="store_true", help="skip the weak-scaling reference leg (the N > 1 per-GPU problem on one GPU)")
-    ap.add_argument("--no-generic", action="store_true", help="N > 1: skip the generic (12 B/nnz) leg")
+    ap.add_argument("--no-generic", action="store_true", help="skip the generic (12 B/nnz) leg")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the host-vector leg")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (Q2, patch smoother, FGMRES)")
+    ap.add_argument("--config3-cells", type=int, default=128, help="cells per direction of the config-3 leg (BASELINE: 256; 5 levels)")
+    ap.add_argument("--config3-levels", type=int, default=5)
     ap.add_argument("--rhs", choices=["lin", "rand"], default="lin")
     args = ap.parse_args()
     if args.cells is None:
         args.cells = 128 if args.gpus == 1 else WS_CELLS
     if args.levels is None:
         args.levels = 4 if args.gpus == 1 else WS_LEVELS
+    legs = set(ALL_LEGS) if args.legs == "all" else set(x.strip() for x in args.legs.split(",") if x.strip())
+    bad = legs - set(ALL_LEGS)
+    if bad:
+        raise SystemExit(f"unknown legs {sorted(bad)}; choose from {ALL_LEGS}")
+    for flag, leg in (("no_cpu_baseline", "cpu"), ("no_varcoef", "varcoef"), ("no_weak_ref", "weak_ref"), ("no_generic", "generic"),
+                      ("no_host_io", "host_io"), ("no_config3", "config3")):
+        if getattr(args, flag):
+            legs.discard(leg)
+    legs.add("default")
+    args.legset = legs
+    args.no_generic = "generic" not in legs          # (multigpu.run_bench reads this)
     return args
 
 
@@ -104,7 +132,7 @@ def usable_cores():
     return n, quota, (n if quota is None else max(1, min(n, int(quota + 0.5))))
 
 
-def run_oracle_child(cells, levels, rhs, kappa, variant, threads, limit_s, max_reps, want_x):
+def run_oracle_child(cells, levels, rhs, kappa, variant, threads, limit_s, max_reps, want_x, config3=False):
     env = dict(os.environ)
     for k in list(env):
         if k.startswith(("OMP_", "GOMP_", "KMP_")):
@@ -116,6 +144,8 @@ def run_oracle_child(cells, levels, rhs, kappa, variant, threads, limit_s, max_r
     xfile = None
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--cells", str(cells), "--levels", str(levels),
            "--rhs", rhs, "--kappa", kappa, "--variant", variant, "--limit-s", str(limit_s), "--max-reps", str(max_reps)]
+    if config3:
+        cmd.append("--config3")
     if want_x:
         fd, xfile = tempfile.mkstemp(suffix=".npy")
         os.close(fd)
@@ -131,31 +161,34 @@ def run_oracle_child(cells, levels, rhs, kappa, variant, threads, limit_s, max_r
     return out, x
 
 
-def cpu_baseline(cells, levels, rhs):
-    """kind "port": oracle/gmg_oracle.c (same operation sequence as the reference) on full solves of the bench workload,
+def cpu_baseline(cells, levels, rhs, config3=False, limit_seq=10.0, limit_omp=8.0):
+    """kind "port": oracle/gmg_oracle.c (same operation sequence as the reference) on full solves of the workload,
     bounded to ~10 s per variant.  (1) one thread -- the analogue of ONE reference MPI rank, also what the GPU result is
     checked against; (2) all usable host cores (OpenMP build of the same file, pinned threads, parallel first touch) -- the
     analogue of the reference under MPI on P ranks.  `value` is the faster of the two, `cores` says which."""
     naff, quota, ncore = usable_cores()
-    r1, x = run_oracle_child(cells, levels, rhs, "const", "seq", 1, 10.0, 8, True)
+    what = "FGMRES(5)+GMG(patch smoother)" if config3 else "CG+GMG"
+    r1, x = run_oracle_child(cells, levels, rhs, "const", "seq", 1, limit_seq, 8, True, config3)
     n = r1["dofs"]
     out = dict(value=n / r1["seconds"], unit="DoFs/s", cores=1, kind="port",
-               sample=f"{r1['reps']} full CG+GMG solves of the bench workload ({n} dofs, {r1['iters']} CG iterations each) by "
+               sample=f"{r1['reps']} full {what} solves ({n} dofs, {r1['iters']} iterations each) by "
                       f"oracle/gmg_oracle.c in a child process, single thread, {r1['seconds']:.2f} s per solve",
                iters=r1["iters"], seconds=r1["seconds"], single_thread_value=n / r1["seconds"],
                host=dict(affinity_cores=naff, cgroup_cpu_quota=quota, usable_cores=ncore, os_cpu_count=os.cpu_count()))
-    if ncore > 1:
+    if ncore > 1 and not config3:
         try:
-            rp, _ = run_oracle_child(cells, levels, rhs, "const", "omp", ncore, 8.0, 16, False)
+            rp, _ = run_oracle_child(cells, levels, rhs, "const", "omp", ncore, limit_omp, 16, False, config3)
             out["all_cores"] = dict(value=n / rp["seconds"], cores=rp["threads"], seconds=rp["seconds"], iters=rp["iters"],
                                     reps=rp["reps"], speedup_vs_single_thread=r1["seconds"] / rp["seconds"], omp_env=rp["omp_env"])
             if rp["iters"] == r1["iters"] and rp["seconds"] < r1["seconds"]:
                 out.update(value=n / rp["seconds"], cores=rp["threads"], seconds=rp["seconds"],
-                           sample=f"{rp['reps']} full CG+GMG solves of the bench workload ({n} dofs, {rp['iters']} CG iterations each) by "
+                           sample=f"{rp['reps']} full {what} solves ({n} dofs, {rp['iters']} iterations each) by "
                                   f"the OpenMP build of oracle/gmg_oracle.c on {rp['threads']} pinned host threads (child process, "
                                   f"parallel first touch), {rp['seconds']:.3f} s per solve; single thread: {r1['seconds']:.2f} s per solve")
         except Exception as e:      # the OpenMP build is optional
             out["all_cores"] = {"error": str(e)[-300:]}
+    elif config3:
+        out["all_cores"] = {"skipped": "the oracle's patch solve is sequential (PatchSolvers.jl:279-300 is a serial loop over patches)"}
     else:
         out["all_cores"] = {"skipped": f"process may use {ncore} core (affinity {naff}, cgroup quota {quota})"}
     return out, x, r1["iters"], np.asarray(r1["hist"])
@@ -166,7 +199,7 @@ def kernel_label(fmt):
     """name of the finest-level fused sweep kernel for the storage layout the setup chose"""
     what = "<EPI_SWEEP,ONEG> (fused Richardson-Jacobi sweep, finest level, " + fmt["layout"]
     if fmt["row_patterns"]:
-        return "sells_sweep_kernel<XM,NB,TD,MK> (fused Richardson-Jacobi sweep, finest level, " + fmt["layout"] + \
+        return "sells_*sweep_kernel (fused Richardson-Jacobi sweep, finest level, " + fmt["layout"] + \
                ": row-pattern dictionary in LDS, %.2f B/nnz of matrix stream)" % fmt["stream_bytes_per_nnz"]
     if fmt["value_dictionary"] or fmt["idx16"]:
         return "sellc_kernel" + what + ", lossless stream compression %.0f B/nnz)" % fmt["stream_bytes_per_nnz"]
@@ -191,8 +224,8 @@ def kernel_source_sha():
     return hashlib.sha256(open(os.path.join(ROOT, "gridapsolvers.jl_amd", "csrc", "kernels.hpp"), "rb").read()).hexdigest()[:16]
 
 
-def committed_traffic(family, cells, levels, rows, signature):
-    """HBM bytes per launch of the sweep from the committed PMC passes (profiles/traffic_latest.json, written by
+def committed_traffic(family, cells, levels, rows, signature, order=1):
+    """HBM bytes per launch of the timed kernel from the committed PMC passes (profiles/traffic_latest.json, written by
     profiles/summarize.py from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` runs of THIS command).  Counters cannot
     be read from inside the bench process, so the figure is only attached when the profiled run matches the current one in
     kernel family, problem, row count, the sweep's signature as the library reports it (gmg_sweep_signature: template
@@ -205,12 +238,103 @@ def committed_traffic(family, cells, levels, rows, signature):
     if T.get("kernels_hpp_sha") != kernel_source_sha():
         return None, f"profiles/traffic_latest.json ({T.get('tag', '?')}) was measured on another version of csrc/kernels.hpp: not attached"
     for rec in T.get("kernels", []):
-        if rec.get("family") == family and rec.get("cells") == cells and rec.get("levels") == levels and rec.get("rows") == rows:
-            if rec.get("signature") != signature:
+        if rec.get("family") == family and rec.get("cells") == cells and rec.get("levels") == levels and rec.get("rows") == rows \
+                and rec.get("order", 1) == order:
+            if signature is not None and rec.get("signature") != signature:
                 return None, f"profiled sweep was '{rec.get('signature')}', this run's is '{signature}': not attached"
             return rec.get("hbm_bytes_per_launch"), f"profiles/traffic_latest.json ({T.get('tag', '?')}: rocprofv3 --pmc passes of the same command, same " \
                                                       f"kernel source and sweep signature; not re-measured in this run)"
     return None, "no matching record in profiles/traffic_latest.json"
+
+
+def pcie_probe(torch, nbytes):
+    """page-locked host <-> device copy rates of this box (GB/s), the ceiling of every host-vector figure"""
+    n = nbytes // 8
+    hp = torch.empty(n, dtype=torch.float64).pin_memory()
+    d = torch.empty(n, dtype=torch.float64, device="cuda")
+    out = {}
+    for name, dst, src in (("h2d", d, hp), ("d2h", hp, d)):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        out[name + "_GBs"] = 5 * nbytes / (time.perf_counter() - t0) / 1e9
+    del hp, d
+    return out
+
+
+def host_io_leg(torch, S, ns, b, dev_ms, steps, label):
+    """The solves of a leg again with b / x as HOST arrays through GMG_MEM_HOST -- exactly what julia/GridapSolversAMD.jl passes for
+    Vector{Float64} -- timed per call (the call returns when x is back in the caller's array).  Variants: pageable arrays (the
+    library pipelines them through its own page-locked chunks), the same arrays page-locked ONCE with gmg_host_register (the pattern
+    of ext/GridapPETScExt/PETScCaches.jl:23-36), and additionally the x0_zero option (the initial guess is not uploaded).
+    precond_only: ONE V-cycle per call with host r / z (gmg_apply) -- the library as preconditioner of a host-language Krylov loop."""
+    g = ns.P_ns
+    n = b.size
+    nb = 8 * n
+
+    def timed(fn, reps, warm=1):
+        ts = []
+        for i in range(warm + reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                ts.append(dt)
+        return float(np.mean(ts)), float(np.min(ts))
+
+    def solve_on(x, bb):
+        def f():
+            x.fill(0.0)
+            S.solve_(x, ns, bb)
+        return f
+    out = {"workload": label, "bytes_per_vector": nb, "device_resident_ms": dev_ms, "pcie": pcie_probe(torch, nb)}
+    reps = max(3, steps // 2)
+    # (the x.fill(0) of the caller is inside the timed call: a few hundred us at 189 MB; reported separately below)
+    x0 = np.zeros(n)
+    t0 = time.perf_counter(); x0.fill(0.0); out["caller_fill_ms"] = (time.perf_counter() - t0) * 1e3
+    b1, x1 = b.copy(), np.zeros(n)
+    m, mn = timed(solve_on(x1, b1), reps)
+    out["pageable"] = dict(ms_per_step=m * 1e3, min_ms=mn * 1e3, value=n / m)
+    xp = x1.copy()
+    b2, x2 = b.copy(), np.zeros(n)
+    t0 = time.perf_counter()
+    g.pin(b2, x2)
+    out["register_ms_once"] = (time.perf_counter() - t0) * 1e3
+    m, mn = timed(solve_on(x2, b2), reps)
+    out["registered"] = dict(ms_per_step=m * 1e3, min_ms=mn * 1e3, value=n / m)
+    g.set_option("x0_zero", 1)
+    m, mn = timed(solve_on(x2, b2), reps)
+    g.set_option("x0_zero", 0)
+    out["registered_x0_zero"] = dict(ms_per_step=m * 1e3, min_ms=mn * 1e3, value=n / m)
+    out["bitwise_equal_pageable_vs_registered"] = bool(np.array_equal(xp, x2))
+    # floor of this path on this box: the device-resident solve + b up + x down at the measured link rates
+    up, down = out["pcie"]["h2d_GBs"], out["pcie"]["d2h_GBs"]
+    floor_ms = dev_ms + nb / up / 1e6 + nb / down / 1e6
+    out["floor_ms"] = floor_ms
+    out["floor_note"] = ("device-resident solve + 8N bytes up (b) + 8N bytes down (x) at the page-locked copy rates measured in this run; "
+                         "x only exists after the last CG update and b is needed by the first sweep, so neither copy can hide behind the solve")
+    out["value"] = out["registered_x0_zero"]["value"]
+    out["ms_per_step"] = out["registered_x0_zero"]["ms_per_step"]
+    out["frac_of_device_resident"] = dev_ms / out["ms_per_step"]
+    out["frac_of_floor"] = floor_ms / out["ms_per_step"]
+    # one V-cycle per call (GMG as :preconditioner, maxiter = 1): z = M r with host vectors vs device vectors
+    r_h, z_h = b2, x2
+    m_h, _ = timed(lambda: S.solve_(z_h, g, r_h), reps)
+    rd, zd = torch.from_numpy(b).cuda(), torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+
+    def dev_call():
+        S.solve_(zd, g, rd)
+        torch.cuda.synchronize()
+    m_d, _ = timed(dev_call, reps)
+    out["precond_only"] = dict(host_registered_ms=m_h * 1e3, device_ms=m_d * 1e3, frac=m_d / m_h,
+                               note="one gmg_apply (one V-cycle) per call: 16 N bytes over PCIe per application -- a host-language Krylov loop "
+                                    "should hand the library device vectors or call the whole-solve entry points (gmg_cg_solve / gmg_fgmres_solve)")
+    out["host_io_stats"] = g.host_io_stats()
+    return out
 
 
 def main():
@@ -237,49 +361,22 @@ def main():
 
     pkg = entry.import_package()
     po, S = pkg.poisson, pkg.solvers
+    legs = args.legset
 
-    if world > 1:
-        from gridapsolvers_jl_amd import multigpu
-        out = multigpu.run_bench(args, rank, world, local_rank)
-        if rank == 0 and not args.no_cpu_baseline:
-            # the per-GPU problem of this run (args.cells^3 cells, args.levels levels) on the host cores: a bounded number of solves
-            try:
-                cb, _x, _nit, _h = cpu_baseline(args.cells, args.levels, "lin")
-                cb["sample"] = f"the per-GPU problem of this run ({args.cells}^3 cells, {args.levels} levels) on the host cores: " + cb["sample"]
-                out["cpu_baseline"] = cb
-            except Exception as e:
-                out["cpu_baseline"] = {"error": str(e)[-300:]}
-        dist.barrier()
-        if rank == 0:
-            print(json.dumps(out))
-        dist.destroy_process_group()
-        return
-
-    nc = (args.cells,) * 3
-    nlev = args.levels
-    maxiter, atol, rtol = (20, 1e-14, 1e-6) if args.rhs == "lin" else (100, 1e-14, 1e-8)
-
-    def make_solver(H):
+    def make_solver(H, nlev, maxiter, atol, rtol, options=None):
         sm = [S.RichardsonSmoother(S.JacobiLinearSolver(), 10, 2.0 / 3.0)] * (nlev - 1)
         gmg = S.GMGLinearSolver(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=sm, post_smoothers=sm,
-                                coarsest_solver=S.LUSolver(), maxiter=1, mode="preconditioner", cycle_type="v_cycle")
+                                coarsest_solver=S.LUSolver(), maxiter=1, mode="preconditioner", cycle_type="v_cycle", options=options)
         return S.CGSolver(gmg, maxiter=maxiter, atol=atol, rtol=rtol)
 
-    def leg(H, b, steps, warmup, env=None):
-        """numerical_setup + `steps` timed solves; HIP events around every 8th finest-level sweep launch (GMG_PROF_STRIDE)."""
-        saved = {k: os.environ.get(k) for k in (env or {})}
-        os.environ.update(env or {})
-        try:
-            solver = make_solver(H)
-            t0 = time.perf_counter()
-            ns = S.numerical_setup(S.symbolic_setup(solver, H["mats"][0]), H["mats"][0])
-            t_setup = time.perf_counter() - t0
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+    maxiter, atol, rtol = (20, 1e-14, 1e-6) if args.rhs == "lin" else (100, 1e-14, 1e-8)
+
+    def leg(H, b, nlev, steps, warmup, options=None):
+        """numerical_setup + `steps` timed solves; HIP events around every 8th finest-level sweep launch (prof_stride)."""
+        solver = make_solver(H, nlev, maxiter, atol, rtol, options)
+        t0 = time.perf_counter()
+        ns = S.numerical_setup(S.symbolic_setup(solver, H["mats"][0]), H["mats"][0])
+        t_setup = time.perf_counter() - t0
         n = H["mats"][0].shape[0]
         bd = torch.from_numpy(b).cuda()
         xd = torch.zeros(n, dtype=torch.float64, device="cuda")
@@ -303,15 +400,14 @@ def main():
         fmt = ns.P_ns.level_format(0)
         fmt["sweep_signature"] = ns.P_ns.sweep_signature(0)
         avg_ms = st["total_ms"] / max(st["launches"], 1)
-        r = dict(ns=ns, solver=solver, xd=xd, bd=bd, step=step, n=n, dt=dt, steps=steps, st=st, fmt=fmt, avg_ms=avg_ms,
-                 t_setup=t_setup, iters=int(solver.log.num_iters), dofs_per_s=n * steps / dt,
-                 hist=np.array(solver.log.residuals[: solver.log.num_iters + 1]))
-        return r
+        return dict(ns=ns, solver=solver, xd=xd, bd=bd, step=step, n=n, dt=dt, steps=steps, st=st, fmt=fmt, avg_ms=avg_ms,
+                    t_setup=t_setup, iters=int(solver.log.num_iters), dofs_per_s=n * steps / dt,
+                    hist=np.array(solver.log.residuals[: solver.log.num_iters + 1]))
 
-    def roof(r, bytes_key, label_extra=None, leg=None):
+    def roof(r, bytes_key, label_extra=None, leg=None, kernel=None):
         ach = r["st"][bytes_key] / (r["avg_ms"] * 1e-3) / 1e9 if r["st"]["launches"] else None
         d = {"leg": leg, "leg_value": r["dofs_per_s"], "leg_ms_per_step": r["dt"] / r["steps"] * 1e3,
-             "bound": "hbm", "kernel": kernel_label(r["fmt"]), "sweep_signature": r["fmt"].get("sweep_signature"),
+             "bound": "hbm", "kernel": kernel or kernel_label(r["fmt"]), "sweep_signature": r["fmt"].get("sweep_signature"),
              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": (ach / HBM_PEAK_GBS) if ach else None,
              "bytes_per_launch": r["st"][bytes_key], "avg_launch_ms": r["avg_ms"], "launches_timed": r["st"]["launches"],
@@ -323,17 +419,101 @@ def main():
                          "pass time / sweeps and the per-sweep byte models do not describe what moves")
         return d
 
-    # ---------------- leg 1: the product as shipped --------------------------------------------------------
-    t0 = time.perf_counter()
-    H = po.build_hierarchy(nc, nlev, 1)
-    n = H["mats"][0].shape[0]
-    b = po.dirichlet_lift_rhs(nc, 1) if args.rhs == "lin" else po.random_rhs(n)
-    t_asm = time.perf_counter() - t0
-    D = leg(H, b, args.steps, args.warmup)
-    ns = D["ns"]
-    x = D["xd"].cpu().numpy()
-    l2 = po.l2_error_sq(nc, 1, x) if args.rhs == "lin" else None
-    vbytes, cgbytes = ns.P_ns.model_bytes()
+    def q1_pair(cells, nlev, steps, warmup, want_generic, want_host_io, tag):
+        """default + generic leg (+ host-vector leg) of one Q1 problem: the same blocks at every size and every N"""
+        nc = (cells,) * 3
+        t0 = time.perf_counter()
+        H = po.build_hierarchy(nc, nlev, 1)
+        n = H["mats"][0].shape[0]
+        b = po.dirichlet_lift_rhs(nc, 1) if args.rhs == "lin" else po.random_rhs(n)
+        t_asm = time.perf_counter() - t0
+        D = leg(H, b, nlev, steps, warmup)
+        ns = D["ns"]
+        x = D["xd"].cpu().numpy()
+        R = dict(H=H, b=b, D=D, x=x, n=n, nc=nc, t_asm=t_asm, l2=po.l2_error_sq(nc, 1, x) if args.rhs == "lin" else None)
+        R["model_bytes"] = ns.P_ns.model_bytes()
+        R["device_bytes"] = ns.P_ns.device_bytes()
+        compressed = D["fmt"]["row_patterns"] or D["fmt"]["value_dictionary"] or D["fmt"]["idx16"]
+        R["compressed"] = compressed
+        rc = roof(D, "layout_bytes", "bytes the chosen layout moves per launch: matrix stream as stored + row-wise vectors, each once "
+                                     "(gmg_kernel_stats.layout_bytes); NOT the 12 B/nnz model -- that stream does not exist in this layout", leg=tag + "default")
+        rc["pairs_with"] = "value / ms_per_step"
+        tr, src = committed_traffic(kernel_family(D["fmt"]), cells, nlev, int(D["st"]["rows"]), D["fmt"].get("sweep_signature"))
+        rc["traffic"], rc["traffic_source"] = tr, src
+        if tr:
+            rc["traffic_GBs"] = tr / (D["avg_ms"] * 1e-3) / 1e9
+            rc["traffic_frac"] = rc["traffic_GBs"] / HBM_PEAK_GBS
+        rc["speedup_vs_12B_per_nnz_model"] = D["st"]["alg_bytes"] / D["st"]["layout_bytes"]
+        R["roofline_compressed"] = rc
+        if want_host_io:
+            try:
+                R["host_io"] = host_io_leg(torch, S, ns, b, D["dt"] / D["steps"] * 1e3, steps,
+                                           f"the {tag or 'default '}leg's solves ({cells}^3 cells, {nlev} levels) with b / x as host arrays (GMG_MEM_HOST)")
+            except Exception as e:
+                R["host_io"] = {"error": str(e)[-300:]}
+        R["per_level"] = []
+        return R
+
+    def generic_of(R, cells, nlev, steps, tag):
+        G = leg(R["H"], R["b"], nlev, steps, 1, GENERIC_OPTIONS)
+        xg = G["xd"].cpu().numpy()
+        G["rel_diff_vs_default"] = float(np.linalg.norm(xg - R["x"]) / np.linalg.norm(R["x"]))
+        G["ns"].P_ns.close()
+        rl = roof(G, "alg_bytes", "SURVEY 8(d): B_sweep = 12 Z + 68 N (fp64 value + int32 column per stored nonzero; row-wise "
+                                  "vectors each once), Z = stored nonzeros of the caller's operator", leg=tag + "generic")
+        vbytes, cgbytes = R["model_bytes"]
+        # SURVEY 8(d) model bytes of one whole solve of THIS leg / its time: must stay below the peak if the pair is self-consistent
+        smb = cgbytes * G["iters"] + 12.0 * R["H"]["mats"][0].nnz + 52.0 * R["n"]
+        rl["solve_model_bytes"] = smb
+        rl["solve_model_GBps"] = smb / (G["dt"] / G["steps"]) / 1e9
+        rl["pairs_with"] = "value_generic / ms_per_step_generic"
+        tr, src = committed_traffic(kernel_family(G["fmt"]), cells, nlev, int(G["st"]["rows"]), G["fmt"].get("sweep_signature"))
+        rl["traffic"], rl["traffic_source"] = tr, src
+        if tr:
+            rl["traffic_GBs"] = tr / (G["avg_ms"] * 1e-3) / 1e9
+            rl["traffic_over_algorithmic"] = tr / G["st"]["alg_bytes"]
+        return G, rl
+
+    # =====================================================================================================
+    if world > 1:
+        from gridapsolvers_jl_amd import multigpu
+        out = multigpu.run_bench(args, rank, world, local_rank)
+        if rank == 0:
+            if "cpu" in legs:
+                # the per-GPU problem of this run (args.cells^3 cells, args.levels levels) on the host cores: a bounded number of solves
+                try:
+                    cb, _x, _nit, _h = cpu_baseline(args.cells, args.levels, "lin")
+                    cb["sample"] = f"the per-GPU problem of this run ({args.cells}^3 cells, {args.levels} levels) on the host cores: " + cb["sample"]
+                    out["cpu_baseline"] = cb
+                except Exception as e:
+                    out["cpu_baseline"] = {"error": str(e)[-300:]}
+            if "weak_ref" in legs:
+                # the same per-GPU problem on ONE GPU (rank 0, the others wait at the barrier below): the anchor of this line's weak scaling
+                try:
+                    Rw = q1_pair(args.cells, args.levels, max(3, args.steps // 2), 1, False, False, "weak_scaling_ref/")
+                    W = Rw["D"]
+                    out["weak_anchor_value"] = W["dofs_per_s"]
+                    out["weak_anchor_ms_per_step"] = W["dt"] / W["steps"] * 1e3
+                    out["weak_scaling_ref"] = {"workload": f"the per-GPU problem of this run on ONE GPU (rank 0 alone, after the distributed legs)",
+                                               "value": W["dofs_per_s"], "ms_per_step": W["dt"] / W["steps"] * 1e3, "cg_iterations": W["iters"],
+                                               "roofline_compressed": Rw["roofline_compressed"]}
+                    W["ns"].P_ns.close()
+                except Exception as e:
+                    out["weak_anchor_value"] = None
+                    out["weak_scaling_ref"] = {"error": str(e)[-300:]}
+            else:
+                out["weak_anchor_value"] = None
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps(out))
+        dist.destroy_process_group()
+        return
+
+    # ============================ N = 1 ====================================================================
+    nlev = args.levels
+    R = q1_pair(args.cells, nlev, args.steps, args.warmup, "generic" in legs, "host_io" in legs, "")
+    D, H, b, n, x, ns = R["D"], R["H"], R["b"], R["n"], R["x"], R["D"]["ns"]
+    vbytes, cgbytes = R["model_bytes"]
     # the same sweep kernel on the coarser levels (SURVEY 8d: report per level; these fit the Infinity Cache)
     per_level = []
     for lv in range(1, nlev - 1):
@@ -358,29 +538,8 @@ def main():
             per_level.append(rec)
     copy_GBs = ns.P_ns.stream_probe(1 << 30, 10)    # measured streaming ceiling of this box, same run, library's own copy kernel
     read_GBs = ns.P_ns.stream_probe_read(1 << 30, 10)   # ... and of a read-only stream (the sweeps read far more than they write)
-    compressed = D["fmt"]["row_patterns"] or D["fmt"]["value_dictionary"] or D["fmt"]["idx16"]
-
-    # ---------------- leg 2: same problem, plain 12 B/nnz stream (the layout SURVEY 8(d)'s byte model describes) ----
-    if compressed:
-        G = leg(H, b, max(3, args.steps // 2), 1, GENERIC_ENV)
-        xg = G["xd"].cpu().numpy()
-        G["rel_diff_vs_default"] = float(np.linalg.norm(xg - x) / np.linalg.norm(x))
-        G["ns"].P_ns.close()
-    else:
-        G = D
-    roofline = roof(G, "alg_bytes", "SURVEY 8(d): B_sweep = 12 Z + 68 N (fp64 value + int32 column per stored nonzero; row-wise "
-                                    "vectors each once), Z = stored nonzeros of the caller's operator", leg="generic" if compressed else "default")
-    # SURVEY 8(d) model bytes of one whole solve of THIS leg / its time: must stay below the peak if the pair is self-consistent
-    solve_model_bytes = cgbytes * G["iters"] + 12.0 * H["mats"][0].nnz + 52.0 * n
-    roofline["solve_model_bytes"] = solve_model_bytes
-    roofline["solve_model_GBps"] = solve_model_bytes / (G["dt"] / G["steps"]) / 1e9
-    roofline["pairs_with"] = "value_generic / ms_per_step_generic" if compressed else "value / ms_per_step"
-    roofline["measured_copy_ceiling_GBs"] = copy_GBs
-    roofline["frac_of_copy_ceiling"] = roofline["achieved"] / copy_GBs if roofline["achieved"] else None
-    roofline["measured_read_ceiling_GBs"] = read_GBs
-    roofline["frac_of_read_ceiling"] = roofline["achieved"] / read_GBs if roofline["achieved"] else None
-    tr, src = committed_traffic(kernel_family(G["fmt"]), args.cells, nlev, int(G["st"]["rows"]), G["fmt"].get("sweep_signature"))
-    roofline["traffic"], roofline["traffic_source"] = tr, src
+    R["roofline_compressed"]["coarser_levels"] = per_level
+    R["roofline_compressed"]["frac_of_copy_ceiling"] = (R["roofline_compressed"]["achieved"] / copy_GBs) if R["roofline_compressed"]["achieved"] else None
 
     out = {
         "metric": "DoFs/sec, CG+GMG V-cycle on 3D Poisson Q1",
@@ -396,56 +555,64 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "headline_leg": "default",
-        "legs": "default (`value`, `ms_per_step`, `roofline_compressed`): the product as shipped -- gmg_setup picks the storage layout; "
-                "generic (`value_generic`, `ms_per_step_generic`, `roofline`): every structure-exploiting layout off, the 12 B/nnz stream "
-                "SURVEY 8(d)'s byte model describes; variable_coefficient; weak_scaling_ref (the per-GPU problem of the N > 1 runs on this "
-                "one GPU).  Every roofline block names its leg and carries that leg's value / ms_per_step.",
-        "value_generic": G["dofs_per_s"],
-        "ms_per_step_generic": G["dt"] / G["steps"] * 1e3,
+        "legs": LEGS_NOTE,
+        "rccl_ranks": 0,
+        "devices": [dict(rank=0, local_rank=local_rank, device=torch.cuda.current_device(), name=torch.cuda.get_device_properties(torch.cuda.current_device()).name)],
+        "weak_anchor_value": None,
         "config": {
             "workload": f"BASELINE configs[1]: 3D Poisson Q1 {args.cells}^3 cells, {nlev}-level GMG V-cycle, "
                         f"Richardson(Jacobi,10,2/3) pre=post, dense-inverse coarse solve, CG rtol={rtol:g}, "
                         f"rhs={'u=x1+x2 Dirichlet lift' if args.rhs == 'lin' else 'U(-1,1) seed 20240601'}",
             "value_is": "default leg: storage layout chosen by gmg_setup (" + D["fmt"]["layout"] + "); value_generic: same problem, "
-                        "every structure-exploiting layout switched off (GMG_PATTERN=0 GMG_VDICT=0 GMG_IDX16=0 GMG_OPATTERN=0): the plain 12 B/nnz "
+                        "every structure-exploiting layout switched off (options pattern=0 vdict=0 idx16=0 opattern=0): the plain 12 B/nnz "
                         "(col,val) stream, what an operator without any repeating structure (unstructured mesh) gets",
             "dofs": n, "nnz": H["mats"][0].nnz, "levels": nlev, "cg_iterations": D["iters"],
-            "cg_iterations_generic": G["iters"],
             "dofs_x_iters_per_s": n * D["iters"] * args.steps / D["dt"],
-            "l2_error_sq": l2,
+            "l2_error_sq": R["l2"],
             "model_bytes_per_cg_iter": cgbytes, "model_bytes_per_vcycle": vbytes,
-            "solve_model_GBps_generic": (cgbytes * G["iters"] + 12.0 * H["mats"][0].nnz + 52.0 * n) / (G["dt"] / G["steps"]) / 1e9,
-            "setup_s": D["t_setup"], "setup_s_generic": G["t_setup"], "assembly_s": t_asm, "device_bytes": ns.P_ns.device_bytes(),
-            "operator_storage": D["fmt"], "operator_storage_generic": G["fmt"],
-            "generic_rel_diff_vs_default_solution": G.get("rel_diff_vs_default"),
+            "setup_s": D["t_setup"], "assembly_s": R["t_asm"], "device_bytes": R["device_bytes"],
+            "operator_storage": D["fmt"],
+            "measured_copy_ceiling_GBs": copy_GBs, "measured_read_ceiling_GBs": read_GBs,
         },
-        "roofline": roofline,
+        "roofline_compressed": R["roofline_compressed"],
     }
-    if compressed:
-        rc = roof(D, "layout_bytes", "bytes the chosen layout moves per launch: matrix stream as stored + row-wise vectors, each once "
-                                     "(gmg_kernel_stats.layout_bytes); NOT the 12 B/nnz model -- that stream does not exist in this layout", leg="default")
-        rc["pairs_with"] = "value / ms_per_step"
-        rc["coarser_levels"] = per_level
-        tr, src = committed_traffic(kernel_family(D["fmt"]), args.cells, nlev, int(D["st"]["rows"]), D["fmt"].get("sweep_signature"))
-        rc["traffic"], rc["traffic_source"] = tr, src
-        if tr:
-            rc["traffic_GBs"] = tr / (D["avg_ms"] * 1e-3) / 1e9
-            rc["traffic_frac"] = rc["traffic_GBs"] / HBM_PEAK_GBS
-        rc["frac_of_copy_ceiling"] = rc["achieved"] / copy_GBs if rc["achieved"] else None
-        rc["speedup_vs_12B_per_nnz_model"] = D["st"]["alg_bytes"] / D["st"]["layout_bytes"]
-        out["roofline_compressed"] = rc
-    else:
-        roofline["coarser_levels"] = per_level
+    if "host_io" in R:
+        out["host_io"] = R["host_io"]
+        out["value_host_io"] = R["host_io"].get("value")
+        out["ms_per_step_host_io"] = R["host_io"].get("ms_per_step")
 
-    # ---------------- leg 3: variable coefficient (every row distinct -> generic layout by itself) ------------------
+    # ---------------- generic leg: same problem, plain 12 B/nnz stream (the layout SURVEY 8(d)'s byte model describes) ----
+    G = None
+    if "generic" in legs and R["compressed"]:
+        G, roofline = generic_of(R, args.cells, nlev, max(3, args.steps // 2), "")
+    elif "generic" in legs:
+        G = D                                                # the setup chose the plain stream by itself
+        roofline = roof(D, "alg_bytes", "SURVEY 8(d): B_sweep = 12 Z + 68 N", leg="default (no structure found: the generic layout)")
+        roofline["pairs_with"] = "value / ms_per_step"
+    else:
+        roofline = {"leg": "generic", "skipped": "--no-generic / --legs"}
+    if G is not None:
+        roofline["measured_copy_ceiling_GBs"] = copy_GBs
+        roofline["frac_of_copy_ceiling"] = roofline["achieved"] / copy_GBs if roofline.get("achieved") else None
+        roofline["measured_read_ceiling_GBs"] = read_GBs
+        roofline["frac_of_read_ceiling"] = roofline["achieved"] / read_GBs if roofline.get("achieved") else None
+        out["value_generic"] = G["dofs_per_s"]
+        out["ms_per_step_generic"] = G["dt"] / G["steps"] * 1e3
+        out["config"].update(cg_iterations_generic=G["iters"], setup_s_generic=G["t_setup"], operator_storage_generic=G["fmt"],
+                             generic_rel_diff_vs_default_solution=G.get("rel_diff_vs_default"),
+                             solve_model_GBps_generic=roofline.get("solve_model_GBps"))
+    out["roofline"] = roofline
+
+    # ---------------- variable coefficient (every row distinct -> generic layout by itself) ------------------
     V = None
-    if not args.no_varcoef:
+    if "varcoef" in legs:
+        nc = R["nc"]
         t0 = time.perf_counter()
         Hv = po.build_hierarchy(nc, nlev, 1, kappa=po.smooth_kappa)
         uex = po.nodal_values(nc, 1)
         bv = Hv["mats"][0].matvec(uex)
         t_asm_v = time.perf_counter() - t0
-        V = leg(Hv, bv, max(3, args.steps // 2), 1)
+        V = leg(Hv, bv, nlev, max(3, args.steps // 2), 1)
         xv = V["xd"].cpu().numpy()
         if V["fmt"]["layout"] == "SELL-O":
             rv = roof(V, "layout_bytes", "bytes the SELL-O layout moves per launch: 8 B/nnz values + 2 B/row pattern id + row-wise vectors "
@@ -465,48 +632,54 @@ def main():
             "max_abs_error_vs_exact": float(np.max(np.abs(xv - uex))), "roofline": rv,
         }
         V["ns"].P_ns.close()
+        del Hv, bv
 
-    # ---------------- leg 4: the per-GPU problem of the N > 1 runs (BASELINE configs[3]) on this one GPU ------------
+    ns.P_ns.close()
+    del R["H"], H
+
+    # ---------------- the per-GPU problem of the N > 1 runs (BASELINE configs[3]) on this one GPU ------------
     # `bench.py --gpus N` (N > 1) gives every GPU WS_CELLS^3 cells and WS_LEVELS levels; the weak-scaling efficiency of those lines
     # is to be read against THIS figure (same operator family, same smoother, same tolerances), not against configs[1] above.
-    if not args.no_weak_ref and (args.cells, nlev) != (WS_CELLS, WS_LEVELS):
+    if "weak_ref" in legs and (args.cells, nlev) != (WS_CELLS, WS_LEVELS):
         try:
-            D["ns"].P_ns.close()
-            t0 = time.perf_counter()
-            ncw = (WS_CELLS,) * 3
-            Hw = po.build_hierarchy(ncw, WS_LEVELS, 1)
-            bw = po.dirichlet_lift_rhs(ncw, 1)
-            t_asm_w = time.perf_counter() - t0
-            nlev_saved, nlev = nlev, WS_LEVELS          # make_solver reads nlev
-            try:
-                W = leg(Hw, bw, max(3, args.steps // 2), 1)
-                xw = W["xd"].cpu().numpy()
-                rw = roof(W, "layout_bytes", "gmg_kernel_stats.layout_bytes (matrix stream as stored + row-wise vectors, each once)", leg="weak_scaling_ref")
-                wref = {"workload": f"3D Poisson Q1 {WS_CELLS}^3 cells on ONE GPU, {WS_LEVELS}-level GMG V-cycle, same smoother / tolerances: the per-GPU "
-                                    f"problem of `bench.py --gpus N`, N > 1 (BASELINE configs[3]: {2 * WS_CELLS}^3 cells on 2x2x2 GPUs)",
-                        "value": W["dofs_per_s"], "unit": "DoFs/s", "ms_per_step": W["dt"] / W["steps"] * 1e3, "steps": W["steps"],
-                        "dofs": W["n"], "cg_iterations": W["iters"], "l2_error_sq": po.l2_error_sq(ncw, 1, xw),
-                        "operator_storage": W["fmt"], "setup_s": W["t_setup"], "assembly_s": t_asm_w,
-                        "device_bytes": W["ns"].P_ns.device_bytes(), "roofline": rw}
-                W["ns"].P_ns.close()
-                del W, xw
-                Gw = leg(Hw, bw, 3, 1, GENERIC_ENV)
-                rgw = roof(Gw, "alg_bytes", "SURVEY 8(d): B_sweep = 12 Z + 68 N", leg="weak_scaling_ref/generic")
+            Rw = q1_pair(WS_CELLS, WS_LEVELS, max(3, args.steps // 2), 1, "generic" in legs, "host_io" in legs, "weak_scaling_ref/")
+            W = Rw["D"]
+            wref = {"workload": f"3D Poisson Q1 {WS_CELLS}^3 cells on ONE GPU, {WS_LEVELS}-level GMG V-cycle, same smoother / tolerances: the per-GPU "
+                                f"problem of `bench.py --gpus N`, N > 1 (BASELINE configs[3]: {2 * WS_CELLS}^3 cells on 2x2x2 GPUs)",
+                    "value": W["dofs_per_s"], "unit": "DoFs/s", "ms_per_step": W["dt"] / W["steps"] * 1e3, "steps": W["steps"],
+                    "dofs": W["n"], "cg_iterations": W["iters"], "l2_error_sq": Rw["l2"],
+                    "operator_storage": W["fmt"], "setup_s": W["t_setup"], "assembly_s": Rw["t_asm"],
+                    "device_bytes": Rw["device_bytes"], "roofline_compressed": Rw["roofline_compressed"]}
+            if "host_io" in Rw:
+                wref["host_io"] = Rw["host_io"]
+                wref["value_host_io"] = Rw["host_io"].get("value")
+            W["ns"].P_ns.close()
+            if "generic" in legs:
+                Gw, rgw = generic_of(Rw, WS_CELLS, WS_LEVELS, 3, "weak_scaling_ref/")
                 wref.update(value_generic=Gw["dofs_per_s"], ms_per_step_generic=Gw["dt"] / Gw["steps"] * 1e3,
-                            cg_iterations_generic=Gw["iters"], roofline_generic=rgw)
-                Gw["ns"].P_ns.close()
+                            cg_iterations_generic=Gw["iters"], roofline=rgw)
                 del Gw
-            finally:
-                nlev = nlev_saved
             out["weak_scaling_ref"] = wref
-            del Hw, bw
+            out["weak_anchor_value"] = wref["value"]
+            out["weak_anchor_ms_per_step"] = wref["ms_per_step"]
+            del Rw, W
         except Exception as e:          # a box without the memory for it still reports the headline
             out["weak_scaling_ref"] = {"error": str(e)[-300:]}
+    elif (args.cells, nlev) == (WS_CELLS, WS_LEVELS):
+        out["weak_anchor_value"] = out["value"]
+        out["weak_anchor_ms_per_step"] = out["ms_per_step"]
 
-    if not args.no_cpu_baseline:
+    # ---------------- BASELINE configs[2]: Q2, patch smoother, FGMRES(5) ---------------------------------------
+    if "config3" in legs:
+        try:
+            out["config3"] = config3_leg(torch, pkg, args)
+        except Exception as e:
+            out["config3"] = {"error": str(e)[-400:]}
+
+    if "cpu" in legs:
         cb, xo, nit_o, hist_o = cpu_baseline(args.cells, nlev, args.rhs)
         out["cpu_baseline"] = cb
-        out["config"]["iterations_match_cpu"] = bool(nit_o == D["iters"] == G["iters"])
+        out["config"]["iterations_match_cpu"] = bool(nit_o == D["iters"] and (G is None or nit_o == G["iters"]))
         out["config"]["rel_diff_vs_cpu_solution"] = float(np.linalg.norm(x - xo) / np.linalg.norm(xo))
         if V is not None:
             try:
@@ -516,7 +689,111 @@ def main():
                 out["variable_coefficient"]["cpu_single_thread_seconds"] = rvc["seconds"]
             except Exception as e:
                 out["variable_coefficient"]["cpu_check_error"] = str(e)[-300:]
+        if isinstance(out.get("config3"), dict) and "error" not in out["config3"]:
+            try:
+                c3 = out["config3"]
+                cb3, x3o, nit3, hist3 = cpu_baseline(c3["cpu_check"]["cells"], c3["cpu_check"]["levels"], "lin", config3=True, limit_seq=8.0)
+                cb3["sample"] = (f"BASELINE configs[2] shape at {c3['cpu_check']['cells']}^3 cells, {c3['cpu_check']['levels']} levels (the size the sequential "
+                                 f"oracle affords in ~10 s): " + cb3["sample"])
+                c3["cpu_baseline"] = cb3
+                c3["cpu_check"]["iterations_match_cpu"] = bool(nit3 == c3["cpu_check"]["gpu_iters"])
+                c3["cpu_check"]["max_rel_dev_of_residual_history"] = float(np.max(np.abs(np.asarray(c3["cpu_check"]["gpu_hist"])[: nit3 + 1] - hist3) / hist3))
+                c3["cpu_check"]["rel_diff_vs_cpu_solution"] = float(np.linalg.norm(c3["cpu_check"].pop("gpu_x") - x3o) / np.linalg.norm(x3o))
+            except Exception as e:
+                out["config3"]["cpu_baseline"] = {"error": str(e)[-300:]}
+    if isinstance(out.get("config3"), dict) and isinstance(out["config3"].get("cpu_check"), dict):
+        out["config3"]["cpu_check"].pop("gpu_x", None)
     print(json.dumps(out))
+
+
+def config3_leg(torch, pkg, args):
+    """BASELINE configs[2]: 3-D Poisson Q2, 5-level GMG, Richardson(PatchSolver,10,0.2) pre = post on every level, FGMRES(5), rtol 1e-6
+    (test/LinearSolvers/GMGTests.jl:18-47,119-123).  Operators of >= 1e6 rows are streamed (gmg_set_operator_rows): nobody holds their
+    CSR.  The timed kernel is the operator mat-vec of the patch sweep (r -= A dx: 125 entries per row), its byte model 12 Z + 28 N."""
+    po, S, abi = pkg.poisson, pkg.solvers, pkg.abi
+    cells, nlev, order = args.config3_cells, args.config3_levels, 2
+
+    def setup(cells, nlev, stream_min_rows):
+        nc = (cells,) * 3
+        t0 = time.perf_counter()
+        H = po.build_hierarchy(nc, nlev, order, stream_min_rows=stream_min_rows)
+        t_asm = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sm, npatch = [], []
+        for l in range(nlev - 1):
+            pp, pd = po.vertex_star_patches(H["ncells"][l], order)
+            npatch.append(int(pp.size - 1))
+            sm.append(S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2))
+        t_patch = time.perf_counter() - t0
+        b = po.dirichlet_lift_rhs(nc, order)
+        gmg = S.GMGLinearSolver(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=sm, post_smoothers=sm, maxiter=1)
+        solver = S.FGMRESSolver(5, gmg, maxiter=20, atol=1e-14, rtol=1e-6)
+        t0 = time.perf_counter()
+        ns = S.numerical_setup(S.symbolic_setup(solver, H["mats"][0]), H["mats"][0])
+        t_setup = time.perf_counter() - t0
+        del sm, gmg.pre_smoothers[:], gmg.post_smoothers[:]
+        return H, b, solver, ns, dict(assembly_small_levels_s=t_asm, patch_tables_s=t_patch, numerical_setup_incl_stream_generation_s=t_setup), npatch
+
+    H, b, solver, ns, tsetup, npatch = setup(cells, nlev, 1000000)
+    n = b.size
+    bd = torch.from_numpy(b).cuda()
+    xd = torch.zeros_like(bd)
+    torch.cuda.synchronize()
+    steps = max(2, args.steps // 3)
+
+    def step():
+        xd.zero_(); torch.cuda.synchronize(); S.solve_(xd, ns, bd)
+    step()
+    ns.P_ns.profile(0, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = ns.P_ns.kernel_stats()
+    ns.P_ns.profile(0, False)
+    yd = torch.zeros_like(bd)
+    ns.P_ns.op_apply(0, abi.OP_A, xd, yd)
+    true_rel = float(torch.linalg.vector_norm(bd - yd) / torch.linalg.vector_norm(bd))
+    x = xd.cpu().numpy()
+    fmt = ns.P_ns.level_format(0)
+    avg_ms = st["total_ms"] / max(st["launches"], 1)
+    ach = st["alg_bytes"] / (avg_ms * 1e-3) / 1e9 if st["launches"] else None
+    lay = st["layout_bytes"] / (avg_ms * 1e-3) / 1e9 if st["launches"] else None
+    tr, src = committed_traffic("sells_kernel_wide", cells, nlev, int(st["rows"]), None, order=2)
+    rl = {"leg": "config3", "leg_value": n / dt, "leg_ms_per_step": dt * 1e3, "bound": "hbm",
+          "kernel": "sells_kernel<EPI_SUB,...,K=5,VD,WL> (r -= A dx of the patch sweep: Q2 stiffness matrix, 125 entries per row, coded row-pattern "
+                    "table decoded per workgroup into LDS)",
+          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
+          "bytes_model": "SURVEY 8(d): r -= A dx = 12 Z + 28 N -- a (col,val) stream this layout does not have: `frac` > 1 means faster than streaming "
+                         "the CSR would allow; see layout_GBs / traffic for what actually moves",
+          "bytes_per_launch": st["alg_bytes"], "layout_bytes_per_launch": st["layout_bytes"], "layout_GBs": lay,
+          "layout_frac": (lay / HBM_PEAK_GBS) if lay else None,
+          "avg_launch_ms": avg_ms, "launches_timed": st["launches"], "rows": int(st["rows"]), "nnz": int(st["nnz"]),
+          "traffic": tr, "traffic_source": src}
+    if tr:
+        rl["traffic_GBs"] = tr / (avg_ms * 1e-3) / 1e9
+        rl["traffic_frac"] = rl["traffic_GBs"] / HBM_PEAK_GBS
+    out = dict(workload=f"BASELINE configs[2]: 3D Poisson Q2 {cells}^3 cells, {nlev}-level GMG, Richardson(PatchSolver,10,0.2) pre=post, "
+                        f"FGMRES(5) rtol=1e-6, rhs = u=x1+x2 Dirichlet lift" + ("" if cells == 256 else " (full size: --config3-cells 256)"),
+               value=n / dt, unit="DoFs/s", ms_per_step=dt * 1e3, steps=steps, dofs=int(n), dofs_per_level=[int(M.shape[0]) for M in H["mats"]],
+               patches_per_level=npatch, streamed_levels=[l for l, M in enumerate(H["mats"]) if hasattr(M, "row_blocks")],
+               fgmres_iterations=int(solver.log.num_iters), flag=int(solver.log.flag),
+               hist_rel=(solver.log.residuals[:solver.log.num_iters + 1] / solver.log.residuals[0]).tolist(),
+               true_residual_rel=true_rel, l2_error_sq=po.l2_error_sq((cells,) * 3, order, x),
+               setup=tsetup, operator_storage=fmt, device_GB=ns.P_ns.device_bytes() / 1e9, roofline=rl)
+    ns.P_ns.close()
+    del H, bd, xd, yd
+    # the same configuration at the size the CPU oracle affords: iteration count, history and solution against the oracle (run in main)
+    cc, cl = 32, 4
+    H2, b2, solver2, ns2, _t, _np = setup(cc, cl, 20000)
+    x2 = np.zeros_like(b2)
+    S.solve_(x2, ns2, b2)
+    out["cpu_check"] = dict(cells=cc, levels=cl, gpu_iters=int(solver2.log.num_iters),
+                            gpu_hist=[float(v) for v in solver2.log.residuals[: solver2.log.num_iters + 1]], gpu_x=x2)
+    ns2.P_ns.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -58,6 +58,12 @@ SYMBOLS = {
     "gmg_set_coarse_solver": [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
     "gmg_get_coarse_log": [C.c_void_p, C.POINTER(Result)],
     "gmg_set_options": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double],
+    "gmg_set_option": [C.c_void_p, C.c_char_p, C.c_double],
+    "gmg_get_option": [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)],
+    "gmg_host_register": [C.c_void_p, C.c_void_p, C.c_int64],
+    "gmg_host_unregister": [C.c_void_p, C.c_void_p],
+    "gmg_get_host_io_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "gmg_get_persist_retries": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)],
     "gmg_setup": [C.c_void_p],
     "gmg_set_verbose": [C.c_void_p, C.c_int],
     "gmg_get_log": [C.c_void_p, C.POINTER(Result), C.c_void_p, C.c_int],
@@ -85,6 +91,7 @@ SYMBOLS = {
     "gmg_set_partition_overlap": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p],
     "gmg_get_comm_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+    "gmg_get_comm_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "gmg_set_replication": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64],
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
     "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],

@@ -525,7 +525,7 @@ int gmg_block_fgmres_solve(gmg_block_handle_t h, const double *b, double *x, int
     const int64_t n = h->N();
     const double *db = h->eng.in_vec(b, n, memspace, h->st_b);
     double *dx = (memspace == GMG_MEM_DEVICE) ? x : h->st_x;
-    if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->eng.stream));
+    if (memspace == GMG_MEM_HOST) h->eng.h2d(dx, x, n);
     ConvLog log;
     log.configure(maxiter, atol, rtol);
     KrylovOps ops = h->ops(use_precond != 0);
@@ -545,7 +545,7 @@ int gmg_block_cg_solve(gmg_block_handle_t h, const double *b, double *x, int mem
     const int64_t n = h->N();
     const double *db = h->eng.in_vec(b, n, memspace, h->st_b);
     double *dx = (memspace == GMG_MEM_DEVICE) ? x : h->st_x;
-    if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->eng.stream));
+    if (memspace == GMG_MEM_HOST) h->eng.h2d(dx, x, n);
     ConvLog log;
     log.configure(maxiter, atol, rtol);
     KrylovOps ops = h->ops(use_precond != 0);

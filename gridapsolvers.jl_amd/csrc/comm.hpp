@@ -40,6 +40,10 @@ struct RcclApi {
   int (*GroupEnd)() = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  // optional (diagnostics: gmg_get_comm_info)
+  int (*CommCount)(NcclComm, int *) = nullptr;
+  int (*CommCuDevice)(NcclComm, int *) = nullptr;
+  int (*CommUserRank)(NcclComm, int *) = nullptr;
 
   bool load(const char *path, std::string &err)
   {
@@ -61,6 +65,9 @@ struct RcclApi {
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    CommCount = (decltype(CommCount))dlsym(dl, "ncclCommCount");
+    CommCuDevice = (decltype(CommCuDevice))dlsym(dl, "ncclCommCuDevice");
+    CommUserRank = (decltype(CommUserRank))dlsym(dl, "ncclCommUserRank");
     return GetUniqueId && CommInitRank && CommDestroy && Send && Recv && GroupStart && GroupEnd && AllReduce;
   }
 };

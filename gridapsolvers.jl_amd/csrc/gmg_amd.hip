@@ -427,12 +427,6 @@ struct ConvLog {
 
 constexpr int kScalarSlots = 4096;
 
-int env_int(const char *name, int dflt)
-{
-  const char *s = std::getenv(name);
-  return s && *s ? std::atoi(s) : dflt;
-}
-
 } // namespace
 
 // ----------------------------------------------------------------------------
@@ -466,6 +460,19 @@ struct gmg_solver {
   void touch() { setup_done = false; structure_dirty = true; }
   int64_t dev_bytes = 0;
   std::vector<void *> allocs;
+
+  // Layout / schedule policy of this handle (gmg_set_option).  The reference configures a solver through constructor keywords only
+  // (GMGLinearSolvers.jl:48-58); a process-wide environment variable cannot choose a layout per solver, so every switch the library
+  // reads is a per-handle option first.  The environment variable of the same name, when set, overrides it (debugging / A-B runs).
+  std::map<std::string, double> options;
+  double opt_num(const char *name, double dflt) const
+  {
+    const char *s = std::getenv(name);
+    if (s && *s) return std::atof(s);
+    auto it = options.find(name);
+    return it != options.end() ? it->second : dflt;
+  }
+  int opt_int(const char *name, int dflt) const { return (int)opt_num(name, (double)dflt); }
 
   // GMGLinearSolver kwargs (GMGLinearSolvers.jl:56-58)
   int mode = GMG_MODE_PRECONDITIONER, cycle_type = GMG_V_CYCLE;
@@ -570,6 +577,7 @@ struct gmg_solver {
   size_t prof_used = 0;
   double prof_ms = 0.0;
   int64_t prof_launches = 0, prof_fused = 0;
+  bool prof_patch = false;      // the timed launches were `r -= A dx` mat-vecs of a patch-smoother sweep, not fused Jacobi sweeps
   std::vector<int> prof_w;     // sweeps bracketed by each event pair (1, or niter for a pass run as one launch)
 
   // ---- memory -------------------------------------------------------------
@@ -658,7 +666,7 @@ struct gmg_solver {
   {
     DevCSR D;
     D.nrows = H.nrows; D.ncols = H.ncols; D.nnz = H.nnz();
-    D.ptr64 = D.nnz >= (int64_t)INT32_MAX || env_int("GMG_FORCE_PTR64", 0) != 0;   // 64-bit row pointers for >= 2^31 nnz (config 3 scale)
+    D.ptr64 = D.nnz >= (int64_t)INT32_MAX || opt_int("GMG_FORCE_PTR64", 0) != 0;   // 64-bit row pointers for >= 2^31 nnz (config 3 scale)
     if (D.ptr64) D.rowptr = upload(H.ptr);
     else {
       std::vector<int32_t> p32(H.ptr.begin(), H.ptr.end());
@@ -1030,8 +1038,8 @@ struct gmg_solver {
   bool try_eager_pattern(std::shared_ptr<PatStream> &out, int mode, int64_t nrows, int64_t ncols, int64_t nnz, const void *ptr,
                          const void *idx, const double *val, int layout, int base, int bytes)
   {
-    if (layout != GMG_CSR || comm.nranks != 1 || nrows < env_int("GMG_EAGER_MIN_ROWS", 20000) || !env_int("GMG_EAGER", 1)) return false;
-    if (!env_int("GMG_PATTERN", 1) || !env_int("GMG_SELL", 1) || !ptr || !idx || !val) return false;
+    if (layout != GMG_CSR || comm.nranks != 1 || nrows < opt_int("GMG_EAGER_MIN_ROWS", 20000) || !opt_int("GMG_EAGER", 1)) return false;
+    if (!opt_int("GMG_PATTERN", 1) || !opt_int("GMG_SELL", 1) || !ptr || !idx || !val) return false;
     if (ncols >= (int64_t)(1 << 28) || nnz <= 0) return false;
     if (read_index(ptr, 0, bytes) != base || read_index(ptr, nrows, bytes) - base != nnz) return false;   // general path reports it
     auto S = std::make_shared<PatStream>();
@@ -1041,7 +1049,7 @@ struct gmg_solver {
     } catch (const GmgError &) {
       return false;
     }
-    const int un = pat_un_of(env_int("GMG_PAT_UN", 9));      // table stride granularity of the pattern kernel, as finish_stream will see it (read_tuning has not run yet)
+    const int un = pat_un_of(opt_int("GMG_PAT_UN", 9));      // table stride granularity of the pattern kernel, as finish_stream will see it (read_tuning has not run yet)
     const int64_t W = (std::max<int64_t>(S->wmax, 1) + un - 1) / un * un;
     const bool generic = (int64_t)(S->len.size() + 1) * (12 * W + 4) <= 48 * 1024;
     if (!generic) return false;                              // wide / many patterns: let the general path pick the layout
@@ -1231,7 +1239,7 @@ struct gmg_solver {
     if (M.wl_state == 1) { HIP_CHECK(hipStreamSynchronize(stream)); release(M.wl_pids, (size_t)M.wl_nwg * kWideStride); release(M.wl_cnt, (size_t)M.wl_nwg); }
     M.wl_state = 2; M.wl_req = nwg_req; M.wl_nwg = 0; M.wl_wpb = wpb; M.wl_max = 0;
     if (!pat_wide || !M.pat_coded || M.pat_np > 4096 || M.pat_np < 2 || !M.rowpid || !M.pcodes || !M.pdict || !M.prunmask) return 0;
-    const size_t lds_cap = (size_t)env_int("GMG_PAT_WIDE_LDS", 72 * 1024);
+    const size_t lds_cap = (size_t)opt_int("GMG_PAT_WIDE_LDS", 72 * 1024);
     int nwg = nwg_req;
     for (int attempt = 0; attempt < 2; ++attempt) {
       uint16_t *pids = dalloc<uint16_t>((size_t)nwg * kWideStride);
@@ -1246,12 +1254,12 @@ struct gmg_solver {
       // resident workgroups per CU: LDS (160 KB) and registers (128 per lane: 4 waves per SIMD)
       const int per_cu = ok ? (int)std::min<size_t>((size_t)(160 * 1024) / (wide_lds(M, lmax) + 512), (size_t)std::max(1, 16 / wpb)) : 0;
       const int resident = per_cu * 256;
-      if (env_int("GMG_SETUP_TIMING", 0))
+      if (opt_int("GMG_SETUP_TIMING", 0))
         std::fprintf(stderr, "[gmg] wide-row tables: %lld rows, %d patterns x %d entries, %d workgroups, at most %d patterns per chunk -> %zu B of LDS, %d workgroups per CU\n",
                      (long long)M.nrows, M.pat_np, M.pat_k * M.pat_nruns, nwg, lmax, wide_lds(M, std::min(lmax, 255)), per_cu);
       if (!ok) { release(pids, (size_t)nwg * kWideStride); release(cnt, (size_t)nwg); return 0; }
       const int rounds = resident > 0 ? nwg / resident : 0;
-      if (attempt == 0 && env_int("GMG_PAT_WIDE_ROUNDS", 1) && rounds >= 1 && nwg % resident != 0) {
+      if (attempt == 0 && opt_int("GMG_PAT_WIDE_ROUNDS", 1) && rounds >= 1 && nwg % resident != 0) {
         // not a whole number of rounds: take the whole rounds below the request and list the patterns of THAT geometry
         release(pids, (size_t)nwg * kWideStride); release(cnt, (size_t)nwg);
         nwg = rounds * resident;
@@ -1323,7 +1331,7 @@ struct gmg_solver {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_kernel<EPI, ONEG, 5, 5, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set[device & 63] = true;
       }
-      if (env_int("GMG_DBG_NOGATHER", 0)) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true, 8, true>), g, b, ldsw, stream, a);   // timing ablation only
+      if (opt_int("GMG_DBG_NOGATHER", 0)) hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true, 8, true>), g, b, ldsw, stream, a);   // timing ablation only
       else
       hipLaunchKernelGGL((sells_kernel<EPI, ONEG, 5, 5, true, 0, true>), g, b, ldsw, stream, a);
     } else
@@ -1726,7 +1734,7 @@ struct gmg_solver {
   bool launch_tsweep(const DevCSR &M, const SellSArgs &a, int nsl)
   {
     constexpr int WPB = 16, ROWS = 62, TMAX = 3 * WPB;
-    if (M.pat_nruns > 32 || nsl < env_int("GMG_PAT_TILE_MIN", 512)) return false;
+    if (M.pat_nruns > 32 || nsl < opt_int("GMG_PAT_TILE_MIN", 512)) return false;
     std::vector<int32_t> &off = M.h_run_off;
     if (off.empty()) {
       off.resize((size_t)M.pat_nruns);
@@ -1735,7 +1743,7 @@ struct gmg_solver {
     }
     const bool mk = pat_strict || !M.ptab8;
     const int nu = M.pat_k * M.pat_nruns;
-    const size_t lds_cap = (size_t)env_int("GMG_PAT_TILE_LDS", 78 * 1024);      // two workgroups of 16 waves per CU
+    const size_t lds_cap = (size_t)opt_int("GMG_PAT_TILE_LDS", 78 * 1024);      // two workgroups of 16 waves per CU
     std::vector<int> order((size_t)M.pat_nruns);
     for (int r = 0; r < M.pat_nruns; ++r) order[(size_t)r] = r;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return off[(size_t)x] < off[(size_t)y]; });
@@ -1768,7 +1776,7 @@ struct gmg_solver {
     };
     // the largest tile that fits the LDS budget, then the tile size that fills whole rounds of the resident workgroups
     SellTile tl;
-    int tmax = env_int("GMG_PAT_TILE_T", TMAX);
+    int tmax = opt_int("GMG_PAT_TILE_T", TMAX);
     tmax = std::max(WPB, std::min(tmax, TMAX));
     size_t lds = 0;
     for (; tmax >= WPB; --tmax) { lds = geometry(tmax, tl); if (lds != 0 && lds <= lds_cap) break; }
@@ -2206,19 +2214,46 @@ struct gmg_solver {
     return true;
   }
   // Runs a whole solve; if a one-launch smoothing pass timed out inside it (its workgroups were not co-resident: the GPU is shared
-  // with other persistent kernels), the handle has already switched to per-sweep launches -- restore the initial guess and run the
-  // solve again instead of failing the call.  `x_user` is only overwritten in place for single-GPU device vectors: saved first.
+  // with other persistent kernels), the handle switches to per-sweep launches, the initial guess is restored and the solve runs
+  // again instead of failing the call.  `x_user` is only overwritten in place for single-GPU device vectors: saved first, unless
+  // the body never reads it (x_output_only: gmg_apply as a preconditioner -- the path a host-language Krylov loop calls once per
+  // iteration).  Several ranks: a timed-out pass writes nothing, so the solve simply carries on with the values it had, NO rank
+  // leaves the collective sequence in the middle (fetch_scalar does not throw), and at the end of the body every rank learns
+  // through one all-reduce whether ANY rank tripped: either all of them run the solve again or none does.
   template <typename F>
-  void with_persist_retry(double *x_user, int64_t n, int memspace, F &&body)
+  void with_persist_retry(double *x_user, int64_t n, int memspace, bool x_output_only, F &&body)
   {
     const bool armed = persist != 0;
-    const bool inplace = memspace == GMG_MEM_DEVICE && comm.nranks == 1;
+    const bool multi = comm.nranks > 1;
+    const bool inplace = memspace == GMG_MEM_DEVICE && !multi && !x_output_only;
     if (armed && inplace) copy(scratch_vec(6, lev[0].nvec), x_user, n);
+    persist_defer_throw = armed && multi;
+    bool again = false;
     try {
+      if (armed && opt_int("GMG_PERSIST_FORCE_TIMEOUT", 0) > 0 && h_perr) {   // test hook: behave as if a pass timed out in this solve
+        options["GMG_PERSIST_FORCE_TIMEOUT"] = opt_int("GMG_PERSIST_FORCE_TIMEOUT", 0) - 1;
+        force_trip = true;
+      }
       body();
-      check_persistent();
+      if (force_trip) { HIP_CHECK(hipStreamSynchronize(stream)); *h_perr = 1; force_trip = false; }
+      if (!persist_defer_throw) check_persistent();
     } catch (const GmgError &) {
+      persist_defer_throw = false; force_trip = false;
       if (!(armed && persist_tripped)) throw;
+      again = true;
+    }
+    if (armed && multi) {
+      persist_defer_throw = false;
+      HIP_CHECK(hipStreamSynchronize(stream));
+      double flag = (h_perr && *h_perr) ? 1.0 : 0.0;
+      host_allreduce_sum(&flag);                             // joint decision (not counted in gmg_get_comm_stats: control traffic)
+      if (flag > 0.0) {
+        if (h_perr) *h_perr = 0;
+        persist = 0;
+        again = true;
+      }
+    }
+    if (again) {
       persist_tripped = false;
       ++persist_retries;
       HIP_CHECK(hipStreamSynchronize(stream));
@@ -2227,10 +2262,27 @@ struct gmg_solver {
     }
   }
   bool persist_tripped = false;
+  bool persist_defer_throw = false;   // several ranks: the time-out is acted on jointly at the end of the solve
+  bool force_trip = false;
   int64_t persist_retries = 0;
+  // one double summed over the ranks through the host (control decisions; solves use the in-stream reductions)
+  void host_allreduce_sum(double *v)
+  {
+    if (comm.nranks <= 1) return;
+    if (comm.kind == COMM_RCCL) {
+      double *slot = d_scalars + kScalarSlots - 1;
+      HIP_CHECK(hipMemcpyAsync(slot, v, sizeof(double), hipMemcpyHostToDevice, stream));
+      const int rc = comm.api.AllReduce(slot, slot, 1, kNcclDouble, kNcclSum, comm.comm, stream);
+      REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclAllReduce: ") + comm.api.GetErrorString(rc));
+      HIP_CHECK(hipMemcpyAsync(v, slot, sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } else
+      comm.rfn(comm.ctx, v, 1);
+  }
   void check_persistent()
   {
     if (!(h_perr && *h_perr)) return;
+    if (persist_defer_throw) return;                         // multi-rank solve in flight: decided jointly in with_persist_retry
     *h_perr = 0;
     persist = 0;                                             // later solves of this handle sweep launch by launch
     persist_tripped = true;
@@ -2337,7 +2389,16 @@ struct gmg_solver {
     for (int it = 0; it < S.niter; ++it) {
       exchange(l, r);                                      // consistent!(b) PatchSolvers.jl:231 (no-op on one GPU)
       patch_precond(L, S, r, S.omega, true, L.dx, x);      // :91-93
+      // profiled level: HIP events around the operator mat-vec of every prof_stride-th patch sweep (r -= A dx, the wide-row kernel)
+      const bool prof = (l == prof_level) && (prof_seq++ % (uint64_t)prof_stride == 0) && prof_used + 2 <= prof_ev.size();
+      if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
       apply_A_sub(l, L.dx, r);                             // :94-95 (exchanges dx itself: consistent!(x), PatchSolvers.jl:256)
+      if (prof) {
+        HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
+        prof_w[prof_used / 2] = 1;
+        prof_used += 2;
+        prof_patch = true;
+      }
     }
     return r;
   }
@@ -2507,20 +2568,110 @@ struct gmg_solver {
   }
 
   // ---- staging for host-memory callers -----------------------------------------
+  // The Julia binding hands over Vector{Float64} (GMG_MEM_HOST): b and the initial guess go up, x comes back -- 24 N bytes per solve
+  // over PCIe.  Three things keep that near the link rate: (i) caller arrays registered once (gmg_host_register: page-locked and
+  // mapped, the pattern of ext/GridapPETScExt/PETScCaches.jl:23-36, which pins the exact x / b objects) move by DMA straight from /
+  // into the caller's pages; (ii) unregistered (pageable) arrays are pipelined through two page-locked chunks of the library's own
+  // (the memcpy of chunk k+1 overlaps the DMA of chunk k) instead of the runtime's synchronous pageable path; (iii) with the option
+  // GMG_X0_ZERO the initial guess is not uploaded at all (hipMemsetAsync) -- the reference CG reads x (CGSolvers.jl:79), so that is
+  // an opt-in for callers that know x0 = 0.
+  struct HostReg { const char *base; size_t bytes; };
+  std::vector<HostReg> host_regs;
+  bool host_registered(const void *p, size_t bytes) const
+  {
+    const char *c = static_cast<const char *>(p);
+    for (const HostReg &r : host_regs)
+      if (c >= r.base && c + bytes <= r.base + r.bytes) return true;
+    return false;
+  }
+  char *h_chunk[2] = {nullptr, nullptr};     // page-locked staging chunks (pageable callers)
+  hipEvent_t ev_chunk[2] = {nullptr, nullptr};
+  size_t chunk_bytes = 0;
+  int64_t host_bytes_up = 0, host_bytes_down = 0;   // bytes moved for host-memory callers since gmg_create (gmg_get_host_io_stats)
+  void ensure_chunks()
+  {
+    const size_t want = (size_t)std::max(1 << 16, opt_int("GMG_HOST_CHUNK_BYTES", 4 << 20));
+    if (h_chunk[0] && chunk_bytes == want) return;
+    for (int i = 0; i < 2; ++i) {
+      if (h_chunk[i]) (void)hipHostFree(h_chunk[i]);
+      HIP_CHECK(hipHostMalloc((void **)&h_chunk[i], want, hipHostMallocDefault));
+      if (!ev_chunk[i]) HIP_CHECK(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming));
+    }
+    chunk_bytes = want;
+  }
+  void h2d(double *dev, const double *host, int64_t n)
+  {
+    const size_t bytes = sizeof(double) * (size_t)n;
+    host_bytes_up += (int64_t)bytes;
+    if (host_registered(host, bytes) || bytes <= (1 << 16)) {
+      HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream));
+      return;
+    }
+    ensure_chunks();
+    const char *src = reinterpret_cast<const char *>(host);
+    char *dst = reinterpret_cast<char *>(dev);
+    int k = 0;
+    for (size_t off = 0; off < bytes; off += chunk_bytes, k ^= 1) {
+      const size_t len = std::min(chunk_bytes, bytes - off);
+      HIP_CHECK(hipEventSynchronize(ev_chunk[k]));           // the DMA that last read this chunk has finished
+      std::memcpy(h_chunk[k], src + off, len);
+      HIP_CHECK(hipMemcpyAsync(dst + off, h_chunk[k], len, hipMemcpyHostToDevice, stream));
+      HIP_CHECK(hipEventRecord(ev_chunk[k], stream));
+    }
+  }
+  // blocks until the data is in the caller's array
+  void d2h(double *host, const double *dev, int64_t n)
+  {
+    const size_t bytes = sizeof(double) * (size_t)n;
+    host_bytes_down += (int64_t)bytes;
+    if (host_registered(host, bytes) || bytes <= (1 << 16)) {
+      HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      return;
+    }
+    ensure_chunks();
+    char *dst = reinterpret_cast<char *>(host);
+    const char *src = reinterpret_cast<const char *>(dev);
+    const size_t nchunks = (bytes + chunk_bytes - 1) / chunk_bytes;
+    for (size_t c = 0; c < nchunks + 1; ++c) {               // DMA of chunk c is in flight while chunk c-1 is copied out
+      if (c < nchunks) {
+        const size_t off = c * chunk_bytes, len = std::min(chunk_bytes, bytes - off);
+        // (chunk buffer c & 1 was drained when chunk c-2 was copied out, one iteration ago)
+        HIP_CHECK(hipMemcpyAsync(h_chunk[c & 1], src + off, len, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipEventRecord(ev_chunk[c & 1], stream));
+      }
+      if (c >= 1) {
+        const size_t off = (c - 1) * chunk_bytes, len = std::min(chunk_bytes, bytes - off);
+        HIP_CHECK(hipEventSynchronize(ev_chunk[(c - 1) & 1]));
+        std::memcpy(dst + off, h_chunk[(c - 1) & 1], len);
+      }
+    }
+  }
   const double *in_vec(const double *p, int64_t n, int memspace, double *stage)
   {
     if (memspace == GMG_MEM_DEVICE) return p;
-    HIP_CHECK(hipMemcpyAsync(stage, p, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
+    h2d(stage, p, n);
     return stage;
+  }
+  // the initial guess of a Krylov / :solver call -> dx (a no-op for single-GPU device callers, whose x is used in place)
+  void in_guess(double *dx, const double *x_user, int64_t n, int memspace)
+  {
+    const bool host = memspace == GMG_MEM_HOST;
+    if (!host && dx == x_user) {
+      if (opt_int("GMG_X0_ZERO", 0)) zero(dx, n);
+      return;
+    }
+    if (opt_int("GMG_X0_ZERO", 0)) { zero(dx, n); return; }
+    if (host) h2d(dx, x_user, n);
+    else HIP_CHECK(hipMemcpyAsync(dx, x_user, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
   }
   void out_vec(double *user, const double *dev, int64_t n, int memspace)
   {
     if (memspace == GMG_MEM_DEVICE) {
       if (user != dev) copy(user, dev, n);
-    } else {
-      HIP_CHECK(hipMemcpyAsync(user, dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
-    }
-    HIP_CHECK(hipStreamSynchronize(stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    } else
+      d2h(user, dev, n);
   }
   double *scratch_vec(size_t i, int64_t n)
   {
@@ -2531,52 +2682,52 @@ struct gmg_solver {
 
   void read_tuning()
   {
-    xcd_remap = env_int("GMG_XCD_REMAP", 1);   // XCD-contiguous row ranges: each L2 sees 1/8 of the gathered vector (pattern kernels: -6 % per solve)
-    lanes_override = env_int("GMG_LANES_LOG2", -1);
-    one_gather_sweep = env_int("GMG_ONE_GATHER", 1);
-    use_sell = env_int("GMG_SELL", 1);
-    use_idx16 = env_int("GMG_IDX16", 1);
-    use_vdict = env_int("GMG_VDICT", 1);
-    sell_un = env_int("GMG_SELL_UN", 6);
-    sell_block = std::min(256, env_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
-    if (const char *mp = std::getenv("GMG_SELL_MAXPAD")) sell_maxpad = std::atof(mp);
-    nt_loads = env_int("GMG_NT", 1);
-    nt_rowwise = env_int("GMG_NT_ROWWISE", 1);
-    xcd_remap_big = env_int("GMG_XCD_REMAP_BIG", 0);
-    big_rows = (int64_t)env_int("GMG_BIG_ROWS", 4000000);
-    sell_defer = env_int("GMG_SELL_DEFER", 1);
-    use_pattern = env_int("GMG_PATTERN", 1);
-    pat_un = env_int("GMG_PAT_UN", 9);
-    pat_wgs = std::max(1, env_int("GMG_PAT_WGS", 2048));
-    pat_shared = env_int("GMG_PAT_SHARED", 1);
-    halo_fuse_pack = env_int("GMG_HALO_FUSE_PACK", 1);
-    prof_stride = std::max(1, env_int("GMG_PROF_STRIDE", 8));
-    pat_defer = env_int("GMG_PAT_DEFER", 1);
-    pat_rsweep = env_int("GMG_PAT_RSWEEP", 1);
-    persist = env_int("GMG_PERSIST", 1);
+    xcd_remap = opt_int("GMG_XCD_REMAP", 1);   // XCD-contiguous row ranges: each L2 sees 1/8 of the gathered vector (pattern kernels: -6 % per solve)
+    lanes_override = opt_int("GMG_LANES_LOG2", -1);
+    one_gather_sweep = opt_int("GMG_ONE_GATHER", 1);
+    use_sell = opt_int("GMG_SELL", 1);
+    use_idx16 = opt_int("GMG_IDX16", 1);
+    use_vdict = opt_int("GMG_VDICT", 1);
+    sell_un = opt_int("GMG_SELL_UN", 6);
+    sell_block = std::min(256, opt_int("GMG_SELL_BLOCK", 0)) / 64 * 64;
+    sell_maxpad = opt_num("GMG_SELL_MAXPAD", 1.25);
+    nt_loads = opt_int("GMG_NT", 1);
+    nt_rowwise = opt_int("GMG_NT_ROWWISE", 1);
+    xcd_remap_big = opt_int("GMG_XCD_REMAP_BIG", 0);
+    big_rows = (int64_t)opt_int("GMG_BIG_ROWS", 4000000);
+    sell_defer = opt_int("GMG_SELL_DEFER", 1);
+    use_pattern = opt_int("GMG_PATTERN", 1);
+    pat_un = opt_int("GMG_PAT_UN", 9);
+    pat_wgs = std::max(1, opt_int("GMG_PAT_WGS", 2048));
+    pat_shared = opt_int("GMG_PAT_SHARED", 1);
+    halo_fuse_pack = opt_int("GMG_HALO_FUSE_PACK", 1);
+    prof_stride = std::max(1, opt_int("GMG_PROF_STRIDE", 8));
+    pat_defer = opt_int("GMG_PAT_DEFER", 1);
+    pat_rsweep = opt_int("GMG_PAT_RSWEEP", 1);
+    persist = opt_int("GMG_PERSIST", 1);
     // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
     // could keep each other from becoming fully resident, so they are off unless asked for
-    if (comm.kind == COMM_HOST && !env_int("GMG_PERSIST_SHARED", 0)) persist = 0;
+    if (comm.kind == COMM_HOST && !opt_int("GMG_PERSIST_SHARED", 0)) persist = 0;
     // release / acquire on the progress words costs 2.4 us per sweep (43 -> 68 us per pass of 10 on 63^3 rows, profiles/r03_mb_smooth.txt)
     // and adds nothing the explicit ordering does not already give: every datum that crosses workgroups moves with agent-scope
     // (sc1) atomics, the publishing lane stores the word after the workgroup's s_waitcnt vmcnt(0) + barrier, the polling lanes read
     // it with agent-scope loads and a barrier precedes the gathers.  Off by default, kept as a switch.
-    persist_fenced = env_int("GMG_PERSIST_FENCED", 0);
-    pat_strict = env_int("GMG_PAT_STRICT", 1);
-    pat_wide = env_int("GMG_PAT_WIDE", 1);
-    pat_tile = env_int("GMG_PAT_TILE", 1);
-    pat_tile_rows = env_int("GMG_PAT_TILE_ROWS", 6000000);
-    gj_mfma = env_int("GMG_GJ_MFMA", 1);
-    persist_max_slices = env_int("GMG_PERSIST_MAX_SLICES", 0);
-    pat_coded_min_rows = env_int("GMG_PAT_CODED_MIN_ROWS", 500000);
-    pat_emit = env_int("GMG_PAT_EMIT", 1);
-    pat_small_wpb = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB", 4)));
-    pat_small_wpb2 = std::min(4, std::max(1, env_int("GMG_PAT_SMALL_WPB2", 2)));
-    pat_dinv = env_int("GMG_PAT_DINV", 1);
-    pat_rb = env_int("GMG_PAT_RB", 3); pat_rb = pat_rb >= 9 ? 9 : (pat_rb <= 1 ? 1 : 3);
-    pat_batched = env_int("GMG_PAT_BATCHED", 1);
-    use_opattern = env_int("GMG_OPATTERN", 1);
-    pat_nb = std::min(2, std::max(0, env_int("GMG_PAT_NB", 0)));
+    persist_fenced = opt_int("GMG_PERSIST_FENCED", 0);
+    pat_strict = opt_int("GMG_PAT_STRICT", 1);
+    pat_wide = opt_int("GMG_PAT_WIDE", 1);
+    pat_tile = opt_int("GMG_PAT_TILE", 1);
+    pat_tile_rows = opt_int("GMG_PAT_TILE_ROWS", 6000000);
+    gj_mfma = opt_int("GMG_GJ_MFMA", 1);
+    persist_max_slices = opt_int("GMG_PERSIST_MAX_SLICES", 0);
+    pat_coded_min_rows = opt_int("GMG_PAT_CODED_MIN_ROWS", 500000);
+    pat_emit = opt_int("GMG_PAT_EMIT", 1);
+    pat_small_wpb = std::min(4, std::max(1, opt_int("GMG_PAT_SMALL_WPB", 4)));
+    pat_small_wpb2 = std::min(4, std::max(1, opt_int("GMG_PAT_SMALL_WPB2", 2)));
+    pat_dinv = opt_int("GMG_PAT_DINV", 1);
+    pat_rb = opt_int("GMG_PAT_RB", 3); pat_rb = pat_rb >= 9 ? 9 : (pat_rb <= 1 ? 1 : 3);
+    pat_batched = opt_int("GMG_PAT_BATCHED", 1);
+    use_opattern = opt_int("GMG_OPATTERN", 1);
+    pat_nb = std::min(2, std::max(0, opt_int("GMG_PAT_NB", 0)));
     tile = kTile;
   }
   // inv_diag = 1 ./ diag(A) (JacobiLinearSolvers.jl:20-23); needs the CSR stream of A (before drop_csr_stream)
@@ -2827,7 +2978,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
 {
   REQUIRE(S.tab, GMG_ERR_INVALID, "patch tables missing");
   const Smoother::Tables &T = *S.tab;
-  const bool bp_timing = env_int("GMG_SETUP_TIMING", 0) != 0;
+  const bool bp_timing = opt_int("GMG_SETUP_TIMING", 0) != 0;
   auto bp_last = std::chrono::steady_clock::now();
   auto bp_lap = [&](const char *what) {
     if (!bp_timing) return;
@@ -2932,7 +3083,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
   const int pivoting = (S.patch_kind == GMG_PATCH_LU) ? 1 : 0;
   const size_t per = (size_t)max_np * max_np;
   const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(npatch, (int64_t)((512u << 20) / (per * sizeof(double)))));
-  const bool want_dedup = env_int("GMG_PATCH_DEDUP", 1) && max_np <= 32 && npatch >= 64;
+  const bool want_dedup = opt_int("GMG_PATCH_DEDUP", 1) && max_np <= 32 && npatch >= 64;
   int *d_nsing = dalloc<int>(1);
   S.d_boff = upload(boff);
   int64_t tmp_elems = 1;
@@ -3232,7 +3383,7 @@ void gmg_solver::build_patch(Level &L, Smoother &S, bool blocks_only)
     if (bp_timing) std::fprintf(stderr, "[gmg_setup]   patch tables: %lld source signatures, %lld distinct inverse blocks of %lld patches\n", (long long)ngrp, (long long)nu, (long long)npatch);
     return true;
   };
-  const bool by_source = want_dedup && from_pattern && wave_kernel && env_int("GMG_PATCH_SOURCE_DEDUP", 1);
+  const bool by_source = want_dedup && from_pattern && wave_kernel && opt_int("GMG_PATCH_SOURCE_DEDUP", 1);
   bp_lap("block offsets");
   bp_sub = std::chrono::steady_clock::now();
   if (!(by_source && build_blocks_by_source()))
@@ -3281,11 +3432,11 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   S.use_M = false;
   const Smoother::Tables &T = *S.tab;
   const int64_t npatch = S.npatch, n = L.n;
-  if (!env_int("GMG_PATCH_OPERATOR", 1) || !S.dedup || !T.pcol.empty() || (comm.nranks > 1 && L.halo.present) || !use_pattern || !use_sell) return;
+  if (!opt_int("GMG_PATCH_OPERATOR", 1) || !S.dedup || !T.pcol.empty() || (comm.nranks > 1 && L.halo.present) || !use_pattern || !use_sell) return;
   if (npatch < 64 || n < 64 || n >= (int64_t)(1 << 28) || S.max_np > 32 || S.h_ublock.size() != (size_t)npatch) return;
   const auto t_begin = std::chrono::steady_clock::now();
   auto t_sub = t_begin;
-  const bool po_timing = env_int("GMG_SETUP_TIMING", 0) != 0;
+  const bool po_timing = opt_int("GMG_SETUP_TIMING", 0) != 0;
   auto sub = [&](const char *what) { if (!po_timing) return; const auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[gmg_setup]     patch operator: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_sub).count()); t_sub = now; };
   const int64_t ne = T.pptr[npatch];
   if (ne >= (int64_t)INT32_MAX) return;
@@ -3473,7 +3624,7 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   release(S.d_contrib, (size_t)ne + 1);
   if (S.d_isoff) { release(S.d_isoff, (size_t)S.n_isoff); release(S.d_isinc, (size_t)S.n_isinc); }
   if (S.d_iptr) { release(S.d_iptr, (size_t)n + 1); release(S.d_inc, (size_t)ne); }
-  if (env_int("GMG_SETUP_TIMING", 0))
+  if (opt_int("GMG_SETUP_TIMING", 0))
     std::fprintf(stderr, "[gmg_setup] patch operator: %lld rows, %zu shapes, %zu distinct rows, %lld nnz, %.1f ms\n", (long long)n, shape_rep.size(),
                  sig_rep.size(), (long long)P.nnz, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 }
@@ -3622,12 +3773,12 @@ double *gmg_solver::build_dense_inverse(const HostCSR &A, const std::string &wha
   const int n = (int)A.nrows;
   // Small matrices: exact banded LU with partial pivoting on the host (O(n^2 * bandwidth)).
   // Large ones: blocked Gauss-Jordan on the device (no pivoting; result verified below).
-  if (n > env_int("GMG_COARSE_HOST_MAX", 1500)) {
+  if (n > opt_int("GMG_COARSE_HOST_MAX", 1500)) {
     REQUIRE((double)n * n * 8.0 <= 64.0e9, GMG_ERR_UNSUPPORTED,
             what + " has " + std::to_string(n) + " dofs: its dense inverse would not fit; add multigrid levels");
     // the device inversion does not pivot and verifies its result: a matrix that needs pivoting is rejected there -- within
     // reach of the host's pivoted banded LU (seconds up to ~6000 dofs) take that instead of failing the setup
-    if (n > env_int("GMG_COARSE_HOST_FALLBACK_MAX", 6000)) return build_coarse_device(A, what);
+    if (n > opt_int("GMG_COARSE_HOST_FALLBACK_MAX", 6000)) return build_coarse_device(A, what);
     try {
       return build_coarse_device(A, what);
     } catch (const GmgError &e) {
@@ -3664,7 +3815,7 @@ double *gmg_solver::build_coarse_device(const HostCSR &A, const std::string &wha
   const int64_t bytes0 = dev_bytes;
   // large levels: 64-wide panels on a padded leading dimension (half the passes over the matrix, aligned 128-byte row
   // segments), compacted into the n x n result at the end; small ones: 32-wide panels in place
-  const bool wide = gj_mfma && n >= env_int("GMG_GJ_WIDE_MIN", 4096);
+  const bool wide = gj_mfma && n >= opt_int("GMG_GJ_WIDE_MIN", 4096);
   const int64_t lda = wide ? (((int64_t)n + 127) / 128) * 128 : n;        // whole tiles: the update kernel loads unconditionally
   const int64_t nr = wide ? (((int64_t)n + 127) / 128) * 128 : n;
   double *D = dalloc<double>((size_t)n * n);
@@ -3740,7 +3891,7 @@ void gmg_solver::setup()
   free_all();
   read_tuning();
   // GMG_SETUP_TIMING=1: per-phase wall times of the numerical setup on stderr
-  const bool timing = env_int("GMG_SETUP_TIMING", 0) != 0;
+  const bool timing = opt_int("GMG_SETUP_TIMING", 0) != 0;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char *what, int l) {
     if (!timing) return;
@@ -3954,7 +4105,7 @@ void gmg_solver::setup()
 // themselves, so those fall back to a full setup.  Results are bit-identical to a fresh setup with the new values (tested).
 bool gmg_solver::can_refresh() const
 {
-  if (!was_setup || structure_dirty || comm.nranks != 1 || !env_int("GMG_REFRESH", 1)) return false;
+  if (!was_setup || structure_dirty || comm.nranks != 1 || !opt_int("GMG_REFRESH", 1)) return false;
   for (int l = 0; l < nlev; ++l) {
     const Level &L = lev[l];
     if (!L.values_dirty) continue;
@@ -3969,7 +4120,7 @@ bool gmg_solver::can_refresh() const
 void gmg_solver::refresh_values()
 {
   HIP_CHECK(hipSetDevice(device));
-  const bool timing = env_int("GMG_SETUP_TIMING", 0) != 0;
+  const bool timing = opt_int("GMG_SETUP_TIMING", 0) != 0;
   const auto t_begin = std::chrono::steady_clock::now();
   int *d_nzero = nullptr;
   HIP_CHECK(hipMalloc((void **)&d_nzero, sizeof(int)));
@@ -4180,6 +4331,11 @@ int gmg_destroy(gmg_handle_t h)
   for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
   if (h->h_scalars) (void)hipHostFree(h->h_scalars);
   if (h->h_perr) (void)hipHostFree(h->h_perr);
+  for (const auto &r : h->host_regs) (void)hipHostUnregister(const_cast<char *>(r.base));   // the caller's pages are unpinned, never freed
+  for (int i = 0; i < 2; ++i) {
+    if (h->h_chunk[i]) (void)hipHostFree(h->h_chunk[i]);
+    if (h->ev_chunk[i]) (void)hipEventDestroy(h->ev_chunk[i]);
+  }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return GMG_OK;
@@ -4492,6 +4648,110 @@ int gmg_get_coarse_log(gmg_handle_t h, gmg_result *res)
   });
 }
 
+// ---- per-handle policy options --------------------------------------------------------------------------------------------
+namespace {
+// every switch the library reads; `live` options take effect at the next call, the others at the next gmg_setup
+struct OptionKey { const char *name; bool live; };
+const OptionKey kOptionKeys[] = {
+  {"GMG_BIG_ROWS", false}, {"GMG_COARSE_HOST_FALLBACK_MAX", false}, {"GMG_COARSE_HOST_MAX", false}, {"GMG_COARSE_AUTO_CG_MIN", false},
+  {"GMG_DBG_NOGATHER", false}, {"GMG_EAGER", true}, {"GMG_EAGER_MIN_ROWS", true}, {"GMG_FORCE_PTR64", false}, {"GMG_GJ_MFMA", false}, {"GMG_GJ_WIDE_MIN", false},
+  {"GMG_HALO_FUSE_PACK", false}, {"GMG_HOST_ASYNC", false}, {"GMG_IDX16", false}, {"GMG_LANES_LOG2", false}, {"GMG_NT", false},
+  {"GMG_NT_ROWWISE", false}, {"GMG_ONE_GATHER", false}, {"GMG_OPATTERN", false}, {"GMG_OVERLAP", false}, {"GMG_PATCH_DEDUP", false},
+  {"GMG_PATCH_OPERATOR", false}, {"GMG_PATCH_SOURCE_DEDUP", false}, {"GMG_PATTERN", false}, {"GMG_PAT_BATCHED", false},
+  {"GMG_PAT_CODED_MIN_ROWS", false}, {"GMG_PAT_DEFER", false}, {"GMG_PAT_DINV", false}, {"GMG_PAT_EMIT", false}, {"GMG_PAT_NB", false},
+  {"GMG_PAT_RB", false}, {"GMG_PAT_RSWEEP", false}, {"GMG_PAT_SHARED", false}, {"GMG_PAT_SMALL_WPB", false}, {"GMG_PAT_SMALL_WPB2", false},
+  {"GMG_PAT_STRICT", false}, {"GMG_PAT_TILE", false}, {"GMG_PAT_TILE_LDS", false}, {"GMG_PAT_TILE_MIN", false}, {"GMG_PAT_TILE_ROWS", false},
+  {"GMG_PAT_TILE_T", false}, {"GMG_PAT_UN", false}, {"GMG_PAT_WGS", false}, {"GMG_PAT_WIDE", false}, {"GMG_PAT_WIDE_LDS", false},
+  {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
+  {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
+  {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false},
+  {"GMG_PERSIST_FORCE_TIMEOUT", true},
+};
+// "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option
+const OptionKey *find_option(const char *key)
+{
+  if (!key) return nullptr;
+  std::string k(key);
+  for (auto &c : k) c = (char)std::toupper((unsigned char)c);
+  if (k.rfind("GMG_", 0) != 0) k = "GMG_" + k;
+  for (const OptionKey &o : kOptionKeys)
+    if (k == o.name) return &o;
+  return nullptr;
+}
+} // namespace
+
+int gmg_set_option(gmg_handle_t h, const char *key, double value)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    const OptionKey *o = find_option(key);
+    REQUIRE(o, GMG_ERR_INVALID, std::string("unknown option '") + (key ? key : "(null)") + "' (see the option table in include/gmg_amd.h)");
+    auto it = h->options.find(o->name);
+    if (it != h->options.end() && it->second == value) return;
+    h->options[o->name] = value;
+    if (!o->live) h->touch();                                // layouts / schedules are chosen at gmg_setup
+  });
+}
+
+int gmg_get_option(gmg_handle_t h, const char *key, double *value, int *source)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && value, GMG_ERR_INVALID, "null argument");
+    const OptionKey *o = find_option(key);
+    REQUIRE(o, GMG_ERR_INVALID, std::string("unknown option '") + (key ? key : "(null)") + "'");
+    const char *e = std::getenv(o->name);
+    const bool from_env = e && *e;
+    const bool from_handle = h->options.count(o->name) != 0;
+    *value = h->opt_num(o->name, std::nan(""));              // NaN: the library's built-in default applies
+    if (source) *source = from_env ? 2 : (from_handle ? 1 : 0);
+  });
+}
+
+int gmg_host_register(gmg_handle_t h, const void *ptr, int64_t nbytes)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && ptr && nbytes > 0, GMG_ERR_INVALID, "gmg_host_register: null handle / pointer or empty range");
+    if (h->host_registered(ptr, (size_t)nbytes)) return;
+    HIP_CHECK(hipHostRegister(const_cast<void *>(ptr), (size_t)nbytes, hipHostRegisterDefault));
+    h->host_regs.push_back({static_cast<const char *>(ptr), (size_t)nbytes});
+  });
+}
+
+int gmg_host_unregister(gmg_handle_t h, const void *ptr)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && ptr, GMG_ERR_INVALID, "gmg_host_unregister: null handle / pointer");
+    for (size_t i = 0; i < h->host_regs.size(); ++i)
+      if (h->host_regs[i].base == static_cast<const char *>(ptr)) {
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(hipHostUnregister(const_cast<void *>(ptr)));
+        h->host_regs.erase(h->host_regs.begin() + (long)i);
+        return;
+      }
+    throw GmgError{GMG_ERR_INVALID, "gmg_host_unregister: this range was not registered with this handle (pass the base pointer given to gmg_host_register)"};
+  });
+}
+
+int gmg_get_host_io_stats(gmg_handle_t h, int64_t *bytes_up, int64_t *bytes_down, int64_t *nregistered)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    if (bytes_up) *bytes_up = h->host_bytes_up;
+    if (bytes_down) *bytes_down = h->host_bytes_down;
+    if (nregistered) *nregistered = (int64_t)h->host_regs.size();
+  });
+}
+
+int gmg_get_persist_retries(gmg_handle_t h, int64_t *retries, int *persist_active)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    if (retries) *retries = h->persist_retries;
+    if (persist_active) *persist_active = h->persist;
+  });
+}
+
 int gmg_set_verbose(gmg_handle_t h, int verbose)
 {
   return guarded(h, [&] {
@@ -4522,13 +4782,12 @@ int gmg_apply(gmg_handle_t h, const double *b, double *x, int memspace, gmg_resu
   return guarded(h, [&] {
     check_ready(h);
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
-    h->with_persist_retry(x, h->lev[0].n, memspace, [&] {
+    h->with_persist_retry(x, h->lev[0].n, memspace, h->mode == GMG_MODE_PRECONDITIONER, [&] {
       const int64_t n = h->lev[0].n;
       const double *db = h->in_vec(b, n, memspace, h->st_b);
       const bool dist = h->comm.nranks > 1;
       double *dx = dist ? h->cg_x : ((memspace == GMG_MEM_DEVICE) ? x : h->st_x);
-      if (h->mode == GMG_MODE_SOLVER && (memspace == GMG_MEM_HOST || dist))
-        HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
+      if (h->mode == GMG_MODE_SOLVER) h->in_guess(dx, x, n, memspace);   // :preconditioner overwrites x with zeros first (GMGLinearSolvers.jl:619)
       const double last = h->gmg_solve_dev(dx, db, -1.0);
       h->out_vec(x, dx, n, memspace);
       h->log.export_to(res, hist, hist_cap, last);
@@ -4544,15 +4803,14 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
-    h->with_persist_retry(x, h->lev[0].n, memspace, [&] {
+    h->with_persist_retry(x, h->lev[0].n, memspace, false, [&] {
       gmg_solver &S = *h;
       Level &L0 = S.lev[0];
       const int64_t n = L0.n;
       const double *db = S.in_vec(b, n, memspace, S.st_b);
       const bool dist = S.comm.nranks > 1;
       double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
-      if (memspace == GMG_MEM_HOST || dist)
-        HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
+      S.in_guess(dx, x, n, memspace);                        // x = initial guess on entry (CGSolvers.jl:79)
       ConvLog log;
       log.configure(maxiter, atol, rtol);
       KrylovOps ops = S.level0_ops(use_precond);
@@ -4581,7 +4839,7 @@ int gmg_fgmres_solve_pl(gmg_handle_t h, const double *b, double *x, int memspace
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(m0 >= 1 && m_add >= 1 && maxiter >= 0, GMG_ERR_INVALID, "bad FGMRES sizes");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
-    h->with_persist_retry(x, h->lev[0].n, memspace, [&] {
+    h->with_persist_retry(x, h->lev[0].n, memspace, false, [&] {
       gmg_solver &S = *h;
       Level &L0 = S.lev[0];
       const int64_t n = L0.n;
@@ -4589,8 +4847,7 @@ int gmg_fgmres_solve_pl(gmg_handle_t h, const double *b, double *x, int memspace
       const bool dist = S.comm.nranks > 1;
       const int64_t nv = L0.nvec;
       double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
-      if (memspace == GMG_MEM_HOST || dist)
-        HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
+      S.in_guess(dx, x, n, memspace);                        // x = initial guess on entry (CGSolvers.jl:79)
       ConvLog log;
       log.configure(maxiter, atol, rtol);
       KrylovOps ops = S.level0_ops(use_precond);
@@ -4613,14 +4870,13 @@ int gmg_richardson_solve(gmg_handle_t h, const double *b, double *x, int memspac
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
-    h->with_persist_retry(x, h->lev[0].n, memspace, [&] {
+    h->with_persist_retry(x, h->lev[0].n, memspace, false, [&] {
       gmg_solver &S = *h;
       const int64_t n = S.lev[0].n;
       const double *db = S.in_vec(b, n, memspace, S.st_b);
       const bool dist = S.comm.nranks > 1;
       double *dx = dist ? S.cg_x : ((memspace == GMG_MEM_DEVICE) ? x : S.st_x);
-      if (memspace == GMG_MEM_HOST || dist)
-        HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)n, memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, S.stream));
+      S.in_guess(dx, x, n, memspace);                        // x = initial guess on entry (CGSolvers.jl:79)
       double *z = S.cg_z, *r = S.cg_r;
       ConvLog log;
       log.configure(maxiter, atol, rtol);
@@ -4680,12 +4936,17 @@ int gmg_smooth(gmg_handle_t h, int lev, int which, double *x, double *r, int mem
     REQUIRE(x && r, GMG_ERR_INVALID, "null vector");
     REQUIRE(which == GMG_PRE || which == GMG_POST, GMG_ERR_INVALID, "which must be GMG_PRE or GMG_POST");
     Level &L = h->lev[lev];
-    double *dx = memspace == GMG_MEM_DEVICE ? x : h->scratch_vec(0, h->lev[0].nvec);
-    if (memspace == GMG_MEM_HOST) HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * (size_t)L.n, hipMemcpyHostToDevice, h->stream));
-    const double *dr = h->in_vec(r, L.n, memspace, h->scratch_vec(1, h->lev[0].nvec));
-    double *rout = h->smooth(lev, which == GMG_PRE ? L.pre : L.post, dx, dr, false);
-    h->out_vec(r, rout, L.n, memspace);
-    h->out_vec(x, dx, L.n, memspace);
+    // a one-launch pass that times out writes nothing; x is saved, r is only replaced after the pass: the call is re-run per sweep
+    h->with_persist_retry(x, L.n, memspace, false, [&] {
+      double *dx = memspace == GMG_MEM_DEVICE ? x : h->scratch_vec(0, h->lev[0].nvec);
+      if (memspace == GMG_MEM_HOST) h->h2d(dx, x, L.n);
+      const double *dr = h->in_vec(r, L.n, memspace, h->scratch_vec(1, h->lev[0].nvec));
+      double *rout = h->smooth(lev, which == GMG_PRE ? L.pre : L.post, dx, dr, false);
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (!h->persist_defer_throw) h->check_persistent();   // before the caller's r is replaced
+      h->out_vec(r, rout, L.n, memspace);
+      h->out_vec(x, dx, L.n, memspace);
+    });
   });
 }
 
@@ -4769,7 +5030,7 @@ int gmg_comm_init_rccl(gmg_handle_t h, const char *rccl_path, const char *unique
     const int rc = h->comm.api.CommInitRank(&h->comm.comm, nranks, id, rank);
     REQUIRE(rc == 0, GMG_ERR_COMM, std::string("ncclCommInitRank: ") + h->comm.api.GetErrorString(rc));
     h->comm.kind = COMM_RCCL; h->comm.rank = rank; h->comm.nranks = nranks;
-    h->overlap = env_int("GMG_OVERLAP", 1);
+    h->overlap = h->opt_int("GMG_OVERLAP", 1);
     if (!h->comm_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
     if (!h->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
     if (!h->ev_done) HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
@@ -4893,8 +5154,8 @@ int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_f
     REQUIRE(h->comm.kind == COMM_NONE, GMG_ERR_STATE, "communicator already initialised");
     h->comm.kind = COMM_HOST; h->comm.rank = rank; h->comm.nranks = nranks;
     h->comm.xfn = xfn; h->comm.rfn = rfn; h->comm.ctx = ctx;
-    h->host_async = env_int("GMG_HOST_ASYNC", 0);
-    h->overlap = env_int("GMG_OVERLAP", 1);
+    h->host_async = h->opt_int("GMG_HOST_ASYNC", 0);
+    h->overlap = h->opt_int("GMG_OVERLAP", 1);
     if (h->host_async) {
       if (!h->comm_stream) HIP_CHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
       if (!h->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
@@ -4927,6 +5188,23 @@ int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, int64_t 
     static const int64_t none = 0;
     fill_plan(h->lev[lev].halo, h->comm, n_local - n_ghost, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr, rcv_idx ? rcv_idx : &none, depth);
     h->touch();
+  });
+}
+
+int gmg_get_comm_info(gmg_handle_t h, int *transport, int *rank, int *nranks, int *comm_count, int *comm_device)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    if (transport) *transport = h->comm.kind;
+    if (rank) *rank = h->comm.rank;
+    if (nranks) *nranks = h->comm.nranks;
+    int cnt = -1, dev = -1;
+    if (h->comm.kind == COMM_RCCL && h->comm.comm) {
+      if (h->comm.api.CommCount && h->comm.api.CommCount(h->comm.comm, &cnt) != 0) cnt = -1;
+      if (h->comm.api.CommCuDevice && h->comm.api.CommCuDevice(h->comm.comm, &dev) != 0) dev = -1;
+    }
+    if (comm_count) *comm_count = cnt;                       // what ncclCommCount says (-1: not an RCCL communicator)
+    if (comm_device) *comm_device = dev >= 0 ? dev : h->device;
   });
 }
 
@@ -4965,7 +5243,7 @@ int gmg_profile_enable(gmg_handle_t h, int lev, int enable)
     h->prof_level = lev;
     h->prof_used = 0;
     h->prof_ms = 0.0;
-    h->prof_launches = 0; h->prof_fused = 0;
+    h->prof_launches = 0; h->prof_fused = 0; h->prof_patch = false;
   });
 }
 
@@ -4994,6 +5272,13 @@ int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
     // r, D^-1, x, dx read / dx, x, Adx, r written as in RichardsonSmoothers.jl:91-95)
     out->alg_bytes = 12.0 * (double)out->nnz + 68.0 * (double)L.n;
     out->layout_bytes = h->sweep_layout_bytes(l);
+    if (h->prof_patch) {
+      // patch-smoother level: the timed kernel is the operator mat-vec r -= A dx (GMGLinearSolvers.jl:495-496 / RichardsonSmoothers.jl:94-95):
+      // B = 12 Z + 28 N; as stored in the row-pattern layout: pattern id 2 B + dx 8 B + r in / out 16 B per row
+      out->alg_bytes = 12.0 * (double)out->nnz + 28.0 * (double)L.n;
+      if (L.A.pat) out->layout_bytes = ((L.A.rowbase ? 6.0 : 2.0) + 24.0) * (double)L.n;
+      else out->layout_bytes = h->sweep_layout_bytes(l) - 32.0 * (double)L.n;
+    }
   });
 }
 

@@ -76,7 +76,7 @@ class DistributedGMG:
     def __init__(self, cells_per_rank, nlevels, rank, world, device_id=0, transport="rccl", group=None,
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
                  gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None,
-                 smoother="jacobi", depth=None, patch_tables=None, pcorr_tables=None, cells_global=None):
+                 smoother="jacobi", depth=None, patch_tables=None, pcorr_tables=None, cells_global=None, options=None):
         """smoother = "jacobi": Richardson(Jacobi, niter, omega); "patch": Richardson(PatchSolver, niter, omega) with the
         vertex-star patches OWNED by this rank (partition.local_vertex_star_patches) and caller-assembled patch matrices --
         a rank's local matrix has the owned rows only, so the blocks of patches reaching into ghost dofs come from the
@@ -110,6 +110,8 @@ class DistributedGMG:
         self.h = h
         self.transport = transport
         self._keep = []
+        for k, v in (options or {}).items():         # per-handle layout / schedule policy (gmg_set_option), before anything is set
+            abi.check(h, lib.gmg_set_option(h, str(k).encode(), float(v)))
         if world > 1:
             if transport == "rccl":
                 path = rccl_path().encode()
@@ -290,6 +292,18 @@ class DistributedGMG:
         a, b = C.c_int64(0), C.c_int64(0)
         abi.check(self.h, self._lib.gmg_get_comm_stats(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def sweep_signature(self, lev=0):
+        buf = C.create_string_buffer(256)
+        abi.check(self.h, self._lib.gmg_sweep_signature(self.h, lev, buf, 256))
+        return buf.value.decode()
+
+    def comm_info(self):
+        """what the handle communicates through (gmg_get_comm_info): transport, rank, ranks, ncclCommCount, HIP device"""
+        v = [C.c_int(0) for _ in range(5)]
+        abi.check(self.h, self._lib.gmg_get_comm_info(self.h, *[C.byref(x) for x in v]))
+        return dict(transport=("none", "rccl", "host")[v[0].value], rank=v[1].value, nranks=v[2].value, rccl_comm_count=v[3].value,
+                    device=v[4].value)
 
     def close(self):
         if getattr(self, "h", None):
@@ -488,16 +502,24 @@ def run_bench(args, rank, world, local_rank):
     layout_GBs = st["layout_bytes"] / (avg_ms * 1e-3) / 1e9 if st["launches"] else None
     setup_s, asm_s, rep_lvl = g.t_setup, g.t_assembly, int(g.local["rep_from"])
     grid_s, cg_s = "x".join(map(str, g.grid)), "x".join(map(str, g.cells_global))
+    # who really took part: what RCCL reports for the communicator, and the device every rank sits on
+    ci = g.comm_info()
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    mine = dict(rank=rank, local_rank=local_rank, device=ci["device"], rccl_comm_count=ci["rccl_comm_count"], name=props.name,
+                uuid=str(getattr(props, "uuid", "")), pci_bus_id=int(getattr(props, "pci_bus_id", -1)))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    sig = g.sweep_signature(0)
     out = {
         "metric": "DoFs/sec, CG+GMG V-cycle on 3D Poisson Q1",
         "value": n * D["steps"] / D["dt"], "unit": "DoFs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": D["dt"] / D["steps"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "headline_leg": "default",
-        "legs": "default (`value`, `roofline`): storage layout chosen by gmg_setup (row patterns on this constant-coefficient operator); "
-                "generic (`value_generic`, `roofline_generic`): the same partitioned problem with the 12 B/nnz stream SURVEY 8(d) models.  "
-                "The single-GPU figure to hold these against is `weak_scaling_ref` of the N = 1 line (the same per-GPU problem on one GPU).",
+        "legs": LEGS_NOTE,
+        "rccl_ranks": ci["rccl_comm_count"] if transport == "rccl" else 0,
+        "devices": everyone,
         "config": {
-            "workload": f"3D Poisson Q1, {args.cells}^3 cells per GPU on a {grid_s} GPU grid "
+            "workload": f"BASELINE configs[3] shape: 3D Poisson Q1, {args.cells}^3 cells per GPU on a {grid_s} GPU grid "
                         f"(global {cg_s} cells on (0,{'x'.join(str(int(v)) for v in lengths)}): cubic cells), {nlev}-level GMG V-cycle, "
                         f"Richardson(Jacobi,10,2/3), CG rtol={rtol:g}, rhs = u=x1+x2 Dirichlet lift; row partition + "
                         f"halo exchange + scalar all-reduce ({transport}; {overlap_note})",
@@ -507,32 +529,26 @@ def run_bench(args, rank, world, local_rank):
             "halo_exchanges_per_solve": D["exchanges_per_solve"], "allreduces_per_solve": D["allreduces_per_solve"],
             "setup_s": setup_s, "assembly_s": asm_s,
         },
-        # the local operators are constant-coefficient here, so the own x own kernel runs the row-pattern layout: its honest
-        # figure is bytes-actually-moved / time (layout_bytes), not the 12 B/nnz model (which gives > 1; see `roofline_generic`)
-        "roofline": {"leg": "default", "leg_value": n * D["steps"] / D["dt"], "leg_ms_per_step": D["dt"] / D["steps"] * 1e3,
-                     "bound": "hbm", "kernel": "fused Richardson-Jacobi sweep, own x own part (rank 0, finest level)",
-                     "achieved": layout_GBs, "peak": 8000.0, "unit": "GB/s",
-                     "frac": (layout_GBs / 8000.0) if layout_GBs else None, "traffic": None,
-                     "bytes_model": "gmg_kernel_stats.layout_bytes (matrix stream as stored + row-wise vectors, each once)",
-                     "bytes_per_launch": st["layout_bytes"], "model_12B_per_nnz_GBs": achieved,
-                     "avg_launch_ms": avg_ms, "launches_timed": st["launches"]},
+        # default leg: the local operators are constant-coefficient here, so the own x own kernel runs the row-pattern layout; its
+        # honest figure is bytes-actually-moved / time (layout_bytes) -- the 12 B/nnz model describes the generic leg (`roofline`)
+        "roofline_compressed": {"leg": "default", "leg_value": n * D["steps"] / D["dt"], "leg_ms_per_step": D["dt"] / D["steps"] * 1e3,
+                                "pairs_with": "value / ms_per_step",
+                                "bound": "hbm", "kernel": "fused Richardson-Jacobi sweep, own x own part (rank 0, finest level)", "sweep_signature": sig,
+                                "achieved": layout_GBs, "peak": 8000.0, "unit": "GB/s",
+                                "frac": (layout_GBs / 8000.0) if layout_GBs else None, "traffic": None,
+                                "bytes_model": "gmg_kernel_stats.layout_bytes (matrix stream as stored + row-wise vectors, each once)",
+                                "bytes_per_launch": st["layout_bytes"], "model_12B_per_nnz_GBs": achieved,
+                                "avg_launch_ms": avg_ms, "launches_timed": st["launches"]},
     }
     # ---- generic leg: the same partitioned problem on the plain 12 B/nnz stream (what SURVEY 8(d)'s byte model describes) ----
     if not getattr(args, "no_generic", False):
         g.close()
-        saved = {k: os.environ.get(k) for k in GENERIC_ENV}
-        os.environ.update(GENERIC_ENV)
         gg = None
         try:
-            gg = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport=transport, group=group, lengths=lengths, rep_from=rep_from, depth=depths)
+            gg = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport=transport, group=group, lengths=lengths, rep_from=rep_from,
+                                depth=depths, options=GENERIC_OPTIONS)
         except Exception as e:
             err = e
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
         if all_ok(gg is not None):
             G = timed(gg, max(2, args.steps // 3), 1)
             stg = G["st"]
@@ -540,22 +556,31 @@ def run_bench(args, rank, world, local_rank):
             out["value_generic"] = n * G["steps"] / G["dt"]
             out["ms_per_step_generic"] = G["dt"] / G["steps"] * 1e3
             out["config"]["cg_iterations_generic"] = G["iters"]
-            out["roofline_generic"] = {"leg": "generic", "leg_value": out["value_generic"], "leg_ms_per_step": out["ms_per_step_generic"],
-                                       "bound": "hbm", "kernel": "sell_kernel<EPI_SWEEP,ONEG> own x own part (rank 0, finest level), 12 B/nnz (col,val) stream",
-                                       "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": (ach / 8000.0) if ach else None, "traffic": None,
-                                       "bytes_model": "SURVEY 8(d): B_sweep = 12 Z + 68 N on this rank's rows", "bytes_per_launch": stg["alg_bytes"],
-                                       "avg_launch_ms": G["avg_ms"], "launches_timed": stg["launches"]}
+            out["roofline"] = {"leg": "generic", "leg_value": out["value_generic"], "leg_ms_per_step": out["ms_per_step_generic"],
+                               "pairs_with": "value_generic / ms_per_step_generic",
+                               "bound": "hbm", "kernel": "sell_kernel<EPI_SWEEP,ONEG> own x own part (rank 0, finest level), 12 B/nnz (col,val) stream",
+                               "sweep_signature": gg.sweep_signature(0),
+                               "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": (ach / 8000.0) if ach else None, "traffic": None,
+                               "bytes_model": "SURVEY 8(d): B_sweep = 12 Z + 68 N on this rank's rows", "bytes_per_launch": stg["alg_bytes"],
+                               "avg_launch_ms": G["avg_ms"], "launches_timed": stg["launches"]}
             gg.close()
         else:
             if gg is not None:
                 gg.close()
-            out["roofline_generic"] = {"error": f"generic leg could not be set up on every rank ({err})"}
+            out["roofline"] = {"leg": "generic", "error": f"generic leg could not be set up on every rank ({err})"}
     else:
         g.close()
+        out["roofline"] = {"leg": "generic", "skipped": "--no-generic"}
     return out
 
 
-GENERIC_ENV = {"GMG_VDICT": "0", "GMG_IDX16": "0", "GMG_PATTERN": "0", "GMG_OPATTERN": "0"}
+# the generic (12 B/nnz) leg: every structure-exploiting storage layout off -- per-handle options (gmg_set_option), not environment
+GENERIC_OPTIONS = {"vdict": 0, "idx16": 0, "pattern": 0, "opattern": 0}
+LEGS_NOTE = ("same key <-> leg mapping at every --gpus N: default leg (the product as shipped: gmg_setup picks the storage layout) = `value`, "
+             "`ms_per_step`, `roofline_compressed`; generic leg (every structure-exploiting layout off: the 12 B/nnz (col,val) stream SURVEY 8(d)'s "
+             "byte model describes) = `value_generic`, `ms_per_step_generic`, `roofline`.  N = 1 runs BASELINE configs[1] (128^3) and carries the "
+             "per-GPU problem of the N > 1 runs on one GPU as `weak_anchor_value` / `weak_scaling_ref`; N > 1 runs 288^3 cells per GPU: hold "
+             "value / N against weak_anchor_value, never against the N = 1 `value`.")
 
 
 class DistributedBlockSolver:

@@ -155,7 +155,7 @@ class GMGLinearSolver:
 
     def __init__(self, smatrices, interp, restrict=None, pre_smoothers=None, post_smoothers=None,
                  coarsest_solver=None, mode="preconditioner", cycle_type="v_cycle",
-                 maxiter=100, atol=1.0e-14, rtol=1.0e-8, verbose=False):
+                 maxiter=100, atol=1.0e-14, rtol=1.0e-8, verbose=False, options=None, pin_vectors=False):
         nlev = len(smatrices)
         if pre_smoothers is None:  # Fill(RichardsonSmoother(JacobiLinearSolver(),10),nlev-1)
             pre_smoothers = [RichardsonSmoother(JacobiLinearSolver(), 10) for _ in range(nlev - 1)]
@@ -182,6 +182,11 @@ class GMGLinearSolver:
         self.mode, self.cycle_type = mode, cycle_type
         self.verbose = int(verbose)
         self.log = ConvergenceLog("GMG", maxiter, atol, rtol)
+        # device-side policy (no reference counterpart): `options` = {key: number} handed to gmg_set_option before the operators are
+        # set (storage layout, sweep kernels, one-launch passes, x0_zero, ...; keys in include/gmg_amd.h); `pin_vectors` = the
+        # numerical setup page-locks the host vectors it is called with, once (the pattern of ext/GridapPETScExt/PETScCaches.jl:23-36)
+        self.options = dict(options or {})
+        self.pin_vectors = bool(pin_vectors)
 
     def num_levels(self):
         return len(self.smatrices)
@@ -379,11 +384,54 @@ class GMGNumericalSetup:
         h = C.c_void_p()
         abi.check(None, lib.gmg_create(C.byref(h), solver.num_levels(), device_id))
         self.h = h
+        self._pinned = []          # host arrays registered with the handle, kept alive while they are (LRU, at most 8)
         try:
+            for k, v in solver.options.items():
+                self.set_option(k, v)
             self._upload(mat)
         except Exception:
             self.close()
             raise
+
+    # -- per-handle policy (gmg_set_option) and page-locked host vectors (gmg_host_register)
+    def set_option(self, key, value):
+        abi.check(self.h, self._lib.gmg_set_option(self.h, str(key).encode(), float(value)))
+
+    def get_option(self, key):
+        """-> (effective value or None when the built-in default applies, source: 'default' | 'handle' | 'environment')"""
+        v, src = C.c_double(), C.c_int()
+        abi.check(self.h, self._lib.gmg_get_option(self.h, str(key).encode(), C.byref(v), C.byref(src)))
+        return (None if v.value != v.value else v.value), ("default", "handle", "environment")[src.value]
+
+    def setup(self):
+        """gmg_setup again (after set_option changed a layout option)."""
+        abi.check(self.h, self._lib.gmg_setup(self.h))
+
+    def register_host(self, arr):
+        abi.check(self.h, self._lib.gmg_host_register(self.h, C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def unregister_host(self, arr):
+        abi.check(self.h, self._lib.gmg_host_unregister(self.h, C.c_void_p(arr.ctypes.data)))
+
+    def pin(self, *arrays):
+        """Page-lock host vectors for the life of this setup (or until 8 newer ones displaced them); holds a reference to each."""
+        for a in arrays:
+            if not isinstance(a, np.ndarray) or any(a is q for q in self._pinned):
+                continue
+            if len(self._pinned) >= 8:
+                self.unregister_host(self._pinned.pop(0))
+            self.register_host(a)
+            self._pinned.append(a)
+
+    def host_io_stats(self):
+        up, down, nreg = C.c_int64(), C.c_int64(), C.c_int64()
+        abi.check(self.h, self._lib.gmg_get_host_io_stats(self.h, C.byref(up), C.byref(down), C.byref(nreg)))
+        return dict(bytes_up=up.value, bytes_down=down.value, registered=nreg.value)
+
+    def persist_retries(self):
+        r, a = C.c_int64(), C.c_int()
+        abi.check(self.h, self._lib.gmg_get_persist_retries(self.h, C.byref(r), C.byref(a)))
+        return dict(retries=r.value, persist_active=bool(a.value))
 
     def _upload(self, mat):
         lib, h, s = self._lib, self.h, self.solver
@@ -487,8 +535,9 @@ class GMGNumericalSetup:
 
     def close(self):
         if getattr(self, "h", None):
-            self._lib.gmg_destroy(self.h)
+            self._lib.gmg_destroy(self.h)      # unregisters what is still page-locked (never frees caller memory)
             self.h = None
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -789,6 +838,8 @@ def solve_(x, ns, b):
         px, ms2, _kx = _vec(x, ns.n, writable=True)
         if ms != ms2:
             raise TypeError("x and b must live in the same memory space")
+        if ms == abi.MEM_HOST and ns.solver.pin_vectors:
+            ns.pin(_kb, _kx)
         res = abi.Result()
         hist = np.zeros(log.maxiter + 1)
         abi.check(ns.h, ns._lib.gmg_apply(ns.h, pb, px, ms, C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
@@ -828,6 +879,8 @@ def solve_(x, ns, b):
         px, ms2, _kx = _vec(x, ns.n, writable=True)
         if ms != ms2:
             raise TypeError("x and b must live in the same memory space")
+        if ms == abi.MEM_HOST and g.solver.pin_vectors:
+            g.pin(_kb, _kx)
         res = abi.Result()
         hist = np.zeros(log.maxiter + 1)
         if isinstance(s, CGSolver):

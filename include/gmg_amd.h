@@ -194,6 +194,46 @@ GMG_API int gmg_get_coarse_log(gmg_handle_t h, gmg_result *res);
 /* kwargs of GMGLinearSolver: mode, cycle_type, maxiter, atol, rtol (GMGLinearSolvers.jl:56-58). */
 GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, double atol, double rtol);
 
+/* Layout / schedule policy of ONE handle.  The reference configures a solver by constructor keywords only
+ * (GMGLinearSolvers.jl:48-58); every switch this library used to read from the environment is therefore a per-handle option:
+ *     gmg_set_option(h, "pat_tile", 2)        ("PAT_TILE", "GMG_PAT_TILE" name the same option; unknown keys -> GMG_ERR_INVALID)
+ * Options take effect at the next gmg_setup (setting one after a setup invalidates it, like a new operator would), except the
+ * "live" ones marked (*) which act at the next call.  The environment variable GMG_<KEY>, when set, still OVERRIDES the handle's
+ * value -- a debugging / A-B device, not the configuration interface.  Keys (default):
+ *   storage layout   pattern (1) pat_shared (1) opattern (1) sell (1) sell_maxpad (1.25) vdict (1) idx16 (1) force_ptr64 (0)
+ *                    pat_coded_min_rows (500000) eager* (1) eager_min_rows* (20000) refresh* (1)
+ *   sweep kernels    pat_rsweep (1) pat_tile (1: levels >= pat_tile_rows (6000000); 2: wherever it applies; 0: never) pat_tile_min (512)
+ *                    pat_tile_t (48) pat_tile_lds (79872) pat_strict (1) pat_fma (0: products and sums rounded separately, as the
+ *                    reference's mul!; 1: fused multiply-add taps in the row-pattern sweeps -- not bit-identical)
+ *                    pat_defer (1) pat_dinv (1) pat_emit (1) pat_nb (0 = auto) pat_rb (3) pat_un (9) pat_wgs (2048) pat_batched (1)
+ *                    pat_small_wpb (4) pat_small_wpb2 (2) pat_wide (1) pat_wide_lds (73728) pat_wide_rounds (1) one_gather (1)
+ *                    sell_un (6) sell_block (0 = auto) sell_defer (1) nt (1) nt_rowwise (1) big_rows (4000000) xcd_remap (1)
+ *                    xcd_remap_big (0) lanes_log2 (-1 = auto)
+ *   one-launch pass  persist (1) persist_fenced (1) persist_max_slices (0 = one workgroup per CU) persist_shared (0)
+ *   coarsest level   coarse_host_max (1500) coarse_host_fallback_max (6000) coarse_auto_cg_min (20000: a dense-inverse request on a
+ *                    coarsest level of at least this many dofs is served by the device CG-Jacobi solver instead) gj_mfma (1) gj_wide_min (4096)
+ *   patch smoother   patch_dedup (1) patch_source_dedup (1) patch_operator (1)
+ *   distributed      overlap (1) halo_fuse_pack (1) host_async (0)
+ *   host vectors     x0_zero* (0: the solve entry points read x as the initial guess, CGSolvers.jl:79; 1: x is taken as zero on
+ *                    entry and never uploaded) host_chunk_bytes* (4194304: staging chunk of unregistered host vectors)
+ *   diagnostics      prof_stride (8) setup_timing* (0) dbg_nogather (0) persist_force_timeout* (0: test hook, the next n solves
+ *                    behave as if a one-launch pass had timed out) */
+GMG_API int gmg_set_option(gmg_handle_t h, const char *key, double value);
+/* Effective value of an option (NaN: the built-in default applies); *source (may be NULL) = 0 default, 1 gmg_set_option, 2 environment. */
+GMG_API int gmg_get_option(gmg_handle_t h, const char *key, double *value, int *source);
+
+/* Host-memory callers (GMG_MEM_HOST: what the Julia binding passes for Vector{Float64}).  Registering the caller's arrays ONCE
+ * page-locks and maps them, so every later solve moves b / x by DMA straight from / into the caller's pages at the PCIe link rate
+ * instead of through the staging path for pageable memory -- the pattern of ext/GridapPETScExt/PETScCaches.jl:23-36, which pins
+ * the exact x / b objects of a solve.  The range must stay allocated until gmg_host_unregister (or gmg_destroy, which unregisters
+ * what is left; it never frees caller memory).  Vectors inside a registered range are recognised by address. */
+GMG_API int gmg_host_register(gmg_handle_t h, const void *ptr, int64_t nbytes);
+GMG_API int gmg_host_unregister(gmg_handle_t h, const void *ptr);
+/* Bytes moved host -> device / device -> host for host-memory callers since gmg_create, and the number of registered ranges. */
+GMG_API int gmg_get_host_io_stats(gmg_handle_t h, int64_t *bytes_up, int64_t *bytes_down, int64_t *nregistered);
+/* One-launch smoothing passes: solves that were re-run per sweep after a pass timed out, and whether the passes are still on. */
+GMG_API int gmg_get_persist_retries(gmg_handle_t h, int64_t *retries, int *persist_active);
+
 /* kwarg `verbose` of GMGLinearSolver (GMGLinearSolvers.jl:58).  The library never prints; verbose > 0 makes the GMG's own
  * ConvergenceLog complete on every path: as a preconditioner with maxiter = 1 inside gmg_cg_solve / gmg_fgmres_solve the
  * post-cycle norm(rh) of GMGLinearSolvers.jl:639 only feeds that log (update! returns true at maxiter regardless), so
@@ -302,6 +342,10 @@ GMG_API int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, 
                                       const int64_t *rcv_ptr, const int64_t *rcv_idx);
 /* Halo exchanges and all-reduces this handle has issued since gmg_create (either may be NULL). */
 GMG_API int gmg_get_comm_stats(gmg_handle_t h, int64_t *n_exchanges, int64_t *n_allreduces);
+/* What the handle communicates through: *transport = 0 none / 1 RCCL / 2 host callbacks, its rank and rank count, what RCCL itself
+ * reports for the communicator (ncclCommCount; -1 when not RCCL) and the HIP device it sits on (ncclCommCuDevice / the handle's
+ * device).  Any pointer may be NULL.  bench.py prints these so that a multi-GPU line shows how many ranks RCCL really saw. */
+GMG_API int gmg_get_comm_info(gmg_handle_t h, int *transport, int *rank, int *nranks, int *comm_count, int *comm_device);
 /* Levels >= lev are REPLICATED: every rank passes the GLOBAL operators of those levels
  * (gmg_set_matrix / _prolongation / _restriction, no gmg_set_partition) and computes them
  * redundantly -- no halo traffic where the level is tiny.  Across the boundary, P_{lev-1} has
@@ -323,11 +367,11 @@ GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_ite
 /* Storage chosen for A_lev at setup: *sell = 0 CSR-stream, 1 SELL-64 / SELL-C, 2 SELL-P (row-pattern
  * dictionary), 3 SELL-O (SELL-64 value stream, column offsets from an offset-pattern table); 8-bit value dictionary, 16-bit column offsets, bytes of matrix stream per stored nonzero,
  * padding factor. */
+GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
+                             double *stream_bytes_per_nnz, double *padding);
 /* Kernel + template arguments + launch geometry of the fused sweep last launched on level lev ("" before the first sweep):
  * committed counter measurements (profiles/traffic_latest.json) are only attached to a bench line whose sweep has this signature. */
 GMG_API int gmg_sweep_signature(gmg_handle_t h, int lev, char *buf, int cap);
-GMG_API int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
-                             double *stream_bytes_per_nnz, double *padding);
 /* Measured streaming ceiling: a 16 B/lane copy kernel over nbytes (read) + nbytes (write), reps launches timed with HIP
  * events on the handle's stream; *gbytes_per_s = moved bytes / time.  Reported by bench.py beside the 8 TB/s spec. */
 GMG_API int gmg_stream_probe(gmg_handle_t h, int64_t nbytes, int reps, double *gbytes_per_s);

@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--limit-s", type=float, default=10.0)
     ap.add_argument("--max-reps", type=int, default=8)
     ap.add_argument("--out-x", default=None)
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE configs[2] shape: Q2, vertex-star patch smoother Richardson(PatchSolver,10,0.2) pre = post, FGMRES(5) "
+                         "(test/LinearSolvers/GMGTests.jl:18-47,119-123) at --cells / --levels")
     args = ap.parse_args()
     naff, quota, eff = usable_cores()            # before the OpenMP runtime pins this thread
 
@@ -61,6 +64,8 @@ def main():
     po = entry.import_package().poisson          # numpy-only input synthesis (no GPU, no torch)
     orc = entry.import_oracle()
     nc = (args.cells,) * 3
+    if args.config3:
+        return config3(args, po, orc, nc, naff, quota, eff)
     kap = po.smooth_kappa if args.kappa == "smooth" else None
     H = po.build_hierarchy(nc, args.levels, 1, kappa=kap)
     A0 = H["mats"][0]
@@ -102,6 +107,31 @@ def main():
         np.save(args.out_x, x)
     print(json.dumps(dict(variant=args.variant, threads=int(nthr), seconds=total / reps, reps=reps, iters=int(nit), flag=int(flag),
                           hist=[float(v) for v in hist], setup_s=t_setup, dofs=int(n), affinity_cores=naff, cgroup_cpu_quota=quota,
+                          usable_cores=eff, omp_env={k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")})))
+
+
+def config3(args, po, orc, nc, naff, quota, eff):
+    """Q2 + vertex-star patch smoother + FGMRES(5): the oracle's patch solve (PatchSolvers.jl:279-300 restated) on a size it affords"""
+    import numpy as np
+    order = 2
+    H = po.build_hierarchy(nc, args.levels, order)
+    tabs = [po.vertex_star_patches(c, order) for c in H["ncells"][:-1]]
+    b = po.dirichlet_lift_rhs(nc, order)
+    orc.set_variant(args.variant)
+    t0 = time.perf_counter()
+    g = orc.GMG(H["mats"], H["prolongations"], H["restrictions"],
+                pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in tabs], maxiter=1)
+    t_setup = time.perf_counter() - t0
+    reps, total = 0, 0.0
+    while reps == 0 or (total < args.limit_s and reps < args.max_reps):
+        t0 = time.perf_counter()
+        x, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=g, m=5, maxiter=20, atol=1e-14, rtol=1e-6)
+        total += time.perf_counter() - t0
+        reps += 1
+    if args.out_x:
+        np.save(args.out_x, x)
+    print(json.dumps(dict(variant=args.variant, threads=int(orc.threads()), seconds=total / reps, reps=reps, iters=int(nit), flag=int(flag),
+                          hist=[float(v) for v in hist], setup_s=t_setup, dofs=int(b.size), affinity_cores=naff, cgroup_cpu_quota=quota,
                           usable_cores=eff, omp_env={k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES")})))
 
 

@@ -494,9 +494,22 @@ def main():
                                     omega=(p_omega if smoother == "patch" else 2.0 / 3.0), depth=depth)
         b = g.rhs_lin()
         x = np.zeros(g.n_own)
+        # test hook: ONE rank behaves as if a one-launch smoothing pass had timed out in the first solve -- every rank must re-run it
+        if os.environ.get("GMG_TEST_FORCE_TIMEOUT_RANK") is not None and int(os.environ["GMG_TEST_FORCE_TIMEOUT_RANK"]) == rank:
+            import ctypes as C
+            from gridapsolvers_jl_amd import abi
+            abi.check(g.h, g._lib.gmg_set_option(g.h, b"persist_force_timeout", 1.0))
         ex0 = g.comm_stats()[0]
         log = g.cg_solve(b, x, maxiter, atol, rtol)
         verdict["exchanges"] = int(g.comm_stats()[0] - ex0)
+        if os.environ.get("GMG_TEST_FORCE_TIMEOUT_RANK") is not None:
+            import ctypes as C
+            rr, act = C.c_int64(), C.c_int()
+            g._lib.gmg_get_persist_retries(g.h, C.byref(rr), C.byref(act))
+            allr = [None] * world
+            dist.all_gather_object(allr, (int(rr.value), int(act.value)))
+            verdict["persist_retries"] = [a[0] for a in allr]
+            verdict["persist_active"] = [a[1] for a in allr]
         verdict["x_sha"] = __import__("hashlib").sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
         nit, hist = log.num_iters, log.residuals[: log.num_iters + 1].copy()
         # also exercise device-pointer vectors + FGMRES

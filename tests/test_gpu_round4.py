@@ -1,0 +1,219 @@
+"""GPU tests of the round-4 additions: per-handle options (gmg_set_option), host vectors registered once (gmg_host_register),
+the x0_zero option, the joint retry of a timed-out one-launch smoothing pass, fused multiply-add taps.  Same bar as
+tests/test_gpu_parity.py: the HIP path through the C ABI against the CPU oracle on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def jac(S, nlev, niter=10, omega=2.0 / 3.0):
+    return [S.RichardsonSmoother(S.JacobiLinearSolver(), niter, omega)] * (nlev - 1)
+
+
+def make_gmg(S, H, **kw):
+    nlev = len(H["mats"])
+    kw.setdefault("pre_smoothers", jac(S, nlev))
+    kw.setdefault("post_smoothers", kw["pre_smoothers"])
+    kw.setdefault("maxiter", 1)
+    return S.GMGLinearSolver(H["mats"], H["prolongations"], H["restrictions"], **kw)
+
+
+def setup(S, solver, A):
+    return S.numerical_setup(S.symbolic_setup(solver, A), A)
+
+
+def cg(S, H, **kw):
+    return S.CGSolver(make_gmg(S, H, **kw), maxiter=20, atol=1e-14, rtol=1e-6)
+
+
+# ---------------------------------------------------------------- layout policy per handle, not per process
+def test_options_choose_the_layout_per_handle(S, po, orc):
+    """Two solvers in ONE process with different storage layouts (the reference configures by constructor keywords only,
+    GMGLinearSolvers.jl:48-58): options pattern=0,vdict=0,idx16=0,opattern=0 give the plain 12 B/nnz SELL-64 stream, the default
+    handle keeps the row-pattern form; both reproduce the oracle (iterations identical, histories <= 1e-8) and each other bit for
+    bit (every layout sums a row in CSR order).  Unknown keys are rejected; an option set after the setup invalidates it."""
+    nc, nlev = (24, 24, 24), 3
+    H = po.build_hierarchy(nc, nlev, 1)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    s1 = cg(S, H)
+    s2 = cg(S, H, options={"pattern": 0, "GMG_VDICT": 0, "IDX16": 0, "opattern": 0})
+    n1, n2 = setup(S, s1, H["mats"][0]), setup(S, s2, H["mats"][0])
+    assert n1.P_ns.level_format(0)["layout"] == "SELL-P" and n2.P_ns.level_format(0)["layout"] == "SELL-64"
+    assert n2.P_ns.get_option("pattern") == (0.0, "handle") and n1.P_ns.get_option("pattern") == (None, "default")
+    x1, x2 = np.zeros_like(b), np.zeros_like(b)
+    S.solve_(x1, n1, b)
+    S.solve_(x2, n2, b)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
+    for s, x in ((s1, x1), (s2, x2)):
+        assert s.log.num_iters == nit
+        np.testing.assert_allclose(s.log.residuals[: nit + 1], hist, rtol=1e-8)
+        assert rel_err(x, xo) <= 1e-10
+    assert np.array_equal(x1, x2)
+    from gridapsolvers_jl_amd import abi
+    with pytest.raises(abi.GmgError) as e:
+        n1.P_ns.set_option("no_such_option", 1)
+    assert e.value.code == abi.ERR_INVALID
+    # a layout option after the setup: the handle asks for a new gmg_setup instead of silently keeping the old layout
+    n1.P_ns.set_option("pattern", 0)
+    with pytest.raises(abi.GmgError) as e:
+        S.solve_(x1, n1, b)
+    assert e.value.code == abi.ERR_STATE
+    n1.P_ns.setup()
+    assert n1.P_ns.level_format(0)["layout"] == "SELL-64"
+    x3 = np.zeros_like(b)
+    S.solve_(x3, n1, b)
+    assert np.array_equal(x3, x2)
+
+
+def test_environment_overrides_the_handle_option(S, po, monkeypatch):
+    """GMG_<KEY> in the environment is the debugging override of the same option"""
+    nc, nlev = (16, 16, 16), 3
+    H = po.build_hierarchy(nc, nlev, 1)
+    monkeypatch.setenv("GMG_PATTERN", "0")
+    ns = setup(S, cg(S, H, options={"pattern": 1}), H["mats"][0])
+    assert ns.P_ns.get_option("pattern") == (0.0, "environment")
+    assert ns.P_ns.level_format(0)["layout"] != "SELL-P"
+
+
+# ---------------------------------------------------------------- host vectors: the path the Julia binding takes
+@pytest.mark.parametrize("krylov", ["cg", "fgmres"])
+def test_registered_and_unregistered_host_vectors_give_identical_bits(S, po, orc, krylov):
+    """b / x as host arrays through GMG_MEM_HOST (what julia/GridapSolversAMD.jl passes): pageable arrays (chunked staging),
+    arrays page-locked once (gmg_host_register, the pattern of ext/GridapPETScExt/PETScCaches.jl:23-36), a vector INSIDE a registered
+    range, and device tensors all give the same bits; 24 N bytes cross PCIe per solve, 16 N with x0_zero; a non-zero initial guess is
+    honoured by default (CGSolvers.jl:79) and ignored with x0_zero."""
+    import torch
+    nc, nlev = (40, 40, 40), 3        # 59 319 dofs = 474 552 bytes: several staging chunks at host_chunk_bytes = 65536
+    H = po.build_hierarchy(nc, nlev, 1)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    n = b.size
+    if krylov == "cg":
+        solver = cg(S, H, options={"host_chunk_bytes": 65536})
+    else:
+        solver = S.FGMRESSolver(5, make_gmg(S, H, options={"host_chunk_bytes": 65536}), maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = setup(S, solver, H["mats"][0])
+    g = ns.P_ns
+    xd = torch.zeros(n, dtype=torch.float64, device="cuda")
+    S.solve_(xd, ns, torch.from_numpy(b).cuda())
+    x_dev = xd.cpu().numpy()
+    st0 = g.host_io_stats()
+    x_pg = np.zeros(n)
+    S.solve_(x_pg, ns, b.copy())
+    st1 = g.host_io_stats()
+    assert st1["bytes_up"] - st0["bytes_up"] == 16 * n and st1["bytes_down"] - st0["bytes_down"] == 8 * n and st1["registered"] == 0
+    big = np.zeros(3 * n + 5)                         # x lives inside a registered range, at an odd offset
+    b_rg, x_rg = b.copy(), big[n + 3: 2 * n + 3]
+    g.register_host(big); g.register_host(b_rg)
+    assert g.host_io_stats()["registered"] == 2
+    S.solve_(x_rg, ns, b_rg)
+    assert np.array_equal(x_pg, x_dev) and np.array_equal(x_rg, x_dev)
+    assert big[: n + 3].max() == 0.0 and big[2 * n + 3:].max() == 0.0      # nothing written outside x
+    # initial guess: honoured by default, ignored (taken as zero, never uploaded) with x0_zero
+    rng = np.random.default_rng(3)
+    guess = x_dev + 1e-3 * rng.standard_normal(n)
+    x_g = guess.copy()
+    S.solve_(x_g, ns, b_rg)
+    it_guess = solver.log.num_iters
+    g.set_option("x0_zero", 1)
+    st2 = g.host_io_stats()
+    x_z = guess.copy()
+    S.solve_(x_z, ns, b_rg)
+    st3 = g.host_io_stats()
+    assert st3["bytes_up"] - st2["bytes_up"] == 8 * n
+    assert np.array_equal(x_z, x_dev) and not np.array_equal(x_g, x_dev)
+    assert it_guess <= solver.log.num_iters
+    xd2 = torch.from_numpy(guess).cuda()
+    S.solve_(xd2, ns, torch.from_numpy(b).cuda())     # device callers: the same option zeroes x in place
+    assert np.array_equal(xd2.cpu().numpy(), x_dev)
+    g.set_option("x0_zero", 0)
+    g.unregister_host(big); g.unregister_host(b_rg)
+    assert g.host_io_stats()["registered"] == 0
+    from gridapsolvers_jl_amd import abi
+    with pytest.raises(abi.GmgError):
+        g.unregister_host(big)
+    # pin_vectors=True: the numerical setup registers the vectors it is called with, once
+    s2 = cg(S, H, pin_vectors=True)
+    n2 = setup(S, s2, H["mats"][0])
+    xa, ba = np.zeros(n), b.copy()
+    S.solve_(xa, n2, ba); S.solve_(xa, n2, ba)
+    assert n2.P_ns.host_io_stats()["registered"] == 2
+    if krylov == "cg":
+        assert np.array_equal(xa, x_dev) or rel_err(xa, x_dev) < 1e-12     # second solve starts from the converged x
+    n2.P_ns.close()
+    # the oracle, for the record
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    if krylov == "cg":
+        xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
+    else:
+        xo, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert rel_err(x_dev, xo) <= 1e-10
+
+
+def test_preconditioner_apply_with_host_vectors(S, po, orc):
+    """ldiv!(z, ns, r) with host arrays (one V-cycle per call -- the library under a host-language Krylov loop): registered and
+    pageable arrays give the oracle's V-cycle (<= 1e-11) and identical bits; r is untouched"""
+    nc, nlev = (24, 24, 24), 3
+    H = po.build_hierarchy(nc, nlev, 1)
+    gmg = make_gmg(S, H)
+    ns = setup(S, gmg, H["mats"][0])
+    rng = np.random.default_rng(11)
+    r = rng.uniform(-1, 1, H["mats"][0].shape[0])
+    r_keep = r.copy()
+    z1, z2 = np.full_like(r, 7.0), np.full_like(r, -3.0)      # :preconditioner mode overwrites x with zeros first
+    S.solve_(z1, ns, r)
+    ns.pin(r, z2)
+    S.solve_(z2, ns, r)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    zo = go.solve(r.copy())[0]
+    assert np.array_equal(z1, z2) and np.array_equal(r, r_keep)
+    assert rel_err(z1, zo) <= 1e-11
+
+
+# ---------------------------------------------------------------- one-launch passes: a time-out re-runs the call, on every entry point
+def test_forced_timeout_of_a_one_launch_pass_reruns_the_solve(S, po):
+    """persist_force_timeout (test hook): the solve behaves as if a one-launch smoothing pass had timed out -- the initial guess is
+    restored, the handle switches to per-sweep launches, the call is re-run and returns the bits of an undisturbed solve"""
+    import torch
+    nc, nlev = (32, 32, 32), 4
+    H = po.build_hierarchy(nc, nlev, 1)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    n = b.size
+    ref = setup(S, cg(S, H), H["mats"][0])
+    x_ref = np.zeros(n)
+    S.solve_(x_ref, ref, b)
+    assert ref.P_ns.persist_retries() == dict(retries=0, persist_active=True)
+    ns = setup(S, cg(S, H), H["mats"][0])
+    ns.P_ns.set_option("persist_force_timeout", 1)
+    xd = torch.zeros(n, dtype=torch.float64, device="cuda")   # in place on a device vector: x is restored before the re-run
+    S.solve_(xd, ns, torch.from_numpy(b).cuda())
+    assert ns.P_ns.persist_retries() == dict(retries=1, persist_active=False)
+    assert np.array_equal(xd.cpu().numpy(), x_ref)
+    # gmg_smooth directly: x and r come back as from per-sweep launches
+    ns2 = setup(S, cg(S, H), H["mats"][0])
+    rng = np.random.default_rng(5)
+    n1 = H["mats"][1].shape[0]
+    x0, r0 = rng.uniform(-1, 1, n1), rng.uniform(-1, 1, n1)
+    xa, ra = x0.copy(), r0.copy()
+    ref.P_ns.smooth(1, xa, ra)
+    ns2.P_ns.set_option("persist_force_timeout", 1)
+    xb, rb = torch.from_numpy(x0).cuda(), torch.from_numpy(r0).cuda()
+    ns2.P_ns.smooth(1, xb, rb)
+    assert ns2.P_ns.persist_retries()["retries"] == 1
+    assert np.array_equal(xb.cpu().numpy(), xa) and np.array_equal(rb.cpu().numpy(), ra)
+
+
+def test_timeout_on_one_rank_is_acted_on_by_all_ranks(tmp_path):
+    """Several ranks (host transport on one GPU, one-launch passes on the overlapping / replicated levels): a time-out on ONE rank
+    makes EVERY rank restore x and re-run the solve -- the decision is one all-reduce at the end of the solve, no rank leaves the
+    collective sequence in the middle -- and the result is the serial oracle's"""
+    from test_distributed import _launch, _check
+    env = {"GMG_PERSIST_SHARED": "1", "GMG_TEST_DEPTH": "5", "GMG_TEST_FORCE_TIMEOUT_RANK": "1"}
+    v = _launch("gpu", 2, (16, 16, 16), 4, tmp_path, transport="host", rep_from=3, extra_env=env)
+    _check(v)
+    assert v["persist_retries"] == [1, 1] and v["persist_active"] == [0, 0], v
