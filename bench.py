@@ -275,9 +275,11 @@ def host_io_leg(torch, S, ns, b, dev_ms, steps, label):
     n = b.size
     nb = 8 * n
 
-    def timed(fn, reps, warm=1):
+    def timed(fn, before, reps, warm=1):
         ts = []
         for i in range(warm + reps):
+            if before:
+                before()                          # the caller's own work (fill!(x, 0.0)): not part of solve!
             t0 = time.perf_counter()
             fn()
             dt = time.perf_counter() - t0
@@ -286,27 +288,21 @@ def host_io_leg(torch, S, ns, b, dev_ms, steps, label):
         return float(np.mean(ts)), float(np.min(ts))
 
     def solve_on(x, bb):
-        def f():
-            x.fill(0.0)
-            S.solve_(x, ns, bb)
-        return f
+        return (lambda: S.solve_(x, ns, bb)), (lambda: x.fill(0.0))
     out = {"workload": label, "bytes_per_vector": nb, "device_resident_ms": dev_ms, "pcie": pcie_probe(torch, nb)}
     reps = max(3, steps // 2)
-    # (the x.fill(0) of the caller is inside the timed call: a few hundred us at 189 MB; reported separately below)
-    x0 = np.zeros(n)
-    t0 = time.perf_counter(); x0.fill(0.0); out["caller_fill_ms"] = (time.perf_counter() - t0) * 1e3
     b1, x1 = b.copy(), np.zeros(n)
-    m, mn = timed(solve_on(x1, b1), reps)
+    m, mn = timed(*solve_on(x1, b1), reps)
     out["pageable"] = dict(ms_per_step=m * 1e3, min_ms=mn * 1e3, value=n / m)
     xp = x1.copy()
     b2, x2 = b.copy(), np.zeros(n)
     t0 = time.perf_counter()
     g.pin(b2, x2)
     out["register_ms_once"] = (time.perf_counter() - t0) * 1e3
-    m, mn = timed(solve_on(x2, b2), reps)
+    m, mn = timed(*solve_on(x2, b2), reps)
     out["registered"] = dict(ms_per_step=m * 1e3, min_ms=mn * 1e3, value=n / m)
     g.set_option("x0_zero", 1)
-    m, mn = timed(solve_on(x2, b2), reps)
+    m, mn = timed(*solve_on(x2, b2), reps)
     g.set_option("x0_zero", 0)
     out["registered_x0_zero"] = dict(ms_per_step=m * 1e3, min_ms=mn * 1e3, value=n / m)
     out["bitwise_equal_pageable_vs_registered"] = bool(np.array_equal(xp, x2))
@@ -322,14 +318,14 @@ def host_io_leg(torch, S, ns, b, dev_ms, steps, label):
     out["frac_of_floor"] = floor_ms / out["ms_per_step"]
     # one V-cycle per call (GMG as :preconditioner, maxiter = 1): z = M r with host vectors vs device vectors
     r_h, z_h = b2, x2
-    m_h, _ = timed(lambda: S.solve_(z_h, g, r_h), reps)
+    m_h, _ = timed(lambda: S.solve_(z_h, g, r_h), None, reps)
     rd, zd = torch.from_numpy(b).cuda(), torch.zeros(n, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
 
     def dev_call():
         S.solve_(zd, g, rd)
         torch.cuda.synchronize()
-    m_d, _ = timed(dev_call, reps)
+    m_d, _ = timed(dev_call, None, reps)
     out["precond_only"] = dict(host_registered_ms=m_h * 1e3, device_ms=m_d * 1e3, frac=m_d / m_h,
                                note="one gmg_apply (one V-cycle) per call: 16 N bytes over PCIe per application -- a host-language Krylov loop "
                                     "should hand the library device vectors or call the whole-solve entry points (gmg_cg_solve / gmg_fgmres_solve)")

@@ -224,6 +224,7 @@ struct DevCSR {
   int64_t zpad = 0;
   // compressed stream (SELL-C): 16-bit column offsets per slice column, 8-bit value codes
   int64_t nnz_model = -1;   // nnz of the caller's operator when A was split (byte model)
+  int64_t band = 0;         // SELL-64 / SELL-O: largest |column - row|
   bool comp_idx = false, vdict = false;
   int64_t *poff = nullptr;
   uint16_t *pidx = nullptr;
@@ -483,6 +484,17 @@ struct gmg_solver {
   // coarse solver (coarsest_solver kwarg, GMGLinearSolvers.jl:54,423-434)
   double *d_Ainv = nullptr;
   int coarse_kind = GMG_COARSE_DENSE_INVERSE;
+  // what the setup actually builds: a dense-inverse request (LUSolver()) on a coarsest level of >= GMG_COARSE_AUTO_CG_MIN dofs is
+  // served by CGSolver(JacobiLinearSolver()) on the device, run to rtol 1e-10 -- the n x n inverse of such a level costs seconds of
+  // setup and gigabytes (29 791 dofs, BASELINE config 3: 1.9 s, 7.1 GB) for a solve the outer Krylov method only needs to ~1e-7
+  int coarse_eff = GMG_COARSE_DENSE_INVERSE;
+  bool coarse_auto = false;
+  void resolve_coarse_kind()
+  {
+    coarse_eff = coarse_kind; coarse_auto = false;
+    const int amin = opt_int("GMG_COARSE_AUTO_CG_MIN", 20000);
+    if (coarse_kind == GMG_COARSE_DENSE_INVERSE && amin > 0 && nlev > 0 && lev[nlev - 1].n >= amin) { coarse_eff = GMG_COARSE_CG_JACOBI; coarse_auto = true; }
+  }
   int coarse_maxiter = 1000;                 // CGSolver defaults, CGSolvers.jl:19
   double coarse_atol = 1e-12, coarse_rtol = 1e-6;
   gmg_coarse_solve_fn coarse_fn = nullptr;
@@ -536,10 +548,23 @@ struct gmg_solver {
   int sell_un = 6;      // GMG_SELL_UN: independent (col,val,gather) triples in flight per lane
   int nt_loads = 1;     // GMG_NT: non-temporal matrix stream
   int nt_rowwise = 1;   // GMG_NT_ROWWISE: SELL-64 / SELL-O sweeps of big levels read r, x, 1/diag and write r, x non-temporally
-  int xcd_remap_big = 0; // GMG_XCD_REMAP_BIG: XCD-contiguous row ranges also on levels whose gathered vector exceeds the L2s (SELL-64 / SELL-O)
+  int xcd_remap_big = -1; // GMG_XCD_REMAP_BIG: workgroup -> rows mapping on levels whose gathered vector exceeds the L2s (SELL-64 / SELL-O): 0 launch order, 1 contiguous eighths, n > 1 chunks of n workgroups per XCD, -1 chunk from the operator's gather reach
   int64_t big_rows = 4000000;   // GMG_BIG_ROWS: a level is "big" above this many rows (8 B/row against 8 x 4 MB of L2)
   int sell_defer = 1;   // GMG_SELL_DEFER: x updated every second sweep in the SELL-64 / SELL-O sweeps as well
   bool big_level(const DevCSR &M) const { return M.nrows > big_rows; }
+  // Workgroup -> row-range mapping of the SELL-64 / SELL-O kernels on a level whose gathered vector exceeds the L2s.  Launch order
+  // (0) lets all eight XCDs stream inside one window of the arrays, but neighbouring workgroups sit on different XCDs, so every L2
+  // fetches (nearly) the whole gathered vector: 1.09 x the algorithmic bytes at >= 256^3 (profiles/r03f_288_hbm_traffic.txt).
+  // Contiguous eighths (1) fetch it once but stream from eight far-apart windows.  Chunked (> 1: that many consecutive workgroups
+  // per XCD inside a group of 8 chunks): auto (-1) makes a chunk four gather reaches deep, so the reach above and below a chunk --
+  // what a neighbouring XCD also fetches -- is half of what the chunk itself covers once, and the window stays 32 reaches wide.
+  int remap_for_big(const DevCSR &M, int rows_per_wg, int nwg) const
+  {
+    if (xcd_remap_big >= 0) return xcd_remap_big == 1 ? xcd_remap : xcd_remap_big;
+    const int64_t want = (4 * std::max<int64_t>(M.band, 1) + rows_per_wg - 1) / rows_per_wg;
+    if (want < 2 || want * 8 * 4 > nwg) return 0;           // no locality to win / the window would span a quarter of the level: launch order
+    return (int)want;
+  }
   int use_pattern = 1;  // GMG_PATTERN: row-pattern dictionary (SELL-P) when the matrix has few distinct rows
   int pat_un = 9;       // GMG_PAT_UN: gathers in flight per lane in sellp_kernel
   int pat_wgs = 2048;   // GMG_PAT_WGS: resident workgroups of the persistent sellp launch
@@ -562,6 +587,9 @@ struct gmg_solver {
   int n_cus = 0;
   uint32_t *d_perr_dev = nullptr;                  // device-memory twin (the kernel's end-of-pass check)
   uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
+  int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
+  int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: GMG_PAT_WGS)
+  int pat_fma = 0;      // GMG_PAT_FMA: fused multiply-add taps in the row-pattern sweeps (one rounding per tap: not the reference's mul! arithmetic)
   int pat_rsweep = 1;   // GMG_PAT_RSWEEP: sweeps of uniform-diagonal row-pattern levels gather r itself (no s vector: sells_rsweep_kernel)
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
   int pat_dinv = 1;     // GMG_PAT_DINV: Jacobi inverse diagonal from the pattern table instead of its vector
@@ -1387,11 +1415,16 @@ struct gmg_solver {
     if (build_pattern(H, D)) return;
     const int64_t ns = (H.nrows + 63) / 64;
     std::vector<int64_t> soff((size_t)ns + 1, 0);
+    int64_t band = 0;                                        // largest |column - row| (columns ascend inside a row): how far a gather reaches
     for (int64_t sl = 0; sl < ns; ++sl) {
       int64_t w = 0;
-      for (int64_t i = sl * 64; i < std::min<int64_t>(H.nrows, sl * 64 + 64); ++i) w = std::max(w, H.ptr[i + 1] - H.ptr[i]);
+      for (int64_t i = sl * 64; i < std::min<int64_t>(H.nrows, sl * 64 + 64); ++i) {
+        w = std::max(w, H.ptr[i + 1] - H.ptr[i]);
+        if (H.ptr[i + 1] > H.ptr[i]) band = std::max(band, std::max<int64_t>(i - (int64_t)H.col[H.ptr[i]], (int64_t)H.col[H.ptr[i + 1] - 1] - i));
+      }
       soff[sl + 1] = soff[sl] + w * 64;
     }
+    D.band = band;
     const int64_t zp = soff[ns];
     if ((double)zp > sell_maxpad * (double)D.nnz) {
       // Ragged matrix.  SELL still wins when the stream compresses (<= 256 distinct values): a padded
@@ -1579,7 +1612,7 @@ struct gmg_solver {
     const size_t lds = (size_t)M.opat_np * M.opat_w * 4;
     const bool nt = nt_loads && (8.0 * (double)M.zpad > 128.0e6);
     const bool huge = big_level(M);                        // see launch_sell
-    if (huge && xcd_remap_big == 0) a.xcd_remap = 0;
+    if (huge) a.xcd_remap = remap_for_big(M, 64 * wpb, (int)g.x);
     if constexpr (EPI == EPI_SWEEP && ONEG) {
       if (sell_un < 27 && (a2.xmode != 0 || (huge && nt && nt_rowwise))) {
 #define GMG_SELLO_SWEEP(NTV)                                                                                                        \
@@ -1628,7 +1661,7 @@ struct gmg_solver {
     // stream -- and write -- inside one window of the arrays instead of eight far-apart eighths) and the once-per-sweep row-wise
     // operands non-temporal.  Both lose 1-2 % on levels that do fit, so they switch on by size.
     const bool huge = big_level(M);
-    if (huge && xcd_remap_big == 0) a.xcd_remap = 0;
+    if (huge) a.xcd_remap = remap_for_big(M, 64 * wpb, (int)g.x);
     if constexpr (EPI == EPI_SWEEP && ONEG) {
       if (sell_un >= 6 && sell_un < 9 && (a2.xmode != 0 || (huge && nt && nt_rowwise))) {
         // default unroll: the variants with the deferred x update (a2.xmode) and non-temporal row-wise operands
@@ -1790,21 +1823,22 @@ struct gmg_solver {
     const int ntiles = (nsl + T - 1) / T;
     const int nwg = std::max(8, (std::min(ntiles, resident) / 8) * 8);          // a multiple of 8: one share per XCD
     const dim3 g(nwg), b(64 * WPB);
-    M.note_sweep("sells_tsweep_kernel<XM=*,MK=%d,WPB=%d> T=%d tiles=%d wgs=%d segs=%d", mk ? 1 : 0, WPB, T, ntiles, nwg, tl.nseg);
+    M.note_sweep("sells_tsweep_kernel<XM=*,MK=%d,WPB=%d,FM=%d> T=%d tiles=%d wgs=%d segs=%d", mk ? 1 : 0, WPB, pat_fma ? 1 : 0, T, ntiles, nwg, tl.nseg);
+#define GMG_TSWEEP_LAUNCH2(XMV, MKV, FMV)                                                                           \
+    do {                                                                                                              \
+      static bool attr[64] = {false};                                                                                 \
+      if (!attr[device & 63]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, MKV, WPB, FMV>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr[device & 63] = true; } \
+      hipLaunchKernelGGL((sells_tsweep_kernel<XMV, MKV, WPB, FMV>), g, b, lds, stream, a, tl);                        \
+    } while (0)
 #define GMG_TSWEEP_LAUNCH(XMV)                                                                                      \
     do {                                                                                                              \
-      if (mk) {                                                                                                       \
-        static bool attr[64] = {false};                                                                               \
-        if (!attr[device & 63]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, true, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr[device & 63] = true; } \
-        hipLaunchKernelGGL((sells_tsweep_kernel<XMV, true, WPB>), g, b, lds, stream, a, tl);                          \
-      } else {                                                                                                        \
-        static bool attr[64] = {false};                                                                               \
-        if (!attr[device & 63]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, false, WPB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr[device & 63] = true; } \
-        hipLaunchKernelGGL((sells_tsweep_kernel<XMV, false, WPB>), g, b, lds, stream, a, tl);                         \
-      }                                                                                                               \
+      if (mk) { if (pat_fma) GMG_TSWEEP_LAUNCH2(XMV, true, true); else GMG_TSWEEP_LAUNCH2(XMV, true, false); }        \
+      else { if (pat_fma) GMG_TSWEEP_LAUNCH2(XMV, false, true); else GMG_TSWEEP_LAUNCH2(XMV, false, false); }         \
     } while (0)
     if (a.xmode == 0) GMG_TSWEEP_LAUNCH(0); else if (a.xmode == 1) GMG_TSWEEP_LAUNCH(1); else GMG_TSWEEP_LAUNCH(2);
 #undef GMG_TSWEEP_LAUNCH
+#undef GMG_TSWEEP_LAUNCH2
+#undef GMG_TSWEEP_LAUNCH2
     HIP_CHECK(hipGetLastError());
     return true;
   }
@@ -1826,11 +1860,36 @@ struct gmg_solver {
     const dim3 g2(wg2), b(64 * wpb);
     const size_t lds2 = (size_t)M.pat_np * nu * 16 + 16;
     const bool mk = pat_strict || !M.ptab8;
-    M.note_sweep("sells_rsweep_kernel<XM=*,NB=%d,MK=%d> wgs=%d wpb=%d", nb >= 2 ? 2 : 1, mk ? 1 : 0, wg2, wpb);
+    // two rows per lane (kernels.hpp: sells_r2sweep_kernel): slices of 126 rows, 16-byte loads / stores, half the conversions and shifts per row
+    if (pat_r2 && (M.pat_nruns == 9 || M.pat_nruns == 3)) {
+      const int nsl2 = (int)((M.nrows + 125) / 126);
+      a.nslices = nsl2;
+      const int wgr = std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : pat_wgs));
+      const dim3 gr(wgr);
+      M.note_sweep("sells_r2sweep_kernel<XM=*,MK=%d,FM=%d,NR=%d> wgs=%d wpb=%d", mk ? 1 : 0, pat_fma ? 1 : 0, M.pat_nruns, wgr, wpb);
+#define GMG_R2_LAUNCH2(XMV, MKV, FMV)                                                                            \
+      do {                                                                                                       \
+        if (M.pat_nruns == 9) hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, MKV, FMV, 9>), gr, b, lds2, stream, a);   \
+        else hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, MKV, FMV, 3>), gr, b, lds2, stream, a);               \
+      } while (0)
+#define GMG_R2_LAUNCH(XMV)                                                                                       \
+      do {                                                                                                       \
+        if (mk) { if (pat_fma) GMG_R2_LAUNCH2(XMV, true, true); else GMG_R2_LAUNCH2(XMV, true, false); }         \
+        else { if (pat_fma) GMG_R2_LAUNCH2(XMV, false, true); else GMG_R2_LAUNCH2(XMV, false, false); }          \
+      } while (0)
+      if (xmode == 0) GMG_R2_LAUNCH(0); else if (xmode == 1) GMG_R2_LAUNCH(1); else GMG_R2_LAUNCH(2);
+#undef GMG_R2_LAUNCH2
+#undef GMG_R2_LAUNCH
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+    M.note_sweep("sells_rsweep_kernel<XM=*,NB=%d,MK=%d,FM=%d> wgs=%d wpb=%d", nb >= 2 ? 2 : 1, mk ? 1 : 0, pat_fma ? 1 : 0, wg2, wpb);
 #define GMG_RSWEEP_LAUNCH(XMV, NBV)                                                                            \
     do {                                                                                                         \
-      if (mk) hipLaunchKernelGGL((sells_rsweep_kernel<XMV, NBV, true>), g2, b, lds2, stream, a);                 \
-      else hipLaunchKernelGGL((sells_rsweep_kernel<XMV, NBV, false>), g2, b, lds2, stream, a);                   \
+      if (mk) { if (pat_fma) hipLaunchKernelGGL((sells_rsweep_kernel<XMV, NBV, true, 0, true>), g2, b, lds2, stream, a);   \
+                else hipLaunchKernelGGL((sells_rsweep_kernel<XMV, NBV, true>), g2, b, lds2, stream, a); }        \
+      else { if (pat_fma) hipLaunchKernelGGL((sells_rsweep_kernel<XMV, NBV, false, 0, true>), g2, b, lds2, stream, a);     \
+             else hipLaunchKernelGGL((sells_rsweep_kernel<XMV, NBV, false>), g2, b, lds2, stream, a); }          \
     } while (0)
     if (nb >= 2) { if (xmode == 0) GMG_RSWEEP_LAUNCH(0, 2); else if (xmode == 1) GMG_RSWEEP_LAUNCH(1, 2); else GMG_RSWEEP_LAUNCH(2, 2); }
     else { if (xmode == 0) GMG_RSWEEP_LAUNCH(0, 1); else if (xmode == 1) GMG_RSWEEP_LAUNCH(1, 1); else GMG_RSWEEP_LAUNCH(2, 1); }
@@ -2228,24 +2287,27 @@ struct gmg_solver {
     const bool inplace = memspace == GMG_MEM_DEVICE && !multi && !x_output_only;
     if (armed && inplace) copy(scratch_vec(6, lev[0].nvec), x_user, n);
     persist_defer_throw = armed && multi;
-    bool again = false;
+    bool again = false, forced = false;
+    struct Undefer { gmg_solver &S; ~Undefer() { S.defer_out = false; S.pending_out.clear(); } } undefer{*this};
+    defer_out = armed;
+    pending_out.clear();
     try {
-      if (armed && opt_int("GMG_PERSIST_FORCE_TIMEOUT", 0) > 0 && h_perr) {   // test hook: behave as if a pass timed out in this solve
+      if (armed && opt_int("GMG_PERSIST_FORCE_TIMEOUT", 0) > 0) {   // test hook: behave as if a pass timed out in this solve
         options["GMG_PERSIST_FORCE_TIMEOUT"] = opt_int("GMG_PERSIST_FORCE_TIMEOUT", 0) - 1;
-        force_trip = true;
+        forced = true;
+        force_pending = !multi;                              // one rank: the next check_persistent() (first scalar fetch of the solve) trips
       }
       body();
-      if (force_trip) { HIP_CHECK(hipStreamSynchronize(stream)); *h_perr = 1; force_trip = false; }
       if (!persist_defer_throw) check_persistent();
     } catch (const GmgError &) {
-      persist_defer_throw = false; force_trip = false;
+      persist_defer_throw = false;
       if (!(armed && persist_tripped)) throw;
       again = true;
     }
     if (armed && multi) {
       persist_defer_throw = false;
       HIP_CHECK(hipStreamSynchronize(stream));
-      double flag = (h_perr && *h_perr) ? 1.0 : 0.0;
+      double flag = ((h_perr && *h_perr) || forced) ? 1.0 : 0.0;
       host_allreduce_sum(&flag);                             // joint decision (not counted in gmg_get_comm_stats: control traffic)
       if (flag > 0.0) {
         if (h_perr) *h_perr = 0;
@@ -2258,12 +2320,16 @@ struct gmg_solver {
       ++persist_retries;
       HIP_CHECK(hipStreamSynchronize(stream));
       if (inplace) copy(x_user, scratch_vec(6, lev[0].nvec), n);
+      pending_out.clear();
       body();
     }
+    defer_out = false;
+    const std::vector<PendingOut> todo = pending_out;
+    pending_out.clear();
+    for (const PendingOut &o : todo) out_vec(o.user, o.dev, o.n, o.memspace);
   }
   bool persist_tripped = false;
   bool persist_defer_throw = false;   // several ranks: the time-out is acted on jointly at the end of the solve
-  bool force_trip = false;
   int64_t persist_retries = 0;
   // one double summed over the ranks through the host (control decisions; solves use the in-stream reductions)
   void host_allreduce_sum(double *v)
@@ -2279,11 +2345,13 @@ struct gmg_solver {
     } else
       comm.rfn(comm.ctx, v, 1);
   }
+  bool force_pending = false;
   void check_persistent()
   {
-    if (!(h_perr && *h_perr)) return;
+    if (!((h_perr && *h_perr) || force_pending)) return;
     if (persist_defer_throw) return;                         // multi-rank solve in flight: decided jointly in with_persist_retry
-    *h_perr = 0;
+    force_pending = false;
+    if (h_perr) *h_perr = 0;
     persist = 0;                                             // later solves of this handle sweep launch by launch
     persist_tripped = true;
     throw GmgError{GMG_ERR_STATE, "one-launch smoothing pass: a neighbour wait timed out (its workgroups were not all resident -- is the GPU shared with "
@@ -2441,8 +2509,8 @@ struct gmg_solver {
   {
     Level &L = lev[nlev - 1];
     const int64_t n = L.n;
-    if (coarse_kind == GMG_COARSE_DENSE_INVERSE) { dense_solve(d_Ainv, (int)n, r, x); return; }
-    if (coarse_kind == GMG_COARSE_CG_JACOBI) {
+    if (coarse_eff == GMG_COARSE_DENSE_INVERSE) { dense_solve(d_Ainv, (int)n, r, x); return; }
+    if (coarse_eff == GMG_COARSE_CG_JACOBI) {
       // CGSolver(JacobiLinearSolver(); maxiter, atol, rtol) on A_L, initial guess 0
       zero(x, n);
       KrylovOps ops;
@@ -2452,7 +2520,8 @@ struct gmg_solver {
         hipLaunchKernelGGL(jacobi_apply_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, L.dinv, rr, z);
         HIP_CHECK(hipGetLastError());
       };
-      coarse_log.configure(coarse_maxiter, coarse_atol, coarse_rtol);
+      if (coarse_auto) coarse_log.configure(10000, 0.0, 1e-10);
+      else coarse_log.configure(coarse_maxiter, coarse_atol, coarse_rtol);
       const bool saved = reduce_local;
       reduce_local = true;
       try { coarse_last = cg_core(*this, n, r, x, cc_w, cc_p, cc_z, cc_r, ops, false, coarse_log); }
@@ -2665,8 +2734,14 @@ struct gmg_solver {
     if (host) h2d(dx, x_user, n);
     else HIP_CHECK(hipMemcpyAsync(dx, x_user, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
   }
+  // Inside with_persist_retry results are handed to the caller only once the solve is known to stand (single rank: no time-out seen;
+  // several ranks: the joint decision has been taken) -- until then the caller's x still holds the initial guess a re-run starts from.
+  struct PendingOut { double *user; const double *dev; int64_t n; int memspace; };
+  std::vector<PendingOut> pending_out;
+  bool defer_out = false;
   void out_vec(double *user, const double *dev, int64_t n, int memspace)
   {
+    if (defer_out) { pending_out.push_back({user, dev, n, memspace}); return; }
     if (memspace == GMG_MEM_DEVICE) {
       if (user != dev) copy(user, dev, n);
       HIP_CHECK(hipStreamSynchronize(stream));
@@ -2693,7 +2768,7 @@ struct gmg_solver {
     sell_maxpad = opt_num("GMG_SELL_MAXPAD", 1.25);
     nt_loads = opt_int("GMG_NT", 1);
     nt_rowwise = opt_int("GMG_NT_ROWWISE", 1);
-    xcd_remap_big = opt_int("GMG_XCD_REMAP_BIG", 0);
+    xcd_remap_big = opt_int("GMG_XCD_REMAP_BIG", -1);
     big_rows = (int64_t)opt_int("GMG_BIG_ROWS", 4000000);
     sell_defer = opt_int("GMG_SELL_DEFER", 1);
     use_pattern = opt_int("GMG_PATTERN", 1);
@@ -2704,6 +2779,9 @@ struct gmg_solver {
     prof_stride = std::max(1, opt_int("GMG_PROF_STRIDE", 8));
     pat_defer = opt_int("GMG_PAT_DEFER", 1);
     pat_rsweep = opt_int("GMG_PAT_RSWEEP", 1);
+    pat_r2 = opt_int("GMG_PAT_R2", 1);
+    pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
+    pat_fma = opt_int("GMG_PAT_FMA", 0);
     persist = opt_int("GMG_PERSIST", 1);
     // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
     // could keep each other from becoming fully resident, so they are off unless asked for
@@ -3755,10 +3833,10 @@ struct BandLU {
 void gmg_solver::build_coarse()
 {
   const int64_t n = lev[nlev - 1].n;
-  REQUIRE(!(lev[nlev - 1].sA && coarse_kind == GMG_COARSE_DENSE_INVERSE), GMG_ERR_UNSUPPORTED,
+  REQUIRE(!(lev[nlev - 1].sA && coarse_eff == GMG_COARSE_DENSE_INVERSE), GMG_ERR_UNSUPPORTED,
           "the dense-inverse coarse solver needs the coarsest matrix whole (gmg_set_matrix), not streamed");
-  if (coarse_kind == GMG_COARSE_DENSE_INVERSE) d_Ainv = build_dense_inverse(lev[nlev - 1].hA, "coarsest-level matrix");
-  else if (coarse_kind == GMG_COARSE_CG_JACOBI) { cc_w = dvec(n); cc_p = dvec(n); cc_z = dvec(n); cc_r = dvec(n); }
+  if (coarse_eff == GMG_COARSE_DENSE_INVERSE) d_Ainv = build_dense_inverse(lev[nlev - 1].hA, "coarsest-level matrix");
+  else if (coarse_eff == GMG_COARSE_CG_JACOBI) { cc_w = dvec(n); cc_p = dvec(n); cc_z = dvec(n); cc_r = dvec(n); }
   else {
     REQUIRE(coarse_fn, GMG_ERR_STATE, "coarse-solver callback missing");
     if (h_cr) { (void)hipHostFree(h_cr); (void)hipHostFree(h_cx); h_cr = h_cx = nullptr; }
@@ -3779,9 +3857,15 @@ double *gmg_solver::build_dense_inverse(const HostCSR &A, const std::string &wha
     // the device inversion does not pivot and verifies its result: a matrix that needs pivoting is rejected there -- within
     // reach of the host's pivoted banded LU (seconds up to ~6000 dofs) take that instead of failing the setup
     if (n > opt_int("GMG_COARSE_HOST_FALLBACK_MAX", 6000)) return build_coarse_device(A, what);
+    const size_t mark = allocs.size();
+    const int64_t bytes0 = dev_bytes;
     try {
       return build_coarse_device(A, what);
     } catch (const GmgError &e) {
+      // the scratch of the rejected inversion (n^2 result, padded work copy, panels, CSR upload) goes back before the host takes over
+      HIP_CHECK(hipStreamSynchronize(stream));
+      while (allocs.size() > mark) { (void)hipFree(allocs.back()); allocs.pop_back(); }
+      dev_bytes = bytes0;
       if (e.code != GMG_ERR_SINGULAR) throw;
     }
   }
@@ -3890,6 +3974,7 @@ void gmg_solver::setup()
   HIP_CHECK(hipSetDevice(device));
   free_all();
   read_tuning();
+  resolve_coarse_kind();
   // GMG_SETUP_TIMING=1: per-phase wall times of the numerical setup on stderr
   const bool timing = opt_int("GMG_SETUP_TIMING", 0) != 0;
   auto t_last = std::chrono::steady_clock::now();
@@ -4072,7 +4157,7 @@ void gmg_solver::setup()
       drop_csr_stream(L.R);
       lap("D^-1, patch blocks", l);
     }
-    if (l == nlev - 1 && coarse_kind == GMG_COARSE_CG_JACOBI) {
+    if (l == nlev - 1 && coarse_eff == GMG_COARSE_CG_JACOBI) {
       int nzero = 0;
       L.dinv = build_inv_diag(L.A, nzero);                  // JacobiLinearSolvers.jl:20-23 on the coarsest matrix
       REQUIRE(nzero == 0, GMG_ERR_SINGULAR, "zero diagonal entry on the coarsest level");
@@ -4158,7 +4243,7 @@ void gmg_solver::refresh_values()
       int nzero = 0;
       HIP_CHECK(hipMemcpyAsync(&nzero, d_nzero, sizeof(int), hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
-      const bool need_diag = l < nlev - 1 ? (L.pre.kind == SM_JACOBI || L.post.kind == SM_JACOBI) : coarse_kind == GMG_COARSE_CG_JACOBI;
+      const bool need_diag = l < nlev - 1 ? (L.pre.kind == SM_JACOBI || L.post.kind == SM_JACOBI) : coarse_eff == GMG_COARSE_CG_JACOBI;
       REQUIRE(!(want_dinv && need_diag && nzero > 0), GMG_ERR_SINGULAR, "zero diagonal entry on level " + std::to_string(l));
       L.s0_ready = false;
       if (l < nlev - 1) {
@@ -4166,7 +4251,7 @@ void gmg_solver::refresh_values()
         if (L.pre.kind == SM_PATCH) build_patch(L, L.pre, true);
         if (L.post_shares_pre) L.post = L.pre;
         else if (L.post.kind == SM_PATCH) build_patch(L, L.post, true);
-      } else if (coarse_kind == GMG_COARSE_DENSE_INVERSE) {
+      } else if (coarse_eff == GMG_COARSE_DENSE_INVERSE) {
         release(d_Ainv, (size_t)n * (size_t)n);
         build_coarse();
       }
@@ -4643,7 +4728,7 @@ int gmg_get_coarse_log(gmg_handle_t h, gmg_result *res)
 {
   return guarded(h, [&] {
     REQUIRE(h && res, GMG_ERR_INVALID, "null argument");
-    REQUIRE(h->coarse_kind == GMG_COARSE_CG_JACOBI && !h->coarse_log.residuals.empty(), GMG_ERR_STATE, "no iterative coarse solve has run");
+    REQUIRE(h->coarse_eff == GMG_COARSE_CG_JACOBI && !h->coarse_log.residuals.empty(), GMG_ERR_STATE, "no iterative coarse solve has run");
     h->coarse_log.export_to(res, nullptr, 0, h->coarse_last);
   });
 }
@@ -4665,7 +4750,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_PAT_R2_WGS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

@@ -1611,15 +1611,17 @@ __device__ __forceinline__ int clamp0_med3(int x, int hi)
   return r;
 }
 
-template <int XM, int NB, bool MK, int NT = 0>
+template <int XM, int NB, bool MK, int NT = 0, bool FM = false>
 __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
 {
   constexpr int K = 3, ROWS = 65 - K, RB = 3;
   extern __shared__ double sp_smem[];
   const int nu = K * a.nruns;
   const int tot = a.np * nu;
-  PatEntry *s_tab = reinterpret_cast<PatEntry *>(sp_smem);
+  // LDS: [np*nu] coefficients, dense (absent entries hold 0.0) | strict form (MK): [np*nu] high-word masks behind them, read only by
+  // the rare batches that hold a non-finite value -- the finite path reads 8 B per tap, never 16
   double *s_tab8 = sp_smem;
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x;
@@ -1652,13 +1654,13 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
   };
   int sb = s_begin + wave;
   if (sb < s_end) load_batch(sb);
-  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i]; }
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
   else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
   __syncthreads();
   while (sb < s_end) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const PatEntry *te = s_tab + pid[i] * nu;
+      const uint32_t *tm = s_msk + pid[i] * nu;
       const double *tv = s_tab8 + pid[i] * nu;
       double s = 0.0;
       for (int r0 = 0; r0 < a.nruns; r0 += RB) {
@@ -1685,9 +1687,9 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
 #pragma unroll
             for (int t = 0; t < K; ++t) {
               if (t > 0) c = wave_shl1(c);
-              const PatEntry en = te[(r0 + q) * K + t];
-              const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
-              s = s + en.v * g;
+              const int j = (r0 + q) * K + t;
+              const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
+              s = FM ? __builtin_fma(tv[j], g, s) : s + tv[j] * g;
             }
           }
         } else {
@@ -1698,7 +1700,7 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
             for (int t = 0; t < K; ++t) {
               if (t > 0) c = wave_shl1(c);
               const int j = (r0 + q) * K + t;
-              s = s + (MK ? te[j].v : tv[j]) * c;
+              s = FM ? __builtin_fma(tv[j], c, s) : s + tv[j] * c;
             }
           }
         }
@@ -1718,6 +1720,167 @@ __global__ __launch_bounds__(kBlock) void sells_rsweep_kernel(SellSArgs a)
     }
     sb += wpb * NB;
     if (sb < s_end) load_batch(sb);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The r-gather sweep with TWO rows per lane ("pair sweep").  What sells_rsweep_kernel pays per 62-row slice, by ablation at 128^3
+// (tools/mb_psweep.hip, profiles/r04_tuning.md): ~4 us of launch + skeleton, 2 us of row-wise loads, 3.5 us of stores, 6 us of
+// gathers (every vector-memory instruction moves 8 B per lane: the texture-address path runs at half its rate), 7.5 us of taps of
+// which 54 multiply / add instructions are the arithmetic itself and 18 + 36 + 18 convert the loaded values, shift them across
+// lanes and form addresses.  Here a lane owns rows 2l and 2l+1 of a slice of 126 rows: one 16-byte load per run brings its two
+// window values (the next two come from lane l+1: still 4 DPP moves, now per TWO rows), one 16-byte load / store moves the pair's
+// r, x; per row 9 instead of 18 conversions, 18 instead of 36 DPP moves, half the vector-memory instructions at twice the width.
+// Slices whose windows could leave the vector (the first and last few of a level) and the ragged last slice take element-wise
+// clamped loads and stores; all others need no clamp at all.  Same taps in the same order on the same values: bit-identical to
+// sells_rsweep_kernel (FM = false).  FM: fused multiply-add taps (option pat_fma; one rounding per tap -- not the reference's mul!).
+//   a.x = r_k (gathered) ; a.y = r_{k+1} ; a.s_out = r_{k-1} (XM = 2) ; a.pdinv[0] = d ; a.nslices = ceil(nrows / 126)
+// ---------------------------------------------------------------------------
+typedef double gmg_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gmg_d2 ld2_unaligned(const double *p)
+{
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  return *reinterpret_cast<const d2u *>(p);
+}
+__device__ __forceinline__ void st2_unaligned(double *p, gmg_d2 v)
+{
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  *reinterpret_cast<d2u *>(p) = v;
+}
+
+// NR = number of runs (9: 27-point operators; 3: 9-point) -- compile time, so that the run offsets live in scalar registers (read in the
+// loop from the argument array they are vector loads the gathers then wait for) and the run loop is fully unrolled.
+template <int XM, bool MK, bool FM, int NR>
+__global__ __launch_bounds__(kBlock) void sells_r2sweep_kernel(SellSArgs a)
+{
+  constexpr int K = 3, ROWS2 = 126, RB = 3;
+  extern __shared__ double sp_smem[];
+  const int nu = K * NR;
+  const int tot = a.np * nu;
+  double *s_tab8 = sp_smem;                                   // [np*nu] coefficients, dense | MK: [np*nu] high-word masks
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: `inner` is a uniform branch
+  const int nwg = gridDim.x;
+  const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
+  const int chunk_lo = a.nslices / nwg, chunk_rem = a.nslices % nwg;
+  const int s_begin = blk * chunk_lo + min(blk, chunk_rem);
+  const int s_end = s_begin + chunk_lo + (blk < chunk_rem ? 1 : 0);
+  const double *__restrict__ rg = a.x;
+  const double omega = a.omega;
+  const double du = a.pdinv[0];
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  const bool xz = a.x_zero != 0;
+  // a slice is "inner" when every window of every run and the pair loads of all 64 lanes stay inside the vectors
+  const int lo_need = -a.minoff, hi_need = a.maxoff + 2 * 64 + 2;
+  int roff[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  int pidA = 0, pidB = 0, row = 0;
+  bool inner = false;
+  gmg_d2 e0, e2, rp, A[RB];
+  auto load_slice = [&](int slice) {
+    const int r0 = slice * ROWS2;
+    row = r0 + 2 * lane;
+    inner = r0 >= lo_need && r0 + hi_need <= last && r0 + 2 * 64 <= lastrow;      // wave-uniform
+    e2 = gmg_d2{0.0, 0.0}; rp = gmg_d2{0.0, 0.0};
+    if (inner) {
+      const uint32_t pp = *reinterpret_cast<const uint32_t *>(a.rowpid + row);   // row is even: 4-byte aligned
+      pidA = (int)(pp & 0xffffu); pidB = (int)(pp >> 16);
+      e0 = ld2_unaligned(rg + row);
+      if (XM != 1) { const gmg_d2 xl = ld2_unaligned(a.x2 + row); e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
+      if (XM == 2) rp = ld2_unaligned(a.s_out + row);
+#pragma unroll
+      for (int q = 0; q < RB; ++q) A[q] = ld2_unaligned(rg + row + roff[q]);
+    } else {
+      const int ra = min(row, lastrow), rb = min(row + 1, lastrow);
+      pidA = (int)a.rowpid[ra]; pidB = (int)a.rowpid[rb];
+      e0 = gmg_d2{rg[ra], rg[rb]};
+      if (XM != 1) { const gmg_d2 xl = gmg_d2{a.x2[ra], a.x2[rb]}; e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
+      if (XM == 2) rp = gmg_d2{a.s_out[ra], a.s_out[rb]};
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int c = row + roff[q];
+        A[q] = gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
+      }
+    }
+  };
+  int sb = s_begin + wave;
+  if (sb < s_end) load_slice(sb);
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
+  else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
+  __syncthreads();
+  while (sb < s_end) {
+    const uint32_t *tmA = s_msk + pidA * nu, *tmB = s_msk + pidB * nu;
+    const double *tvA = s_tab8 + pidA * nu, *tvB = s_tab8 + pidB * nu;
+    double sA = 0.0, sB = 0.0;
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += RB) {
+      gmg_d2 cur[RB];
+#pragma unroll
+      for (int q = 0; q < RB; ++q) cur[q] = gmg_d2{omega * (du * A[q].x), omega * (du * A[q].y)};   // s = omega*(Dinv*r): once per loaded value
+      if (r0 + RB < NR) {
+        if (inner) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) A[q] = ld2_unaligned(rg + row + roff[r0 + RB + q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            const int c = row + roff[r0 + RB + q];
+            A[q] = gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
+          }
+        }
+      }
+      bool fin = true;
+      if (MK) {
+#pragma unroll
+        for (int q = 0; q < RB; ++q) fin = fin && __builtin_isfinite(cur[q].x) && __builtin_isfinite(cur[q].y);
+        fin = __all(fin);
+      }
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        // the four window values of this lane's two rows: w0, w1 its own, w2, w3 = lane l+1's w0, w1
+        const double w0 = cur[q].x, w1 = cur[q].y;
+        const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+        const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+        if (MK && !fin) {
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            const int j = (r0 + q) * K + t;
+            const double ga = __hiloint2double(__double2hiint(wa[t]) & (int)tmA[j], __double2loint(wa[t]));
+            const double gb = __hiloint2double(__double2hiint(wb[t]) & (int)tmB[j], __double2loint(wb[t]));
+            sA = FM ? __builtin_fma(tvA[j], ga, sA) : sA + tvA[j] * ga;
+            sB = FM ? __builtin_fma(tvB[j], gb, sB) : sB + tvB[j] * gb;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            const int j = (r0 + q) * K + t;
+            const double ca = tvA[j], cb = tvB[j];
+            sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
+            sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+          }
+        }
+      }
+    }
+    // results of the pair
+    const gmg_d2 rn = gmg_d2{e0.x - sA, e0.y - sB};
+    const gmg_d2 sk = gmg_d2{omega * (du * e0.x), omega * (du * e0.y)};     // the rows' own s_k
+    gmg_d2 xn = gmg_d2{0.0, 0.0};
+    if (XM == 0) xn = gmg_d2{e2.x + sk.x, e2.y + sk.y};
+    else if (XM == 2) xn = gmg_d2{(e2.x + omega * (du * rp.x)) + sk.x, (e2.y + omega * (du * rp.y)) + sk.y};
+    if (lane < 63) {
+      if (inner) {
+        if (XM != 1) st2_unaligned(a.x2 + row, xn);
+        st2_unaligned(a.y + row, rn);
+      } else {
+        if (row <= lastrow) { if (XM != 1) a.x2[row] = xn.x; a.y[row] = rn.x; }
+        if (row + 1 <= lastrow) { if (XM != 1) a.x2[row + 1] = xn.y; a.y[row + 1] = rn.y; }
+      }
+    }
+    sb += wpb;
+    if (sb < s_end) load_slice(sb);
   }
 }
 
@@ -1742,7 +1905,7 @@ struct SellTile {
   int elems;                // staged values per tile
 };
 
-template <int XM, bool MK, int WPB>
+template <int XM, bool MK, int WPB, bool FM = false>
 __global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, SellTile tl)
 {
   constexpr int K = 3, ROWS = 65 - K, RB = 3, SPW = 3;       // T <= SPW * WPB slices per tile: slice j of the tile belongs to wave j % WPB
@@ -1750,8 +1913,9 @@ __global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, Sel
   extern __shared__ double sp_smem[];
   const int nu = K * a.nruns;
   const int tot = a.np * nu;
-  PatEntry *s_tab = reinterpret_cast<PatEntry *>(sp_smem);
+  // LDS: [np*nu] coefficients, dense | strict form (MK): [np*nu] high-word masks (only read by batches holding a non-finite value) | stage
   double *s_tab8 = sp_smem;
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
   double *s_stage = sp_smem + (MK ? 2 : 1) * (size_t)tot;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ntiles = (a.nslices + T - 1) / T;
@@ -1761,7 +1925,7 @@ __global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, Sel
   const int last = (int)a.ncols - 1;
   const int lastrow = (int)a.nrows - 1;
   const bool xz = a.x_zero != 0;
-  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i]; }
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
   else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
   // (requesting the next tile's stretches and row-wise operands a tile ahead was tried: the registers it takes leave ONE workgroup
   // per CU instead of two, and the sweep got slower -- 223 instead of 210 us at 288^3; two resident workgroups overlap their phases)
@@ -1801,7 +1965,7 @@ __global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, Sel
     for (int i = 0; i < SPW; ++i) {
       if (!live[i]) continue;                                // uniform in the wave
       const int rel = (wave + i * WPB) * ROWS + lane;
-      const PatEntry *te = s_tab + pid[i] * nu;
+      const uint32_t *tm = s_msk + pid[i] * nu;
       const double *tv = s_tab8 + pid[i] * nu;
       double s = 0.0;
       for (int r0 = 0; r0 < a.nruns; r0 += RB) {
@@ -1821,9 +1985,9 @@ __global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, Sel
 #pragma unroll
             for (int t = 0; t < K; ++t) {
               if (t > 0) c = wave_shl1(c);
-              const PatEntry en = te[(r0 + q) * K + t];
-              const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
-              s = s + en.v * g;
+              const int j = (r0 + q) * K + t;
+              const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
+              s = FM ? __builtin_fma(tv[j], g, s) : s + tv[j] * g;
             }
           }
         } else {
@@ -1834,7 +1998,7 @@ __global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, Sel
             for (int t = 0; t < K; ++t) {
               if (t > 0) c = wave_shl1(c);
               const int j = (r0 + q) * K + t;
-              s = s + (MK ? te[j].v : tv[j]) * c;
+              s = FM ? __builtin_fma(tv[j], c, s) : s + tv[j] * c;
             }
           }
         }

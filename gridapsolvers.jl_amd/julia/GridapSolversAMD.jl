@@ -91,9 +91,14 @@ struct HipGMGLinearSolver{A,B,C,D,E,F} <: Gridap.Algebra.LinearSolver
   cycle_type     :: Symbol
   log            :: ConvergenceLog{Float64}
   device         :: Int
+  options        :: Dict{String,Float64}   # device-side policy handed to gmg_set_option before the operators are set (keys: include/gmg_amd.h)
+  pin_vectors    :: Bool                   # page-lock the Vector{Float64}s solve! is called with, once (PETScCaches.jl:23-36 pins its x / b the same way)
 end
 
-# Same keyword surface as GMGLinearSolver(smatrices,interp,restrict;...) GMGLinearSolvers.jl:48-69
+# Same keyword surface as GMGLinearSolver(smatrices,interp,restrict;...) GMGLinearSolvers.jl:48-69, plus three keywords the
+# reference has no use for: `device`, `options` (layout / schedule policy of THIS solver: e.g. Dict("pat_tile"=>2, "persist"=>0,
+# "x0_zero"=>1); unknown keys are rejected by the library) and `pin_vectors` (default true: the vectors solve! sees are page-locked
+# once and then move over PCIe by DMA at the link rate -- 3.6 ms instead of 4.7 ms per config-2 solve; the setup keeps them alive)
 function HipGMGLinearSolver(
   smatrices::AbstractArray{<:AbstractMatrix}, interp::AbstractArray, restrict = nothing;
   pre_smoothers  = fill(RichardsonSmoother(JacobiLinearSolver(),10),length(smatrices)-1),
@@ -101,6 +106,7 @@ function HipGMGLinearSolver(
   coarsest_solver = Gridap.Algebra.LUSolver(),
   mode = :preconditioner, cycle_type = :v_cycle,
   maxiter = 100, atol = 1.0e-14, rtol = 1.0e-08, verbose = false, device = 0,
+  options = Dict{String,Float64}(), pin_vectors = true,
 )
   nlev = length(smatrices)
   @assert nlev-1 == length(interp) == length(pre_smoothers) == length(post_smoothers)
@@ -109,7 +115,8 @@ function HipGMGLinearSolver(
   @assert cycle_type ∈ [:v_cycle,:w_cycle,:f_cycle]
   tols = SolverTolerances{Float64}(;maxiter=maxiter,atol=atol,rtol=rtol)
   log  = ConvergenceLog("GMG-MI355X",tols;verbose=verbose)
-  return HipGMGLinearSolver(smatrices,interp,restrict,pre_smoothers,post_smoothers,coarsest_solver,mode,cycle_type,log,device)
+  opts = Dict{String,Float64}(string(k) => Float64(v) for (k,v) in pairs(options))
+  return HipGMGLinearSolver(smatrices,interp,restrict,pre_smoothers,post_smoothers,coarsest_solver,mode,cycle_type,log,device,opts,pin_vectors)
 end
 
 struct HipGMGSymbolicSetup{A} <: Gridap.Algebra.SymbolicSetup
@@ -122,7 +129,44 @@ mutable struct HipGMGNumericalSetup{A} <: Gridap.Algebra.NumericalSetup
   handle :: Ptr{Cvoid}
   n      :: Int
   keepalive :: Any          # Julia objects the handle points at (coarse-solver callback context)
-  HipGMGNumericalSetup(solver::A, handle, n) where A = new{A}(solver, handle, n, nothing)
+  pinned :: Vector{Vector{Float64}}   # vectors registered with gmg_host_register: referenced here so that they outlive their registration
+  HipGMGNumericalSetup(solver::A, handle, n) where A = new{A}(solver, handle, n, nothing, Vector{Float64}[])
+end
+
+# gmg_set_option / gmg_get_option: per-handle layout and schedule policy (live options act at the next call, the others at the
+# next gmg_setup -- call numerical_setup! or set them through the solver's `options` keyword instead)
+function set_option!(ns::HipGMGNumericalSetup, key, value::Real)
+  check(ns.handle, ccall((:gmg_set_option, libgmgamd), Cint, (Ptr{Cvoid},Cstring,Float64), ns.handle, string(key), Float64(value)))
+  return ns
+end
+function get_option(ns::HipGMGNumericalSetup, key)
+  v, src = Ref(0.0), Ref(Cint(0))
+  check(ns.handle, ccall((:gmg_get_option, libgmgamd), Cint, (Ptr{Cvoid},Cstring,Ref{Float64},Ref{Cint}), ns.handle, string(key), v, src))
+  return (isnan(v[]) ? nothing : v[], (:default, :handle, :environment)[src[]+1])
+end
+
+# Page-lock the vectors of a solve once (gmg_host_register); at most 8 are held, the oldest is released first.  A Julia Array never
+# moves, and the setup holds a reference, so the registered pages stay valid until gmg_host_unregister / finalize.
+function pin!(ns::HipGMGNumericalSetup, vs::Vector{Float64}...)
+  for v in vs
+    any(p -> p === v, ns.pinned) && continue
+    if length(ns.pinned) >= 8
+      old = popfirst!(ns.pinned)
+      GC.@preserve old ccall((:gmg_host_unregister, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid}), ns.handle, pointer(old))
+    end
+    GC.@preserve v check(ns.handle, ccall((:gmg_host_register, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid},Int64), ns.handle, pointer(v), sizeof(v)))
+    push!(ns.pinned, v)
+  end
+  return ns
+end
+_maybe_pin!(ns::HipGMGNumericalSetup, vs...) = ns.solver.pin_vectors ? pin!(ns, vs...) : ns
+
+# Vectors that already live on the device (e.g. AMDGPU.ROCArray): wrap their pointer; solve! then passes GMG_MEM_DEVICE and nothing
+# crosses PCIe.  `owner` keeps the array alive.
+struct HipDeviceVector
+  ptr   :: Ptr{Float64}
+  n     :: Int
+  owner :: Any
 end
 
 # --- operator upload: SparseMatrixCSC{Float64,Ti} is CSC / 1-based / sizeof(Ti) bytes ----
@@ -196,7 +240,10 @@ function Gridap.Algebra.numerical_setup(ss::HipGMGSymbolicSetup, mat::AbstractMa
   check(C_NULL, ccall((:gmg_create, libgmgamd), Cint, (Ref{Ptr{Cvoid}},Cint,Cint), href, nlev, s.device))
   h = href[]
   ns = HipGMGNumericalSetup(s, h, size(mat,1))
-  finalizer(x -> (x.handle != C_NULL && ccall((:gmg_destroy, libgmgamd), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), ns)
+  finalizer(x -> (x.handle != C_NULL && ccall((:gmg_destroy, libgmgamd), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL; empty!(x.pinned)), ns)
+  for (k,v) in s.options                                          # policy first: some options act while the operators are handed over
+    set_option!(ns, k, v)
+  end
   for l in 1:nlev
     _set_op(:matrix, h, l-1, l == 1 ? mat : s.smatrices[l])       # smatrices[1] = mat (:338)
   end
@@ -260,10 +307,26 @@ function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipGMGNumericalSetup, b::
   log  = ns.solver.log
   res  = Ref(GmgResult(0,0,0.0,0.0))
   hist = zeros(log.tols.maxiter+1)
+  _maybe_pin!(ns, x, b)
   GC.@preserve x b hist begin
     check(ns.handle, ccall((:gmg_apply, libgmgamd), Cint,
       (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Ref{GmgResult},Ptr{Float64},Cint),
       ns.handle, b, x, GMG_MEM_HOST, res, hist, length(hist)))
+  end
+  _fill_log!(log, res[], hist)
+  return x
+end
+# the same on device-resident vectors: one V-cycle per call costs no PCIe traffic (the way to use the library as the preconditioner
+# of a Krylov loop that itself runs on the GPU)
+function Gridap.Algebra.solve!(x::HipDeviceVector, ns::HipGMGNumericalSetup, b::HipDeviceVector)
+  @assert x.n == b.n == ns.n
+  log  = ns.solver.log
+  res  = Ref(GmgResult(0,0,0.0,0.0))
+  hist = zeros(log.tols.maxiter+1)
+  GC.@preserve x b hist begin
+    check(ns.handle, ccall((:gmg_apply, libgmgamd), Cint,
+      (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Ref{GmgResult},Ptr{Float64},Cint),
+      ns.handle, b.ptr, x.ptr, GMG_MEM_DEVICE, res, hist, length(hist)))
   end
   _fill_log!(log, res[], hist)
   return x
@@ -333,6 +396,7 @@ function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<
   tols = s.log.tols
   res  = Ref(GmgResult(0,0,0.0,0.0))
   hist = zeros(tols.maxiter+1)
+  _maybe_pin!(ns.P_ns, x, b)
   GC.@preserve x b hist begin
     check(h, ccall((:gmg_cg_solve, libgmgamd), Cint,
       (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Cint,Float64,Float64,Cint,Cint,Ref{GmgResult},Ptr{Float64},Cint),
@@ -347,6 +411,7 @@ function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<
   tols = s.log.tols
   res  = Ref(GmgResult(0,0,0.0,0.0))
   hist = zeros(tols.maxiter+1)
+  _maybe_pin!(ns.P_ns, x, b)
   GC.@preserve x b hist begin
     check(h, ccall((:gmg_fgmres_solve, libgmgamd), Cint,
       (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Cint,Cint,Cint,Cint,Float64,Float64,Cint,Ref{GmgResult},Ptr{Float64},Cint),
@@ -372,6 +437,7 @@ function Gridap.Algebra.solve!(x::Vector{Float64}, ns::HipKrylovNumericalSetup{<
   tols = s.log.tols
   res  = Ref(GmgResult(0,0,0.0,0.0))
   hist = zeros(tols.maxiter+1)
+  _maybe_pin!(ns.P_ns, x, b)
   GC.@preserve x b hist begin
     check(h, ccall((:gmg_richardson_solve, libgmgamd), Cint,
       (Ptr{Cvoid},Ptr{Float64},Ptr{Float64},Cint,Float64,Cint,Float64,Float64,Cint,Ref{GmgResult},Ptr{Float64},Cint),

@@ -308,7 +308,7 @@ def test_bench_multi_rank_path_with_overlapping_levels(tmp_path):
                           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["n_gpus"] == 2 and d["headline_leg"] == "default" and d["roofline"]["leg"] == "default" and d["roofline_generic"]["leg"] == "generic"
+    assert d["n_gpus"] == 2 and d["headline_leg"] == "default" and d["roofline_compressed"]["leg"] == "default" and d["roofline"]["leg"] == "generic"
     assert d["config"]["halo_depths"][:3] == [0, 5, 0] and d["config"]["replicated_from_level"] == 2
     assert d["config"]["cg_iterations"] == d["config"]["cg_iterations_generic"] <= 4 and d["config"]["max_abs_error_vs_exact"] < 1e-4
     assert d["value_generic"] > 0 and d["config"]["halo_exchanges_per_solve"] > 0
@@ -332,6 +332,10 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(tmp_path):
     assert d["config"]["transport"] == "host" and d["config"]["degraded"] is True
     assert d["config"]["cg_iterations"] <= 4 and d["config"]["max_abs_error_vs_exact"] < 1e-4
     assert d["roofline"]["frac"] is None or d["roofline"]["frac"] <= 1.0
+    # the same shape as the N = 1 line: generic leg = `roofline`, default leg = `roofline_compressed`; who took part; the anchor
+    assert d["roofline"]["leg"] == "generic" and d["roofline_compressed"]["leg"] == "default"
+    assert d["rccl_ranks"] == 0 and len(d["devices"]) == 2 and {x["rank"] for x in d["devices"]} == {0, 1}
+    assert d["weak_anchor_value"] > 0 and d["weak_scaling_ref"]["cg_iterations"] == d["config"]["cg_iterations"]
 
 
 @pytest.mark.gpu
