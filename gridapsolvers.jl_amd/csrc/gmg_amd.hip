@@ -554,14 +554,14 @@ struct gmg_solver {
   bool big_level(const DevCSR &M) const { return M.nrows > big_rows; }
   // Workgroup -> row-range mapping of the SELL-64 / SELL-O kernels on a level whose gathered vector exceeds the L2s.  Launch order
   // (0) lets all eight XCDs stream inside one window of the arrays, but neighbouring workgroups sit on different XCDs, so every L2
-  // fetches (nearly) the whole gathered vector: 1.09 x the algorithmic bytes at >= 256^3 (profiles/r03f_288_hbm_traffic.txt).
-  // Contiguous eighths (1) fetch it once but stream from eight far-apart windows.  Chunked (> 1: that many consecutive workgroups
-  // per XCD inside a group of 8 chunks): auto (-1) makes a chunk four gather reaches deep, so the reach above and below a chunk --
-  // what a neighbouring XCD also fetches -- is half of what the chunk itself covers once, and the window stays 32 reaches wide.
+  // fetches (nearly) the whole gathered vector: 1.095 x the algorithmic bytes at 256^3 (7 075 MB per sweep, profiles/r04_tuning.md).
+  // Contiguous eighths (1) fetch it once but stream from eight far-apart windows.  Chunked (n > 1: n consecutive workgroups per XCD
+  // inside a group of 8 chunks) with a chunk two gather reaches deep (auto, -1): 6 483 MB = 1.003 x at 256^3 in the same time as
+  // launch order (1 106 us); four reaches deep moves the same bytes 4 % slower, so the chunk is kept as small as the reach allows.
   int remap_for_big(const DevCSR &M, int rows_per_wg, int nwg) const
   {
     if (xcd_remap_big >= 0) return xcd_remap_big == 1 ? xcd_remap : xcd_remap_big;
-    const int64_t want = (4 * std::max<int64_t>(M.band, 1) + rows_per_wg - 1) / rows_per_wg;
+    const int64_t want = (2 * std::max<int64_t>(M.band, 1) + rows_per_wg - 1) / rows_per_wg;
     if (want < 2 || want * 8 * 4 > nwg) return 0;           // no locality to win / the window would span a quarter of the level: launch order
     return (int)want;
   }
@@ -588,7 +588,7 @@ struct gmg_solver {
   uint32_t *d_perr_dev = nullptr;                  // device-memory twin (the kernel's end-of-pass check)
   uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
-  int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: GMG_PAT_WGS)
+  int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU)
   int pat_fma = 0;      // GMG_PAT_FMA: fused multiply-add taps in the row-pattern sweeps (one rounding per tap: not the reference's mul! arithmetic)
   int pat_rsweep = 1;   // GMG_PAT_RSWEEP: sweeps of uniform-diagonal row-pattern levels gather r itself (no s vector: sells_rsweep_kernel)
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
@@ -1864,7 +1864,8 @@ struct gmg_solver {
     if (pat_r2 && (M.pat_nruns == 9 || M.pat_nruns == 3)) {
       const int nsl2 = (int)((M.nrows + 125) / 126);
       a.nslices = nsl2;
-      const int wgr = std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : pat_wgs));
+      // one round of four workgroups per CU: 1024 (128^3: 17.4 us per sweep; 768: 19.2, 1280: 20.8, 2048: 19.1 -- profiles/r04_tuning.md)
+      const int wgr = std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : 4 * n_cus));
       const dim3 gr(wgr);
       M.note_sweep("sells_r2sweep_kernel<XM=*,MK=%d,FM=%d,NR=%d> wgs=%d wpb=%d", mk ? 1 : 0, pat_fma ? 1 : 0, M.pat_nruns, wgr, wpb);
 #define GMG_R2_LAUNCH2(XMV, MKV, FMV)                                                                            \
@@ -2779,6 +2780,11 @@ struct gmg_solver {
     prof_stride = std::max(1, opt_int("GMG_PROF_STRIDE", 8));
     pat_defer = opt_int("GMG_PAT_DEFER", 1);
     pat_rsweep = opt_int("GMG_PAT_RSWEEP", 1);
+    if (n_cus <= 0) {
+      int v = 0;
+      HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device));
+      n_cus = std::max(1, v);
+    }
     pat_r2 = opt_int("GMG_PAT_R2", 1);
     pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
     pat_fma = opt_int("GMG_PAT_FMA", 0);

@@ -1832,35 +1832,40 @@ __global__ __launch_bounds__(kBlock) void sells_r2sweep_kernel(SellSArgs a)
           }
         }
       }
-      bool fin = true;
-      if (MK) {
-#pragma unroll
-        for (int q = 0; q < RB; ++q) fin = fin && __builtin_isfinite(cur[q].x) && __builtin_isfinite(cur[q].y);
-        fin = __all(fin);
-      }
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         // the four window values of this lane's two rows: w0, w1 its own, w2, w3 = lane l+1's w0, w1
         const double w0 = cur[q].x, w1 = cur[q].y;
         const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
         const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
-        if (MK && !fin) {
 #pragma unroll
-          for (int t = 0; t < K; ++t) {
-            const int j = (r0 + q) * K + t;
-            const double ga = __hiloint2double(__double2hiint(wa[t]) & (int)tmA[j], __double2loint(wa[t]));
-            const double gb = __hiloint2double(__double2hiint(wb[t]) & (int)tmB[j], __double2loint(wb[t]));
-            sA = FM ? __builtin_fma(tvA[j], ga, sA) : sA + tvA[j] * ga;
-            sB = FM ? __builtin_fma(tvB[j], gb, sB) : sB + tvB[j] * gb;
-          }
-        } else {
+        for (int t = 0; t < K; ++t) {
+          const int j = (r0 + q) * K + t;
+          const double ca = tvA[j], cb = tvB[j];
+          sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
+          sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+        }
+      }
+    }
+    // Strict form: absent entries hold 0.0, so with finite window values their products are exact zeros and the sums above ARE the
+    // masked sums.  A non-finite value in reach turns every sum it touches into NaN / Inf -- through a stored coefficient or through
+    // 0 x Inf = NaN of an absent one -- so "all sums finite" proves no mask was needed; otherwise (rare: a vector that already holds
+    // Inf / NaN) the slice is redone with the masks, which confine the value to the rows that store a coefficient for it.
+    if (MK && !__all(__builtin_isfinite(sA) && __builtin_isfinite(sB))) {
+      sA = 0.0; sB = 0.0;
+#pragma unroll 1
+      for (int q = 0; q < NR; ++q) {
+        const int c = row + roff[q];
+        const double w0 = omega * (du * rg[min(max(c, 0), last)]), w1 = omega * (du * rg[min(max(c + 1, 0), last)]);
+        const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+        const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
 #pragma unroll
-          for (int t = 0; t < K; ++t) {
-            const int j = (r0 + q) * K + t;
-            const double ca = tvA[j], cb = tvB[j];
-            sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
-            sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
-          }
+        for (int t = 0; t < K; ++t) {
+          const int j = q * K + t;
+          const double ga = __hiloint2double(__double2hiint(wa[t]) & (int)tmA[j], __double2loint(wa[t]));
+          const double gb = __hiloint2double(__double2hiint(wb[t]) & (int)tmB[j], __double2loint(wb[t]));
+          sA = FM ? __builtin_fma(tvA[j], ga, sA) : sA + tvA[j] * ga;
+          sB = FM ? __builtin_fma(tvB[j], gb, sB) : sB + tvB[j] * gb;
         }
       }
     }
@@ -1972,34 +1977,29 @@ __global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, Sel
         double cur[RB];
 #pragma unroll
         for (int q = 0; q < RB; ++q) cur[q] = s_stage[tl.run_lds[r0 + q] + rel];
-        bool fin = true;
-        if (MK) {
 #pragma unroll
-          for (int q = 0; q < RB; ++q) fin = fin && __builtin_isfinite(cur[q]);
-          fin = __all(fin);
-        }
-        if (MK && !fin) {
+        for (int q = 0; q < RB; ++q) {
+          double c = cur[q];
 #pragma unroll
-          for (int q = 0; q < RB; ++q) {
-            double c = cur[q];
-#pragma unroll
-            for (int t = 0; t < K; ++t) {
-              if (t > 0) c = wave_shl1(c);
-              const int j = (r0 + q) * K + t;
-              const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
-              s = FM ? __builtin_fma(tv[j], g, s) : s + tv[j] * g;
-            }
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) c = wave_shl1(c);
+            const int j = (r0 + q) * K + t;
+            s = FM ? __builtin_fma(tv[j], c, s) : s + tv[j] * c;
           }
-        } else {
+        }
+      }
+      // strict form: "every sum of the slice finite" proves that no mask was needed (see sells_r2sweep_kernel); otherwise the slice
+      // is redone from the staged windows with the masks
+      if (MK && !__all(__builtin_isfinite(s))) {
+        s = 0.0;
+        for (int r0 = 0; r0 < a.nruns; ++r0) {
+          double c = s_stage[tl.run_lds[r0] + rel];
 #pragma unroll
-          for (int q = 0; q < RB; ++q) {
-            double c = cur[q];
-#pragma unroll
-            for (int t = 0; t < K; ++t) {
-              if (t > 0) c = wave_shl1(c);
-              const int j = (r0 + q) * K + t;
-              s = FM ? __builtin_fma(tv[j], c, s) : s + tv[j] * c;
-            }
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) c = wave_shl1(c);
+            const int j = r0 * K + t;
+            const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
+            s = FM ? __builtin_fma(tv[j], g, s) : s + tv[j] * g;
           }
         }
       }
