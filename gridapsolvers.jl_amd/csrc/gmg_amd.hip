@@ -493,7 +493,7 @@ struct gmg_solver {
   {
     coarse_eff = coarse_kind; coarse_auto = false;
     const int amin = opt_int("GMG_COARSE_AUTO_CG_MIN", 20000);
-    if (coarse_kind == GMG_COARSE_DENSE_INVERSE && amin > 0 && nlev > 0 && lev[nlev - 1].n >= amin) { coarse_eff = GMG_COARSE_CG_JACOBI; coarse_auto = true; }
+    if (coarse_kind == GMG_COARSE_DENSE_INVERSE && amin > 0 && nlev > 0 && lev[nlev - 1].hA.nrows >= amin) { coarse_eff = GMG_COARSE_CG_JACOBI; coarse_auto = true; }
   }
   int coarse_maxiter = 1000;                 // CGSolver defaults, CGSolvers.jl:19
   double coarse_atol = 1e-12, coarse_rtol = 1e-6;
@@ -2171,8 +2171,41 @@ struct gmg_solver {
     spmv_resid(lev[l].A, x, b, y);
     finish_ghost<1>(l, x, y);
   }
+  // The one value per Krylov iteration the host needs (the residual norm: the stopping rule of ConvergenceLogs.jl:101-150 is evaluated
+  // on the host).  A copy + hipStreamSynchronize leaves the GPU idle for 23-39 us per iteration (profiles/r04_tuning.md: the blocking
+  // wait's wake-up); instead a one-lane kernel posts {value, sequence number} into page-locked host memory the device can write
+  // (system-scope stores: value first, then the number, release) and the host spins on the number -- the stream stays in order, so
+  // everything issued before has completed when the number arrives.  Option host_poll = 0 restores the copy + synchronize.
+  struct Mail { double value; unsigned long long seq; };
+  Mail *h_mail = nullptr, *d_mail = nullptr;
+  unsigned long long mail_seq = 0;
   double fetch_scalar(int slot)
   {
+    if (opt_int("GMG_HOST_POLL", 1)) {
+      if (!h_mail) {
+        HIP_CHECK(hipHostMalloc((void **)&h_mail, 64, hipHostMallocMapped));
+        h_mail->value = 0.0; h_mail->seq = 0;
+        HIP_CHECK(hipHostGetDevicePointer((void **)&d_mail, h_mail, 0));
+      }
+      const unsigned long long want = ++mail_seq;
+      hipLaunchKernelGGL(post_scalar_kernel, dim3(1), dim3(1), 0, stream, d_scalars + slot, &d_mail->value, &d_mail->seq, want);
+      HIP_CHECK(hipGetLastError());
+      volatile unsigned long long *seq = &h_mail->seq;
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) {
+        if ((++spins & 0x3ff) == 0) {
+          // a launch that failed would never post: look at the stream every ~1000 polls, give up on polling after 2 s
+          const hipError_t q = hipStreamQuery(stream);
+          if (q != hipSuccess && q != hipErrorNotReady) HIP_CHECK(q);
+          if (q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != want &&
+              std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+            throw GmgError{GMG_ERR_HIP, "the device never posted the residual norm (host-mapped memory not visible?): set option host_poll = 0"};
+        }
+      }
+      check_persistent();
+      return h_mail->value;
+    }
     HIP_CHECK(hipMemcpyAsync(h_scalars + slot, d_scalars + slot, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     check_persistent();
@@ -3528,35 +3561,6 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   std::vector<double> ubinv((size_t)S.n_ubinv);
   HIP_CHECK(hipMemcpyAsync(ubinv.data(), S.d_ubinv, sizeof(double) * (size_t)S.n_ubinv, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
-  // slot -> patch, dof -> slots in ascending patch order
-  std::vector<int32_t> s2p((size_t)ne);
-  parallel_for(npatch, [&](int64_t p) { for (int64_t q = T.pptr[p]; q < T.pptr[p + 1]; ++q) s2p[(size_t)q] = (int32_t)p; });
-  // (counting sort over 4.6e8 slots at 256^3 Q2: counted and scattered by all cores with relaxed atomic increments, then every
-  // dof's short list is sorted back into ascending slot = patch order -- the result does not depend on the interleaving)
-  std::vector<int64_t> iptr((size_t)n + 1, 0);
-  std::vector<int32_t> inc((size_t)ne);
-  {
-    const int64_t TQ = std::max<int64_t>(1, std::min<int64_t>(64, ne / (1 << 20)));
-    const int64_t perq = (ne + TQ - 1) / TQ;
-    parallel_chunks(TQ, [&](int64_t t) {
-      for (int64_t q = t * perq; q < std::min(ne, (t + 1) * perq); ++q) __atomic_fetch_add(&iptr[(size_t)T.prow[(size_t)q] + 1], (int64_t)1, __ATOMIC_RELAXED);
-    });
-    for (int64_t i = 0; i < n; ++i) iptr[(size_t)i + 1] += iptr[(size_t)i];
-    std::vector<int64_t> fill(iptr.begin(), iptr.end() - 1);
-    parallel_chunks(TQ, [&](int64_t t) {
-      for (int64_t q = t * perq; q < std::min(ne, (t + 1) * perq); ++q)
-        inc[(size_t)__atomic_fetch_add(&fill[(size_t)T.prow[(size_t)q]], (int64_t)1, __ATOMIC_RELAXED)] = (int32_t)q;
-    });
-    const int64_t TD = std::max<int64_t>(1, std::min<int64_t>(64, n / (1 << 18)));
-    const int64_t perd = (n + TD - 1) / TD;
-    parallel_chunks(TD, [&](int64_t t) {
-      for (int64_t i = t * perd; i < std::min(n, (t + 1) * perd); ++i) {
-        int32_t *lo = inc.data() + iptr[(size_t)i], *hi = inc.data() + iptr[(size_t)i + 1];
-        if (hi - lo > 1) std::sort(lo, hi);
-      }
-    });
-  }
-  sub("slot lists (counting sort)");
   // exact numbering of integer sequences: ids by first appearance (two parallel passes + a short sequential one)
   auto sequence_ids = [&](int64_t nitems, auto len, auto word, std::vector<int32_t> &ids, std::vector<int64_t> &rep, int max_ids) -> bool {
     ids.assign((size_t)nitems, -1);
@@ -3632,6 +3636,129 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
                     [&](int64_t p, int j) { return (int64_t)T.prow[(size_t)(T.pptr[p] + j)] - (int64_t)T.prow[(size_t)T.pptr[p]]; }, shape, shape_rep, 4096))
     return;
   sub("patch shapes");
+  // ---- which patches touch a dof (ascending patch order) and one signature per row: on the device (option patch_op_device, default)
+  //      -- 4.6e8 slots / 1.3e8 rows at 256^3 Q2 took 2.1 s on 16 host cores -- or on the host
+  std::vector<int64_t> iptr;
+  std::vector<int32_t> inc, s2p, sig;
+  std::vector<int64_t> sig_rep;
+  std::vector<std::vector<int32_t>> rep_slots;               // slots of every representative row, ascending
+  std::vector<uint16_t> rowpid_dev;
+  bool on_device = opt_int("GMG_PATCH_OP_DEVICE", 1) != 0 && S.d_pptr && S.d_pdofs && S.d_ublock && n + 1 < (int64_t)INT32_MAX;
+  if (on_device) {
+    const size_t mark = allocs.size();
+    const int64_t bytes0 = dev_bytes;
+    auto drop_scratch = [&]() { HIP_CHECK(hipStreamSynchronize(stream)); while (allocs.size() > mark) { (void)hipFree(allocs.back()); allocs.pop_back(); } dev_bytes = bytes0; };
+    int32_t *d_shape = upload(shape);
+    int32_t *d_iptr = dalloc<int32_t>((size_t)n + 2), *d_fill = dalloc<int32_t>((size_t)n + 1), *d_inc = dalloc<int32_t>((size_t)ne), *d_s2p = dalloc<int32_t>((size_t)ne);
+    const int nb = (int)((n + kScanTile - 1) / kScanTile);
+    int32_t *d_tot = dalloc<int32_t>((size_t)nb + 1);
+    unsigned long long *d_hash = dalloc<unsigned long long>((size_t)n);
+    HIP_CHECK(hipMemsetAsync(d_fill, 0, sizeof(int32_t) * ((size_t)n + 1), stream));
+    const dim3 gs((unsigned)std::min<int64_t>((ne + 255) / 256, 1 << 20)), gn((unsigned)std::min<int64_t>((n + 255) / 256, 1 << 20)), b256(256);
+    hipLaunchKernelGGL(slot_count_kernel, gs, b256, 0, stream, ne, S.d_pdofs, d_fill);
+    hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, stream, n, d_fill, d_iptr, d_tot);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(1024), 0, stream, nb, d_tot);
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, stream, n, d_iptr, d_tot, (int32_t)ne);
+    HIP_CHECK(hipMemsetAsync(d_fill, 0, sizeof(int32_t) * ((size_t)n + 1), stream));
+    hipLaunchKernelGGL(slot_scatter_kernel, gs, b256, 0, stream, ne, S.d_pdofs, d_iptr, d_fill, d_inc);
+    hipLaunchKernelGGL(slot_sort_kernel, gn, b256, 0, stream, n, d_iptr, d_inc);
+    hipLaunchKernelGGL(slot_patch_kernel, dim3((unsigned)std::min<int64_t>((npatch + 255) / 256, 1 << 20)), b256, 0, stream, npatch, S.d_pptr, d_s2p);
+    hipLaunchKernelGGL(row_sig_hash_kernel, gn, b256, 0, stream, n, d_iptr, d_inc, d_s2p, S.d_pptr, S.d_pdofs, S.d_ublock, d_shape, d_hash);
+    HIP_CHECK(hipGetLastError());
+    std::vector<unsigned long long> hash((size_t)n);
+    HIP_CHECK(hipMemcpyAsync(hash.data(), d_hash, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    sub("slot lists + row hashes (device)");
+    // distinct hashes and the first row that carries each: per chunk, then merged
+    const int TN = (int)std::max<int64_t>(1, std::min<int64_t>(64, n / (1 << 18)));
+    const int64_t pern = (n + TN - 1) / TN;
+    std::vector<std::vector<std::pair<unsigned long long, int64_t>>> found((size_t)TN);
+    std::atomic<bool> over(false);
+    parallel_chunks(TN, [&](int64_t t) {
+      std::unordered_map<unsigned long long, int64_t> first;
+      unsigned long long last_h = 0; bool have_last = false;
+      for (int64_t i = t * pern; i < std::min(n, (t + 1) * pern); ++i) {
+        const unsigned long long h = hash[(size_t)i];
+        if (have_last && h == last_h) continue;
+        last_h = h; have_last = true;
+        if (first.emplace(h, i).second && first.size() > 8192) { over.store(true); return; }
+      }
+      found[(size_t)t].assign(first.begin(), first.end());
+    });
+    std::unordered_map<unsigned long long, int64_t> groups;
+    if (!over.load())
+      for (auto &f : found)
+        for (auto &kv : f) { auto it = groups.find(kv.first); if (it == groups.end()) groups.emplace(kv.first, kv.second); else it->second = std::min(it->second, kv.second); }
+    if (over.load() || groups.size() > 4096) { drop_scratch(); return; }
+    std::vector<std::pair<int64_t, unsigned long long>> byrow;
+    for (auto &kv : groups) byrow.emplace_back(kv.second, kv.first);
+    std::sort(byrow.begin(), byrow.end());                    // ids by first appearance
+    const int ng = (int)byrow.size();
+    std::vector<std::pair<unsigned long long, int32_t>> byhash((size_t)ng);
+    for (int g = 0; g < ng; ++g) { byhash[(size_t)g] = {byrow[(size_t)g].second, (int32_t)g}; sig_rep.push_back(byrow[(size_t)g].first); }
+    std::sort(byhash.begin(), byhash.end());
+    std::vector<unsigned long long> ghash((size_t)ng);
+    std::vector<int64_t> grep((size_t)ng);
+    std::vector<int32_t> gid((size_t)ng);
+    for (int g = 0; g < ng; ++g) { ghash[(size_t)g] = byhash[(size_t)g].first; gid[(size_t)g] = byhash[(size_t)g].second; grep[(size_t)g] = sig_rep[(size_t)gid[(size_t)g]]; }
+    unsigned long long *d_ghash = upload(ghash);
+    int64_t *d_grep = upload(grep);
+    int32_t *d_gid = upload(gid);
+    uint16_t *d_rowpid = dalloc<uint16_t>((size_t)n);
+    int *d_nmis = dalloc<int>(1);
+    HIP_CHECK(hipMemsetAsync(d_nmis, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(row_sig_assign_kernel, gn, b256, 0, stream, n, d_iptr, d_inc, d_s2p, S.d_pptr, S.d_pdofs, S.d_ublock, d_shape, d_hash, ng, d_ghash, d_grep,
+                       d_gid, d_rowpid, d_nmis);
+    HIP_CHECK(hipGetLastError());
+    int nmis = 0;
+    HIP_CHECK(hipMemcpyAsync(&nmis, d_nmis, sizeof(int), hipMemcpyDeviceToHost, stream));
+    rowpid_dev.resize((size_t)n);
+    HIP_CHECK(hipMemcpyAsync(rowpid_dev.data(), d_rowpid, sizeof(uint16_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (nmis != 0) { rowpid_dev.clear(); sig_rep.clear(); on_device = false; }   // a 64-bit hash collision: the exact host path decides
+    else {
+      // the slot lists of the representative rows (a few dozen short copies)
+      rep_slots.resize((size_t)ng);
+      for (int g = 0; g < ng; ++g) {
+        int32_t be[2];
+        HIP_CHECK(hipMemcpy(be, d_iptr + sig_rep[(size_t)g], sizeof(be), hipMemcpyDeviceToHost));
+        rep_slots[(size_t)g].resize((size_t)(be[1] - be[0]));
+        if (be[1] > be[0]) HIP_CHECK(hipMemcpy(rep_slots[(size_t)g].data(), d_inc + be[0], sizeof(int32_t) * (size_t)(be[1] - be[0]), hipMemcpyDeviceToHost));
+      }
+    }
+    drop_scratch();
+    sub("row signatures: groups + exact check (device)");
+  }
+  if (!on_device) {
+  // slot -> patch, dof -> slots in ascending patch order
+  s2p.assign((size_t)ne, 0);
+  parallel_for(npatch, [&](int64_t p) { for (int64_t q = T.pptr[p]; q < T.pptr[p + 1]; ++q) s2p[(size_t)q] = (int32_t)p; });
+  // (counting sort over 4.6e8 slots at 256^3 Q2: counted and scattered by all cores with relaxed atomic increments, then every
+  // dof's short list is sorted back into ascending slot = patch order -- the result does not depend on the interleaving)
+  iptr.assign((size_t)n + 1, 0);
+  inc.assign((size_t)ne, 0);
+  {
+    const int64_t TQ = std::max<int64_t>(1, std::min<int64_t>(64, ne / (1 << 20)));
+    const int64_t perq = (ne + TQ - 1) / TQ;
+    parallel_chunks(TQ, [&](int64_t t) {
+      for (int64_t q = t * perq; q < std::min(ne, (t + 1) * perq); ++q) __atomic_fetch_add(&iptr[(size_t)T.prow[(size_t)q] + 1], (int64_t)1, __ATOMIC_RELAXED);
+    });
+    for (int64_t i = 0; i < n; ++i) iptr[(size_t)i + 1] += iptr[(size_t)i];
+    std::vector<int64_t> fill(iptr.begin(), iptr.end() - 1);
+    parallel_chunks(TQ, [&](int64_t t) {
+      for (int64_t q = t * perq; q < std::min(ne, (t + 1) * perq); ++q)
+        inc[(size_t)__atomic_fetch_add(&fill[(size_t)T.prow[(size_t)q]], (int64_t)1, __ATOMIC_RELAXED)] = (int32_t)q;
+    });
+    const int64_t TD = std::max<int64_t>(1, std::min<int64_t>(64, n / (1 << 18)));
+    const int64_t perd = (n + TD - 1) / TD;
+    parallel_chunks(TD, [&](int64_t t) {
+      for (int64_t i = t * perd; i < std::min(n, (t + 1) * perd); ++i) {
+        int32_t *lo = inc.data() + iptr[(size_t)i], *hi = inc.data() + iptr[(size_t)i + 1];
+        if (hi - lo > 1) std::sort(lo, hi);
+      }
+    });
+  }
+  sub("slot lists (counting sort)");
   // row signatures: (block, local row, shape, first dof - row) of every patch of the row, in patch order
   auto sig_len = [&](int64_t i) { return (int)(4 * (iptr[(size_t)i + 1] - iptr[(size_t)i])); };
   auto sig_word = [&](int64_t i, int j) -> int64_t {
@@ -3644,10 +3771,14 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
     default: return (int64_t)T.prow[(size_t)T.pptr[p]] - i;
     }
   };
-  std::vector<int32_t> sig;
-  std::vector<int64_t> sig_rep;
   if (!sequence_ids(n, sig_len, sig_word, sig, sig_rep, 4096)) return;
   sub("row signatures");
+    rep_slots.resize(sig_rep.size());
+    for (size_t g = 0; g < sig_rep.size(); ++g) {
+      const int64_t i = sig_rep[g];
+      rep_slots[g].assign(inc.begin() + iptr[(size_t)i], inc.begin() + iptr[(size_t)i + 1]);
+    }
+  }
   // one merged row per signature
   auto S_ = std::make_shared<PatStream>();
   PatStream &P = *S_;
@@ -3655,8 +3786,8 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   for (size_t sgi = 0; sgi < sig_rep.size(); ++sgi) {
     const int64_t i = sig_rep[sgi];
     std::vector<std::pair<int64_t, double>> ent;             // (column offset, value) in patch order
-    for (int64_t k = iptr[(size_t)i]; k < iptr[(size_t)i + 1]; ++k) {
-      const int64_t q = inc[(size_t)k], p = s2p[(size_t)q];
+    for (const int32_t qs : rep_slots[sgi]) {
+      const int64_t q = qs, p = (int64_t)(std::upper_bound(T.pptr.begin(), T.pptr.end(), q) - T.pptr.begin()) - 1;
       const int64_t np = T.pptr[p + 1] - T.pptr[p], li = q - T.pptr[p];
       const double *blk = ubinv.data() + S.h_uboff[(size_t)S.h_ublock[(size_t)p]];
       for (int64_t j = 0; j < np; ++j) ent.emplace_back((int64_t)T.prow[(size_t)(T.pptr[p] + j)] - i, blk[li * np + j]);
@@ -3679,15 +3810,18 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
     P.len.push_back(len);
     P.wmax = std::max<int64_t>(P.wmax, len);
   }
-  P.rowpid.resize((size_t)n);
-  parallel_for(n, [&](int64_t i) { P.rowpid[(size_t)i] = (uint16_t)sig[(size_t)i]; });
+  if (on_device) P.rowpid.swap(rowpid_dev);
+  else {
+    P.rowpid.resize((size_t)n);
+    parallel_for(n, [&](int64_t i) { P.rowpid[(size_t)i] = (uint16_t)sig[(size_t)i]; });
+  }
   {
     const int64_t TN = std::max<int64_t>(1, std::min<int64_t>(64, n / (1 << 18)));
     const int64_t pern = (n + TN - 1) / TN;
     std::vector<int64_t> part((size_t)TN, 0);
     parallel_chunks(TN, [&](int64_t t) {
       int64_t c = 0;
-      for (int64_t i = t * pern; i < std::min(n, (t + 1) * pern); ++i) c += P.len[(size_t)sig[(size_t)i]];
+      for (int64_t i = t * pern; i < std::min(n, (t + 1) * pern); ++i) c += P.len[(size_t)P.rowpid[(size_t)i]];
       part[(size_t)t] = c;
     });
     for (int64_t c : part) P.nnz += c;
@@ -4422,6 +4556,7 @@ int gmg_destroy(gmg_handle_t h)
   for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
   if (h->h_scalars) (void)hipHostFree(h->h_scalars);
   if (h->h_perr) (void)hipHostFree(h->h_perr);
+  if (h->h_mail) (void)hipHostFree(h->h_mail);
   for (const auto &r : h->host_regs) (void)hipHostUnregister(const_cast<char *>(r.base));   // the caller's pages are unpinned, never freed
   for (int i = 0; i < 2; ++i) {
     if (h->h_chunk[i]) (void)hipHostFree(h->h_chunk[i]);
@@ -4748,7 +4883,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_DBG_NOGATHER", false}, {"GMG_EAGER", true}, {"GMG_EAGER_MIN_ROWS", true}, {"GMG_FORCE_PTR64", false}, {"GMG_GJ_MFMA", false}, {"GMG_GJ_WIDE_MIN", false},
   {"GMG_HALO_FUSE_PACK", false}, {"GMG_HOST_ASYNC", false}, {"GMG_IDX16", false}, {"GMG_LANES_LOG2", false}, {"GMG_NT", false},
   {"GMG_NT_ROWWISE", false}, {"GMG_ONE_GATHER", false}, {"GMG_OPATTERN", false}, {"GMG_OVERLAP", false}, {"GMG_PATCH_DEDUP", false},
-  {"GMG_PATCH_OPERATOR", false}, {"GMG_PATCH_SOURCE_DEDUP", false}, {"GMG_PATTERN", false}, {"GMG_PAT_BATCHED", false},
+  {"GMG_PATCH_OPERATOR", false}, {"GMG_PATCH_OP_DEVICE", false}, {"GMG_PATCH_SOURCE_DEDUP", false}, {"GMG_PATTERN", false}, {"GMG_PAT_BATCHED", false},
   {"GMG_PAT_CODED_MIN_ROWS", false}, {"GMG_PAT_DEFER", false}, {"GMG_PAT_DINV", false}, {"GMG_PAT_EMIT", false}, {"GMG_PAT_NB", false},
   {"GMG_PAT_RB", false}, {"GMG_PAT_RSWEEP", false}, {"GMG_PAT_SHARED", false}, {"GMG_PAT_SMALL_WPB", false}, {"GMG_PAT_SMALL_WPB2", false},
   {"GMG_PAT_STRICT", false}, {"GMG_PAT_TILE", false}, {"GMG_PAT_TILE_LDS", false}, {"GMG_PAT_TILE_MIN", false}, {"GMG_PAT_TILE_ROWS", false},
@@ -4756,7 +4891,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_PAT_R2_WGS", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_PAT_R2_WGS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

@@ -202,18 +202,21 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  * value -- a debugging / A-B device, not the configuration interface.  Keys (default):
  *   storage layout   pattern (1) pat_shared (1) opattern (1) sell (1) sell_maxpad (1.25) vdict (1) idx16 (1) force_ptr64 (0)
  *                    pat_coded_min_rows (500000) eager* (1) eager_min_rows* (20000) refresh* (1)
- *   sweep kernels    pat_rsweep (1) pat_tile (1: levels >= pat_tile_rows (6000000); 2: wherever it applies; 0: never) pat_tile_min (512)
+ *   sweep kernels    pat_rsweep (1) pat_r2 (1: two rows per lane in the r-gather sweep) pat_r2_wgs (0 = four workgroups per CU) pat_tile (1: levels >= pat_tile_rows (6000000); 2: wherever it applies; 0: never) pat_tile_min (512)
  *                    pat_tile_t (48) pat_tile_lds (79872) pat_strict (1) pat_fma (0: products and sums rounded separately, as the
  *                    reference's mul!; 1: fused multiply-add taps in the row-pattern sweeps -- not bit-identical)
  *                    pat_defer (1) pat_dinv (1) pat_emit (1) pat_nb (0 = auto) pat_rb (3) pat_un (9) pat_wgs (2048) pat_batched (1)
  *                    pat_small_wpb (4) pat_small_wpb2 (2) pat_wide (1) pat_wide_lds (73728) pat_wide_rounds (1) one_gather (1)
  *                    sell_un (6) sell_block (0 = auto) sell_defer (1) nt (1) nt_rowwise (1) big_rows (4000000) xcd_remap (1)
- *                    xcd_remap_big (0) lanes_log2 (-1 = auto)
- *   one-launch pass  persist (1) persist_fenced (1) persist_max_slices (0 = one workgroup per CU) persist_shared (0)
+ *                    xcd_remap_big (-1: chunks two gather reaches deep per XCD; 0 launch order; 1 contiguous eighths; n chunk of n workgroups)
+ *                    lanes_log2 (-1 = auto)
+ *   one-launch pass  persist (1) persist_fenced (0) persist_max_slices (0 = one workgroup per CU) persist_shared (0)
  *   coarsest level   coarse_host_max (1500) coarse_host_fallback_max (6000) coarse_auto_cg_min (20000: a dense-inverse request on a
  *                    coarsest level of at least this many dofs is served by the device CG-Jacobi solver instead) gj_mfma (1) gj_wide_min (4096)
  *   patch smoother   patch_dedup (1) patch_source_dedup (1) patch_operator (1)
  *   distributed      overlap (1) halo_fuse_pack (1) host_async (0)
+ *   host round trip  host_poll* (1: the residual norm of every Krylov iteration is posted into page-locked host memory and polled; 0: copy +
+ *                    hipStreamSynchronize)
  *   host vectors     x0_zero* (0: the solve entry points read x as the initial guess, CGSolvers.jl:79; 1: x is taken as zero on
  *                    entry and never uploaded) host_chunk_bytes* (4194304: staging chunk of unregistered host vectors)
  *   diagnostics      prof_stride (8) setup_timing* (0) dbg_nogather (0) persist_force_timeout* (0: test hook, the next n solves

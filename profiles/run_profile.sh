@@ -1,16 +1,22 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash profiles/run_profile.sh <tag> [extra bench.py args]
-# Produces gpurun_out/prof_<tag>/{trace,fetch,write}/... and the summaries gpurun_out/<tag>_*.txt|json
-# (copy those into profiles/).  Counters are collected in their own passes (--pmc + --kernel-trace only).
-TAG=${1:-r02}; shift
+# Usage (on the GPU box, from the repo root): bash profiles/run_profile.sh <tag> [summarize flags] -- [bench.py args]
+#   e.g.  bash profiles/run_profile.sh r04                 -- --legs default,generic,varcoef
+#         bash profiles/run_profile.sh r04_288 --merge-latest -- --cells 288 --levels 6 --legs default,generic
+#         bash profiles/run_profile.sh r04_config3_128 --merge-latest --order 2 --cells 128 --levels 5 -- --legs default,config3 --config3-cells 128
+# Produces gpurun_out/<tag>_kernel_stats.txt, _hbm_traffic.txt / .json (copy those into profiles/) and refreshes / extends
+# profiles/traffic_latest.json.  Counters are collected in their own passes (--pmc + --kernel-trace only), as the MI355X guide prescribes.
+TAG=${1:-r04}; shift
+SFLAGS=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do SFLAGS+=("$1"); shift; done
+[ "$1" = "--" ] && shift
 ROOTDIR=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-weak-ref $*"
-timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/trace.log 2>&1
-timeout -k 5 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/fetch.log 2>&1
-timeout -k 5 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/write.log 2>&1
+ARGS="--steps 5 --warmup 2 $*"
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/trace.log 2>&1
+timeout -k 5 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/fetch.log 2>&1
+timeout -k 5 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o bench -- python3 $ROOTDIR/bench.py $ARGS > $OUT/write.log 2>&1
 cd $ROOTDIR
 # problem size of the run, for the records' labels (bench.py defaults: 128 cells, 4 levels)
 CELLS=128; LEVELS=4; prev=""
@@ -19,8 +25,12 @@ for w in "$@"; do
   [ "$prev" = "--levels" ] && LEVELS=$w
   prev=$w
 done
-python3 profiles/summarize.py $OUT gpurun_out/$TAG --no-latest --cells $CELLS --levels $LEVELS --cmd "python3 bench.py $ARGS" > $OUT/summary.log 2>&1
-tail -5 $OUT/trace.log | cut -c1-600
-cat $OUT/summary.log | tail -30
+HAVE_CELLS=0
+for w in "${SFLAGS[@]}"; do [ "$w" = "--cells" ] && HAVE_CELLS=1; done
+[ $HAVE_CELLS = 0 ] && SFLAGS+=(--cells $CELLS --levels $LEVELS)
+python3 profiles/summarize.py $OUT gpurun_out/$TAG "${SFLAGS[@]}" --cmd "python3 bench.py $ARGS" > $OUT/summary.log 2>&1
+grep -a '^{' $OUT/trace.log | tail -1 > gpurun_out/${TAG}_bench.json
+tail -3 $OUT/trace.log | cut -c1-400
+tail -30 $OUT/summary.log
 # keep the databases out of the merged gpurun_out (size limit): summaries only
 rm -rf $OUT/trace $OUT/fetch $OUT/write

@@ -26,7 +26,7 @@ def db(path):
 
 
 def family(name):
-    if "gmg::sells_sweep_kernel<" in name or "gmg::sells_rsweep_kernel<" in name or "gmg::sells_tsweep_kernel<" in name:   # the fused sweeps on the shared-offset pattern table (XM = 0/1/2 variants)
+    if any("gmg::" + k + "<" in name for k in ("sells_sweep_kernel", "sells_rsweep_kernel", "sells_r2sweep_kernel", "sells_tsweep_kernel")):   # the fused sweeps on the shared-offset pattern table (XM = 0/1/2 variants)
         return "sells_kernel"
     for fam in ("sells_kernel", "sellp_kernel", "sellc_kernel", "sello_kernel", "sell_kernel", "csr_stream1_kernel"):
         if "gmg::" + fam + "<" in name:
@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--cmd", default="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
     ap.add_argument("--no-latest", action="store_true")
+    ap.add_argument("--merge-latest", action="store_true", help="add this run's records to profiles/traffic_latest.json (same kernels.hpp sha) instead of replacing it")
+    ap.add_argument("--order", type=int, default=1, help="2: the config-3 leg (Q2): the record is the wide-row operator mat-vec r -= A dx of the patch sweep")
     ap.add_argument("--bench-log", default=None, help="stdout of the profiled bench.py run (default: <src>/trace.log): its JSON line supplies the sweep signatures")
     a = ap.parse_args()
     src, out = a.src, a.out
@@ -62,12 +64,17 @@ def main():
 
     cdb = {c: db(os.path.join(src, sub)) for c, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write"))}
 
+    min_frac = 0.0
+
     def counter(cname, kname, grid):
         c = cdb[cname]
         if c is None:
             return None
+        mx = c.execute("select max(end-start) from counters_collection where counter_name=? and kernel_name=? and grid_size_x=?", (cname, kname, grid)).fetchone()[0]
+        if mx is None:
+            return None
         r = c.execute("select avg(value), min(value), max(value), count(*), avg(end-start)/1e3 from counters_collection "
-                      "where counter_name=? and kernel_name=? and grid_size_x=?", (cname, kname, grid)).fetchone()
+                      "where counter_name=? and kernel_name=? and grid_size_x=? and (end-start) >= ?", (cname, kname, grid, min_frac * mx)).fetchone()
         return r if r and r[3] else None
 
     tl = []
@@ -86,13 +93,30 @@ def main():
 
     # ---- finest-level fused sweeps (EPI_SWEEP = 3 kernels and the sells_sweep_kernel variants): largest grid per family;
     #      variants of one family at that grid (x updated every second sweep) are averaged, weighted by launches ----
-    sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%_kernel<3,%' or name like '%sells_sweep_kernel<%' or name like '%sells_rsweep_kernel<%' or name like '%sells_tsweep_kernel<%' "
+    sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%_kernel<3,%' or name like '%sells_sweep_kernel<%' or name like '%sells_rsweep_kernel<%' or name like '%sells_r2sweep_kernel<%' or name like '%sells_tsweep_kernel<%' "
                      "group by name, grid_x order by grid_x desc").fetchall()
     recs = []
     nrows = (a.cells - 1) ** 3
+    if a.order == 2:
+        # config-3 leg: the timed kernel is the operator mat-vec of the patch sweep, sells_kernel<EPI_SUB = 1, ..., K = 5, VD, ..., WL> on the
+        # finest Q2 level ((2 cells - 1)^3 rows); the additive-Schwarz mat-vec (EPI_ADDTO = 4) runs on the same grid and is listed beside it
+        nrows = (2 * a.cells - 1) ** 3
+        # (coarser levels launch the same kernels on the same capped grid: only the dispatches of the finest level -- at least 0.75 of the
+        # longest -- enter the record)
+        sw = []
+        for epi in ("1", "4"):
+            rows = con.execute("select name, grid_x, max(end-start) from kernels where name like ? group by name, grid_x order by 3 desc",
+                               ("%gmg::sells_kernel<" + epi + ",%, 5, true%",)).fetchall()
+            if rows:
+                name, grid, mx = rows[0]
+                r = con.execute("select avg(end-start)/1e3, count(*) from kernels where name=? and grid_x=? and (end-start) >= ?", (name, grid, 0.75 * mx)).fetchone()
+                sw.append((name, grid, r[0], r[1]))
+        min_frac = 0.75
     fams = {}
     for name, grid, avg_us, cnt in sw:
         fam = family(name)
+        if a.order == 2:
+            fam = "sells_kernel_wide" if "sells_kernel<1," in name else "sells_kernel_wide_schwarz"
         if fam is None:
             continue
         # one record per (family, grid): the finest level and, when its batched variant runs on a smaller grid than the next
@@ -108,7 +132,7 @@ def main():
         tot_cnt = sum(m[2] for m in info["members"])
         avg_us = sum(m[1] * m[2] for m in info["members"]) / tot_cnt
         names = [m[0] for m in info["members"]]
-        rec = dict(family=fam, kernel=" | ".join(names), grid_x=grid, avg_us_kernel_trace=avg_us, launches=tot_cnt, cells=a.cells, levels=a.levels, rows=nrows)
+        rec = dict(family=fam, kernel=" | ".join(names), grid_x=grid, avg_us_kernel_trace=avg_us, launches=tot_cnt, cells=a.cells, levels=a.levels, rows=nrows, order=a.order)
         tl.append(f"# {' | '.join(names)} grid_x={grid}: avg {avg_us:.2f} us over {tot_cnt} launches (kernel-trace pass)")
         fsum = wsum = n_f = n_w = 0.0
         for name, _, _ in info["members"]:
@@ -135,7 +159,7 @@ def main():
         for fam_leg, blk in (("generic", bj.get("roofline")), ("default", bj.get("roofline_compressed")),
                              ("varcoef", (bj.get("variable_coefficient") or {}).get("roofline"))):
             if blk and blk.get("sweep_signature"):
-                sigs[blk["sweep_signature"].split("<")[0].replace("sells_sweep_kernel", "sells_kernel").replace("sells_rsweep_kernel", "sells_kernel").replace("sells_tsweep_kernel", "sells_kernel")] = blk["sweep_signature"]
+                sigs[blk["sweep_signature"].split("<")[0].replace("sells_sweep_kernel", "sells_kernel").replace("sells_rsweep_kernel", "sells_kernel").replace("sells_r2sweep_kernel", "sells_kernel").replace("sells_tsweep_kernel", "sells_kernel")] = blk["sweep_signature"]
     except Exception as e:
         tl.append(f"# (no sweep signatures: {e})")
     for rec in recs:
@@ -147,8 +171,19 @@ def main():
     res = dict(tag=os.path.basename(out), command=a.cmd, calibration=cal, kernels_hpp_sha=sha, kernels=recs)
     open(out + "_hbm_traffic.txt", "w").write("\n".join(tl) + "\n")
     json.dump(res, open(out + "_hbm_traffic.json", "w"), indent=1)
-    if not a.no_latest:
-        json.dump(res, open(os.path.join(os.path.dirname(os.path.abspath(out)), "traffic_latest.json"), "w"), indent=1)
+    latest = os.path.join(os.path.dirname(os.path.abspath(out)), "traffic_latest.json")
+    if a.merge_latest:
+        try:
+            old = json.load(open(latest))
+        except Exception:
+            old = None
+        if old and old.get("kernels_hpp_sha") == sha:
+            keep = [r for r in old.get("kernels", []) if not any(r.get("family") == n.get("family") and r.get("cells") == n.get("cells") and r.get("levels") == n.get("levels")
+                                                                   and r.get("order", 1) == n.get("order", 1) for n in recs)]
+            res = dict(old, tag=old.get("tag", "") + "+" + os.path.basename(out), kernels=keep + recs)
+        json.dump(res, open(latest, "w"), indent=1)
+    elif not a.no_latest:
+        json.dump(res, open(latest, "w"), indent=1)
     print("\n".join(tl))
 
 

@@ -219,3 +219,74 @@ def test_timeout_on_one_rank_is_acted_on_by_all_ranks(tmp_path):
     v = _launch("gpu", 2, (16, 16, 16), 4, tmp_path, transport="host", rep_from=3, extra_env=env)
     _check(v)
     assert v["persist_retries"] == [1, 1] and v["persist_active"] == [0, 0], v
+
+
+# ---------------------------------------------------------------- two rows per lane, fused multiply-add taps
+@pytest.mark.parametrize("nc,nlev,niter", [((40, 40, 40), 3, 10), ((130, 66), 2, 5), ((34, 46, 30), 2, 3)])
+def test_pair_sweep_is_bitwise_the_single_row_sweep(S, po, orc, nc, nlev, niter):
+    """sells_r2sweep_kernel (default: a lane owns two rows of a 126-row slice, 16-byte loads / stores, masks only applied when a sum
+    comes out non-finite) against sells_rsweep_kernel (option pat_r2 = 0) on levels whose row count is not a multiple of 126 and
+    whose first / last slices need the clamped path: smoothing passes from a given x and from x = 0, odd and even sweep counts, a
+    vector holding Inf (confined to the rows that store a coefficient for it, as in the oracle's mul!), chained passes and a CG
+    solve agree to the last bit; the solve equals the oracle's."""
+    H = po.build_hierarchy(nc, nlev, 1)
+    n = H["mats"][0].shape[0]
+    b = po.dirichlet_lift_rhs(nc, 1)
+    res = {}
+    for r2 in (0, 1):
+        solver = S.CGSolver(make_gmg(S, H, pre_smoothers=jac(S, nlev, niter), options={"pat_r2": r2, "persist": 0}), maxiter=40, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        out = []
+        x, r = np.random.default_rng(3).uniform(-1, 1, n), np.random.default_rng(50).uniform(-1, 1, n)
+        for _ in range(3):
+            ns.P_ns.smooth(0, x, r)
+        out += [x.copy(), r.copy()]
+        xi, ri = np.zeros(n), np.random.default_rng(51).uniform(-1, 1, n)
+        ri[n // 3] = np.inf
+        ri[5] = -np.inf
+        ns.P_ns.smooth(0, xi, ri)
+        out += [np.isfinite(xi), np.isfinite(ri), np.where(np.isfinite(xi), xi, 0.0), np.where(np.isfinite(ri), ri, 0.0)]
+        xs = np.zeros(n)
+        S.solve_(xs, ns, b)
+        out += [xs, solver.log.residuals[: solver.log.num_iters + 1].copy()]
+        sig = ns.P_ns.sweep_signature(0)
+        assert ("sells_r2sweep_kernel" in sig) == (r2 == 1) and ("sells_rsweep_kernel" in sig) == (r2 == 0), sig
+        res[r2] = out
+        ns.P_ns.close()
+    for a, c in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, c)
+    assert not res[1][2].all() and res[1][2].sum() > 0.9 * n          # the Inf reached some rows and stayed confined
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, niter, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
+    xo, nit, flag_o, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=40, atol=1e-14, rtol=1e-8)
+    assert len(res[1][-1]) == nit + 1
+    np.testing.assert_allclose(res[1][-1], hist, rtol=1e-8)
+    assert rel_err(res[1][-2], xo) <= 1e-10
+
+
+@pytest.mark.parametrize("nc,nlev,tile", [((32, 32, 32), 4, 0), ((64, 64), 3, 0), ((40, 36, 28), 2, 2)])
+def test_fused_multiply_add_taps_stay_inside_the_parity_gates(S, po, orc, nc, nlev, tile, monkeypatch):
+    """Option pat_fma = 1 (one rounding per tap instead of the two of the reference's mul!: RichardsonSmoothers.jl:94 through
+    SparseArrays): NOT bit-identical, so it is an opt-in -- but it must stay inside the gates SURVEY 8(c) states for the HIP path:
+    a smoothing pass <= 1e-13 of the oracle's (max-norm relative), CG iteration count identical, residual history <= 1e-8 per entry,
+    solution <= 1e-10."""
+    if tile:
+        monkeypatch.setenv("GMG_PAT_TILE_MIN", "0")
+    H = po.build_hierarchy(nc, nlev, 1)
+    n = H["mats"][0].shape[0]
+    b = po.dirichlet_lift_rhs(nc, 1)
+    solver = S.CGSolver(make_gmg(S, H, options={"pat_fma": 1, "persist": 0, "pat_tile": tile}), maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = setup(S, solver, H["mats"][0])
+    assert "FM=1" in (ns.P_ns.sweep_signature(0) or "FM=1")
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+    x, r = np.random.default_rng(3).uniform(-1, 1, n), np.random.default_rng(50).uniform(-1, 1, n)
+    xo_, ro_ = go.smooth(0, x.copy(), r.copy())
+    ns.P_ns.smooth(0, x, r)
+    assert "FM=1" in ns.P_ns.sweep_signature(0)
+    assert np.max(np.abs(x - xo_)) <= 1e-13 * np.max(np.abs(xo_)) and np.max(np.abs(r - ro_)) <= 1e-13 * np.max(np.abs(ro_))
+    assert not (np.array_equal(x, xo_) and np.array_equal(r, ro_))         # (it really is another arithmetic)
+    xs = np.zeros(n)
+    S.solve_(xs, ns, b)
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert solver.log.num_iters == nit
+    np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-8)
+    assert rel_err(xs, xo) <= 1e-10
