@@ -587,6 +587,7 @@ struct gmg_solver {
   int n_cus = 0;
   uint32_t *d_perr_dev = nullptr;                  // device-memory twin (the kernel's end-of-pass check)
   uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
+  int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
   int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU)
   int pat_fma = 0;      // GMG_PAT_FMA: fused multiply-add taps in the row-pattern sweeps (one rounding per tap: not the reference's mul! arithmetic)
@@ -1823,13 +1824,17 @@ struct gmg_solver {
     const int ntiles = (nsl + T - 1) / T;
     const int nwg = std::max(8, (std::min(ntiles, resident) / 8) * 8);          // a multiple of 8: one share per XCD
     const dim3 g(nwg), b(64 * WPB);
-    M.note_sweep("sells_tsweep_kernel<XM=*,MK=%d,WPB=%d,FM=%d> T=%d tiles=%d wgs=%d segs=%d", mk ? 1 : 0, WPB, pat_fma ? 1 : 0, T, ntiles, nwg, tl.nseg);
-#define GMG_TSWEEP_LAUNCH2(XMV, MKV, FMV)                                                                           \
+    // coefficients broadcast inside DPP rows (27-point operators), in the sweeps that leave x alone: 190.7 -> 184.8 us at 288^3; the sweeps
+    // that also update x have no registers to spare under the 64 the two resident workgroups allow (252.8 -> 282 us with it)
+    const bool bc = pat_bcast && M.pat_nruns == 9 && M.pat_k == 3 && a.xmode == 1;
+    M.note_sweep("sells_tsweep_kernel<XM=*,MK=%d,WPB=%d,FM=%d,BC=%d> T=%d tiles=%d wgs=%d segs=%d", mk ? 1 : 0, WPB, pat_fma ? 1 : 0, bc ? 1 : 0, T, ntiles, nwg, tl.nseg);
+#define GMG_TSWEEP_LAUNCH3(XMV, MKV, FMV, BCV)                                                                      \
     do {                                                                                                              \
       static bool attr[64] = {false};                                                                                 \
-      if (!attr[device & 63]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, MKV, WPB, FMV>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr[device & 63] = true; } \
-      hipLaunchKernelGGL((sells_tsweep_kernel<XMV, MKV, WPB, FMV>), g, b, lds, stream, a, tl);                        \
+      if (!attr[device & 63]) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_tsweep_kernel<XMV, MKV, WPB, FMV, BCV>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); attr[device & 63] = true; } \
+      hipLaunchKernelGGL((sells_tsweep_kernel<XMV, MKV, WPB, FMV, BCV>), g, b, lds, stream, a, tl);                   \
     } while (0)
+#define GMG_TSWEEP_LAUNCH2(XMV, MKV, FMV) do { if (bc) GMG_TSWEEP_LAUNCH3(XMV, MKV, FMV, true); else GMG_TSWEEP_LAUNCH3(XMV, MKV, FMV, false); } while (0)
 #define GMG_TSWEEP_LAUNCH(XMV)                                                                                      \
     do {                                                                                                              \
       if (mk) { if (pat_fma) GMG_TSWEEP_LAUNCH2(XMV, true, true); else GMG_TSWEEP_LAUNCH2(XMV, true, false); }        \
@@ -1837,6 +1842,7 @@ struct gmg_solver {
     } while (0)
     if (a.xmode == 0) GMG_TSWEEP_LAUNCH(0); else if (a.xmode == 1) GMG_TSWEEP_LAUNCH(1); else GMG_TSWEEP_LAUNCH(2);
 #undef GMG_TSWEEP_LAUNCH
+#undef GMG_TSWEEP_LAUNCH3
 #undef GMG_TSWEEP_LAUNCH2
 #undef GMG_TSWEEP_LAUNCH2
     HIP_CHECK(hipGetLastError());
@@ -2818,6 +2824,7 @@ struct gmg_solver {
       HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device));
       n_cus = std::max(1, v);
     }
+    pat_bcast = opt_int("GMG_PAT_BCAST", 1);
     pat_r2 = opt_int("GMG_PAT_R2", 1);
     pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
     pat_fma = opt_int("GMG_PAT_FMA", 0);
@@ -4891,7 +4898,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_PAT_R2_WGS", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

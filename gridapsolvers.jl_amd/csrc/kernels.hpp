@@ -1910,8 +1910,34 @@ struct SellTile {
   int elems;                // staged values per tile
 };
 
-template <int XM, bool MK, int WPB, bool FM = false>
-__global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, SellTile tl)
+// BC: coefficients broadcast inside DPP rows.  27 of the 36 LDS reads of a slice are coefficient reads (216 of 290 B per row: at 288^3
+// the LDS pipes are busy for 99 us of a 203 us sweep).  When the 16 lanes of every DPP row of the slice carry ONE pattern (no grid-line
+// end inside the slice: 4 of 5 slices at 288^3) the lanes of a row load that pattern's 27 coefficients ONCE -- lane l the entries
+// l % 16 and 16 + l % 16 -- and a tap takes its coefficient from lane j of the row with ONE `v_mov_b64_dpp row_newbcast:j` (gfx950 has
+// no DPP form of the 64-bit multiply): a vector instruction on one of four SIMDs instead of a 512-byte read on the CU's one LDS pipe.
+// Same coefficient values, same products, same order: bit-identical.  Other slices keep the per-lane LDS reads.
+template <int J>
+__device__ __forceinline__ double row_bcast(double v)        // lane J of the caller's DPP row (16 lanes) to every lane of that row
+{
+  double r;
+  asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+  return r;
+}
+// the three taps of run Q of a 27-point slice with coefficients c0 (entries 0..15 in lanes 0..15 of every DPP row) and c1 (entries 16..26)
+template <bool FM, int Q>
+__device__ __forceinline__ double taps_bcast_run(double s, double c, double c0, double c1)
+{
+  constexpr int J0 = 3 * Q, J1 = 3 * Q + 1, J2 = 3 * Q + 2;
+  const double k0 = row_bcast<J0 & 15>(J0 < 16 ? c0 : c1), k1 = row_bcast<J1 & 15>(J1 < 16 ? c0 : c1), k2 = row_bcast<J2 & 15>(J2 < 16 ? c0 : c1);
+  s = FM ? __builtin_fma(k0, c, s) : s + k0 * c;
+  c = wave_shl1(c);
+  s = FM ? __builtin_fma(k1, c, s) : s + k1 * c;
+  c = wave_shl1(c);
+  s = FM ? __builtin_fma(k2, c, s) : s + k2 * c;
+  return s;
+}
+template <int XM, bool MK, int WPB, bool FM = false, bool BC = false>
+__global__ __launch_bounds__(64 * WPB, 8) void sells_tsweep_kernel(SellSArgs a, SellTile tl)   // 8 waves per SIMD = two resident workgroups of 16 waves per CU: <= 64 VGPRs
 {
   constexpr int K = 3, ROWS = 65 - K, RB = 3, SPW = 3;       // T <= SPW * WPB slices per tile: slice j of the tile belongs to wave j % WPB
   const int T = tl.T;
@@ -1973,6 +1999,24 @@ __global__ __launch_bounds__(64 * WPB) void sells_tsweep_kernel(SellSArgs a, Sel
       const uint32_t *tm = s_msk + pid[i] * nu;
       const double *tv = s_tab8 + pid[i] * nu;
       double s = 0.0;
+      bool done = false;
+      if (BC) {                                              // (the launcher sets BC only for nine runs of three)
+        // the pattern of the DPP row's first lane; the two halo lanes (no row of their own) follow their row
+        const int lead = __builtin_amdgcn_update_dpp(0, pid[i], 0x150, 0xf, 0xf, true);
+        if (__all(lane >= ROWS || pid[i] == lead)) {
+          const double *tl16 = s_tab8 + lead * nu + (lane & 15);
+          const double c0 = tl16[0], c1 = (lane & 15) < 11 ? tl16[16] : 0.0;
+          // (three windows in flight at a time: more would cost the second resident workgroup its registers)
+          double w0 = s_stage[tl.run_lds[0] + rel], w1 = s_stage[tl.run_lds[1] + rel], w2 = s_stage[tl.run_lds[2] + rel];
+          double v0 = s_stage[tl.run_lds[3] + rel], v1 = s_stage[tl.run_lds[4] + rel], v2 = s_stage[tl.run_lds[5] + rel];
+          s = taps_bcast_run<FM, 0>(s, w0, c0, c1); s = taps_bcast_run<FM, 1>(s, w1, c0, c1); s = taps_bcast_run<FM, 2>(s, w2, c0, c1);
+          w0 = s_stage[tl.run_lds[6] + rel]; w1 = s_stage[tl.run_lds[7] + rel]; w2 = s_stage[tl.run_lds[8] + rel];
+          s = taps_bcast_run<FM, 3>(s, v0, c0, c1); s = taps_bcast_run<FM, 4>(s, v1, c0, c1); s = taps_bcast_run<FM, 5>(s, v2, c0, c1);
+          s = taps_bcast_run<FM, 6>(s, w0, c0, c1); s = taps_bcast_run<FM, 7>(s, w1, c0, c1); s = taps_bcast_run<FM, 8>(s, w2, c0, c1);
+          done = true;
+        }
+      }
+      if (!done)
       for (int r0 = 0; r0 < a.nruns; r0 += RB) {
         double cur[RB];
 #pragma unroll
