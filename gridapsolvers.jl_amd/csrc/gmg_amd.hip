@@ -2494,12 +2494,20 @@ struct gmg_solver {
     if (r_internal) r = const_cast<double *>(r_in);
     else { r = L.rbuf[0]; copy(r, r_in, n); }
     if (x_zero) zero(x, n);
+    // Overlapping layout (gmg_set_partition_overlap): consistent!(r) once per block of `depth` sweeps; inside a block every local row
+    // is swept with the patches of the local box -- no assemble!, no exchange of dx (ghost layers are recomputed redundantly and stay
+    // exact for depth - j blocks of 3 order - 2 node layers, see partition._OverlapGeom).  Same arithmetic per owned row as on one GPU.
+    const bool ovl_patch = comm.nranks > 1 && L.halo.present && L.halo.ovl;
+    const int pblock = ovl_patch ? std::max(1, std::min(L.halo.depth, S.niter)) : 1;
     for (int it = 0; it < S.niter; ++it) {
+      if (!ovl_patch || it % pblock == 0)
       exchange(l, r);                                      // consistent!(b) PatchSolvers.jl:231 (no-op on one GPU)
       patch_precond(L, S, r, S.omega, true, L.dx, x);      // :91-93
       // profiled level: HIP events around the operator mat-vec of every prof_stride-th patch sweep (r -= A dx, the wide-row kernel)
       const bool prof = (l == prof_level) && (prof_seq++ % (uint64_t)prof_stride == 0) && prof_used + 2 <= prof_ev.size();
       if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
+      if (ovl_patch) spmv_sub(L.A, L.dx, r);               // every local row, no exchange
+      else
       apply_A_sub(l, L.dx, r);                             // :94-95 (exchanges dx itself: consistent!(x), PatchSolvers.jl:256)
       if (prof) {
         HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
@@ -3556,7 +3564,7 @@ void gmg_solver::build_patch_operator(Level &L, Smoother &S)
   S.use_M = false;
   const Smoother::Tables &T = *S.tab;
   const int64_t npatch = S.npatch, n = L.n;
-  if (!opt_int("GMG_PATCH_OPERATOR", 1) || !S.dedup || !T.pcol.empty() || (comm.nranks > 1 && L.halo.present) || !use_pattern || !use_sell) return;
+  if (!opt_int("GMG_PATCH_OPERATOR", 1) || !S.dedup || !T.pcol.empty() || (comm.nranks > 1 && L.halo.present && !L.halo.ovl) || !use_pattern || !use_sell) return;
   if (npatch < 64 || n < 64 || n >= (int64_t)(1 << 28) || S.max_np > 32 || S.h_ublock.size() != (size_t)npatch) return;
   const auto t_begin = std::chrono::steady_clock::now();
   auto t_sub = t_begin;
@@ -3888,7 +3896,7 @@ void gmg_solver::patch_precond(Level &L, Smoother &S, const double *r, double om
   // local contributions are gathered for ALL local dofs, the ghost ones are added to their owners (assemble!,
   // PatchSolvers.jl:251-258), then the relaxation runs on the owned entries.
   const int l = (int)(&L - &lev[0]);
-  const bool dist = comm.nranks > 1 && L.halo.present;
+  const bool dist = comm.nranks > 1 && L.halo.present && !L.halo.ovl;   // (overlapping layout: a single-GPU level between two exchanges)
   const int64_t ng = dist ? L.nvec : L.n;
   const int grid = (int)((ng + 255) / 256);
   const int fused_relax = (relax && !dist) ? 1 : 0;
@@ -4166,8 +4174,11 @@ void gmg_solver::setup()
         REQUIRE(l >= 1, GMG_ERR_UNSUPPORTED, "the finest level keeps the own | ghost layout (its vectors are the caller's): gmg_set_partition");
         REQUIRE(L.hA.nrows == L.hA.ncols && L.hA.nrows == L.halo.n_own + L.halo.n_ghost, GMG_ERR_INVALID,
                 "overlapping layout: the local matrix must be square over all local entries on level " + std::to_string(l));
-        REQUIRE(l == nlev - 1 || (L.pre.kind == SM_JACOBI && L.post.kind == SM_JACOBI), GMG_ERR_UNSUPPORTED,
-                "overlapping layout: Richardson-Jacobi smoothers only (patch smoothers need assemble!, which needs the own | ghost layout)");
+        // patch smoothers: the caller lists every patch whose dofs all lie in the local box and the blocks A[p,p] come from the local
+        // matrix (exact there) -- no assemble!; patches with their own matrices / separate column tables keep the own | ghost layout
+        for (const Smoother *sp : {&L.pre, &L.post})
+          REQUIRE(l == nlev - 1 || sp->kind == SM_JACOBI || (sp->tab && sp->tab->pcol.empty() && !sp->tab->has_blocks), GMG_ERR_UNSUPPORTED,
+                  "overlapping layout: patch smoothers take their blocks from the local matrix (gmg_set_smoother_patch), patch_cols = patch_rows");
         REQUIRE(!L.has_pcorr, GMG_ERR_UNSUPPORTED, "overlapping layout: no patch-corrected prolongation");
       } else
       REQUIRE(L.halo.n_own == L.hA.nrows && L.halo.n_own + L.halo.n_ghost == L.hA.ncols, GMG_ERR_INVALID,
@@ -4192,7 +4203,7 @@ void gmg_solver::setup()
       REQUIRE((boundary ? L.hR.nrows == (int64_t)h_rep_gid.size() : L.hR.nrows == lev[l + 1].n) && L.hR.ncols == L.nvec,
               GMG_ERR_INVALID, "restriction shape mismatch");
     }
-    if (comm.nranks > 1 && L.halo.present)
+    if (comm.nranks > 1 && L.halo.present && !L.halo.ovl)
       for (const Smoother *sp : {&L.pre, &L.post})
         REQUIRE(sp->kind == SM_JACOBI || (sp->tab && sp->tab->has_blocks), GMG_ERR_UNSUPPORTED,
                 "distributed patch smoothers need the caller's patch matrices (gmg_set_smoother_patch_matrices): a rank's local matrix "

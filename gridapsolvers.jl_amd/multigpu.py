@@ -102,7 +102,7 @@ class DistributedGMG:
         # (an anisotropic mesh would change the iteration count with the rank grid)
         self.lengths = lengths
         self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order, lengths, rep_from,
-                                                                  depth if smoother == "jacobi" else None)
+                                                                  depth, smoother)
         self.t_assembly = time.perf_counter() - t0
         self.order = order
         h = C.c_void_p()
@@ -194,6 +194,14 @@ class DistributedGMG:
                                                                  C.c_void_p(blocks.ctypes.data), 0, None))
             return
         cells_l = self.local["cells"][l]
+        if getattr(L, "overlap", False):
+            # overlapping layout: every vertex star inside the extended box, blocks A[p,p] from the local matrix (exact there): no
+            # caller-assembled matrices, no assemble! -- the level is a single-GPU level between two exchanges
+            pp, pd = L.ogeom.vertex_star_patches()
+            self._keep += [pp, pd]
+            abi.check(h, lib.gmg_set_smoother_patch(h, l, abi.PRE_AND_POST, niter, omega, abi.PATCH_LU, pp.size - 1,
+                                                    C.c_void_p(pp.ctypes.data), C.c_void_p(pd.ctypes.data), 0, 8))
+            return
         if L.replicated or self.world == 1:
             pp, pd = po.vertex_star_patches(cells_l, self.order)
             pd64 = pd.astype(np.int64)

@@ -179,22 +179,27 @@ class _LevelGeom:
 
 
 class _OverlapGeom:
-    """One level on one rank in the overlapping layout: the owned node box extended by `depth` layers per direction (clipped at the
-    Dirichlet boundary), numbered lexicographically (x fastest) -- owned and ghost entries interleaved.  Exact rows exist for
-    every local entry except the outermost layer, so `depth` sweeps of the 27-point operator can run between two exchanges."""
+    """One level on one rank in the overlapping layout: the owned node box extended by `layers` node layers per direction (clipped at
+    the Dirichlet boundary), numbered lexicographically (x fastest) -- owned and ghost entries interleaved.  Exact rows exist for
+    every local entry except the outermost `order` layers, so `depth` smoothing sweeps can run between two exchanges when
+    layers = depth * reach, reach = how far one sweep carries an error inwards: `order` nodes for Richardson(Jacobi) (the operator couples
+    nodes up to `order` apart), 3 * order - 2 for Richardson(PatchSolver) on vertex stars (a star reaches order - 1 nodes from its
+    vertex, so dx_i needs r within 2 (order - 1) of i, and r_i -= (A dx)_i another `order`)."""
 
-    def __init__(self, cells_global, grid, rank, d, depth):
-        self.cells, self.grid, self.rank, self.d, self.depth = cells_global, grid, rank, d, int(depth)
+    def __init__(self, cells_global, grid, rank, d, depth, order=1, reach=None):
+        self.cells, self.grid, self.rank, self.d, self.depth, self.order = cells_global, grid, rank, d, int(depth), int(order)
+        self.reach = int(order if reach is None else reach)
+        self.layers = self.depth * self.reach
         co = _coords(rank, grid)
         self.rng = []
         for k in range(3):
             if k < d:
-                lo, hi, _, _ = _axis_ranges(cells_global[k], 1, grid[k], co[k])
-                nlast = cells_global[k] - 1
-                self.rng.append((lo, hi, max(lo - depth, 1), min(hi + depth, nlast)))
+                lo, hi, _, _ = _axis_ranges(cells_global[k], order, grid[k], co[k])
+                nlast = order * cells_global[k] - 1
+                self.rng.append((lo, hi, max(lo - self.layers, 1), min(hi + self.layers, nlast)))
             else:
                 self.rng.append((0, 0, 0, 0))
-        self.nfree = [cells_global[k] - 1 if k < d else 1 for k in range(3)]
+        self.nfree = [order * cells_global[k] - 1 if k < d else 1 for k in range(3)]
         self.ext_shape = [r[3] - r[2] + 1 for r in self.rng]
         self.own_shape = [r[1] - r[0] + 1 for r in self.rng]
         self.n_local = int(np.prod(self.ext_shape))
@@ -208,6 +213,37 @@ class _OverlapGeom:
         self.own_idx = np.nonzero(own)[0].astype(np.int64)
         self.n_own = self.own_idx.size
         self.own_gid = self.gid[self.own_idx]
+
+    def vertex_star_patches(self):
+        """(patch_ptr, patch_dofs): every vertex star whose dofs ALL lie in this rank's extended box, in lexicographic vertex order,
+        dofs ascending, in the LOCAL numbering of the overlapping layout -- the serial `poisson.vertex_star_patches` restricted to
+        the box.  Blocks A[p,p] of such patches are exact in the local matrix (its rows only drop columns outside the box), so the
+        patch smoother of an overlapping level needs neither caller-assembled matrices nor assemble!: stars cut by the box edge are
+        left out, which only touches the layers the exchange refreshes."""
+        order, d = self.order, self.d
+        per_axis = []
+        for k in range(3):
+            if k >= d:
+                per_axis.append([np.zeros(1, dtype=np.int64)]); continue
+            nlast = order * self.cells[k] - 1
+            lst = []
+            for v in range(self.cells[k] + 1):               # boundary vertices too: their stars hold the free nodes next to them
+                node = order * v
+                a, b = max(node - (order - 1), 1), min(node + (order - 1), nlast)
+                if b < a:
+                    continue                                 # (order 1: a boundary vertex has no free dof)
+                if a >= self.rng[k][2] and b <= self.rng[k][3]:
+                    lst.append(np.arange(a, b + 1, dtype=np.int64) - self.rng[k][2])
+            per_axis.append(lst)
+        ex, ey = self.ext_shape[0], self.ext_shape[1]
+        ptr, dofs = [0], []
+        for lz in per_axis[2]:
+            for ly in per_axis[1]:
+                for lx in per_axis[0]:
+                    idx = (lz[:, None, None] * (ey * ex) + ly[None, :, None] * ex + lx[None, None, :]).reshape(-1)
+                    dofs.append(idx)
+                    ptr.append(ptr[-1] + idx.size)
+        return np.asarray(ptr, dtype=np.int64), (np.concatenate(dofs).astype(np.int64) if dofs else np.zeros(0, np.int64))
 
     def _sub_box(self, box):
         """local ids (lexicographic) of the global node box [(lo,hi)]*3 intersected with this rank's extended box"""
@@ -234,8 +270,8 @@ class _OverlapGeom:
             for k in range(3):
                 if k >= d:
                     q_own.append((0, 0)); q_ext.append((0, 0)); continue
-                lo, hi, _, _ = _axis_ranges(self.cells[k], 1, grid[k], qc[k])
-                q_own.append((lo, hi)); q_ext.append((max(lo - self.depth, 1), min(hi + self.depth, self.cells[k] - 1)))
+                lo, hi, _, _ = _axis_ranges(self.cells[k], self.order, grid[k], qc[k])
+                q_own.append((lo, hi)); q_ext.append((max(lo - self.layers, 1), min(hi + self.layers, self.order * self.cells[k] - 1)))
             my_own = [(self.rng[k][0], self.rng[k][1]) for k in range(3)]
             s_box = [(max(my_own[k][0], q_ext[k][0]), min(my_own[k][1], q_ext[k][1])) for k in range(3)]
             sidx = self._sub_box(s_box)
@@ -355,13 +391,14 @@ def _restr_tables_ext(nc_coarse_global, order, c_elo, c_ehi, clo, chi, felo, feh
     return n, c, v
 
 
-def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None, rep_from=None, depth=None):
+def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None, rep_from=None, depth=None, smoother="jacobi"):
     """Local operators of `rank` for every level.
 
     Levels >= rep_from are REPLICATED (global operators on every rank, no halo); by default only the
     coarsest level is.  `depth`: None / 0 = every partitioned level in the own | ghost layout (one exchange per mat-vec); an int or a
     per-level list = ghost layers of the OVERLAPPING layout on the partitioned levels >= 1 (`LocalLevel.overlap`: one local numbering
-    over the extended box, square local matrix, one exchange per `depth` sweeps; Q1 only).  Returns dict(levels=[LocalLevel...],
+    over the extended box, square local matrix, one exchange per `depth` sweeps; any order; `smoother` = "jacobi" or "patch" sets how
+    many node layers a sweep consumes, see _OverlapGeom).  Returns dict(levels=[LocalLevel...],
     rep_from, rep_gid (global ids, in level rep_from numbering, of the rows this rank's boundary restriction produces), cells, grid)."""
     nc = tuple(int(c) for c in cells_global_fine)
     d = len(nc)
@@ -381,8 +418,7 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
     for l in range(nlevels):
         if l >= rep_from or nranks == 1:
             depths[l] = 0
-    if any(depths) and order != 1:
-        raise ValueError("the overlapping layout is implemented for Q1 hierarchies")
+    reach = order if smoother == "jacobi" else 3 * order - 2
     cells = [tuple(c // (2 ** l) for c in nc3[:d]) + (1,) * (3 - d) for l in range(nlevels)]
     for l in range(nlevels):
         for k in range(d):
@@ -393,7 +429,7 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
     Ls = po._lengths(lengths, d)
     ngeom = min(rep_from + 1, nlevels)
     geoms = [_LevelGeom(cells[l], order, grid, rank, d) for l in range(ngeom)]
-    ogeoms = [_OverlapGeom(cells[l], grid, rank, d, depths[l]) if depths[l] > 0 else None for l in range(nlevels)]
+    ogeoms = [_OverlapGeom(cells[l], grid, rank, d, depths[l], order, reach) if depths[l] > 0 else None for l in range(nlevels)]
 
     def fine_cols(l):
         """(elo, ehi) per axis of the column numbering of level l's vectors + the remap to apply afterwards (None: lexicographic as is)"""
@@ -415,7 +451,7 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
             if d == 3:
                 terms.append((M[0], M[1], K[2]))
             L.A = po._tensor_csr(cols, terms, ncols)
-            L.overlap, L.depth, L.n_local = True, og.depth, og.n_local
+            L.overlap, L.depth, L.n_local, L.layers, L.ogeom = True, og.depth, og.n_local, og.layers, og
             L.n_own, L.n_ghost = og.n_own, og.n_local - og.n_own
             L.own_idx, L.local_gid, L.own_gid = og.own_idx, og.gid, og.own_gid
             L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr, L.rcv_idx = og.plan()

@@ -339,7 +339,11 @@ GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_
  * rows of non-owned coarse entries are empty.  Levels >= 1 with Jacobi smoothers; the finest level keeps gmg_set_partition.
  * snd_idx / rcv_idx: local ids (0-based) sent to / received from each neighbour, both sides enumerating in the same (global) order.
  * Reference analogue: consistent!(::PVector) once per mul! (RichardsonSmoothers.jl:94 through PartitionedArrays) -- here once per
- * `depth` applications. */
+ * `depth` applications.
+ * Patch smoothers (round 4): gmg_set_smoother_patch with EVERY patch whose dofs all lie in the local box (local numbering), blocks
+ * A[p,p] from the local matrix -- exact there --, patch_cols = patch_rows; `depth` then counts sweeps of Richardson(PatchSolver),
+ * each of which consumes 3 order - 2 node layers on vertex stars (partition._OverlapGeom).  No assemble! and no consistent!(dx)
+ * inside a block: ceil(niter / depth) exchanges per pass instead of 2 niter + niter reverse exchanges (PatchSolvers.jl:227-258). */
 GMG_API int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, int64_t n_ghost, int depth, int nnbr,
                                       const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
                                       const int64_t *rcv_ptr, const int64_t *rcv_idx);

@@ -101,7 +101,17 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
             for blk in range(0, niter, k):
                 exchange(l, r)
                 for _ in range(min(k, niter - blk)):
-                    dx = omega * (dinv[l] * r)
+                    if patches is not None:
+                        # additive Schwarz over EVERY vertex star inside the extended box: no assemble!, no exchange of dx
+                        pp, pl, Binv = patches[l]
+                        dx = np.zeros_like(r)
+                        for p in range(pp.size - 1):
+                            idx = pl[pp[p]:pp[p + 1]]
+                            if idx.size:
+                                dx[idx] += Binv[p] @ r[idx]
+                        dx *= omega
+                    else:
+                        dx = omega * (dinv[l] * r)
                     x += dx
                     r -= A[l] @ dx
             return
@@ -464,7 +474,7 @@ def main():
     if mode == "gpu_block":
         pass
     elif mode == "numpy":
-        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from, depth)
+        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from, depth, smoother)
         b = po.dirichlet_lift_rhs(cg, order)[local["levels"][0].own_gid]
         patches = None
         if smoother == "patch":
@@ -472,6 +482,13 @@ def main():
             for l in range(nlev - 1):
                 Lc = local["levels"][l]
                 Ag = po.poisson_matrix(local["cells"][l], order).to_scipy().tocsr()
+                if getattr(Lc, "overlap", False):
+                    pp, pl = Lc.ogeom.vertex_star_patches()
+                    Al = Lc.A.to_scipy().tocsr()
+                    Binv = [np.linalg.inv(Al[pl[pp[p]:pp[p + 1]]][:, pl[pp[p]:pp[p + 1]]].toarray()) if pp[p + 1] > pp[p] else None
+                            for p in range(pp.size - 1)]
+                    patches.append((pp, pl.astype(np.int64), Binv))
+                    continue
                 if Lc.replicated:
                     pp, pd = po.vertex_star_patches(local["cells"][l], order)
                     pl, pg = pd.astype(np.int64), pd.astype(np.int64)
@@ -481,6 +498,7 @@ def main():
                         for p in range(pp.size - 1)]
                 patches.append((pp, pl.astype(np.int64), Binv))
             x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol, p_niter, p_omega, patches)
+            verdict["exchanges"] = int(numpy_distributed_cg.last_exchanges)
         else:
             x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol)
             verdict["exchanges"] = int(numpy_distributed_cg.last_exchanges)
