@@ -1760,7 +1760,8 @@ struct gmg_solver {
     const DevCSR &M = L.A;
     if (!(pat_rsweep && one_gather_sweep && pat_dinv && M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && pat_rb == 3 && pat_batched)) return false;
     if (M.pat_nruns % 3 != 0 || !M.pdinv || !M.pdinv_uniform || !L.rbuf[0] || !L.rbuf[1]) return false;
-    if (M.ncols >= (int64_t)(1 << 28) || M.nrows >= (int64_t)(1 << 28)) return false;      // signed 32-bit byte offsets in the gathers
+    // signed 32-bit byte offsets in the gathers: 8 * (row + run offset) is formed BEFORE the clamp, and row reaches 63 past the last slice
+    if (M.ncols >= (int64_t)(1 << 28) || M.nrows + 64 + std::max<int64_t>(M.pat_maxoff, -(int64_t)M.pat_minoff) >= (int64_t)(1 << 28)) return false;
     const int nu = M.pat_k * M.pat_nruns;
     return (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16 <= 64 * 1024;
   }

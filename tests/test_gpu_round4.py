@@ -290,3 +290,79 @@ def test_fused_multiply_add_taps_stay_inside_the_parity_gates(S, po, orc, nc, nl
     assert solver.log.num_iters == nit
     np.testing.assert_allclose(solver.log.residuals[: nit + 1], hist, rtol=1e-8)
     assert rel_err(xs, xo) <= 1e-10
+
+
+# ---------------------------------------------------------------- config 3: setup on the device, coarse solver chosen by size
+def q2_patch_solver(S, po, nc, nlev, **opts):
+    H = po.build_hierarchy(nc, nlev, 2)
+    tabs = [po.vertex_star_patches(c, 2) for c in H["ncells"][:-1]]
+    sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2) for pp, pd in tabs]
+    return H, tabs, S.FGMRESSolver(5, make_gmg(S, H, pre_smoothers=sm, options=opts), maxiter=20, atol=1e-14, rtol=1e-6)
+
+
+def test_patch_operator_lists_built_on_the_device_equal_the_host_path(S, po, orc):
+    """Additive-Schwarz operator in row-pattern form (PatchSolvers.jl:279-300 as ONE mat-vec): the counting sort of the patch slots by
+    dof and the row signatures on the device (option patch_op_device, default) against the exact host path: identical pattern ids,
+    hence bit-identical solves; and the oracle's iteration count / history / solution."""
+    nc, nlev = (16, 16, 16), 3
+    res = {}
+    for dev in (0, 1):
+        H, tabs, solver = q2_patch_solver(S, po, nc, nlev, patch_op_device=dev)
+        ns = setup(S, solver, H["mats"][0])
+        b = po.dirichlet_lift_rhs(nc, 2)
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        res[dev] = (x, solver.log.residuals[: solver.log.num_iters + 1].copy(), solver.log.num_iters)
+        ns.P_ns.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in tabs], maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert res[1][2] == nit
+    np.testing.assert_allclose(res[1][1], hist, rtol=1e-6)
+    assert rel_err(res[1][0], xo) <= 1e-9
+
+
+def test_coarse_solver_chosen_by_size_keeps_the_iteration_count(S, po, orc):
+    """A dense-inverse request (LUSolver(), GMGLinearSolvers.jl:54) on a coarsest level of at least coarse_auto_cg_min dofs is served by
+    CGSolver(JacobiLinearSolver()) on the device run to rtol 1e-10 (default threshold 20 000: config 3's 29 791-dof coarsest level;
+    lowered here): the outer iteration count and flag are those of the exact coarse solve and of the oracle, the history agrees to
+    1e-6, the solution to 1e-8; the coarse solver's own log is available."""
+    nc, nlev = (16, 16, 16), 3          # coarsest level: 7^3 = 343 dofs
+    out = {}
+    for amin in (0, 100):
+        H, tabs, solver = q2_patch_solver(S, po, nc, nlev, coarse_auto_cg_min=amin)
+        ns = setup(S, solver, H["mats"][0])
+        b = po.dirichlet_lift_rhs(nc, 2)
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        out[amin] = (x, solver.log.residuals[: solver.log.num_iters + 1].copy(), solver.log.num_iters, solver.log.flag)
+        if amin:
+            cl = ns.P_ns.coarse_log()
+            assert 5 < cl["niters"] < 2000 and cl["res"] <= 1.0001e-10 * cl["res0"]
+        else:
+            from gridapsolvers_jl_amd import abi
+            with pytest.raises(abi.GmgError):
+                ns.P_ns.coarse_log()                      # the exact path has no iterative coarse solve
+        ns.P_ns.close()
+    assert out[0][2] == out[100][2] and out[0][3] == out[100][3]
+    np.testing.assert_allclose(out[100][1], out[0][1], rtol=1e-6)
+    assert rel_err(out[100][0], out[0][0]) <= 1e-8
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in tabs], maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-6)
+    assert out[100][2] == nit
+
+
+def test_posted_norm_equals_the_copied_norm(S, po):
+    """host_poll: the residual norm of every Krylov iteration posted into host-mapped memory and polled (default) against the copy +
+    hipStreamSynchronize path -- the same kernels produce the number: identical histories and solutions"""
+    nc, nlev = (24, 24, 24), 3
+    H = po.build_hierarchy(nc, nlev, 1)
+    b = po.dirichlet_lift_rhs(nc, 1)
+    res = []
+    for poll in (1, 0):
+        solver = cg(S, H, options={"host_poll": poll})
+        ns = setup(S, solver, H["mats"][0])
+        x = np.zeros_like(b)
+        S.solve_(x, ns, b)
+        res.append((x, solver.log.residuals[: solver.log.num_iters + 1].copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
