@@ -2693,7 +2693,7 @@ struct gmg_solver {
   // (the memcpy of chunk k+1 overlaps the DMA of chunk k) instead of the runtime's synchronous pageable path; (iii) with the option
   // GMG_X0_ZERO the initial guess is not uploaded at all (hipMemsetAsync) -- the reference CG reads x (CGSolvers.jl:79), so that is
   // an opt-in for callers that know x0 = 0.
-  struct HostReg { const char *base; size_t bytes; };
+  struct HostReg { const char *base; size_t bytes; bool ours; };
   std::vector<HostReg> host_regs;
   bool host_registered(const void *p, size_t bytes) const
   {
@@ -4576,7 +4576,8 @@ int gmg_destroy(gmg_handle_t h)
   if (h->h_scalars) (void)hipHostFree(h->h_scalars);
   if (h->h_perr) (void)hipHostFree(h->h_perr);
   if (h->h_mail) (void)hipHostFree(h->h_mail);
-  for (const auto &r : h->host_regs) (void)hipHostUnregister(const_cast<char *>(r.base));   // the caller's pages are unpinned, never freed
+  for (const auto &r : h->host_regs)
+    if (r.ours) (void)hipHostUnregister(const_cast<char *>(r.base));   // the caller's pages are unpinned, never freed
   for (int i = 0; i < 2; ++i) {
     if (h->h_chunk[i]) (void)hipHostFree(h->h_chunk[i]);
     if (h->ev_chunk[i]) (void)hipEventDestroy(h->ev_chunk[i]);
@@ -4958,8 +4959,21 @@ int gmg_host_register(gmg_handle_t h, const void *ptr, int64_t nbytes)
   return guarded(h, [&] {
     REQUIRE(h && ptr && nbytes > 0, GMG_ERR_INVALID, "gmg_host_register: null handle / pointer or empty range");
     if (h->host_registered(ptr, (size_t)nbytes)) return;
-    HIP_CHECK(hipHostRegister(const_cast<void *>(ptr), (size_t)nbytes, hipHostRegisterDefault));
-    h->host_regs.push_back({static_cast<const char *>(ptr), (size_t)nbytes});
+    // page-locked by somebody else already (hipHostMalloc'd, or registered through another handle or library)?  DMA works as it is;
+    // remembered as foreign so that this handle never unregisters it
+    hipPointerAttribute_t attr;
+    const hipError_t pa = hipPointerGetAttributes(&attr, ptr);
+    (void)hipGetLastError();                                 // (a plain malloc'd pointer is "invalid value" for the query)
+    hipError_t e = hipSuccess;
+    const bool foreign = pa == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!foreign) e = hipHostRegister(const_cast<void *>(ptr), (size_t)nbytes, hipHostRegisterDefault);
+    if (foreign || e == hipErrorHostMemoryAlreadyRegistered) {
+      (void)hipGetLastError();
+      h->host_regs.push_back({static_cast<const char *>(ptr), (size_t)nbytes, false});
+      return;
+    }
+    HIP_CHECK(e);
+    h->host_regs.push_back({static_cast<const char *>(ptr), (size_t)nbytes, true});
   });
 }
 
@@ -4970,7 +4984,7 @@ int gmg_host_unregister(gmg_handle_t h, const void *ptr)
     for (size_t i = 0; i < h->host_regs.size(); ++i)
       if (h->host_regs[i].base == static_cast<const char *>(ptr)) {
         HIP_CHECK(hipStreamSynchronize(h->stream));
-        HIP_CHECK(hipHostUnregister(const_cast<void *>(ptr)));
+        if (h->host_regs[i].ours) HIP_CHECK(hipHostUnregister(const_cast<void *>(ptr)));
         h->host_regs.erase(h->host_regs.begin() + (long)i);
         return;
       }

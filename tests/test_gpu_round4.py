@@ -132,6 +132,14 @@ def test_registered_and_unregistered_host_vectors_give_identical_bits(S, po, orc
     S.solve_(xd2, ns, torch.from_numpy(b).cuda())     # device callers: the same option zeroes x in place
     assert np.array_equal(xd2.cpu().numpy(), x_dev)
     g.set_option("x0_zero", 0)
+    # memory somebody else page-locked already (here: torch) registers as foreign: used by DMA as it is, never unregistered by the handle
+    tp = torch.zeros(n, dtype=torch.float64).pin_memory()
+    x_tp = tp.numpy()
+    g.register_host(x_tp)
+    S.solve_(x_tp, ns, b_rg)
+    assert np.array_equal(x_tp, x_dev)
+    g.unregister_host(x_tp)
+    tp.copy_(torch.from_numpy(x_dev))                 # still page-locked for its owner
     g.unregister_host(big); g.unregister_host(b_rg)
     assert g.host_io_stats()["registered"] == 0
     from gridapsolvers_jl_amd import abi
