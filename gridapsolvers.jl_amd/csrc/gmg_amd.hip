@@ -590,6 +590,8 @@ struct gmg_solver {
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
   int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU)
+  int pat_r2mv = 1;     // GMG_PAT_R2MV: mat-vecs (y = A x, y -= A x, y = b - A x) with two rows per lane (sells_r2mv_kernel)
+  int64_t pat_r2mv_min = 100000;   // GMG_PAT_R2MV_MIN: smallest level (rows) that takes it
   int pat_fma = 0;      // GMG_PAT_FMA: fused multiply-add taps in the row-pattern sweeps (one rounding per tap: not the reference's mul! arithmetic)
   int pat_rsweep = 1;   // GMG_PAT_RSWEEP: sweeps of uniform-diagonal row-pattern levels gather r itself (no s vector: sells_rsweep_kernel)
   int pat_defer = 1;    // GMG_PAT_DEFER: x updated every second sweep (shared-offset pattern kernel)
@@ -682,6 +684,7 @@ struct gmg_solver {
       L.s0_ready = false;
     }
     d_Ainv = d_partials = d_scalars = nullptr;
+    d_partials2 = nullptr;
     cc_w = cc_p = cc_z = cc_r = nullptr;
     d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr;
     for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; L.halo.d_recvbuf = nullptr; L.halo.d_pk_ptr = nullptr; L.halo.d_pk_slot = nullptr; }
@@ -1323,6 +1326,28 @@ struct gmg_solver {
     const size_t lds = M.pat_coded ? (size_t)2048 + (((size_t)M.pat_np * nu + 7) / 8) * 8 + (size_t)M.pat_np * 12 + 8
                                    : (size_t)M.pat_np * nu * 12 + 8 + (size_t)M.pat_np * 8;
     const dim3 g(nwg), b(64 * wpb);
+    if constexpr ((EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID) && !ONEG) {
+      // two rows per lane (sells_r2mv_kernel): the mat-vecs of CG and of the coarse-grid correction on the big row-pattern levels
+      if (pat_r2mv && !M.pat_coded && M.pat_k == 3 && (M.pat_nruns == 9 || M.pat_nruns == 3) && !a2.s_out && M.nrows >= pat_r2mv_min &&
+          M.ncols < (int64_t)(1 << 28) && M.nrows + 192 + std::max<int64_t>(M.pat_maxoff, -(int64_t)M.pat_minoff) < (int64_t)(1 << 28) &&
+          (size_t)M.pat_np * nu * 16 + 16 <= 64 * 1024) {
+        const int nsl2 = (int)((M.nrows + 125) / 126);
+        a.nslices = nsl2;
+        const dim3 gr(std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : 4 * n_cus)));
+        const size_t lds2 = (size_t)M.pat_np * nu * 16 + 16;
+        const bool mk = pat_strict || !M.ptab8;
+#define GMG_R2MV_LAUNCH(MKV, FMV)                                                                              \
+        do {                                                                                                     \
+          if (M.pat_nruns == 9) hipLaunchKernelGGL((sells_r2mv_kernel<EPI, MKV, FMV, 9>), gr, b, lds2, stream, a);   \
+          else hipLaunchKernelGGL((sells_r2mv_kernel<EPI, MKV, FMV, 3>), gr, b, lds2, stream, a);                \
+        } while (0)
+        if (mk) { if (pat_fma) GMG_R2MV_LAUNCH(true, true); else GMG_R2MV_LAUNCH(true, false); }
+        else { if (pat_fma) GMG_R2MV_LAUNCH(false, true); else GMG_R2MV_LAUNCH(false, false); }
+#undef GMG_R2MV_LAUNCH
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
+    }
     if (EPI == EPI_SWEEP && ONEG && !M.pat_coded && M.pat_k == 3 && pat_rb == 3 && pat_batched && M.pat_nruns % 3 == 0 &&
         (size_t)M.pat_np * nu * 16 + (size_t)M.pat_np * 8 + 16 <= 64 * 1024) {
       // restructured sweep (sells_sweep_kernel): no conditional operand loads, one store drain per NB slices
@@ -1971,21 +1996,43 @@ struct gmg_solver {
   }
 
   // dot -> device scalar slot (no host sync)
-  void dot_async(int64_t n, const double *a, const double *b, int slot, bool take_sqrt)
+  // first stage only: partial sums into `parts` (kRedBlocks doubles); returns how many.  The second stage is either
+  // finish_reduction or the consumer kernel itself (sum_partials_all).
+  int dot_partials(int64_t n, const double *a, const double *b, double *parts)
   {
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n / 2 + kBlock - 1) / kBlock));
     const bool aligned = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
-    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, n, a, b, d_partials, aligned ? 1 : 0);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(kBlock), 0, stream, n, a, b, parts, aligned ? 1 : 0);
     HIP_CHECK(hipGetLastError());
-    finish_reduction(nb, slot, take_sqrt);
+    return nb;
   }
+  void dot_async(int64_t n, const double *a, const double *b, int slot, bool take_sqrt, bool post = false)
+  {
+    const int nb = dot_partials(n, a, b, d_partials);
+    finish_reduction(nb, slot, take_sqrt, d_partials, post);
+  }
+  // red_fused (default): inside cg_core the second stage of a reduction is done by the kernel that consumes the scalar, and the one
+  // the host needs is reduced and posted by one launch -- single rank (or rank-local reductions) only
+  int red_fused = 1;                   // GMG_RED_FUSED
+  double *d_partials2 = nullptr;
+  bool fuse_reductions() const { return red_fused != 0 && (comm.nranks == 1 || reduce_local) && d_partials2 != nullptr; }
   // partials -> d_scalars[slot] = (sqrt of) the GLOBAL sum.  Single GPU: one kernel.  Several
   // ranks: local sum, all-reduce over the parts (the reduction PartitionedArrays performs
   // inside dot/norm on a PVector), then the square root.
-  void finish_reduction(int nb, int slot, bool take_sqrt)
+  // post: single rank with host_poll -- the scalar is also posted to the host by the same launch (fetch_scalar then only waits)
+  void finish_reduction(int nb, int slot, bool take_sqrt, const double *parts = nullptr, bool post = false)
   {
+    if (!parts) parts = d_partials;
     const bool dist = comm.nranks > 1 && !reduce_local;
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, stream, nb, d_partials, d_scalars + slot,
+    if (post && !dist && red_fused && opt_int("GMG_HOST_POLL", 1)) {
+      need_mail();
+      posted = ++mail_seq;
+      hipLaunchKernelGGL(reduce_post_kernel, dim3(1), dim3(kBlock), 0, stream, nb, parts, d_scalars + slot, take_sqrt ? 1 : 0,
+                         &d_mail->value, &d_mail->seq, posted);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, stream, nb, parts, d_scalars + slot,
                        (take_sqrt && !dist) ? 1 : 0);
     HIP_CHECK(hipGetLastError());
     if (!dist) return;
@@ -2186,17 +2233,26 @@ struct gmg_solver {
   struct Mail { double value; unsigned long long seq; };
   Mail *h_mail = nullptr, *d_mail = nullptr;
   unsigned long long mail_seq = 0;
+  void need_mail()
+  {
+    if (h_mail) return;
+    HIP_CHECK(hipHostMalloc((void **)&h_mail, 64, hipHostMallocMapped));
+    h_mail->value = 0.0; h_mail->seq = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&d_mail, h_mail, 0));
+  }
+  // finish_reduction(..., post = true) posts the scalar with the launch that reduces it: `posted` != 0 tells fetch_scalar to wait for that number
+  unsigned long long posted = 0;
   double fetch_scalar(int slot)
   {
     if (opt_int("GMG_HOST_POLL", 1)) {
-      if (!h_mail) {
-        HIP_CHECK(hipHostMalloc((void **)&h_mail, 64, hipHostMallocMapped));
-        h_mail->value = 0.0; h_mail->seq = 0;
-        HIP_CHECK(hipHostGetDevicePointer((void **)&d_mail, h_mail, 0));
+      need_mail();
+      unsigned long long want = posted;
+      posted = 0;
+      if (!want) {
+        want = ++mail_seq;
+        hipLaunchKernelGGL(post_scalar_kernel, dim3(1), dim3(1), 0, stream, d_scalars + slot, &d_mail->value, &d_mail->seq, want);
+        HIP_CHECK(hipGetLastError());
       }
-      const unsigned long long want = ++mail_seq;
-      hipLaunchKernelGGL(post_scalar_kernel, dim3(1), dim3(1), 0, stream, d_scalars + slot, &d_mail->value, &d_mail->seq, want);
-      HIP_CHECK(hipGetLastError());
       volatile unsigned long long *seq = &h_mail->seq;
       const auto t0 = std::chrono::steady_clock::now();
       unsigned spins = 0;
@@ -2213,6 +2269,7 @@ struct gmg_solver {
       check_persistent();
       return h_mail->value;
     }
+    posted = 0;
     HIP_CHECK(hipMemcpyAsync(h_scalars + slot, d_scalars + slot, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     check_persistent();
@@ -2220,12 +2277,12 @@ struct gmg_solver {
   }
   double dot(int64_t n, const double *a, const double *b)
   {
-    dot_async(n, a, b, 0, false);
+    dot_async(n, a, b, 0, false, true);
     return fetch_scalar(0);
   }
   double norm(int64_t n, const double *a)
   {
-    dot_async(n, a, a, 0, true);
+    dot_async(n, a, a, 0, true, true);
     return fetch_scalar(0);
   }
 
@@ -2834,8 +2891,11 @@ struct gmg_solver {
       n_cus = std::max(1, v);
     }
     pat_bcast = opt_int("GMG_PAT_BCAST", 1);
+    red_fused = opt_int("GMG_RED_FUSED", 1);
     pat_r2 = opt_int("GMG_PAT_R2", 1);
     pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
+    pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
+    pat_r2mv_min = opt_int("GMG_PAT_R2MV_MIN", 100000);
     pat_fma = opt_int("GMG_PAT_FMA", 0);
     persist = opt_int("GMG_PERSIST", 1);
     // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
@@ -2895,6 +2955,7 @@ struct gmg_solver {
   void init_reductions()
   {
     d_partials = dvec(kRedBlocks);
+    d_partials2 = dvec(kRedBlocks);
     d_scalars = dvec(kScalarSlots);
     if (!h_scalars) HIP_CHECK(hipHostMalloc((void **)&h_scalars, kScalarSlots * sizeof(double)));
   }
@@ -2967,27 +3028,35 @@ static double cg_core(gmg_solver &S, int64_t n, const double *db, double *dx, do
   bool done = log.init(resn);                            // :86
   bool first = true;
   const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kRedBlocks, (n + kBlock - 1) / kBlock));
+  // fused second stages (sum_partials_all): gamma = dot(z,r) is summed by xpby_dev_kernel, dot(p,w) by cg_update_kernel, and
+  // ||r|| is reduced and posted to the host by one launch -- 4 launches per iteration instead of 8 for the scalars
+  const bool fuse = S.fuse_reductions();
+  const unsigned xgrid = fuse ? (unsigned)nb : (unsigned)gmg_solver::grid_for(n);
   while (!done) {
+    int ngp = 0;                                         // gamma still in partials?
     if (!ops.precond) {                                  // :90-92
       S.copy(z, r, n);
-      S.dot_async(n, r, r, g_new, false);
+      if (fuse) ngp = S.dot_partials(n, r, r, S.d_partials); else S.dot_async(n, r, r, g_new, false);
     } else if (!flexible) {                              // :93-95
       ops.precond(z, r, resn);
-      S.dot_async(n, z, r, g_new, false);
+      if (fuse) ngp = S.dot_partials(n, z, r, S.d_partials); else S.dot_async(n, z, r, g_new, false);
     } else {                                             // :96-99
       S.dot_async(n, z, r, kDelta, false);
       ops.precond(z, r, resn);
-      S.dot_async(n, z, r, g_new, false);
+      if (fuse) ngp = S.dot_partials(n, z, r, S.d_partials); else S.dot_async(n, z, r, g_new, false);
     }
-    hipLaunchKernelGGL(xpby_dev_kernel, dim3(gmg_solver::grid_for(n)), dim3(256), 0, S.stream, n, z, S.d_scalars + g_new,
-                       S.d_scalars + g_old, (ops.precond && flexible) ? S.d_scalars + kDelta : nullptr, p, first ? 1 : 0); // :101
+    hipLaunchKernelGGL(xpby_dev_kernel, dim3(xgrid), dim3(kBlock), 0, S.stream, n, z, S.d_scalars + g_new,
+                       S.d_scalars + g_old, (ops.precond && flexible) ? S.d_scalars + kDelta : nullptr, p, first ? 1 : 0,
+                       ngp ? S.d_partials : nullptr, ngp); // :101
     HIP_CHECK(hipGetLastError());
     ops.apply(p, w);                                     // :104
-    S.dot_async(n, p, w, kPW, false);                    // :105
+    int npw = 0;
+    if (fuse) npw = S.dot_partials(n, p, w, S.d_partials); else S.dot_async(n, p, w, kPW, false);   // :105
+    double *nparts = fuse ? S.d_partials2 : S.d_partials;
     hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, S.d_scalars + g_new, S.d_scalars + kPW, p, w, dx, r,
-                       S.d_partials); // :108-109
+                       nparts, npw ? S.d_partials : nullptr, npw); // :108-109
     HIP_CHECK(hipGetLastError());
-    S.finish_reduction(nb, 0, true);
+    S.finish_reduction(nb, 0, true, nparts, true);
     resn = S.fetch_scalar(0);                            // :111
     done = log.update(resn);                             // :112
     std::swap(g_old, g_new);
@@ -4911,7 +4980,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

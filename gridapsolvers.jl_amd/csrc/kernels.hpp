@@ -1890,6 +1890,135 @@ __global__ __launch_bounds__(kBlock) void sells_r2sweep_kernel(SellSArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// The operator mat-vecs of a row-pattern level with two rows per lane: y = A x (EPI_SET: CGSolvers.jl:104), y -= A x (EPI_SUB:
+// GMGLinearSolvers.jl:495), y = b - A x (EPI_RESID: CGSolvers.jl:79).  The layout, the windows and the strict-mask rule of
+// sells_r2sweep_kernel without the omega*(d*.) of a sweep: the gathered value IS the window value.  Same taps in the same order as
+// sells_kernel<EPI, false, 3>: bit-identical (FM = false).
+//   a.x gathered ; a.y result (SUB: also read) ; a.b (RESID) ; a.nslices = ceil(nrows / 126)
+// ---------------------------------------------------------------------------
+template <int EPI, bool MK, bool FM, int NR>
+__global__ __launch_bounds__(kBlock) void sells_r2mv_kernel(SellSArgs a)
+{
+  static_assert(EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID, "mat-vec epilogues only");
+  constexpr int K = 3, ROWS2 = 126, RB = 3;
+  extern __shared__ double sp_smem[];
+  const int nu = K * NR;
+  const int tot = a.np * nu;
+  double *s_tab8 = sp_smem;
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x;
+  const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
+  const int chunk_lo = a.nslices / nwg, chunk_rem = a.nslices % nwg;
+  const int s_begin = blk * chunk_lo + min(blk, chunk_rem);
+  const int s_end = s_begin + chunk_lo + (blk < chunk_rem ? 1 : 0);
+  const double *__restrict__ xg = a.x;
+  const double *__restrict__ eg = EPI == EPI_RESID ? a.b : a.y;
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  const int lo_need = -a.minoff, hi_need = a.maxoff + 2 * 64 + 2;
+  int roff[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  int pidA = 0, pidB = 0, row = 0;
+  bool inner = false;
+  gmg_d2 e0, A[RB];
+  auto load_slice = [&](int slice) {
+    const int r0 = slice * ROWS2;
+    row = r0 + 2 * lane;
+    inner = r0 >= lo_need && r0 + hi_need <= last && r0 + 2 * 64 <= lastrow;      // wave-uniform
+    e0 = gmg_d2{0.0, 0.0};
+    if (inner) {
+      const uint32_t pp = *reinterpret_cast<const uint32_t *>(a.rowpid + row);
+      pidA = (int)(pp & 0xffffu); pidB = (int)(pp >> 16);
+      if (EPI != EPI_SET) e0 = ld2_unaligned(eg + row);
+#pragma unroll
+      for (int q = 0; q < RB; ++q) A[q] = ld2_unaligned(xg + row + roff[q]);
+    } else {
+      const int ra = min(row, lastrow), rb = min(row + 1, lastrow);
+      pidA = (int)a.rowpid[ra]; pidB = (int)a.rowpid[rb];
+      if (EPI != EPI_SET) e0 = gmg_d2{eg[ra], eg[rb]};
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int c = row + roff[q];
+        A[q] = gmg_d2{xg[min(max(c, 0), last)], xg[min(max(c + 1, 0), last)]};
+      }
+    }
+  };
+  int sb = s_begin + wave;
+  if (sb < s_end) load_slice(sb);
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
+  else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
+  __syncthreads();
+  while (sb < s_end) {
+    const uint32_t *tmA = s_msk + pidA * nu, *tmB = s_msk + pidB * nu;
+    const double *tvA = s_tab8 + pidA * nu, *tvB = s_tab8 + pidB * nu;
+    double sA = 0.0, sB = 0.0;
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += RB) {
+      gmg_d2 cur[RB];
+#pragma unroll
+      for (int q = 0; q < RB; ++q) cur[q] = A[q];
+      if (r0 + RB < NR) {
+        if (inner) {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) A[q] = ld2_unaligned(xg + row + roff[r0 + RB + q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < RB; ++q) {
+            const int c = row + roff[r0 + RB + q];
+            A[q] = gmg_d2{xg[min(max(c, 0), last)], xg[min(max(c + 1, 0), last)]};
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const double w0 = cur[q].x, w1 = cur[q].y;
+        const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+        const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const int j = (r0 + q) * K + t;
+          const double ca = tvA[j], cb = tvB[j];
+          sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
+          sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+        }
+      }
+    }
+    // strict form: see sells_r2sweep_kernel -- "all sums finite" proves that no mask was needed
+    if (MK && !__all(__builtin_isfinite(sA) && __builtin_isfinite(sB))) {
+      sA = 0.0; sB = 0.0;
+#pragma unroll 1
+      for (int q = 0; q < NR; ++q) {
+        const int c = row + roff[q];
+        const double w0 = xg[min(max(c, 0), last)], w1 = xg[min(max(c + 1, 0), last)];
+        const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+        const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const int j = q * K + t;
+          const double ga = __hiloint2double(__double2hiint(wa[t]) & (int)tmA[j], __double2loint(wa[t]));
+          const double gb = __hiloint2double(__double2hiint(wb[t]) & (int)tmB[j], __double2loint(wb[t]));
+          sA = FM ? __builtin_fma(tvA[j], ga, sA) : sA + tvA[j] * ga;
+          sB = FM ? __builtin_fma(tvB[j], gb, sB) : sB + tvB[j] * gb;
+        }
+      }
+    }
+    const gmg_d2 yn = EPI == EPI_SET ? gmg_d2{sA, sB} : gmg_d2{e0.x - sA, e0.y - sB};
+    if (lane < 63) {
+      if (inner) st2_unaligned(a.y + row, yn);
+      else {
+        if (row <= lastrow) a.y[row] = yn.x;
+        if (row + 1 <= lastrow) a.y[row + 1] = yn.y;
+      }
+    }
+    sb += wpb;
+    if (sb < s_end) load_slice(sb);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The r-gather sweep with the gathers shared through LDS ("tile sweep").  sells_rsweep_kernel fetches every r value nine times out of
 // L2 (once per run: 3 x 3 neighbouring grid lines; only the three taps of a run are shared inside the wave) -- at 128^3 that is
 // 150 MB of L2 -> L1 traffic per sweep on top of the 61 MB the sweep has to move, and neither fewer instructions nor another launch
@@ -2455,6 +2584,24 @@ __device__ __forceinline__ double block_sum(double s, double *sh /*[4]*/)
   return t; // valid on thread 0
 }
 
+// The second stage of a two-stage reduction done by the CONSUMER: every workgroup of the kernel that needs the scalar sums the
+// producer's partials itself -- the very sum reduce_final_kernel forms (same strided accumulation over kBlock lanes, same tree), so
+// every workgroup holds the same bits as the one-workgroup kernel would have written -- instead of a dependent 4.5 us launch in
+// between (three per CG iteration; a ticket scheme that lets the producer's last workgroup finalise was measured slower: +12 us per
+// producer for the agent-scope store / ticket / reload chain).  blockDim.x must be kBlock.  Returns the sum to every thread.
+__device__ __forceinline__ double sum_partials_all(const double *__restrict__ parts, int nparts, double *sh /*[5]*/)
+{
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) s += parts[i];
+  s = wave_sum(s);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sh[4] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return sh[4];
+}
+
 __global__ __launch_bounds__(kBlock) void dot_partial_kernel(int64_t n, const double *__restrict__ a,
                                                              const double *__restrict__ b,
                                                              double *__restrict__ partials, int vec)
@@ -2489,6 +2636,22 @@ __global__ __launch_bounds__(kBlock) void reduce_final_kernel(int nparts, const 
   if (threadIdx.x == 0) out[0] = take_sqrt ? sqrt(t) : t;
 }
 
+// reduce_final_kernel + post_scalar_kernel in one launch: the scalar is also posted into host-mapped memory (fetch_scalar polls the number)
+__global__ __launch_bounds__(kBlock) void reduce_post_kernel(int nparts, const double *__restrict__ partials, double *__restrict__ out,
+                                                             int take_sqrt, double *value, unsigned long long *seq, unsigned long long want)
+{
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) s += partials[i];
+  const double t = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    const double res = take_sqrt ? sqrt(t) : t;
+    out[0] = res;
+    __hip_atomic_store(value, res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(seq, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K8: axpy-class kernels
 // ---------------------------------------------------------------------------
@@ -2501,11 +2664,19 @@ __global__ void xpby_kernel(int64_t n, const double *__restrict__ z, double beta
 // The same with beta formed on the device from reduction results: beta = gamma/gamma_old, or
 // (gamma - delta)/gamma_old for the flexible variant (CGSolvers.jl:95,99) -- no host round trip.
 // first != 0: p is the zero vector of CGSolvers.jl:80 and is not read.
-__global__ void xpby_dev_kernel(int64_t n, const double *__restrict__ z, const double *__restrict__ gamma,
-                                const double *__restrict__ gamma_old, const double *__restrict__ delta,
-                                double *__restrict__ p, int first)
+// gparts != nullptr: gamma is still in the producer's partials (dot_partial_kernel): every workgroup sums them (sum_partials_all) and
+// workgroup 0 stores the scalar for the kernels that read it later.  blockDim.x == kBlock.
+__global__ __launch_bounds__(kBlock) void xpby_dev_kernel(int64_t n, const double *__restrict__ z, double *__restrict__ gamma,
+                                                          const double *__restrict__ gamma_old, const double *__restrict__ delta,
+                                                          double *__restrict__ p, int first, const double *__restrict__ gparts, int ngparts)
 {
-  const double beta = delta ? (gamma[0] - delta[0]) / gamma_old[0] : gamma[0] / gamma_old[0];
+  __shared__ double sh[5];
+  double g;
+  if (gparts) {
+    g = sum_partials_all(gparts, ngparts, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) gamma[0] = g;
+  } else g = gamma[0];
+  const double beta = delta ? (g - delta[0]) / gamma_old[0] : g / gamma_old[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     p[i] = z[i] + beta * (first ? 0.0 : p[i]);
 }
@@ -2519,13 +2690,22 @@ __global__ void post_scalar_kernel(const double *__restrict__ src, double *value
 }
 // x += alpha*p ; r -= alpha*w ; partial ||r||^2   (CGSolvers.jl:108-111)
 // alpha = gamma / dot(p,w) (CGSolvers.jl:105) formed on the device from the two reduction results
+// pwparts != nullptr: dot(p,w) is still in dot_partial_kernel's partials: summed by every workgroup (sum_partials_all), stored by
+// workgroup 0; `partials` (the output) must then be a different array
 __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, const double *__restrict__ gamma,
-                                                           const double *__restrict__ pw, const double *__restrict__ p,
+                                                           double *__restrict__ pw, const double *__restrict__ p,
                                                            const double *__restrict__ w, double *__restrict__ x,
-                                                           double *__restrict__ r, double *__restrict__ partials)
+                                                           double *__restrict__ r, double *__restrict__ partials,
+                                                           const double *__restrict__ pwparts, int npwparts)
 {
-  __shared__ double sh[4];
-  const double alpha = gamma[0] / pw[0];
+  __shared__ double sh[5];
+  double pwv;
+  if (pwparts) {
+    pwv = sum_partials_all(pwparts, npwparts, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) pw[0] = pwv;
+    __syncthreads();                                         // sh is reused below
+  } else pwv = pw[0];
+  const double alpha = gamma[0] / pwv;
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     x[i] += alpha * p[i];

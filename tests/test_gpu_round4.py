@@ -374,3 +374,46 @@ def test_posted_norm_equals_the_copied_norm(S, po):
         S.solve_(x, ns, b)
         res.append((x, solver.log.residuals[: solver.log.num_iters + 1].copy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("nc,nlev", [((48, 48, 48), 3), ((130, 66), 2), ((34, 46, 30), 2)])
+def test_pair_matvec_and_fused_reductions_are_bitwise_the_separate_forms(S, po, orc, nc, nlev):
+    """sells_r2mv_kernel (y = A x, y -= A x, y = b - A x with two rows per lane, default on levels of >= pat_r2mv_min rows) against
+    sells_kernel (option pat_r2mv = 0), and the reductions finalised by the producing kernel's last workgroup (norm posted to the host
+    from there) against dot_partial_kernel + reduce_final_kernel + post_scalar_kernel (red_fused = 0): the operator applied to a
+    vector holding Inf (confined to the rows that store a coefficient for it), a CG solve (RESID at the start, SET every iteration,
+    SUB in every V-cycle) with its residual history, and a plain dot agree to the last bit; the solve equals the oracle's."""
+    from gridapsolvers_jl_amd.abi import OP_A
+    H = po.build_hierarchy(nc, nlev, 1)
+    n = H["mats"][0].shape[0]
+    b = po.dirichlet_lift_rhs(nc, 1)
+    res = {}
+    for key in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        opts = {"pat_r2mv": key[0], "pat_r2mv_min": 1, "red_fused": key[1]}
+        solver = S.CGSolver(make_gmg(S, H, pre_smoothers=jac(S, nlev, 4), options=opts), maxiter=40, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        out = []
+        x = np.random.default_rng(7).uniform(-1, 1, n)
+        y = np.zeros(n)
+        ns.P_ns.op_apply(0, OP_A, x, y)
+        out.append(y.copy())
+        x[n // 2] = np.inf
+        x[3] = -np.inf
+        ns.P_ns.op_apply(0, OP_A, x, y)
+        out += [np.isfinite(y), np.where(np.isfinite(y), y, 0.0)]
+        xs = np.random.default_rng(8).uniform(-1, 1, n)      # a guess: y = b - A x at the start
+        S.solve_(xs, ns, b)
+        out += [xs, solver.log.residuals[: solver.log.num_iters + 1].copy()]
+        res[key] = out
+        ns.P_ns.close()
+    for key in ((0, 1), (1, 0), (0, 0)):
+        for a, c in zip(res[(1, 1)], res[key]):
+            np.testing.assert_array_equal(a, c)
+    np.testing.assert_array_equal(res[(1, 1)][0], orc.spmv(H["mats"][0], np.random.default_rng(7).uniform(-1, 1, n)))   # rows summed in the oracle's order
+    fin = res[(1, 1)][1]
+    assert not fin.all() and fin.sum() > 0.9 * n
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, 4, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
+    xo, nit, flag_o, hist = orc.cg_solve(H["mats"][0], b, x0=np.random.default_rng(8).uniform(-1, 1, n), Pl=go, maxiter=40, atol=1e-14, rtol=1e-8)
+    assert len(res[(1, 1)][-1]) == nit + 1
+    np.testing.assert_allclose(res[(1, 1)][-1], hist, rtol=1e-8)
+    assert rel_err(res[(1, 1)][-2], xo) <= 1e-10
