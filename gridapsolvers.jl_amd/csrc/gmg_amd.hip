@@ -437,6 +437,7 @@ constexpr int kScalarSlots = 4096;
 struct KrylovOps {
   std::function<void(double *x, const double *b, double *r)> resid;          // r = b - A x
   std::function<void(double *x, double *y)> apply;                           // y = A x
+  std::function<int(double *x, double *y, double *parts)> apply_dot;         // optional: y = A x + first stage of dot(x, y) -> #partials (0: not done)
   std::function<void(double *z, const double *r, double known_res)> precond; // empty: Pl === nothing (CG) / Pr === nothing (FGMRES)
   std::function<void(double *z, const double *r)> precond_left;              // FGMRES only: Pl of KrylovUtils.jl:14-18,46-50
   double *zl = nullptr;                                                      // its work vector (FGMRESSolvers.jl:66)
@@ -581,6 +582,7 @@ struct gmg_solver {
   int64_t pat_tile_rows = 6000000;
   int pat_wide = 1;     // GMG_PAT_WIDE: coded (wide-row) operators decode the patterns of each workgroup's chunk into a plain LDS value table
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
+  int persist_wpb_min = 1;   // GMG_PERSIST_WPB: smallest workgroup (in waves) of a one-launch pass
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
   int persist_fenced = 0; // GMG_PERSIST_FENCED: progress words published with release / polled with acquire semantics (agent scope)
   int persist_max_slices = 0;  // GMG_PERSIST_MAX_SLICES (0: what one workgroup per CU holds)
@@ -590,6 +592,8 @@ struct gmg_solver {
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
   int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU)
+  int pat_r2mv_dot = 1; // GMG_PAT_R2MV_DOT: dot(p, A p) of CG formed by the mat-vec kernel (first stage; order of the sum differs from dot_partial_kernel's)
+  int pat_pair_p = 1;   // GMG_PAT_PAIR_P: prolongation + correction with two rows per lane (sellp_pair_addto_kernel), levels of >= pat_r2mv_min rows
   int pat_r2mv = 1;     // GMG_PAT_R2MV: mat-vecs (y = A x, y -= A x, y = b - A x) with two rows per lane (sells_r2mv_kernel)
   int64_t pat_r2mv_min = 100000;   // GMG_PAT_R2MV_MIN: smallest level (rows) that takes it
   int pat_fma = 0;      // GMG_PAT_FMA: fused multiply-add taps in the row-pattern sweeps (one rounding per tap: not the reference's mul! arithmetic)
@@ -668,6 +672,7 @@ struct gmg_solver {
   }
   void free_all()
   {
+    dump_host_steps();
     for (void *p : allocs) (void)hipFree(p);
     allocs.clear();
     d_perr_dev = nullptr;
@@ -1307,6 +1312,26 @@ struct gmg_solver {
     const size_t nu = (size_t)M.pat_k * M.pat_nruns;
     return (size_t)lmax * (nu + M.pat_k) * 8 + (size_t)lmax * 12 + (size_t)M.pat_np + 16;
   }
+  // sells_r2mv_kernel applies: plain shared-offset table, 27- / 9-point runs, signed 32-bit offsets, table + masks within 64 KB of LDS
+  bool r2mv_ok(const DevCSR &M) const
+  {
+    const int nu = M.pat_k * M.pat_nruns;
+    return pat_r2mv && M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && (M.pat_nruns == 9 || M.pat_nruns == 3) && M.nrows >= pat_r2mv_min &&
+           M.ncols < (int64_t)(1 << 28) && M.nrows + 192 + std::max<int64_t>(M.pat_maxoff, -(int64_t)M.pat_minoff) < (int64_t)(1 << 28) &&
+           (size_t)M.pat_np * nu * 16 + 16 <= 64 * 1024;
+  }
+  double *r2mv_dot_parts = nullptr;    // set by spmv_set_dot around its launch
+  int r2mv_dot_n = 0;
+  // y = M x and the first stage of dot(x, y) in one kernel; returns the number of partials written to `parts`, 0 = not available
+  // (the caller then runs the separate dot).  Single rank, no halo.
+  int spmv_set_dot(const DevCSR &M, const double *x, double *y, double *parts)
+  {
+    if (!pat_r2mv_dot || comm.nranks > 1 || !r2mv_ok(M)) return 0;
+    r2mv_dot_parts = parts; r2mv_dot_n = 0;
+    try { spmv_set(M, x, y); } catch (...) { r2mv_dot_parts = nullptr; throw; }
+    r2mv_dot_parts = nullptr;
+    return r2mv_dot_n;
+  }
   template <int EPI, bool ONEG>
   void launch_sells(const DevCSR &M, const StreamArgs2 &a2)
   {
@@ -1328,9 +1353,7 @@ struct gmg_solver {
     const dim3 g(nwg), b(64 * wpb);
     if constexpr ((EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID) && !ONEG) {
       // two rows per lane (sells_r2mv_kernel): the mat-vecs of CG and of the coarse-grid correction on the big row-pattern levels
-      if (pat_r2mv && !M.pat_coded && M.pat_k == 3 && (M.pat_nruns == 9 || M.pat_nruns == 3) && !a2.s_out && M.nrows >= pat_r2mv_min &&
-          M.ncols < (int64_t)(1 << 28) && M.nrows + 192 + std::max<int64_t>(M.pat_maxoff, -(int64_t)M.pat_minoff) < (int64_t)(1 << 28) &&
-          (size_t)M.pat_np * nu * 16 + 16 <= 64 * 1024) {
+      if (r2mv_ok(M) && !a2.s_out) {
         const int nsl2 = (int)((M.nrows + 125) / 126);
         a.nslices = nsl2;
         const dim3 gr(std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : 4 * n_cus)));
@@ -1341,6 +1364,22 @@ struct gmg_solver {
           if (M.pat_nruns == 9) hipLaunchKernelGGL((sells_r2mv_kernel<EPI, MKV, FMV, 9>), gr, b, lds2, stream, a);   \
           else hipLaunchKernelGGL((sells_r2mv_kernel<EPI, MKV, FMV, 3>), gr, b, lds2, stream, a);                \
         } while (0)
+        if constexpr (EPI == EPI_SET) {
+          if (r2mv_dot_parts && gr.x <= (unsigned)kRedBlocks) {   // the first stage of dot(x, A x) rides along (spmv_set_dot)
+            a.s_out = r2mv_dot_parts;
+            r2mv_dot_n = (int)gr.x;
+#define GMG_R2MV_DOT(MKV, FMV)                                                                                 \
+            do {                                                                                                 \
+              if (M.pat_nruns == 9) hipLaunchKernelGGL((sells_r2mv_kernel<EPI_SET, MKV, FMV, 9, true>), gr, b, lds2, stream, a);   \
+              else hipLaunchKernelGGL((sells_r2mv_kernel<EPI_SET, MKV, FMV, 3, true>), gr, b, lds2, stream, a);  \
+            } while (0)
+            if (mk) { if (pat_fma) GMG_R2MV_DOT(true, true); else GMG_R2MV_DOT(true, false); }
+            else { if (pat_fma) GMG_R2MV_DOT(false, true); else GMG_R2MV_DOT(false, false); }
+#undef GMG_R2MV_DOT
+            HIP_CHECK(hipGetLastError());
+            return;
+          }
+        }
         if (mk) { if (pat_fma) GMG_R2MV_LAUNCH(true, true); else GMG_R2MV_LAUNCH(true, false); }
         else { if (pat_fma) GMG_R2MV_LAUNCH(false, true); else GMG_R2MV_LAUNCH(false, false); }
 #undef GMG_R2MV_LAUNCH
@@ -1411,6 +1450,22 @@ struct gmg_solver {
     const int nwg = std::max(1, std::min((M.nslices + wpb - 1) / wpb, pat_wgs));
     const size_t lds = (size_t)M.pat_np * M.pat_w * 12 + (size_t)M.pat_np * 4;
     const dim3 g(nwg), b(64 * wpb);
+    if constexpr (EPI == EPI_ADDTO && !ONEG) {
+      // two rows per lane (sellp_pair_addto_kernel): the prolongation + correction of the big levels
+      if (pat_pair_p && M.pat_generic && M.rowbase && M.nrows >= pat_r2mv_min && M.ncols < (int64_t)(1 << 28)) {
+        a.nslices = (int)((M.nrows + 127) / 128);
+        const dim3 gp(std::max(1, std::min((a.nslices + wpb - 1) / wpb, pat_wgs)));
+        switch (pat_un_eff()) {
+        case 27: hipLaunchKernelGGL((sellp_pair_addto_kernel<9>), gp, b, lds, stream, a); break;
+        case 14: hipLaunchKernelGGL((sellp_pair_addto_kernel<7>), gp, b, lds, stream, a); break;
+        case 9: hipLaunchKernelGGL((sellp_pair_addto_kernel<9>), gp, b, lds, stream, a); break;
+        case 6: hipLaunchKernelGGL((sellp_pair_addto_kernel<6>), gp, b, lds, stream, a); break;
+        default: hipLaunchKernelGGL((sellp_pair_addto_kernel<3>), gp, b, lds, stream, a); break;
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
+    }
     if (!M.pat_generic) {                                   // table kept in global memory / L2 (does not fit LDS)
       switch (pat_un_eff()) {
       case 27: hipLaunchKernelGGL((sellp_kernel<EPI, ONEG, 27, true>), g, b, 0, stream, a); break;
@@ -2315,7 +2370,7 @@ struct gmg_solver {
     const int cap = persist_max_slices > 0 ? persist_max_slices : n_cus * 16 * 2;
     if (nsl > cap || nsl > n_cus * 16 * 2 || M.nrows >= (int64_t)1 << 30) return false;
     // geometry: as many workgroups as CUs allow (latency-bound: spread the waves), one or two slices per wave
-    int wpb = 1;
+    int wpb = std::max(1, std::min(16, persist_wpb_min));
     while (wpb < 16 && (nsl + wpb - 1) / wpb > n_cus) wpb *= 2;
     int ns = (nsl + wpb - 1) / wpb > n_cus ? 2 : 1;
     const int64_t reach = std::max<int64_t>(-(int64_t)M.pat_minoff, (int64_t)M.pat_maxoff + 2);
@@ -2644,26 +2699,49 @@ struct gmg_solver {
     HIP_CHECK(hipMemcpyAsync(x, h_cx, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
   }
 
+  // GMG_HOST_TIMELINE=1 (debug): host-side duration of every step of the cycles (is a launch blocking?), printed when the handle dies
+  struct HostStep { const char *what; int lev; double t0, t1; };
+  std::vector<HostStep> host_steps;
+  int host_timeline = -1;
+  struct StepTimer {
+    gmg_solver &S; const char *what; int lev; double t0;
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    StepTimer(gmg_solver &s, const char *w, int l) : S(s), what(w), lev(l), t0(0.0) { if (S.host_timeline > 0) t0 = now(); }
+    ~StepTimer() { if (S.host_timeline > 0 && S.host_steps.size() < 4096) S.host_steps.push_back({what, lev, t0, now()}); }
+  };
+  void dump_host_steps()
+  {
+    if (host_steps.empty()) return;
+    const size_t first = host_steps.size() > 80 ? host_steps.size() - 80 : 0;
+    for (size_t i = first; i < host_steps.size(); ++i)
+      std::fprintf(stderr, "[gmg host] %10.1f us  +%7.1f  lev %d  %s\n", host_steps[i].t0 - host_steps[first].t0, host_steps[i].t1 - host_steps[i].t0, host_steps[i].lev, host_steps[i].what);
+  }
   // gmg_v_cycle! / gmg_w_cycle! / gmg_f_cycle!, GMGLinearSolvers.jl:468-610
   void cycle(int l, double *x, const double *r_in, bool x_zero, int ctype)
   {
+    if (host_timeline < 0) host_timeline = opt_int("GMG_HOST_TIMELINE", 0);
     Level &L = lev[l];
     if (l == nlev - 1) {                                   // :472-474
+      StepTimer tm(*this, "coarse", l);
       coarse_solve(r_in, x);
       return;
     }
     Level &C = lev[l + 1];
-    double *r = smooth(l, L.pre, x, r_in, x_zero);         // :481
+    double *r;
+    { StepTimer tm(*this, "pre-smooth", l); r = smooth(l, L.pre, x, r_in, x_zero); }         // :481
     const int passes = (ctype == GMG_V_CYCLE) ? 1 : 2;
     for (int pass = 0; pass < passes; ++pass) {
       if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
       exchange(l, r);
       if (comm.nranks > 1 && l + 1 == rep_from) restrict_replicate(l, r, C.rbuf[0]);
       else if (l + 1 < nlev - 1 && emits_s0(C, C.pre, L.R)) {
+        StepTimer tm(*this, "restrict+s0", l);
         spmv_set(L.R, r, C.rbuf[0], C.sbuf[0], C.dinv, C.pre.omega);   // :484 rH = R rh (+ the child's first s)
         C.s0_ready = true; C.s0_src = C.rbuf[0]; C.s0_omega = C.pre.omega;
-      } else
+      } else {
+      StepTimer tm(*this, "restrict", l);
       spmv_set(L.R, r, C.rbuf[0]);                         // :484 rH = R rh
+      }
       // :487 fill!(dxH,0) is implicit: the first sweep below / the coarse solve write dxH
       const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
       cycle(l + 1, C.x, C.rbuf[0], true, child);           // :488
@@ -2677,10 +2755,10 @@ struct gmg_solver {
         hipLaunchKernelGGL(prolong_correct_kernel, dim3(grid_for(L.n)), dim3(256), 0, stream, L.n, L.pcor, L.dx, x);
         HIP_CHECK(hipGetLastError());
       } else
-      spmv_addto(L.P, C.x, L.dx, x);                       // :491,494 dxh = P dxH ; xh += dxh
-      apply_A_sub(l, L.dx, r, &L.post);                    // :495-496 rh -= Ah dxh (+ the post-smoother's first s)
+      { StepTimer tm(*this, "prolong", l); spmv_addto(L.P, C.x, L.dx, x); }                       // :491,494 dxh = P dxH ; xh += dxh
+      { StepTimer tm(*this, "r -= A dx", l); apply_A_sub(l, L.dx, r, &L.post); }                    // :495-496 rh -= Ah dxh (+ the post-smoother's first s)
     }
-    r = smooth(l, L.post, x, r, false);                    // :499
+    { StepTimer tm(*this, "post-smooth", l); r = smooth(l, L.post, x, r, false); }                    // :499
     L.rcur = r;
   }
 
@@ -2894,7 +2972,10 @@ struct gmg_solver {
     red_fused = opt_int("GMG_RED_FUSED", 1);
     pat_r2 = opt_int("GMG_PAT_R2", 1);
     pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
+    persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
+    pat_pair_p = opt_int("GMG_PAT_PAIR_P", 1);
+    pat_r2mv_dot = opt_int("GMG_PAT_R2MV_DOT", 1);
     pat_r2mv_min = opt_int("GMG_PAT_R2MV_MIN", 100000);
     pat_fma = opt_int("GMG_PAT_FMA", 0);
     persist = opt_int("GMG_PERSIST", 1);
@@ -3001,6 +3082,7 @@ KrylovOps gmg_solver::level0_ops(int use_precond)
   KrylovOps ops;
   ops.resid = [this](double *x, const double *b, double *r) { apply_A_resid(0, x, b, r); };
   ops.apply = [this](double *x, double *y) { apply_A_set(0, x, y); };
+  if (comm.nranks == 1) ops.apply_dot = [this](double *x, double *y, double *parts) { return spmv_set_dot(lev[0].A, x, y, parts); };
   if (use_precond) ops.precond = [this, use_precond](double *z, const double *r, double known) { krylov_precond(use_precond, z, r, known); };
   return ops;
 }
@@ -3049,9 +3131,12 @@ static double cg_core(gmg_solver &S, int64_t n, const double *db, double *dx, do
                        S.d_scalars + g_old, (ops.precond && flexible) ? S.d_scalars + kDelta : nullptr, p, first ? 1 : 0,
                        ngp ? S.d_partials : nullptr, ngp); // :101
     HIP_CHECK(hipGetLastError());
-    ops.apply(p, w);                                     // :104
     int npw = 0;
-    if (fuse) npw = S.dot_partials(n, p, w, S.d_partials); else S.dot_async(n, p, w, kPW, false);   // :105
+    if (fuse && ops.apply_dot) npw = ops.apply_dot(p, w, S.d_partials);   // :104-105 in one kernel
+    if (!npw) {
+      ops.apply(p, w);                                   // :104
+      if (fuse) npw = S.dot_partials(n, p, w, S.d_partials); else S.dot_async(n, p, w, kPW, false);   // :105
+    }
     double *nparts = fuse ? S.d_partials2 : S.d_partials;
     hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, S.d_scalars + g_new, S.d_scalars + kPW, p, w, dx, r,
                        nparts, npw ? S.d_partials : nullptr, npw); // :108-109
@@ -4980,7 +5065,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

@@ -1039,6 +1039,96 @@ __global__ __launch_bounds__(kBlock) void sellp_kernel(SellPArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Prolongation + correction  dxh = P dxH ; xh += dxh  (GMGLinearSolvers.jl:491,494) of a big level with TWO rows per lane.  The
+// one-row kernel is a chain of three memory latencies per 64-row slice (pattern id / base / x -> gathers -> stores, and the next
+// slice's loads wait for the stores: one vmcnt) with four slices per wave at 128^3: 24 us for 62 MB.  Here a lane owns rows 2l and
+// 2l+1 of a 128-row slice: half the chains, twice the gathers in flight per chain, 16-byte loads / stores of x and dx, the two
+// pattern ids in one 4-byte load and the two base columns in one 8-byte load.  Rows are summed left to right as before: bit-identical.
+//   a.nslices = ceil(nrows / 128) ; a.rowbase != nullptr ; table in LDS (not the GT form)
+// ---------------------------------------------------------------------------
+typedef double gmg_pd2 __attribute__((ext_vector_type(2)));
+template <int UN>
+__global__ __launch_bounds__(kBlock) void sellp_pair_addto_kernel(SellPArgs a)
+{
+  extern __shared__ double sp_smem[];
+  const int tot = a.np * a.W;
+  {
+    double *w_val = sp_smem;
+    int32_t *w_off = reinterpret_cast<int32_t *>(sp_smem + tot);
+    int32_t *w_len = w_off + tot;
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) { w_val[i] = a.pval[i]; w_off[i] = a.poff[i]; }
+    for (int i = threadIdx.x; i < a.np; i += blockDim.x) w_len[i] = a.plen[i];
+    __syncthreads();
+  }
+  const double *s_val = sp_smem;
+  const int32_t *s_off = reinterpret_cast<const int32_t *>(sp_smem + tot);
+  const int32_t *s_len = s_off + tot;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwg = gridDim.x;
+  const int blk = remap_block(blockIdx.x, nwg, a.xcd_remap);
+  const int chunk_lo = a.nslices / nwg, chunk_rem = a.nslices % nwg;
+  const int s_begin = blk * chunk_lo + min(blk, chunk_rem);
+  const int s_end = s_begin + chunk_lo + (blk < chunk_rem ? 1 : 0);
+  const double *__restrict__ xg = a.x;
+  const int W = a.W;
+  const double omega = a.omega;
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  for (int slice = s_begin + wave; slice < s_end; slice += wpb) {
+    const int64_t row = (int64_t)slice * 128 + 2 * lane;
+    const bool inner = (int64_t)slice * 128 + 128 <= a.nrows;   // wave-uniform: every lane owns two rows
+    const bool vA = row < a.nrows, vB = row + 1 < a.nrows;
+    int pidA = a.np - 1, pidB = a.np - 1;                  // the last pattern is empty
+    uint32_t baseA = 0u, baseB = 0u;
+    gmg_pd2 e0 = gmg_pd2{0.0, 0.0};
+    if (inner) {
+      const uint32_t pp = *reinterpret_cast<const uint32_t *>(a.rowpid + row);
+      pidA = (int)(pp & 0xffffu); pidB = (int)(pp >> 16);
+      const int2 bb = *reinterpret_cast<const int2 *>(a.rowbase + row);
+      baseA = 8u * (uint32_t)bb.x; baseB = 8u * (uint32_t)bb.y;
+      e0 = *reinterpret_cast<const d2u *>(a.x2 + row);
+    } else {
+      if (vA) { pidA = (int)a.rowpid[row]; baseA = 8u * (uint32_t)a.rowbase[row]; e0.x = a.x2[row]; }
+      if (vB) { pidB = (int)a.rowpid[row + 1]; baseB = 8u * (uint32_t)a.rowbase[row + 1]; e0.y = a.x2[row + 1]; }
+    }
+    const int lenA = s_len[pidA], lenB = s_len[pidB];
+    int lmax = max(lenA, lenB);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o));
+    lmax = __builtin_amdgcn_readfirstlane(lmax);
+    const double *tvA = s_val + pidA * W, *tvB = s_val + pidB * W;
+    const int32_t *toA = s_off + pidA * W, *toB = s_off + pidB * W;
+    double sA = 0.0, sB = 0.0;
+    for (int j = 0; j < lmax; j += UN) {
+      double cA[UN], cB[UN], gA[UN], gB[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        cA[u] = tvA[j + u]; cB[u] = tvB[j + u];
+        gA[u] = ld_off(xg, baseA + (uint32_t)toA[j + u]);
+        gB[u] = ld_off(xg, baseB + (uint32_t)toB[j + u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {                       // entries past the end of a row: (offset 0, value 0.0), high word cleared -- see sellp_kernel
+        double ga = gA[u], gb = gB[u];
+        if (!(j + u < lenA)) ga = __hiloint2double(0, __double2loint(ga));
+        if (!(j + u < lenB)) gb = __hiloint2double(0, __double2loint(gb));
+        sA = sA + cA[u] * ga;
+        sB = sB + cB[u] * gb;
+      }
+    }
+    const gmg_pd2 t = gmg_pd2{omega != 0.0 ? omega * sA : sA, omega != 0.0 ? omega * sB : sB};
+    const gmg_pd2 xn = gmg_pd2{e0.x + t.x, e0.y + t.y};
+    if (inner) {
+      *reinterpret_cast<d2u *>(a.y + row) = t;
+      *reinterpret_cast<d2u *>(a.x2 + row) = xn;
+    } else {
+      if (vA) { a.y[row] = t.x; a.x2[row] = xn.x; }
+      if (vB) { a.y[row + 1] = t.y; a.x2[row + 1] = xn.y; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // SELL-P, shared-offset form ("stencil mode"): when the offsets are relative to the row index, every
 // row pattern is a subset of the union U of all offsets, so ALL rows can share one offset list and
 // differ only in their coefficients (absent entries become explicit zeros, which add an exact +0.0;
@@ -1896,10 +1986,15 @@ __global__ __launch_bounds__(kBlock) void sells_r2sweep_kernel(SellSArgs a)
 // sells_kernel<EPI, false, 3>: bit-identical (FM = false).
 //   a.x gathered ; a.y result (SUB: also read) ; a.b (RESID) ; a.nslices = ceil(nrows / 126)
 // ---------------------------------------------------------------------------
-template <int EPI, bool MK, bool FM, int NR>
+__device__ __forceinline__ double block_sum(double s, double *sh /*[4]*/);
+// DOT (EPI_SET): also the first stage of dot(x, y) = dot(p, w) of CGSolvers.jl:105 -- every workgroup stores the sum over its rows in
+// a.s_out[blockIdx.x] (the consumer sums the partials: sum_partials_all); p and w are not read again by a dot kernel.
+template <int EPI, bool MK, bool FM, int NR, bool DOT = false>
 __global__ __launch_bounds__(kBlock) void sells_r2mv_kernel(SellSArgs a)
 {
   static_assert(EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID, "mat-vec epilogues only");
+  static_assert(!DOT || EPI == EPI_SET, "the fused dot is dot(x, A x)");
+  double dsum = 0.0;
   constexpr int K = 3, ROWS2 = 126, RB = 3;
   extern __shared__ double sp_smem[];
   const int nu = K * NR;
@@ -1933,12 +2028,14 @@ __global__ __launch_bounds__(kBlock) void sells_r2mv_kernel(SellSArgs a)
       const uint32_t pp = *reinterpret_cast<const uint32_t *>(a.rowpid + row);
       pidA = (int)(pp & 0xffffu); pidB = (int)(pp >> 16);
       if (EPI != EPI_SET) e0 = ld2_unaligned(eg + row);
+      else if (DOT) e0 = ld2_unaligned(xg + row);
 #pragma unroll
       for (int q = 0; q < RB; ++q) A[q] = ld2_unaligned(xg + row + roff[q]);
     } else {
       const int ra = min(row, lastrow), rb = min(row + 1, lastrow);
       pidA = (int)a.rowpid[ra]; pidB = (int)a.rowpid[rb];
       if (EPI != EPI_SET) e0 = gmg_d2{eg[ra], eg[rb]};
+      else if (DOT) e0 = gmg_d2{xg[ra], xg[rb]};
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         const int c = row + roff[q];
@@ -2007,14 +2104,19 @@ __global__ __launch_bounds__(kBlock) void sells_r2mv_kernel(SellSArgs a)
     }
     const gmg_d2 yn = EPI == EPI_SET ? gmg_d2{sA, sB} : gmg_d2{e0.x - sA, e0.y - sB};
     if (lane < 63) {
-      if (inner) st2_unaligned(a.y + row, yn);
+      if (inner) { st2_unaligned(a.y + row, yn); if (DOT) dsum += e0.x * yn.x + e0.y * yn.y; }
       else {
-        if (row <= lastrow) a.y[row] = yn.x;
-        if (row + 1 <= lastrow) a.y[row + 1] = yn.y;
+        if (row <= lastrow) { a.y[row] = yn.x; if (DOT) dsum += e0.x * yn.x; }
+        if (row + 1 <= lastrow) { a.y[row + 1] = yn.y; if (DOT) dsum += e0.y * yn.y; }
       }
     }
     sb += wpb;
     if (sb < s_end) load_slice(sb);
+  }
+  if (DOT) {                                                 // blockDim.x == kBlock
+    __shared__ double sh[4];
+    const double t = block_sum(dsum, sh);
+    if (threadIdx.x == 0) a.s_out[blockIdx.x] = t;
   }
 }
 

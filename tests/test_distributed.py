@@ -246,6 +246,13 @@ def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_p
     v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep)
     _check(v)
     assert v["fgmres_iters"] <= v["iters"] + 1 and v["fgmres_vs_cg"] < 1e-5
+    if world == 2:
+        # the kernels the big partitioned levels of the bench take (two rows per lane: mat-vecs on the own x own part, prolongation +
+        # correction), forced onto these small levels: same bits
+        w = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env={"GMG_PAT_R2MV_MIN": "1"})
+        _check(w)
+        assert w["iters"] == v["iters"]
+        np.testing.assert_array_equal(w["x"], v["x"])
 
 
 @pytest.mark.gpu

@@ -388,8 +388,9 @@ def test_pair_matvec_and_fused_reductions_are_bitwise_the_separate_forms(S, po, 
     n = H["mats"][0].shape[0]
     b = po.dirichlet_lift_rhs(nc, 1)
     res = {}
-    for key in ((1, 1), (0, 1), (1, 0), (0, 0)):
-        opts = {"pat_r2mv": key[0], "pat_r2mv_min": 1, "red_fused": key[1]}
+    for key in ((1, 1), (0, 1), (1, 0), (0, 0), "dot"):
+        # "dot": the default -- dot(p, A p) also formed by the mat-vec kernel (another order of the sum: not bitwise, checked below)
+        opts = {"pat_r2mv_min": 1} if key == "dot" else {"pat_r2mv": key[0], "pat_r2mv_min": 1, "red_fused": key[1], "pat_r2mv_dot": 0}
         solver = S.CGSolver(make_gmg(S, H, pre_smoothers=jac(S, nlev, 4), options=opts), maxiter=40, atol=1e-14, rtol=1e-8)
         ns = setup(S, solver, H["mats"][0])
         out = []
@@ -410,6 +411,11 @@ def test_pair_matvec_and_fused_reductions_are_bitwise_the_separate_forms(S, po, 
         for a, c in zip(res[(1, 1)], res[key]):
             np.testing.assert_array_equal(a, c)
     np.testing.assert_array_equal(res[(1, 1)][0], orc.spmv(H["mats"][0], np.random.default_rng(7).uniform(-1, 1, n)))   # rows summed in the oracle's order
+    for a, c in zip(res[(1, 1)][:3], res["dot"][:3]):
+        np.testing.assert_array_equal(a, c)
+    assert len(res["dot"][-1]) == len(res[(1, 1)][-1])
+    np.testing.assert_allclose(res["dot"][-1], res[(1, 1)][-1], rtol=1e-9)
+    assert rel_err(res["dot"][-2], res[(1, 1)][-2]) <= 1e-12
     fin = res[(1, 1)][1]
     assert not fin.all() and fin.sum() > 0.9 * n
     go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, 4, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
@@ -417,3 +423,28 @@ def test_pair_matvec_and_fused_reductions_are_bitwise_the_separate_forms(S, po, 
     assert len(res[(1, 1)][-1]) == nit + 1
     np.testing.assert_allclose(res[(1, 1)][-1], hist, rtol=1e-8)
     assert rel_err(res[(1, 1)][-2], xo) <= 1e-10
+
+
+@pytest.mark.parametrize("nc,nlev", [((48, 48, 48), 3), ((132, 68), 3), ((34, 46, 30), 2)])
+def test_pair_prolongation_is_bitwise_the_single_row_kernel(S, po, orc, nc, nlev):
+    """sellp_pair_addto_kernel (dxh = P dxH ; xh += dxh with two rows per lane, levels of >= pat_r2mv_min rows) against sellp_kernel
+    (option pat_pair_p = 0): V-cycles from random residuals (row counts that are not multiples of 128: the ragged last slice takes
+    the element-wise path) agree to the last bit, and with the oracle's V-cycle to 1e-12."""
+    H = po.build_hierarchy(nc, nlev, 1)
+    n = H["mats"][0].shape[0]
+    res = {}
+    for pp in (1, 0):
+        gmg = make_gmg(S, H, pre_smoothers=jac(S, nlev, 3), options={"pat_pair_p": pp, "pat_r2mv_min": 1})
+        ns = setup(S, gmg, H["mats"][0])
+        out = []
+        for seed in (1, 2):
+            z = np.zeros(n)
+            S.solve_(z, ns, np.random.default_rng(seed).uniform(-1, 1, n))
+            out.append(z)
+        res[pp] = out
+        ns.close()
+    for a, c in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, c)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, 3, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
+    zo = go.solve(np.random.default_rng(1).uniform(-1, 1, n))[0]
+    assert rel_err(res[1][0], zo) <= 1e-12
