@@ -210,7 +210,13 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  *                    sell_un (6) sell_block (0 = auto) sell_defer (1) nt (1) nt_rowwise (1) big_rows (4000000) xcd_remap (1)
  *                    xcd_remap_big (-1: chunks two gather reaches deep per XCD; 0 launch order; 1 contiguous eighths; n chunk of n workgroups)
  *                    lanes_log2 (-1 = auto)
+ *                    pat_r2mv (1: y = A x, y -= A x, y = b - A x of row-pattern levels with two rows per lane) pat_r2mv_min (100000:
+ *                    smallest level, in rows, that takes it and the pair prolongation) pat_r2mv_dot (1: dot(p, A p) of CG formed by
+ *                    the mat-vec kernel) pat_pair_p (1: prolongation + correction with two rows per lane)
+ *   reductions       red_fused (1: inside CG the second stage of every dot is done by the kernel that consumes the scalar and the
+ *                    norm is reduced + posted to the host by one launch; 0: one reduce launch per dot.  Same bits either way)
  *   one-launch pass  persist (1) persist_fenced (0) persist_max_slices (0 = one workgroup per CU) persist_shared (0)
+ *                    persist_wpb (1: smallest workgroup, in waves)
  *   coarsest level   coarse_host_max (1500) coarse_host_fallback_max (6000) coarse_auto_cg_min (20000: a dense-inverse request on a
  *                    coarsest level of at least this many dofs is served by the device CG-Jacobi solver instead) gj_mfma (1) gj_wide_min (4096)
  *   patch smoother   patch_dedup (1) patch_source_dedup (1) patch_operator (1)
@@ -219,7 +225,8 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  *                    hipStreamSynchronize)
  *   host vectors     x0_zero* (0: the solve entry points read x as the initial guess, CGSolvers.jl:79; 1: x is taken as zero on
  *                    entry and never uploaded) host_chunk_bytes* (4194304: staging chunk of unregistered host vectors)
- *   diagnostics      prof_stride (8) setup_timing* (0) dbg_nogather (0) persist_force_timeout* (0: test hook, the next n solves
+ *   diagnostics      prof_stride (8) setup_timing* (0) dbg_nogather (0) host_timeline* (0: 1 = host-side duration of every step of
+ *                    the cycles on stderr when the handle is destroyed) persist_force_timeout* (0: test hook, the next n solves
  *                    behave as if a one-launch pass had timed out) */
 GMG_API int gmg_set_option(gmg_handle_t h, const char *key, double value);
 /* Effective value of an option (NaN: the built-in default applies); *source (may be NULL) = 0 default, 1 gmg_set_option, 2 environment. */
