@@ -282,9 +282,16 @@ def test_fused_multiply_add_taps_stay_inside_the_parity_gates(S, po, orc, nc, nl
     H = po.build_hierarchy(nc, nlev, 1)
     n = H["mats"][0].shape[0]
     b = po.dirichlet_lift_rhs(nc, 1)
-    solver = S.CGSolver(make_gmg(S, H, options={"pat_fma": 1, "persist": 0, "pat_tile": tile}), maxiter=20, atol=1e-14, rtol=1e-6)
+    # pat_r2mv_min = 1: the pair mat-vec kernels (FM variants of sells_r2mv_kernel, with the fused dot) on these small levels too
+    solver = S.CGSolver(make_gmg(S, H, options={"pat_fma": 1, "persist": 0, "pat_tile": tile, "pat_r2mv_min": 1}), maxiter=20, atol=1e-14, rtol=1e-6)
     ns = setup(S, solver, H["mats"][0])
     assert "FM=1" in (ns.P_ns.sweep_signature(0) or "FM=1")
+    from gridapsolvers_jl_amd.abi import OP_A
+    v = np.random.default_rng(9).uniform(-1, 1, n)
+    y = np.zeros(n)
+    ns.P_ns.op_apply(0, OP_A, v, y)
+    yo = orc.spmv(H["mats"][0], v)
+    assert np.max(np.abs(y - yo)) <= 1e-13 * np.max(np.abs(yo)) and not np.array_equal(y, yo)
     go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
     x, r = np.random.default_rng(3).uniform(-1, 1, n), np.random.default_rng(50).uniform(-1, 1, n)
     xo_, ro_ = go.smooth(0, x.copy(), r.copy())
