@@ -4307,13 +4307,14 @@ void gmg_solver::setup()
     if (big > 64) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
   }
   if (comm.nranks > 1) {
-    // operators handed over BEFORE the communicator was initialised may sit in the (single-GPU) row-pattern-only form: the
-    // distributed setup splits own / ghost columns on the CSR, so give them their rows back
+    // Row-pattern-only operators (streamed with gmg_set_operator_rows, or handed over whole before the communicator was initialised)
+    // stay as they are on levels that are laid out like a single-GPU level: the overlapping layout (one square local operator over the
+    // extended box) and the replicated levels.  An own | ghost level splits own / ghost columns on the CSR: its matrix gets its rows
+    // back.  Transfers are applied whole (the vectors carry their ghost space), so their pattern form is kept everywhere.
     for (int l = 0; l < nlev; ++l) {
       Level &L = lev[l];
-      if (L.sA && L.sA->complete()) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
-      if (L.sP && L.sP->complete()) { L.hP = expand_stream(*L.sP); L.sP.reset(); }
-      if (L.sR && L.sR->complete()) { L.hR = expand_stream(*L.sR); L.sR.reset(); }
+      const bool own_ghost = L.halo.present && !L.halo.ovl;
+      if (own_ghost && L.sA && L.sA->complete()) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
     }
   }
   for (int l = 0; l < nlev; ++l) {
@@ -4377,7 +4378,7 @@ void gmg_solver::setup()
       L.split = false; L.nbnd = 0;
       L.A = L.sA ? finish_stream(*L.sA, "level matrix") : upload_csr(L.hA);
     } else if (L.halo.present && comm.nranks > 1) {
-      REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "streamed operators are single-GPU in this round");
+      REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "own | ghost levels hold their matrix as CSR (streamed level matrices: overlapping layout or replicated levels)");
       // own x own / own x ghost split: A keeps the owned columns, the ghost columns of the rows
       // that have any go to a small CSR applied after the halo has arrived (finish_ghost)
       HostCSR loc;
@@ -4767,13 +4768,16 @@ int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, 
     REQUIRE(index_bytes == 4 || index_bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
     REQUIRE(index_base == 0 || index_base == 1, GMG_ERR_INVALID, "index_base must be 0 or 1");
     REQUIRE(nrows_total >= 1 && ncols >= 1 && nrows_total < (int64_t)INT32_MAX && ncols < (int64_t)INT32_MAX, GMG_ERR_INVALID, "bad operator shape");
-    REQUIRE(h->comm.nranks == 1, GMG_ERR_UNSUPPORTED, "streamed operators are single-GPU in this round");
     Level &L = h->lev[lev];
     std::shared_ptr<PatStream> &S = op == GMG_OP_A ? L.sA : op == GMG_OP_P ? L.sP : L.sR;
     HostCSR &H = op == GMG_OP_A ? L.hA : op == GMG_OP_P ? L.hP : L.hR;
     bool &has = op == GMG_OP_A ? L.hasA : op == GMG_OP_P ? L.hasP : L.hasR;
     if (row0 == 0) {                                        // first block: (re)start the stream
-      if (op == GMG_OP_A) REQUIRE(nrows_total == ncols, GMG_ERR_INVALID, "level matrix must be square");
+      if (op == GMG_OP_A)
+        REQUIRE(nrows_total == ncols, GMG_ERR_INVALID,
+                h->comm.nranks > 1 ? "a streamed level matrix must be square: own | ghost levels take their rows whole (gmg_set_matrix), levels in the "
+                                     "overlapping layout (gmg_set_partition_overlap) and replicated levels can be streamed"
+                                   : "level matrix must be square");
       S = std::make_shared<PatStream>();
       S->mode = (op == GMG_OP_A) ? 0 : 1;
       S->nrows = nrows_total; S->ncols = ncols;

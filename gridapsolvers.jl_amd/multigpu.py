@@ -76,7 +76,8 @@ class DistributedGMG:
     def __init__(self, cells_per_rank, nlevels, rank, world, device_id=0, transport="rccl", group=None,
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
                  gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None,
-                 smoother="jacobi", depth=None, patch_tables=None, pcorr_tables=None, cells_global=None, options=None):
+                 smoother="jacobi", depth=None, patch_tables=None, pcorr_tables=None, cells_global=None, options=None,
+                 stream_rows=0):
         """smoother = "jacobi": Richardson(Jacobi, niter, omega); "patch": Richardson(PatchSolver, niter, omega) with the
         vertex-star patches OWNED by this rank (partition.local_vertex_star_patches) and caller-assembled patch matrices --
         a rank's local matrix has the owned rows only, so the blocks of patches reaching into ghost dofs come from the
@@ -89,7 +90,10 @@ class DistributedGMG:
         and pcorr_tables[l] = (patch_ptr, local dofs, G_local or None) a patch-corrected prolongation
         (PatchProlongationOperator, PatchTransferOperators.jl:153-172) with its rhs form.
         depth: ghost layers of the OVERLAPPING layout on the partitioned levels >= 1 (int or per-level list; None / 0 = every level in
-        the own | ghost layout): one halo exchange per `depth` sweeps instead of one per sweep (gmg_set_partition_overlap)."""
+        the own | ghost layout): one halo exchange per `depth` sweeps instead of one per sweep (gmg_set_partition_overlap).
+        stream_rows > 0: the operators of the levels that are laid out like a single-GPU level -- overlapping layout, replicated levels
+        -- are handed over in blocks of that many rows (gmg_set_operator_rows): the library keeps their row-pattern form only, never
+        a CSR copy (what a per-rank assembler that produces its rows plane by plane would do)."""
         import torch.distributed as dist
         lib = abi.load()
         self._lib, self.rank, self.world = lib, rank, world
@@ -145,10 +149,22 @@ class DistributedGMG:
                     abi.check(h, lib.gmg_set_partition(h, l, L.n_own, L.n_ghost, nbr.size, C.c_void_p(nbr.ctypes.data),
                                                        C.c_void_p(sp.ctypes.data), C.c_void_p(si.ctypes.data),
                                                        C.c_void_p(rp.ctypes.data)))
-            self._set(lib.gmg_set_matrix, l, L.A)
+            # single-GPU-like levels: overlapping layout or replicated (the coarsest level needs its matrix whole: dense inverse)
+            streamable = stream_rows > 0 and (L.replicated or getattr(L, "overlap", False) or world == 1) and l < nlevels - 1
+            self.streamed_levels = getattr(self, "streamed_levels", []) + ([l] if streamable else [])
+            if streamable:
+                self._stream(abi.OP_A, l, L.A, stream_rows)
+            else:
+                self._set(lib.gmg_set_matrix, l, L.A)
             if l < nlevels - 1:
-                self._set(lib.gmg_set_prolongation, l, L.P)
-                self._set(lib.gmg_set_restriction, l, L.R)
+                nxt = levels[l + 1]
+                t_stream = streamable and (nxt.replicated or getattr(nxt, "overlap", False) or world == 1)
+                if t_stream:
+                    self._stream(abi.OP_P, l, L.P, stream_rows)
+                    self._stream(abi.OP_R, l, L.R, stream_rows)
+                else:
+                    self._set(lib.gmg_set_prolongation, l, L.P)
+                    self._set(lib.gmg_set_restriction, l, L.R)
                 if smoother == "patch":
                     self._set_patch_smoother(l, L, niter, omega)
                 else:
@@ -218,6 +234,18 @@ class DistributedGMG:
         abi.check(h, lib.gmg_set_smoother_patch_matrices(h, l, abi.PRE_AND_POST, niter, omega, abi.PATCH_LU, pp.size - 1,
                                                          C.c_void_p(pp.ctypes.data), C.c_void_p(pl64.ctypes.data), None, 0, 8,
                                                          C.c_void_p(blocks.ctypes.data), 0, None))
+
+    def _stream(self, op, l, M, block):
+        """the rows of M in consecutive blocks (gmg_set_operator_rows); every block is dropped after the call"""
+        n = M.shape[0]
+        for r0 in range(0, n, block):
+            r1 = min(n, r0 + block)
+            k0, k1 = int(M.ptr[r0]), int(M.ptr[r1])
+            ptr = (M.ptr[r0:r1 + 1] - k0).astype(np.int64)
+            idx = np.ascontiguousarray(M.idx[k0:k1], dtype=np.int64)
+            val = np.ascontiguousarray(M.val[k0:k1])
+            abi.check(self.h, self._lib.gmg_set_operator_rows(self.h, l, op, M.shape[0], M.shape[1], r0, r1 - r0, C.c_void_p(ptr.ctypes.data),
+                                                              C.c_void_p(idx.ctypes.data), C.c_void_p(val.ctypes.data), 0, 8))
 
     def _set(self, fn, l, M):
         if M.nnz < 2 ** 31 - 1:            # int32 columns as they are, the (short) pointer array narrowed to match

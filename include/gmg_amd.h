@@ -105,7 +105,10 @@ GMG_API int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols
  * per row + the dictionary of distinct rows): host memory is O(block).  Operators with more than 4096 distinct rows
  * (variable coefficients, unstructured meshes) are rejected with GMG_ERR_UNSUPPORTED -- pass those whole.
  * A streamed P needs a streamed R (R = P^T is not formed from a stream); the coarsest matrix is passed whole unless the
- * coarse solver is iterative / a callback.  Single GPU. */
+ * coarse solver is iterative / a callback.  Several ranks: levels that are laid out like a single-GPU level -- the overlapping
+ * layout (gmg_set_partition_overlap: one square local operator over the extended box) and the replicated levels -- keep the stream
+ * form, transfers included; an own | ghost level (gmg_set_partition) splits own / ghost columns on the CSR and takes its matrix
+ * whole (gmg_set_matrix). */
 GMG_API int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, int64_t ncols, int64_t row0,
                                   int64_t nrows_block, const void *ptr, const void *idx, const double *val,
                                   int index_base, int index_bytes);

@@ -509,7 +509,9 @@ def main():
         torch.cuda.set_device(dev)
         g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=rep_from,
                                     order=order, smoother=smoother, niter=(p_niter if smoother == "patch" else 10),
-                                    omega=(p_omega if smoother == "patch" else 2.0 / 3.0), depth=depth)
+                                    omega=(p_omega if smoother == "patch" else 2.0 / 3.0), depth=depth,
+                                    stream_rows=int(os.environ.get("GMG_TEST_STREAM_ROWS", "0")))
+        verdict["streamed_levels"] = list(getattr(g, "streamed_levels", []))
         b = g.rhs_lin()
         x = np.zeros(g.n_own)
         # test hook: ONE rank behaves as if a one-launch smoothing pass had timed out in the first solve -- every rank must re-run it
