@@ -345,6 +345,12 @@ struct Level {
   HostCSR hA, hP, hR;
   bool hasA = false, hasP = false, hasR = false;
   std::shared_ptr<PatStream> sA, sP, sR;   // streamed operators (hA/hP/hR then carry the shape only)
+  // streamed matrix of an own | ghost level: the own x own part goes to the stream, the entries in ghost columns of the rows that
+  // have any are kept as the small CSR the boundary fix-up applies (gmg_set_operator_rows splits every block)
+  bool sA_split = false;
+  std::vector<int32_t> g_rows, g_col;
+  std::vector<int64_t> g_ptr;
+  std::vector<double> g_val;
   bool values_dirty = false;               // gmg_update_values since the last setup
   DevCSR A, P, R;
   double *dinv = nullptr;
@@ -4314,7 +4320,7 @@ void gmg_solver::setup()
     for (int l = 0; l < nlev; ++l) {
       Level &L = lev[l];
       const bool own_ghost = L.halo.present && !L.halo.ovl;
-      if (own_ghost && L.sA && L.sA->complete()) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
+      if (own_ghost && L.sA && L.sA->complete() && !L.sA_split) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
     }
   }
   for (int l = 0; l < nlev; ++l) {
@@ -4378,15 +4384,19 @@ void gmg_solver::setup()
       L.split = false; L.nbnd = 0;
       L.A = L.sA ? finish_stream(*L.sA, "level matrix") : upload_csr(L.hA);
     } else if (L.halo.present && comm.nranks > 1) {
-      REQUIRE(!L.sA, GMG_ERR_UNSUPPORTED, "own | ghost levels hold their matrix as CSR (streamed level matrices: overlapping layout or replicated levels)");
+      REQUIRE(!L.sA || L.sA_split, GMG_ERR_UNSUPPORTED, "own | ghost levels hold their matrix as CSR or as a stream split by gmg_set_operator_rows");
       // own x own / own x ghost split: A keeps the owned columns, the ghost columns of the rows
       // that have any go to a small CSR applied after the halo has arrived (finish_ghost)
       HostCSR loc;
       loc.nrows = L.hA.nrows; loc.ncols = L.hA.ncols;
-      loc.ptr.assign((size_t)L.n + 1, 0);
       std::vector<int32_t> brows, bcol;
       std::vector<int64_t> bptr(1, 0);
       std::vector<double> bval;
+      if (L.sA) {                                            // streamed: gmg_set_operator_rows has split every block already
+        REQUIRE(L.sA->complete(), GMG_ERR_STATE, "row stream incomplete");
+        brows = L.g_rows; bcol = L.g_col; bptr = L.g_ptr; bval = L.g_val;
+      } else {
+      loc.ptr.assign((size_t)L.n + 1, 0);
       for (int64_t i = 0; i < L.n; ++i) {
         bool any = false;
         for (int64_t k = L.hA.ptr[i]; k < L.hA.ptr[i + 1]; ++k) {
@@ -4395,6 +4405,7 @@ void gmg_solver::setup()
         }
         loc.ptr[i + 1] = (int64_t)loc.col.size();
         if (any) { brows.push_back((int32_t)i); bptr.push_back((int64_t)bcol.size()); }
+      }
       }
       L.split = true;
       L.nbnd = (int64_t)brows.size();
@@ -4421,8 +4432,13 @@ void gmg_solver::setup()
         if (timing) std::fprintf(stderr, "[gmg_setup] level %d halo: %lld boundary rows, %lld send slots, pack fused into the fix-up: %s\n", l,
                                  (long long)brows.size(), (long long)Hp.nsend(), Hp.d_pk_ptr ? "yes" : "no");
       }
+      if (L.sA) {
+        L.A = finish_stream(*L.sA, "level matrix (own x own part)");
+        L.A.nnz_model = L.sA->nnz + (int64_t)bcol.size();
+      } else {
       L.A = upload_csr(loc);
       L.A.nnz_model = L.hA.nnz();
+      }
     } else if (L.sA) L.A = finish_stream(*L.sA, "level matrix");
     else
     L.A = upload_csr(L.hA);                                 // :185 gmg_compute_matrices
@@ -4772,21 +4788,55 @@ int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, 
     std::shared_ptr<PatStream> &S = op == GMG_OP_A ? L.sA : op == GMG_OP_P ? L.sP : L.sR;
     HostCSR &H = op == GMG_OP_A ? L.hA : op == GMG_OP_P ? L.hP : L.hR;
     bool &has = op == GMG_OP_A ? L.hasA : op == GMG_OP_P ? L.hasP : L.hasR;
+    // own | ghost level (gmg_set_partition called before): rows are n_own x (n_own + n_ghost); the stream takes the own columns
+    const bool split = op == GMG_OP_A && h->comm.nranks > 1 && L.halo.present && !L.halo.ovl;
+    if (split)
+      REQUIRE(nrows_total == L.halo.n_own && ncols == L.halo.n_own + L.halo.n_ghost, GMG_ERR_INVALID,
+              "streamed matrix of an own | ghost level: n_own rows, n_own + n_ghost columns (declare the partition first)");
     if (row0 == 0) {                                        // first block: (re)start the stream
-      if (op == GMG_OP_A)
+      if (op == GMG_OP_A && !split)
         REQUIRE(nrows_total == ncols, GMG_ERR_INVALID,
                 h->comm.nranks > 1 ? "a streamed level matrix must be square: own | ghost levels take their rows whole (gmg_set_matrix), levels in the "
                                      "overlapping layout (gmg_set_partition_overlap) and replicated levels can be streamed"
                                    : "level matrix must be square");
       S = std::make_shared<PatStream>();
       S->mode = (op == GMG_OP_A) ? 0 : 1;
-      S->nrows = nrows_total; S->ncols = ncols;
+      S->nrows = nrows_total; S->ncols = split ? nrows_total : ncols;
       H = HostCSR();
       H.nrows = nrows_total; H.ncols = ncols;               // shape only: the rows are never kept
       has = false;
+      if (op == GMG_OP_A) {
+        L.sA_split = split;
+        L.g_rows.clear(); L.g_col.clear(); L.g_val.clear(); L.g_ptr.assign(1, 0);
+      }
       h->touch();
     }
-    REQUIRE(S && S->nrows == nrows_total && S->ncols == ncols, GMG_ERR_STATE, "row block does not continue the stream started with row0 = 0");
+    REQUIRE(S && S->nrows == nrows_total && S->ncols == (split ? nrows_total : ncols), GMG_ERR_STATE, "row block does not continue the stream started with row0 = 0");
+    if (split) {
+      REQUIRE(L.sA_split && ptr && (nrows_block == 0 || (idx && val)), GMG_ERR_INVALID, "null row block");
+      REQUIRE(row0 + nrows_block <= nrows_total && nrows_block >= 0, GMG_ERR_INVALID, "row block exceeds the operator");
+      const int64_t n_own = nrows_total;
+      const int64_t k00 = read_index(ptr, 0, index_bytes);
+      const int64_t kend = read_index(ptr, nrows_block, index_bytes);
+      REQUIRE(k00 == index_base && kend >= k00, GMG_ERR_INVALID, "row pointers of a block start at index_base");
+      std::vector<int64_t> fptr((size_t)nrows_block + 1, 0), fidx;
+      std::vector<double> fval;
+      fidx.reserve((size_t)(kend - k00)); fval.reserve((size_t)(kend - k00));
+      for (int64_t i = 0; i < nrows_block; ++i) {
+        const int64_t k0 = read_index(ptr, i, index_bytes) - index_base, k1 = read_index(ptr, i + 1, index_bytes) - index_base;
+        REQUIRE(k1 >= k0, GMG_ERR_INVALID, "row pointers must ascend");
+        bool any = false;
+        for (int64_t k = k0; k < k1; ++k) {
+          const int64_t c = read_index(idx, k, index_bytes) - index_base;
+          REQUIRE(c >= 0 && c < ncols, GMG_ERR_INVALID, "column index out of range");
+          if (c < n_own) { fidx.push_back(c); fval.push_back(val[k]); }
+          else { L.g_col.push_back((int32_t)c); L.g_val.push_back(val[k]); any = true; }
+        }
+        fptr[(size_t)i + 1] = (int64_t)fidx.size();
+        if (any) { L.g_rows.push_back((int32_t)(row0 + i)); L.g_ptr.push_back((int64_t)L.g_col.size()); }
+      }
+      h->stream_append(*S, row0, nrows_block, fptr.data(), fidx.data(), fval.data(), 0, 8);
+    } else
     h->stream_append(*S, row0, nrows_block, ptr, idx, val, index_base, index_bytes);
     if (S->complete()) has = true;
   });

@@ -152,7 +152,11 @@ class DistributedGMG:
             # single-GPU-like levels: overlapping layout or replicated (the coarsest level needs its matrix whole: dense inverse)
             streamable = stream_rows > 0 and (L.replicated or getattr(L, "overlap", False) or world == 1) and l < nlevels - 1
             self.streamed_levels = getattr(self, "streamed_levels", []) + ([l] if streamable else [])
-            if streamable:
+            # an own | ghost level: the library splits every block into the own x own part (stream) and the ghost columns (small CSR)
+            split_stream = stream_rows > 0 and world > 1 and not L.replicated and not getattr(L, "overlap", False) and l < nlevels - 1
+            if split_stream:
+                self.streamed_levels.append(l)
+            if streamable or split_stream:
                 self._stream(abi.OP_A, l, L.A, stream_rows)
             else:
                 self._set(lib.gmg_set_matrix, l, L.A)

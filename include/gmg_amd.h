@@ -107,8 +107,9 @@ GMG_API int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols
  * A streamed P needs a streamed R (R = P^T is not formed from a stream); the coarsest matrix is passed whole unless the
  * coarse solver is iterative / a callback.  Several ranks: levels that are laid out like a single-GPU level -- the overlapping
  * layout (gmg_set_partition_overlap: one square local operator over the extended box) and the replicated levels -- keep the stream
- * form, transfers included; an own | ghost level (gmg_set_partition) splits own / ghost columns on the CSR and takes its matrix
- * whole (gmg_set_matrix). */
+ * form, transfers included; the matrix of an own | ghost level (gmg_set_partition, called BEFORE the first block) is streamed with
+ * its local shape n_own x (n_own + n_ghost): every block is split into the own x own part, which goes to the stream, and the
+ * entries in ghost columns, which become the small CSR the boundary fix-up applies once the halo has arrived. */
 GMG_API int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, int64_t ncols, int64_t row0,
                                   int64_t nrows_block, const void *ptr, const void *idx, const double *val,
                                   int index_base, int index_bytes);
