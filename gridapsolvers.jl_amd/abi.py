@@ -66,6 +66,8 @@ SYMBOLS = {
     "gmg_get_persist_retries": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)],
     "gmg_setup": [C.c_void_p],
     "gmg_set_verbose": [C.c_void_p, C.c_int],
+    "gmg_set_stream": [C.c_void_p, C.c_void_p],
+    "gmg_get_stream": [C.c_void_p, C.POINTER(C.c_void_p)],
     "gmg_get_log": [C.c_void_p, C.POINTER(Result), C.c_void_p, C.c_int],
     "gmg_apply": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Result), C.c_void_p, C.c_int],
     "gmg_cg_solve": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,

@@ -5219,6 +5219,26 @@ int gmg_get_persist_retries(gmg_handle_t h, int64_t *retries, int *persist_activ
   });
 }
 
+// The stream the handle issues its work on.  stream = NULL: back to the handle's own (created by gmg_create).
+int gmg_set_stream(gmg_handle_t h, void *stream)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    REQUIRE(!h->attached_to, GMG_ERR_STATE, "this handle is a diagonal block of a block preconditioner, which issues its work on the block handle's stream");
+    HIP_CHECK(hipSetDevice(h->device));
+    HIP_CHECK(hipStreamSynchronize(h->stream));             // nothing of ours is left on the stream we leave
+    h->stream = stream ? static_cast<hipStream_t>(stream) : h->own_stream;
+  });
+}
+
+int gmg_get_stream(gmg_handle_t h, void **stream)
+{
+  return guarded(h, [&] {
+    REQUIRE(h && stream, GMG_ERR_INVALID, "null argument");
+    *stream = static_cast<void *>(h->stream);
+  });
+}
+
 int gmg_set_verbose(gmg_handle_t h, int verbose)
 {
   return guarded(h, [&] {

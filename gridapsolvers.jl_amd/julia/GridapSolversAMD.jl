@@ -145,6 +145,19 @@ function get_option(ns::HipGMGNumericalSetup, key)
   return (isnan(v[]) ? nothing : v[], (:default, :handle, :environment)[src[]+1])
 end
 
+# gmg_set_stream: issue the handle's work on the caller's HIP stream (e.g. `AMDGPU.stream().stream` as a Ptr{Cvoid}): device vectors
+# (HipDeviceVector) produced / consumed by the caller's kernels on that stream need no synchronisation around solve! / ldiv!.
+# C_NULL returns to the handle's own stream.
+function set_stream!(ns::HipGMGNumericalSetup, stream::Ptr{Cvoid})
+  check(ns.handle, ccall((:gmg_set_stream, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid}), ns.handle, stream))
+  return ns
+end
+function get_stream(ns::HipGMGNumericalSetup)
+  s = Ref{Ptr{Cvoid}}(C_NULL)
+  check(ns.handle, ccall((:gmg_get_stream, libgmgamd), Cint, (Ptr{Cvoid},Ref{Ptr{Cvoid}}), ns.handle, s))
+  return s[]
+end
+
 # Page-lock the vectors of a solve once (gmg_host_register); at most 8 are held, the oldest is released first.  A Julia Array never
 # moves, and the setup holds a reference, so the registered pages stay valid until gmg_host_unregister / finalize.
 function pin!(ns::HipGMGNumericalSetup, vs::Vector{Float64}...)

@@ -403,6 +403,17 @@ class GMGNumericalSetup:
         abi.check(self.h, self._lib.gmg_get_option(self.h, str(key).encode(), C.byref(v), C.byref(src)))
         return (None if v.value != v.value else v.value), ("default", "handle", "environment")[src.value]
 
+    def set_stream(self, stream=None):
+        """gmg_set_stream: issue the handle's work on the caller's HIP stream (an integer hipStream_t, a torch.cuda.Stream, or None for
+        the handle's own) -- ordered with the caller's kernels on that stream, no device synchronisation in between."""
+        ptr = getattr(stream, "cuda_stream", stream)
+        abi.check(self.h, self._lib.gmg_set_stream(self.h, C.c_void_p(int(ptr) if ptr else None)))
+
+    def get_stream(self):
+        out = C.c_void_p()
+        abi.check(self.h, self._lib.gmg_get_stream(self.h, C.byref(out)))
+        return out.value or 0
+
     def setup(self):
         """gmg_setup again (after set_option changed a layout option)."""
         abi.check(self.h, self._lib.gmg_setup(self.h))

@@ -252,6 +252,14 @@ GMG_API int gmg_get_persist_retries(gmg_handle_t h, int64_t *retries, int *persi
  * ConvergenceLog complete on every path: as a preconditioner with maxiter = 1 inside gmg_cg_solve / gmg_fgmres_solve the
  * post-cycle norm(rh) of GMGLinearSolvers.jl:639 only feeds that log (update! returns true at maxiter regardless), so
  * with verbose = 0 (default) it is not evaluated and residuals[2] of the GMG log reads NaN. */
+/* The HIP stream (hipStream_t, passed as void*) the handle issues ALL its work on -- kernels, copies, the RCCL collectives.  By
+ * default every handle owns a non-blocking stream (gmg_create).  A caller that produces b and consumes x with its own kernels
+ * (a device-resident Krylov loop around gmg_apply; PyTorch / AMDGPU.jl arrays) passes ITS stream: the library's work is then
+ * ordered with the caller's without any device synchronisation on either side.  stream = NULL returns to the handle's own
+ * stream.  The call waits for the work already issued on the stream it leaves.  No reference counterpart (the reference runs on
+ * the host); `gmg_get_stream` returns the current one (e.g. to record an event on it). */
+GMG_API int gmg_set_stream(gmg_handle_t h, void *stream);
+GMG_API int gmg_get_stream(gmg_handle_t h, void **stream);
 GMG_API int gmg_set_verbose(gmg_handle_t h, int verbose);
 /* ns.solver.log of the GMG after the last solve!/ldiv! (also when it ran as a preconditioner inside a Krylov call). */
 GMG_API int gmg_get_log(gmg_handle_t h, gmg_result *res, double *hist, int hist_cap);

@@ -455,3 +455,49 @@ def test_pair_prolongation_is_bitwise_the_single_row_kernel(S, po, orc, nc, nlev
     go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, 3, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
     zo = go.solve(np.random.default_rng(1).uniform(-1, 1, n))[0]
     assert rel_err(res[1][0], zo) <= 1e-12
+
+
+def test_work_issued_on_the_callers_stream_needs_no_synchronisation(S, po, orc):
+    """gmg_set_stream: b is produced and x consumed by the caller's kernels on ITS stream, the V-cycle (gmg_apply on device vectors) is
+    issued on the same stream, and nothing synchronises in between -- a long-running kernel queued in front of b's producer makes a
+    missing ordering visible.  Same bits as the run on the handle's own stream with explicit synchronisation; back on the own stream
+    (None) the handle keeps working."""
+    import torch
+    nc, nlev = (40, 40, 40), 3
+    H = po.build_hierarchy(nc, nlev, 1)
+    n = H["mats"][0].shape[0]
+    gmg = make_gmg(S, H, pre_smoothers=jac(S, nlev, 4))
+    ns = setup(S, gmg, H["mats"][0])
+    base = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, n)).cuda()
+    torch.cuda.synchronize()
+    # reference: own stream, synchronised by hand
+    b0 = (base * 3.0 + 1.0)
+    x0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    S.solve_(x0, ns, b0)
+    torch.cuda.synchronize()
+    ref = (x0 * 2.0).cpu().numpy()
+    own = ns.get_stream()
+    st = torch.cuda.Stream()
+    ns.set_stream(st)
+    assert ns.get_stream() == st.cuda_stream != own
+    big = torch.empty(1 << 28, dtype=torch.float64, device="cuda")   # 2 GiB: the fill takes a few hundred microseconds
+    with torch.cuda.stream(st):
+        big.fill_(1.0)                                        # keeps the stream busy while the host runs ahead
+        b1 = (base * 3.0 + 1.0)
+        x1 = torch.zeros(n, dtype=torch.float64, device="cuda")
+        S.solve_(x1, ns, b1)                                  # no synchronisation before ...
+        out = x1 * 2.0                                        # ... or after
+    st.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    ns.set_stream(None)
+    assert ns.get_stream() == own
+    x2 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    S.solve_(x2, ns, b0)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal((x2 * 2.0).cpu().numpy(), ref)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, 4, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
+    zo = go.solve(b0.cpu().numpy())[0]
+    assert rel_err(x2.cpu().numpy(), zo) <= 1e-12
+    ns.close()
