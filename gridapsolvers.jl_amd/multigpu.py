@@ -296,6 +296,11 @@ class DistributedGMG:
         log._fill(res, hist)
         return log
 
+    def set_stream(self, stream=None):
+        """gmg_set_stream: the handle's work on the caller's HIP stream (torch.cuda.Stream, integer hipStream_t, None = its own)"""
+        ptr = getattr(stream, "cuda_stream", stream)
+        abi.check(self.h, self._lib.gmg_set_stream(self.h, C.c_void_p(int(ptr) if ptr else None)))
+
     def fgmres_solve(self, b, x, m=5, maxiter=20, atol=1e-14, rtol=1e-6, restart=False, m_add=1):
         log = ConvergenceLog("FGMRES", maxiter, atol, rtol)
         pb, ms, _kb = _vec(b, self.n_own)
