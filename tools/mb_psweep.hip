@@ -209,7 +209,10 @@ int main(int argc, char **argv)
   const int64_t N = (int64_t)m * m * m;
   const int nruns = 9, nu = 27, np = 28;
   std::vector<int32_t> runs;
-  for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) runs.push_back(dz * m * m + dy * m - 1);
+  // argv[3] = 1: timing experiment only (wrong results) -- the three runs of a plane all read the SAME line, so two of three gathers hit
+  // in L1: what would the sweep gain if the lines of a plane were fetched once from L2 instead of three times?
+  const int same_line = argc > 3 ? atoi(argv[3]) : 0;
+  for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) runs.push_back(dz * m * m + (same_line ? 0 : dy) * m - 1);
   std::vector<PatEntry> tab((size_t)np * nu);
   std::memset(tab.data(), 0, tab.size() * sizeof(PatEntry));
   std::vector<double> pdinv(np, 3.0 / 8.0);
