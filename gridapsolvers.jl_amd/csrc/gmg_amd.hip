@@ -597,7 +597,8 @@ struct gmg_solver {
   uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
-  int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU)
+  int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU, eight with pat_r2_occ)
+  int pat_r2_occ = 1;   // GMG_PAT_R2_OCC: the 64-register form of the pair sweep (rolled run loop, eight waves per SIMD)
   int pat_r2mv_dot = 1; // GMG_PAT_R2MV_DOT: dot(p, A p) of CG formed by the mat-vec kernel (first stage; order of the sum differs from dot_partial_kernel's)
   int pat_pair_p = 1;   // GMG_PAT_PAIR_P: prolongation + correction with two rows per lane (sellp_pair_addto_kernel), levels of >= pat_r2mv_min rows
   int pat_r2mv = 1;     // GMG_PAT_R2MV: mat-vecs (y = A x, y -= A x, y = b - A x) with two rows per lane (sells_r2mv_kernel)
@@ -1362,6 +1363,7 @@ struct gmg_solver {
       if (r2mv_ok(M) && !a2.s_out) {
         const int nsl2 = (int)((M.nrows + 125) / 126);
         a.nslices = nsl2;
+        // (the 64-register form of the sweeps, pat_r2_occ, does not pay here: 14.8 -> 15.3 us)
         const dim3 gr(std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : 4 * n_cus)));
         const size_t lds2 = (size_t)M.pat_np * nu * 16 + 16;
         const bool mk = pat_strict || !M.ptab8;
@@ -1957,13 +1959,16 @@ struct gmg_solver {
     if (pat_r2 && (M.pat_nruns == 9 || M.pat_nruns == 3)) {
       const int nsl2 = (int)((M.nrows + 125) / 126);
       a.nslices = nsl2;
-      // one round of four workgroups per CU: 1024 (128^3: 17.4 us per sweep; 768: 19.2, 1280: 20.8, 2048: 19.1 -- profiles/r04_tuning.md)
-      const int wgr = std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : 4 * n_cus));
+      // one round of workgroups: four per CU at 105 registers (128^3: 17.4 us per sweep; 768: 19.2, 1280: 20.8, 2048: 19.1 --
+      // profiles/r04_tuning.md), eight per CU for the 64-register form (pat_r2_occ: rolled run loop; 15.7 -> 14.4 us, section 13)
+      const bool occ = pat_r2_occ && wpb == 4 && M.pat_nruns == 9;
+      const int wgr = std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : (occ ? 8 : 4) * n_cus));
       const dim3 gr(wgr);
-      M.note_sweep("sells_r2sweep_kernel<XM=*,MK=%d,FM=%d,NR=%d> wgs=%d wpb=%d", mk ? 1 : 0, pat_fma ? 1 : 0, M.pat_nruns, wgr, wpb);
+      M.note_sweep("sells_r2sweep_kernel<XM=*,MK=%d,FM=%d,NR=%d,OCC=%d> wgs=%d wpb=%d", mk ? 1 : 0, pat_fma ? 1 : 0, M.pat_nruns, occ ? 1 : 0, wgr, wpb);
 #define GMG_R2_LAUNCH2(XMV, MKV, FMV)                                                                            \
       do {                                                                                                       \
-        if (M.pat_nruns == 9) hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, MKV, FMV, 9>), gr, b, lds2, stream, a);   \
+        if (occ) hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, MKV, FMV, 9, 1>), gr, b, lds2, stream, a);        \
+        else if (M.pat_nruns == 9) hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, MKV, FMV, 9>), gr, b, lds2, stream, a);   \
         else hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, MKV, FMV, 3>), gr, b, lds2, stream, a);               \
       } while (0)
 #define GMG_R2_LAUNCH(XMV)                                                                                       \
@@ -2978,6 +2983,7 @@ struct gmg_solver {
     red_fused = opt_int("GMG_RED_FUSED", 1);
     pat_r2 = opt_int("GMG_PAT_R2", 1);
     pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
+    pat_r2_occ = opt_int("GMG_PAT_R2_OCC", 1);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
     pat_pair_p = opt_int("GMG_PAT_PAIR_P", 1);
@@ -5119,7 +5125,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

@@ -1840,8 +1840,10 @@ __device__ __forceinline__ void st2_unaligned(double *p, gmg_d2 v)
 
 // NR = number of runs (9: 27-point operators; 3: 9-point) -- compile time, so that the run offsets live in scalar registers (read in the
 // loop from the argument array they are vector loads the gathers then wait for) and the run loop is fully unrolled.
-template <int XM, bool MK, bool FM, int NR>
-__global__ __launch_bounds__(kBlock) void sells_r2sweep_kernel(SellSArgs a)
+// OCC = 1: the run loop stays rolled (groups of three runs; unrolled, the compiler hoists the 54 coefficient reads of a slice and the
+// kernel takes 105 registers: four waves per SIMD) and the kernel is capped at 64 registers -- eight waves per SIMD.
+template <int XM, bool MK, bool FM, int NR, int OCC = 0>
+__global__ __launch_bounds__(kBlock, OCC ? 8 : 1) void sells_r2sweep_kernel(SellSArgs a)
 {
   constexpr int K = 3, ROWS2 = 126, RB = 3;
   extern __shared__ double sp_smem[];
@@ -1867,6 +1869,7 @@ __global__ __launch_bounds__(kBlock) void sells_r2sweep_kernel(SellSArgs a)
   int roff[NR];
 #pragma unroll
   for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  const int voff = a.run_off[min(lane, NR - 1)];             // OCC: lane q holds run_off[q], read with v_readlane in the rolled loop
   int pidA = 0, pidB = 0, row = 0;
   bool inner = false;
   gmg_d2 e0, e2, rp, A[RB];
@@ -1905,6 +1908,39 @@ __global__ __launch_bounds__(kBlock) void sells_r2sweep_kernel(SellSArgs a)
     const uint32_t *tmA = s_msk + pidA * nu, *tmB = s_msk + pidB * nu;
     const double *tvA = s_tab8 + pidA * nu, *tvB = s_tab8 + pidB * nu;
     double sA = 0.0, sB = 0.0;
+    if constexpr (OCC != 0) {
+#pragma unroll 1
+      for (int r0 = 0; r0 < NR; r0 += RB) {
+        gmg_d2 cur[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) cur[q] = gmg_d2{omega * (du * A[q].x), omega * (du * A[q].y)};
+        if (r0 + RB < NR) {
+          if (inner) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) A[q] = ld2_unaligned(rg + row + __builtin_amdgcn_readlane(voff, r0 + RB + q));
+          } else {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+              const int c = row + __builtin_amdgcn_readlane(voff, r0 + RB + q);
+              A[q] = gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
+            }
+          }
+        }
+        const double *ta = tvA + r0 * K, *tb = tvB + r0 * K;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          const double w0 = cur[q].x, w1 = cur[q].y;
+          const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+          const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            const double ca = ta[q * K + t], cb = tb[q * K + t];
+            sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
+            sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int r0 = 0; r0 < NR; r0 += RB) {
       gmg_d2 cur[RB];

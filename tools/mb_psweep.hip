@@ -317,6 +317,16 @@ int main(int argc, char **argv)
       hipLaunchKernelGGL((sells_r2sweep_kernel<2, MKV, FMV, 9>), dim3(g2), dim3(64 * wpbv), lds, 0, b); }); \
     printf("%-64s %7.2f us per sweep (wpb %d, wgs %d)\n", label, t * 1e3 / 2, wpbv, g2); }
     for (int wg : {512, 1024, 1355, 2048, 4096}) RUN2(true, false, 4, wg, "sells_r2sweep_kernel (two rows per lane)")
+#define RUN2O(MKV, FMV, wpbv, wg, label) { const int g2 = std::min((a2.nslices + wpbv - 1) / wpbv, wg); \
+    float t = time_it([&] { SellSArgs b = a2; b.x = r0; b.b = r0; b.y = r1; b.x2 = x; b.s_out = nullptr; b.xmode = 1; \
+      hipLaunchKernelGGL((sells_r2sweep_kernel<1, MKV, FMV, 9, 1>), dim3(g2), dim3(64 * wpbv), lds, 0, b); \
+      b.x = r1; b.b = r1; b.y = r0; b.s_out = r0; b.xmode = 2; \
+      hipLaunchKernelGGL((sells_r2sweep_kernel<2, MKV, FMV, 9, 1>), dim3(g2), dim3(64 * wpbv), lds, 0, b); }); \
+    printf("%-64s %7.2f us per sweep (wpb %d, wgs %d)\n", label, t * 1e3 / 2, wpbv, g2); }
+    for (int wg : {1024, 1536, 2048, 2560, 3072, 4096}) RUN2O(true, false, 4, wg, "sells_r2sweep_kernel, rolled run loop, <= 64 registers")
+    for (int wg : {512, 1024, 2048}) RUN2O(true, false, 8, wg, "sells_r2sweep_kernel, rolled run loop, <= 64 registers")
+    for (int wg : {2048, 4096}) RUN2O(true, false, 2, wg, "sells_r2sweep_kernel, rolled run loop, <= 64 registers")
+    for (int wg : {2048}) RUN2O(true, true, 4, wg, "sells_r2sweep_kernel, rolled, fused multiply-add")
     for (int wg : {1024, 2048}) RUN2(true, true, 4, wg, "sells_r2sweep_kernel, fused multiply-add taps")
     for (int wg : {1024, 2048}) RUN2(false, false, 4, wg, "sells_r2sweep_kernel, no mask array at all")
     for (int wg : {2048}) RUN2(false, true, 4, wg, "sells_r2sweep_kernel, no masks, fused multiply-add")
