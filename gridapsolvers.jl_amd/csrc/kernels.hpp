@@ -2385,8 +2385,10 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
   extern __shared__ double sp_smem[];
   const int nu = K * a.nruns;
   const int tot = a.np * nu;
-  PatEntry *s_tab = reinterpret_cast<PatEntry *>(sp_smem);
+  // [np*nu] coefficients, dense (absent entries hold 0.0) | strict form (MK): [np*nu] high-word masks behind them, read only by a
+  // slice whose sum came out non-finite (see sells_r2sweep_kernel: "all sums finite" proves that no mask was needed)
   double *s_tab8 = sp_smem;
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
   double *s_dinv = sp_smem + (MK ? 2 : 1) * (size_t)tot;
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -2409,7 +2411,7 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
     so[i] = a.s_a[rc];
     dv[i] = TD ? 0.0 : a.dinv[rc];
   }
-  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab[i] = a.tab[i]; }
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
   else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
   if (TD)
     for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
@@ -2446,7 +2448,7 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
       double A[RB];
 #pragma unroll
       for (int q = 0; q < RB; ++q) { const double *ga = sin + min(max(row[i] + a.run_off[q], 0), last); A[q] = (DBG & 2) ? *ga : ld_agent(ga); }
-      const PatEntry *te = s_tab + pid[i] * nu;
+      const uint32_t *tm = s_msk + pid[i] * nu;
       const double *tv = s_tab8 + pid[i] * nu;
       double s = 0.0;
       for (int r0 = 0; r0 < ((DBG & 8) ? RB : a.nruns); r0 += RB) {
@@ -2464,12 +2466,22 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
           for (int t = 0; t < K; ++t) {
             if (t > 0) c = wave_shl1(c);
             const int j = (r0 + q) * K + t;
-            if (MK) {
-              const PatEntry en = te[j];
-              const double g = __hiloint2double(__double2hiint(c) & (int)en.m, __double2loint(c));
-              s = s + en.v * g;
-            } else
-              s = s + tv[j] * c;
+            s = s + tv[j] * c;
+          }
+        }
+      }
+      if (MK && !(DBG & 8) && !__all(__builtin_isfinite(s))) {   // rare: a vector that already holds Inf / NaN -- redo the slice with the masks
+        s = 0.0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < a.nruns; ++r0) {
+          const double *ga = sin + min(max(row[i] + a.run_off[r0], 0), last);
+          double c = (DBG & 2) ? *ga : ld_agent(ga);
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) c = wave_shl1(c);
+            const int j = r0 * K + t;
+            const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
+            s = s + tv[j] * g;
           }
         }
       }
