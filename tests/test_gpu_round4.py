@@ -501,3 +501,33 @@ def test_work_issued_on_the_callers_stream_needs_no_synchronisation(S, po, orc):
     zo = go.solve(b0.cpu().numpy())[0]
     assert rel_err(x2.cpu().numpy(), zo) <= 1e-12
     ns.close()
+
+
+def test_streamed_matrix_of_an_own_ghost_level_needs_its_partition_first(S, po):
+    """gmg_set_operator_rows on an own | ghost level splits every block at n_own: without the partition the shape n_own x (n_own +
+    n_ghost) is rejected as a non-square level matrix, with it a block whose shape disagrees with the partition is rejected too."""
+    import ctypes as C
+    from gridapsolvers_jl_amd import abi
+    lib = abi.load()
+    h = C.c_void_p()
+    abi.check(None, lib.gmg_create(C.byref(h), 2, 0))
+    try:
+        cb_x = abi.HOST_EXCHANGE_FN(lambda *a: None)
+        cb_r = abi.HOST_ALLREDUCE_FN(lambda *a: None)
+        abi.check(h, lib.gmg_comm_init_host(h, 0, 2, C.cast(cb_x, C.c_void_p), C.cast(cb_r, C.c_void_p), None))
+        n_own, n_ghost = 6, 2
+        ptr = np.arange(0, 2 * n_own + 1, 2, dtype=np.int64)
+        idx = np.stack([np.arange(n_own), np.array([6, 7, 6, 7, 6, 7])], axis=1).reshape(-1).astype(np.int64)
+        val = np.ones(idx.size)
+        args = (C.c_void_p(ptr.ctypes.data), C.c_void_p(idx.ctypes.data), C.c_void_p(val.ctypes.data), 0, 8)
+        rc = lib.gmg_set_operator_rows(h, 0, abi.OP_A, n_own, n_own + n_ghost, 0, n_own, *args)
+        assert rc == abi.ERR_INVALID                          # no partition declared: not a square level matrix
+        nbr = np.array([1], dtype=np.int32)
+        sp, si, rp = np.array([0, 2], dtype=np.int64), np.array([0, 1], dtype=np.int64), np.array([0, 2], dtype=np.int64)
+        abi.check(h, lib.gmg_set_partition(h, 0, n_own, n_ghost, 1, C.c_void_p(nbr.ctypes.data), C.c_void_p(sp.ctypes.data),
+                                           C.c_void_p(si.ctypes.data), C.c_void_p(rp.ctypes.data)))
+        rc = lib.gmg_set_operator_rows(h, 0, abi.OP_A, n_own, n_own + n_ghost + 1, 0, n_own, *args)
+        assert rc == abi.ERR_INVALID                          # shape disagrees with the partition
+        abi.check(h, lib.gmg_set_operator_rows(h, 0, abi.OP_A, n_own, n_own + n_ghost, 0, n_own, *args))
+    finally:
+        lib.gmg_destroy(h)
