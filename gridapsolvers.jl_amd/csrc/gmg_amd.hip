@@ -584,7 +584,7 @@ struct gmg_solver {
   int pat_emit = 1;     // GMG_PAT_EMIT: restriction / r -= A dx kernels also write the next smoothing pass' s_0
   int64_t pat_coded_min_rows = 500000;   // GMG_PAT_CODED_MIN_ROWS
   int gj_mfma = 1;      // GMG_GJ_MFMA: trailing update of the device coarse inversion on the FP64 matrix cores
-  int pat_tile = 1;     // GMG_PAT_TILE: r-gather sweeps share their gathers through LDS (sells_tsweep_kernel): 0 never, 1 on levels of >= GMG_PAT_TILE_ROWS rows, 2 wherever it applies
+  int pat_tile = 0;     // GMG_PAT_TILE: r-gather sweeps share their gathers through LDS (sells_tsweep_kernel): 0 never (default since the 64-register pair sweep beats it), 1 on levels of >= GMG_PAT_TILE_ROWS rows, 2 wherever it applies
   int64_t pat_tile_rows = 6000000;
   int pat_wide = 1;     // GMG_PAT_WIDE: coded (wide-row) operators decode the patterns of each workgroup's chunk into a plain LDS value table
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
@@ -1961,8 +1961,12 @@ struct gmg_solver {
       a.nslices = nsl2;
       // one round of workgroups: four per CU at 105 registers (128^3: 17.4 us per sweep; 768: 19.2, 1280: 20.8, 2048: 19.1 --
       // profiles/r04_tuning.md), eight per CU for the 64-register form (pat_r2_occ: rolled run loop; 15.7 -> 14.4 us, section 13)
+      // Levels of >= pat_tile_rows rows (256^3 and up): the 64-register form with ONE slice per wave -- workgroups are dealt to the CUs
+      // as they retire, neighbouring slices run at the same time on the same XCD and meet in its L2 -- beats the tile sweep that
+      // these levels took before: 256^3 134 / 185 -> 123 / 166 us per sweep by variant, 288^3 184 / 271 -> 173 / 253 (section 14)
       const bool occ = pat_r2_occ && wpb == 4 && M.pat_nruns == 9;
-      const int wgr = std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : (occ ? 8 : 4) * n_cus));
+      const int full = (nsl2 + wpb - 1) / wpb;
+      const int wgr = std::max(1, std::min(full, pat_r2_wgs > 0 ? pat_r2_wgs : (occ && M.nrows >= pat_tile_rows ? full : (occ ? 8 : 4) * n_cus)));
       const dim3 gr(wgr);
       M.note_sweep("sells_r2sweep_kernel<XM=*,MK=%d,FM=%d,NR=%d,OCC=%d> wgs=%d wpb=%d", mk ? 1 : 0, pat_fma ? 1 : 0, M.pat_nruns, occ ? 1 : 0, wgr, wpb);
 #define GMG_R2_LAUNCH2(XMV, MKV, FMV)                                                                            \
@@ -3001,7 +3005,7 @@ struct gmg_solver {
     persist_fenced = opt_int("GMG_PERSIST_FENCED", 0);
     pat_strict = opt_int("GMG_PAT_STRICT", 1);
     pat_wide = opt_int("GMG_PAT_WIDE", 1);
-    pat_tile = opt_int("GMG_PAT_TILE", 1);
+    pat_tile = opt_int("GMG_PAT_TILE", 0);
     pat_tile_rows = opt_int("GMG_PAT_TILE_ROWS", 6000000);
     gj_mfma = opt_int("GMG_GJ_MFMA", 1);
     persist_max_slices = opt_int("GMG_PERSIST_MAX_SLICES", 0);
