@@ -347,6 +347,7 @@ struct Level {
   std::shared_ptr<PatStream> sA, sP, sR;   // streamed operators (hA/hP/hR then carry the shape only)
   // streamed matrix of an own | ghost level: the own x own part goes to the stream, the entries in ghost columns of the rows that
   // have any are kept as the small CSR the boundary fix-up applies (gmg_set_operator_rows splits every block)
+  bool rs_forbid = false;           // several ranks: the r-gather sweep form is a joint decision (gmg_solver::setup)
   bool sA_split = false;
   std::vector<int32_t> g_rows, g_col;
   std::vector<int64_t> g_ptr;
@@ -1231,7 +1232,8 @@ struct gmg_solver {
         }
       {   // inverse diagonal per pattern (JacobiLinearSolvers.jl:20-23: 1 ./ diag(A)); rows of the same pattern share it
         std::vector<double> pd((size_t)np, 0.0);
-        bool all = D.nrows == D.ncols;
+        // (own | ghost levels: the own x own part is n_own x (n_own + n_ghost) with the diagonal at column = row)
+        bool all = D.nrows <= D.ncols;
         for (int p = 0; p < np - 1 && all; ++p) {
           bool found = false;
           for (int j = 0; j < plen[p]; ++j)
@@ -1846,6 +1848,7 @@ struct gmg_solver {
   bool rsweep_level(const Level &L) const
   {
     const DevCSR &M = L.A;
+    if (L.rs_forbid) return false;                           // several ranks: some rank's part does not qualify (decided jointly at setup)
     if (!(pat_rsweep && one_gather_sweep && pat_dinv && M.sell && M.pat && M.pat_shared && !M.pat_coded && M.pat_k == 3 && pat_rb == 3 && pat_batched)) return false;
     if (M.pat_nruns % 3 != 0 || !M.pdinv || !M.pdinv_uniform || !L.rbuf[0] || !L.rbuf[1]) return false;
     // signed 32-bit byte offsets in the gathers: 8 * (row + run offset) is formed BEFORE the clamp, and row reaches 63 past the last slice
@@ -4515,6 +4518,19 @@ void gmg_solver::setup()
     d_rep_tmp = dvec((int64_t)h_rep_gid.size());
     if (comm.kind == COMM_HOST && !h_rep_full)
       HIP_CHECK(hipHostMalloc((void **)&h_rep_full, sizeof(double) * (size_t)std::max<int64_t>(1, lev[rep_from].n)));
+  }
+  if (comm.nranks > 1) {
+    // The sweep form of a partitioned level decides WHAT its halo carries (r_k for the r-gather sweeps, s_k otherwise), so it is a
+    // joint decision: a level sweeps in the r-gather form only if EVERY rank's part qualifies (a rank with fewer than 64 rows has no
+    // row-pattern table).  One all-reduce per own | ghost level at setup.
+    for (int l = 0; l + 1 < nlev; ++l) {
+      Level &L = lev[l];
+      if (!(L.halo.present && !L.halo.ovl)) continue;
+      L.rs_forbid = false;
+      double ok = rsweep_level(L) ? 1.0 : 0.0;
+      host_allreduce_sum(&ok);
+      L.rs_forbid = ok < (double)comm.nranks - 0.5;
+    }
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   setup_done = true;
