@@ -1969,7 +1969,9 @@ struct gmg_solver {
       // these levels took before: 256^3 134 / 185 -> 123 / 166 us per sweep by variant, 288^3 184 / 271 -> 173 / 253 (section 14)
       const bool occ = pat_r2_occ && wpb == 4 && M.pat_nruns == 9;
       const int full = (nsl2 + wpb - 1) / wpb;
-      const int wgr = std::max(1, std::min(full, pat_r2_wgs > 0 ? pat_r2_wgs : (occ && M.nrows >= pat_tile_rows ? full : (occ ? 8 : 4) * n_cus)));
+      // in between (3.5e6 .. pat_tile_rows rows) two rounds of eight per CU: 160^3 24.5 / 38.3 -> 23.7 / 31.8 us (one slice per wave: 24.6 / 33.3)
+      const int wgr = std::max(1, std::min(full, pat_r2_wgs > 0 ? pat_r2_wgs
+                                                 : (occ && M.nrows >= pat_tile_rows ? full : (occ ? (M.nrows >= 3500000 ? 16 : 8) : 4) * n_cus)));
       const dim3 gr(wgr);
       M.note_sweep("sells_r2sweep_kernel<XM=*,MK=%d,FM=%d,NR=%d,OCC=%d> wgs=%d wpb=%d", mk ? 1 : 0, pat_fma ? 1 : 0, M.pat_nruns, occ ? 1 : 0, wgr, wpb);
 #define GMG_R2_LAUNCH2(XMV, MKV, FMV)                                                                            \
