@@ -367,10 +367,11 @@ class DistributedGMG:
 # ---------------------------------------------------------------------------------------------------------------------------
 # Measured on MI355X (profiles/r03_rccl_latency.json, tools/rccl_latency.py; RCCL 2.26 self send/recv, 7 messages): one halo
 # exchange costs 28-42 us of stream time issued in-stream and 51-63 us with the event hand-off to a second stream; the host needs
-# 23-36 us to enqueue it.  A 1-double all-reduce + sqrt: 5-6 us on one rank.  Sweep kernels: 11.3 ns per 1000 rows (row-pattern
-# layout, profiles/r02b_kernel_stats.txt) with a floor of 4.4 us + 1.5 us of dependent-launch gap per launch; a whole block of k
+# 23-36 us to enqueue it.  A 1-double all-reduce + sqrt: 5-6 us on one rank.  Sweep kernels: 9.0 ns per 1000 rows (row-pattern
+# layout, pair sweep: 213 us per sweep on 2.36e7 rows, 16 us on 2.05e6 -- profiles/r04_288_kernel_stats.txt; round 2: 11.3)
+# with a floor of 4.4 us + 1.5 us of dependent-launch gap per launch; a whole block of k
 # sweeps as ONE launch (<= 5.08e5 rows: sells_smooth_kernel): 2.8 us + 6.0e-6 us per row per sweep (profiles/r02_tuning.md section 6).
-MODEL = dict(exchange_us=40.0, exchange_overlapped_us=60.0, link_GBs=50.0, sweep_ns_per_krow=11.3, launch_floor_us=5.9,
+MODEL = dict(exchange_us=40.0, exchange_overlapped_us=60.0, link_GBs=50.0, sweep_ns_per_krow=9.0, launch_floor_us=5.9,
              one_launch_rows=507904, one_launch_base_us=2.8, one_launch_us_per_row=6.0e-6, allreduce_us=30.0, allreduce_GBs=50.0)
 
 
