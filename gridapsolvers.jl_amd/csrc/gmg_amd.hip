@@ -2098,6 +2098,7 @@ struct gmg_solver {
   void finish_reduction(int nb, int slot, bool take_sqrt, const double *parts = nullptr, bool post = false)
   {
     if (!parts) parts = d_partials;
+    posted = 0;                                              // (a number left over by a call that threw before its fetch)
     const bool dist = comm.nranks > 1 && !reduce_local;
     if (post && !dist && red_fused && opt_int("GMG_HOST_POLL", 1)) {
       need_mail();
@@ -2331,12 +2332,12 @@ struct gmg_solver {
       volatile unsigned long long *seq = &h_mail->seq;
       const auto t0 = std::chrono::steady_clock::now();
       unsigned spins = 0;
-      while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) {
+      while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) < want) {       // (the numbers only grow: a later post also releases an earlier wait)
         if ((++spins & 0x3ff) == 0) {
           // a launch that failed would never post: look at the stream every ~1000 polls, give up on polling after 2 s
           const hipError_t q = hipStreamQuery(stream);
           if (q != hipSuccess && q != hipErrorNotReady) HIP_CHECK(q);
-          if (q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != want &&
+          if (q == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) < want &&
               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
             throw GmgError{GMG_ERR_HIP, "the device never posted the residual norm (host-mapped memory not visible?): set option host_poll = 0"};
         }
@@ -4884,6 +4885,8 @@ int gmg_set_operator_rows_repeat(gmg_handle_t h, int lev, int op, int64_t nrows_
     std::shared_ptr<PatStream> &S = op == GMG_OP_A ? L.sA : op == GMG_OP_P ? L.sP : L.sR;
     bool &has = op == GMG_OP_A ? L.hasA : op == GMG_OP_P ? L.hasP : L.hasR;
     REQUIRE(S && !S->complete(), GMG_ERR_STATE, "no row stream in progress (gmg_set_operator_rows first)");
+    REQUIRE(!(op == GMG_OP_A && L.sA_split), GMG_ERR_UNSUPPORTED,
+            "the matrix of an own | ghost level is split block by block (its ghost columns do not repeat with a shift): hand every block over");
     PatStream &P = *S;
     REQUIRE(nrows_block >= 1 && count >= 1 && nrows_block <= P.rows_seen, GMG_ERR_INVALID, "the repeated block must lie inside the rows already handed over");
     REQUIRE(P.rows_seen + nrows_block * count <= P.nrows, GMG_ERR_INVALID, "repeated rows exceed the operator");

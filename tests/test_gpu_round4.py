@@ -528,6 +528,9 @@ def test_streamed_matrix_of_an_own_ghost_level_needs_its_partition_first(S, po):
                                            C.c_void_p(si.ctypes.data), C.c_void_p(rp.ctypes.data)))
         rc = lib.gmg_set_operator_rows(h, 0, abi.OP_A, n_own, n_own + n_ghost + 1, 0, n_own, *args)
         assert rc == abi.ERR_INVALID                          # shape disagrees with the partition
+        rc = lib.gmg_set_operator_rows(h, 0, abi.OP_A, n_own, n_own + n_ghost, 0, 3, *args)   # first half of the rows ...
+        assert rc == abi.OK
+        assert lib.gmg_set_operator_rows_repeat(h, 0, abi.OP_A, 3, 1, 3) == abi.ERR_UNSUPPORTED  # ... cannot be "repeated": ghost columns do not shift
         abi.check(h, lib.gmg_set_operator_rows(h, 0, abi.OP_A, n_own, n_own + n_ghost, 0, n_own, *args))
     finally:
         lib.gmg_destroy(h)
