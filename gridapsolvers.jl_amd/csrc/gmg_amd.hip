@@ -1331,15 +1331,15 @@ struct gmg_solver {
   }
   double *r2mv_dot_parts = nullptr;    // set by spmv_set_dot around its launch
   int r2mv_dot_n = 0;
-  // y = M x and the first stage of dot(x, y) in one kernel; returns the number of partials written to `parts`, 0 = not available
-  // (the caller then runs the separate dot).  Single rank, no halo.
+  // y = M x and the first stage of dot(x, y) in one kernel; returns the number of partials written to `parts`, 0 = nothing done
+  // (the caller applies the operator and runs the separate dot), -1 = y is done but the dot is not.  Single rank, no halo.
   int spmv_set_dot(const DevCSR &M, const double *x, double *y, double *parts)
   {
     if (!pat_r2mv_dot || comm.nranks > 1 || !r2mv_ok(M)) return 0;
     r2mv_dot_parts = parts; r2mv_dot_n = 0;
     try { spmv_set(M, x, y); } catch (...) { r2mv_dot_parts = nullptr; throw; }
     r2mv_dot_parts = nullptr;
-    return r2mv_dot_n;
+    return r2mv_dot_n > 0 ? r2mv_dot_n : -1;                 // -1: y = M x is done, the dot is not (a grid of more than kRedBlocks workgroups)
   }
   template <int EPI, bool ONEG>
   void launch_sells(const DevCSR &M, const StreamArgs2 &a2)
@@ -3154,10 +3154,10 @@ static double cg_core(gmg_solver &S, int64_t n, const double *db, double *dx, do
                        ngp ? S.d_partials : nullptr, ngp); // :101
     HIP_CHECK(hipGetLastError());
     int npw = 0;
-    if (fuse && ops.apply_dot) npw = ops.apply_dot(p, w, S.d_partials);   // :104-105 in one kernel
-    if (!npw) {
-      ops.apply(p, w);                                   // :104
-      if (fuse) npw = S.dot_partials(n, p, w, S.d_partials); else S.dot_async(n, p, w, kPW, false);   // :105
+    if (fuse && ops.apply_dot) npw = ops.apply_dot(p, w, S.d_partials);   // :104-105 in one kernel (> 0), or :104 alone (-1)
+    if (npw <= 0) {
+      if (npw == 0) ops.apply(p, w);                     // :104
+      if (fuse) npw = S.dot_partials(n, p, w, S.d_partials); else { S.dot_async(n, p, w, kPW, false); npw = 0; }   // :105
     }
     double *nparts = fuse ? S.d_partials2 : S.d_partials;
     hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(kBlock), 0, S.stream, n, S.d_scalars + g_new, S.d_scalars + kPW, p, w, dx, r,
