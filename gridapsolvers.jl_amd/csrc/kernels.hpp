@@ -1901,7 +1901,12 @@ __global__ __launch_bounds__(kBlock, OCC ? 8 : 1) void sells_r2sweep_kernel(Sell
   };
   int sb = s_begin + wave;
   if (sb < s_end) load_slice(sb);
-  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
+  // GM: the masks stay in global memory -- only the rare redo of a slice whose sum came out non-finite reads them; staging them is a
+  // third of every workgroup's table traffic, 4-5 % of the sweep at one slice per wave (288^3: 172 -> 164 us).  Only where the redo
+  // path's addresses fit the registers: the x-updating forms of the 64-register kernel have none to spare (they spill with it).
+  constexpr bool GM = MK && OCC != 0 && XM == 1;
+  if (MK && !GM) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
+  else if (GM) { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8 ? a.tab8[i] : a.tab[i].v; }
   else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
   __syncthreads();
   while (sb < s_end) {
@@ -1988,8 +1993,9 @@ __global__ __launch_bounds__(kBlock, OCC ? 8 : 1) void sells_r2sweep_kernel(Sell
 #pragma unroll
         for (int t = 0; t < K; ++t) {
           const int j = q * K + t;
-          const double ga = __hiloint2double(__double2hiint(wa[t]) & (int)tmA[j], __double2loint(wa[t]));
-          const double gb = __hiloint2double(__double2hiint(wb[t]) & (int)tmB[j], __double2loint(wb[t]));
+          const int ma = GM ? (int)a.tab[pidA * nu + j].m : (int)tmA[j], mb = GM ? (int)a.tab[pidB * nu + j].m : (int)tmB[j];
+          const double ga = __hiloint2double(__double2hiint(wa[t]) & ma, __double2loint(wa[t]));
+          const double gb = __hiloint2double(__double2hiint(wb[t]) & mb, __double2loint(wb[t]));
           sA = FM ? __builtin_fma(tvA[j], ga, sA) : sA + tvA[j] * ga;
           sB = FM ? __builtin_fma(tvB[j], gb, sB) : sB + tvB[j] * gb;
         }
