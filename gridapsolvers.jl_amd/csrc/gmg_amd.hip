@@ -599,7 +599,7 @@ struct gmg_solver {
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
   int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU, eight with pat_r2_occ)
-  int pat_r2_occ = 1;   // GMG_PAT_R2_OCC: the 64-register form of the pair sweep (rolled run loop, eight waves per SIMD)
+  int pat_r2_occ = 2;   // GMG_PAT_R2_OCC: the 64-register form of the pair sweep (rolled run loop, eight waves per SIMD); 2: workgroups of eight waves at one slice per wave (big levels)
   int pat_r2mv_dot = 1; // GMG_PAT_R2MV_DOT: dot(p, A p) of CG formed by the mat-vec kernel (first stage; order of the sum differs from dot_partial_kernel's)
   int pat_pair_p = 1;   // GMG_PAT_PAIR_P: prolongation + correction with two rows per lane (sellp_pair_addto_kernel), levels of >= pat_r2mv_min rows
   int pat_r2mv = 1;     // GMG_PAT_R2MV: mat-vecs (y = A x, y -= A x, y = b - A x) with two rows per lane (sells_r2mv_kernel)
@@ -1968,6 +1968,23 @@ struct gmg_solver {
       // as they retire, neighbouring slices run at the same time on the same XCD and meet in its L2 -- beats the tile sweep that
       // these levels took before: 256^3 134 / 185 -> 123 / 166 us per sweep by variant, 288^3 184 / 271 -> 173 / 253 (section 14)
       const bool occ = pat_r2_occ && wpb == 4 && M.pat_nruns == 9;
+      // one slice per wave: workgroups of eight waves stage the coefficient table once per eight slices (pat_r2_occ = 2)
+      const bool occ8 = occ && pat_r2_occ >= 2 && M.nrows >= pat_tile_rows && pat_r2_wgs <= 0;
+      if (occ8) {
+        const dim3 g8((nsl2 + 7) / 8), b8(512);
+        M.note_sweep("sells_r2sweep_kernel<XM=*,MK=%d,FM=%d,NR=%d,OCC=2> wgs=%d wpb=8", mk ? 1 : 0, pat_fma ? 1 : 0, M.pat_nruns, (int)g8.x);
+#define GMG_R2_LAUNCH8(XMV)                                                                                      \
+        do {                                                                                                     \
+          if (mk) { if (pat_fma) hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, true, true, 9, 2>), g8, b8, lds2, stream, a);   \
+                    else hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, true, false, 9, 2>), g8, b8, lds2, stream, a); }        \
+          else { if (pat_fma) hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, false, true, 9, 2>), g8, b8, lds2, stream, a);     \
+                 else hipLaunchKernelGGL((sells_r2sweep_kernel<XMV, false, false, 9, 2>), g8, b8, lds2, stream, a); }          \
+        } while (0)
+        if (xmode == 0) GMG_R2_LAUNCH8(0); else if (xmode == 1) GMG_R2_LAUNCH8(1); else GMG_R2_LAUNCH8(2);
+#undef GMG_R2_LAUNCH8
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
       const int full = (nsl2 + wpb - 1) / wpb;
       // in between (3.5e6 .. pat_tile_rows rows) two rounds of eight per CU: 160^3 24.5 / 38.3 -> 23.7 / 31.8 us (one slice per wave: 24.6 / 33.3)
       const int wgr = std::max(1, std::min(full, pat_r2_wgs > 0 ? pat_r2_wgs
@@ -2993,7 +3010,7 @@ struct gmg_solver {
     red_fused = opt_int("GMG_RED_FUSED", 1);
     pat_r2 = opt_int("GMG_PAT_R2", 1);
     pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
-    pat_r2_occ = opt_int("GMG_PAT_R2_OCC", 1);
+    pat_r2_occ = opt_int("GMG_PAT_R2_OCC", 2);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
     pat_pair_p = opt_int("GMG_PAT_PAIR_P", 1);

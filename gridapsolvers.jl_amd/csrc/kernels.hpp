@@ -1842,8 +1842,10 @@ __device__ __forceinline__ void st2_unaligned(double *p, gmg_d2 v)
 // loop from the argument array they are vector loads the gathers then wait for) and the run loop is fully unrolled.
 // OCC = 1: the run loop stays rolled (groups of three runs; unrolled, the compiler hoists the 54 coefficient reads of a slice and the
 // kernel takes 105 registers: four waves per SIMD) and the kernel is capped at 64 registers -- eight waves per SIMD.
+// OCC = 2: the same for workgroups of eight waves (four per CU): at one slice per wave the table is staged once per eight slices
+// (288^3: 164 / 236 -> 153 / 225 us by variant; sixteen waves: no further gain)
 template <int XM, bool MK, bool FM, int NR, int OCC = 0>
-__global__ __launch_bounds__(kBlock, OCC ? 8 : 1) void sells_r2sweep_kernel(SellSArgs a)
+__global__ __launch_bounds__(OCC == 2 ? 2 * kBlock : kBlock, OCC == 2 ? 4 : (OCC ? 8 : 1)) void sells_r2sweep_kernel(SellSArgs a)
 {
   constexpr int K = 3, ROWS2 = 126, RB = 3;
   extern __shared__ double sp_smem[];
