@@ -1369,6 +1369,19 @@ struct gmg_solver {
         const dim3 gr(std::max(1, std::min((nsl2 + wpb - 1) / wpb, pat_r2_wgs > 0 ? pat_r2_wgs : 4 * n_cus)));
         const size_t lds2 = (size_t)M.pat_np * nu * 16 + 16;
         const bool mk = pat_strict || !M.ptab8;
+        // big levels (>= pat_tile_rows rows), no fused dot asked for: one slice per wave in workgroups of eight waves, 64-register form
+        // (as the sweeps of these levels: launch_rsweep)
+        bool dot_here = false;
+        if constexpr (EPI == EPI_SET) dot_here = r2mv_dot_parts != nullptr;
+        if (pat_r2_occ >= 2 && M.nrows >= pat_tile_rows && M.pat_nruns == 9 && pat_r2_wgs <= 0 && !dot_here) {
+          const dim3 g8((nsl2 + 7) / 8), b8(512);
+          if (mk) { if (pat_fma) hipLaunchKernelGGL((sells_r2mv_kernel<EPI, true, true, 9, false, 2>), g8, b8, lds2, stream, a);
+                    else hipLaunchKernelGGL((sells_r2mv_kernel<EPI, true, false, 9, false, 2>), g8, b8, lds2, stream, a); }
+          else { if (pat_fma) hipLaunchKernelGGL((sells_r2mv_kernel<EPI, false, true, 9, false, 2>), g8, b8, lds2, stream, a);
+                 else hipLaunchKernelGGL((sells_r2mv_kernel<EPI, false, false, 9, false, 2>), g8, b8, lds2, stream, a); }
+          HIP_CHECK(hipGetLastError());
+          return;
+        }
 #define GMG_R2MV_LAUNCH(MKV, FMV)                                                                              \
         do {                                                                                                     \
           if (M.pat_nruns == 9) hipLaunchKernelGGL((sells_r2mv_kernel<EPI, MKV, FMV, 9>), gr, b, lds2, stream, a);   \

@@ -2033,8 +2033,9 @@ __global__ __launch_bounds__(OCC == 2 ? 2 * kBlock : kBlock, OCC == 2 ? 4 : (OCC
 __device__ __forceinline__ double block_sum(double s, double *sh /*[4]*/);
 // DOT (EPI_SET): also the first stage of dot(x, y) = dot(p, w) of CGSolvers.jl:105 -- every workgroup stores the sum over its rows in
 // a.s_out[blockIdx.x] (the consumer sums the partials: sum_partials_all); p and w are not read again by a dot kernel.
-template <int EPI, bool MK, bool FM, int NR, bool DOT = false>
-__global__ __launch_bounds__(kBlock) void sells_r2mv_kernel(SellSArgs a)
+// OCC = 2 (big levels, one slice per wave in workgroups of eight waves): the 64-register form -- rolled run loop -- of sells_r2sweep_kernel
+template <int EPI, bool MK, bool FM, int NR, bool DOT = false, int OCC = 0>
+__global__ __launch_bounds__(OCC == 2 ? 2 * kBlock : kBlock, OCC == 2 ? 4 : 1) void sells_r2mv_kernel(SellSArgs a)
 {
   static_assert(EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID, "mat-vec epilogues only");
   static_assert(!DOT || EPI == EPI_SET, "the fused dot is dot(x, A x)");
@@ -2060,6 +2061,7 @@ __global__ __launch_bounds__(kBlock) void sells_r2mv_kernel(SellSArgs a)
   int roff[NR];
 #pragma unroll
   for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  const int voff = a.run_off[min(lane, NR - 1)];             // OCC: lane q holds run_off[q] (rolled run loop)
   int pidA = 0, pidB = 0, row = 0;
   bool inner = false;
   gmg_d2 e0, A[RB];
@@ -2096,6 +2098,39 @@ __global__ __launch_bounds__(kBlock) void sells_r2mv_kernel(SellSArgs a)
     const uint32_t *tmA = s_msk + pidA * nu, *tmB = s_msk + pidB * nu;
     const double *tvA = s_tab8 + pidA * nu, *tvB = s_tab8 + pidB * nu;
     double sA = 0.0, sB = 0.0;
+    if constexpr (OCC != 0) {
+#pragma unroll 1
+      for (int r0 = 0; r0 < NR; r0 += RB) {
+        gmg_d2 cur[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) cur[q] = A[q];
+        if (r0 + RB < NR) {
+          if (inner) {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) A[q] = ld2_unaligned(xg + row + __builtin_amdgcn_readlane(voff, r0 + RB + q));
+          } else {
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+              const int c = row + __builtin_amdgcn_readlane(voff, r0 + RB + q);
+              A[q] = gmg_d2{xg[min(max(c, 0), last)], xg[min(max(c + 1, 0), last)]};
+            }
+          }
+        }
+        const double *ta = tvA + r0 * K, *tb = tvB + r0 * K;
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+          const double w0 = cur[q].x, w1 = cur[q].y;
+          const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+          const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            const double ca = ta[q * K + t], cb = tb[q * K + t];
+            sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
+            sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int r0 = 0; r0 < NR; r0 += RB) {
       gmg_d2 cur[RB];
