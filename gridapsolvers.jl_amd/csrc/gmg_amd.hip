@@ -586,7 +586,7 @@ struct gmg_solver {
   int64_t pat_coded_min_rows = 500000;   // GMG_PAT_CODED_MIN_ROWS
   int gj_mfma = 1;      // GMG_GJ_MFMA: trailing update of the device coarse inversion on the FP64 matrix cores
   int pat_tile = 0;     // GMG_PAT_TILE: r-gather sweeps share their gathers through LDS (sells_tsweep_kernel): 0 never (default since the 64-register pair sweep beats it), 1 on levels of >= GMG_PAT_TILE_ROWS rows, 2 wherever it applies
-  int64_t pat_tile_rows = 6000000;
+  int64_t pat_tile_rows = 3500000;   // "big" row-pattern levels: pair sweep / mat-vecs at one slice per wave in eight-wave workgroups (and the tile sweep with pat_tile = 1)
   int pat_wide = 1;     // GMG_PAT_WIDE: coded (wide-row) operators decode the patterns of each workgroup's chunk into a plain LDS value table
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist_wpb_min = 1;   // GMG_PERSIST_WPB: smallest workgroup (in waves) of a one-launch pass
@@ -1999,9 +1999,7 @@ struct gmg_solver {
         return;
       }
       const int full = (nsl2 + wpb - 1) / wpb;
-      // in between (3.5e6 .. pat_tile_rows rows) two rounds of eight per CU: 160^3 24.5 / 38.3 -> 23.7 / 31.8 us (one slice per wave: 24.6 / 33.3)
-      const int wgr = std::max(1, std::min(full, pat_r2_wgs > 0 ? pat_r2_wgs
-                                                 : (occ && M.nrows >= pat_tile_rows ? full : (occ ? (M.nrows >= 3500000 ? 16 : 8) : 4) * n_cus)));
+      const int wgr = std::max(1, std::min(full, pat_r2_wgs > 0 ? pat_r2_wgs : (occ && M.nrows >= pat_tile_rows ? full : (occ ? 8 : 4) * n_cus)));
       const dim3 gr(wgr);
       M.note_sweep("sells_r2sweep_kernel<XM=*,MK=%d,FM=%d,NR=%d,OCC=%d> wgs=%d wpb=%d", mk ? 1 : 0, pat_fma ? 1 : 0, M.pat_nruns, occ ? 1 : 0, wgr, wpb);
 #define GMG_R2_LAUNCH2(XMV, MKV, FMV)                                                                            \
@@ -3042,7 +3040,7 @@ struct gmg_solver {
     pat_strict = opt_int("GMG_PAT_STRICT", 1);
     pat_wide = opt_int("GMG_PAT_WIDE", 1);
     pat_tile = opt_int("GMG_PAT_TILE", 0);
-    pat_tile_rows = opt_int("GMG_PAT_TILE_ROWS", 6000000);
+    pat_tile_rows = opt_int("GMG_PAT_TILE_ROWS", 3500000);
     gj_mfma = opt_int("GMG_GJ_MFMA", 1);
     persist_max_slices = opt_int("GMG_PERSIST_MAX_SLICES", 0);
     pat_coded_min_rows = opt_int("GMG_PAT_CODED_MIN_ROWS", 500000);

@@ -206,7 +206,7 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  * value -- a debugging / A-B device, not the configuration interface.  Keys (default):
  *   storage layout   pattern (1) pat_shared (1) opattern (1) sell (1) sell_maxpad (1.25) vdict (1) idx16 (1) force_ptr64 (0)
  *                    pat_coded_min_rows (500000) eager* (1) eager_min_rows* (20000) refresh* (1)
- *   sweep kernels    pat_rsweep (1) pat_r2 (1: two rows per lane in the r-gather sweep) pat_r2_occ (2: its 64-register form, eight waves per SIMD, in workgroups of eight waves on big levels; 1: four waves; 0: off) pat_r2_wgs (0 = one round of workgroups) pat_tile (0: never -- levels >= pat_tile_rows (6000000) take the pair sweep with one slice per wave; 1: tile sweep on those levels; 2: wherever it applies) pat_tile_min (512)
+ *   sweep kernels    pat_rsweep (1) pat_r2 (1: two rows per lane in the r-gather sweep) pat_r2_occ (2: its 64-register form, eight waves per SIMD, in workgroups of eight waves on big levels; 1: four waves; 0: off) pat_r2_wgs (0 = one round of workgroups) pat_tile (0: never -- levels >= pat_tile_rows (3500000) take the pair sweep with one slice per wave; 1: tile sweep on those levels; 2: wherever it applies) pat_tile_min (512)
  *                    pat_tile_t (48) pat_tile_lds (79872) pat_strict (1) pat_fma (0: products and sums rounded separately, as the
  *                    reference's mul!; 1: fused multiply-add taps in the row-pattern sweeps -- not bit-identical)
  *                    pat_defer (1) pat_dinv (1) pat_emit (1) pat_nb (0 = auto) pat_rb (3) pat_un (9) pat_wgs (2048) pat_batched (1)
