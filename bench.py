@@ -19,12 +19,16 @@ N = 1  BASELINE configs[1]: 128^3 cells, Q1, 4 levels, Richardson(Jacobi,10,2/3)
          host_io                the same solves with b / x as HOST arrays through GMG_MEM_HOST -- what the Julia binding passes --
                                 pageable, page-locked once (gmg_host_register) and with the x0_zero option; + one V-cycle per call
                                 (`precond_only`: the library as the preconditioner of a host-language Krylov loop)
-         config3                BASELINE configs[2]: Q2, vertex-star patch smoother Richardson(PatchSolver,10,0.2), FGMRES(5)
-                                (test/LinearSolvers/GMGTests.jl:18-47,119-123) at 128^3 (--config3-cells 256 for the full size)
+         config3                BASELINE configs[2] at its stated size: Q2 256^3, 5 levels, vertex-star patch smoother
+                                Richardson(PatchSolver,10,0.2), FGMRES(5) (test/LinearSolvers/GMGTests.jl:18-47,119-123)
+         config5                BASELINE configs[4] on one GPU: 2-D Stokes Q2 / P1disc (lid-driven cavity), FGMRES(20) with the upper
+                                block-triangular preconditioner, GMG(patch smoothers, patch-corrected prolongation) on the velocity
+                                block, CG-Jacobi on the pressure block (test/Applications/StokesGMG.jl:79-166)
 N > 1  BASELINE configs[3]: 288^3 cells per GPU (576^3 on 2x2x2), 6 levels, box row partition, halo exchange and
        scalar all-reduces over RCCL; launched by torch.distributed.run, or by bench.py itself when WORLD_SIZE is unset.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--legs default,generic,varcoef,weak_ref,host_io,config3,cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--legs default,generic,varcoef,weak_ref,host_io,config3,config5,cpu]
+                    [--allow-degraded]   (N > 1 only: without it a run whose transport is not RCCL on all N ranks exits non-zero)
 
 Prints ONE JSON line (rank 0)."""
 from __future__ import annotations
@@ -48,7 +52,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 WS_CELLS, WS_LEVELS = 288, 6   # per-GPU problem of the N > 1 runs: BASELINE configs[3] = 576^3 cells on 2x2x2 GPUs, 6 levels
 # the generic (12 B/nnz) leg: per-handle options (gmg_set_option), not environment variables
 GENERIC_OPTIONS = {"vdict": 0, "idx16": 0, "pattern": 0, "opattern": 0}
-ALL_LEGS = ("default", "generic", "varcoef", "weak_ref", "host_io", "config3", "cpu")
+ALL_LEGS = ("default", "generic", "varcoef", "weak_ref", "host_io", "config3", "config5", "cpu")
 LEGS_NOTE = ("same key <-> leg mapping at every --gpus N: default leg (the product as shipped: gmg_setup picks the storage layout) = `value`, "
              "`ms_per_step`, `roofline_compressed`; generic leg (every structure-exploiting layout off: the 12 B/nnz (col,val) stream SURVEY 8(d)'s "
              "byte model describes) = `value_generic`, `ms_per_step_generic`, `roofline`.  N = 1 runs BASELINE configs[1] (128^3) and carries the "
@@ -71,8 +75,13 @@ def parse():
     ap.add_argument("--no-generic", action="store_true", help="skip the generic (12 B/nnz) leg")
     ap.add_argument("--no-host-io", action="store_true", help="skip the host-vector leg")
     ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (Q2, patch smoother, FGMRES)")
-    ap.add_argument("--config3-cells", type=int, default=128, help="cells per direction of the config-3 leg (BASELINE: 256; 5 levels)")
+    ap.add_argument("--config3-cells", type=int, default=256, help="cells per direction of the config-3 leg (BASELINE configs[2]: 256; 5 levels)")
     ap.add_argument("--config3-levels", type=int, default=5)
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (Stokes Q2/P1disc, block-triangular FGMRES)")
+    ap.add_argument("--config5-cells", type=int, default=512, help="cells per direction of the 2-D Stokes leg (2 (2n-1)^2 velocity dofs)")
+    ap.add_argument("--config5-levels", type=int, default=6)
+    ap.add_argument("--allow-degraded", action="store_true",
+                    help="N > 1: accept the host-staged transport / in-stream exchanges when RCCL is unavailable (the line then says degraded: true)")
     ap.add_argument("--rhs", choices=["lin", "rand"], default="lin")
     args = ap.parse_args()
     if args.cells is None:
@@ -84,7 +93,7 @@ def parse():
     if bad:
         raise SystemExit(f"unknown legs {sorted(bad)}; choose from {ALL_LEGS}")
     for flag, leg in (("no_cpu_baseline", "cpu"), ("no_varcoef", "varcoef"), ("no_weak_ref", "weak_ref"), ("no_generic", "generic"),
-                      ("no_host_io", "host_io"), ("no_config3", "config3")):
+                      ("no_host_io", "host_io"), ("no_config3", "config3"), ("no_config5", "config5")):
         if getattr(args, flag):
             legs.discard(leg)
     legs.add("default")
@@ -368,7 +377,8 @@ def main():
     maxiter, atol, rtol = (20, 1e-14, 1e-6) if args.rhs == "lin" else (100, 1e-14, 1e-8)
 
     def leg(H, b, nlev, steps, warmup, options=None):
-        """numerical_setup + `steps` timed solves; HIP events around every 8th finest-level sweep launch (prof_stride)."""
+        """numerical_setup + `steps` timed solves; HIP events around every 7th finest-level sweep launch (prof_stride: odd, so that
+        both alternating sweep variants are sampled in proportion)."""
         solver = make_solver(H, nlev, maxiter, atol, rtol, options)
         t0 = time.perf_counter()
         ns = S.numerical_setup(S.symbolic_setup(solver, H["mats"][0]), H["mats"][0])
@@ -410,6 +420,12 @@ def main():
              "rows": int(r["st"]["rows"]), "nnz": int(r["st"]["nnz"])}
         if label_extra:
             d["bytes_model"] = label_extra
+        bv = r["st"].get("by_variant") or {}
+        if len(bv) > 1 or (bv and "x_every_sweep" not in bv):
+            # the sweeps of a pass alternate between two forms (x untouched / x updated with two increments); events sit on every
+            # 7th launch (odd stride), so avg_launch_ms is the launch-weighted mean of both -- each form's own figure here
+            d["by_variant"] = {k: dict(v, achieved=r["st"][bytes_key] / (v["avg_ms"] * 1e-3) / 1e9,
+                                       frac=r["st"][bytes_key] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) for k, v in bv.items()}
         if r["st"].get("fused_passes"):
             d["note"] = ("this level is small enough to run every smoothing pass as ONE launch (sells_smooth_kernel): avg_launch_ms is "
                          "pass time / sweeps and the per-sweep byte models do not describe what moves")
@@ -672,6 +688,13 @@ def main():
         except Exception as e:
             out["config3"] = {"error": str(e)[-400:]}
 
+    # ---------------- BASELINE configs[4] on one GPU: Stokes Q2/P1disc, block-triangular FGMRES + GMG -----------
+    if "config5" in legs:
+        try:
+            out["config5"] = config5_leg(torch, pkg, args, "cpu" in legs)
+        except Exception as e:
+            out["config5"] = {"error": str(e)[-400:]}
+
     if "cpu" in legs:
         cb, xo, nit_o, hist_o = cpu_baseline(args.cells, nlev, args.rhs)
         out["cpu_baseline"] = cb
@@ -772,7 +795,7 @@ def config3_leg(torch, pkg, args):
         rl["traffic_GBs"] = tr / (avg_ms * 1e-3) / 1e9
         rl["traffic_frac"] = rl["traffic_GBs"] / HBM_PEAK_GBS
     out = dict(workload=f"BASELINE configs[2]: 3D Poisson Q2 {cells}^3 cells, {nlev}-level GMG, Richardson(PatchSolver,10,0.2) pre=post, "
-                        f"FGMRES(5) rtol=1e-6, rhs = u=x1+x2 Dirichlet lift" + ("" if cells == 256 else " (full size: --config3-cells 256)"),
+                        f"FGMRES(5) rtol=1e-6, rhs = u=x1+x2 Dirichlet lift" + ("" if cells == 256 else " (BASELINE size: --config3-cells 256)"),
                value=n / dt, unit="DoFs/s", ms_per_step=dt * 1e3, steps=steps, dofs=int(n), dofs_per_level=[int(M.shape[0]) for M in H["mats"]],
                patches_per_level=npatch, streamed_levels=[l for l, M in enumerate(H["mats"]) if hasattr(M, "row_blocks")],
                fgmres_iterations=int(solver.log.num_iters), flag=int(solver.log.flag),
@@ -789,6 +812,111 @@ def config3_leg(torch, pkg, args):
     out["cpu_check"] = dict(cells=cc, levels=cl, gpu_iters=int(solver2.log.num_iters),
                             gpu_hist=[float(v) for v in solver2.log.residuals[: solver2.log.num_iters + 1]], gpu_x=x2)
     ns2.P_ns.close()
+    return out
+
+
+def config5_leg(torch, pkg, args, want_cpu):
+    """BASELINE configs[4] on ONE GPU (its 8-GPU form needs the node): the reference application test/Applications/StokesGMG.jl:79-166 --
+    lid-driven cavity, Q2 velocity / discontinuous P1 pressure, grad-div augmented velocity form (alpha = 1e3), FGMRES(20; atol 1e-10,
+    rtol 1e-12) with the upper block-triangular preconditioner [A_uu (GMG)  -B^T ; 0  -1/alpha M_p (CG-Jacobi, 20 its, rtol 1e-6)],
+    velocity GMG = maxiter 4, vertex-star patch smoothers Richardson(PatchSolver,10,0.2), patch-corrected prolongation with the grad-div rhs
+    form, LU coarsest -- on synthesised inputs (gridapsolvers.jl_amd/stokes.py).  A step = one whole solve!(x, ns, b) from x = 0, b and x
+    resident in HBM.  Checked in the same run: ||K x - b|| < 1e-7 (StokesGMG.jl:165) through scipy on the host; on an affordable size the
+    oracle's iteration count / history / solution and its time (cpu_baseline, one thread: the oracle's patch solves are sequential)."""
+    S, st, po = pkg.solvers, pkg.stokes, pkg.poisson
+    alpha = 1.0e3
+
+    def make(n, nlev):
+        t0 = time.perf_counter()
+        sysd = st.stokes_system(n, alpha)
+        Hv = st.velocity_hierarchy(n, nlev, alpha)
+        t_asm = time.perf_counter() - t0
+        sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2) for pp, pd in Hv["star_patches"]]
+        interp = [S.PatchProlongationOperator(Hv["prolongations"][l], *Hv["interior_patches"][l], pivoting=True, rhs=Hv["graddiv"][l])
+                  for l in range(nlev - 1)]
+        gmg = S.GMGLinearSolver(Hv["mats"], interp, Hv["restrictions"], pre_smoothers=sm, post_smoothers=sm,
+                                coarsest_solver=S.LUSolver(), maxiter=4, mode="preconditioner")
+        solver_p = S.CGSolver(S.JacobiLinearSolver(), maxiter=20, atol=1e-14, rtol=1e-6)
+        blocks = [[S.LinearSystemBlock(), S.LinearSystemBlock()], [S.LinearSystemBlock(), S.MatrixBlock(sysd["Mp_scaled"])]]
+        Pd = S.BlockTriangularSolver(blocks, [gmg, solver_p], coeffs=[[1.0, 1.0], [0.0, 1.0]], half="upper")
+        solver = S.FGMRESSolver(20, Pd, atol=1e-10, rtol=1e-12, maxiter=100)
+        t0 = time.perf_counter()
+        ns = S.numerical_setup(S.symbolic_setup(solver, sysd["A"]), sysd["A"])
+        return sysd, Hv, solver, gmg, solver_p, ns, t_asm, time.perf_counter() - t0
+
+    n, nlev = args.config5_cells, args.config5_levels
+    sysd, Hv, solver, gmg, solver_p, ns, t_asm, t_setup = make(n, nlev)
+    b = sysd["b"]
+    N = b.size
+    bd = torch.from_numpy(b).cuda()
+    xd = torch.zeros_like(bd)
+    torch.cuda.synchronize()
+    steps = max(2, args.steps // 3)
+    gv = ns.P_ns.block_ns[0]                         # the velocity block's GMG setup
+
+    def step():
+        xd.zero_(); torch.cuda.synchronize(); S.solve_(xd, ns, bd)
+    step()
+    gv.profile(0, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kst = gv.kernel_stats()
+    gv.profile(0, False)
+    x = xd.cpu().numpy()
+    res = float(np.linalg.norm(sysd["K"] @ x - b))
+    nu, npp = sysd["sizes"]
+    fmt = gv.level_format(0)
+    avg_ms = kst["total_ms"] / max(kst["launches"], 1)
+    rl = None
+    if kst["launches"]:
+        ach = kst["alg_bytes"] / (avg_ms * 1e-3) / 1e9
+        lay = kst["layout_bytes"] / (avg_ms * 1e-3) / 1e9
+        rl = {"leg": "config5", "bound": "hbm", "kernel": "r -= A dx of the velocity block's finest patch sweep (vector Q2 + grad-div: up to 50 entries per row)",
+              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "bytes_model": "SURVEY 8(d): 12 Z + 28 N",
+              "bytes_per_launch": kst["alg_bytes"], "layout_bytes_per_launch": kst["layout_bytes"], "layout_GBs": lay,
+              "avg_launch_ms": avg_ms, "launches_timed": kst["launches"], "rows": int(kst["rows"]), "nnz": int(kst["nnz"]), "traffic": None,
+              "note": "a 2-D level of 2e6 rows: it sits in the 256 MB Infinity Cache / L2s, the HBM roofline is an upper bound only"}
+    out = dict(workload=f"BASELINE configs[4] on one GPU: 2-D Stokes lid-driven cavity, Q2 / P1disc on {n}x{n} cells, alpha = {alpha:g}; FGMRES(20, atol 1e-10, "
+                        f"rtol 1e-12) + upper block-triangular preconditioner; velocity: {nlev}-level GMG(maxiter 4, Richardson(PatchSolver,10,0.2) pre = post, "
+                        f"patch-corrected prolongation (grad-div rhs), LU coarsest); pressure: CG-Jacobi(20, rtol 1e-6) on -1/alpha M_p",
+               value=N / dt, unit="DoFs/s", ms_per_step=dt * 1e3, steps=steps, dofs=int(N), velocity_dofs=int(nu), pressure_dofs=int(npp),
+               velocity_dofs_per_level=[int(M.shape[0]) for M in Hv["mats"]],
+               fgmres_iterations=int(solver.log.num_iters), flag=int(solver.log.flag), gmg_iterations_last_application=int(gmg.log.num_iters),
+               pressure_cg_iterations_last_application=int(solver_p.log.num_iters),
+               residual_norm_host_check=res, reference_criterion="norm(A x - b) < 1e-7 (StokesGMG.jl:165)", criterion_met=bool(res < 1e-7),
+               hist_rel=(solver.log.residuals[: solver.log.num_iters + 1] / solver.log.residuals[0]).tolist(),
+               lid_velocity_max=float(x[:nu].max()), setup_s=t_setup, assembly_s=t_asm, operator_storage=fmt, roofline=rl)
+    ns.P_ns.close()
+    del sysd, Hv, bd, xd
+    if want_cpu:
+        # the same configuration at the size the sequential oracle affords: iterations, history, solution and time against it
+        orc = entry.import_oracle()
+        cn, cl = 64, 3
+        sysd, Hv, solver, gmg, solver_p, ns, _a, _s = make(cn, cl)
+        b = sysd["b"]
+        x = np.zeros(b.size)
+        S.solve_(x, ns, b)
+        osm = [orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in Hv["star_patches"]]
+        go = orc.GMG(Hv["mats"], Hv["prolongations"], Hv["restrictions"], pre_smoothers=osm, maxiter=4, rtol=1e-8,
+                     prolongation_patches=[(orc.PATCH, *Hv["interior_patches"][l], Hv["graddiv"][l]) for l in range(cl - 1)])
+        nu, npp = sysd["sizes"]
+        Po = orc.BlockPreconditioner([nu, npp], [go, (orc.BD_CG_JACOBI, sysd["Mp_scaled"], 20, 1e-14, 1e-6)],
+                                     {(0, 1): (sysd["A"][0][1], 1.0), (1, 0): (sysd["A"][1][0], 0.0)}, orc.UPPER)
+        Kc = po.CSR(sysd["K"].shape, sysd["K"].indptr, sysd["K"].indices, sysd["K"].data)
+        t0 = time.perf_counter()
+        xo, nit, flag, hist = orc.fgmres_solve(Kc, b, Pr=Po, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=b.size / t_cpu, unit="DoFs/s", cores=1, kind="port", seconds=t_cpu, iters=int(nit),
+                                   sample=f"one full solve of the same configuration at {cn}x{cn} cells, {cl} levels ({b.size} dofs) by oracle/gmg_oracle.c, "
+                                          f"single thread ({t_cpu:.2f} s)")
+        out["cpu_check"] = dict(cells=cn, levels=cl, gpu_iters=int(solver.log.num_iters), iterations_match_cpu=bool(solver.log.num_iters == nit),
+                                max_dev_of_residual_history_rel_r0=float(np.max(np.abs(solver.log.residuals[: nit + 1] - hist)) / hist[0]),
+                                rel_diff_vs_cpu_solution=float(np.linalg.norm(x - xo) / np.linalg.norm(xo)))
+        ns.P_ns.close()
     return out
 
 

@@ -42,6 +42,7 @@ SYMBOLS = {
                               C.c_void_p, C.c_int, C.c_int],
     "gmg_set_operator_rows_repeat": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64],
     "gmg_update_values": [C.c_void_p, C.c_int, C.c_void_p],
+    "gmg_update_values_csc": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int],
     "gmg_set_prolongation": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int, C.c_int, C.c_int],
     "gmg_set_restriction": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
@@ -97,6 +98,7 @@ SYMBOLS = {
     "gmg_set_replication": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64],
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
     "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],
+    "gmg_get_kernel_stats_by_variant": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "gmg_model_bytes": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gmg_sweep_signature": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "gmg_level_format": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -141,6 +143,19 @@ class GmgError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libgmgamd status {code}: {msg}")
         self.code = code
+
+
+# gmg_set_stream: names for HIP's default streams (hipStream_t 0 cannot be passed: NULL means "the handle's own stream")
+STREAM_LEGACY, STREAM_PER_THREAD = 1, 2
+
+
+def stream_arg(stream):
+    """None -> NULL (back to the handle's own stream); a torch.cuda.Stream / integer hipStream_t -> that stream; the null stream
+    (cuda_stream == 0: torch.cuda.current_stream() / default_stream() unless the caller made another one current) -> hipStreamLegacy."""
+    if stream is None:
+        return C.c_void_p(None)
+    ptr = int(getattr(stream, "cuda_stream", stream))
+    return C.c_void_p(ptr if ptr != 0 else STREAM_LEGACY)
 
 
 def load(path=None):

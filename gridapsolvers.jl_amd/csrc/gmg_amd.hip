@@ -352,7 +352,14 @@ struct Level {
   std::vector<int32_t> g_rows, g_col;
   std::vector<int64_t> g_ptr;
   std::vector<double> g_val;
+  // how the caller interleaved own and ghost columns inside the rows of g_rows (1 = ghost column), row t at g_mptr[t]..g_mptr[t+1]:
+  // what gmg_update_values needs to route a full-row value array into the stream values and g_val
+  std::vector<uint8_t> g_mask;
+  std::vector<int64_t> g_mptr;
+  void clear_split() { sA_split = false; g_rows.clear(); g_col.clear(); g_val.clear(); g_ptr.assign(1, 0); g_mask.clear(); g_mptr.assign(1, 0); }
   bool values_dirty = false;               // gmg_update_values since the last setup
+  int input_layout = GMG_CSR;              // layout gmg_set_matrix was called with
+  std::vector<uint32_t> csc_perm;          // gmg_update_values_csc: CSR position (the handle's order) of every CSC entry, built on first use
   DevCSR A, P, R;
   double *dinv = nullptr;
   Smoother pre, post;
@@ -614,7 +621,7 @@ struct gmg_solver {
 
   // profiling of the fused sweep
   int prof_level = -1;
-  int prof_stride = 8;          // GMG_PROF_STRIDE
+  int prof_stride = 7;          // GMG_PROF_STRIDE (odd: the sweeps alternate between two variants, an even stride would sample one of them only)
   uint64_t prof_seq = 0;
   std::vector<hipEvent_t> prof_ev;
   size_t prof_used = 0;
@@ -622,6 +629,8 @@ struct gmg_solver {
   int64_t prof_launches = 0, prof_fused = 0;
   bool prof_patch = false;      // the timed launches were `r -= A dx` mat-vecs of a patch-smoother sweep, not fused Jacobi sweeps
   std::vector<int> prof_w;     // sweeps bracketed by each event pair (1, or niter for a pass run as one launch)
+  std::vector<int8_t> prof_xm; // variant (xmode 0 / 1 / 2) of the sweep each event pair brackets
+  double prof_ms_v[3] = {0, 0, 0}; int64_t prof_n_v[3] = {0, 0, 0};
 
   // ---- memory -------------------------------------------------------------
   template <typename T>
@@ -1120,6 +1129,38 @@ struct gmg_solver {
       }
     });
     return H;
+  }
+  // split stream of an own | ghost level (own x own rows in the pattern form + ghost-column CSR of the boundary rows) back to
+  // whole rows, n_own x (n_own + n_ghost): own columns first, then the ghost columns -- the order the own | ghost kernels sum in
+  static HostCSR merge_split(const HostCSR &own, int64_t ncols, const std::vector<int32_t> &g_rows, const std::vector<int64_t> &g_ptr,
+                             const std::vector<int32_t> &g_col, const std::vector<double> &g_val)
+  {
+    HostCSR H;
+    H.nrows = own.nrows; H.ncols = ncols;
+    H.ptr.assign((size_t)own.nrows + 1, 0);
+    std::vector<int64_t> gcount((size_t)own.nrows, 0);
+    for (size_t t = 0; t < g_rows.size(); ++t) gcount[(size_t)g_rows[t]] = g_ptr[t + 1] - g_ptr[t];
+    for (int64_t i = 0; i < own.nrows; ++i) H.ptr[(size_t)i + 1] = H.ptr[(size_t)i] + (own.ptr[(size_t)i + 1] - own.ptr[(size_t)i]) + gcount[(size_t)i];
+    H.col.resize((size_t)H.nnz()); H.val.resize((size_t)H.nnz());
+    parallel_for(own.nrows, [&](int64_t i) {
+      const int64_t k0 = own.ptr[(size_t)i], k1 = own.ptr[(size_t)i + 1];
+      std::copy(own.col.begin() + k0, own.col.begin() + k1, H.col.begin() + H.ptr[(size_t)i]);
+      std::copy(own.val.begin() + k0, own.val.begin() + k1, H.val.begin() + H.ptr[(size_t)i]);
+    });
+    for (size_t t = 0; t < g_rows.size(); ++t) {
+      const int64_t i = g_rows[t], at = H.ptr[(size_t)i] + (own.ptr[(size_t)i + 1] - own.ptr[(size_t)i]);
+      std::copy(g_col.begin() + g_ptr[t], g_col.begin() + g_ptr[t + 1], H.col.begin() + at);
+      std::copy(g_val.begin() + g_ptr[t], g_val.begin() + g_ptr[t + 1], H.val.begin() + at);
+    }
+    return H;
+  }
+  // a level that cannot keep its stream gets its rows back (whole rows when the stream was split)
+  static void rows_from_stream(Level &L)
+  {
+    HostCSR own = expand_stream(*L.sA);
+    if (L.sA_split) { L.hA = merge_split(own, L.hA.ncols, L.g_rows, L.g_ptr, L.g_col, L.g_val); L.clear_split(); }
+    else L.hA = std::move(own);
+    L.sA.reset();
   }
   // device form of a completed stream (the counterpart of upload_csr)
   DevCSR finish_stream(PatStream &P, const char *what)
@@ -2045,6 +2086,7 @@ struct gmg_solver {
     if (prof) {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
       prof_w[prof_used / 2] = 1;
+      prof_xm[prof_used / 2] = (int8_t)xmode;
       prof_used += 2;
     }
     if (halo_sweep) {
@@ -2084,6 +2126,7 @@ struct gmg_solver {
     if (prof) {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
       prof_w[prof_used / 2] = 1;
+      prof_xm[prof_used / 2] = (int8_t)xmode;
       prof_used += 2;
     }
     if (halo_sweep) finish_ghost<2>(l, s_old, r_new, S.omega, s_new, pack_next);   // distributed => one-gather sweep
@@ -2470,6 +2513,7 @@ struct gmg_solver {
     if (prof) {
       HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
       prof_w[prof_used / 2] = niter;
+      prof_xm[prof_used / 2] = 0;
       prof_used += 2;
     }
     return true;
@@ -2500,7 +2544,12 @@ struct gmg_solver {
         force_pending = !multi;                              // one rank: the next check_persistent() (first scalar fetch of the solve) trips
       }
       body();
-      if (!persist_defer_throw) check_persistent();
+      if (!persist_defer_throw) {
+        // out_vec is deferred while armed, so nothing above guarantees that the stream has drained: a one-launch pass issued after
+        // the body's last scalar fetch must have posted its time-out word before the solve is declared good
+        if (armed) HIP_CHECK(hipStreamSynchronize(stream));
+        check_persistent();
+      }
     } catch (const GmgError &) {
       persist_defer_throw = false;
       if (!(armed && persist_tripped)) throw;
@@ -2674,6 +2723,7 @@ struct gmg_solver {
       if (prof) {
         HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
         prof_w[prof_used / 2] = 1;
+        prof_xm[prof_used / 2] = 0;
         prof_used += 2;
         prof_patch = true;
       }
@@ -3009,7 +3059,7 @@ struct gmg_solver {
     pat_wgs = std::max(1, opt_int("GMG_PAT_WGS", 2048));
     pat_shared = opt_int("GMG_PAT_SHARED", 1);
     halo_fuse_pack = opt_int("GMG_HALO_FUSE_PACK", 1);
-    prof_stride = std::max(1, opt_int("GMG_PROF_STRIDE", 8));
+    prof_stride = std::max(1, opt_int("GMG_PROF_STRIDE", 7));
     pat_defer = opt_int("GMG_PAT_DEFER", 1);
     pat_rsweep = opt_int("GMG_PAT_RSWEEP", 1);
     if (n_cus <= 0) {
@@ -4354,7 +4404,7 @@ void gmg_solver::setup()
     for (const Smoother *sp : {&L.pre, &L.post, &L.pcorr})
       if (sp->kind == SM_PATCH && sp->tab && !sp->tab->has_blocks)
         for (size_t q = 0; q + 1 < sp->tab->pptr.size(); ++q) big = std::max(big, sp->tab->pptr[q + 1] - sp->tab->pptr[q]);
-    if (big > 64) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
+    if (big > 64) rows_from_stream(L);
   }
   if (comm.nranks > 1) {
     // Row-pattern-only operators (streamed with gmg_set_operator_rows, or handed over whole before the communicator was initialised)
@@ -4364,7 +4414,7 @@ void gmg_solver::setup()
     for (int l = 0; l < nlev; ++l) {
       Level &L = lev[l];
       const bool own_ghost = L.halo.present && !L.halo.ovl;
-      if (own_ghost && L.sA && L.sA->complete() && !L.sA_split) { L.hA = expand_stream(*L.sA); L.sA.reset(); }
+      if (own_ghost && L.sA && L.sA->complete() && !L.sA_split) rows_from_stream(L);
     }
   }
   for (int l = 0; l < nlev; ++l) {
@@ -4823,6 +4873,9 @@ int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_
     REQUIRE(nrows == ncols || h->comm.nranks > 1, GMG_ERR_INVALID, "level matrix must be square");
     Level &L = h->lev[lev];
     L.sA.reset();
+    L.clear_split();                                        // (a split stream of an earlier gmg_set_operator_rows is gone with it)
+    L.input_layout = layout;
+    L.csc_perm.clear(); L.csc_perm.shrink_to_fit();
     if (lev < h->nlev - 1 && h->try_eager_pattern(L.sA, 0, nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes)) {
       L.hA = HostCSR(); L.hA.nrows = nrows; L.hA.ncols = ncols;     // shape only
     } else
@@ -4863,8 +4916,8 @@ int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, 
       H.nrows = nrows_total; H.ncols = ncols;               // shape only: the rows are never kept
       has = false;
       if (op == GMG_OP_A) {
+        L.clear_split();
         L.sA_split = split;
-        L.g_rows.clear(); L.g_col.clear(); L.g_val.clear(); L.g_ptr.assign(1, 0);
       }
       h->touch();
     }
@@ -4890,7 +4943,11 @@ int gmg_set_operator_rows(gmg_handle_t h, int lev, int op, int64_t nrows_total, 
           else { L.g_col.push_back((int32_t)c); L.g_val.push_back(val[k]); any = true; }
         }
         fptr[(size_t)i + 1] = (int64_t)fidx.size();
-        if (any) { L.g_rows.push_back((int32_t)(row0 + i)); L.g_ptr.push_back((int64_t)L.g_col.size()); }
+        if (any) {
+          L.g_rows.push_back((int32_t)(row0 + i)); L.g_ptr.push_back((int64_t)L.g_col.size());
+          for (int64_t k = k0; k < k1; ++k) L.g_mask.push_back((read_index(idx, k, index_bytes) - index_base) >= n_own ? 1 : 0);
+          L.g_mptr.push_back((int64_t)L.g_mask.size());
+        }
       }
       h->stream_append(*S, row0, nrows_block, fptr.data(), fidx.data(), fval.data(), 0, 8);
     } else
@@ -4948,10 +5005,9 @@ int gmg_set_operator_rows_repeat(gmg_handle_t h, int lev, int op, int64_t nrows_
   });
 }
 
-int gmg_update_values(gmg_handle_t h, int lev, const double *val)
+static void update_values_impl(gmg_handle_t h, int lev, const double *val)
 {
-  return guarded(h, [&] {
-    check_level(h, lev, false);
+  {
     Level &L = h->lev[lev];
     REQUIRE(L.hasA, GMG_ERR_STATE, "no matrix set on this level");
     REQUIRE(val, GMG_ERR_INVALID, "null values");
@@ -4962,6 +5018,27 @@ int gmg_update_values(gmg_handle_t h, int lev, const double *val)
       REQUIRE(L.sA->complete(), GMG_ERR_STATE, "row stream incomplete");
       HostCSR S = gmg_solver::expand_stream(*L.sA);
       const int64_t nnz = S.nnz();
+      if (L.sA_split) {
+        // own | ghost level streamed with gmg_set_operator_rows: `val` follows the caller's whole rows (own and ghost columns
+        // interleaved as they were handed over); own-column values go to the stream's rows, ghost-column values to the fix-up CSR
+        int64_t k = 0, go = 0;
+        size_t t = 0;
+        for (int64_t i = 0; i < S.nrows; ++i) {
+          int64_t so = S.ptr[(size_t)i];
+          if (t < L.g_rows.size() && L.g_rows[t] == i) {
+            for (int64_t m = L.g_mptr[t]; m < L.g_mptr[t + 1]; ++m) {
+              if (L.g_mask[(size_t)m]) L.g_val[(size_t)go++] = val[k++];
+              else S.val[(size_t)so++] = val[k++];
+            }
+            REQUIRE(so == S.ptr[(size_t)i + 1] && go == L.g_ptr[t + 1], GMG_ERR_STATE, "split row stream: inconsistent interleave record");
+            ++t;
+          } else {
+            const int64_t c = S.ptr[(size_t)i + 1] - so;
+            std::memcpy(&S.val[(size_t)so], val + k, sizeof(double) * (size_t)c);
+            k += c;
+          }
+        }
+      } else
       std::memcpy(S.val.data(), val, sizeof(double) * (size_t)nnz);
       std::shared_ptr<PatStream> N;
       bool eager = false;
@@ -4969,7 +5046,11 @@ int gmg_update_values(gmg_handle_t h, int lev, const double *val)
         std::vector<int32_t> p32(S.ptr.begin(), S.ptr.end());
         eager = h->try_eager_pattern(N, 0, S.nrows, S.ncols, nnz, p32.data(), S.col.data(), S.val.data(), GMG_CSR, 0, 4);
       }
-      if (eager) L.sA = N;                                  // (hA keeps the shape only)
+      if (eager) L.sA = N;                                  // (hA keeps the shape only; a split stream keeps its refreshed ghost CSR)
+      else if (L.sA_split) {                                // whole rows again: own columns first, then the ghost columns
+        L.hA = gmg_solver::merge_split(S, L.hA.ncols, L.g_rows, L.g_ptr, L.g_col, L.g_val);
+        L.clear_split(); L.sA.reset();
+      }
       else { L.hA = std::move(S); L.sA.reset(); }
       h->touch();
       return;
@@ -4978,6 +5059,68 @@ int gmg_update_values(gmg_handle_t h, int lev, const double *val)
     std::memcpy(L.hA.val.data(), val, sizeof(double) * (size_t)L.hA.nnz());
     L.values_dirty = true;
     h->setup_done = false;                                  // structure untouched: gmg_setup takes the value-refresh path when it can
+  }
+}
+
+int gmg_update_values(gmg_handle_t h, int lev, const double *val)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, false);
+    update_values_impl(h, lev, val);
+  });
+}
+
+int gmg_update_values_csc(gmg_handle_t h, int lev, const void *colptr, const void *rowidx, const double *val, int index_base, int index_bytes)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, false);
+    Level &L = h->lev[lev];
+    REQUIRE(L.hasA, GMG_ERR_STATE, "no matrix set on this level");
+    REQUIRE(val, GMG_ERR_INVALID, "null values");
+    REQUIRE(L.input_layout == GMG_CSC && !L.sA_split, GMG_ERR_STATE,
+            "gmg_update_values_csc: this level's matrix was not handed over with gmg_set_matrix in GMG_CSC layout");
+    REQUIRE(index_bytes == 4 || index_bytes == 8, GMG_ERR_INVALID, "index_bytes must be 4 or 8");
+    REQUIRE(index_base == 0 || index_base == 1, GMG_ERR_INVALID, "index_base must be 0 or 1");
+    // the handle's CSR row pointer (a level kept in row-pattern form only: from the pattern lengths)
+    std::vector<int64_t> rp;
+    const int64_t nrows = L.hA.nrows, ncols = L.hA.ncols;
+    if (L.sA) {
+      REQUIRE(L.sA->complete(), GMG_ERR_STATE, "row stream incomplete");
+      rp.assign((size_t)nrows + 1, 0);
+      for (int64_t i = 0; i < nrows; ++i) rp[(size_t)i + 1] = rp[(size_t)i] + L.sA->len[L.sA->rowpid[(size_t)i]];
+    } else rp = L.hA.ptr;
+    const int64_t nnz = rp.back();
+    if (L.csc_perm.size() != (size_t)nnz) {
+      // first refresh: where the counting-sort transposition of gmg_set_matrix (convert_input) put every CSC entry
+      REQUIRE(colptr && rowidx, GMG_ERR_INVALID, "gmg_update_values_csc: the first call on a level needs colptr and rowidx");
+      REQUIRE(nnz < (int64_t)UINT32_MAX, GMG_ERR_UNSUPPORTED, "more than 2^32-1 stored entries on one level");
+      REQUIRE(read_index(colptr, 0, index_bytes) == index_base && read_index(colptr, ncols, index_bytes) - index_base == nnz, GMG_ERR_INVALID,
+              "gmg_update_values_csc: the column pointers do not describe the pattern this level was set with");
+      std::vector<uint32_t> perm((size_t)nnz);
+      std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+      for (int64_t c = 0; c < ncols; ++c) {
+        const int64_t k0 = read_index(colptr, c, index_bytes) - index_base, k1 = read_index(colptr, c + 1, index_bytes) - index_base;
+        REQUIRE(k0 <= k1 && k1 <= nnz, GMG_ERR_INVALID, "column pointers not monotone");
+        for (int64_t k = k0; k < k1; ++k) {
+          const int64_t r = read_index(rowidx, k, index_bytes) - index_base;
+          REQUIRE(r >= 0 && r < nrows, GMG_ERR_INVALID, "row index out of range");
+          REQUIRE(fill[(size_t)r] < rp[(size_t)r + 1], GMG_ERR_INVALID, "gmg_update_values_csc: the pattern differs from the one this level was set with");
+          perm[(size_t)k] = (uint32_t)fill[(size_t)r]++;
+        }
+      }
+      L.csc_perm.swap(perm);
+    }
+    std::vector<double> v((size_t)nnz);
+    const uint32_t *pm = L.csc_perm.data();
+    const int64_t nchunk = (nnz + (1 << 20) - 1) >> 20;
+    parallel_chunks(nchunk, [&](int64_t t) {
+      const int64_t k0 = t << 20, k1 = std::min(nnz, k0 + (1 << 20));
+      for (int64_t k = k0; k < k1; ++k) v[pm[k]] = val[k];
+    });
+    std::vector<uint32_t> keep;
+    keep.swap(L.csc_perm);                                   // (update_values_impl may re-hash the level; the pattern, hence the permutation, stays)
+    update_values_impl(h, lev, v.data());
+    L.csc_perm.swap(keep);
   });
 }
 
@@ -5784,12 +5927,14 @@ int gmg_profile_enable(gmg_handle_t h, int lev, int enable)
     if (h->prof_ev.empty()) {
       h->prof_ev.resize(2 * 8192);
       h->prof_w.assign(8192, 1);
+      h->prof_xm.assign(8192, 0);
       for (auto &ev : h->prof_ev) HIP_CHECK(hipEventCreate(&ev));
     }
     h->prof_level = lev;
     h->prof_used = 0;
     h->prof_ms = 0.0;
     h->prof_launches = 0; h->prof_fused = 0; h->prof_patch = false;
+    for (int v = 0; v < 3; ++v) { h->prof_ms_v[v] = 0.0; h->prof_n_v[v] = 0; }
   });
 }
 
@@ -5805,6 +5950,8 @@ int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
       h->prof_ms += ms;
       h->prof_launches += h->prof_w[i / 2];
       if (h->prof_w[i / 2] > 1) h->prof_fused += 1;
+      const int v = std::min(2, std::max(0, (int)h->prof_xm[i / 2]));
+      h->prof_ms_v[v] += ms; h->prof_n_v[v] += h->prof_w[i / 2];
     }
     h->prof_used = 0;
     const int l = h->prof_level >= 0 ? h->prof_level : 0;
@@ -5825,6 +5972,18 @@ int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
       if (L.A.pat) out->layout_bytes = ((L.A.rowbase ? 6.0 : 2.0) + 24.0) * (double)L.n;
       else out->layout_bytes = h->sweep_layout_bytes(l) - 32.0 * (double)L.n;
     }
+  });
+}
+
+int gmg_get_kernel_stats_by_variant(gmg_handle_t h, double total_ms[3], int64_t launches[3])
+{
+  return guarded(h, [&] {
+    check_ready(h);
+    REQUIRE(total_ms && launches, GMG_ERR_INVALID, "null output");
+    gmg_kernel_stats tmp;
+    const int st = gmg_get_kernel_stats(h, &tmp);            // folds the pending event pairs into the accumulators
+    REQUIRE(st == GMG_OK, st, "gmg_get_kernel_stats failed");
+    for (int v = 0; v < 3; ++v) { total_ms[v] = h->prof_ms_v[v]; launches[v] = h->prof_n_v[v]; }
   });
 }
 

@@ -97,8 +97,9 @@ end
 
 # Same keyword surface as GMGLinearSolver(smatrices,interp,restrict;...) GMGLinearSolvers.jl:48-69, plus three keywords the
 # reference has no use for: `device`, `options` (layout / schedule policy of THIS solver: e.g. Dict("pat_tile"=>2, "persist"=>0,
-# "x0_zero"=>1); unknown keys are rejected by the library) and `pin_vectors` (default true: the vectors solve! sees are page-locked
-# once and then move over PCIe by DMA at the link rate -- 3.6 ms instead of 4.7 ms per config-2 solve; the setup keeps them alive)
+# "x0_zero"=>1); unknown keys are rejected by the library) and `pin_vectors` (default false; true: the vectors solve! sees are page-locked
+# once and then move over PCIe by DMA at the link rate -- 3.6 ms instead of 4.7 ms per config-2 solve; the setup keeps them alive.
+# For a top-level solve! that is called again and again with the SAME x and b; not for a preconditioner applied to rotating work vectors)
 function HipGMGLinearSolver(
   smatrices::AbstractArray{<:AbstractMatrix}, interp::AbstractArray, restrict = nothing;
   pre_smoothers  = fill(RichardsonSmoother(JacobiLinearSolver(),10),length(smatrices)-1),
@@ -106,7 +107,7 @@ function HipGMGLinearSolver(
   coarsest_solver = Gridap.Algebra.LUSolver(),
   mode = :preconditioner, cycle_type = :v_cycle,
   maxiter = 100, atol = 1.0e-14, rtol = 1.0e-08, verbose = false, device = 0,
-  options = Dict{String,Float64}(), pin_vectors = true,
+  options = Dict{String,Float64}(), pin_vectors = false,
 )
   nlev = length(smatrices)
   @assert nlev-1 == length(interp) == length(pre_smoothers) == length(post_smoothers)
@@ -129,8 +130,10 @@ mutable struct HipGMGNumericalSetup{A} <: Gridap.Algebra.NumericalSetup
   handle :: Ptr{Cvoid}
   n      :: Int
   keepalive :: Any          # Julia objects the handle points at (coarse-solver callback context)
-  pinned :: Vector{Vector{Float64}}   # vectors registered with gmg_host_register: referenced here so that they outlive their registration
-  HipGMGNumericalSetup(solver::A, handle, n) where A = new{A}(solver, handle, n, nothing, Vector{Float64}[])
+  pinned :: Vector{Tuple{Vector{Float64},Ptr{Float64},Int}}   # vectors registered with gmg_host_register (+ the pointer and byte count they
+                                                              # were registered with): referenced here so that they outlive their registration
+  pin_stats :: Vector{Int}                                    # [registrations, hits]: pinning switches itself off when it thrashes
+  HipGMGNumericalSetup(solver::A, handle, n) where A = new{A}(solver, handle, n, nothing, Tuple{Vector{Float64},Ptr{Float64},Int}[], [0,0])
 end
 
 # gmg_set_option / gmg_get_option: per-handle layout and schedule policy (live options act at the next call, the others at the
@@ -147,9 +150,16 @@ end
 
 # gmg_set_stream: issue the handle's work on the caller's HIP stream (e.g. `AMDGPU.stream().stream` as a Ptr{Cvoid}): device vectors
 # (HipDeviceVector) produced / consumed by the caller's kernels on that stream need no synchronisation around solve! / ldiv!.
-# C_NULL returns to the handle's own stream.
+# A null hipStream_t IS a stream -- HIP's default one, what AMDGPU.jl reports for its default stream -- so it is passed on as
+# GMG_STREAM_LEGACY (hipStreamLegacy); `reset_stream!` returns to the handle's own stream (gmg_set_stream(h, NULL)).
+const GMG_STREAM_LEGACY = Ptr{Cvoid}(UInt(1))
 function set_stream!(ns::HipGMGNumericalSetup, stream::Ptr{Cvoid})
-  check(ns.handle, ccall((:gmg_set_stream, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid}), ns.handle, stream))
+  s = stream == C_NULL ? GMG_STREAM_LEGACY : stream
+  check(ns.handle, ccall((:gmg_set_stream, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid}), ns.handle, s))
+  return ns
+end
+function reset_stream!(ns::HipGMGNumericalSetup)
+  check(ns.handle, ccall((:gmg_set_stream, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid}), ns.handle, C_NULL))
   return ns
 end
 function get_stream(ns::HipGMGNumericalSetup)
@@ -158,17 +168,37 @@ function get_stream(ns::HipGMGNumericalSetup)
   return s[]
 end
 
-# Page-lock the vectors of a solve once (gmg_host_register); at most 8 are held, the oldest is released first.  A Julia Array never
-# moves, and the setup holds a reference, so the registered pages stay valid until gmg_host_unregister / finalize.
+# Page-lock the vectors of a solve once (gmg_host_register); at most 8 are held, the oldest is released first.  The setup holds a
+# reference, and every entry remembers the (pointer, bytes) it was registered with: a vector that was resize!d / push!ed since is
+# released and registered again.  A host-language Krylov loop that rotates through more work vectors than the table holds
+# (FGMRES: solve!(Z[j], Pr, V[j])) would re-register on every call -- slower than the pageable path --, so pinning switches itself off
+# for this setup once registrations outnumber hits 4 : 1 after the first 32.
+function _unpin_entry(ns, e)
+  st = ccall((:gmg_host_unregister, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid}), ns.handle, e[2])
+  return st          # (GMG_ERR_INVALID: the range was released already -- nothing to undo)
+end
 function pin!(ns::HipGMGNumericalSetup, vs::Vector{Float64}...)
   for v in vs
-    any(p -> p === v, ns.pinned) && continue
+    isempty(v) && continue
+    i = findfirst(e -> e[1] === v, ns.pinned)
+    if !isnothing(i)
+      e = ns.pinned[i]
+      if e[2] == pointer(v) && e[3] == sizeof(v)
+        ns.pin_stats[2] += 1
+        continue
+      end
+      _unpin_entry(ns, e)                                  # the array was reallocated: the old range is stale
+      deleteat!(ns.pinned, i)
+    end
+    if ns.pin_stats[1] >= 32 && ns.pin_stats[1] > 4*ns.pin_stats[2]
+      continue                                             # thrashing: leave the vectors pageable
+    end
     if length(ns.pinned) >= 8
-      old = popfirst!(ns.pinned)
-      GC.@preserve old ccall((:gmg_host_unregister, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid}), ns.handle, pointer(old))
+      _unpin_entry(ns, popfirst!(ns.pinned))
     end
     GC.@preserve v check(ns.handle, ccall((:gmg_host_register, libgmgamd), Cint, (Ptr{Cvoid},Ptr{Cvoid},Int64), ns.handle, pointer(v), sizeof(v)))
-    push!(ns.pinned, v)
+    push!(ns.pinned, (v, pointer(v), sizeof(v)))
+    ns.pin_stats[1] += 1
   end
   return ns
 end
@@ -294,15 +324,40 @@ function Gridap.Algebra.numerical_setup(ss::HipGMGSymbolicSetup, mat::AbstractMa
   return ns
 end
 
-# numerical_setup!(ns,A): new values on the same pattern (the reference's FromMatrices
-# variant only logs an @error, GMGLinearSolvers.jl:249-258; the weak-form variant :260-297
-# re-assembles every level -- pass the re-assembled finest matrix here).
-function Gridap.Algebra.numerical_setup!(ns::HipGMGNumericalSetup, mat::AbstractMatrix)
-  At = SparseMatrixCSC{Float64,Int64}(sparse(transpose(mat)))    # CSR value order of `mat`
-  GC.@preserve At begin
-    check(ns.handle, ccall((:gmg_update_values, libgmgamd), Cint, (Ptr{Cvoid},Cint,Ptr{Float64}), ns.handle, 0, At.nzval))
+# numerical_setup!(ns,A[,smatrices]): new values on the same pattern.  The reference's FromMatrices variant only logs an @error
+# (GMGLinearSolvers.jl:249-258); its weak-form variant (:260-297) re-assembles EVERY level and recomputes the smoothers and the
+# coarsest solver: pass the re-assembled level matrices as `smatrices` (entry 1 is ignored, `mat` is level 1 as in :338) and
+# every level is refreshed -- gmg_setup rebuilds D^-1, the patch blocks and the coarse inverse from the new values.  CSC values go
+# over as they are (gmg_update_values_csc: the library scatters them into its row order; no sparse(transpose(A)) here).
+function _update_values(h, lev, M::SparseMatrixCSC{Float64,Ti}) where Ti
+  GC.@preserve M begin
+    check(h, ccall((:gmg_update_values_csc, libgmgamd), Cint, (Ptr{Cvoid},Cint,Ptr{Cvoid},Ptr{Cvoid},Ptr{Float64},Cint,Cint),
+                   h, lev, M.colptr, M.rowval, M.nzval, 1, sizeof(Ti)))
   end
-  check(ns.handle, ccall((:gmg_setup, libgmgamd), Cint, (Ptr{Cvoid},), ns.handle))
+end
+function _update_values(h, lev, M::AbstractMatrix)
+  if hasproperty(M,:rowptr) && hasproperty(M,:colval)       # SparseMatrixCSR: already the handle's order
+    GC.@preserve M begin
+      check(h, ccall((:gmg_update_values, libgmgamd), Cint, (Ptr{Cvoid},Cint,Ptr{Float64}), h, lev, M.nzval))
+    end
+  else
+    _update_values(h, lev, SparseMatrixCSC{Float64,Int64}(sparse(M)))
+  end
+end
+function Gridap.Algebra.numerical_setup!(ns::HipGMGNumericalSetup, mat::AbstractMatrix, smatrices = nothing)
+  _update_values(ns.handle, 0, mat)
+  if !isnothing(smatrices)
+    @assert length(smatrices) == length(ns.solver.smatrices)
+    for l in 2:length(smatrices)
+      _update_values(ns.handle, l-1, smatrices[l])
+    end
+  end
+  if ns.solver.coarsest_solver isa Gridap.Algebra.LUSolver
+    check(ns.handle, ccall((:gmg_setup, libgmgamd), Cint, (Ptr{Cvoid},), ns.handle))
+  else                                                      # the caller's coarsest solver is set up again on the new coarsest matrix (:291-294)
+    nlev = length(ns.solver.smatrices)
+    set_coarsest_solver!(ns, ns.solver.coarsest_solver, isnothing(smatrices) ? ns.solver.smatrices[nlev] : smatrices[nlev])
+  end
   return ns
 end
 

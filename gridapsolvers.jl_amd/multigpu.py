@@ -298,8 +298,7 @@ class DistributedGMG:
 
     def set_stream(self, stream=None):
         """gmg_set_stream: the handle's work on the caller's HIP stream (torch.cuda.Stream, integer hipStream_t, None = its own)"""
-        ptr = getattr(stream, "cuda_stream", stream)
-        abi.check(self.h, self._lib.gmg_set_stream(self.h, C.c_void_p(int(ptr) if ptr else None)))
+        abi.check(self.h, self._lib.gmg_set_stream(self.h, abi.stream_arg(stream)))
 
     def fgmres_solve(self, b, x, m=5, maxiter=20, atol=1e-14, rtol=1e-6, restart=False, m_add=1):
         log = ConvergenceLog("FGMRES", maxiter, atol, rtol)
@@ -427,6 +426,12 @@ def run_bench(args, rank, world, local_rank):
     import torch.distributed as dist
     nc = (args.cells,) * 3
     transport = os.environ.get("GMG_TRANSPORT", "rccl")
+    # STRICT by default: a `--gpus N` line is the product's RCCL path or no line at all (non-zero exit).  The host-staged transport and
+    # the in-stream exchange are fallbacks for debugging -- only with --allow-degraded, or in the several-ranks-on-one-GPU test set-up
+    # (GMG_SHARE_GPU, which asks for GMG_TRANSPORT=host itself).
+    strict = bool(os.environ.get("GMG_BENCH_STRICT_RCCL")) or not (getattr(args, "allow_degraded", False) or os.environ.get("GMG_SHARE_GPU"))
+    if strict and transport != "rccl":
+        raise SystemExit(f"bench.py --gpus {world}: GMG_TRANSPORT={transport} is not the product's transport (RCCL); pass --allow-degraded to run it anyway")
     group = None
     lengths = tuple(float(v) for v in pa.rank_grid(world, 3))      # cubic cells at every GPU count
     # BASELINE configs[3] (SURVEY 8 size table): 288^3 cells per GPU, 6 levels -> 576,288,144,72,36,18 cells per direction on
@@ -457,8 +462,8 @@ def run_bench(args, rank, world, local_rank):
             if rank == 0:
                 print(f"[bench] librccl could not be loaded on at least one rank (rank 0: {err}); falling back to the host-staged transport",
                       flush=True, file=sys.stderr)
-            if os.environ.get("GMG_BENCH_STRICT_RCCL"):
-                raise RuntimeError("librccl could not be loaded on at least one rank")
+            if strict:
+                raise RuntimeError("librccl could not be loaded on at least one rank (pass --allow-degraded to fall back to the host-staged transport)")
             transport = "host"
     if transport != "host":
         try:
@@ -475,8 +480,8 @@ def run_bench(args, rank, world, local_rank):
             if rank == 0:
                 print(f"[bench] RCCL transport unavailable on at least one rank (rank 0: {err}); falling back to the host-staged transport",
                       flush=True, file=sys.stderr)
-            if os.environ.get("GMG_BENCH_STRICT_RCCL"):
-                raise RuntimeError(f"RCCL transport unavailable on at least one rank (this rank: {err})")
+            if strict:
+                raise RuntimeError(f"RCCL transport unavailable on at least one rank (this rank: {err}); pass --allow-degraded to fall back to the host-staged transport")
             transport = "host"
     if transport == "host":
         group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
@@ -500,6 +505,8 @@ def run_bench(args, rank, world, local_rank):
     if not sane() and transport == "rccl":
         # safety net: the overlapped exchange (comm stream + events) cannot be exercised on the 1-GPU
         # development boxes; if it ever misbehaves fall back to in-stream exchanges and say so
+        if strict:
+            raise RuntimeError("overlapped halo exchange gave a wrong solution (pass --allow-degraded to retry with in-stream exchanges)")
         if rank == 0:
             print("[bench] overlapped halo exchange gave a wrong solution; retrying with GMG_OVERLAP=0", flush=True, file=sys.stderr)
         os.environ["GMG_OVERLAP"] = "0"
@@ -556,6 +563,8 @@ def run_bench(args, rank, world, local_rank):
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     sig = g.sweep_signature(0)
+    if strict and not (transport == "rccl" and ci["rccl_comm_count"] == world and all(e["rccl_comm_count"] == world for e in everyone)):
+        raise RuntimeError(f"RCCL communicator reports {[e['rccl_comm_count'] for e in everyone]} ranks, expected {world} on every rank")
     out = {
         "metric": "DoFs/sec, CG+GMG V-cycle on 3D Poisson Q1",
         "value": n * D["steps"] / D["dt"], "unit": "DoFs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -406,8 +406,7 @@ class GMGNumericalSetup:
     def set_stream(self, stream=None):
         """gmg_set_stream: issue the handle's work on the caller's HIP stream (an integer hipStream_t, a torch.cuda.Stream, or None for
         the handle's own) -- ordered with the caller's kernels on that stream, no device synchronisation in between."""
-        ptr = getattr(stream, "cuda_stream", stream)
-        abi.check(self.h, self._lib.gmg_set_stream(self.h, C.c_void_p(int(ptr) if ptr else None)))
+        abi.check(self.h, self._lib.gmg_set_stream(self.h, abi.stream_arg(stream)))
 
     def get_stream(self):
         out = C.c_void_p()
@@ -425,14 +424,24 @@ class GMGNumericalSetup:
         abi.check(self.h, self._lib.gmg_host_unregister(self.h, C.c_void_p(arr.ctypes.data)))
 
     def pin(self, *arrays):
-        """Page-lock host vectors for the life of this setup (or until 8 newer ones displaced them); holds a reference to each."""
+        """Page-lock host vectors for the life of this setup (or until 8 newer ones displaced them); holds a reference to each.
+        Keyed by address range, as the C registry is: two views of one buffer are one registration."""
         for a in arrays:
-            if not isinstance(a, np.ndarray) or any(a is q for q in self._pinned):
+            if not isinstance(a, np.ndarray) or a.nbytes == 0:
+                continue
+            key = (a.ctypes.data, a.nbytes)
+            hit = next((i for i, (k, _q) in enumerate(self._pinned) if k == key), None)
+            if hit is not None:
+                self._pinned.append(self._pinned.pop(hit))          # most recently used last
                 continue
             if len(self._pinned) >= 8:
-                self.unregister_host(self._pinned.pop(0))
+                _k, old = self._pinned.pop(0)
+                try:
+                    self.unregister_host(old)
+                except abi.GmgError:                                 # (a range another view had already released)
+                    pass
             self.register_host(a)
-            self._pinned.append(a)
+            self._pinned.append((key, a))
 
     def host_io_stats(self):
         up, down, nreg = C.c_int64(), C.c_int64(), C.c_int64()
@@ -534,9 +543,11 @@ class GMGNumericalSetup:
             if M is None:
                 continue
             shape, ptr, idx, val, layout, base = _csr_fields(M)
-            if layout != abi.CSR:
-                raise NotImplementedError("numerical_setup! needs CSR values in the handle's order")
-            st = self._lib.gmg_update_values(self.h, l, C.c_void_p(val.ctypes.data))
+            if layout == abi.CSC:           # values in the caller's CSC order (the level was set in CSC layout): scattered by the library
+                st = self._lib.gmg_update_values_csc(self.h, l, C.c_void_p(ptr.ctypes.data), C.c_void_p(idx.ctypes.data),
+                                                     C.c_void_p(val.ctypes.data), base, ptr.dtype.itemsize)
+            else:
+                st = self._lib.gmg_update_values(self.h, l, C.c_void_p(val.ctypes.data))
             if st == abi.ERR_UNSUPPORTED:       # level held in row-pattern form only: hand the whole matrix over again
                 _set_op(self._lib.gmg_set_matrix, self.h, l, M)
             else:
@@ -617,8 +628,12 @@ class GMGNumericalSetup:
     def kernel_stats(self):
         st = abi.KernelStats()
         abi.check(self.h, self._lib.gmg_get_kernel_stats(self.h, C.byref(st)))
+        ms, nl = (C.c_double * 3)(), (C.c_int64 * 3)()
+        abi.check(self.h, self._lib.gmg_get_kernel_stats_by_variant(self.h, ms, nl))
+        names = ("x_every_sweep", "x_untouched", "x_two_increments")
+        by_variant = {names[v]: dict(launches=int(nl[v]), total_ms=float(ms[v]), avg_ms=float(ms[v]) / nl[v]) for v in range(3) if nl[v]}
         return dict(launches=st.launches, total_ms=st.total_ms, alg_bytes=st.alg_bytes, rows=st.rows, nnz=st.nnz,
-                    layout_bytes=st.layout_bytes, fused_passes=st.fused_passes)
+                    layout_bytes=st.layout_bytes, fused_passes=st.fused_passes, by_variant=by_variant)
 
     def stream_probe(self, nbytes=1 << 30, reps=10):
         v = C.c_double(0.0)
@@ -850,7 +865,7 @@ def solve_(x, ns, b):
         if ms != ms2:
             raise TypeError("x and b must live in the same memory space")
         if ms == abi.MEM_HOST and ns.solver.pin_vectors:
-            ns.pin(_kb, _kx)
+            ns.pin(*(k for k, u in ((_kb, b), (_kx, x)) if k is u))       # the caller's own arrays only, never a conversion copy
         res = abi.Result()
         hist = np.zeros(log.maxiter + 1)
         abi.check(ns.h, ns._lib.gmg_apply(ns.h, pb, px, ms, C.byref(res), C.c_void_p(hist.ctypes.data), hist.size))
@@ -891,7 +906,7 @@ def solve_(x, ns, b):
         if ms != ms2:
             raise TypeError("x and b must live in the same memory space")
         if ms == abi.MEM_HOST and g.solver.pin_vectors:
-            g.pin(_kb, _kx)
+            g.pin(*(k for k, u in ((_kb, b), (_kx, x)) if k is u))
         res = abi.Result()
         hist = np.zeros(log.maxiter + 1)
         if isinstance(s, CGSolver):

@@ -125,6 +125,13 @@ GMG_API int gmg_set_operator_rows_repeat(gmg_handle_t h, int lev, int op, int64_
  * value arrays, D^-1, the patch inverse blocks and the coarse inverse on the device -- bit-identical to a fresh setup.
  * Dictionary / row-pattern layouts depend on the values themselves: those levels trigger a full setup. */
 GMG_API int gmg_update_values(gmg_handle_t h, int lev, const double *val);
+/* The same for a level whose matrix was handed to gmg_set_matrix in GMG_CSC layout (Julia's SparseMatrixCSC, Gridap's default):
+ * `val` = the new nzval in CSC order.  The first call on a level also takes the (unchanged) colptr / rowidx and records where
+ * the transposition of gmg_set_matrix put every entry; later calls may pass NULL for both and cost one parallel scatter -- no
+ * `sparse(transpose(A))` on the caller's side.  numerical_setup!(ns,A) of the weak-form variant refreshes EVERY level this way
+ * (GMGLinearSolvers.jl:260-297: smatrices, smoothers and the coarsest solver are all recomputed). */
+GMG_API int gmg_update_values_csc(gmg_handle_t h, int lev, const void *colptr, const void *rowidx, const double *val,
+                                  int index_base, int index_bytes);
 /* interp[lev+1] : level lev+1 -> lev, `mul!(dxh,interp,dxH)` GMGLinearSolvers.jl:491
  * (y = P x, GridTransferOperators.jl:391-401).  nrows = n(lev), ncols = n(lev+1). */
 GMG_API int gmg_set_prolongation(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_t nnz,
@@ -256,8 +263,13 @@ GMG_API int gmg_get_persist_retries(gmg_handle_t h, int64_t *retries, int *persi
  * default every handle owns a non-blocking stream (gmg_create).  A caller that produces b and consumes x with its own kernels
  * (a device-resident Krylov loop around gmg_apply; PyTorch / AMDGPU.jl arrays) passes ITS stream: the library's work is then
  * ordered with the caller's without any device synchronisation on either side.  stream = NULL returns to the handle's own
- * stream.  The call waits for the work already issued on the stream it leaves.  No reference counterpart (the reference runs on
+ * stream -- it does NOT name HIP's null stream.  The device's default ("null", legacy-synchronising) stream, whose hipStream_t
+ * is 0 -- what `torch.cuda.current_stream().cuda_stream` and AMDGPU.jl's default stream report -- is named by
+ * GMG_STREAM_LEGACY (= hipStreamLegacy), the per-thread default stream by GMG_STREAM_PER_THREAD (= hipStreamPerThread).
+ * The call waits for the work already issued on the stream it leaves.  No reference counterpart (the reference runs on
  * the host); `gmg_get_stream` returns the current one (e.g. to record an event on it). */
+#define GMG_STREAM_LEGACY ((void *)1)
+#define GMG_STREAM_PER_THREAD ((void *)2)
 GMG_API int gmg_set_stream(gmg_handle_t h, void *stream);
 GMG_API int gmg_get_stream(gmg_handle_t h, void **stream);
 GMG_API int gmg_set_verbose(gmg_handle_t h, int verbose);
@@ -384,10 +396,14 @@ GMG_API int gmg_set_replication(gmg_handle_t h, int lev, const int64_t *own_glob
 
 /* ---- measurement --------------------------------------------------------------- */
 /* Bracket launches of the fused Richardson-Jacobi sweep on `lev` with HIP events on the handle's
- * stream: every GMG_PROF_STRIDE-th launch (default 8; an event pair costs ~4 us of stream time);
- * enable=0 stops.  Read with gmg_get_kernel_stats. */
+ * stream: every GMG_PROF_STRIDE-th launch (default 7 -- odd on purpose: sweeps alternate between the variant that leaves x
+ * alone and the one that adds two increments to it, `x = (x + s_{k-1}) + s_k`, and an even stride would time one of them only;
+ * an event pair costs ~4 us of stream time); enable=0 stops.  Read with gmg_get_kernel_stats (launch-weighted totals) and
+ * gmg_get_kernel_stats_by_variant (index 0: sweeps that update x every time -- the generic layouts' first sweep, one-launch
+ * passes, patch sweeps; 1: x untouched; 2: x updated with two increments). */
 GMG_API int gmg_profile_enable(gmg_handle_t h, int lev, int enable);
 GMG_API int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out);
+GMG_API int gmg_get_kernel_stats_by_variant(gmg_handle_t h, double total_ms[3], int64_t launches[3]);
 /* Algorithmic bytes (SURVEY 8d byte model) of one V-cycle / one CG iteration. */
 GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes);
 /* Storage chosen for A_lev at setup: *sell = 0 CSR-stream, 1 SELL-64 / SELL-C, 2 SELL-P (row-pattern

@@ -531,6 +531,24 @@ def main():
             verdict["persist_retries"] = [a[0] for a in allr]
             verdict["persist_active"] = [a[1] for a in allr]
         verdict["x_sha"] = __import__("hashlib").sha256(np.ascontiguousarray(x).tobytes()).hexdigest()
+        if os.environ.get("GMG_TEST_REFRESH"):
+            # numerical_setup! on EVERY level (GMGLinearSolvers.jl:260-297): all values doubled -- exact in binary floating point, so
+            # solving A' x = 2 b must reproduce x -- through gmg_update_values with this rank's whole local rows (own and ghost columns
+            # interleaved as they were handed over: a split stream routes them into the stream values and the boundary fix-up CSR)
+            import ctypes as C
+            from gridapsolvers_jl_amd import abi
+            for l, Ll in enumerate(g.local["levels"]):
+                v2 = np.ascontiguousarray(Ll.A.val * 2.0)
+                abi.check(g.h, g._lib.gmg_update_values(g.h, l, C.c_void_p(v2.ctypes.data)))
+            abi.check(g.h, g._lib.gmg_setup(g.h))
+            x2 = np.zeros(g.n_own)
+            log_r = g.cg_solve(2.0 * b, x2, maxiter, atol, rtol)
+            mine = (int(log_r.num_iters), float(np.max(np.abs(x2 - x)) / np.max(np.abs(x))), bool(np.array_equal(x2, x)))
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            verdict["refresh_iters"] = [a[0] for a in allr]
+            verdict["refresh_dev"] = max(a[1] for a in allr)
+            verdict["refresh_bitwise"] = all(a[2] for a in allr)
         nit, hist = log.num_iters, log.residuals[: log.num_iters + 1].copy()
         # also exercise device-pointer vectors + FGMRES
         xd = torch.zeros(g.n_own, dtype=torch.float64, device="cuda"); bd = torch.from_numpy(b).cuda(); torch.cuda.synchronize()

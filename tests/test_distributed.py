@@ -479,3 +479,22 @@ def test_partitioned_stokes_system_numpy_gloo(world, n, tmp_path):
     v = _launch("numpy_stokes", world, (n, n), 2, tmp_path)
     assert v["matvec_err"] < 1e-13 and v["assemble_err"] == 0.0, v
     assert v["ghosts"][0] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cells,nlev,rep,stream", [(2, (16, 16, 16), 4, 3, 97), (4, (32, 32), 4, 3, 97), (2, (16, 16, 16), 4, 3, 0)])
+def test_value_refresh_on_a_streamed_own_ghost_level(world, cells, nlev, rep, stream, tmp_path):
+    """numerical_setup! (gmg_update_values on every level + gmg_setup) on a partitioned hierarchy whose own | ghost finest level was
+    STREAMED (gmg_set_operator_rows: own x own part in the row-pattern stream, ghost columns in the boundary fix-up CSR): the caller's
+    whole-row value array is routed into both parts.  All values doubled and b doubled: the second solve reproduces the first --
+    same iteration count on every rank, x to rounding (bitwise in practice: scaling by 2 is exact).  Before round 5 the ghost-column
+    values kept their old numbers and the refreshed operator was silently wrong.  stream = 0: the same through whole CSR levels."""
+    env = {"GMG_PERSIST_SHARED": "1", "GMG_TEST_DEPTH": "2", "GMG_TEST_REFRESH": "1"}
+    if stream:
+        env["GMG_TEST_STREAM_ROWS"] = str(stream)
+    v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env=env)
+    _check(v)
+    if stream:
+        assert 0 in v["streamed_levels"]
+    assert v["refresh_iters"] == [v["iters"]] * world, v
+    assert v["refresh_dev"] <= 1e-13, v
