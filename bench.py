@@ -823,7 +823,9 @@ def config5_leg(torch, pkg, args, want_cpu):
     form, LU coarsest -- on synthesised inputs (gridapsolvers.jl_amd/stokes.py).  A step = one whole solve!(x, ns, b) from x = 0, b and x
     resident in HBM.  Checked in the same run: ||K x - b|| < 1e-7 (StokesGMG.jl:165) through scipy on the host; on an affordable size the
     oracle's iteration count / history / solution and its time (cpu_baseline, one thread: the oracle's patch solves are sequential)."""
-    S, st, po = pkg.solvers, pkg.stokes, pkg.poisson
+    import importlib
+    S, po = pkg.solvers, pkg.poisson
+    st = importlib.import_module(pkg.__name__ + ".stokes")
     alpha = 1.0e3
 
     def make(n, nlev):

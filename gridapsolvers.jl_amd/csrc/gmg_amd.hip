@@ -605,6 +605,9 @@ struct gmg_solver {
   uint32_t *h_perr = nullptr, *d_perr = nullptr;   // pinned + mapped: a bounded wait of the persistent kernel timed out
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
+  int pat_zwalk = 1;    // GMG_PAT_ZWALK: the pair sweep as a walk along the slowest grid direction (kernels.hpp: sells_zsweep_kernel); 1: levels of >= pat_zwalk_rows rows, 2: every level
+  int pat_zwalk_T = 16; // GMG_PAT_ZWALK_T: planes per chain
+  int64_t pat_zwalk_rows = 3500000;
   int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU, eight with pat_r2_occ)
   int pat_r2_occ = 2;   // GMG_PAT_R2_OCC: the 64-register form of the pair sweep (rolled run loop, eight waves per SIMD); 2: workgroups of eight waves at one slice per wave (big levels)
   int pat_r2mv_dot = 1; // GMG_PAT_R2MV_DOT: dot(p, A p) of CG formed by the mat-vec kernel (first stage; order of the sum differs from dot_partial_kernel's)
@@ -1994,6 +1997,35 @@ struct gmg_solver {
     HIP_CHECK(hipGetLastError());
     return true;
   }
+  const std::vector<int32_t> &host_run_off(const DevCSR &M)
+  {
+    std::vector<int32_t> &off = M.h_run_off;
+    if (off.empty()) {
+      off.resize((size_t)M.pat_nruns);
+      HIP_CHECK(hipMemcpyAsync(off.data(), M.prun, sizeof(int32_t) * (size_t)M.pat_nruns, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    return off;
+  }
+  // geometry of the z-walk (kernels.hpp: sells_zsweep_kernel): the nine runs must be a 3 x 3 grid of offsets whose rows differ by a
+  // constant plane offset P -- window q of the slice at r0 + P is window q + 3 of the slice at r0
+  bool zwalk_geo(const DevCSR &M, ZWalkGeo &g)
+  {
+    if (M.pat_nruns != 9 || M.pat_k != 3 || !M.ptab) return false;
+    const std::vector<int32_t> &off = host_run_off(M);
+    const int64_t P = (int64_t)off[3] - off[0];
+    if (P < 64 || P > (int64_t)(1 << 24)) return false;
+    for (int q = 0; q < 6; ++q) if ((int64_t)off[(size_t)q + 3] - off[(size_t)q] != P) return false;
+    g.P = (int)P;
+    g.m = (int)((P + 125) / 126);
+    g.T = pat_zwalk_T;
+    g.nplanes = (int)((M.nrows + P - 1) / P);
+    if (g.nplanes < 3) return false;
+    const int64_t nch = (int64_t)((g.nplanes + g.T - 1) / g.T) * g.m;
+    if (nch >= (int64_t)(1 << 30)) return false;
+    g.nchains = (int)nch;
+    return true;
+  }
   void launch_rsweep(const DevCSR &M, const double *r_cur, double *r_next, const double *r_prev, double *x, bool x_zero, double omega, int xmode)
   {
     SellSArgs a;
@@ -2012,6 +2044,25 @@ struct gmg_solver {
     const dim3 g2(wg2), b(64 * wpb);
     const size_t lds2 = (size_t)M.pat_np * nu * 16 + 16;
     const bool mk = pat_strict || !M.ptab8;
+    // the pair sweep as a walk along the slowest grid direction: three new windows per step instead of nine, one step of requests in flight
+    ZWalkGeo zg;
+    if (pat_r2 && pat_zwalk && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_rows) && zwalk_geo(M, zg)) {
+      const int wz = 4;
+      const dim3 gz((unsigned)((zg.nchains + wz - 1) / wz)), bz(64 * wz);
+      const size_t ldsz = (size_t)M.pat_np * nu * 8 + 16;
+      M.note_sweep("sells_zsweep_kernel<XM=*,MK=%d,FM=%d> chains=%d P=%d m=%d T=%d", mk ? 1 : 0, pat_fma ? 1 : 0, zg.nchains, zg.P, zg.m, zg.T);
+#define GMG_ZW_LAUNCH(XMV)                                                                                       \
+      do {                                                                                                       \
+        if (mk) { if (pat_fma) hipLaunchKernelGGL((sells_zsweep_kernel<XMV, true, true>), gz, bz, ldsz, stream, a, zg);     \
+                  else hipLaunchKernelGGL((sells_zsweep_kernel<XMV, true, false>), gz, bz, ldsz, stream, a, zg); }          \
+        else { if (pat_fma) hipLaunchKernelGGL((sells_zsweep_kernel<XMV, false, true>), gz, bz, ldsz, stream, a, zg);       \
+               else hipLaunchKernelGGL((sells_zsweep_kernel<XMV, false, false>), gz, bz, ldsz, stream, a, zg); }            \
+      } while (0)
+      if (xmode == 0) GMG_ZW_LAUNCH(0); else if (xmode == 1) GMG_ZW_LAUNCH(1); else GMG_ZW_LAUNCH(2);
+#undef GMG_ZW_LAUNCH
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     // two rows per lane (kernels.hpp: sells_r2sweep_kernel): slices of 126 rows, 16-byte loads / stores, half the conversions and shifts per row
     if (pat_r2 && (M.pat_nruns == 9 || M.pat_nruns == 3)) {
       const int nsl2 = (int)((M.nrows + 125) / 126);
@@ -3072,6 +3123,9 @@ struct gmg_solver {
     pat_r2 = opt_int("GMG_PAT_R2", 1);
     pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
     pat_r2_occ = opt_int("GMG_PAT_R2_OCC", 2);
+    pat_zwalk = opt_int("GMG_PAT_ZWALK", 1);
+    pat_zwalk_T = std::max(1, opt_int("GMG_PAT_ZWALK_T", 16));
+    pat_zwalk_rows = opt_int("GMG_PAT_ZWALK_ROWS", 3500000);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
     pat_pair_p = opt_int("GMG_PAT_PAIR_P", 1);
@@ -5321,7 +5375,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

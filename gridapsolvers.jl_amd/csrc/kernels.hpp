@@ -2024,6 +2024,168 @@ __global__ __launch_bounds__(OCC == 2 ? 2 * kBlock : kBlock, OCC == 2 ? 4 : (OCC
 }
 
 // ---------------------------------------------------------------------------
+// The pair sweep as a WALK along the slowest grid direction ("z-walk"; round 5).  The nine runs of a 27-point operator are a 3 x 3
+// grid of offsets, run q = 3 (dz + 1) + (dy + 1) at dz P + dy L - 1 (P = rows per grid plane, L = rows per grid line), so the window
+// of run q of the slice at row r0 + P IS the window of run q + 3 of the slice at r0.  A wave therefore keeps an interval of <= 126
+// rows of the plane and walks T planes upwards: per step it loads THREE new windows instead of nine and converts 6 instead of 18
+// loaded values (s = omega (d r)); the other six windows stay in registers, already converted.  The loads of step k + 1 (three
+// windows, the pair's own r / x / r_{k-1}, the pattern ids) are issued BEFORE the taps of step k: a wave always has one step of
+// memory requests in flight behind ~160 VALU instructions, which the per-slice kernels (three dependent load -> use phases per
+// slice, nothing in flight while a slice is multiplied) leave to the other waves of the SIMD.
+// A plane of P rows is cut into m = ceil(P / 126) intervals of floor / ceil (P / m) rows (the slices of the per-slice kernels are
+// cut from the flattened row range instead: their starts drift against the grid planes by P mod 126 per plane, so nothing lines up).
+// Chain c = (z-block c / m, interval c % m): neighbouring waves hold neighbouring intervals of the same planes and meet in L1 / L2.
+// Same taps in the same order on the same values, same strict-mask rule: bit-identical to sells_rsweep_kernel / sells_r2sweep_kernel.
+//   a.x = r_k (gathered) ; a.y = r_{k+1} ; a.s_out = r_{k-1} (XM = 2) ; a.pdinv[0] = d
+// ---------------------------------------------------------------------------
+struct ZWalkGeo {
+  int P;        // rows per plane: run_off[q + 3] - run_off[q]
+  int m;        // intervals per plane
+  int T;        // planes per chain
+  int nplanes;  // ceil(nrows / P)
+  int nchains;  // ceil(nplanes / T) * m
+};
+
+template <int XM, bool MK, bool FM>
+__global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZWalkGeo g)
+{
+  constexpr int K = 3, NR = 9, nu = K * NR;
+  extern __shared__ double sp_smem[];
+  const int tot = a.np * nu;
+  double *s_tab8 = sp_smem;                                   // [np*nu] coefficients, dense (the masks stay in global memory: rare path)
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int blk = remap_block(blockIdx.x, gridDim.x, a.xcd_remap);
+  const int chain = blk * wpb + wave;                         // wave-uniform
+  const double *__restrict__ rg = a.x;
+  const double omega = a.omega;
+  const double du = a.pdinv[0];
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  const bool xz = a.x_zero != 0;
+  int roff[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  const bool live = chain < g.nchains;
+  const int zb = live ? chain / g.m : 0, iv = live ? chain - zb * g.m : 0;
+  const int b0 = (int)(((int64_t)iv * g.P) / g.m), b1 = (int)(((int64_t)(iv + 1) * g.P) / g.m);
+  const int len = b1 - b0;                                    // <= 126
+  const int z0 = zb * g.T, z1 = min(g.nplanes, z0 + g.T);
+  int r0 = z0 * g.P + b0;                                     // first row of the step's slice (scalar)
+  // one window: the lane's two values at base + 2 lane, base + 2 lane + 1 (lane l + 1 holds the next two)
+  auto loadw = [&](int base) -> gmg_d2 {
+    if (base >= 0 && base + 2 * 63 + 1 <= last) return ld2_unaligned(rg + base + 2 * lane);       // wave-uniform
+    const int c = base + 2 * lane;
+    return gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
+  };
+  auto conv = [&](gmg_d2 v) -> gmg_d2 { return gmg_d2{omega * (du * v.x), omega * (du * v.y)}; };   // s = omega*(Dinv*r): once per loaded value
+  struct RowOps { int pidA, pidB; gmg_d2 e0, e2, rp; };
+  auto load_rows = [&](int rbase) -> RowOps {
+    RowOps o;
+    const int row = rbase + 2 * lane;
+    o.e2 = gmg_d2{0.0, 0.0}; o.rp = gmg_d2{0.0, 0.0};
+    if (rbase + 2 * 63 + 1 <= lastrow) {                      // wave-uniform
+      o.pidA = (int)a.rowpid[row]; o.pidB = (int)a.rowpid[row + 1];
+      o.e0 = ld2_unaligned(rg + row);
+      if (XM != 1) { const gmg_d2 xl = ld2_unaligned(a.x2 + row); o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
+      if (XM == 2) o.rp = ld2_unaligned(a.s_out + row);
+    } else {
+      const int ra = min(row, lastrow), rb = min(row + 1, lastrow);
+      o.pidA = (int)a.rowpid[ra]; o.pidB = (int)a.rowpid[rb];
+      o.e0 = gmg_d2{rg[ra], rg[rb]};
+      if (XM != 1) { const gmg_d2 xl = gmg_d2{a.x2[ra], a.x2[rb]}; o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
+      if (XM == 2) o.rp = gmg_d2{a.s_out[ra], a.s_out[rb]};
+    }
+    return o;
+  };
+  gmg_d2 C[NR];
+  RowOps cur;
+  if (live && z0 < z1) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q) C[q] = loadw(r0 + roff[q]);
+    cur = load_rows(r0);
+  }
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8 ? a.tab8[i] : a.tab[i].v;
+  __syncthreads();
+  if (!live || z0 >= z1) return;
+#pragma unroll
+  for (int q = 0; q < NR; ++q) C[q] = conv(C[q]);
+#pragma unroll 1
+  for (int z = z0; z < z1; ++z) {
+    const bool more = z + 1 < z1;
+    gmg_d2 N[3];
+    RowOps nxt;
+    if (more) {                                               // step z + 1: requested before the taps of step z
+#pragma unroll
+      for (int q = 0; q < 3; ++q) N[q] = loadw(r0 + g.P + roff[6 + q]);
+      nxt = load_rows(r0 + g.P);
+    }
+    const double *tvA = s_tab8 + cur.pidA * nu, *tvB = s_tab8 + cur.pidB * nu;
+    double sA = 0.0, sB = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      // the four window values of this lane's two rows: w0, w1 its own, w2, w3 = lane l+1's w0, w1
+      const double w0 = C[q].x, w1 = C[q].y;
+      const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+      const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        const double ca = tvA[q * K + t], cb = tvB[q * K + t];
+        sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
+        sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+      }
+    }
+    // strict form (see sells_r2sweep_kernel): "all sums of the slice finite" proves that no mask was needed; otherwise the slice is
+    // redone from memory with the masks (read from global memory: a vector that already holds Inf / NaN)
+    if (MK && !__all(__builtin_isfinite(sA) && __builtin_isfinite(sB))) {
+      sA = 0.0; sB = 0.0;
+      const int row = r0 + 2 * lane;
+#pragma unroll 1
+      for (int q = 0; q < NR; ++q) {
+        const int c = row + roff[q];
+        const double w0 = omega * (du * rg[min(max(c, 0), last)]), w1 = omega * (du * rg[min(max(c + 1, 0), last)]);
+        const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+        const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const int j = q * K + t;
+          const int ma = (int)a.tab[cur.pidA * nu + j].m, mb = (int)a.tab[cur.pidB * nu + j].m;
+          const double ga = __hiloint2double(__double2hiint(wa[t]) & ma, __double2loint(wa[t]));
+          const double gb = __hiloint2double(__double2hiint(wb[t]) & mb, __double2loint(wb[t]));
+          sA = FM ? __builtin_fma(tvA[j], ga, sA) : sA + tvA[j] * ga;
+          sB = FM ? __builtin_fma(tvB[j], gb, sB) : sB + tvB[j] * gb;
+        }
+      }
+    }
+    // results of the pair
+    const gmg_d2 rn = gmg_d2{cur.e0.x - sA, cur.e0.y - sB};
+    const gmg_d2 sk = gmg_d2{omega * (du * cur.e0.x), omega * (du * cur.e0.y)};     // the rows' own s_k
+    gmg_d2 xn = gmg_d2{0.0, 0.0};
+    if (XM == 0) xn = gmg_d2{cur.e2.x + sk.x, cur.e2.y + sk.y};
+    else if (XM == 2) xn = gmg_d2{(cur.e2.x + omega * (du * cur.rp.x)) + sk.x, (cur.e2.y + omega * (du * cur.rp.y)) + sk.y};
+    {
+      const int row = r0 + 2 * lane;
+      const int nmine = min(len - 2 * lane, lastrow + 1 - row);          // rows of this lane inside the interval and the level: <= 0, 1, >= 2
+      if (nmine >= 2) {
+        if (XM != 1) st2_unaligned(a.x2 + row, xn);
+        st2_unaligned(a.y + row, rn);
+      } else if (nmine == 1) {
+        if (XM != 1) a.x2[row] = xn.x;
+        a.y[row] = rn.x;
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) C[q] = C[q + 3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) C[6 + q] = conv(N[q]);
+      cur = nxt;
+      r0 += g.P;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The operator mat-vecs of a row-pattern level with two rows per lane: y = A x (EPI_SET: CGSolvers.jl:104), y -= A x (EPI_SUB:
 // GMGLinearSolvers.jl:495), y = b - A x (EPI_RESID: CGSolvers.jl:79).  The layout, the windows and the strict-mask rule of
 // sells_r2sweep_kernel without the omega*(d*.) of a sweep: the gathered value IS the window value.  Same taps in the same order as

@@ -39,14 +39,26 @@ BIG_LEVEL_CASES = [((40, 40, 40), 3, 10), ((34, 46, 30), 2, 3), ((26, 22, 58), 2
 
 
 # ---------------------------------------------------------------- big-level sweep (OCC = 2) against the single-row sweep and the oracle
+BIG_FORMS = {"occ2": ({"pat_tile_rows": 0, "pat_zwalk": 0, "persist": 0}, ("sells_r2sweep_kernel", "OCC=2", "wpb=8")),
+             "zwalk": ({"pat_zwalk": 2, "persist": 0}, ("sells_zsweep_kernel", "T=16")),
+             "zwalk_T3": ({"pat_zwalk": 2, "pat_zwalk_T": 3, "persist": 0}, ("sells_zsweep_kernel", "T=3")),
+             "zwalk_T1": ({"pat_zwalk": 2, "pat_zwalk_T": 1, "persist": 0}, ("sells_zsweep_kernel", "T=1"))}
+
+
+@pytest.mark.parametrize("form", list(BIG_FORMS))
 @pytest.mark.parametrize("nc,nlev,niter", BIG_LEVEL_CASES)
-def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(S, po, orc, nc, nlev, niter):
+def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(S, po, orc, nc, nlev, niter, form):
     """sells_r2sweep_kernel<XM, MK, FM, 9, OCC=2> -- the form every Q1 level of >= pat_tile_rows (3.5e6) rows takes: 288^3, 256^3,
     the finest level of BASELINE configs[3] -- forced onto small levels with pat_tile_rows = 0 and compared (i) bit for bit with
     sells_rsweep_kernel (pat_r2 = 0, one row per lane, masks in LDS) and (ii) with the oracle's literal
     RichardsonSmoothers.jl:84-98 loop to 1e-13: passes from a given x and from x = 0, odd and even sweep counts (both xmode
     variants, the deferred x update), chained passes, +-Inf and NaN in r (the slice's vote fails and the redo path reads the
-    masks from GLOBAL memory -- the `GM` branch that no small level reaches by default), and a whole CG solve."""
+    masks from GLOBAL memory -- the `GM` branch that no small level reaches by default), and a whole CG solve.
+    form = zwalk*: the same for sells_zsweep_kernel (round 5: the pair sweep as a walk along the slowest grid direction -- an interval
+    of <= 126 rows of a grid plane per wave, three new windows per step, six carried in registers; default on levels of >=
+    pat_zwalk_rows = 3.5e6 rows), forced onto the small levels with pat_zwalk = 2, with chains of 16, 3 and 1 planes (chain starts
+    and ends in the middle of the level, planes whose row count is not a multiple of the interval, the clamped first / last planes)."""
+    big_opts, big_sig = BIG_FORMS[form]
     H = po.build_hierarchy(nc, nlev, 1)
     n = H["mats"][0].shape[0]
     b = po.dirichlet_lift_rhs(nc, 1)
@@ -58,7 +70,7 @@ def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(
     ri0[(2 * n) // 3] = np.nan
     ri0[n - 2] = np.inf                                   # inside the ragged last slice
     res = {}
-    for key, opts in (("big", {"pat_tile_rows": 0, "persist": 0}), ("single", {"pat_r2": 0, "persist": 0})):
+    for key, opts in (("big", big_opts), ("single", {"pat_r2": 0, "persist": 0})):
         solver = S.CGSolver(make_gmg(S, H, pre_smoothers=jac(S, nlev, niter), options=opts), maxiter=40, atol=1e-14, rtol=1e-8)
         ns = setup(S, solver, H["mats"][0])
         out = []
@@ -79,7 +91,7 @@ def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(
         out += [xs, solver.log.residuals[: solver.log.num_iters + 1].copy()]
         sig = ns.P_ns.sweep_signature(0)
         if key == "big":
-            assert "sells_r2sweep_kernel" in sig and "OCC=2" in sig and "wpb=8" in sig, sig
+            assert all(t in sig for t in big_sig), sig
         else:
             assert "sells_rsweep_kernel" in sig, sig
         res[key] = out
