@@ -606,7 +606,7 @@ struct gmg_solver {
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
   int pat_zwalk = 1;    // GMG_PAT_ZWALK: the pair sweep as a walk along the slowest grid direction (kernels.hpp: sells_zsweep_kernel); 1: levels of >= pat_zwalk_rows rows, 2: every level
-  int pat_zwalk_T = 16; // GMG_PAT_ZWALK_T: planes per chain
+  int pat_zwalk_T = 12; // GMG_PAT_ZWALK_T: planes per chain (288^3: 8 / 12 / 16 / 24 / 32 -> 149 / 114 / 120 / 118 / 155 us for the x-untouched form)
   int64_t pat_zwalk_rows = 3500000;
   int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU, eight with pat_r2_occ)
   int pat_r2_occ = 2;   // GMG_PAT_R2_OCC: the 64-register form of the pair sweep (rolled run loop, eight waves per SIMD); 2: workgroups of eight waves at one slice per wave (big levels)
@@ -2049,7 +2049,7 @@ struct gmg_solver {
     if (pat_r2 && pat_zwalk && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_rows) && zwalk_geo(M, zg)) {
       const int wz = 4;
       const dim3 gz((unsigned)((zg.nchains + wz - 1) / wz)), bz(64 * wz);
-      const size_t ldsz = (size_t)M.pat_np * nu * 8 + 16;
+      const size_t ldsz = (size_t)M.pat_np * 28 * 8 + 16;       // patterns padded to 28 doubles (16-byte aligned coefficient pairs)
       M.note_sweep("sells_zsweep_kernel<XM=*,MK=%d,FM=%d> chains=%d P=%d m=%d T=%d", mk ? 1 : 0, pat_fma ? 1 : 0, zg.nchains, zg.P, zg.m, zg.T);
 #define GMG_ZW_LAUNCH(XMV)                                                                                       \
       do {                                                                                                       \
@@ -3124,7 +3124,7 @@ struct gmg_solver {
     pat_r2_wgs = opt_int("GMG_PAT_R2_WGS", 0);
     pat_r2_occ = opt_int("GMG_PAT_R2_OCC", 2);
     pat_zwalk = opt_int("GMG_PAT_ZWALK", 1);
-    pat_zwalk_T = std::max(1, opt_int("GMG_PAT_ZWALK_T", 16));
+    pat_zwalk_T = std::max(1, opt_int("GMG_PAT_ZWALK_T", 12));
     pat_zwalk_rows = opt_int("GMG_PAT_ZWALK_ROWS", 3500000);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);

@@ -2038,6 +2038,18 @@ __global__ __launch_bounds__(OCC == 2 ? 2 * kBlock : kBlock, OCC == 2 ? 4 : (OCC
 // Same taps in the same order on the same values, same strict-mask rule: bit-identical to sells_rsweep_kernel / sells_r2sweep_kernel.
 //   a.x = r_k (gathered) ; a.y = r_{k+1} ; a.s_out = r_{k-1} (XM = 2) ; a.pdinv[0] = d
 // ---------------------------------------------------------------------------
+// build-time switches of the z-walk (defaults = the product; profiles/r05_tuning.md has the A/B runs): NT bit 0 = results stored
+// non-temporally, bit 1 = x / r_{k-1} loaded non-temporally (each is touched once per sweep); PF = steps the requests run ahead of the
+// taps; PD = runs the coefficient reads run ahead of the taps
+#ifndef GMG_ZW_NT
+#define GMG_ZW_NT 3
+#endif
+#ifndef GMG_ZW_PF
+#define GMG_ZW_PF 1
+#endif
+#ifndef GMG_ZW_PD
+#define GMG_ZW_PD 1
+#endif
 struct ZWalkGeo {
   int P;        // rows per plane: run_off[q + 3] - run_off[q]
   int m;        // intervals per plane
@@ -2049,10 +2061,10 @@ struct ZWalkGeo {
 template <int XM, bool MK, bool FM>
 __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZWalkGeo g)
 {
-  constexpr int K = 3, NR = 9, nu = K * NR;
+  constexpr int K = 3, NR = 9, nu = K * NR, NUP = 28;       // NUP: LDS stride of a pattern (doubles) -- even, so that pairs of coefficients are 16-byte aligned
   extern __shared__ double sp_smem[];
-  const int tot = a.np * nu;
-  double *s_tab8 = sp_smem;                                   // [np*nu] coefficients, dense (the masks stay in global memory: rare path)
+  const int tot = a.np * NUP;
+  double *s_tab8 = sp_smem;                                   // [np*NUP] coefficients, dense (the masks stay in global memory: rare path)
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int blk = remap_block(blockIdx.x, gridDim.x, a.xcd_remap);
@@ -2072,117 +2084,180 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
   const int len = b1 - b0;                                    // <= 126
   const int z0 = zb * g.T, z1 = min(g.nplanes, z0 + g.T);
   int r0 = z0 * g.P + b0;                                     // first row of the step's slice (scalar)
-  // one window: the lane's two values at base + 2 lane, base + 2 lane + 1 (lane l + 1 holds the next two)
-  auto loadw = [&](int base) -> gmg_d2 {
-    if (base >= 0 && base + 2 * 63 + 1 <= last) return ld2_unaligned(rg + base + 2 * lane);       // wave-uniform
-    const int c = base + 2 * lane;
-    return gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
-  };
   auto conv = [&](gmg_d2 v) -> gmg_d2 { return gmg_d2{omega * (du * v.x), omega * (du * v.y)}; };   // s = omega*(Dinv*r): once per loaded value
   struct RowOps { int pidA, pidB; gmg_d2 e0, e2, rp; };
-  auto load_rows = [&](int rbase) -> RowOps {
-    RowOps o;
-    const int row = rbase + 2 * lane;
-    o.e2 = gmg_d2{0.0, 0.0}; o.rp = gmg_d2{0.0, 0.0};
-    if (rbase + 2 * 63 + 1 <= lastrow) {                      // wave-uniform
-      o.pidA = (int)a.rowpid[row]; o.pidB = (int)a.rowpid[row + 1];
-      o.e0 = ld2_unaligned(rg + row);
-      if (XM != 1) { const gmg_d2 xl = ld2_unaligned(a.x2 + row); o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
-      if (XM == 2) o.rp = ld2_unaligned(a.s_out + row);
-    } else {
-      const int ra = min(row, lastrow), rb = min(row + 1, lastrow);
-      o.pidA = (int)a.rowpid[ra]; o.pidB = (int)a.rowpid[rb];
-      o.e0 = gmg_d2{rg[ra], rg[rb]};
-      if (XM != 1) { const gmg_d2 xl = gmg_d2{a.x2[ra], a.x2[rb]}; o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
-      if (XM == 2) o.rp = gmg_d2{a.s_out[ra], a.s_out[rb]};
-    }
-    return o;
-  };
-  gmg_d2 C[NR];
-  RowOps cur;
-  if (live && z0 < z1) {
+  const int nsteps = z1 - z0;
+  // A chain is "inner" when every window of every step and the pair loads of all 64 lanes stay inside the vectors: no clamp anywhere.
+  // The two forms of the loop differ ONLY in how a value is addressed; each issues a fixed number of memory instructions per step
+  // on a single control path -- with a branch around the requests the wait-count pass must assume the path without them and parks
+  // the wave (vmcnt(0)) on the requests of step k + 1 before the taps of step k: nothing overlaps (measured: 68 % of the wave
+  // cycles in s_waitcnt).  The last step re-requests its own operands instead of branching around the prefetch.
+  const bool inner_chain = live && nsteps > 0 && r0 + roff[0] >= 0 && r0 + (nsteps - 1) * g.P + roff[NR - 1] + 2 * 63 + 1 <= last &&
+                           r0 + (nsteps - 1) * g.P + 2 * 63 + 1 <= lastrow;
+  auto run_chain = [&](auto in_tag) {
+    constexpr bool IN = decltype(in_tag)::value;
+    // one window: the lane's two values at base + 2 lane, base + 2 lane + 1 (lane l + 1 holds the next two)
+    auto loadw = [&](int base) -> gmg_d2 {
+      if (IN) return ld2_unaligned(rg + base + 2 * lane);
+      const int c = base + 2 * lane;
+      return gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
+    };
+    auto load_rows = [&](int rbase) -> RowOps {
+      RowOps o;
+      const int row = rbase + 2 * lane;
+      o.e2 = gmg_d2{0.0, 0.0}; o.rp = gmg_d2{0.0, 0.0};
+      if (IN) {
+        o.pidA = (int)a.rowpid[row]; o.pidB = (int)a.rowpid[row + 1];
+        o.e0 = ld2_unaligned(rg + row);
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        if (GMG_ZW_NT & 2) {
+          if (XM != 1) { const gmg_d2 xl = __builtin_nontemporal_load(reinterpret_cast<const d2u *>(a.x2 + row)); o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
+          if (XM == 2) o.rp = __builtin_nontemporal_load(reinterpret_cast<const d2u *>(a.s_out + row));
+        } else {
+        if (XM != 1) { const gmg_d2 xl = ld2_unaligned(a.x2 + row); o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
+        if (XM == 2) o.rp = ld2_unaligned(a.s_out + row);
+        }
+      } else {
+        const int ra = min(row, lastrow), rb = min(row + 1, lastrow);
+        o.pidA = (int)a.rowpid[ra]; o.pidB = (int)a.rowpid[rb];
+        o.e0 = gmg_d2{rg[ra], rg[rb]};
+        if (XM != 1) { const gmg_d2 xl = gmg_d2{a.x2[ra], a.x2[rb]}; o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
+        if (XM == 2) o.rp = gmg_d2{a.s_out[ra], a.s_out[rb]};
+      }
+      return o;
+    };
+    gmg_d2 C[NR];
+    RowOps cur;
 #pragma unroll
     for (int q = 0; q < NR; ++q) C[q] = loadw(r0 + roff[q]);
     cur = load_rows(r0);
-  }
-  for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8 ? a.tab8[i] : a.tab[i].v;
-  __syncthreads();
-  if (!live || z0 >= z1) return;
+    // requests run PF steps ahead of the taps (GMG_ZW_PF; 1: the operands of step k + 1 are requested before the taps of step k)
+    constexpr int PF = XM == 1 ? GMG_ZW_PF : 1;
+    const int rfirst = r0;
+    gmg_d2 N[PF][3];
+    RowOps nx[PF];
 #pragma unroll
-  for (int q = 0; q < NR; ++q) C[q] = conv(C[q]);
-#pragma unroll 1
-  for (int z = z0; z < z1; ++z) {
-    const bool more = z + 1 < z1;
-    gmg_d2 N[3];
-    RowOps nxt;
-    if (more) {                                               // step z + 1: requested before the taps of step z
+    for (int d = 1; d < PF; ++d) {
+      const int rb = rfirst + min(d, nsteps - 1) * g.P;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) N[q] = loadw(r0 + g.P + roff[6 + q]);
-      nxt = load_rows(r0 + g.P);
+      for (int q = 0; q < 3; ++q) N[d - 1][q] = loadw(rb + roff[6 + q]);
+      nx[d - 1] = load_rows(rb);
     }
-    const double *tvA = s_tab8 + cur.pidA * nu, *tvB = s_tab8 + cur.pidB * nu;
-    double sA = 0.0, sB = 0.0;
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
-      // the four window values of this lane's two rows: w0, w1 its own, w2, w3 = lane l+1's w0, w1
-      const double w0 = C[q].x, w1 = C[q].y;
-      const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
-      const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
-#pragma unroll
-      for (int t = 0; t < K; ++t) {
-        const double ca = tvA[q * K + t], cb = tvB[q * K + t];
-        sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
-        sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+    for (int q = 0; q < NR; ++q) C[q] = conv(C[q]);
+    // results of a step are stored at the top of the NEXT step, in front of that step's requests: the wait for the requests at the
+    // end of a step (in-order counter) then never includes a store that was issued a few cycles earlier
+    gmg_d2 prn = gmg_d2{0.0, 0.0}, pxn = gmg_d2{0.0, 0.0};
+    int prow = 0, pnm = 0;
+    auto put = [&]() {
+      if (pnm >= 2) {
+        typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+        if (GMG_ZW_NT & 1) {
+          if (XM != 1) __builtin_nontemporal_store(pxn, reinterpret_cast<d2u *>(a.x2 + prow));
+          __builtin_nontemporal_store(prn, reinterpret_cast<d2u *>(a.y + prow));
+        } else {
+        if (XM != 1) st2_unaligned(a.x2 + prow, pxn);
+        st2_unaligned(a.y + prow, prn);
+        }
+      } else if (pnm == 1) {
+        if (XM != 1) a.x2[prow] = pxn.x;
+        a.y[prow] = prn.x;
       }
-    }
-    // strict form (see sells_r2sweep_kernel): "all sums of the slice finite" proves that no mask was needed; otherwise the slice is
-    // redone from memory with the masks (read from global memory: a vector that already holds Inf / NaN)
-    if (MK && !__all(__builtin_isfinite(sA) && __builtin_isfinite(sB))) {
-      sA = 0.0; sB = 0.0;
-      const int row = r0 + 2 * lane;
+    };
 #pragma unroll 1
+    for (int z = z0; z < z1; ++z) {
+      put();
+      // step z + PF (past the end of the chain: the last step again, unused): requested before the taps of step z
+      {
+        const int rb = rfirst + min(z - z0 + PF, nsteps - 1) * g.P;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) N[PF - 1][q] = loadw(rb + roff[6 + q]);
+        nx[PF - 1] = load_rows(rb);
+      }
+      const double *tvA = s_tab8 + cur.pidA * NUP, *tvB = s_tab8 + cur.pidB * NUP;
+      double sA = 0.0, sB = 0.0;
+      // the coefficients of run q + PD are requested before the taps of run q (the scheduler, left alone, issues every LDS read right
+      // in front of its first use and the wave waits out the LDS latency 14 times per step)
+      constexpr int PD = GMG_ZW_PD;
+      double ca[NR][K], cb[NR][K];
+      // the three coefficients of run q: one 16-byte read (the pair at an even index) + one 8-byte read
+      auto coef3 = [&](const double *tv, int q, double *out) {
+        typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
+        if ((q & 1) == 0) { const d2a pr = *reinterpret_cast<const d2a *>(tv + q * K); out[0] = pr.x; out[1] = pr.y; out[2] = tv[q * K + 2]; }
+        else { const d2a pr = *reinterpret_cast<const d2a *>(tv + q * K + 1); out[0] = tv[q * K]; out[1] = pr.x; out[2] = pr.y; }
+      };
+#pragma unroll
+      for (int q = 0; q < PD; ++q) { coef3(tvA, q, ca[q]); coef3(tvB, q, cb[q]); }
+#pragma unroll
       for (int q = 0; q < NR; ++q) {
-        const int c = row + roff[q];
-        const double w0 = omega * (du * rg[min(max(c, 0), last)]), w1 = omega * (du * rg[min(max(c + 1, 0), last)]);
+        if (q + PD < NR) { coef3(tvA, q + PD, ca[q + PD]); coef3(tvB, q + PD, cb[q + PD]); }
+        __builtin_amdgcn_sched_barrier(0);
+        // the four window values of this lane's two rows: w0, w1 its own, w2, w3 = lane l+1's w0, w1
+        const double w0 = C[q].x, w1 = C[q].y;
         const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
         const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
 #pragma unroll
         for (int t = 0; t < K; ++t) {
-          const int j = q * K + t;
-          const int ma = (int)a.tab[cur.pidA * nu + j].m, mb = (int)a.tab[cur.pidB * nu + j].m;
-          const double ga = __hiloint2double(__double2hiint(wa[t]) & ma, __double2loint(wa[t]));
-          const double gb = __hiloint2double(__double2hiint(wb[t]) & mb, __double2loint(wb[t]));
-          sA = FM ? __builtin_fma(tvA[j], ga, sA) : sA + tvA[j] * ga;
-          sB = FM ? __builtin_fma(tvB[j], gb, sB) : sB + tvB[j] * gb;
+          sA = FM ? __builtin_fma(ca[q][t], wa[t], sA) : sA + ca[q][t] * wa[t];
+          sB = FM ? __builtin_fma(cb[q][t], wb[t], sB) : sB + cb[q][t] * wb[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // strict form (see sells_r2sweep_kernel): "all sums of the slice finite" proves that no mask was needed; otherwise the slice is
+      // redone from memory with the masks (read from global memory: a vector that already holds Inf / NaN)
+      if (MK && !__all(__builtin_isfinite(sA) && __builtin_isfinite(sB))) {
+        sA = 0.0; sB = 0.0;
+        const int row = r0 + 2 * lane;
+#pragma unroll 1
+        for (int q = 0; q < NR; ++q) {
+          const int c = row + roff[q];
+          const double w0 = omega * (du * rg[min(max(c, 0), last)]), w1 = omega * (du * rg[min(max(c + 1, 0), last)]);
+          const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+          const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            const int j = q * K + t;
+            const int ma = (int)a.tab[cur.pidA * nu + j].m, mb = (int)a.tab[cur.pidB * nu + j].m;
+            const double ga = __hiloint2double(__double2hiint(wa[t]) & ma, __double2loint(wa[t]));
+            const double gb = __hiloint2double(__double2hiint(wb[t]) & mb, __double2loint(wb[t]));
+            sA = FM ? __builtin_fma(tvA[j], ga, sA) : sA + tvA[j] * ga;
+            sB = FM ? __builtin_fma(tvB[j], gb, sB) : sB + tvB[j] * gb;
+          }
         }
       }
-    }
-    // results of the pair
-    const gmg_d2 rn = gmg_d2{cur.e0.x - sA, cur.e0.y - sB};
-    const gmg_d2 sk = gmg_d2{omega * (du * cur.e0.x), omega * (du * cur.e0.y)};     // the rows' own s_k
-    gmg_d2 xn = gmg_d2{0.0, 0.0};
-    if (XM == 0) xn = gmg_d2{cur.e2.x + sk.x, cur.e2.y + sk.y};
-    else if (XM == 2) xn = gmg_d2{(cur.e2.x + omega * (du * cur.rp.x)) + sk.x, (cur.e2.y + omega * (du * cur.rp.y)) + sk.y};
-    {
-      const int row = r0 + 2 * lane;
-      const int nmine = min(len - 2 * lane, lastrow + 1 - row);          // rows of this lane inside the interval and the level: <= 0, 1, >= 2
-      if (nmine >= 2) {
-        if (XM != 1) st2_unaligned(a.x2 + row, xn);
-        st2_unaligned(a.y + row, rn);
-      } else if (nmine == 1) {
-        if (XM != 1) a.x2[row] = xn.x;
-        a.y[row] = rn.x;
-      }
-    }
-    if (more) {
+      // results of the pair
+      const gmg_d2 rn = gmg_d2{cur.e0.x - sA, cur.e0.y - sB};
+      const gmg_d2 sk = gmg_d2{omega * (du * cur.e0.x), omega * (du * cur.e0.y)};     // the rows' own s_k
+      gmg_d2 xn = gmg_d2{0.0, 0.0};
+      if (XM == 0) xn = gmg_d2{cur.e2.x + sk.x, cur.e2.y + sk.y};
+      else if (XM == 2) xn = gmg_d2{(cur.e2.x + omega * (du * cur.rp.x)) + sk.x, (cur.e2.y + omega * (du * cur.rp.y)) + sk.y};
+      prow = r0 + 2 * lane;
+      pnm = min(len - 2 * lane, lastrow + 1 - prow);                       // rows of this lane inside the interval and the level: <= 0, 1, >= 2
+      prn = rn; pxn = xn;
 #pragma unroll
       for (int q = 0; q < 6; ++q) C[q] = C[q + 3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) C[6 + q] = conv(N[q]);
-      cur = nxt;
+      for (int q = 0; q < 3; ++q) C[6 + q] = conv(N[0][q]);
+      cur = nx[0];
+#pragma unroll
+      for (int d = 0; d + 1 < PF; ++d) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) N[d][q] = N[d + 1][q];
+        nx[d] = nx[d + 1];
+      }
       r0 += g.P;
     }
+    put();
+  };
+  // the coefficient table: staged by the whole workgroup (also by the waves of the last workgroup that have no chain)
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+    const int pq = i / NUP, j = i - pq * NUP;
+    s_tab8[i] = j < nu ? (a.tab8 ? a.tab8[pq * nu + j] : a.tab[pq * nu + j].v) : 0.0;
   }
+  __syncthreads();
+  if (!live || nsteps <= 0) return;
+  if (inner_chain) run_chain(std::integral_constant<bool, true>{});
+  else run_chain(std::integral_constant<bool, false>{});
 }
 
 // ---------------------------------------------------------------------------
