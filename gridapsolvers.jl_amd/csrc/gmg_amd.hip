@@ -606,6 +606,7 @@ struct gmg_solver {
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
   int pat_zwalk = 1;    // GMG_PAT_ZWALK: the pair sweep as a walk along the slowest grid direction (kernels.hpp: sells_zsweep_kernel); 1: levels of >= pat_zwalk_rows rows, 2: every level
+  int pat_zwalk_mv = 1; // GMG_PAT_ZWALK_MV: also the operator mat-vecs of those levels
   int pat_zwalk_T = 12; // GMG_PAT_ZWALK_T: planes per chain (288^3: 8 / 12 / 16 / 24 / 32 -> 149 / 114 / 120 / 118 / 155 us for the x-untouched form)
   int64_t pat_zwalk_rows = 3500000;
   int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU, eight with pat_r2_occ)
@@ -1417,6 +1418,18 @@ struct gmg_solver {
         // (as the sweeps of these levels: launch_rsweep)
         bool dot_here = false;
         if constexpr (EPI == EPI_SET) dot_here = r2mv_dot_parts != nullptr;
+        // the same levels in the z-walk form (kernels.hpp: sells_zsweep_kernel<..., EPI>): three new windows per step, requests a step ahead
+        ZWalkGeo zg;
+        if (pat_zwalk && pat_zwalk_mv && !dot_here && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_rows) && zwalk_geo(M, zg)) {
+          const dim3 gz((unsigned)((zg.nchains + 3) / 4)), bz(256);
+          const size_t ldsz = (size_t)M.pat_np * 28 * 8 + 16;
+          if (mk) { if (pat_fma) hipLaunchKernelGGL((sells_zsweep_kernel<1, true, true, EPI>), gz, bz, ldsz, stream, a, zg);
+                    else hipLaunchKernelGGL((sells_zsweep_kernel<1, true, false, EPI>), gz, bz, ldsz, stream, a, zg); }
+          else { if (pat_fma) hipLaunchKernelGGL((sells_zsweep_kernel<1, false, true, EPI>), gz, bz, ldsz, stream, a, zg);
+                 else hipLaunchKernelGGL((sells_zsweep_kernel<1, false, false, EPI>), gz, bz, ldsz, stream, a, zg); }
+          HIP_CHECK(hipGetLastError());
+          return;
+        }
         if (pat_r2_occ >= 2 && M.nrows >= pat_tile_rows && M.pat_nruns == 9 && pat_r2_wgs <= 0 && !dot_here) {
           const dim3 g8((nsl2 + 7) / 8), b8(512);
           if (mk) { if (pat_fma) hipLaunchKernelGGL((sells_r2mv_kernel<EPI, true, true, 9, false, 2>), g8, b8, lds2, stream, a);
@@ -3125,6 +3138,7 @@ struct gmg_solver {
     pat_r2_occ = opt_int("GMG_PAT_R2_OCC", 2);
     pat_zwalk = opt_int("GMG_PAT_ZWALK", 1);
     pat_zwalk_T = std::max(1, opt_int("GMG_PAT_ZWALK_T", 12));
+    pat_zwalk_mv = opt_int("GMG_PAT_ZWALK_MV", 1);
     pat_zwalk_rows = opt_int("GMG_PAT_ZWALK_ROWS", 3500000);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
@@ -5375,7 +5389,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

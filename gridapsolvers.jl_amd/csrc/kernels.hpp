@@ -2058,9 +2058,14 @@ struct ZWalkGeo {
   int nchains;  // ceil(nplanes / T) * m
 };
 
-template <int XM, bool MK, bool FM>
+// EPI = EPI_SWEEP: the sweep (XM = its x mode).  EPI_SET / EPI_SUB / EPI_RESID: the operator mat-vecs of the same levels in the same
+// walk -- y = A x (CGSolvers.jl:104), y -= A x (GMGLinearSolvers.jl:495), y = b - A x (CGSolvers.jl:79): the gathered value IS the
+// window value, a.x gathered, a.y result (SUB: also read), a.b (RESID); same taps in the same order as sells_kernel / sells_r2mv_kernel.
+template <int XM, bool MK, bool FM, int EPI = EPI_SWEEP>
 __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZWalkGeo g)
 {
+  constexpr bool SW = EPI == EPI_SWEEP;
+  static_assert(SW || (XM == 1 && (EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID)), "mat-vec epilogues: instantiate with XM = 1");
   constexpr int K = 3, NR = 9, nu = K * NR, NUP = 28;       // NUP: LDS stride of a pattern (doubles) -- even, so that pairs of coefficients are 16-byte aligned
   extern __shared__ double sp_smem[];
   const int tot = a.np * NUP;
@@ -2071,7 +2076,8 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
   const int chain = blk * wpb + wave;                         // wave-uniform
   const double *__restrict__ rg = a.x;
   const double omega = a.omega;
-  const double du = a.pdinv[0];
+  const double du = SW ? a.pdinv[0] : 1.0;
+  const double *__restrict__ eg = SW ? a.x : (EPI == EPI_RESID ? a.b : a.y);   // the rows' own operand (SET: none)
   const int last = (int)a.ncols - 1;
   const int lastrow = (int)a.nrows - 1;
   const bool xz = a.x_zero != 0;
@@ -2084,7 +2090,7 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
   const int len = b1 - b0;                                    // <= 126
   const int z0 = zb * g.T, z1 = min(g.nplanes, z0 + g.T);
   int r0 = z0 * g.P + b0;                                     // first row of the step's slice (scalar)
-  auto conv = [&](gmg_d2 v) -> gmg_d2 { return gmg_d2{omega * (du * v.x), omega * (du * v.y)}; };   // s = omega*(Dinv*r): once per loaded value
+  auto conv = [&](gmg_d2 v) -> gmg_d2 { return SW ? gmg_d2{omega * (du * v.x), omega * (du * v.y)} : v; };   // sweep: s = omega*(Dinv*r), once per loaded value
   struct RowOps { int pidA, pidB; gmg_d2 e0, e2, rp; };
   const int nsteps = z1 - z0;
   // A chain is "inner" when every window of every step and the pair loads of all 64 lanes stay inside the vectors: no clamp anywhere.
@@ -2108,7 +2114,8 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
       o.e2 = gmg_d2{0.0, 0.0}; o.rp = gmg_d2{0.0, 0.0};
       if (IN) {
         o.pidA = (int)a.rowpid[row]; o.pidB = (int)a.rowpid[row + 1];
-        o.e0 = ld2_unaligned(rg + row);
+        o.e0 = gmg_d2{0.0, 0.0};
+        if (EPI != EPI_SET) o.e0 = ld2_unaligned(eg + row);
         typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
         if (GMG_ZW_NT & 2) {
           if (XM != 1) { const gmg_d2 xl = __builtin_nontemporal_load(reinterpret_cast<const d2u *>(a.x2 + row)); o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
@@ -2120,7 +2127,8 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
       } else {
         const int ra = min(row, lastrow), rb = min(row + 1, lastrow);
         o.pidA = (int)a.rowpid[ra]; o.pidB = (int)a.rowpid[rb];
-        o.e0 = gmg_d2{rg[ra], rg[rb]};
+        o.e0 = gmg_d2{0.0, 0.0};
+        if (EPI != EPI_SET) o.e0 = gmg_d2{eg[ra], eg[rb]};
         if (XM != 1) { const gmg_d2 xl = gmg_d2{a.x2[ra], a.x2[rb]}; o.e2 = xz ? gmg_d2{0.0, 0.0} : xl; }
         if (XM == 2) o.rp = gmg_d2{a.s_out[ra], a.s_out[rb]};
       }
@@ -2211,7 +2219,8 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
 #pragma unroll 1
         for (int q = 0; q < NR; ++q) {
           const int c = row + roff[q];
-          const double w0 = omega * (du * rg[min(max(c, 0), last)]), w1 = omega * (du * rg[min(max(c + 1, 0), last)]);
+          const double g0 = rg[min(max(c, 0), last)], g1 = rg[min(max(c + 1, 0), last)];
+          const double w0 = SW ? omega * (du * g0) : g0, w1 = SW ? omega * (du * g1) : g1;
           const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
           const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
 #pragma unroll
@@ -2226,7 +2235,7 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
         }
       }
       // results of the pair
-      const gmg_d2 rn = gmg_d2{cur.e0.x - sA, cur.e0.y - sB};
+      const gmg_d2 rn = EPI == EPI_SET ? gmg_d2{sA, sB} : gmg_d2{cur.e0.x - sA, cur.e0.y - sB};
       const gmg_d2 sk = gmg_d2{omega * (du * cur.e0.x), omega * (du * cur.e0.y)};     // the rows' own s_k
       gmg_d2 xn = gmg_d2{0.0, 0.0};
       if (XM == 0) xn = gmg_d2{cur.e2.x + sk.x, cur.e2.y + sk.y};

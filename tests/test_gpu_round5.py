@@ -123,14 +123,21 @@ def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(
 
 
 # ---------------------------------------------------------------- big-level mat-vecs (OCC = 2) against the single-row kernels and the oracle
+MV_FORMS = {"occ2": {"pat_tile_rows": 0, "pat_zwalk": 0, "pat_r2mv_min": 1, "pat_r2mv_dot": 0, "persist": 0},
+            "zwalk": {"pat_zwalk": 2, "pat_r2mv_min": 1, "pat_r2mv_dot": 0, "persist": 0},
+            "zwalk_T2": {"pat_zwalk": 2, "pat_zwalk_T": 2, "pat_r2mv_min": 1, "pat_r2mv_dot": 0, "persist": 0}}
+
+
+@pytest.mark.parametrize("form", list(MV_FORMS))
 @pytest.mark.parametrize("nc,nlev,niter", BIG_LEVEL_CASES)
-def test_big_level_matvecs_are_bitwise_the_single_row_kernels_and_the_oracle(S, po, orc, nc, nlev, niter):
+def test_big_level_matvecs_are_bitwise_the_single_row_kernels_and_the_oracle(S, po, orc, nc, nlev, niter, form):
     """sells_r2mv_kernel<EPI_SET / EPI_SUB / EPI_RESID, MK, FM, 9, false, OCC=2> (w = A p of CGSolvers.jl:104 without the fused dot,
     r -= A dx of GMGLinearSolvers.jl:495, r = b - A x of CGSolvers.jl:79 on levels of >= pat_tile_rows rows), forced with
     pat_tile_rows = 0, against sells_kernel (pat_r2mv = 0): y = A x equals the oracle's mul! bit for bit (rows summed in CSR
     order), also with +-Inf / NaN in x (confined to the rows that store a coefficient for them); a CG solve from a random guess
     (RESID at the start, SET every iteration, SUB in every V-cycle) gives the same bits as the single-row kernels and the oracle's
-    iteration count and history."""
+    iteration count and history.  form = zwalk*: the same three mat-vecs in the z-walk form (sells_zsweep_kernel<1, MK, FM, EPI>, the
+    default on levels of >= pat_zwalk_rows rows since round 5), sweeps included."""
     from gridapsolvers_jl_amd.abi import OP_A
     H = po.build_hierarchy(nc, nlev, 1)
     A = H["mats"][0]
@@ -143,8 +150,7 @@ def test_big_level_matvecs_are_bitwise_the_single_row_kernels_and_the_oracle(S, 
     xi[n - 1] = np.nan
     guess = np.random.default_rng(8).uniform(-1, 1, n)
     res = {}
-    for key, opts in (("big", {"pat_tile_rows": 0, "pat_r2mv_min": 1, "pat_r2mv_dot": 0, "persist": 0}),
-                      ("single", {"pat_r2mv": 0, "pat_r2": 0, "persist": 0})):
+    for key, opts in (("big", MV_FORMS[form]), ("single", {"pat_r2mv": 0, "pat_r2": 0, "persist": 0})):
         solver = S.CGSolver(make_gmg(S, H, pre_smoothers=jac(S, nlev, niter), options=opts), maxiter=40, atol=1e-14, rtol=1e-8)
         ns = setup(S, solver, A)
         y = np.zeros(n)
