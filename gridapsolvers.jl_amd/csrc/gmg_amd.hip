@@ -261,6 +261,11 @@ struct DevCSR {
   mutable int wl_state = 0;     // 0 not looked at, 1 in use, 2 not applicable (too many patterns in one chunk / switched off)
   mutable int wl_req = 0, wl_nwg = 0, wl_wpb = 0, wl_max = 0;   // requested / launched workgroups
   mutable uint16_t *wl_pids = nullptr;
+  // the same for the z-walk form of the wide-row kernels (sellw_zwalk_kernel): one list per workgroup of four chains
+  mutable int wz_state = 0, wz_T = 0, wz_nwg = 0, wz_max = 0;   // 0 not tried, 1 lists ready, 2 does not apply
+  mutable uint16_t *wz_pids = nullptr;
+  mutable int32_t *wz_cnt = nullptr;
+  mutable ZWalkGeo wz_geo = {0, 0, 0, 0, 0};
   mutable int32_t *wl_cnt = nullptr;
   // offset-pattern layout (SELL-O): SELL-64 value stream + a 16-bit offset-pattern id per row, no column stream
   bool opat = false;
@@ -606,6 +611,7 @@ struct gmg_solver {
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
   int pat_zwalk = 1;    // GMG_PAT_ZWALK: the pair sweep as a walk along the slowest grid direction (kernels.hpp: sells_zsweep_kernel); 1: levels of >= pat_zwalk_rows rows, 2: every level
+  int pat_zwalk_wide = 1; // GMG_PAT_ZWALK_WIDE: the wide-row (Q2) operator applications of those levels (sellw_zwalk_kernel)
   int pat_zwalk_mv = 1; // GMG_PAT_ZWALK_MV: also the operator mat-vecs of those levels
   int pat_zwalk_T = 12; // GMG_PAT_ZWALK_T: planes per chain (288^3: 8 / 12 / 16 / 24 / 32 -> 149 / 114 / 120 / 118 / 155 us for the x-untouched form)
   int64_t pat_zwalk_rows = 3500000;
@@ -1366,6 +1372,44 @@ struct gmg_solver {
     const size_t nu = (size_t)M.pat_k * M.pat_nruns;
     return (size_t)lmax * (nu + M.pat_k) * 8 + (size_t)lmax * 12 + (size_t)M.pat_np + 16;
   }
+  // z-walk form of the wide-row kernels (kernels.hpp: sellw_zwalk_kernel): the 25 runs must be a 5 x 5 grid of offsets whose rows
+  // differ by a constant plane offset; lists of the patterns every workgroup (four chains) touches.  Returns the workgroups to launch.
+  int prepare_wide_z(const DevCSR &M)
+  {
+    if (M.wz_state != 0 && M.wz_T == pat_zwalk_T) return M.wz_state == 1 ? M.wz_nwg : 0;
+    if (M.wz_state == 1) { HIP_CHECK(hipStreamSynchronize(stream)); release(M.wz_pids, (size_t)M.wz_nwg * kWideStride); release(M.wz_cnt, (size_t)M.wz_nwg); }
+    M.wz_state = 2; M.wz_T = pat_zwalk_T; M.wz_nwg = 0; M.wz_max = 0;
+    if (!pat_wide || !M.pat_coded || M.pat_k != 5 || M.pat_nruns != 25 || M.pat_np > 4096 || M.pat_np < 2 || !M.rowpid || !M.pcodes || !M.pdict || !M.prunmask) return 0;
+    if (M.ncols >= (int64_t)(1 << 28) || M.nrows + 64 + std::max<int64_t>(M.pat_maxoff, -(int64_t)M.pat_minoff) >= (int64_t)(1 << 28)) return 0;
+    const std::vector<int32_t> &off = host_run_off(M);
+    const int64_t P = (int64_t)off[5] - off[0];
+    if (P < 64 || P > (int64_t)(1 << 24)) return 0;
+    for (int q = 0; q < 20; ++q) if ((int64_t)off[(size_t)q + 5] - off[(size_t)q] != P) return 0;
+    ZWalkGeo g;
+    g.P = (int)P; g.m = (int)((P + 59) / 60); g.T = pat_zwalk_T;
+    g.nplanes = (int)((M.nrows + P - 1) / P);
+    if (g.nplanes < 5) return 0;
+    const int64_t nch = (int64_t)((g.nplanes + g.T - 1) / g.T) * g.m;
+    if (nch >= (int64_t)(1 << 30)) return 0;
+    g.nchains = (int)nch;
+    const int wpb = 4, nwg = (g.nchains + wpb - 1) / wpb;
+    uint16_t *pids = dalloc<uint16_t>((size_t)nwg * kWideStride);
+    int32_t *cnt = dalloc<int32_t>((size_t)nwg);
+    hipLaunchKernelGGL(sellwz_patterns_kernel, dim3(nwg), dim3(256), 0, stream, M.rowpid, M.nrows, g, wpb, M.pat_np, kWideStride, pids, cnt);
+    HIP_CHECK(hipGetLastError());
+    std::vector<int32_t> h((size_t)nwg);
+    HIP_CHECK(hipMemcpyAsync(h.data(), cnt, sizeof(int32_t) * (size_t)nwg, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const int lmax = *std::max_element(h.begin(), h.end());
+    const size_t lds_cap = (size_t)opt_int("GMG_PAT_WIDE_LDS", 72 * 1024);
+    if (opt_int("GMG_SETUP_TIMING", 0))
+      std::fprintf(stderr, "[gmg] wide-row z-walk: %lld rows, P = %d, %d intervals x %d z-blocks, at most %d patterns per workgroup -> %zu B of LDS\n",
+                   (long long)M.nrows, g.P, g.m, (g.nplanes + g.T - 1) / g.T, lmax, wide_z_lds(M, std::min(lmax, 255)));
+    if (!(lmax <= kWideStride && lmax <= 255 && wide_z_lds(M, lmax) <= lds_cap)) { release(pids, (size_t)nwg * kWideStride); release(cnt, (size_t)nwg); return 0; }
+    M.wz_pids = pids; M.wz_cnt = cnt; M.wz_max = lmax; M.wz_nwg = nwg; M.wz_geo = g; M.wz_state = 1;
+    return nwg;
+  }
+  static size_t wide_z_lds(const DevCSR &M, int lmax) { return (size_t)lmax * 126 * 8 + (size_t)lmax * 4 + (size_t)M.pat_np + 16; }
   // sells_r2mv_kernel applies: plain shared-offset table, 27- / 9-point runs, signed 32-bit offsets, table + masks within 64 KB of LDS
   bool r2mv_ok(const DevCSR &M) const
   {
@@ -1494,6 +1538,24 @@ struct gmg_solver {
       return;
     }
     if (EPI == EPI_SWEEP) M.note_sweep("sells_kernel<EPI_SWEEP,%s,RB=%d,K=%d,VD=%d> wgs=%d wpb=%d", ONEG ? "ONEG" : "2G", M.pat_coded ? M.pat_k : pat_rb, M.pat_k, M.pat_coded ? 1 : 0, nwg, wpb);
+    if constexpr ((EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID || EPI == EPI_ADDTO) && !ONEG) {
+      // big wide-row levels: the z-walk form (five new windows per step instead of up to 25 gathers per slice)
+      if (M.pat_coded && M.pat_k == 5 && pat_zwalk && pat_zwalk_wide && !a.s_out && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_rows)) {
+        const int nwz = prepare_wide_z(M);
+        if (nwz > 0) {
+          a.wl_pids = M.wz_pids; a.wl_cnt = M.wz_cnt; a.wl_stride = kWideStride; a.wl_max = M.wz_max;
+          const size_t ldsz = wide_z_lds(M, M.wz_max);
+          static bool attr_z[64] = {false};
+          if (!attr_z[device & 63]) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sellw_zwalk_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_z[device & 63] = true;
+          }
+          hipLaunchKernelGGL((sellw_zwalk_kernel<EPI>), dim3((unsigned)nwz), dim3(256), ldsz, stream, a, M.wz_geo);
+          HIP_CHECK(hipGetLastError());
+          return;
+        }
+      }
+    }
     const int nwg_wide = (M.pat_coded && M.pat_k == 5) ? prepare_wide(M, nwg, wpb, nsl, rows) : 0;
     if (nwg_wide > 0) {
       const dim3 g(nwg_wide);
@@ -3139,6 +3201,7 @@ struct gmg_solver {
     pat_zwalk = opt_int("GMG_PAT_ZWALK", 1);
     pat_zwalk_T = std::max(1, opt_int("GMG_PAT_ZWALK_T", 12));
     pat_zwalk_mv = opt_int("GMG_PAT_ZWALK_MV", 1);
+    pat_zwalk_wide = opt_int("GMG_PAT_ZWALK_WIDE", 1);
     pat_zwalk_rows = opt_int("GMG_PAT_ZWALK_ROWS", 3500000);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
@@ -3878,6 +3941,7 @@ void gmg_solver::free_pattern(DevCSR &M)
   release(M.ptab, (size_t)1); release(M.ptab8, (size_t)1); release(M.prun, (size_t)1); release(M.pdinv, (size_t)1);
   release(M.pcodes, (size_t)1); release(M.pdict, (size_t)1); release(M.prunmask, (size_t)1);
   if (M.wl_state == 1) { release(M.wl_pids, (size_t)1); release(M.wl_cnt, (size_t)1); }
+  if (M.wz_state == 1) { release(M.wz_pids, (size_t)1); release(M.wz_cnt, (size_t)1); }
   M = DevCSR();
 }
 
@@ -5389,7 +5453,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

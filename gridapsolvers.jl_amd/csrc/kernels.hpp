@@ -2270,6 +2270,209 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
 }
 
 // ---------------------------------------------------------------------------
+// Wide rows (Q2: 25 runs of 5 consecutive offsets, 125 entries per row) in the z-walk form (round 5).  The runs are a 5 x 5 grid,
+// run q = 5 (dz + 2) + (dy + 2) at dz P + dy L - 2, so 20 of the 25 windows of the slice at r0 + P are windows of the slice at r0:
+// a wave keeps an interval of <= 60 rows of a grid plane, walks T planes upwards and gathers FIVE new windows per step instead of
+// up to 25 (sells_kernel<..., WL>: 16 gathers per slice on average -- at 8 bytes per lane the texture-address path ran as long as
+// the multiply / add stream, and the two added up).  One row per lane, the 25 windows in registers; the per-workgroup value tables
+// of the wide-row kernel (the patterns a workgroup's four chains touch, decoded into LDS; absent entries are 0.0) and its skipping
+// of runs no row of the wave has, by grid plane: the five runs of a dz are skipped when absent for the whole wave, and cut to the
+// middle three when the outer two are (a line of Q2 mid-edge dofs).  Requests run one step ahead on a single control path (every
+// address clamped: the same instruction count in the first / last planes as inside), results are stored one step late.
+// Rows are summed over the runs in ascending order with exact-zero products for absent entries, and a step whose sums are not all
+// finite is redone from memory with the masks of the coded table: bit-identical to sells_kernel<EPI, false, 5, 5, true, 0, true>.
+//   a.x gathered ; a.y result (SUB: also read) ; a.b (RESID) ; a.x2 (ADDTO: x2 += omega * A x, y = omega * A x)
+// ---------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWalkGeo g)
+{
+  static_assert(EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID || EPI == EPI_ADDTO, "operator applications only");
+  constexpr int K = 5, NR = 25, nu = K * NR, NUT = nu + 1;    // NUT: LDS stride of a pattern (even: 16-byte aligned rows)
+  extern __shared__ double sp_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int blk = remap_block(blockIdx.x, gridDim.x, a.xcd_remap);
+  const int chain = blk * wpb + wave;
+  const double *__restrict__ xg = a.x;
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  // [wl_max * NUT] values | [wl_max] run masks | [np] pattern id -> local id
+  uint32_t *s_rmask = reinterpret_cast<uint32_t *>(sp_smem + (size_t)a.wl_max * NUT);
+  uint8_t *s_map = reinterpret_cast<uint8_t *>(s_rmask + a.wl_max);
+  {
+    const int lnp = a.wl_cnt[blk];
+    const uint16_t *mine = a.wl_pids + (size_t)blk * a.wl_stride;
+    for (int i = threadIdx.x; i < lnp; i += blockDim.x) {
+      const int p = mine[i];
+      s_map[p] = (uint8_t)i;
+      s_rmask[i] = a.runmask[p];
+    }
+    for (int i = threadIdx.x; i < lnp * NUT; i += blockDim.x) {
+      const int l = i / NUT, e = i - l * NUT;
+      sp_smem[i] = e < nu ? a.dict[a.codes[(size_t)mine[l] * nu + e]] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (chain >= g.nchains) return;
+  int roff[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  const int zb = chain / g.m, iv = chain - zb * g.m;
+  const int b0 = (int)(((int64_t)iv * g.P) / g.m), b1 = (int)(((int64_t)(iv + 1) * g.P) / g.m);
+  const int len = b1 - b0;                                    // <= 60
+  const int z0 = zb * g.T, z1 = min(g.nplanes, z0 + g.T);
+  const int nsteps = z1 - z0;
+  if (nsteps <= 0) return;
+  const int rfirst = z0 * g.P + b0;
+  const double *__restrict__ eg = EPI == EPI_RESID ? a.b : (EPI == EPI_ADDTO ? a.x2 : a.y);
+  auto loadw = [&](int base) -> double { return xg[min(max(base + lane, 0), last)]; };
+  struct RowOps { int pid; double e0; };
+  auto load_rows = [&](int rbase) -> RowOps {
+    RowOps o;
+    const int r = min(rbase + lane, lastrow);
+    o.pid = (int)a.rowpid[r];
+    o.e0 = EPI == EPI_SET ? 0.0 : eg[r];
+    return o;
+  };
+  double C[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) C[q] = loadw(rfirst + roff[q]);
+  RowOps cur = load_rows(rfirst);
+  int r0 = rfirst;
+  double p0 = 0.0, p1 = 0.0;                                   // results of the previous step (stored at the top of the next one)
+  int prow = 0;
+  bool pok = false;
+  auto put = [&]() {
+    if (pok) {
+      a.y[prow] = p0;
+      if (EPI == EPI_ADDTO) a.x2[prow] = p1;
+    }
+  };
+#pragma unroll 1
+  for (int k = 0; k < nsteps; ++k) {
+    put();
+    // step k + 1 (the last step: this step again, unused): requested before the taps of step k
+    const int rb = rfirst + min(k + 1, nsteps - 1) * g.P;
+    double N[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) N[q] = loadw(rb + roff[NR - K + q]);
+    const RowOps nxt = load_rows(rb);
+    const int row = r0 + lane;
+    const bool mine = lane < len && row <= lastrow;
+    const int gpid = mine ? cur.pid : a.np - 1;                // halo lanes / rows of other chains: the empty pattern
+    const int lid = (int)s_map[gpid];
+    uint32_t m = s_rmask[lid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m |= (uint32_t)__shfl_xor((int)m, o);
+    const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    const double *tv = sp_smem + lid * NUT;
+    double sum = 0.0;
+    // the runs LO .. HI of plane group ZI: coefficients of the next run requested before the taps of the current one
+    auto group = [&](auto zi_tag, auto lo_tag, auto hi_tag) {
+      constexpr int ZI = decltype(zi_tag)::value, LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
+      double cf[2][K];
+#pragma unroll
+      for (int t = 0; t < K; ++t) cf[LO & 1][t] = tv[(ZI * K + LO) * K + t];
+#pragma unroll
+      for (int y = LO; y <= HI; ++y) {
+        if (y < HI) {
+#pragma unroll
+          for (int t = 0; t < K; ++t) cf[(y + 1) & 1][t] = tv[(ZI * K + y + 1) * K + t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double v = C[ZI * K + y];
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          if (t > 0) v = wave_shl1(v);
+          sum = sum + cf[y & 1][t] * v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto plane = [&](auto zi_tag) {
+      constexpr int ZI = decltype(zi_tag)::value;
+      const uint32_t gm = (M >> (ZI * K)) & 31u;              // wave-uniform
+      if (gm == 0u) return;
+      if ((gm & 0x11u) == 0u) group(zi_tag, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
+      else group(zi_tag, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+    };
+    plane(std::integral_constant<int, 0>{});
+    plane(std::integral_constant<int, 1>{});
+    plane(std::integral_constant<int, 2>{});
+    plane(std::integral_constant<int, 3>{});
+    plane(std::integral_constant<int, 4>{});
+    // "all sums finite" proves that no mask was needed (absent entries are exact zeros against finite values); otherwise -- a vector
+    // that already holds Inf / NaN -- the step is redone from memory with the masks of the coded table
+    if (!__all(__builtin_isfinite(sum))) {
+      sum = 0.0;
+      const uint8_t *gc = a.codes + (size_t)gpid * nu;
+#pragma unroll 1
+      for (int q = 0; q < NR; ++q) {
+        if (!((M >> q) & 1u)) continue;
+        double v = xg[min(max(row + roff[q], 0), last)];
+#pragma unroll 1
+        for (int t = 0; t < K; ++t) {
+          if (t > 0) v = wave_shl1(v);
+          const int code = gc[q * K + t];
+          const double gv = __hiloint2double(__double2hiint(v) & ((code == 255) ? 0 : -1), __double2loint(v));
+          sum = sum + tv[q * K + t] * gv;
+        }
+      }
+    }
+    if (EPI == EPI_SET) p0 = sum;
+    else if (EPI == EPI_SUB || EPI == EPI_RESID) p0 = cur.e0 - sum;
+    else { const double t = a.omega != 0.0 ? a.omega * sum : sum; p0 = t; p1 = cur.e0 + t; }
+    prow = row; pok = mine;
+#pragma unroll
+    for (int q = 0; q < NR - K; ++q) C[q] = C[q + K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) C[NR - K + q] = N[q];
+    cur = nxt;
+    r0 += g.P;
+  }
+  put();
+}
+
+// the patterns the four chains of every workgroup of sellw_zwalk_kernel touch (one list per workgroup, ascending; the empty pattern
+// np - 1 is always in it)
+__global__ __launch_bounds__(256) void sellwz_patterns_kernel(const uint16_t *__restrict__ rowpid, int64_t nrows, ZWalkGeo g, int wpb, int np, int stride,
+                                                               uint16_t *__restrict__ pids, int32_t *__restrict__ cnt)
+{
+  __shared__ uint32_t bits[128];                             // np <= 4096
+  const int blk = blockIdx.x;
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) bits[i] = 0u;
+  __syncthreads();
+  for (int w = 0; w < wpb; ++w) {
+    const int chain = blk * wpb + w;
+    if (chain >= g.nchains) break;
+    const int zb = chain / g.m, iv = chain - zb * g.m;
+    const int b0 = (int)(((int64_t)iv * g.P) / g.m), b1 = (int)(((int64_t)(iv + 1) * g.P) / g.m);
+    const int len = b1 - b0;
+    const int z0 = zb * g.T, z1 = min(g.nplanes, z0 + g.T);
+    const int tot = (z1 - z0) * len;
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+      const int z = z0 + i / len, j = i - (i / len) * len;
+      const int64_t r = (int64_t)z * g.P + b0 + j;
+      if (r < nrows) {
+        const int p = rowpid[r];
+        atomicOr(&bits[p >> 5], 1u << (p & 31));
+      }
+    }
+  }
+  if (threadIdx.x == 0) atomicOr(&bits[(np - 1) >> 5], 1u << ((np - 1) & 31));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < (np + 31) / 32; ++w)
+      for (uint32_t m = bits[w]; m; m &= m - 1) {
+        if (c < stride) pids[(size_t)blk * stride + c] = (uint16_t)(w * 32 + __builtin_ctz(m));
+        ++c;
+      }
+    cnt[blk] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The operator mat-vecs of a row-pattern level with two rows per lane: y = A x (EPI_SET: CGSolvers.jl:104), y -= A x (EPI_SUB:
 // GMGLinearSolvers.jl:495), y = b - A x (EPI_RESID: CGSolvers.jl:79).  The layout, the windows and the strict-mask rule of
 // sells_r2sweep_kernel without the omega*(d*.) of a sweep: the gathered value IS the window value.  Same taps in the same order as

@@ -387,3 +387,59 @@ def test_all_level_refresh_with_csc_values_is_bitwise_a_fresh_setup(S, po, orc):
     assert rel_err(xf, xo) <= 1e-9
     for q in (nf, nr, nc_):
         q.P_ns.close()
+
+
+# ---------------------------------------------------------------- wide rows (Q2) in the z-walk form
+@pytest.mark.parametrize("nc,T", [((16, 16, 16), 12), ((24, 10, 12), 3), ((10, 14, 20), 1), ((12, 12, 12), 5)])
+def test_wide_row_zwalk_is_bitwise_the_wide_row_kernel_and_the_oracle(S, po, orc, monkeypatch, nc, T):
+    """sellw_zwalk_kernel<EPI> (round 5; default on Q2 levels of >= pat_zwalk_rows rows: the finest two levels of BASELINE configs[2]):
+    the 25 windows of a row's 5 x 5 runs kept in registers while a wave walks up the grid planes, five new ones gathered per step;
+    per-workgroup value tables, runs skipped by plane group.  Forced onto small levels (pat_zwalk = 2, chains of 12 / 3 / 1 / 5
+    planes: chain starts and ends inside the level, intervals that straddle grid lines of different dof types, the clamped first and
+    last planes).  mul!(y, A, x) equals the oracle's sequential row sums bit for bit; an Inf / NaN in x reaches exactly the rows that
+    store a coefficient for it (the step is redone with the coded table's masks); a patch-smoothed FGMRES solve -- r -= A dx
+    (EPI_SUB), dx = omega S r ; x += dx (EPI_ADDTO on the additive-Schwarz operator), b - A x (EPI_RESID) -- gives the bits of
+    sells_kernel<..., WL> (pat_zwalk = 0) and the oracle's iteration count."""
+    from gridapsolvers_jl_amd import abi
+    monkeypatch.setenv("GMG_PAT_CODED_MIN_ROWS", "0")               # the coded shared-offset table (what the 10^8-dof levels use) for A and M
+    order, nlev = 2, 2
+    H = po.build_hierarchy(nc, nlev, order, stream_min_rows=5000)
+    Hw = po.build_hierarchy(nc, nlev, order)
+    A = Hw["mats"][0]
+    n = A.shape[0]
+    b = po.dirichlet_lift_rhs(nc, order)
+    tabs = [po.vertex_star_patches(c, order) for c in H["ncells"][:-1]]
+    x = np.random.default_rng(11).uniform(-1, 1, n)
+    ks = [n // 2 + 3, 7, n - 2]
+    xi = x.copy(); xi[ks[0]] = np.inf; xi[ks[1]] = -np.inf; xi[ks[2]] = np.nan
+    As = A.to_scipy().tocsc()
+    touched = np.zeros(n, dtype=bool)
+    for k in ks:
+        touched[As.indices[As.indptr[k]:As.indptr[k + 1]]] = True
+    guess = np.random.default_rng(12).uniform(-1, 1, n)
+    sols = {}
+    for mode in ("zwalk", "wl"):
+        opts = {"pat_zwalk": 2, "pat_zwalk_T": T} if mode == "zwalk" else {"pat_zwalk": 0}
+        sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 5, 0.2) for pp, pd in tabs]
+        solver = S.FGMRESSolver(5, make_gmg(S, H, pre_smoothers=sm, options=opts), maxiter=20, atol=1e-14, rtol=1e-8)
+        ns = setup(S, solver, H["mats"][0])
+        assert ns.P_ns.level_format(0)["row_patterns"]
+        y = np.zeros_like(x)
+        ns.P_ns.op_apply(0, abi.OP_A, x, y)
+        assert np.array_equal(y, orc.spmv(A, x))
+        yi = np.zeros_like(x)
+        ns.P_ns.op_apply(0, abi.OP_A, xi, yi)
+        assert np.all(np.isfinite(yi[~touched])) and not np.any(np.isfinite(yi[touched]))
+        assert np.array_equal(yi[~touched], y[~touched])
+        xs = guess.copy()
+        S.solve_(xs, ns, b)
+        sols[mode] = (xs, solver.log.num_iters, np.array(solver.log.residuals[: solver.log.num_iters + 1]), yi.copy())
+        ns.P_ns.close()
+    assert sols["zwalk"][1] == sols["wl"][1] and np.array_equal(sols["zwalk"][2], sols["wl"][2]) and np.array_equal(sols["zwalk"][0], sols["wl"][0])
+    np.testing.assert_array_equal(np.isnan(sols["zwalk"][3]), np.isnan(sols["wl"][3]))
+    osm = [orc.Smoother(orc.PATCH, 5, 0.2, pp, pd) for pp, pd in tabs]
+    go = orc.GMG(Hw["mats"], Hw["prolongations"], Hw["restrictions"], pre_smoothers=osm, maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(A, b, x0=guess, Pr=go, m=5, maxiter=20, atol=1e-14, rtol=1e-8)
+    assert sols["zwalk"][1] == nit
+    np.testing.assert_allclose(sols["zwalk"][2], hist, rtol=1e-7)
+    assert rel_err(sols["zwalk"][0], xo) <= 1e-9
