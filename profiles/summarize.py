@@ -26,7 +26,7 @@ def db(path):
 
 
 def family(name):
-    if any("gmg::" + k + "<" in name for k in ("sells_sweep_kernel", "sells_rsweep_kernel", "sells_r2sweep_kernel", "sells_tsweep_kernel")):   # the fused sweeps on the shared-offset pattern table (XM = 0/1/2 variants)
+    if any("gmg::" + k + "<" in name for k in ("sells_sweep_kernel", "sells_rsweep_kernel", "sells_r2sweep_kernel", "sells_tsweep_kernel", "sells_zsweep_kernel")):   # the fused sweeps on the shared-offset pattern table (XM = 0/1/2 variants)
         return "sells_kernel"
     for fam in ("sells_kernel", "sellp_kernel", "sellc_kernel", "sello_kernel", "sell_kernel", "csr_stream1_kernel"):
         if "gmg::" + fam + "<" in name:
@@ -94,6 +94,7 @@ def main():
     # ---- finest-level fused sweeps (EPI_SWEEP = 3 kernels and the sells_sweep_kernel variants): largest grid per family;
     #      variants of one family at that grid (x updated every second sweep) are averaged, weighted by launches ----
     sw = con.execute("select name, grid_x, avg(end-start)/1e3, count(*) from kernels where name like '%_kernel<3,%' or name like '%sells_sweep_kernel<%' or name like '%sells_rsweep_kernel<%' or name like '%sells_r2sweep_kernel<%' or name like '%sells_tsweep_kernel<%' "
+                     "or name like '%sells_zsweep_kernel<%, 3>%' "      # (the z-walk sweep: EPI_SWEEP = 3 is its last template argument; its mat-vec forms are not sweeps)
                      "group by name, grid_x order by grid_x desc").fetchall()
     recs = []
     nrows = (a.cells - 1) ** 3
@@ -105,8 +106,12 @@ def main():
         # longest -- enter the record)
         sw = []
         for epi in ("1", "4"):
+            # round 5: levels of >= 3.5e6 rows run the z-walk form (sellw_zwalk_kernel<EPI>); smaller ones sells_kernel<EPI, ..., WL>
             rows = con.execute("select name, grid_x, max(end-start) from kernels where name like ? group by name, grid_x order by 3 desc",
-                               ("%gmg::sells_kernel<" + epi + ",%, 5, true%",)).fetchall()
+                               ("%gmg::sellw_zwalk_kernel<" + epi + ">%",)).fetchall()
+            if not rows:
+                rows = con.execute("select name, grid_x, max(end-start) from kernels where name like ? group by name, grid_x order by 3 desc",
+                                   ("%gmg::sells_kernel<" + epi + ",%, 5, true%",)).fetchall()
             if rows:
                 name, grid, mx = rows[0]
                 r = con.execute("select avg(end-start)/1e3, count(*) from kernels where name=? and grid_x=? and (end-start) >= ?", (name, grid, 0.75 * mx)).fetchone()
@@ -116,7 +121,7 @@ def main():
     for name, grid, avg_us, cnt in sw:
         fam = family(name)
         if a.order == 2:
-            fam = "sells_kernel_wide" if "sells_kernel<1," in name else "sells_kernel_wide_schwarz"
+            fam = "sells_kernel_wide" if ("sells_kernel<1," in name or "sellw_zwalk_kernel<1>" in name) else "sells_kernel_wide_schwarz"
         if fam is None:
             continue
         # one record per (family, grid): the finest level and, when its batched variant runs on a smaller grid than the next
@@ -159,7 +164,7 @@ def main():
         for fam_leg, blk in (("generic", bj.get("roofline")), ("default", bj.get("roofline_compressed")),
                              ("varcoef", (bj.get("variable_coefficient") or {}).get("roofline"))):
             if blk and blk.get("sweep_signature"):
-                sigs[blk["sweep_signature"].split("<")[0].replace("sells_sweep_kernel", "sells_kernel").replace("sells_rsweep_kernel", "sells_kernel").replace("sells_r2sweep_kernel", "sells_kernel").replace("sells_tsweep_kernel", "sells_kernel")] = blk["sweep_signature"]
+                sigs[blk["sweep_signature"].split("<")[0].replace("sells_sweep_kernel", "sells_kernel").replace("sells_rsweep_kernel", "sells_kernel").replace("sells_r2sweep_kernel", "sells_kernel").replace("sells_tsweep_kernel", "sells_kernel").replace("sells_zsweep_kernel", "sells_kernel")] = blk["sweep_signature"]
     except Exception as e:
         tl.append(f"# (no sweep signatures: {e})")
     for rec in recs:

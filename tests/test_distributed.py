@@ -253,6 +253,13 @@ def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_p
         _check(w)
         assert w["iters"] == v["iters"]
         np.testing.assert_array_equal(w["x"], v["x"])
+        # round 5: the z-walk form of the sweep and of the mat-vecs (what the 288^3-per-GPU finest level of BASELINE configs[3] runs), forced
+        # onto these small partitioned levels -- own x own part of an own | ghost level, n_own rows x (n_own + n_ghost) columns: same bits
+        z = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep,
+                    extra_env={"GMG_PAT_R2MV_MIN": "1", "GMG_PAT_ZWALK": "2", "GMG_PAT_ZWALK_T": "3"})
+        _check(z)
+        assert z["iters"] == v["iters"]
+        np.testing.assert_array_equal(z["x"], v["x"])
 
 
 @pytest.mark.gpu
@@ -314,6 +321,15 @@ def test_overlapping_layout_q2_and_patch_smoothers_on_gpu_host_transport(world, 
     assert v["iters"] == v0["iters"]
     assert v0["exchanges"] - v["exchanges"] == v0["iters"] * 2 * saved_per_pass, (v0["exchanges"], v["exchanges"])
     assert np.linalg.norm(v["x"] - v0["x"]) <= 1e-11 * np.linalg.norm(v0["x"])
+    if world == 2:
+        # round 5: the wide-row operators of these levels in the z-walk form (sellw_zwalk_kernel, forced with pat_zwalk = 2): same bits
+        z = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep,
+                    extra_env=dict(env, GMG_TEST_DEPTH=str(depth), GMG_PAT_ZWALK="2", GMG_PAT_ZWALK_T="2", GMG_PAT_CODED_MIN_ROWS="0"))
+        w = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep,
+                    extra_env=dict(env, GMG_TEST_DEPTH=str(depth), GMG_PAT_ZWALK="0", GMG_PAT_CODED_MIN_ROWS="0"))
+        _check(z)
+        assert z["iters"] == w["iters"]
+        np.testing.assert_array_equal(z["x"], w["x"])
 
 
 @pytest.mark.gpu
