@@ -897,7 +897,7 @@ def config5_leg(torch, pkg, args, want_cpu):
     if want_cpu:
         # the same configuration at the size the sequential oracle affords: iterations, history, solution and time against it
         orc = entry.import_oracle()
-        cn, cl = 64, 3
+        cn, cl = 256, 5                              # ~10 s of single-thread oracle work
         sysd, Hv, solver, gmg, solver_p, ns, _a, _s = make(cn, cl)
         b = sysd["b"]
         x = np.zeros(b.size)
