@@ -390,6 +390,9 @@ struct Level {
   double *rbuf[2] = {nullptr, nullptr};
   double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
   uint32_t *pflags = nullptr;     // persistent smoothing pass (sells_smooth_kernel): one progress word per workgroup, 64 B apart
+  double *tbuf[3] = {nullptr, nullptr, nullptr};   // data-tagged pass (sells_smooth_tag_kernel): three s buffers, sentinel where not yet written
+  int t_off = 0;                  // rotation offset of the next tagged pass
+  int t_sym = -1;                 // run offsets symmetric (every reader of a row is gathered from)? -1 not checked yet
   int pf_nwg = 0;
   uint32_t pf_epoch = 1;
   double *dx = nullptr;
@@ -602,6 +605,9 @@ struct gmg_solver {
   int pat_wide = 1;     // GMG_PAT_WIDE: coded (wide-row) operators decode the patterns of each workgroup's chunk into a plain LDS value table
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist_wpb_min = 1;   // GMG_PERSIST_WPB: smallest workgroup (in waves) of a one-launch pass
+  int persist_tag = 1;  // GMG_PERSIST_TAG: the one-launch passes of SMALL levels hand s over through data-tagged buffers (sells_smooth_tag_kernel) instead of progress words
+  int persist_tag_max_slices = 1024;   // GMG_PERSIST_TAG_MAX_SLICES: ... of levels up to this many 62-row slices (31^3 rows: 30.5 -> 23.3 us per pass of 10; 63^3 rows, 4 034 slices
+                                       // on 253 workgroups of 16 waves: 43.2 -> 78.7 us -- 4 048 polling waves and two 8-byte write-through stores per row and sweep)
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
   int persist_fenced = 0; // GMG_PERSIST_FENCED: progress words published with release / polled with acquire semantics (agent scope)
   int persist_max_slices = 0;  // GMG_PERSIST_MAX_SLICES (0: what one workgroup per CU holds)
@@ -712,6 +718,7 @@ struct gmg_solver {
       L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
       L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pflags = nullptr; L.pf_nwg = 0; L.pf_epoch = 1;
+      L.tbuf[0] = L.tbuf[1] = L.tbuf[2] = nullptr; L.t_off = 0; L.t_sym = -1;
       for (Smoother *sp : {&L.pre, &L.post, &L.pcorr}) sp->reset_device();
       L.s0_ready = false;
     }
@@ -2598,6 +2605,72 @@ struct gmg_solver {
     const int nwg = (nsl + wpb * ns - 1) / (wpb * ns);
     if (nwg > n_cus) return false;
     if (dry) return true;
+    if (!h_perr) {
+      HIP_CHECK(hipHostMalloc((void **)&h_perr, 64, hipHostMallocMapped));
+      *h_perr = 0;
+      HIP_CHECK(hipHostGetDevicePointer((void **)&d_perr, h_perr, 0));
+    }
+    if (!d_perr_dev) {                                       // (released with the other device arrays by free_all)
+      d_perr_dev = dalloc<uint32_t>(16);
+      HIP_CHECK(hipMemsetAsync(d_perr_dev, 0, 64, stream));
+    }
+    // data-tagged hand-offs (kernels.hpp: sells_smooth_tag_kernel): 27-point operators whose run offsets are symmetric about the
+    // window centre -- every wave that reads a row is a wave the row's owner gathers from
+    if (persist_tag && M.pat_nruns == 9 && nsl <= persist_tag_max_slices) {
+      if (L.t_sym < 0) {
+        const std::vector<int32_t> &off = host_run_off(M);
+        bool sym = true;
+        for (int q = 0; q < 9 && sym; ++q) {
+          bool found = false;
+          for (int p = 0; p < 9; ++p) found = found || ((int64_t)off[(size_t)p] == -(int64_t)off[(size_t)q] - (M.pat_k - 1));
+          sym = found;
+        }
+        L.t_sym = sym ? 1 : 0;
+      }
+      if (L.t_sym == 1) {
+        if (!L.tbuf[0]) {
+          for (int j = 0; j < 3; ++j) {
+            L.tbuf[j] = dvec(L.nvec);
+            hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)std::min<int64_t>(1024, (L.nvec + 255) / 256)), dim3(256), 0, stream, L.nvec, L.tbuf[j]);
+            HIP_CHECK(hipGetLastError());
+          }
+          L.t_off = 0;
+        }
+        SellSmoothTagArgs ta;
+        std::memset(&ta, 0, sizeof(ta));
+        SellSmoothArgs &a = ta.b;
+        a.rowpid = M.rowpid; a.tab = M.ptab; a.tab8 = M.ptab8; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
+        a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl;
+        a.pdinv = pat_dinv ? M.pdinv : nullptr; a.dinv = L.dinv; a.omega = S.omega;
+        a.niter = niter; a.x_zero = x_zero ? 1 : 0;
+        a.r_in = r_in; a.r_out = r_out; a.x = x; a.s_a = L.sbuf[0]; a.s_b = L.sbuf[1];
+        a.err = d_perr; a.err_dev = d_perr_dev;
+        for (int j = 0; j < 3; ++j) ta.t[j] = L.tbuf[j];
+        ta.off = L.t_off;
+        L.t_off = (L.t_off + niter - 1) % 3;
+        const dim3 g(nwg), b(64 * wpb);
+        const bool td = a.pdinv != nullptr;
+        const bool mk = pat_strict || !M.ptab8;
+        const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();
+        if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
+#define GMG_SMOOTH_TAG_LAUNCH(NSV, TDV)                                                                        \
+        do {                                                                                                     \
+          if (mk) hipLaunchKernelGGL((sells_smooth_tag_kernel<NSV, TDV, true>), g, b, lds, stream, ta);          \
+          else hipLaunchKernelGGL((sells_smooth_tag_kernel<NSV, TDV, false>), g, b, lds, stream, ta);            \
+        } while (0)
+        if (ns == 2) { if (td) GMG_SMOOTH_TAG_LAUNCH(2, true); else GMG_SMOOTH_TAG_LAUNCH(2, false); }
+        else { if (td) GMG_SMOOTH_TAG_LAUNCH(1, true); else GMG_SMOOTH_TAG_LAUNCH(1, false); }
+#undef GMG_SMOOTH_TAG_LAUNCH
+        HIP_CHECK(hipGetLastError());
+        if (prof) {
+          HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
+          prof_w[prof_used / 2] = niter;
+          prof_xm[prof_used / 2] = 0;
+          prof_used += 2;
+        }
+        return true;
+      }
+    }
     if (!L.pflags || L.pf_nwg < nwg) {
       if (L.pflags) { HIP_CHECK(hipStreamSynchronize(stream)); release(L.pflags, (size_t)L.pf_nwg * 16); }
       L.pflags = dalloc<uint32_t>((size_t)nwg * 16);
@@ -3210,6 +3283,8 @@ struct gmg_solver {
     pat_r2mv_min = opt_int("GMG_PAT_R2MV_MIN", 100000);
     pat_fma = opt_int("GMG_PAT_FMA", 0);
     persist = opt_int("GMG_PERSIST", 1);
+    persist_tag = opt_int("GMG_PERSIST_TAG", 1);
+    persist_tag_max_slices = opt_int("GMG_PERSIST_TAG_MAX_SLICES", 1024);
     // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
     // could keep each other from becoming fully resident, so they are off unless asked for
     if (comm.kind == COMM_HOST && !opt_int("GMG_PERSIST_SHARED", 0)) persist = 0;
@@ -5453,7 +5528,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PERSIST_TAG", false}, {"GMG_PERSIST_TAG_MAX_SLICES", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

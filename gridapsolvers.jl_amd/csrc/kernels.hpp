@@ -3024,6 +3024,176 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// The one-launch pass with DATA-TAGGED hand-offs (round 5).  sells_smooth_kernel pays per sweep: the neighbours' progress words polled
+// by one lane per neighbour, a workgroup barrier, the gathers, the store drain (s_waitcnt vmcnt(0)), another barrier, the flag store --
+// a flag hand-off, 1.7-1.9 x the price of a data-tagged one (MI355X_MICROARCH.md, price list: handoff-flag vs handoff-1to1), 3.1 us
+// per sweep on 31^3 rows for 0.3 us of work.  Here the VALUE is the flag: s moves through three buffers T[0..2] that hold a sentinel
+// (a signalling NaN -- no arithmetic result is one, and s = omega (d r) is always an arithmetic result) wherever the value of the
+// coming sweep has not been written yet; a lane gathers with agent-scope loads and simply repeats a load that returned the sentinel.
+// No progress words, no barrier, no store drain in front of a publish: every wave runs on as soon as ITS windows are there.
+//   sweep k reads   k = 0: a.s_a (s_0, written by the previous kernel)      k >= 1: T[(off + k) % 3]
+//   sweep k         resets its own rows of T[(off + k + 2) % 3] to the sentinel (after its gathers: every reader of those rows --
+//                   the waves it has just gathered from: the run offsets are symmetric, checked by the launcher -- finished the
+//                   sweep that read them before publishing what this wave has just seen), drains THOSE stores behind the taps,
+//   then publishes  s_{k+1} into T[(off + k + 1) % 3] (reset two sweeps ago, or sentinel since the previous pass).
+// After a pass of n sweeps T[(off + n) % 3] and T[(off + n + 1) % 3] are all sentinel and the third holds stale values: the next pass
+// starts with off' = off + n - 1, so that its first publish goes to a sentinel buffer and the stale one is reset in its sweep 1
+// before anybody polls it (gmg_solver keeps off per level; a timed-out pass leaves the handle on per-sweep launches for good).
+// Same arithmetic, operand order and roundings as sells_smooth_kernel / sells_sweep_kernel: bit-identical.
+// ---------------------------------------------------------------------------
+constexpr unsigned long long kSmoothSentinel = 0x7FF4A5C3D2E1F00Full;   // signalling NaN (quiet bit clear, payload non-zero)
+__device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == kSmoothSentinel; }
+__global__ void fill_sentinel_kernel(int64_t n, double *p)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    reinterpret_cast<unsigned long long *>(p)[i] = kSmoothSentinel;
+}
+
+struct SellSmoothTagArgs {
+  SellSmoothArgs b;         // flags / epoch / halo_wg / fenced unused
+  double *t[3];             // tagged s buffers
+  int off;                  // rotation offset of this pass
+};
+
+template <int NS, bool TD, bool MK>
+__global__ __launch_bounds__(1024) void sells_smooth_tag_kernel(SellSmoothTagArgs ta)
+{
+  const SellSmoothArgs &a = ta.b;
+  constexpr int K = 3, ROWS = 65 - K, NR = 9;
+  extern __shared__ double sp_smem[];
+  constexpr int nu = K * NR;
+  const int tot = a.np * nu;
+  double *s_tab8 = sp_smem;
+  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
+  double *s_dinv = sp_smem + (MK ? 2 : 1) * (size_t)tot;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int w = blockIdx.x;
+  const int last = (int)a.ncols - 1;
+  const int lastrow = (int)a.nrows - 1;
+  const double omega = a.omega;
+  int pid[NS], row[NS];
+  bool own[NS];
+  bool need[NS];                                            // the lane's window values are used by some existing row of the slice (see the gathers)
+  double r[NS], xr[NS], so[NS], dv[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int slice = w * (wpb * NS) + i * wpb + wave;
+    row[i] = min(slice, a.nslices - 1) * ROWS + lane;       // slices past the end recompute the last one, store nothing
+    own[i] = slice < a.nslices && lane < ROWS && row[i] <= lastrow;
+    need[i] = slice < a.nslices && lane <= min(ROWS - 1, lastrow - slice * ROWS) + (K - 1);   // (a slice past the end owns nothing and nobody gathers from it: it must not wait)
+    const int rc = min(row[i], lastrow);
+    pid[i] = (int)a.rowpid[rc];
+    r[i] = a.r_in[rc];
+    { const double xl = a.x[rc]; xr[i] = a.x_zero ? 0.0 : xl; }
+    so[i] = a.s_a[rc];
+    dv[i] = TD ? 0.0 : a.dinv[rc];
+  }
+  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
+  else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
+  if (TD)
+    for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
+  __syncthreads();
+  if (TD) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) dv[i] = s_dinv[pid[i]];
+  }
+  int roff[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  bool dead = false;                                         // a wait timed out: the pass is void (see the end)
+  for (int k = 0; k < a.niter; ++k) {
+    const double *sin = k == 0 ? a.s_a : ta.t[(ta.off + k) % 3];
+    double *sout = ta.t[(ta.off + k + 1) % 3];
+    double *srst = ta.t[(ta.off + k + 2) % 3];
+    const bool publish = k + 1 < a.niter;                    // the s of the last sweep has no reader
+    double acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      // the nine windows of the slice: a load that returns the sentinel is repeated (bounded)
+      double A[NR];
+      unsigned spins = 0;
+      for (;;) {
+        bool wait = false;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          // Only positions some existing row of the slice has a tap on are waited for: positions outside the vector (the other kernels
+          // read a clamped element there) and the lanes past the last row of a ragged slice take 0.0 -- their coefficients are absent,
+          // the products exact zeros either way.  A wave that polled such a position would read rows of a wave that does NOT gather
+          // from it, which may reset them under it: with this rule "w' reads rows of w" <=> "w gathers from w'" (symmetric run offsets)
+          const int c = row[i] + roff[q];
+          const double v = ld_agent(sin + min(max(c, 0), last));
+          A[q] = (need[i] && c >= 0 && c <= last) ? v : 0.0;
+          wait = wait || is_sentinel(A[q]);
+        }
+        if (k == 0 || !wait || dead) break;
+        if (++spins > (1u << 17)) {
+          __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (a.err_dev) __hip_atomic_store(a.err_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (i == NS - 1) {
+        // ALL gathers of the wave are in: the readers of this wave's rows in srst are done with it (they published what was gathered
+        // above after reading it) -- reset, the stores drain behind the taps of the last slice
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+          if (own[j]) __hip_atomic_store(reinterpret_cast<unsigned long long *>(srst + row[j]), kSmoothSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const uint32_t *tm = s_msk + pid[i] * nu;
+      const double *tv = s_tab8 + pid[i] * nu;
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        double c = A[q];
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          if (t > 0) c = wave_shl1(c);
+          s = s + tv[q * K + t] * c;
+        }
+      }
+      if (MK && !__all(__builtin_isfinite(s))) {             // rare: a vector that already holds Inf / NaN -- redo the slice with the masks
+        s = 0.0;
+#pragma unroll 1
+        for (int q = 0; q < NR; ++q) {
+          const int cc = row[i] + roff[q];
+          double c = ld_agent(sin + min(max(cc, 0), last));
+          if (!(need[i] && cc >= 0 && cc <= last)) c = 0.0;
+#pragma unroll
+          for (int t = 0; t < K; ++t) {
+            if (t > 0) c = wave_shl1(c);
+            const int j = q * K + t;
+            const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
+            s = s + tv[j] * g;
+          }
+        }
+      }
+      acc[i] = s;
+    }
+    // the resets have left the CU (agent-scope stores, write-through) before anything of sweep k + 1 is published: a neighbour that
+    // sees s_{k+1} of this wave and runs on to poll srst two sweeps later finds the sentinel or the new value there, never the old one
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      xr[i] = xr[i] + so[i];                                 // x += s_k
+      const double rn = r[i] - acc[i];                       // r -= A s_k
+      r[i] = rn;
+      so[i] = omega * (dv[i] * rn);                          // s_{k+1} = omega * Dinv r
+      if (publish && own[i]) st_agent(sout + row[i], so[i]);
+    }
+  }
+  // a wait timed out somewhere (as far as this workgroup can see): the pass is void -- leave x and r as they were, the host
+  // re-runs the solve sweep by sweep (with_persist_retry)
+  if (dead || (a.err_dev && __hip_atomic_load(a.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) return;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    if (own[i]) { a.x[row[i]] = xr[i]; a.r_out[row[i]] = r[i]; }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Setup of the additive-Schwarz operator in row-pattern form (gmg_solver::build_patch_operator) on the device: which patches touch a
 // dof, in ascending patch order (a counting sort of the patch slots by dof), and one 64-bit signature per row over
 // (inverse block, local row, patch shape, first dof - row) of its patches -- 4.6e8 slots / 1.3e8 rows at 256^3 Q2, 2.1 s on 16 host cores.
