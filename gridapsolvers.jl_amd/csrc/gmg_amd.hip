@@ -605,7 +605,9 @@ struct gmg_solver {
   int pat_wide = 1;     // GMG_PAT_WIDE: coded (wide-row) operators decode the patterns of each workgroup's chunk into a plain LDS value table
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist_wpb_min = 1;   // GMG_PERSIST_WPB: smallest workgroup (in waves) of a one-launch pass
-  int persist_tag = 1;  // GMG_PERSIST_TAG: the one-launch passes of SMALL levels hand s over through data-tagged buffers (sells_smooth_tag_kernel) instead of progress words
+  int persist_tag = 0;  // GMG_PERSIST_TAG (opt-in): the one-launch passes of SMALL levels hand s over through data-tagged buffers (sells_smooth_tag_kernel) instead of
+                        // progress words.  -7 us per pass on 31^3 rows and bit-identical over 4 500 soaked V-cycles, but forced onto a level of 4 034 slices
+                        // it timed out intermittently (cause not found: profiles/r05_tuning.md section 5) -- a time-out costs the handle its one-launch passes
   int persist_tag_max_slices = 1024;   // GMG_PERSIST_TAG_MAX_SLICES: ... of levels up to this many 62-row slices (31^3 rows: 30.5 -> 23.3 us per pass of 10; 63^3 rows, 4 034 slices
                                        // on 253 workgroups of 16 waves: 43.2 -> 78.7 us -- 4 048 polling waves and two 8-byte write-through stores per row and sweep)
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
@@ -3283,7 +3285,7 @@ struct gmg_solver {
     pat_r2mv_min = opt_int("GMG_PAT_R2MV_MIN", 100000);
     pat_fma = opt_int("GMG_PAT_FMA", 0);
     persist = opt_int("GMG_PERSIST", 1);
-    persist_tag = opt_int("GMG_PERSIST_TAG", 1);
+    persist_tag = opt_int("GMG_PERSIST_TAG", 0);
     persist_tag_max_slices = opt_int("GMG_PERSIST_TAG_MAX_SLICES", 1024);
     // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
     // could keep each other from becoming fully resident, so they are off unless asked for

@@ -443,3 +443,48 @@ def test_wide_row_zwalk_is_bitwise_the_wide_row_kernel_and_the_oracle(S, po, orc
     assert sols["zwalk"][1] == nit
     np.testing.assert_allclose(sols["zwalk"][2], hist, rtol=1e-7)
     assert rel_err(sols["zwalk"][0], xo) <= 1e-9
+
+
+# ---------------------------------------------------------------- one-launch passes with data-tagged hand-offs
+@pytest.mark.parametrize("nc,nlev,niter", [((64, 64, 64), 4, 10), ((32, 32, 32), 3, 10), ((40, 36, 28), 3, 7), ((64, 64, 64), 4, 5)])
+def test_data_tagged_one_launch_pass_is_bitwise_the_flag_pass_and_the_sweep_loop(S, po, orc, nc, nlev, niter):
+    """sells_smooth_tag_kernel (round 5; option persist_tag = 1, levels of <= persist_tag_max_slices = 1024 slices): the s of a sweep moves through
+    three buffers that hold a signalling-NaN sentinel wherever the coming sweep's value is not written yet; a lane repeats a load that
+    returned the sentinel -- no progress words, no barriers.  Against sells_smooth_kernel (persist_tag = 0: progress words) and the
+    per-sweep launches (persist = 0) on every level >= 1: chained passes (the buffer rotation carries over from pass to pass), odd and
+    even sweep counts, levels with a ragged last slice and with MORE waves than slices (the waves past the end must not wait: nobody
+    gathers from them -- the deadlock of the first version); bit-identical, and the passes match the oracle's
+    RichardsonSmoothers.jl:84-98 loop.  (Opt-in: forced onto a level of 4 034 slices on 253 workgroups the tagged pass timed out
+    intermittently -- the handle then falls back to per-sweep launches, results stay correct -- so the progress-word pass stays the default.)"""
+    H = po.build_hierarchy(nc, nlev, 1)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, niter, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
+    res = {}
+    for key, opts in (("tag", {"persist_tag": 1}), ("flag", {"persist_tag": 0}), ("sweeps", {"persist": 0})):
+        gmg = make_gmg(S, H, pre_smoothers=jac(S, nlev, niter), options=opts)
+        ns = setup(S, gmg, H["mats"][0])
+        out = []
+        for lev in range(1, nlev - 1):
+            n = H["mats"][lev].shape[0]
+            x, r = np.random.default_rng(10 + lev).uniform(-1, 1, n), np.random.default_rng(20 + lev).uniform(-1, 1, n)
+            for rep in range(4):                                        # chained: pass k + 1 starts from the buffers pass k left
+                ns.smooth(lev, x, r)
+                out += [x.copy(), r.copy()]
+            xz, rz = np.zeros(n), np.random.default_rng(30 + lev).uniform(-1, 1, n)
+            rz[n // 2] = np.inf
+            ns.smooth(lev, xz, rz)
+            out += [np.isfinite(xz), np.where(np.isfinite(xz), xz, 0.0), np.isfinite(rz), np.where(np.isfinite(rz), rz, 0.0)]
+        b = np.random.default_rng(5).uniform(-1, 1, H["mats"][0].shape[0])
+        z = np.zeros_like(b)
+        for _ in range(3):
+            S.solve_(z, ns, b)                                          # whole V-cycles (pre and post passes on every level)
+        out.append(z.copy())
+        if key != "tag":
+            assert ns.persist_retries() == dict(retries=0, persist_active=(key != "sweeps")), (key, ns.persist_retries())
+        res[key] = out
+        ns.close()
+    for key in ("flag", "sweeps"):
+        for a, c in zip(res["tag"], res[key]):
+            np.testing.assert_array_equal(a, c)
+    n1 = H["mats"][1].shape[0]
+    xo, ro = go.smooth(1, np.random.default_rng(11).uniform(-1, 1, n1), np.random.default_rng(21).uniform(-1, 1, n1))
+    assert max_rel(res["tag"][0], xo) <= TOL_KERNEL and max_rel(res["tag"][1], ro) <= TOL_KERNEL
