@@ -213,6 +213,7 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  * value -- a debugging / A-B device, not the configuration interface.  Keys (default):
  *   storage layout   pattern (1) pat_shared (1) opattern (1) sell (1) sell_maxpad (1.25) vdict (1) idx16 (1) force_ptr64 (0)
  *                    pat_coded_min_rows (500000) eager* (1) eager_min_rows* (20000) refresh* (1)
+ *   measurement      prof_stride (7: HIP events on every n-th sweep launch of the profiled level)
  *   sweep kernels    pat_rsweep (1) pat_r2 (1: two rows per lane in the r-gather sweep) pat_r2_occ (2: its 64-register form, eight waves per SIMD, in workgroups of eight waves on big levels; 1: four waves; 0: off) pat_r2_wgs (0 = one round of workgroups) pat_tile (0: never -- levels >= pat_tile_rows (3500000) take the pair sweep with one slice per wave; 1: tile sweep on those levels; 2: wherever it applies) pat_tile_min (512)
  *                    pat_tile_t (48) pat_tile_lds (79872) pat_strict (1) pat_fma (0: products and sums rounded separately, as the
  *                    reference's mul!; 1: fused multiply-add taps in the row-pattern sweeps -- not bit-identical)
@@ -224,10 +225,14 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  *                    pat_r2mv (1: y = A x, y -= A x, y = b - A x of row-pattern levels with two rows per lane) pat_r2mv_min (100000:
  *                    smallest level, in rows, that takes it and the pair prolongation) pat_r2mv_dot (1: dot(p, A p) of CG formed by
  *                    the mat-vec kernel) pat_pair_p (1: prolongation + correction with two rows per lane)
+ *                    pat_zwalk (1: levels of >= pat_zwalk_rows (3500000) rows sweep as a walk up the grid planes -- an interval of a plane
+ *                    per wave, three new windows per step, pat_zwalk_t (12) planes per chain; 2: every level; 0: off) pat_zwalk_mv (1: their
+ *                    mat-vecs too) pat_zwalk_wide (1: the wide-row (Q2) operator applications of those levels, 25 windows in registers)
  *   reductions       red_fused (1: inside CG the second stage of every dot is done by the kernel that consumes the scalar and the
  *                    norm is reduced + posted to the host by one launch; 0: one reduce launch per dot.  Same bits either way)
  *   one-launch pass  persist (1) persist_fenced (0) persist_max_slices (0 = one workgroup per CU) persist_shared (0)
  *                    persist_wpb (1: smallest workgroup, in waves)
+ *                    persist_tag (0: opt-in -- data-tagged hand-offs instead of progress words on levels of <= persist_tag_max_slices (1024) slices)
  *   coarsest level   coarse_host_max (1500) coarse_host_fallback_max (6000) coarse_auto_cg_min (20000: a dense-inverse request on a
  *                    coarsest level of at least this many dofs is served by the device CG-Jacobi solver instead) gj_mfma (1) gj_wide_min (4096)
  *   patch smoother   patch_dedup (1) patch_source_dedup (1) patch_operator (1)
