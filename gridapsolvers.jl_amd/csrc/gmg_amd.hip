@@ -1556,10 +1556,13 @@ struct gmg_solver {
           const size_t ldsz = wide_z_lds(M, M.wz_max);
           static bool attr_z[64] = {false};
           if (!attr_z[device & 63]) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sellw_zwalk_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sellw_zwalk_kernel<EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sellw_zwalk_kernel<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             attr_z[device & 63] = true;
           }
-          hipLaunchKernelGGL((sellw_zwalk_kernel<EPI>), dim3((unsigned)nwz), dim3(256), ldsz, stream, a, M.wz_geo);
+          if (pat_fma) hipLaunchKernelGGL((sellw_zwalk_kernel<EPI, true>), dim3((unsigned)nwz), dim3(256), ldsz, stream, a, M.wz_geo);
+          else
+          hipLaunchKernelGGL((sellw_zwalk_kernel<EPI, false>), dim3((unsigned)nwz), dim3(256), ldsz, stream, a, M.wz_geo);
           HIP_CHECK(hipGetLastError());
           return;
         }

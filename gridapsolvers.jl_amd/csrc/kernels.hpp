@@ -2283,7 +2283,8 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
 // finite is redone from memory with the masks of the coded table: bit-identical to sells_kernel<EPI, false, 5, 5, true, 0, true>.
 //   a.x gathered ; a.y result (SUB: also read) ; a.b (RESID) ; a.x2 (ADDTO: x2 += omega * A x, y = omega * A x)
 // ---------------------------------------------------------------------------
-template <int EPI>
+// FM: fused multiply-add taps (option pat_fma: one rounding per tap -- not the reference's mul!, inside the parity gates)
+template <int EPI, bool FM = false>
 __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWalkGeo g)
 {
   static_assert(EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID || EPI == EPI_ADDTO, "operator applications only");
@@ -2334,6 +2335,10 @@ __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWa
     o.e0 = EPI == EPI_SET ? 0.0 : eg[r];
     return o;
   };
+  // The 25 windows live in a ring of registers: logical window q of the step with rotation R is C[(q + K R) % NR].  The step loop is
+  // unrolled over the five rotations, so "the windows move up one plane" costs nothing (shifting 20 doubles was 40 of the ~420 vector
+  // instructions of a step); the five new windows are requested into their own registers and take the places of the oldest plane
+  // group after the step.
   double C[NR];
 #pragma unroll
   for (int q = 0; q < NR; ++q) C[q] = loadw(rfirst + roff[q]);
@@ -2348,8 +2353,8 @@ __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWa
       if (EPI == EPI_ADDTO) a.x2[prow] = p1;
     }
   };
-#pragma unroll 1
-  for (int k = 0; k < nsteps; ++k) {
+  auto step = [&](auto rot_tag, int k) {
+    constexpr int R = decltype(rot_tag)::value;
     put();
     // step k + 1 (the last step: this step again, unused): requested before the taps of step k
     const int rb = rfirst + min(k + 1, nsteps - 1) * g.P;
@@ -2396,11 +2401,11 @@ __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWa
           else rd(std::integral_constant<int, ZI * K + 4>{}, cf[0]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        double v = C[ZI * K + y];
+        double v = C[((ZI + R) * K + y) % NR];
 #pragma unroll
         for (int t = 0; t < K; ++t) {
           if (t > 0) v = wave_shl1(v);
-          sum = sum + cf[y & 1][t] * v;
+          sum = FM ? __builtin_fma(cf[y & 1][t], v, sum) : sum + cf[y & 1][t] * v;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -2431,7 +2436,7 @@ __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWa
           if (t > 0) v = wave_shl1(v);
           const int code = gc[q * K + t];
           const double gv = __hiloint2double(__double2hiint(v) & ((code == 255) ? 0 : -1), __double2loint(v));
-          sum = sum + tv[q * K + t] * gv;
+          sum = FM ? __builtin_fma(tv[q * K + t], gv, sum) : sum + tv[q * K + t] * gv;
         }
       }
     }
@@ -2439,12 +2444,19 @@ __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWa
     else if (EPI == EPI_SUB || EPI == EPI_RESID) p0 = cur.e0 - sum;
     else { const double t = a.omega != 0.0 ? a.omega * sum : sum; p0 = t; p1 = cur.e0 + t; }
     prow = row; pok = mine;
+    // the oldest plane group (logical runs 0 .. 4 of this step) makes room for the new one (logical 20 .. 24 of the next step)
 #pragma unroll
-    for (int q = 0; q < NR - K; ++q) C[q] = C[q + K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) C[NR - K + q] = N[q];
+    for (int q = 0; q < K; ++q) C[(R * K + q) % NR] = N[q];
     cur = nxt;
     r0 += g.P;
+  };
+#pragma unroll 1
+  for (int k = 0; k < nsteps; k += K) {
+    step(std::integral_constant<int, 0>{}, k);
+    if (k + 1 < nsteps) step(std::integral_constant<int, 1>{}, k + 1);
+    if (k + 2 < nsteps) step(std::integral_constant<int, 2>{}, k + 2);
+    if (k + 3 < nsteps) step(std::integral_constant<int, 3>{}, k + 3);
+    if (k + 4 < nsteps) step(std::integral_constant<int, 4>{}, k + 4);
   }
   put();
 }
