@@ -109,7 +109,7 @@ def main():
         for epi in ("1", "4"):
             # round 5: levels of >= 3.5e6 rows run the z-walk form (sellw_zwalk_kernel<EPI>); smaller ones sells_kernel<EPI, ..., WL>
             rows = con.execute("select name, grid_x, max(end-start) from kernels where name like ? group by name, grid_x order by 3 desc",
-                               ("%gmg::sellw_zwalk_kernel<" + epi + ">%",)).fetchall()
+                               ("%gmg::sellw_zwalk_kernel<" + epi + ",%",)).fetchall()
             if not rows:
                 rows = con.execute("select name, grid_x, max(end-start) from kernels where name like ? group by name, grid_x order by 3 desc",
                                    ("%gmg::sells_kernel<" + epi + ",%, 5, true%",)).fetchall()
@@ -128,7 +128,7 @@ def main():
     for name, grid, avg_us, cnt in sw:
         fam = family(name)
         if a.order == 2:
-            fam = "sells_kernel_wide" if ("sells_kernel<1," in name or "sellw_zwalk_kernel<1>" in name) else "sells_kernel_wide_schwarz"
+            fam = "sells_kernel_wide" if ("sells_kernel<1," in name or "sellw_zwalk_kernel<1," in name) else "sells_kernel_wide_schwarz"
         if fam is None:
             continue
         # one record per (family, grid): the finest level and, when its batched variant runs on a smaller grid than the next
