@@ -622,7 +622,8 @@ struct gmg_solver {
   int pat_zwalk_wide = 1; // GMG_PAT_ZWALK_WIDE: the wide-row (Q2) operator applications of those levels (sellw_zwalk_kernel)
   int pat_zwalk_mv = 1; // GMG_PAT_ZWALK_MV: also the operator mat-vecs of those levels
   int pat_zwalk_T = 12; // GMG_PAT_ZWALK_T: planes per chain (288^3: 8 / 12 / 16 / 24 / 32 -> 149 / 114 / 120 / 118 / 155 us for the x-untouched form)
-  int64_t pat_zwalk_rows = 3500000;
+  int64_t pat_zwalk_rows = 9000000;   // the walk pays once r, r', x and the pattern ids (26 B per row) no longer fit the 256 MB Infinity Cache: 224^3 (1.09e7 rows) 8.13 -> 7.59 ms per solve,
+                                      // 192^3 (7.0e6) 4.89 -> 5.23-5.50 with every chain length (profiles/r05_sizes.txt)
   int pat_r2_wgs = 0;   // GMG_PAT_R2_WGS: its resident workgroups (0: four per CU, eight with pat_r2_occ)
   int pat_r2_occ = 2;   // GMG_PAT_R2_OCC: the 64-register form of the pair sweep (rolled run loop, eight waves per SIMD); 2: workgroups of eight waves at one slice per wave (big levels)
   int pat_r2mv_dot = 1; // GMG_PAT_R2MV_DOT: dot(p, A p) of CG formed by the mat-vec kernel (first stage; order of the sum differs from dot_partial_kernel's)
@@ -3280,7 +3281,7 @@ struct gmg_solver {
     pat_zwalk_T = std::max(1, opt_int("GMG_PAT_ZWALK_T", 12));
     pat_zwalk_mv = opt_int("GMG_PAT_ZWALK_MV", 1);
     pat_zwalk_wide = opt_int("GMG_PAT_ZWALK_WIDE", 1);
-    pat_zwalk_rows = opt_int("GMG_PAT_ZWALK_ROWS", 3500000);
+    pat_zwalk_rows = opt_int("GMG_PAT_ZWALK_ROWS", 9000000);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
     pat_pair_p = opt_int("GMG_PAT_PAIR_P", 1);

@@ -225,7 +225,7 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  *                    pat_r2mv (1: y = A x, y -= A x, y = b - A x of row-pattern levels with two rows per lane) pat_r2mv_min (100000:
  *                    smallest level, in rows, that takes it and the pair prolongation) pat_r2mv_dot (1: dot(p, A p) of CG formed by
  *                    the mat-vec kernel) pat_pair_p (1: prolongation + correction with two rows per lane)
- *                    pat_zwalk (1: levels of >= pat_zwalk_rows (3500000) rows sweep as a walk up the grid planes -- an interval of a plane
+ *                    pat_zwalk (1: levels of >= pat_zwalk_rows (9000000: where the vectors of a sweep outgrow the 256 MB Infinity Cache) rows sweep as a walk up the grid planes -- an interval of a plane
  *                    per wave, three new windows per step, pat_zwalk_t (12) planes per chain; 2: every level; 0: off) pat_zwalk_mv (1: their
  *                    mat-vecs too) pat_zwalk_wide (1: the wide-row (Q2) operator applications of those levels, 25 windows in registers)
  *   reductions       red_fused (1: inside CG the second stage of every dot is done by the kernel that consumes the scalar and the

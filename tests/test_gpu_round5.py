@@ -56,7 +56,7 @@ def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(
     masks from GLOBAL memory -- the `GM` branch that no small level reaches by default), and a whole CG solve.
     form = zwalk*: the same for sells_zsweep_kernel (round 5: the pair sweep as a walk along the slowest grid direction -- an interval
     of <= 126 rows of a grid plane per wave, three new windows per step, six carried in registers; default on levels of >=
-    pat_zwalk_rows = 3.5e6 rows), forced onto the small levels with pat_zwalk = 2, with chains of 12, 3 and 1 planes (chain starts
+    pat_zwalk_rows = 9e6 rows), forced onto the small levels with pat_zwalk = 2, with chains of 12, 3 and 1 planes (chain starts
     and ends in the middle of the level, planes whose row count is not a multiple of the interval, the clamped first / last planes)."""
     big_opts, big_sig = BIG_FORMS[form]
     H = po.build_hierarchy(nc, nlev, 1)
