@@ -782,7 +782,7 @@ def config3_leg(torch, pkg, args):
     lay = st["layout_bytes"] / (avg_ms * 1e-3) / 1e9 if st["launches"] else None
     tr, src = committed_traffic("sells_kernel_wide", cells, nlev, int(st["rows"]), None, order=2)
     rl = {"leg": "config3", "leg_value": n / dt, "leg_ms_per_step": dt * 1e3, "bound": "hbm",
-          "kernel": "sellw_zwalk_kernel<EPI_SUB> on levels of >= 9e6 rows (sells_kernel<EPI_SUB,...,K=5,VD,WL> below): r -= A dx of the patch sweep -- Q2 "
+          "kernel": "sellw_zwalk_kernel<EPI_SUB> on levels of >= 1e6 rows (sells_kernel<EPI_SUB,...,K=5,VD,WL> below): r -= A dx of the patch sweep -- Q2 "
                     "stiffness matrix, 125 entries per row, coded row-pattern table decoded per workgroup into LDS, the 25 windows of a row walked up the grid planes",
           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None,
           "bytes_model": "SURVEY 8(d): r -= A dx = 12 Z + 28 N -- a (col,val) stream this layout does not have: `frac` > 1 means faster than streaming "

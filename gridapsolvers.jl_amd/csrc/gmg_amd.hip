@@ -619,6 +619,8 @@ struct gmg_solver {
   int pat_bcast = 1;    // GMG_PAT_BCAST: tile sweep: slices whose DPP rows are single-pattern take their coefficients by row broadcast (no LDS read per tap)
   int pat_r2 = 1;       // GMG_PAT_R2: r-gather sweeps with two rows per lane (sells_r2sweep_kernel)
   int pat_zwalk = 1;    // GMG_PAT_ZWALK: the pair sweep as a walk along the slowest grid direction (kernels.hpp: sells_zsweep_kernel); 1: levels of >= pat_zwalk_rows rows, 2: every level
+  int64_t pat_zwalk_wide_rows = 1000000;   // GMG_PAT_ZWALK_WIDE_ROWS: smallest wide-row level that takes the walk -- it wins wherever there are enough chains (it removes gathers,
+                                           // not bytes): Q2 64^3 (2.05e6 rows) 18.6 -> 16.0 ms per solve, 96^3 (7.0e6) 40.3 -> 30.0, 128^3 89 -> 70
   int pat_zwalk_wide = 1; // GMG_PAT_ZWALK_WIDE: the wide-row (Q2) operator applications of those levels (sellw_zwalk_kernel)
   int pat_zwalk_mv = 1; // GMG_PAT_ZWALK_MV: also the operator mat-vecs of those levels
   int pat_zwalk_T = 12; // GMG_PAT_ZWALK_T: planes per chain (288^3: 8 / 12 / 16 / 24 / 32 -> 149 / 114 / 120 / 118 / 155 us for the x-untouched form)
@@ -1550,7 +1552,7 @@ struct gmg_solver {
     if (EPI == EPI_SWEEP) M.note_sweep("sells_kernel<EPI_SWEEP,%s,RB=%d,K=%d,VD=%d> wgs=%d wpb=%d", ONEG ? "ONEG" : "2G", M.pat_coded ? M.pat_k : pat_rb, M.pat_k, M.pat_coded ? 1 : 0, nwg, wpb);
     if constexpr ((EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID || EPI == EPI_ADDTO) && !ONEG) {
       // big wide-row levels: the z-walk form (five new windows per step instead of up to 25 gathers per slice)
-      if (M.pat_coded && M.pat_k == 5 && pat_zwalk && pat_zwalk_wide && !a.s_out && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_rows)) {
+      if (M.pat_coded && M.pat_k == 5 && pat_zwalk && pat_zwalk_wide && !a.s_out && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_wide_rows)) {
         const int nwz = prepare_wide_z(M);
         if (nwz > 0) {
           a.wl_pids = M.wz_pids; a.wl_cnt = M.wz_cnt; a.wl_stride = kWideStride; a.wl_max = M.wz_max;
@@ -3281,6 +3283,7 @@ struct gmg_solver {
     pat_zwalk_T = std::max(1, opt_int("GMG_PAT_ZWALK_T", 12));
     pat_zwalk_mv = opt_int("GMG_PAT_ZWALK_MV", 1);
     pat_zwalk_wide = opt_int("GMG_PAT_ZWALK_WIDE", 1);
+    pat_zwalk_wide_rows = opt_int("GMG_PAT_ZWALK_WIDE_ROWS", 1000000);
     pat_zwalk_rows = opt_int("GMG_PAT_ZWALK_ROWS", 9000000);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
@@ -5534,7 +5537,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PERSIST_TAG", false}, {"GMG_PERSIST_TAG_MAX_SLICES", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PAT_ZWALK_WIDE_ROWS", false}, {"GMG_PERSIST_TAG", false}, {"GMG_PERSIST_TAG_MAX_SLICES", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

@@ -227,7 +227,7 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  *                    the mat-vec kernel) pat_pair_p (1: prolongation + correction with two rows per lane)
  *                    pat_zwalk (1: levels of >= pat_zwalk_rows (9000000: where the vectors of a sweep outgrow the 256 MB Infinity Cache) rows sweep as a walk up the grid planes -- an interval of a plane
  *                    per wave, three new windows per step, pat_zwalk_t (12) planes per chain; 2: every level; 0: off) pat_zwalk_mv (1: their
- *                    mat-vecs too) pat_zwalk_wide (1: the wide-row (Q2) operator applications of those levels, 25 windows in registers)
+ *                    mat-vecs too) pat_zwalk_wide (1: the wide-row (Q2) operator applications of levels of >= pat_zwalk_wide_rows (1000000) rows in the same form, 25 windows in registers)
  *   reductions       red_fused (1: inside CG the second stage of every dot is done by the kernel that consumes the scalar and the
  *                    norm is reduced + posted to the host by one launch; 0: one reduce launch per dot.  Same bits either way)
  *   one-launch pass  persist (1) persist_fenced (0) persist_max_slices (0 = one workgroup per CU) persist_shared (0)
