@@ -16,6 +16,7 @@ CONVERGED_ATOL, CONVERGED_RTOL, DIVERGED_MAXITER, DIVERGED_BREAKDOWN = 0, 1, 2, 
 PRE, POST, PRE_AND_POST = 0, 1, 2
 PATCH_LU, PATCH_NOPIVOT = 0, 1
 OP_A, OP_P, OP_R = 0, 1, 2
+LEVEL_KRYLOV = -1          # GMG_LEVEL_KRYLOV: the separate Krylov operator of a finest level in the overlapping layout
 COARSE_DENSE_INVERSE, COARSE_CG_JACOBI, COARSE_HOST_CALLBACK = 0, 1, 2
 BLOCK_DIAGONAL, BLOCK_LOWER, BLOCK_UPPER = 0, 1, 2
 BLOCK_GMG, BLOCK_CG_JACOBI, BLOCK_LU, BLOCK_JACOBI = 1, 2, 3, 4
@@ -96,6 +97,7 @@ SYMBOLS = {
     "gmg_get_comm_stats": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "gmg_get_comm_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "gmg_set_replication": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64],
+    "gmg_set_krylov_map": [C.c_void_p, C.c_void_p, C.c_int64],
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
     "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],
     "gmg_get_kernel_stats_by_variant": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],

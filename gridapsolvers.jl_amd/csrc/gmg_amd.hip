@@ -476,8 +476,16 @@ struct gmg_solver {
   hipStream_t stream = nullptr;      // the stream work is issued on (a block solver re-points it at its own)
   hipStream_t own_stream = nullptr;  // the stream this handle created and destroys
   int nlev = 0;
-  std::vector<Level> lev;
+  std::vector<Level> lev;            // nlev levels + one slot (index nlev) for a separate Krylov operator, see has_outer()
   std::string err;
+  // Finest level in the overlapping layout (gmg_set_partition_overlap on level 0): the Krylov solver keeps the caller's own | ghost
+  // vectors and its own finest operator (lev[nlev]: gmg_set_matrix / gmg_set_partition with GMG_LEVEL_KRYLOV), the preconditioner's
+  // level 0 lives in the overlapping numbering; own2loc maps every owned entry to its place there (gmg_set_krylov_map).
+  std::vector<int64_t> h_own2loc;
+  int64_t *d_own2loc = nullptr;
+  bool has_outer() const { return (int)lev.size() > nlev && lev[nlev].hasA; }
+  int kl() const { return has_outer() ? nlev : 0; }                 // the level the Krylov solvers' operator and vectors belong to
+  int64_t user_n() const { return lev[kl()].n; }
   bool setup_done = false;
   bool structure_dirty = true;       // anything but values changed since the last setup
   bool was_setup = false;
@@ -730,7 +738,7 @@ struct gmg_solver {
     d_Ainv = d_partials = d_scalars = nullptr;
     d_partials2 = nullptr;
     cc_w = cc_p = cc_z = cc_r = nullptr;
-    d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr;
+    d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr; d_own2loc = nullptr;
     for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; L.halo.d_recvbuf = nullptr; L.halo.d_pk_ptr = nullptr; L.halo.d_pk_slot = nullptr; }
     cg_w = cg_p = cg_z = cg_r = st_b = st_x = nullptr;
     fg_V.clear(); fg_Z.clear(); st_extra.clear();
@@ -3094,7 +3102,7 @@ struct gmg_solver {
       cycle(0, x, r_in, x_zero, cycle_type);               // :630-637
       r_in = L0.rcur;
       x_zero = false;
-      if (single && known_res0 >= 0.0 && verbose <= 0) {
+      if (single && known_res0 >= 0.0 && (verbose <= 0 || has_outer())) {
         // maxiter == 1: update! returns true whatever the norm is (:640); the post-cycle norm is a
         // logging-only quantity here and is not evaluated unless the solver is verbose (gmg_set_verbose):
         // residuals[1] of the GMG's own log then reads NaN (documented in INTEGRATION.md).
@@ -3115,7 +3123,21 @@ struct gmg_solver {
   // 2 = JacobiLinearSolver() on the finest matrix (JacobiLinearSolvers.jl:43-47)
   void krylov_precond(int kind, double *z, const double *r, double known_res0)
   {
-    const int64_t n = lev[0].n;
+    const int64_t n = user_n();
+    if (has_outer()) {
+      // finest level in the overlapping layout: r (own | ghost numbering) -> level 0's numbering, cycle, owned entries of the
+      // correction back.  The ghost layers of r are filled by the exchange that opens the first smoothing block.
+      REQUIRE(kind == 0 || kind == 1, GMG_ERR_UNSUPPORTED, "finest level in the overlapping layout: the preconditioner is the GMG (use_precond 0 or 1)");
+      if (kind == 0) { copy(z, r, n); return; }
+      Level &L0 = lev[0];
+      const unsigned grid = (unsigned)std::max<int64_t>(1, (n + 255) / 256);
+      hipLaunchKernelGGL(halo_unpack_kernel, dim3(grid), dim3(256), 0, stream, n, d_own2loc, r, L0.rbuf[0]);
+      HIP_CHECK(hipGetLastError());
+      gmg_solve_dev(L0.x, L0.rbuf[0], known_res0 >= 0.0 ? known_res0 : norm(n, r));   // (the GMG's own norm would count ghost entries)
+      hipLaunchKernelGGL(halo_pack_kernel, dim3(grid), dim3(256), 0, stream, n, d_own2loc, L0.x, z);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     if (kind == 1) gmg_solve_dev(z, r, known_res0);
     else if (kind == 3) {
       // LinearSolverFromSmoother(pre_smoothers[1]): x = 0 ; r = copy(b) ; solve!(x,smoother,r)  (LinearSolverFromSmoothers.jl:44-50)
@@ -3395,8 +3417,9 @@ struct gmg_solver {
 KrylovOps gmg_solver::level0_ops(int use_precond)
 {
   KrylovOps ops;
-  ops.resid = [this](double *x, const double *b, double *r) { apply_A_resid(0, x, b, r); };
-  ops.apply = [this](double *x, double *y) { apply_A_set(0, x, y); };
+  const int k = kl();
+  ops.resid = [this, k](double *x, const double *b, double *r) { apply_A_resid(k, x, b, r); };
+  ops.apply = [this, k](double *x, double *y) { apply_A_set(k, x, y); };
   if (comm.nranks == 1) ops.apply_dot = [this](double *x, double *y, double *parts) { return spmv_set_dot(lev[0].A, x, y, parts); };
   if (use_precond) ops.precond = [this, use_precond](double *z, const double *r, double known) { krylov_precond(use_precond, z, r, known); };
   return ops;
@@ -4643,7 +4666,9 @@ void gmg_solver::setup()
       REQUIRE(comm.nranks > 1, GMG_ERR_STATE, "gmg_set_partition needs gmg_comm_init_* first");
       REQUIRE(!replicated, GMG_ERR_INVALID, "replicated levels take global operators, not a partition");
       if (L.halo.ovl) {
-        REQUIRE(l >= 1, GMG_ERR_UNSUPPORTED, "the finest level keeps the own | ghost layout (its vectors are the caller's): gmg_set_partition");
+        REQUIRE(l >= 1 || has_outer(), GMG_ERR_UNSUPPORTED,
+                "finest level in the overlapping layout: the Krylov operator must be given in the own | ghost layout as well "
+                "(gmg_set_matrix / gmg_set_partition with GMG_LEVEL_KRYLOV, gmg_set_krylov_map)");
         REQUIRE(L.hA.nrows == L.hA.ncols && L.hA.nrows == L.halo.n_own + L.halo.n_ghost, GMG_ERR_INVALID,
                 "overlapping layout: the local matrix must be square over all local entries on level " + std::to_string(l));
         // patch smoothers: the caller lists every patch whose dofs all lie in the local box and the blocks A[p,p] come from the local
@@ -4651,7 +4676,10 @@ void gmg_solver::setup()
         for (const Smoother *sp : {&L.pre, &L.post})
           REQUIRE(l == nlev - 1 || sp->kind == SM_JACOBI || (sp->tab && sp->tab->pcol.empty() && !sp->tab->has_blocks), GMG_ERR_UNSUPPORTED,
                   "overlapping layout: patch smoothers take their blocks from the local matrix (gmg_set_smoother_patch), patch_cols = patch_rows");
-        REQUIRE(!L.has_pcorr, GMG_ERR_UNSUPPORTED, "overlapping layout: no patch-corrected prolongation");
+        // patch-corrected prolongation (round 5): the correction patches a rank lists are the ones inside its local entries, blocks from
+        // the local matrix; dxh = P dxH is made consistent before the rhs form is applied and again before r -= A dxh (cycle())
+        REQUIRE(!L.has_pcorr || (L.pcorr.tab && !L.pcorr.tab->has_blocks), GMG_ERR_UNSUPPORTED,
+                "overlapping layout: the patch-corrected prolongation takes its blocks from the local matrix");
       } else
       REQUIRE(L.halo.n_own == L.hA.nrows && L.halo.n_own + L.halo.n_ghost == L.hA.ncols, GMG_ERR_INVALID,
               "local matrix must be n_own x (n_own+n_ghost) on level " + std::to_string(l));
@@ -4663,6 +4691,22 @@ void gmg_solver::setup()
   if (comm.nranks > 1)
     REQUIRE(rep_from >= 1 && rep_from <= nlev - 1, GMG_ERR_STATE,
             "distributed runs need gmg_set_replication: at least the coarsest level must be replicated");
+  if (has_outer()) {
+    // separate Krylov operator (GMG_LEVEL_KRYLOV): own | ghost layout over the caller's vectors, level 0 in the overlapping layout
+    Level &K = lev[nlev];
+    K.n = K.hA.nrows; K.nvec = K.hA.ncols;
+    REQUIRE(comm.nranks > 1 && lev[0].halo.present && lev[0].halo.ovl, GMG_ERR_STATE,
+            "a separate Krylov operator goes with a finest level in the overlapping layout (gmg_set_partition_overlap on level 0)");
+    REQUIRE(K.halo.present && !K.halo.ovl, GMG_ERR_STATE, "gmg_set_partition(h, GMG_LEVEL_KRYLOV, ...) missing");
+    REQUIRE(K.halo.n_own == K.hA.nrows && K.halo.n_own + K.halo.n_ghost == K.hA.ncols, GMG_ERR_INVALID,
+            "Krylov operator: the local matrix must be n_own x (n_own + n_ghost)");
+    REQUIRE((int64_t)h_own2loc.size() == K.n && K.n == lev[0].halo.n_own, GMG_ERR_INVALID,
+            "gmg_set_krylov_map: one local id of level 0 per owned entry");
+    for (int64_t q : h_own2loc) REQUIRE(q >= 0 && q < lev[0].n, GMG_ERR_INVALID, "gmg_set_krylov_map: local id out of range");
+    REQUIRE(mode == GMG_MODE_PRECONDITIONER && log.maxiter == 1, GMG_ERR_UNSUPPORTED,
+            "finest level in the overlapping layout: the GMG runs as a preconditioner with maxiter = 1");
+  } else
+    REQUIRE((int)lev.size() <= nlev || !lev[nlev].halo.present, GMG_ERR_STATE, "gmg_set_partition(GMG_LEVEL_KRYLOV) without gmg_set_matrix(GMG_LEVEL_KRYLOV)");
   for (int l = 0; l < nlev - 1; ++l) {
     Level &L = lev[l];
     REQUIRE(L.hasP, GMG_ERR_STATE, "gmg_set_prolongation missing for level " + std::to_string(l));
@@ -4686,7 +4730,7 @@ void gmg_solver::setup()
     for (int64_t g : h_rep_gid) REQUIRE(g >= 0 && g < lev[rep_from].n, GMG_ERR_INVALID, "replication: global id out of range");
   }
   init_reductions();
-  for (int l = 0; l < nlev; ++l) {
+  for (int l = 0; l < nlev + (has_outer() ? 1 : 0); ++l) {   // (index nlev: the separate Krylov operator -- matrix and exchange plan only)
     Level &L = lev[l];
     if (L.halo.present && comm.nranks > 1 && L.halo.ovl) {
       // overlapping layout: one square local operator over all local entries -- laid out like a single-GPU level (row patterns,
@@ -4753,8 +4797,8 @@ void gmg_solver::setup()
     else
     L.A = upload_csr(L.hA);                                 // :185 gmg_compute_matrices
     lap("A: upload + layout", l);
-    L.rbuf[0] = dvec(L.nvec);                               // :187,188 rh / rH
-    if (l > 0) L.x = dvec(L.nvec);                          // :188 dxH
+    if (l < nlev) L.rbuf[0] = dvec(L.nvec);                 // :187,188 rh / rH
+    if (l > 0 ? l < nlev : has_outer()) L.x = dvec(L.nvec); // :188 dxH (level 0: only when the Krylov vectors live in another numbering)
     if (L.halo.present) {
       alloc_plan_buffers(L.halo);
     }
@@ -4775,7 +4819,7 @@ void gmg_solver::setup()
       const bool need_diag = (L.pre.kind == SM_JACOBI) || (L.post.kind == SM_JACOBI);
       REQUIRE(!(need_diag && nzero > 0), GMG_ERR_SINGULAR, "zero diagonal entry on level " + std::to_string(l));
       if (L.has_pcorr) {
-        if (comm.nranks > 1 && L.halo.present) {
+        if (comm.nranks > 1 && L.halo.present && !L.halo.ovl) {
           // distributed (PatchTransferOperators.jl:153-172 on PVectors): the correction patches (coarse-cell interiors) must lie
           // inside the owned dofs -- their blocks are then rows / columns of the own x own part of the local matrix
           REQUIRE(L.pcorr.tab && !L.pcorr.tab->has_blocks, GMG_ERR_UNSUPPORTED, "distributed patch prolongation: blocks come from the level matrix");
@@ -4806,7 +4850,8 @@ void gmg_solver::setup()
   }
   build_coarse();                                           // :195 gmg_coarse_solver_caches
   lap("coarse inverse", nlev - 1);
-  const int64_t n0 = lev[0].nvec;
+  const int64_t n0 = lev[kl()].nvec;
+  if (has_outer()) d_own2loc = upload(h_own2loc);
   cg_w = dvec(n0); cg_p = dvec(n0); cg_z = dvec(n0); cg_r = dvec(n0);
   st_b = dvec(n0); st_x = dvec(n0);
   if (comm.nranks > 1) {
@@ -4955,6 +5000,14 @@ void check_level(gmg_handle_t h, int lev, bool not_coarsest)
   REQUIRE(lev >= 0 && lev < h->nlev, GMG_ERR_INVALID, "level out of range");
   if (not_coarsest) REQUIRE(lev < h->nlev - 1, GMG_ERR_INVALID, "level must not be the coarsest");
 }
+// level index of the entry points that also take the separate Krylov operator (GMG_LEVEL_KRYLOV -> the slot behind the levels)
+int slot_of(gmg_handle_t h, int lev)
+{
+  REQUIRE(h, GMG_ERR_INVALID, "null handle");
+  if (lev == GMG_LEVEL_KRYLOV) return h->nlev;
+  check_level(h, lev, false);
+  return lev;
+}
 // exchange plan of one vector space (PartitionedArrays: assembly neighbours + local indices), validated
 void fill_plan_checked(HaloPlan &H, const Comm &comm, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
                        const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr, const int64_t *rcv_idx, int depth);
@@ -5033,7 +5086,7 @@ int gmg_create(gmg_handle_t *out, int nlevels, int device_id)
     gmg_solver *s = new gmg_solver();
     s->device = device_id;
     s->nlev = nlevels;
-    s->lev.resize(nlevels);
+    s->lev.resize(nlevels + 1);                             // + the slot of a separate Krylov operator (GMG_LEVEL_KRYLOV)
     s->log.configure(100, 1.0e-14, 1.0e-8); // GMGLinearSolvers.jl:58 defaults
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -5085,14 +5138,14 @@ int gmg_set_matrix(gmg_handle_t h, int lev, int64_t nrows, int64_t ncols, int64_
                    const void *idx, const double *val, int layout, int index_base, int index_bytes)
 {
   return guarded(h, [&] {
-    check_level(h, lev, false);
+    const int slot = slot_of(h, lev);
     REQUIRE(nrows == ncols || h->comm.nranks > 1, GMG_ERR_INVALID, "level matrix must be square");
-    Level &L = h->lev[lev];
+    Level &L = h->lev[slot];
     L.sA.reset();
     L.clear_split();                                        // (a split stream of an earlier gmg_set_operator_rows is gone with it)
     L.input_layout = layout;
     L.csc_perm.clear(); L.csc_perm.shrink_to_fit();
-    if (lev < h->nlev - 1 && h->try_eager_pattern(L.sA, 0, nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes)) {
+    if (slot < h->nlev - 1 && h->try_eager_pattern(L.sA, 0, nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes)) {
       L.hA = HostCSR(); L.hA.nrows = nrows; L.hA.ncols = ncols;     // shape only
     } else
     L.hA = convert_input(nrows, ncols, nnz, ptr, idx, val, layout, index_base, index_bytes);
@@ -5687,13 +5740,15 @@ int gmg_apply(gmg_handle_t h, const double *b, double *x, int memspace, gmg_resu
   return guarded(h, [&] {
     check_ready(h);
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
-    h->with_persist_retry(x, h->lev[0].n, memspace, h->mode == GMG_MODE_PRECONDITIONER, [&] {
-      const int64_t n = h->lev[0].n;
+    h->with_persist_retry(x, h->user_n(), memspace, h->mode == GMG_MODE_PRECONDITIONER, [&] {
+      const int64_t n = h->user_n();
       const double *db = h->in_vec(b, n, memspace, h->st_b);
       const bool dist = h->comm.nranks > 1;
       double *dx = dist ? h->cg_x : ((memspace == GMG_MEM_DEVICE) ? x : h->st_x);
       if (h->mode == GMG_MODE_SOLVER) h->in_guess(dx, x, n, memspace);   // :preconditioner overwrites x with zeros first (GMGLinearSolvers.jl:619)
-      const double last = h->gmg_solve_dev(dx, db, -1.0);
+      double last = NAN;
+      if (h->has_outer()) h->krylov_precond(1, dx, db, -1.0);   // finest level in the overlapping layout: through level 0's numbering
+      else last = h->gmg_solve_dev(dx, db, -1.0);
       h->out_vec(x, dx, n, memspace);
       h->log.export_to(res, hist, hist_cap, last);
     });
@@ -5708,9 +5763,9 @@ int gmg_cg_solve(gmg_handle_t h, const double *b, double *x, int memspace, int m
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
-    h->with_persist_retry(x, h->lev[0].n, memspace, false, [&] {
+    h->with_persist_retry(x, h->user_n(), memspace, false, [&] {
       gmg_solver &S = *h;
-      Level &L0 = S.lev[0];
+      Level &L0 = S.lev[S.kl()];
       const int64_t n = L0.n;
       const double *db = S.in_vec(b, n, memspace, S.st_b);
       const bool dist = S.comm.nranks > 1;
@@ -5744,9 +5799,9 @@ int gmg_fgmres_solve_pl(gmg_handle_t h, const double *b, double *x, int memspace
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(m0 >= 1 && m_add >= 1 && maxiter >= 0, GMG_ERR_INVALID, "bad FGMRES sizes");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
-    h->with_persist_retry(x, h->lev[0].n, memspace, false, [&] {
+    h->with_persist_retry(x, h->user_n(), memspace, false, [&] {
       gmg_solver &S = *h;
-      Level &L0 = S.lev[0];
+      Level &L0 = S.lev[S.kl()];
       const int64_t n = L0.n;
       const double *db = S.in_vec(b, n, memspace, S.st_b);
       const bool dist = S.comm.nranks > 1;
@@ -5775,6 +5830,7 @@ int gmg_richardson_solve(gmg_handle_t h, const double *b, double *x, int memspac
     REQUIRE(b && x, GMG_ERR_INVALID, "null vector");
     REQUIRE(maxiter >= 0, GMG_ERR_INVALID, "maxiter < 0");
     REQUIRE(use_precond >= 0 && use_precond <= 3, GMG_ERR_INVALID, "use_precond must be 0, 1, 2 or 3");
+    REQUIRE(!h->has_outer(), GMG_ERR_UNSUPPORTED, "finest level in the overlapping layout: CG / FGMRES only");
     h->with_persist_retry(x, h->lev[0].n, memspace, false, [&] {
       gmg_solver &S = *h;
       const int64_t n = S.lev[0].n;
@@ -6074,10 +6130,20 @@ int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, i
                       const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr)
 {
   return guarded(h, [&] {
-    check_level(h, lev, false);
+    const int slot = slot_of(h, lev);
     REQUIRE(n_own >= 0 && n_ghost >= 0 && nnbr >= 0, GMG_ERR_INVALID, "negative sizes");
     REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
-    fill_plan(h->lev[lev].halo, h->comm, n_own, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr);
+    fill_plan(h->lev[slot].halo, h->comm, n_own, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr);
+    h->touch();
+  });
+}
+
+int gmg_set_krylov_map(gmg_handle_t h, const int64_t *own_to_local, int64_t n_own)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    REQUIRE(n_own >= 0 && (n_own == 0 || own_to_local), GMG_ERR_INVALID, "null map");
+    h->h_own2loc.assign(own_to_local, own_to_local + n_own);
     h->touch();
   });
 }

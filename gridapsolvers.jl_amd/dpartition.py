@@ -19,7 +19,7 @@ import scipy.sparse as sp
 
 from . import poisson as po
 
-__all__ = ["Space", "partition_spaces", "local_operator", "local_patches"]
+__all__ = ["Space", "partition_spaces", "local_operator", "local_patches", "OverlapSpace"]
 
 
 class Space:
@@ -131,3 +131,93 @@ def local_patches(pp, pd, spc, powner, rank, A_global=None):
             blocks.append(Ag[g][:, g].toarray().reshape(-1, order="F"))
     cat = (lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt))
     return ptr, cat(loc, np.int64), cat(glob, np.int64), (cat(blocks, np.float64) if Ag is not None else None)
+
+
+class OverlapSpace:
+    """A vector space in the OVERLAPPING layout (gmg_set_partition_overlap) for operators that exist as global sparse matrices --
+    the general counterpart of partition._OverlapGeom, e.g. the vector-valued Q2 velocity levels of the Stokes hierarchy
+    (test/Applications/mpi/StokesGMG.jl:5-12; both components of a node share its coordinates).
+
+    coords[i] = integer node coordinates of global dof i; a rank owns the dofs of a node box.  Its local entries are ALL dofs whose
+    node lies in that box extended by `layers` node layers, numbered by ascending global id -- owned and ghost entries interleaved,
+    so an owned row of a local operator is summed in the order of the single-GPU run.  layers = depth * reach with
+    reach = order for Richardson(Jacobi), 3 order - 2 for Richardson(PatchSolver) on vertex stars (partition._OverlapGeom)."""
+
+    def __init__(self, name, owner, coords, nranks, layers):
+        self.name, self.nranks, self.layers = name, int(nranks), int(layers)
+        self.owner = np.asarray(owner, dtype=np.int64)
+        self.n = self.owner.size
+        X = np.asarray(coords, dtype=np.int64).reshape(self.n, -1)
+        self.own = [np.nonzero(self.owner == r)[0].astype(np.int64) for r in range(nranks)]
+        self.ext, self.g2l, self.is_own = [], [], []
+        for r in range(nranks):
+            lo, hi = X[self.own[r]].min(axis=0) - self.layers, X[self.own[r]].max(axis=0) + self.layers
+            e = np.nonzero(((X >= lo) & (X <= hi)).all(axis=1))[0].astype(np.int64)      # ascending global id
+            assert np.isin(self.own[r], e).all()
+            m = -np.ones(self.n, dtype=np.int64)
+            m[e] = np.arange(e.size)
+            self.ext.append(e); self.g2l.append(m); self.is_own.append(self.owner[e] == r)
+        self.plan = []
+        for r in range(nranks):
+            nbr, snd_ptr, rcv_ptr, snd, rcv = [], [0], [0], [], []
+            for q in range(nranks):
+                if q == r:
+                    continue
+                mine_at_q = self.ext[q][self.owner[self.ext[q]] == r]         # what q holds of my owned dofs, ascending id
+                theirs = self.ext[r][self.owner[self.ext[r]] == q]
+                if mine_at_q.size == 0 and theirs.size == 0:
+                    continue
+                nbr.append(q); snd.append(self.g2l[r][mine_at_q]); rcv.append(self.g2l[r][theirs])
+                snd_ptr.append(snd_ptr[-1] + mine_at_q.size); rcv_ptr.append(rcv_ptr[-1] + theirs.size)
+            cat = (lambda xs: np.concatenate(xs).astype(np.int64) if xs else np.zeros(0, np.int64))
+            assert rcv_ptr[-1] == self.ext[r].size - self.own[r].size
+            self.plan.append(dict(nbr_rank=np.asarray(nbr, dtype=np.int32), snd_ptr=np.asarray(snd_ptr, dtype=np.int64), snd_idx=cat(snd),
+                                  rcv_ptr=np.asarray(rcv_ptr, dtype=np.int64), rcv_idx=cat(rcv)))
+
+    def n_local(self, r):
+        return int(self.ext[r].size)
+
+    def n_own(self, r):
+        return int(self.own[r].size)
+
+    def own_idx(self, r):
+        return self.g2l[r][self.own[r]]
+
+    def square(self, A, rank):
+        """A[ext, ext]: rows of ghost entries are the true global rows restricted to the local columns"""
+        e = self.ext[rank]
+        M = A.tocsr()[e][:, e].tocsr()
+        M.sort_indices()
+        return po.CSR(M.shape, M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data)
+
+    def patches(self, pp, pd, rank):
+        """every patch whose dofs ALL lie among the local entries, in the serial order, local numbering (blocks A[p,p] are then exact
+        in the local matrix: gmg_set_smoother_patch / gmg_set_prolongation_patch_correction, no caller-assembled matrices)"""
+        m = self.g2l[rank]
+        ptr, loc = [0], []
+        for p in range(pp.size - 1):
+            l = m[pd[pp[p]:pp[p + 1]].astype(np.int64)]
+            if l.size and (l >= 0).all():
+                loc.append(l); ptr.append(ptr[-1] + l.size)
+        return np.asarray(ptr, dtype=np.int64), (np.concatenate(loc).astype(np.int64) if loc else np.zeros(0, np.int64))
+
+
+def sliced_operator(M, rows, colmap=None, keep_row=None, ncols=None, strict_rows=None):
+    """Rows `rows` (global ids, in that order) of the global operator M with the columns renumbered through `colmap` (global ->
+    local id, -1 = not held by this rank: such entries are DROPPED -- in the overlapping layout they belong to rows of ghost layers the
+    next exchange refreshes; colmap None = global columns as they are).  keep_row[i] False empties row i (R in the overlapping layout:
+    the rows of non-owned coarse entries, whose residual arrives with the exchange that opens the smoothing block).  strict_rows: a
+    mask of rows that must not lose an entry (the owned ones)."""
+    S = M.tocsr()[np.asarray(rows, dtype=np.int64)].tocoo()
+    r, c, v = S.row, S.col.astype(np.int64), S.data
+    if colmap is not None:
+        c = colmap[c]
+    keep = c >= 0
+    if strict_rows is not None:
+        assert keep[np.asarray(strict_rows)[r]].all(), "an owned row references a dof outside the local entries: more ghost layers needed"
+    if keep_row is not None:
+        keep &= np.asarray(keep_row)[r]
+    nc = int(ncols if ncols is not None else M.shape[1])
+    L = sp.csr_matrix((v[keep], (r[keep], c[keep])), shape=(len(rows), nc))
+    L.sort_indices()
+    return po.CSR(L.shape, L.indptr.astype(np.int64), L.indices.astype(np.int32), L.data)

@@ -77,7 +77,7 @@ class DistributedGMG:
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
                  gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None,
                  smoother="jacobi", depth=None, patch_tables=None, pcorr_tables=None, cells_global=None, options=None,
-                 stream_rows=0):
+                 stream_rows=0, finest_depth=0):
         """smoother = "jacobi": Richardson(Jacobi, niter, omega); "patch": Richardson(PatchSolver, niter, omega) with the
         vertex-star patches OWNED by this rank (partition.local_vertex_star_patches) and caller-assembled patch matrices --
         a rank's local matrix has the owned rows only, so the blocks of patches reaching into ghost dofs come from the
@@ -91,6 +91,9 @@ class DistributedGMG:
         (PatchProlongationOperator, PatchTransferOperators.jl:153-172) with its rhs form.
         depth: ghost layers of the OVERLAPPING layout on the partitioned levels >= 1 (int or per-level list; None / 0 = every level in
         the own | ghost layout): one halo exchange per `depth` sweeps instead of one per sweep (gmg_set_partition_overlap).
+        finest_depth > 0: the finest level in the overlapping layout as well -- the Krylov solver keeps the caller's own | ghost vectors
+        and its own finest operator (GMG_LEVEL_KRYLOV: gmg_set_matrix / gmg_set_partition / gmg_set_krylov_map), the preconditioner's
+        level 0 smooths in the extended-box numbering with one exchange per `finest_depth` sweeps.
         stream_rows > 0: the operators of the levels that are laid out like a single-GPU level -- overlapping layout, replicated levels
         -- are handed over in blocks of that many rows (gmg_set_operator_rows): the library keeps their row-pattern form only, never
         a CSR copy (what a per-rank assembler that produces its rows plane by plane would do)."""
@@ -106,7 +109,7 @@ class DistributedGMG:
         # (an anisotropic mesh would change the iteration count with the rank grid)
         self.lengths = lengths
         self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order, lengths, rep_from,
-                                                                  depth, smoother)
+                                                                  depth, smoother, finest_depth=finest_depth)
         self.t_assembly = time.perf_counter() - t0
         self.order = order
         h = C.c_void_p()
@@ -183,6 +186,16 @@ class DistributedGMG:
                         gp, gi = np.ascontiguousarray(G.ptr, dtype=np.int64), np.ascontiguousarray(G.idx, dtype=np.int64)
                         abi.check(h, lib.gmg_set_prolongation_patch_correction_rhs(h, l, G.shape[0], G.nnz, C.c_void_p(gp.ctypes.data),
                                                                                    C.c_void_p(gi.ctypes.data), C.c_void_p(G.val.ctypes.data), abi.CSR, 0, 8))
+        K = self.local.get("krylov") if world > 1 else None
+        if K is not None:
+            # finest level in the overlapping layout: the Krylov operator in the caller's own | ghost numbering + the owned entries' places
+            nbr = np.ascontiguousarray(K.nbr_rank, dtype=np.int32)
+            sp, si, rp, o2l = (np.ascontiguousarray(a, dtype=np.int64) for a in (K.snd_ptr, K.snd_idx, K.rcv_ptr, K.own_idx))
+            self._keep += [nbr, sp, si, rp, o2l]
+            abi.check(h, lib.gmg_set_partition(h, abi.LEVEL_KRYLOV, K.n_own, K.n_ghost, nbr.size, C.c_void_p(nbr.ctypes.data),
+                                               C.c_void_p(sp.ctypes.data), C.c_void_p(si.ctypes.data), C.c_void_p(rp.ctypes.data)))
+            self._set(lib.gmg_set_matrix, abi.LEVEL_KRYLOV, K.A)
+            abi.check(h, lib.gmg_set_krylov_map(h, C.c_void_p(o2l.ctypes.data), o2l.size))
         if world > 1:
             gid = self.local["rep_gid"]
             self._keep.append(gid)
@@ -276,7 +289,7 @@ class DistributedGMG:
         """Owned part of the Dirichlet-lift rhs of u = x1 + x2 (reference test problem, f = 0): u is in the FE space, so
         A_ff u_f + A_fd u_d = 0 and b = -A_fd u_d = A_ff u_f -- evaluated with this rank's local rows on the nodal values of its
         [own | ghost] dofs; nothing of global size is formed (576^3 nodes at 8 x 288^3)."""
-        L0 = self.local["levels"][0]
+        L0 = self.local.get("krylov") or self.local["levels"][0]   # (the own | ghost rows: the Krylov operator when level 0 overlaps)
         u = self._nodal_u(np.concatenate([L0.own_gid, L0.ghost_gid]))
         return np.ascontiguousarray(L0.A.matvec(u))
 
@@ -393,8 +406,10 @@ def _pass_us(n_own_cells, depth, niter, m=MODEL):
 
 def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, depth_choices=(0, 1, 2, 3, 5, 10)):
     """(rep_from, depths, table): replicate every level whose GLOBAL size is <= rep_rows dofs (latency-bound: redundant compute beats
-    any exchange); give every other level >= 1 the halo depth that minimises the modelled smoothing-pass time.  The finest level
-    keeps the own | ghost layout (its own x own kernel hides the exchange)."""
+    any exchange); give every other level the halo depth that minimises the modelled smoothing-pass time.  The finest level keeps the
+    own | ghost layout while its own x own kernel hides the exchange (288^3 cells per GPU: 215 us per sweep against 60 us); below
+    ~170^3 cells per rank a sweep is shorter than the exchange and the finest level goes into the overlapping layout as well (depths[0]
+    > 0: DistributedGMG(finest_depth=...), separate Krylov operator), charged with its two index passes per V-cycle."""
     grid = pa.rank_grid(world, 3)
     rep_rows = int(os.environ.get("GMG_REP_ROWS", rep_rows))
     rep_from = nlevels - 1
@@ -408,15 +423,22 @@ def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, de
         if l >= rep_from or world == 1:
             table.append(dict(level=l, cells_per_rank=c, layout="replicated" if world > 1 else "single GPU"))
             continue
-        cand = {k: _pass_us(c, k, niter) for k in depth_choices if k == 0 or (l >= 1 and k <= niter and c >= 2)}
-        best = 0 if l == 0 else min(cand, key=cand.get)
+        cand = {k: _pass_us(c, k, niter) for k in depth_choices if k == 0 or (k <= niter and c >= 2)}
+        if l == 0:
+            # r scattered into / z gathered from the extended-box numbering: two launches of 16 B per owned row per V-cycle = per two passes
+            idx_us = max(MODEL["launch_floor_us"], c ** 3 * 16.0 / 4.0e6)
+            cand = {k: v + (idx_us if k > 0 else 0.0) for k, v in cand.items()}
+        best = min(cand, key=cand.get)
         depths[l] = best
         table.append(dict(level=l, cells_per_rank=c, layout="own|ghost, exchange overlapped" if best == 0 else f"overlapping, depth {best}",
                           modelled_pass_us={str(k): round(v, 1) for k, v in cand.items()},
                           exchanges_per_pass=niter if best == 0 else -(-niter // best)))
     env = os.environ.get("GMG_HALO_DEPTH")
     if env is not None:
-        depths = [0] + [int(env) if l < rep_from else 0 for l in range(1, nlevels)]
+        depths = [depths[0]] + [int(env) if l < rep_from else 0 for l in range(1, nlevels)]
+    env0 = os.environ.get("GMG_FINEST_DEPTH")
+    if env0 is not None and world > 1:
+        depths[0] = int(env0)
     return rep_from, depths, table
 
 
@@ -467,7 +489,8 @@ def run_bench(args, rank, world, local_rank):
             transport = "host"
     if transport != "host":
         try:
-            g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from, depth=depths)
+            g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from, depth=depths,
+                               finest_depth=depths[0])
         except Exception as e:
             err = e
         if not all_ok(g is not None):
@@ -485,7 +508,8 @@ def run_bench(args, rank, world, local_rank):
             transport = "host"
     if transport == "host":
         group = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else None
-        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths, rep_from=rep_from, depth=depths)
+        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="host", group=group, lengths=lengths, rep_from=rep_from, depth=depths,
+                           finest_depth=depths[0])
     b = g.rhs_lin()
     bd = torch.from_numpy(b).cuda()
     xd = torch.zeros(g.n_own, dtype=torch.float64, device="cuda")
@@ -511,7 +535,8 @@ def run_bench(args, rank, world, local_rank):
             print("[bench] overlapped halo exchange gave a wrong solution; retrying with GMG_OVERLAP=0", flush=True, file=sys.stderr)
         os.environ["GMG_OVERLAP"] = "0"
         g.close()
-        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from, depth=depths)
+        g = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport="rccl", lengths=lengths, rep_from=rep_from, depth=depths,
+                           finest_depth=depths[0])
         overlap_note = "in-stream halo exchange (overlap disabled after a failed self-check)"
         degraded = True
         if not sane():
@@ -601,7 +626,7 @@ def run_bench(args, rank, world, local_rank):
         gg = None
         try:
             gg = DistributedGMG(nc, nlev, rank, world, device_id=local_rank, transport=transport, group=group, lengths=lengths, rep_from=rep_from,
-                                depth=depths, options=GENERIC_OPTIONS)
+                                depth=depths, options=GENERIC_OPTIONS, finest_depth=depths[0])
         except Exception as e:
             err = e
         if all_ok(gg is not None):

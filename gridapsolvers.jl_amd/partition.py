@@ -391,14 +391,18 @@ def _restr_tables_ext(nc_coarse_global, order, c_elo, c_ehi, clo, chi, felo, feh
     return n, c, v
 
 
-def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None, rep_from=None, depth=None, smoother="jacobi"):
+def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None, rep_from=None, depth=None, smoother="jacobi",
+                          finest_depth=0):
     """Local operators of `rank` for every level.
 
     Levels >= rep_from are REPLICATED (global operators on every rank, no halo); by default only the
     coarsest level is.  `depth`: None / 0 = every partitioned level in the own | ghost layout (one exchange per mat-vec); an int or a
     per-level list = ghost layers of the OVERLAPPING layout on the partitioned levels >= 1 (`LocalLevel.overlap`: one local numbering
     over the extended box, square local matrix, one exchange per `depth` sweeps; any order; `smoother` = "jacobi" or "patch" sets how
-    many node layers a sweep consumes, see _OverlapGeom).  Returns dict(levels=[LocalLevel...],
+    many node layers a sweep consumes, see _OverlapGeom).  finest_depth > 0: the FINEST level in the overlapping layout too -- the
+    preconditioner's level 0 then lives in the extended-box numbering while the Krylov solver keeps the caller's own | ghost vectors:
+    the dict gains "krylov" = the finest operator in the own | ghost layout (a LocalLevel with A and the exchange plan) whose
+    `own_idx` maps every owned entry to its local id on level 0 (gmg_set_krylov_map).  Returns dict(levels=[LocalLevel...],
     rep_from, rep_gid (global ids, in level rep_from numbering, of the rows this rank's boundary restriction produces), cells, grid)."""
     nc = tuple(int(c) for c in cells_global_fine)
     d = len(nc)
@@ -414,7 +418,7 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
     if depth is None:
         depth = 0
     depths = [int(depth)] * nlevels if np.isscalar(depth) else [int(v) for v in depth] + [0] * (nlevels - len(depth))
-    depths[0] = 0                    # the finest level's vectors are the caller's: own | ghost
+    depths[0] = int(finest_depth or 0)   # the finest level's vectors are the caller's (own | ghost) unless a separate Krylov operator is built
     for l in range(nlevels):
         if l >= rep_from or nranks == 1:
             depths[l] = 0
@@ -437,9 +441,31 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
             return [(ogeoms[l].rng[k][2], ogeoms[l].rng[k][3]) for k in range(3)], None
         return [(geoms[l].rng[k][2], geoms[l].rng[k][3]) for k in range(3)], geoms[l].remap
 
+    def own_ghost_level(l):
+        L = LocalLevel()
+        g = geoms[l]
+        tabs = [_axis_tables_local(cells[l][k], order, *g.rng[k], k < d, Ls[k]) for k in range(3)]
+        ncols = [t[0] for t in tabs]
+        cols = [t[1] for t in tabs]
+        K = [t[2] for t in tabs]
+        M = [t[3] for t in tabs]
+        terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
+        if d == 3:
+            terms.append((M[0], M[1], K[2]))
+        L.A = g.remap(po._tensor_csr(cols, terms, ncols))
+        L.n_own, L.n_ghost = g.n_own, g.n_ghost
+        L.own_gid, L.ghost_gid = g.own_gid, g.ghost_gid
+        L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr = _exchange_plan(g)
+        return L
+
     levels = []
+    krylov = None
     for l in range(nlevels):
         L = LocalLevel()
+        if l == 0 and l < rep_from and ogeoms[0] is not None:
+            krylov = own_ghost_level(0)
+            krylov.own_idx = ogeoms[0].own_idx        # owned entries (ascending global id on both sides) -> local ids on level 0
+            assert np.array_equal(krylov.own_gid, ogeoms[0].own_gid)
         if l < rep_from and ogeoms[l] is not None:
             og = ogeoms[l]
             tabs = [_axis_tables_local(cells[l][k], order, og.rng[k][2], og.rng[k][3], og.rng[k][2], og.rng[k][3], k < d, Ls[k]) for k in range(3)]
@@ -457,19 +483,7 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
             L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr, L.rcv_idx = og.plan()
             L.ghost_gid = og.gid[L.rcv_idx]
         elif l < rep_from:
-            g = geoms[l]
-            tabs = [_axis_tables_local(cells[l][k], order, *g.rng[k], k < d, Ls[k]) for k in range(3)]
-            ncols = [t[0] for t in tabs]
-            cols = [t[1] for t in tabs]
-            K = [t[2] for t in tabs]
-            M = [t[3] for t in tabs]
-            terms = [(K[0], M[1], M[2]), (M[0], K[1], M[2])]
-            if d == 3:
-                terms.append((M[0], M[1], K[2]))
-            L.A = g.remap(po._tensor_csr(cols, terms, ncols))
-            L.n_own, L.n_ghost = g.n_own, g.n_ghost
-            L.own_gid, L.ghost_gid = g.own_gid, g.ghost_gid
-            L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr = _exchange_plan(g)
+            L = own_ghost_level(l)
         else:
             L.A = po.poisson_matrix(cells[l][:d], order, lengths)
             L.n_own, L.n_ghost = L.A.shape[0], 0
@@ -508,4 +522,4 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
             levels[l].P = po.prolongation(cells[l + 1][:d], order)
             levels[l].R = levels[l].P.transpose()
     return dict(levels=levels, rep_from=rep_from, rep_gid=np.ascontiguousarray(rep_gid, dtype=np.int64),
-                cells=[c[:d] for c in cells], grid=grid[:d], order=order, rank=rank, nranks=nranks, depths=depths)
+                cells=[c[:d] for c in cells], grid=grid[:d], order=order, rank=rank, nranks=nranks, depths=depths, krylov=krylov)

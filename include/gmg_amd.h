@@ -372,7 +372,7 @@ GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_
  * one exchange makes `depth` layers consistent.  A smoothing pass of Richardson(Jacobi) then communicates once per `depth`
  * sweeps instead of once per sweep: ghost layer j is recomputed redundantly and stays exact for depth - j sweeps, owned rows are
  * exact throughout and are summed in the order of a single-GPU run.  Transfers: P_lev has a row per local entry of level lev, R_lev's
- * rows of non-owned coarse entries are empty.  Levels >= 1 with Jacobi smoothers; the finest level keeps gmg_set_partition.
+ * rows of non-owned coarse entries are empty.  Levels >= 1; the finest level too when the Krylov operator is given separately (below).
  * snd_idx / rcv_idx: local ids (0-based) sent to / received from each neighbour, both sides enumerating in the same (global) order.
  * Reference analogue: consistent!(::PVector) once per mul! (RichardsonSmoothers.jl:94 through PartitionedArrays) -- here once per
  * `depth` applications.
@@ -383,6 +383,21 @@ GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_
 GMG_API int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, int64_t n_ghost, int depth, int nnbr,
                                       const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
                                       const int64_t *rcv_ptr, const int64_t *rcv_idx);
+/* FINEST level in the overlapping layout (round 5).  The Krylov solver's vectors are the caller's -- own | ghost numbering, its dot
+ * products run over owned entries -- so the solver then holds TWO finest operators: the preconditioner's level 0 in the overlapping
+ * layout (gmg_set_partition_overlap(h, 0, ...), gmg_set_matrix(h, 0, square local matrix), P_0 / R_0 in that numbering) and the
+ * Krylov operator in the own | ghost layout, passed through the same entry points with lev = GMG_LEVEL_KRYLOV:
+ *   gmg_set_partition(h, GMG_LEVEL_KRYLOV, n_own, n_ghost, ...) ; gmg_set_matrix(h, GMG_LEVEL_KRYLOV, n_own x (n_own + n_ghost), ...)
+ *   gmg_set_krylov_map(h, own_to_local, n_own)   -- local id, in level 0's overlapping numbering, of every owned entry.
+ * gmg_cg_solve / gmg_fgmres_solve / gmg_apply take vectors of n_own entries; applying the preconditioner scatters r into level 0's
+ * numbering (the first smoothing block's exchange fills the ghost layers), runs the cycle, and gathers the owned entries of the
+ * correction: the finest smoothing passes then communicate once per `depth` sweeps like every other overlapping level, at the price
+ * of (n_local - n_own) redundant rows and 32 bytes per owned row for the two index passes.  Worth it when the finest sweep is
+ * shorter than a halo exchange (multigpu.plan_partition decides; at BASELINE config 4's 288^3 cells per GPU it is not).
+ * The GMG runs as a preconditioner with maxiter = 1 in this form (its own residual norms would count ghost entries).
+ * Reference analogue: none -- PartitionedArrays exchanges once per mul! (RichardsonSmoothers.jl:94). */
+#define GMG_LEVEL_KRYLOV (-1)
+GMG_API int gmg_set_krylov_map(gmg_handle_t h, const int64_t *own_to_local, int64_t n_own);
 /* Halo exchanges and all-reduces this handle has issued since gmg_create (either may be NULL). */
 GMG_API int gmg_get_comm_stats(gmg_handle_t h, int64_t *n_exchanges, int64_t *n_allreduces);
 /* What the handle communicates through: *transport = 0 none / 1 RCCL / 2 host callbacks, its rank and rank count, what RCCL itself

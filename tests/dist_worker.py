@@ -32,7 +32,7 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
     Gc = A[nlev - 1].tocsc()                    # coarsest level is always replicated (global matrix)
 
     def exchange(l, v):
-        L = levels[l]
+        L = levels[l] if isinstance(l, int) else l           # (a LocalLevel: the separate Krylov operator of a finest overlapping level)
         if L.nbr_rank.size:
             stats["exchanges"] += 1
         if L.overlap:                                # one local numbering: scatter through rcv_idx
@@ -171,6 +171,33 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
         smooth(l, x, r)
 
     n = levels[0].n_own
+    K = local.get("krylov")
+    if K is not None:
+        # finest level in the overlapping layout: the Krylov vectors stay own | ghost (operator K.A, one exchange per mat-vec), the
+        # preconditioner works in level 0's extended-box numbering -- r scattered in, the owned entries of z gathered out
+        AK = K.A.to_scipy()
+        x, p, z, r = (np.zeros(K.n_own + K.n_ghost) for _ in range(4))
+        r[:n] = b_own
+        gamma = 1.0
+        res = np.sqrt(gdot(r[:n], r[:n])); hist = [res]
+        it = 0
+        done = (it >= maxiter) or (1.0 < rtol) or (res < atol)
+        while not done:
+            ze, re = vec(0), vec(0)
+            re[K.own_idx] = r[:n]
+            cycle(0, ze, re)
+            z[:n] = ze[K.own_idx]
+            beta = gamma; gamma = gdot(z[:n], r[:n]); beta = gamma / beta
+            p[:n] = z[:n] + beta * p[:n]
+            exchange(K, p)
+            w = AK @ p
+            alpha = gamma / gdot(p[:n], w)
+            x[:n] += alpha * p[:n]
+            r[:n] -= alpha * w
+            res = np.sqrt(gdot(r[:n], r[:n])); hist.append(res); it += 1
+            done = (it >= maxiter) or (res / hist[0] < rtol) or (res < atol)
+        numpy_distributed_cg.last_exchanges = stats["exchanges"]
+        return x[:n].copy(), it, np.array(hist)
     x, p, z = vec(0), vec(0), vec(0)
     r = vec(0); r[:n] = b_own                      # x0 = 0
     gamma = 1.0
@@ -285,6 +312,15 @@ def stokes_mode(n, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, 
         int_own.append(st.patch_owner(*Hv["interior_patches"][l], V[l].owner))
         pats += [(*Hv["star_patches"][l], V[l], star_own[l]), (*Hv["interior_patches"][l], V[l], int_own[l])]
     dp.partition_spaces(V + [Pq], ops, pats)
+    # GMG_TEST_DEPTH > 0: the partitioned velocity levels >= 1 in the OVERLAPPING layout (dpartition.OverlapSpace: node box + 4 * depth
+    # node layers -- a sweep of Richardson(PatchSolver) on Q2 vertex stars consumes 3 * 2 - 2 = 4), both components of a node together
+    depth = int(os.environ.get("GMG_TEST_DEPTH", "0"))
+
+    def node_coords(c):
+        k = np.arange((2 * c - 1) ** 2)
+        xy = np.stack([k % (2 * c - 1) + 1, k // (2 * c - 1) + 1], axis=1)
+        return np.repeat(xy, 2, axis=0)
+    OV = {l: dp.OverlapSpace(f"ov{l}", V[l].owner, node_coords(cells[l]), world, 4 * depth) for l in range(1, npart)} if depth > 0 else {}
 
     class LL:
         overlap = False
@@ -297,11 +333,38 @@ def stokes_mode(n, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, 
     rep_gid = np.zeros(0, dtype=np.int64)
     for l in range(nlev):
         L = LL()
-        if l < npart:
+        if l in OV:
+            S, pl = OV[l], OV[l].plan[rank]
+            L.replicated, L.overlap, L.depth = False, True, depth
+            L.n_local, L.n_own = S.n_local(rank), S.n_own(rank)
+            L.n_ghost = L.n_local - L.n_own
+            L.nbr_rank, L.snd_ptr, L.snd_idx, L.rcv_ptr, L.rcv_idx = pl["nbr_rank"], pl["snd_ptr"], pl["snd_idx"], pl["rcv_ptr"], pl["rcv_idx"]
+            L.A = S.square(sc(Hv["mats"][l]), rank)
+            if l + 1 in OV:
+                Cs = OV[l + 1]
+                L.P = dp.sliced_operator(sc(Hv["prolongations"][l]), S.ext[rank], Cs.g2l[rank], ncols=Cs.n_local(rank))
+                L.R = dp.sliced_operator(sc(Hv["restrictions"][l]), Cs.ext[rank], S.g2l[rank], keep_row=Cs.is_own[rank], ncols=S.n_local(rank),
+                                         strict_rows=Cs.is_own[rank])
+            else:                                               # boundary to the replicated level
+                L.P = dp.sliced_operator(sc(Hv["prolongations"][l]), S.ext[rank])
+                rows = V[l + 1].own[rank]
+                L.R = dp.sliced_operator(sc(Hv["restrictions"][l]), rows, S.g2l[rank], ncols=S.n_local(rank), strict_rows=np.ones(rows.size, bool))
+                rep_gid = rows
+            ptr, loc = S.patches(*Hv["star_patches"][l], rank)
+            ptabs.append((ptr, loc, None))                      # blocks A[p,p] from the local matrix
+            cptr, cloc = S.patches(*Hv["interior_patches"][l], rank)
+            ctabs.append((cptr, cloc, S.square(sc(Hv["graddiv"][l]), rank)))
+        elif l < npart:
             plan_of(L, V[l])
             L.replicated = False
             L.A = dp.local_operator(sc(Hv["mats"][l]), V[l], V[l], rank)
-            if l + 1 < npart:
+            if l + 1 in OV:                                     # own | ghost fine level, overlapping coarse level
+                Cs = OV[l + 1]
+                L.P = dp.sliced_operator(sc(Hv["prolongations"][l]), V[l].own[rank], Cs.g2l[rank], ncols=Cs.n_local(rank),
+                                         strict_rows=np.ones(V[l].n_own(rank), bool))
+                L.R = dp.sliced_operator(sc(Hv["restrictions"][l]), Cs.ext[rank], V[l].g2l[rank], keep_row=Cs.is_own[rank],
+                                         ncols=V[l].n_own(rank) + V[l].n_ghost(rank), strict_rows=Cs.is_own[rank])
+            elif l + 1 < npart:
                 L.P = dp.local_operator(sc(Hv["prolongations"][l]), V[l], V[l + 1], rank)
                 L.R = dp.local_operator(sc(Hv["restrictions"][l]), V[l + 1], V[l], rank)
             else:                                               # boundary to the replicated level: global coarse columns, this rank's coarse rows
@@ -466,6 +529,7 @@ def main():
     smoother = os.environ.get("GMG_TEST_SMOOTHER", "jacobi")
     p_niter, p_omega = 4, 0.2
     depth = int(os.environ.get("GMG_TEST_DEPTH", "0"))      # > 0: partitioned levels >= 1 in the overlapping layout with that many ghost layers
+    fdepth = int(os.environ.get("GMG_TEST_FINEST_DEPTH", "0"))   # > 0: the finest level in the overlapping layout too (separate Krylov operator)
     verdict = {}
     if mode == "numpy_stokes":
         return stokes_matvec_mode(cells[0], nlev, out, rank, world, dist, torch, pkg, po, pa)
@@ -474,7 +538,7 @@ def main():
     if mode == "gpu_block":
         pass
     elif mode == "numpy":
-        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from, depth, smoother)
+        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from, depth, smoother, finest_depth=fdepth)
         b = po.dirichlet_lift_rhs(cg, order)[local["levels"][0].own_gid]
         patches = None
         if smoother == "patch":
@@ -509,7 +573,7 @@ def main():
         torch.cuda.set_device(dev)
         g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=rep_from,
                                     order=order, smoother=smoother, niter=(p_niter if smoother == "patch" else 10),
-                                    omega=(p_omega if smoother == "patch" else 2.0 / 3.0), depth=depth,
+                                    omega=(p_omega if smoother == "patch" else 2.0 / 3.0), depth=depth, finest_depth=fdepth,
                                     stream_rows=int(os.environ.get("GMG_TEST_STREAM_ROWS", "0")))
         verdict["streamed_levels"] = list(getattr(g, "streamed_levels", []))
         b = g.rhs_lin()

@@ -514,3 +514,51 @@ def test_value_refresh_on_a_streamed_own_ghost_level(world, cells, nlev, rep, st
         assert 0 in v["streamed_levels"]
     assert v["refresh_iters"] == [v["iters"]] * world, v
     assert v["refresh_dev"] <= 1e-13, v
+
+
+FINEST_CASES = [(2, (16, 16, 16), 3, 2, 2, 2), (8, (8, 8, 8), 3, 2, 2, 5), (4, (16, 16), 4, 3, 3, 2), (2, (16, 16, 16), 3, 1, 0, 3)]
+
+
+@pytest.mark.parametrize("world,cells,nlev,rep,depth,fdepth", FINEST_CASES)
+def test_finest_level_in_the_overlapping_layout_numpy_gloo(world, cells, nlev, rep, depth, fdepth, tmp_path):
+    """The FINEST level in the overlapping layout too (`fdepth` ghost layers): the Krylov solver keeps the own | ghost vectors and
+    operator (one exchange per mat-vec), the preconditioner's level 0 smooths in the extended-box numbering with one exchange per
+    `fdepth` sweeps.  Iteration count and history of the serial oracle; exchanges saved on level 0 exactly
+    iterations x 2 passes x (10 - ceil(10 / fdepth))."""
+    v0 = _launch("numpy", world, cells, nlev, tmp_path, rep_from=rep, extra_env={"GMG_TEST_DEPTH": str(depth)})
+    v = _launch("numpy", world, cells, nlev, tmp_path, rep_from=rep, extra_env={"GMG_TEST_DEPTH": str(depth), "GMG_TEST_FINEST_DEPTH": str(fdepth)})
+    _check(v0); _check(v)
+    saved = v["iters"] * 2 * (10 - (-(-10 // fdepth)))
+    assert v0["exchanges"] - v["exchanges"] == saved, (v0["exchanges"], v["exchanges"], saved)
+    assert np.abs(v["x"] - v0["x"]).max() <= 1e-12 * np.abs(v0["x"]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cells,nlev,rep,depth,fdepth", FINEST_CASES)
+def test_finest_level_in_the_overlapping_layout_on_gpu_host_transport(world, cells, nlev, rep, depth, fdepth, tmp_path):
+    """The real library (several ranks on one GPU, host transport) with the finest level in the overlapping layout and the Krylov
+    operator handed over separately (GMG_LEVEL_KRYLOV + gmg_set_krylov_map): CG and FGMRES reproduce the serial oracle's iteration
+    count and history, the exchanges per solve drop by exactly iterations x 2 x (10 - ceil(10 / fdepth)), the solution agrees with
+    the own | ghost finest level to rounding, and one-launch passes == per-sweep launches bitwise."""
+    env = {"GMG_PERSIST_SHARED": "1", "GMG_TEST_DEPTH": str(depth)}
+    v0 = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env=env)
+    v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env=dict(env, GMG_TEST_FINEST_DEPTH=str(fdepth)))
+    vl = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env=dict(env, GMG_TEST_FINEST_DEPTH=str(fdepth), GMG_PERSIST="0"))
+    _check(v0); _check(v); _check(vl)
+    assert v["iters"] == v0["iters"] and v["fgmres_iters"] == v0["fgmres_iters"] and v["fgmres_vs_cg"] < 1e-6
+    assert v0["exchanges"] - v["exchanges"] == v0["iters"] * 2 * (10 - -(-10 // fdepth)), (v0["exchanges"], v["exchanges"])
+    assert np.linalg.norm(v["x"] - v0["x"]) <= 1e-12 * np.linalg.norm(v0["x"])
+    np.testing.assert_array_equal(v["x"], vl["x"])
+
+
+@pytest.mark.gpu
+def test_finest_overlapping_level_with_q2_patch_smoother_on_gpu_host_transport(tmp_path):
+    """Q2 + Richardson(PatchSolver) with the finest level in the overlapping layout (depth 2 = 8 node layers): serial oracle's
+    iterations; 2 passes x (4 sweeps x 2 forward exchanges - 2 block exchanges) saved per iteration on level 0."""
+    env = {"GMG_TEST_ORDER": "2", "GMG_TEST_SMOOTHER": "patch", "GMG_PERSIST_SHARED": "1"}
+    v0 = _launch("gpu", 2, (8, 8, 8), 3, tmp_path, transport="host", rep_from=1, extra_env=env)
+    v = _launch("gpu", 2, (8, 8, 8), 3, tmp_path, transport="host", rep_from=1, extra_env=dict(env, GMG_TEST_FINEST_DEPTH="2"))
+    _check(v0); _check(v)
+    assert v["iters"] == v0["iters"]
+    assert v0["exchanges"] - v["exchanges"] == v0["iters"] * 2 * 6, (v0["exchanges"], v["exchanges"])
+    assert np.linalg.norm(v["x"] - v0["x"]) <= 1e-11 * np.linalg.norm(v0["x"])
