@@ -392,6 +392,7 @@ def stokes_mode(n, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, 
     # (1) the distributed velocity GMG alone
     rg = np.random.default_rng(2).uniform(-1, 1, nu)
     z = np.zeros(V[0].n_own(rank))
+    ex0 = g.comm_stats()[0]
     glog = g.apply(np.ascontiguousarray(rg[V[0].own[rank]]), z, maxiter=4)
     # (2) the whole solve
     lev1 = LL(); plan_of(lev1, Pq)
@@ -403,6 +404,7 @@ def stokes_mode(n, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, 
     b = np.concatenate([bg[:nu][V[0].own[rank]], bg[nu:][Pq.own[rank]]])
     x = np.zeros_like(b)
     log = blk.fgmres_solve(b, x, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+    n_exchanges = int(g.comm_stats()[0] - ex0)
     parts = [None] * world
     dist.all_gather_object(parts, (V[0].own[rank], Pq.own[rank], x, z, int(log.num_iters), log.residuals[: log.num_iters + 1].tolist(), int(glog.num_iters)))
     if rank == 0:
@@ -429,7 +431,8 @@ def stokes_mode(n, nlev, out, transport, rank, world, dist, torch, pkg, po, pa, 
                        rel_err=float(np.linalg.norm(xg - xo) / np.linalg.norm(xo)),
                        hist_dev=float(np.max(np.abs(hist_d - hist) / hist[0])) if len(hist_d) == len(hist) else 1.0,
                        true_residual=float(np.linalg.norm(K @ xg - bg)), div_residual=float(np.linalg.norm(sc(A[1][0]) @ xg[:nu] - bg[nu:])),
-                       umax=float(xg[:nu].max()), world=world, grid=list(grid), mode="gpu_stokes",
+                       umax=float(xg[:nu].max()), world=world, grid=list(grid), mode="gpu_stokes", exchanges=n_exchanges,
+                       overlap_levels=sorted(OV), local_entries=[int(OV[l].n_local(0)) for l in sorted(OV)],
                        ghosts=[int(V[0].n_ghost(0)), int(Pq.n_ghost(0))])
         json.dump(verdict, open(out, "w"))
     dist.barrier()

@@ -562,3 +562,80 @@ def test_finest_overlapping_level_with_q2_patch_smoother_on_gpu_host_transport(t
     assert v["iters"] == v0["iters"]
     assert v0["exchanges"] - v["exchanges"] == v0["iters"] * 2 * 6, (v0["exchanges"], v["exchanges"])
     assert np.linalg.norm(v["x"] - v0["x"]) <= 1e-11 * np.linalg.norm(v0["x"])
+
+
+def test_overlap_space_of_the_vector_valued_stokes_velocity(po, pkg):
+    """dpartition.OverlapSpace on the vector-valued Q2 velocity levels: owned rows of the square local operators reproduce the global
+    mat-vec (and every row at least 2 nodes inside the local box), the exchange plans of all ranks fit together (what r sends to q
+    is what q expects from r, in the same order), every ghost is received exactly once, the local patch lists are the global patches
+    that fit in the box, and the sliced transfers reproduce P on owned fine rows / R on owned coarse rows."""
+    import importlib
+    st = importlib.import_module(pkg.__name__ + ".stokes")
+    dp = importlib.import_module(pkg.__name__ + ".dpartition")
+    pa = importlib.import_module(pkg.__name__ + ".partition")
+    n, nlev, nranks, depth = 16, 3, 4, 1
+    grid = pa.rank_grid(nranks, 2)
+    Hv = st.velocity_hierarchy(n, nlev)
+    cells = Hv["ncells"]
+
+    def coords(c):
+        k = np.arange((2 * c - 1) ** 2)
+        return np.repeat(np.stack([k % (2 * c - 1) + 1, k // (2 * c - 1) + 1], axis=1), 2, axis=0)
+    S = [dp.OverlapSpace(f"v{l}", st.velocity_owner(cells[l], grid), coords(cells[l]), nranks, 4 * depth) for l in range(2)]
+    rng = np.random.default_rng(3)
+    for l, Sp in enumerate(S):
+        A = Hv["mats"][l].to_scipy().tocsr()
+        x = rng.uniform(-1, 1, Sp.n)
+        y = A @ x
+        X = coords(cells[l])
+        assert sum(Sp.n_own(r) for r in range(nranks)) == Sp.n
+        for r in range(nranks):
+            e = Sp.ext[r]
+            Al = Sp.square(A, r)
+            yl = Al.matvec(x[e])
+            assert np.abs(yl[Sp.own_idx(r)] - y[Sp.own[r]]).max() < 1e-11
+            lo, hi = X[e].min(axis=0), X[e].max(axis=0)
+            nmax = 2 * cells[l] - 1
+            inner = (((X[e] - lo >= 2) | (X[e] <= 2)) & ((hi - X[e] >= 2) | (X[e] >= nmax - 1))).all(axis=1)
+            assert inner.sum() > Sp.n_own(r) and np.abs(yl[inner] - y[e][inner]).max() < 1e-11
+            # exchange emulation: owners' values into my ghosts
+            v = np.where(Sp.is_own[r], x[e], np.nan)
+            pl = Sp.plan[r]
+            for k, q in enumerate(pl["nbr_rank"]):
+                plq = Sp.plan[q]
+                kk = list(plq["nbr_rank"]).index(r)
+                sent = Sp.ext[q][plq["snd_idx"][plq["snd_ptr"][kk]:plq["snd_ptr"][kk + 1]]]          # global ids q sends to r
+                want = e[pl["rcv_idx"][pl["rcv_ptr"][k]:pl["rcv_ptr"][k + 1]]]
+                assert np.array_equal(sent, want)
+                v[pl["rcv_idx"][pl["rcv_ptr"][k]:pl["rcv_ptr"][k + 1]]] = x[sent]
+            assert np.array_equal(v, x[e])
+            pp, pd = Hv["star_patches"][l]
+            ptr, loc = Sp.patches(pp, pd, r)
+            glob = {tuple(pd[pp[p]:pp[p + 1]]) for p in range(pp.size - 1)}
+            assert ptr.size - 1 > 0 and all(tuple(e[loc[ptr[p]:ptr[p + 1]]]) in glob for p in range(ptr.size - 1))
+    P, R = Hv["prolongations"][0].to_scipy().tocsr(), Hv["restrictions"][0].to_scipy().tocsr()
+    xc, xf = rng.uniform(-1, 1, S[1].n), rng.uniform(-1, 1, S[0].n)
+    for r in range(nranks):
+        Pl = dp.sliced_operator(P, S[0].ext[r], S[1].g2l[r], ncols=S[1].n_local(r))
+        assert np.abs(Pl.matvec(xc[S[1].ext[r]])[S[0].own_idx(r)] - (P @ xc)[S[0].own[r]]).max() < 1e-12
+        Rl = dp.sliced_operator(R, S[1].ext[r], S[0].g2l[r], keep_row=S[1].is_own[r], ncols=S[0].n_local(r), strict_rows=S[1].is_own[r])
+        yr = Rl.matvec(xf[S[0].ext[r]])
+        assert np.abs(yr[S[1].own_idx(r)] - (R @ xf)[S[1].own[r]]).max() < 1e-12 and not yr[~S[1].is_own[r]].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,nlev,depth", [(2, 16, 3, 2), (4, 16, 3, 1), (8, 16, 3, 1), (2, 32, 4, 2)])
+def test_distributed_real_stokes_with_overlapping_velocity_levels(world, n, nlev, depth, tmp_path):
+    """Round 5: the partitioned vector-valued velocity levels >= 1 of the distributed Stokes solve in the OVERLAPPING layout
+    (dpartition.OverlapSpace; patch smoother AND patch-corrected prolongation with blocks from the local matrix, no assemble!):
+    the same iteration counts as the serial oracle for the velocity GMG alone and for the whole FGMRES solve, the same solution as
+    the own | ghost run to rounding, fewer halo exchanges."""
+    v0 = _launch("gpu_stokes", world, (n, n), nlev, tmp_path, transport="host")
+    v = _launch("gpu_stokes", world, (n, n), nlev, tmp_path, transport="host", extra_env={"GMG_TEST_DEPTH": str(depth)})
+    for w in (v0, v):
+        assert w["gmg_iters"] == w["gmg_iters_oracle"] and w["gmg_rel_err"] < 1e-8, w
+        assert w["iters"] == w["iters_oracle"] and w["iters_all_equal"], w
+        assert w["rel_err"] < 1e-6 and w["hist_dev"] < 1e-6, w
+        assert w["true_residual"] < 1e-7 and w["div_residual"] < 1e-7, w
+    assert v["overlap_levels"] == list(range(1, nlev - 1)) and v0["overlap_levels"] == []
+    assert v["exchanges"] < v0["exchanges"], (v["exchanges"], v0["exchanges"])
