@@ -26,6 +26,22 @@ class Result(C.Structure):
     _fields_ = [("niters", C.c_int32), ("flag", C.c_int32), ("res0", C.c_double), ("res", C.c_double)]
 
 
+class RedistPlan(C.Structure):
+    """gmg_redist_plan: one direction of the redistribution between the glued and the subset partition of a level"""
+    _fields_ = [("nnbr", C.c_int), ("nbr_rank", C.c_void_p), ("snd_ptr", C.c_void_p), ("snd_idx", C.c_void_p), ("rcv_ptr", C.c_void_p),
+                ("rcv_idx", C.c_void_p), ("nself", C.c_int64), ("self_src", C.c_void_p), ("self_dst", C.c_void_p)]
+
+    @classmethod
+    def from_dict(cls, d, keep):
+        """d: partition.build_local_hierarchy(...)["sub"]["to_sub" | "from_sub"]; `keep` collects the arrays the pointers refer to"""
+        import numpy as np
+        nbr = np.ascontiguousarray(d["nbr_rank"], dtype=np.int32)
+        a = [np.ascontiguousarray(d[k], dtype=np.int64) for k in ("snd_ptr", "snd_idx", "rcv_ptr", "rcv_idx", "self_src", "self_dst")]
+        keep += [nbr] + a
+        return cls(int(nbr.size), nbr.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                   int(a[4].size), a[4].ctypes.data, a[5].ctypes.data)
+
+
 class KernelStats(C.Structure):
     _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("alg_bytes", C.c_double),
                 ("rows", C.c_int64), ("nnz", C.c_int64), ("layout_bytes", C.c_double), ("fused_passes", C.c_int64)]
@@ -98,6 +114,7 @@ SYMBOLS = {
     "gmg_get_comm_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "gmg_set_replication": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64],
     "gmg_set_krylov_map": [C.c_void_p, C.c_void_p, C.c_int64],
+    "gmg_set_redistribution": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(RedistPlan), C.POINTER(RedistPlan)],
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
     "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],
     "gmg_get_kernel_stats_by_variant": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],

@@ -131,6 +131,13 @@ __global__ void halo_unpack_kernel(int64_t n, const int64_t *__restrict__ idx, c
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[idx[i]] = buf[i];
 }
+// dst[di[i]] = src[si[i]]  (redistribution between two partitions of a level: the entries that stay on this rank)
+__global__ void gather_scatter_kernel(int64_t n, const int64_t *__restrict__ si, const int64_t *__restrict__ di,
+                                      const double *__restrict__ src, double *__restrict__ dst)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[di[i]] = src[si[i]];
+}
 // assemble!(v) (PatchSolvers.jl:254): v[idx[i]] += buf[i] -- the ghost copies' contributions added to the owner's entry.
 // One launch per neighbour, in neighbour order: targets are unique inside a neighbour's list, so the sum order is fixed.
 __global__ void halo_unpack_add_kernel(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ buf,

@@ -483,6 +483,21 @@ struct gmg_solver {
   // level 0 lives in the overlapping numbering; own2loc maps every owned entry to its place there (gmg_set_krylov_map).
   std::vector<int64_t> h_own2loc;
   int64_t *d_own2loc = nullptr;
+  // Levels sub_from .. rep_from-1 on a RANK SUBSET (gmg_set_redistribution; np_per_level / redistribute!, ModelHierarchies.jl:80-148,
+  // GridTransferOperators.jl:447-532): level sub_from exists in the glued partition of all ranks (P / R of level sub_from-1 are built
+  // against it) and in the subset's; two p2p plans move the restricted residual to the subset owners and the correction back to the
+  // glued own AND ghost entries.  Ranks outside the subset hold nothing of those levels and only shadow their collectives.
+  struct Redist {
+    bool present = false, member = false;
+    int64_t n_glue_own = 0, n_glue_ghost = 0;
+    HaloPlan to_sub, from_sub;                      // snd_idx: local ids in the source space, rcv_idx: in the destination space
+    std::vector<int64_t> h_self[4];                 // to_sub (src, dst), from_sub (src, dst): entries that stay on this rank
+    int64_t *d_self[4] = {nullptr, nullptr, nullptr, nullptr};
+    double *glue_r = nullptr, *glue_x = nullptr;
+  } redist;
+  int sub_from = -1;
+  int64_t n_redist = 0;                             // redistributions issued (gmg_get_comm_stats counts them with the exchanges)
+  bool inactive(int l) const { return redist.present && !redist.member && l >= sub_from && l < rep_from; }
   bool has_outer() const { return (int)lev.size() > nlev && lev[nlev].hasA; }
   int kl() const { return has_outer() ? nlev : 0; }                 // the level the Krylov solvers' operator and vectors belong to
   int64_t user_n() const { return lev[kl()].n; }
@@ -739,6 +754,9 @@ struct gmg_solver {
     d_partials2 = nullptr;
     cc_w = cc_p = cc_z = cc_r = nullptr;
     d_rep_gid = nullptr; d_rep_tmp = nullptr; cg_x = nullptr; d_own2loc = nullptr;
+    redist.glue_r = redist.glue_x = nullptr;
+    for (auto &q : redist.d_self) q = nullptr;
+    for (HaloPlan *H : {&redist.to_sub, &redist.from_sub}) { H->d_snd_idx = nullptr; H->d_sendbuf = nullptr; H->d_recvbuf = nullptr; H->d_pk_ptr = nullptr; H->d_pk_slot = nullptr; }
     for (auto &L : lev) { L.halo.d_snd_idx = nullptr; L.halo.d_sendbuf = nullptr; L.halo.d_recvbuf = nullptr; L.halo.d_pk_ptr = nullptr; L.halo.d_pk_slot = nullptr; }
     cg_w = cg_p = cg_z = cg_r = st_b = st_x = nullptr;
     fg_V.clear(); fg_Z.clear(); st_extra.clear();
@@ -2355,16 +2373,18 @@ struct gmg_solver {
   // prepacked: the send buffer already holds v's boundary entries (written by the previous sweep's ghost_fix_kernel)
   void exchange_on(int l, double *v, hipStream_t stream, bool prepacked = false) { exchange_plan(lev[l].halo, v, stream, prepacked); }
   // the same for any exchange plan (block preconditioners keep one per block)
-  void exchange_plan(HaloPlan &H, double *v, hipStream_t stream, bool prepacked = false)
+  // (dst: where the received values go when it is not the vector the sent ones come from -- redistribution between two partitions)
+  void exchange_plan(HaloPlan &H, double *v, hipStream_t stream, bool prepacked = false, double *dst = nullptr)
   {
     if (comm.nranks <= 1 || !H.present || H.nbr.empty()) return;
+    if (!dst) dst = v;
     const int64_t ns = H.nsend();
     if (ns > 0 && !prepacked) {
       hipLaunchKernelGGL(halo_pack_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ns, H.d_snd_idx, v, H.d_sendbuf);
       HIP_CHECK(hipGetLastError());
     }
     // own | ghost layout: received straight into the ghost segment; overlapping layout: into a landing buffer, then scattered
-    double *ghost = H.ovl ? H.d_unpack : v + H.n_own;
+    double *ghost = H.ovl ? H.d_unpack : dst + H.n_own;
     if (comm.kind == COMM_RCCL) {
       int rc = comm.api.GroupStart();
       for (size_t k = 0; k < H.nbr.size() && rc == 0; ++k) {
@@ -2381,10 +2401,36 @@ struct gmg_solver {
       if (H.n_ghost > 0) HIP_CHECK(hipMemcpyAsync(ghost, H.h_recv, sizeof(double) * (size_t)H.n_ghost, hipMemcpyHostToDevice, stream));
     }
     if (H.ovl && H.n_ghost > 0) {
-      hipLaunchKernelGGL(halo_unpack_kernel, dim3((unsigned)((H.n_ghost + 255) / 256)), dim3(256), 0, stream, H.n_ghost, H.d_rcv_idx, H.d_unpack, v);
+      hipLaunchKernelGGL(halo_unpack_kernel, dim3((unsigned)((H.n_ghost + 255) / 256)), dim3(256), 0, stream, H.n_ghost, H.d_rcv_idx, H.d_unpack, dst);
       HIP_CHECK(hipGetLastError());
     }
     ++n_exchanges;
+  }
+  // redistribute!(dst, src) between the two partitions of level sub_from: entries that stay on this rank are copied, the others travel
+  // with one grouped send / receive (same primitive as a halo exchange: pack by local id, receive, scatter by local id)
+  void redistribute(HaloPlan &H, int self, const double *src, double *dst)
+  {
+    const int64_t nself = (int64_t)redist.h_self[self].size();
+    if (nself > 0) {
+      hipLaunchKernelGGL(gather_scatter_kernel, dim3((unsigned)((nself + 255) / 256)), dim3(256), 0, stream, nself, redist.d_self[self], redist.d_self[self + 1], src, dst);
+      HIP_CHECK(hipGetLastError());
+    }
+    const int64_t before = n_exchanges;
+    exchange_plan(H, const_cast<double *>(src), stream, false, dst);
+    n_exchanges = before;
+    ++n_redist;
+  }
+  // a rank outside the subset takes part in the collectives below level sub_from-1 without holding the levels: the all-reduce that
+  // assembles the replicated residual (zero contribution); mirrors cycle()'s recursion
+  void shadow_cycle(int l, int ctype)
+  {
+    if (l >= nlev - 1 || l >= rep_from) return;
+    const int passes = (ctype == GMG_V_CYCLE) ? 1 : 2;
+    for (int pass = 0; pass < passes; ++pass) {
+      const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
+      if (l + 1 == rep_from) restrict_replicate(l, nullptr, lev[l + 1].rbuf[0]);
+      else shadow_cycle(l + 1, child);
+    }
   }
   void alloc_plan_buffers(HaloPlan &H)
   {
@@ -2951,8 +2997,8 @@ struct gmg_solver {
   void restrict_replicate(int l, const double *r, double *rH_global)
   {
     Level &L = lev[l];
-    const int64_t nrows = L.R.nrows, ng = lev[l + 1].n;
-    spmv_set(L.R, r, d_rep_tmp);
+    const int64_t nrows = r ? L.R.nrows : 0, ng = lev[l + 1].n;   // (r == nullptr: a rank that holds no part of level l, shadow_cycle)
+    if (r) spmv_set(L.R, r, d_rep_tmp);
     zero(rH_global, ng);
     if (nrows > 0) {
       hipLaunchKernelGGL(scatter_gid_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, nrows, d_rep_gid, d_rep_tmp, rH_global);
@@ -3047,6 +3093,19 @@ struct gmg_solver {
     for (int pass = 0; pass < passes; ++pass) {
       if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
       exchange(l, r);
+      if (redist.present && l + 1 == sub_from) {
+        // level l+1 lives on a rank subset: restrict in the glued partition, redistribute! to the subset owners, recurse there (the
+        // other ranks shadow the collectives), bring the correction back to the glued own and ghost entries, prolongate from those
+        const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
+        spmv_set(L.R, r, redist.glue_r);
+        redistribute(redist.to_sub, 0, redist.glue_r, C.rbuf[0]);
+        if (redist.member) cycle(l + 1, C.x, C.rbuf[0], true, child);
+        else shadow_cycle(l + 1, child);
+        redistribute(redist.from_sub, 2, C.x, redist.glue_x);
+        spmv_addto(L.P, redist.glue_x, L.dx, x);
+        apply_A_sub(l, L.dx, r, &L.post);
+        continue;
+      }
       if (comm.nranks > 1 && l + 1 == rep_from) restrict_replicate(l, r, C.rbuf[0]);
       else if (l + 1 < nlev - 1 && emits_s0(C, C.pre, L.R)) {
         StepTimer tm(*this, "restrict+s0", l);
@@ -4656,8 +4715,18 @@ void gmg_solver::setup()
       if (own_ghost && L.sA && L.sA->complete() && !L.sA_split) rows_from_stream(L);
     }
   }
+  if (redist.present) {
+    REQUIRE(comm.nranks > 1 && rep_from >= 2 && sub_from >= 1 && sub_from < rep_from, GMG_ERR_STATE,
+            "gmg_set_redistribution: the subset levels lie between level 1 and the first replicated level (gmg_set_replication first)");
+    REQUIRE(!lev[sub_from - 1].has_pcorr, GMG_ERR_UNSUPPORTED, "no patch-corrected prolongation across a redistribution");
+  }
   for (int l = 0; l < nlev; ++l) {
     Level &L = lev[l];
+    if (inactive(l)) {                                       // a level of a rank subset this rank is not part of
+      REQUIRE(!L.hasA && !L.halo.present, GMG_ERR_INVALID, "this rank is not a member of the subset that holds level " + std::to_string(l));
+      L.n = L.nvec = 0;
+      continue;
+    }
     REQUIRE(L.hasA, GMG_ERR_STATE, "gmg_set_matrix missing for level " + std::to_string(l));
     L.n = L.hA.nrows;
     L.nvec = L.hA.ncols;
@@ -4709,14 +4778,16 @@ void gmg_solver::setup()
     REQUIRE((int)lev.size() <= nlev || !lev[nlev].halo.present, GMG_ERR_STATE, "gmg_set_partition(GMG_LEVEL_KRYLOV) without gmg_set_matrix(GMG_LEVEL_KRYLOV)");
   for (int l = 0; l < nlev - 1; ++l) {
     Level &L = lev[l];
+    if (inactive(l)) continue;
     REQUIRE(L.hasP, GMG_ERR_STATE, "gmg_set_prolongation missing for level " + std::to_string(l));
-    REQUIRE(L.hP.nrows == L.n && L.hP.ncols == lev[l + 1].nvec, GMG_ERR_INVALID,
+    const bool to_glue = redist.present && l + 1 == sub_from;   // P / R against the glued partition of level l+1 (own | ghost numbering)
+    REQUIRE(L.hP.nrows == L.n && L.hP.ncols == (to_glue ? redist.n_glue_own + redist.n_glue_ghost : lev[l + 1].nvec), GMG_ERR_INVALID,
             "prolongation shape does not match level sizes (GMGLinearSolvers.jl:59-61)");
     if (comm.nranks > 1)
       REQUIRE(L.hasR, GMG_ERR_STATE, "distributed runs need the local rows of R (gmg_set_restriction): a local P^T misses off-rank rows");
     if (L.hasR) {
       const bool boundary = comm.nranks > 1 && l + 1 == rep_from;   // R yields this rank's rows of the replicated level
-      REQUIRE((boundary ? L.hR.nrows == (int64_t)h_rep_gid.size() : L.hR.nrows == lev[l + 1].n) && L.hR.ncols == L.nvec,
+      REQUIRE((boundary ? L.hR.nrows == (int64_t)h_rep_gid.size() : to_glue ? L.hR.nrows == redist.n_glue_own : L.hR.nrows == lev[l + 1].n) && L.hR.ncols == L.nvec,
               GMG_ERR_INVALID, "restriction shape mismatch");
     }
     if (comm.nranks > 1 && L.halo.present && !L.halo.ovl)
@@ -4732,6 +4803,7 @@ void gmg_solver::setup()
   init_reductions();
   for (int l = 0; l < nlev + (has_outer() ? 1 : 0); ++l) {   // (index nlev: the separate Krylov operator -- matrix and exchange plan only)
     Level &L = lev[l];
+    if (l < nlev && inactive(l)) continue;
     if (L.halo.present && comm.nranks > 1 && L.halo.ovl) {
       // overlapping layout: one square local operator over all local entries -- laid out like a single-GPU level (row patterns,
       // shared offsets, one-launch smoothing passes all apply); ghost rows are recomputed redundantly between exchanges
@@ -4851,6 +4923,21 @@ void gmg_solver::setup()
   build_coarse();                                           // :195 gmg_coarse_solver_caches
   lap("coarse inverse", nlev - 1);
   const int64_t n0 = lev[kl()].nvec;
+  if (redist.present) {
+    const int64_t nsub = lev[sub_from].nvec, nglue = redist.n_glue_own + redist.n_glue_ghost;
+    const int64_t src_n[2] = {redist.n_glue_own, nsub}, dst_n[2] = {nsub, nglue};
+    HaloPlan *plans[2] = {&redist.to_sub, &redist.from_sub};
+    for (int k = 0; k < 2; ++k) {
+      for (int64_t q : plans[k]->h_snd_idx) REQUIRE(q >= 0 && q < src_n[k], GMG_ERR_INVALID, "redistribution plan: sent id out of range");
+      for (int64_t q : plans[k]->h_rcv_idx) REQUIRE(q >= 0 && q < dst_n[k], GMG_ERR_INVALID, "redistribution plan: received id out of range");
+      for (int64_t q : redist.h_self[2 * k]) REQUIRE(q >= 0 && q < src_n[k], GMG_ERR_INVALID, "redistribution plan: local id out of range");
+      for (int64_t q : redist.h_self[2 * k + 1]) REQUIRE(q >= 0 && q < dst_n[k], GMG_ERR_INVALID, "redistribution plan: local id out of range");
+      alloc_plan_buffers(*plans[k]);
+    }
+    for (int k = 0; k < 4; ++k) redist.d_self[k] = upload(redist.h_self[k]);
+    redist.glue_r = dvec(redist.n_glue_own);
+    redist.glue_x = dvec(nglue);
+  }
   if (has_outer()) d_own2loc = upload(h_own2loc);
   cg_w = dvec(n0); cg_p = dvec(n0); cg_z = dvec(n0); cg_r = dvec(n0);
   st_b = dvec(n0); st_x = dvec(n0);
@@ -4867,11 +4954,15 @@ void gmg_solver::setup()
     // row-pattern table).  One all-reduce per own | ghost level at setup.
     for (int l = 0; l + 1 < nlev; ++l) {
       Level &L = lev[l];
-      if (!(L.halo.present && !L.halo.ovl)) continue;
-      L.rs_forbid = false;
-      double ok = rsweep_level(L) ? 1.0 : 0.0;
+      // (levels of a rank subset: every rank votes -- the ranks that hold nothing of the level, or hold it in the overlapping layout,
+      // with a yes -- so that the collective sequence is the same everywhere whatever a rank knows about the level)
+      const bool subset_level = redist.present && l >= sub_from && l < rep_from;
+      const bool own_ghost = !inactive(l) && L.halo.present && !L.halo.ovl;
+      if (!own_ghost && !subset_level) continue;
+      if (own_ghost) L.rs_forbid = false;
+      double ok = (!own_ghost || rsweep_level(L)) ? 1.0 : 0.0;
       host_allreduce_sum(&ok);
-      L.rs_forbid = ok < (double)comm.nranks - 0.5;
+      if (own_ghost) L.rs_forbid = ok < (double)comm.nranks - 0.5;
     }
   }
   HIP_CHECK(hipStreamSynchronize(stream));
@@ -5110,6 +5201,10 @@ int gmg_destroy(gmg_handle_t h)
   for (auto &L : h->lev) {
     if (L.halo.h_send) (void)hipHostFree(L.halo.h_send);
     if (L.halo.h_recv) (void)hipHostFree(L.halo.h_recv);
+  }
+  for (HaloPlan *H : {&h->redist.to_sub, &h->redist.from_sub}) {
+    if (H->h_send) (void)hipHostFree(H->h_send);
+    if (H->h_recv) (void)hipHostFree(H->h_recv);
   }
   if (h->h_rep_full) (void)hipHostFree(h->h_rep_full);
   if (h->h_cr) (void)hipHostFree(h->h_cr);
@@ -6183,8 +6278,53 @@ int gmg_get_comm_stats(gmg_handle_t h, int64_t *n_exchanges, int64_t *n_allreduc
 {
   return guarded(h, [&] {
     REQUIRE(h, GMG_ERR_INVALID, "null handle");
-    if (n_exchanges) *n_exchanges = h->n_exchanges;
+    if (n_exchanges) *n_exchanges = h->n_exchanges + h->n_redist;   // (redistributions between two partitions are exchanges too)
     if (n_allreduces) *n_allreduces = h->n_allreduces;
+  });
+}
+
+int gmg_set_redistribution(gmg_handle_t h, int lev, int member, int64_t n_glue_own, int64_t n_glue_ghost,
+                           const gmg_redist_plan *to_sub, const gmg_redist_plan *from_sub)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    REQUIRE(lev >= 1, GMG_ERR_INVALID, "the finest level lives on all ranks");
+    REQUIRE(h->comm.nranks > 1, GMG_ERR_STATE, "gmg_set_redistribution needs gmg_comm_init_* first");
+    REQUIRE(to_sub && from_sub && n_glue_own >= 0 && n_glue_ghost >= 0, GMG_ERR_INVALID, "null plan / negative sizes");
+    gmg_solver::Redist R;
+    R.present = true; R.member = member != 0;
+    R.n_glue_own = n_glue_own; R.n_glue_ghost = n_glue_ghost;
+    const gmg_redist_plan *in[2] = {to_sub, from_sub};
+    HaloPlan *out[2] = {&R.to_sub, &R.from_sub};
+    for (int k = 0; k < 2; ++k) {
+      const gmg_redist_plan &p = *in[k];
+      HaloPlan &H = *out[k];
+      REQUIRE(p.nnbr >= 0 && p.nself >= 0, GMG_ERR_INVALID, "negative sizes");
+      REQUIRE(p.nnbr == 0 || (p.nbr_rank && p.snd_ptr && p.rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
+      REQUIRE(p.nself == 0 || (p.self_src && p.self_dst), GMG_ERR_INVALID, "null self lists");
+      H.present = true; H.ovl = true; H.depth = 1;
+      H.nbr.assign(p.nbr_rank, p.nbr_rank + p.nnbr);
+      H.snd_ptr.assign(1, 0); H.rcv_ptr.assign(1, 0);
+      if (p.nnbr > 0) { H.snd_ptr.assign(p.snd_ptr, p.snd_ptr + p.nnbr + 1); H.rcv_ptr.assign(p.rcv_ptr, p.rcv_ptr + p.nnbr + 1); }
+      REQUIRE(H.snd_ptr[0] == 0 && H.rcv_ptr[0] == 0, GMG_ERR_INVALID, "snd_ptr / rcv_ptr must start at 0");
+      for (int q = 0; q < p.nnbr; ++q) {
+        REQUIRE(H.snd_ptr[q] <= H.snd_ptr[q + 1] && H.rcv_ptr[q] <= H.rcv_ptr[q + 1], GMG_ERR_INVALID, "pointers not monotone");
+        REQUIRE(p.nbr_rank[q] >= 0 && p.nbr_rank[q] < h->comm.nranks && p.nbr_rank[q] != h->comm.rank, GMG_ERR_INVALID, "bad neighbour rank");
+      }
+      REQUIRE((H.snd_ptr.back() == 0 || p.snd_idx) && (H.rcv_ptr.back() == 0 || p.rcv_idx), GMG_ERR_INVALID, "null index lists");
+      H.h_snd_idx.assign(p.snd_idx, p.snd_idx + H.snd_ptr.back());
+      H.h_rcv_idx.assign(p.rcv_idx, p.rcv_idx + H.rcv_ptr.back());
+      H.n_own = 0; H.n_ghost = H.rcv_ptr.back();             // (n_ghost: what the landing buffer of the scatter holds)
+      R.h_self[2 * k].assign(p.self_src, p.self_src + p.nself);
+      R.h_self[2 * k + 1].assign(p.self_dst, p.self_dst + p.nself);
+    }
+    for (HaloPlan *H : {&h->redist.to_sub, &h->redist.from_sub}) {
+      if (H->h_send) (void)hipHostFree(H->h_send);
+      if (H->h_recv) (void)hipHostFree(H->h_recv);
+    }
+    h->redist = std::move(R);
+    h->sub_from = lev;
+    h->touch();
   });
 }
 

@@ -77,7 +77,7 @@ class DistributedGMG:
                  order=1, niter=10, omega=2.0 / 3.0, mode="preconditioner", cycle_type="v_cycle",
                  gmg_maxiter=1, gmg_atol=1e-14, gmg_rtol=1e-8, local_hierarchy=None, lengths=None, rep_from=None,
                  smoother="jacobi", depth=None, patch_tables=None, pcorr_tables=None, cells_global=None, options=None,
-                 stream_rows=0, finest_depth=0):
+                 stream_rows=0, finest_depth=0, sub_from=None, sub_ranks=None):
         """smoother = "jacobi": Richardson(Jacobi, niter, omega); "patch": Richardson(PatchSolver, niter, omega) with the
         vertex-star patches OWNED by this rank (partition.local_vertex_star_patches) and caller-assembled patch matrices --
         a rank's local matrix has the owned rows only, so the blocks of patches reaching into ghost dofs come from the
@@ -94,6 +94,9 @@ class DistributedGMG:
         finest_depth > 0: the finest level in the overlapping layout as well -- the Krylov solver keeps the caller's own | ghost vectors
         and its own finest operator (GMG_LEVEL_KRYLOV: gmg_set_matrix / gmg_set_partition / gmg_set_krylov_map), the preconditioner's
         level 0 smooths in the extended-box numbering with one exchange per `finest_depth` sweeps.
+        sub_from / sub_ranks: the partitioned levels sub_from .. rep_from-1 on the first `sub_ranks` ranks only (np_per_level /
+        redistribute! of the reference; gmg_set_redistribution: glued partition on all ranks + the subset's, two p2p plans) -- a
+        capability: the communication model never prefers it on this hardware.
         stream_rows > 0: the operators of the levels that are laid out like a single-GPU level -- overlapping layout, replicated levels
         -- are handed over in blocks of that many rows (gmg_set_operator_rows): the library keeps their row-pattern form only, never
         a CSR copy (what a per-rank assembler that produces its rows plane by plane would do)."""
@@ -109,7 +112,8 @@ class DistributedGMG:
         # (an anisotropic mesh would change the iteration count with the rank grid)
         self.lengths = lengths
         self.local = local_hierarchy or pa.build_local_hierarchy(self.cells_global, nlevels, self.grid, rank, order, lengths, rep_from,
-                                                                  depth, smoother, finest_depth=finest_depth)
+                                                                  depth, smoother, finest_depth=finest_depth, sub_from=sub_from,
+                                                                  sub_ranks=sub_ranks)
         self.t_assembly = time.perf_counter() - t0
         self.order = order
         h = C.c_void_p()
@@ -136,6 +140,8 @@ class DistributedGMG:
                 raise ValueError("transport must be 'rccl' or 'host'")
         levels = self.local["levels"]
         for l, L in enumerate(levels):
+            if L is None:                                     # a level of a rank subset this rank is not part of
+                continue
             if world > 1 and not L.replicated:
                 if not hasattr(L, "overlap"):
                     L.overlap = False
@@ -165,7 +171,7 @@ class DistributedGMG:
                 self._set(lib.gmg_set_matrix, l, L.A)
             if l < nlevels - 1:
                 nxt = levels[l + 1]
-                t_stream = streamable and (nxt.replicated or getattr(nxt, "overlap", False) or world == 1)
+                t_stream = streamable and nxt is not None and (nxt.replicated or getattr(nxt, "overlap", False) or world == 1)
                 if t_stream:
                     self._stream(abi.OP_P, l, L.P, stream_rows)
                     self._stream(abi.OP_R, l, L.R, stream_rows)
@@ -186,6 +192,11 @@ class DistributedGMG:
                         gp, gi = np.ascontiguousarray(G.ptr, dtype=np.int64), np.ascontiguousarray(G.idx, dtype=np.int64)
                         abi.check(h, lib.gmg_set_prolongation_patch_correction_rhs(h, l, G.shape[0], G.nnz, C.c_void_p(gp.ctypes.data),
                                                                                    C.c_void_p(gi.ctypes.data), C.c_void_p(G.val.ctypes.data), abi.CSR, 0, 8))
+        sub = self.local.get("sub") if world > 1 else None
+        if sub is not None:
+            tp, fp = abi.RedistPlan.from_dict(sub["to_sub"], self._keep), abi.RedistPlan.from_dict(sub["from_sub"], self._keep)
+            abi.check(h, lib.gmg_set_redistribution(h, sub["sub_from"], int(sub["member"]), sub["n_glue_own"], sub["n_glue_ghost"],
+                                                    C.byref(tp), C.byref(fp)))
         K = self.local.get("krylov") if world > 1 else None
         if K is not None:
             # finest level in the overlapping layout: the Krylov operator in the caller's own | ghost numbering + the owned entries' places
@@ -430,8 +441,20 @@ def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, de
             cand = {k: v + (idx_us if k > 0 else 0.0) for k, v in cand.items()}
         best = min(cand, key=cand.get)
         depths[l] = best
+        # the same level on a SUBSET of M ranks (np_per_level of the reference; DistributedGMG(sub_from=..., sub_ranks=M)): each member
+        # holds world / M times the rows, and every pass pays one redistribution (latency + n_own doubles over one link) -- reported so
+        # that the choice "all ranks" is visible as a number; the planner never picks a subset unless this beats `best`
+        subset = {}
+        if l >= 1:
+            for M in (1, 2, 4):
+                if M >= world:
+                    continue
+                cm = c * (world / M) ** (1.0 / 3.0)
+                redist_us = MODEL["exchange_us"] + c ** 3 * 8.0 / (MODEL["link_GBs"] * 1e3)
+                subset[str(M)] = round(min(_pass_us(cm, k, niter) for k in depth_choices if k <= niter and (k > 0 or M > 1)) + redist_us, 1)
         table.append(dict(level=l, cells_per_rank=c, layout="own|ghost, exchange overlapped" if best == 0 else f"overlapping, depth {best}",
                           modelled_pass_us={str(k): round(v, 1) for k, v in cand.items()},
+                          modelled_pass_us_on_rank_subset=subset,
                           exchanges_per_pass=niter if best == 0 else -(-niter // best)))
     env = os.environ.get("GMG_HALO_DEPTH")
     if env is not None:

@@ -392,7 +392,7 @@ def _restr_tables_ext(nc_coarse_global, order, c_elo, c_ehi, clo, chi, felo, feh
 
 
 def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengths=None, rep_from=None, depth=None, smoother="jacobi",
-                          finest_depth=0):
+                          finest_depth=0, sub_from=None, sub_ranks=None):
     """Local operators of `rank` for every level.
 
     Levels >= rep_from are REPLICATED (global operators on every rank, no halo); by default only the
@@ -402,7 +402,15 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
     many node layers a sweep consumes, see _OverlapGeom).  finest_depth > 0: the FINEST level in the overlapping layout too -- the
     preconditioner's level 0 then lives in the extended-box numbering while the Krylov solver keeps the caller's own | ghost vectors:
     the dict gains "krylov" = the finest operator in the own | ghost layout (a LocalLevel with A and the exchange plan) whose
-    `own_idx` maps every owned entry to its local id on level 0 (gmg_set_krylov_map).  Returns dict(levels=[LocalLevel...],
+    `own_idx` maps every owned entry to its local id on level 0 (gmg_set_krylov_map).
+    sub_from / sub_ranks: the partitioned levels sub_from .. rep_from-1 live on the FIRST `sub_ranks` ranks only (their own rank grid
+    over the same domain; the other ranks hold nothing of them -- entries None) -- the reference's np_per_level / redistribute!
+    (ModelHierarchies.jl:80-148, GridTransferOperators.jl:447-532).  Level sub_from then exists in two partitions: the GLUED one on all
+    ranks (coarse nodes with the owners of the fine nodes they coincide with: P / R of level sub_from-1 are built against it, own |
+    ghost numbering) and the subset's; the dict gains "sub" = dict(sub_from, members, member, n_glue_own, n_glue_ghost, to_sub,
+    from_sub): the two redistribution plans (restricted residual: glued owners -> subset owners; correction: subset owners -> glued
+    own AND ghost entries, so no separate consistent! is needed), each dict(nbr_rank, snd_ptr, snd_idx, rcv_ptr, rcv_idx, self_src,
+    self_dst) with source / destination LOCAL ids, both sides enumerating by ascending global id.  Returns dict(levels=[LocalLevel...],
     rep_from, rep_gid (global ids, in level rep_from numbering, of the rows this rank's boundary restriction produces), cells, grid)."""
     nc = tuple(int(c) for c in cells_global_fine)
     d = len(nc)
@@ -424,16 +432,31 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
             depths[l] = 0
     reach = order if smoother == "jacobi" else 3 * order - 2
     cells = [tuple(c // (2 ** l) for c in nc3[:d]) + (1,) * (3 - d) for l in range(nlevels)]
+    if sub_from is not None and nranks > 1:
+        if not (1 <= sub_from < rep_from and 1 <= int(sub_ranks) < nranks):
+            raise ValueError("sub_from must be in 1..rep_from-1 and sub_ranks in 1..nranks-1")
+        subgrid = tuple(rank_grid(int(sub_ranks), d))[:3]
+    else:
+        sub_from, subgrid = None, None
+
+    def grid_of(l):
+        return subgrid if (sub_from is not None and l >= sub_from) else grid
+    member = sub_from is None or rank < int(sub_ranks)
+
+    def active(l):
+        """does this rank hold a part of level l?"""
+        return l >= rep_from or sub_from is None or l < sub_from or member
     for l in range(nlevels):
         for k in range(d):
             if cells[l][k] * 2 ** l != nc3[k] or cells[l][k] < 2:
                 raise ValueError("cells must be divisible by 2^(nlevels-1) with >= 2 coarsest cells")
-            if l < min(rep_from + 1, nlevels) and (cells[l][k] % grid[k] or cells[l][k] // grid[k] < 2):
+            if l < min(rep_from + 1, nlevels) and (cells[l][k] % grid_of(l)[k] or cells[l][k] // grid_of(l)[k] < 2):
                 raise ValueError("partitioned levels need >= 2 cells per rank and direction")
     Ls = po._lengths(lengths, d)
     ngeom = min(rep_from + 1, nlevels)
-    geoms = [_LevelGeom(cells[l], order, grid, rank, d) for l in range(ngeom)]
-    ogeoms = [_OverlapGeom(cells[l], grid, rank, d, depths[l], order, reach) if depths[l] > 0 else None for l in range(nlevels)]
+    geoms = [_LevelGeom(cells[l], order, grid_of(l), rank, d) if (active(l) and (member or l < rep_from)) else None for l in range(ngeom)]
+    ogeoms = [_OverlapGeom(cells[l], grid_of(l), rank, d, depths[l], order, reach) if (depths[l] > 0 and active(l)) else None for l in range(nlevels)]
+    glue = _LevelGeom(cells[sub_from], order, grid, rank, d) if sub_from is not None else None   # level sub_from as the fine partition sees it
 
     def fine_cols(l):
         """(elo, ehi) per axis of the column numbering of level l's vectors + the remap to apply afterwards (None: lexicographic as is)"""
@@ -466,6 +489,9 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
             krylov = own_ghost_level(0)
             krylov.own_idx = ogeoms[0].own_idx        # owned entries (ascending global id on both sides) -> local ids on level 0
             assert np.array_equal(krylov.own_gid, ogeoms[0].own_gid)
+        if not active(l):
+            levels.append(None)
+            continue
         if l < rep_from and ogeoms[l] is not None:
             og = ogeoms[l]
             tabs = [_axis_tables_local(cells[l][k], order, og.rng[k][2], og.rng[k][3], og.rng[k][2], og.rng[k][3], k < d, Ls[k]) for k in range(3)]
@@ -492,14 +518,22 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
         levels.append(L)
     rep_gid = np.zeros(0, dtype=np.int64)
     for l in range(nlevels - 1):
+        if not active(l):
+            continue
         if l + 1 <= rep_from and l < rep_from:    # fine level partitioned
             gf, gc = geoms[l], geoms[l + 1]
             of, oc = ogeoms[l], ogeoms[l + 1] if l + 1 < rep_from else None
+            to_glue = sub_from is not None and l + 1 == sub_from     # the coarse level as the FINE partition sees it (own | ghost)
+            if to_glue:
+                gc, oc = glue, None
             # rows of P: the fine level's matrix rows (owned rows, or every local entry in the overlapping layout)
             frows = [(of.rng[k][2], of.rng[k][3]) if of is not None else (gf.rng[k][0], gf.rng[k][1]) for k in range(3)]
             fcols, fremap = fine_cols(l)
             if l + 1 < rep_from:                  # coarse level partitioned too
-                ccols, cremap = fine_cols(l + 1)
+                if to_glue:
+                    ccols, cremap = [(glue.rng[k][2], glue.rng[k][3]) for k in range(3)], glue.remap
+                else:
+                    ccols, cremap = fine_cols(l + 1)
                 pt = [_interp_tables_local(cells[l + 1][k], order, frows[k][0], frows[k][1], ccols[k][0], ccols[k][1], k < d) for k in range(3)]
                 Pm = po._tensor_csr([t[1] for t in pt], [tuple(t[2] for t in pt)], [t[0] for t in pt])
                 levels[l].P = cremap(Pm) if cremap is not None else Pm
@@ -521,5 +555,57 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
         else:                                     # both replicated: global transfer operators
             levels[l].P = po.prolongation(cells[l + 1][:d], order)
             levels[l].R = levels[l].P.transpose()
+    sub = None
+    if sub_from is not None:
+        M = int(sub_ranks)
+        glues = [glue if q == rank else _LevelGeom(cells[sub_from], order, grid, q, d) for q in range(nranks)]
+
+        def subset_own(m):
+            """(global ids, local ids on the subset's level sub_from) of the entries member m owns, ascending global id"""
+            if depths[sub_from] > 0:
+                og = ogeoms[sub_from] if m == rank else _OverlapGeom(cells[sub_from], subgrid, m, d, depths[sub_from], order, reach)
+                return og.own_gid, og.own_idx
+            g = geoms[sub_from] if m == rank else _LevelGeom(cells[sub_from], order, subgrid, m, d)
+            return g.own_gid, np.arange(g.n_own, dtype=np.int64)
+        subs = [subset_own(m) for m in range(M)]
+
+        def need(q):
+            """(global ids, local ids) of glued own + ghost entries of rank q, sorted by global id"""
+            gid = np.concatenate([glues[q].own_gid, glues[q].ghost_gid])
+            o = np.argsort(gid, kind="stable")
+            return gid[o], o.astype(np.int64)
+
+        def plan(src_of, dst_of, senders, receivers):
+            """rank -> (gids ascending, local ids) of what it holds (src) / wants (dst); entries travel from the sender that holds them
+            to every receiver that wants them"""
+            nbr, sp, rp, si, ri = [], [0], [0], [], []
+            self_src = self_dst = np.zeros(0, np.int64)
+            mine_s = src_of(rank) if rank in senders else None
+            mine_d = dst_of(rank) if rank in receivers else None
+            for q in range(nranks):
+                snd = rcv = np.zeros(0, np.int64)
+                if mine_s is not None and q in receivers:
+                    gq, _ = dst_of(q)
+                    common = np.intersect1d(mine_s[0], gq, assume_unique=True)
+                    snd = mine_s[1][np.searchsorted(mine_s[0], common)]
+                if mine_d is not None and q in senders:
+                    gq, _ = src_of(q)
+                    common = np.intersect1d(gq, mine_d[0], assume_unique=True)
+                    rcv = mine_d[1][np.searchsorted(mine_d[0], common)]
+                if q == rank:
+                    self_src, self_dst = snd, rcv
+                    continue
+                if snd.size or rcv.size:
+                    nbr.append(q); si.append(snd); ri.append(rcv)
+                    sp.append(sp[-1] + snd.size); rp.append(rp[-1] + rcv.size)
+            cat = (lambda xs: np.concatenate(xs).astype(np.int64) if xs else np.zeros(0, np.int64))
+            return dict(nbr_rank=np.asarray(nbr, dtype=np.int32), snd_ptr=np.asarray(sp, dtype=np.int64), snd_idx=cat(si),
+                        rcv_ptr=np.asarray(rp, dtype=np.int64), rcv_idx=cat(ri), self_src=self_src.astype(np.int64), self_dst=self_dst.astype(np.int64))
+        allr, mem = set(range(nranks)), set(range(M))
+        glue_own = lambda q: (glues[q].own_gid, np.arange(glues[q].n_own, dtype=np.int64))
+        sub_own = lambda m: subs[m]
+        sub = dict(sub_from=int(sub_from), members=M, member=bool(member), n_glue_own=int(glue.n_own), n_glue_ghost=int(glue.n_ghost),
+                   to_sub=plan(glue_own, sub_own, allr, mem), from_sub=plan(sub_own, need, mem, allr),
+                   n_sub_local=(int(levels[sub_from].n_own + levels[sub_from].n_ghost) if member else 0))
     return dict(levels=levels, rep_from=rep_from, rep_gid=np.ascontiguousarray(rep_gid, dtype=np.int64),
-                cells=[c[:d] for c in cells], grid=grid[:d], order=order, rank=rank, nranks=nranks, depths=depths, krylov=krylov)
+                cells=[c[:d] for c in cells], grid=grid[:d], order=order, rank=rank, nranks=nranks, depths=depths, krylov=krylov, sub=sub)

@@ -413,6 +413,25 @@ GMG_API int gmg_get_comm_info(gmg_handle_t h, int *transport, int *rank, int *nr
  * Reference analogue: coarse levels living on fewer ranks (np_per_level, ModelHierarchies.jl:80-148)
  * with redistribute! at the boundary (GridTransferOperators.jl:447-532). */
 GMG_API int gmg_set_replication(gmg_handle_t h, int lev, const int64_t *own_global_ids, int64_t n_own);
+/* Levels lev .. (first replicated level - 1) live on a RANK SUBSET (round 5; the reference's np_per_level with redistribute! at the
+ * boundary, ModelHierarchies.jl:80-148, GridTransferOperators.jl:447-532 -- redistribute_cell_dofs! there, two p2p plans here).
+ * Level lev then exists in two partitions: the GLUED one of all ranks (its dofs with the owners of the fine dofs they coincide with;
+ * own | ghost numbering of n_glue_own + n_glue_ghost entries: P_{lev-1} has those columns, R_{lev-1} yields the n_glue_own owned rows)
+ * and the subset's (gmg_set_partition / _overlap + operators on the member ranks only; the other ranks pass nothing for the levels
+ * lev .. rep-1 and member = 0).  to_sub carries the restricted residual from the glued owners to the subset owners; from_sub carries
+ * the correction from the subset owners to the glued own AND ghost entries (so P needs no consistent! of its own).  A plan lists
+ * per neighbour the local ids sent (in the source space) and the local ids received (in the destination space), both sides in the
+ * same order, plus the entries that stay on the rank.  Ranks outside the subset take part in the collectives below (the all-reduce
+ * that assembles the replicated residual) with a zero contribution.  Every rank calls this, with its own plans, before gmg_setup. */
+typedef struct {
+  int nnbr;
+  const int32_t *nbr_rank;
+  const int64_t *snd_ptr, *snd_idx, *rcv_ptr, *rcv_idx;
+  int64_t nself;
+  const int64_t *self_src, *self_dst;
+} gmg_redist_plan;
+GMG_API int gmg_set_redistribution(gmg_handle_t h, int lev, int member, int64_t n_glue_own, int64_t n_glue_ghost,
+                                   const gmg_redist_plan *to_sub, const gmg_redist_plan *from_sub);
 
 /* ---- measurement --------------------------------------------------------------- */
 /* Bracket launches of the fused Richardson-Jacobi sweep on `lev` with HIP events on the handle's

@@ -23,10 +23,13 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
     import scipy.sparse.linalg as spla
     levels = local["levels"]
     nlev = len(levels)
-    A = [L.A.to_scipy() for L in levels]
-    P = [L.P.to_scipy() for L in levels[:-1]]
-    R = [L.R.to_scipy() for L in levels[:-1]]
-    dinv = [1.0 / A[l].diagonal() if levels[l].overlap else 1.0 / A[l].diagonal()[: levels[l].n_own] for l in range(nlev - 1)]   # own x own diagonal (overlapping layout: every local row)
+    # (levels a rank holds nothing of -- they live on a rank subset, local["sub"] -- are None)
+    A = [L.A.to_scipy() if L is not None else None for L in levels]
+    P = [L.P.to_scipy() if L is not None and L.P is not None else None for L in levels[:-1]]
+    R = [L.R.to_scipy() if L is not None and L.R is not None else None for L in levels[:-1]]
+    dinv = [None if levels[l] is None else 1.0 / A[l].diagonal() if levels[l].overlap else 1.0 / A[l].diagonal()[: levels[l].n_own]
+            for l in range(nlev - 1)]   # own x own diagonal (overlapping layout: every local row)
+    sub = local.get("sub")
     stats = {"exchanges": 0}
     rep_from, rep_gid = local["rep_from"], local["rep_gid"]
     Gc = A[nlev - 1].tocsc()                    # coarsest level is always replicated (global matrix)
@@ -65,6 +68,35 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
                 w.wait()
         for t, r0, r1 in keep:
             v[L.n_own + r0: L.n_own + r1] = t.numpy()
+
+    def redistribute(plan, src, dst):
+        """entries of `src` to the ranks that hold them in another partition of the same level (redistribute!,
+        GridTransferOperators.jl:447-532): local ids on both sides, ascending global id per neighbour"""
+        stats["redistributions"] = stats.get("redistributions", 0) + 1
+        dst[plan["self_dst"]] = src[plan["self_src"]]
+        ops, keep = [], []
+        for k, q in enumerate(plan["nbr_rank"]):
+            r0, r1 = plan["rcv_ptr"][k], plan["rcv_ptr"][k + 1]
+            if r1 > r0:
+                t = torch.zeros(int(r1 - r0), dtype=torch.float64); keep.append((t, r0, r1))
+                ops.append(dist.P2POp(dist.irecv, t, int(q)))
+            sidx = plan["snd_idx"][plan["snd_ptr"][k]:plan["snd_ptr"][k + 1]]
+            if sidx.size:
+                ops.append(dist.P2POp(dist.isend, torch.from_numpy(src[sidx].copy()), int(q)))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for t, r0, r1 in keep:
+            dst[plan["rcv_idx"][r0:r1]] = t.numpy()
+
+    def shadow(l):
+        """a rank that holds nothing of levels sub_from .. rep_from-1 still takes part in the collectives below them: the all-reduce
+        that assembles the replicated residual (with a zero contribution)"""
+        if l + 1 == rep_from:
+            full = torch.zeros(levels[l + 1].n_own, dtype=torch.float64)
+            dist.all_reduce(full)
+        elif l + 1 < rep_from:
+            shadow(l + 1)
 
     def assemble(l, v):
         """ghost -> owner add (reverse of `exchange`)"""
@@ -145,6 +177,30 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
             return
         smooth(l, x, r)
         exchange(l, r)
+        if sub is not None and l + 1 == sub["sub_from"]:
+            # level l+1 lives on a rank subset: restrict in the glued partition, redistribute, recurse on the members, bring the
+            # correction back to the glued own AND ghost entries (P reads both)
+            rg = R[l] @ r
+            rH, dxH = np.zeros(sub["n_sub_local"]), np.zeros(sub["n_sub_local"])
+            redistribute(sub["to_sub"], rg, rH)
+            if sub["member"]:
+                cycle(l + 1, dxH, rH)
+            else:
+                shadow(l + 1)
+            xg = np.zeros(sub["n_glue_own"] + sub["n_glue_ghost"])
+            redistribute(sub["from_sub"], dxH, xg)
+            if levels[l].overlap:
+                dx = P[l] @ xg
+                x += dx
+                exchange(l, dx)
+                r -= A[l] @ dx
+            else:
+                dx = vec(l); dx[:n] = P[l] @ xg
+                x[:n] += dx[:n]
+                exchange(l, dx)
+                r[:n] -= A[l] @ dx
+            smooth(l, x, r)
+            return
         rH = vec(l + 1)
         if l + 1 == rep_from:                    # distributed -> replicated boundary: assemble by all-reduce
             full = torch.zeros(levels[l + 1].n_own, dtype=torch.float64)
@@ -197,6 +253,7 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
             res = np.sqrt(gdot(r[:n], r[:n])); hist.append(res); it += 1
             done = (it >= maxiter) or (res / hist[0] < rtol) or (res < atol)
         numpy_distributed_cg.last_exchanges = stats["exchanges"]
+        numpy_distributed_cg.last_redistributions = stats.get("redistributions", 0)
         return x[:n].copy(), it, np.array(hist)
     x, p, z = vec(0), vec(0), vec(0)
     r = vec(0); r[:n] = b_own                      # x0 = 0
@@ -218,6 +275,7 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
         res = np.sqrt(gdot(r[:n], r[:n])); hist.append(res); it += 1
         done = (it >= maxiter) or (res / hist[0] < rtol) or (res < atol)
     numpy_distributed_cg.last_exchanges = stats["exchanges"]
+    numpy_distributed_cg.last_redistributions = stats.get("redistributions", 0)
     return x[:n].copy(), it, np.array(hist)
 
 
@@ -532,6 +590,7 @@ def main():
     smoother = os.environ.get("GMG_TEST_SMOOTHER", "jacobi")
     p_niter, p_omega = 4, 0.2
     depth = int(os.environ.get("GMG_TEST_DEPTH", "0"))      # > 0: partitioned levels >= 1 in the overlapping layout with that many ghost layers
+    sub_from, sub_ranks = int(os.environ.get("GMG_TEST_SUB_FROM", "0")) or None, int(os.environ.get("GMG_TEST_SUB_RANKS", "0")) or None
     fdepth = int(os.environ.get("GMG_TEST_FINEST_DEPTH", "0"))   # > 0: the finest level in the overlapping layout too (separate Krylov operator)
     verdict = {}
     if mode == "numpy_stokes":
@@ -541,13 +600,16 @@ def main():
     if mode == "gpu_block":
         pass
     elif mode == "numpy":
-        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from, depth, smoother, finest_depth=fdepth)
+        local = pa.build_local_hierarchy(cg, nlev, grid, rank, order, None, rep_from, depth, smoother, finest_depth=fdepth,
+                                         sub_from=sub_from, sub_ranks=sub_ranks)
         b = po.dirichlet_lift_rhs(cg, order)[local["levels"][0].own_gid]
         patches = None
         if smoother == "patch":
             patches = []
             for l in range(nlev - 1):
                 Lc = local["levels"][l]
+                if Lc is None:                                  # a level of a rank subset this rank is not part of
+                    patches.append(None); continue
                 Ag = po.poisson_matrix(local["cells"][l], order).to_scipy().tocsr()
                 if getattr(Lc, "overlap", False):
                     pp, pl = Lc.ogeom.vertex_star_patches()
@@ -569,6 +631,7 @@ def main():
         else:
             x, nit, hist = numpy_distributed_cg(local, rank, world, dist, torch, b, maxiter, atol, rtol)
             verdict["exchanges"] = int(numpy_distributed_cg.last_exchanges)
+            verdict["redistributions"] = int(numpy_distributed_cg.last_redistributions)
         gid = local["levels"][0].own_gid
     else:
         ndev = torch.cuda.device_count()
@@ -577,6 +640,7 @@ def main():
         g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=rep_from,
                                     order=order, smoother=smoother, niter=(p_niter if smoother == "patch" else 10),
                                     omega=(p_omega if smoother == "patch" else 2.0 / 3.0), depth=depth, finest_depth=fdepth,
+                                    sub_from=sub_from, sub_ranks=sub_ranks,
                                     stream_rows=int(os.environ.get("GMG_TEST_STREAM_ROWS", "0")))
         verdict["streamed_levels"] = list(getattr(g, "streamed_levels", []))
         b = g.rhs_lin()

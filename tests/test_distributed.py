@@ -390,12 +390,15 @@ def test_rccl_binding_selftest_single_rank(pkg):
 
 
 @pytest.mark.gpu
-def test_bench_multi_rank_path_with_overlapping_levels(tmp_path):
+@pytest.mark.parametrize("finest", [None, 0])
+def test_bench_multi_rank_path_with_overlapping_levels(finest, tmp_path):
     """`bench.py --gpus 2` with the planner forced to keep level 1 partitioned in the overlapping layout (depth 5): the N > 1 line
-    carries both legs, the partition plan and the per-solve exchange counts."""
+    carries both legs, the partition plan and the per-solve exchange counts.  At 32^3 cells per rank the planner puts the FINEST level
+    into the overlapping layout too (depth 10: a sweep is far shorter than an exchange; separate Krylov operator); GMG_FINEST_DEPTH=0
+    keeps it own | ghost as at BASELINE config 4's size."""
     import subprocess
     env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1",
-               GMG_REP_ROWS="3000", GMG_HALO_DEPTH="5")
+               GMG_REP_ROWS="3000", GMG_HALO_DEPTH="5", **({} if finest is None else {"GMG_FINEST_DEPTH": str(finest)}))
     root = os.path.dirname(HERE)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "32", "--levels", "4",
@@ -403,7 +406,7 @@ def test_bench_multi_rank_path_with_overlapping_levels(tmp_path):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["headline_leg"] == "default" and d["roofline_compressed"]["leg"] == "default" and d["roofline"]["leg"] == "generic"
-    assert d["config"]["halo_depths"][:3] == [0, 5, 0] and d["config"]["replicated_from_level"] == 2
+    assert d["config"]["halo_depths"][:3] == [10 if finest is None else finest, 5, 0] and d["config"]["replicated_from_level"] == 2
     assert d["config"]["cg_iterations"] == d["config"]["cg_iterations_generic"] <= 4 and d["config"]["max_abs_error_vs_exact"] < 1e-4
     assert d["value_generic"] > 0 and d["config"]["halo_exchanges_per_solve"] > 0
 
@@ -639,3 +642,33 @@ def test_distributed_real_stokes_with_overlapping_velocity_levels(world, n, nlev
         assert w["true_residual"] < 1e-7 and w["div_residual"] < 1e-7, w
     assert v["overlap_levels"] == list(range(1, nlev - 1)) and v0["overlap_levels"] == []
     assert v["exchanges"] < v0["exchanges"], (v["exchanges"], v0["exchanges"])
+
+
+SUBSET_CASES = [(4, (8, 8, 8), 3, 2, 1, 2, 0), (8, (8, 8, 8), 3, 2, 1, 2, 0), (8, (8, 8, 8), 3, 2, 1, 4, 2), (4, (16, 16), 4, 3, 1, 2, 0),
+                (4, (16, 16), 4, 3, 2, 1, 0)]
+
+
+@pytest.mark.parametrize("world,cells,nlev,rep,sub_from,sub_ranks,depth", SUBSET_CASES)
+def test_levels_on_a_rank_subset_numpy_gloo(world, cells, nlev, rep, sub_from, sub_ranks, depth, tmp_path):
+    """np_per_level / redistribute! (ModelHierarchies.jl:80-148, GridTransferOperators.jl:447-532): the partitioned levels
+    sub_from .. rep-1 on the first `sub_ranks` ranks only.  Level sub_from exists in the glued partition of all ranks and in the
+    subset's; the restricted residual and the correction cross with one redistribution each per V-cycle (2 per CG iteration), the
+    other ranks shadow the all-reduce of the replicated boundary.  Iteration count, history and solution of the serial oracle."""
+    env = {"GMG_TEST_SUB_FROM": str(sub_from), "GMG_TEST_SUB_RANKS": str(sub_ranks), "GMG_TEST_DEPTH": str(depth)}
+    v = _launch("numpy", world, cells, nlev, tmp_path, rep_from=rep, extra_env=env)
+    _check(v)
+    assert v["redistributions"] == 2 * v["iters"], v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,cells,nlev,rep,sub_from,sub_ranks,depth", SUBSET_CASES)
+def test_levels_on_a_rank_subset_on_gpu_host_transport(world, cells, nlev, rep, sub_from, sub_ranks, depth, tmp_path):
+    """The same through the library (gmg_set_redistribution; several ranks on one GPU, host transport): CG and FGMRES with the serial
+    oracle's iteration counts, the solution of the all-rank layout to rounding."""
+    env = {"GMG_PERSIST_SHARED": "1", "GMG_TEST_DEPTH": str(depth)}
+    v0 = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env=env)
+    v = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep,
+                extra_env=dict(env, GMG_TEST_SUB_FROM=str(sub_from), GMG_TEST_SUB_RANKS=str(sub_ranks)))
+    _check(v0); _check(v)
+    assert v["iters"] == v0["iters"] and v["fgmres_iters"] == v0["fgmres_iters"] and v["fgmres_vs_cg"] < 1e-6
+    assert np.linalg.norm(v["x"] - v0["x"]) <= 1e-12 * np.linalg.norm(v0["x"])
