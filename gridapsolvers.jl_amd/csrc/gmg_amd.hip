@@ -5960,6 +5960,7 @@ int gmg_op_apply(gmg_handle_t h, int lev, int op, const double *x, double *y, in
   return guarded(h, [&] {
     check_ready(h);
     check_level(h, lev, op != GMG_OP_A);
+    REQUIRE(!h->inactive(lev), GMG_ERR_STATE, "this rank holds no part of that level (it lives on a rank subset, gmg_set_redistribution)");
     REQUIRE(x && y, GMG_ERR_INVALID, "null vector");
     Level &L = h->lev[lev];
     const DevCSR *M = op == GMG_OP_A ? &L.A : op == GMG_OP_P ? &L.P : op == GMG_OP_R ? &L.R : nullptr;
@@ -5989,6 +5990,7 @@ int gmg_smooth(gmg_handle_t h, int lev, int which, double *x, double *r, int mem
   return guarded(h, [&] {
     check_ready(h);
     check_level(h, lev, true);
+    REQUIRE(!h->inactive(lev), GMG_ERR_STATE, "this rank holds no part of that level (it lives on a rank subset, gmg_set_redistribution)");
     REQUIRE(x && r, GMG_ERR_INVALID, "null vector");
     REQUIRE(which == GMG_PRE || which == GMG_POST, GMG_ERR_INVALID, "which must be GMG_PRE or GMG_POST");
     Level &L = h->lev[lev];
@@ -6011,6 +6013,7 @@ int gmg_precond_apply(gmg_handle_t h, int lev, int which, const double *r, doubl
   return guarded(h, [&] {
     check_ready(h);
     check_level(h, lev, true);
+    REQUIRE(!h->inactive(lev), GMG_ERR_STATE, "this rank holds no part of that level (it lives on a rank subset, gmg_set_redistribution)");
     REQUIRE(r && dx, GMG_ERR_INVALID, "null vector");
     Level &L = h->lev[lev];
     Smoother &S = which == GMG_POST ? L.post : L.pre;
@@ -6432,6 +6435,7 @@ int gmg_sweep_signature(gmg_handle_t h, int lev, char *buf, int cap)
   return guarded(h, [&] {
     check_ready(h);
     check_level(h, lev, false);
+    REQUIRE(!h->inactive(lev), GMG_ERR_STATE, "this rank holds no part of that level (it lives on a rank subset, gmg_set_redistribution)");
     REQUIRE(buf && cap > 0, GMG_ERR_INVALID, "null buffer");
     std::snprintf(buf, (size_t)cap, "%s", h->lev[lev].A.sweep_sig);
   });
@@ -6442,6 +6446,7 @@ int gmg_level_format(gmg_handle_t h, int lev, int *sell, int *vdict, int *idx16,
   return guarded(h, [&] {
     check_ready(h);
     check_level(h, lev, false);
+    REQUIRE(!h->inactive(lev), GMG_ERR_STATE, "this rank holds no part of that level (it lives on a rank subset, gmg_set_redistribution)");
     const DevCSR &A = h->lev[lev].A;
     if (sell) *sell = A.pat ? 2 : (A.sell ? (A.opat ? 3 : 1) : 0);
     if (vdict) *vdict = A.vdict ? 1 : 0;
