@@ -52,6 +52,17 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 WS_CELLS, WS_LEVELS = 288, 6   # per-GPU problem of the N > 1 runs: BASELINE configs[3] = 576^3 cells on 2x2x2 GPUs, 6 levels
 # the generic (12 B/nnz) leg: per-handle options (gmg_set_option), not environment variables
 GENERIC_OPTIONS = {"vdict": 0, "idx16": 0, "pattern": 0, "opattern": 0}
+
+
+def prof_stride_for(steps, sweeps_per_solve=60):
+    """how rarely the timed solves' sweep launches are bracketed by HIP events: the largest odd stride that leaves >= 8 samples"""
+    env = os.environ.get("GMG_PROF_STRIDE")
+    if env:
+        return int(env)
+    for s in (61, 31, 13, 7):
+        if steps * sweeps_per_solve // s >= 8:
+            return s
+    return 7
 ALL_LEGS = ("default", "generic", "varcoef", "weak_ref", "host_io", "config3", "config5", "cpu")
 LEGS_NOTE = ("same key <-> leg mapping at every --gpus N: default leg (the product as shipped: gmg_setup picks the storage layout) = `value`, "
              "`ms_per_step`, `roofline_compressed`; generic leg (every structure-exploiting layout off: the 12 B/nnz (col,val) stream SURVEY 8(d)'s "
@@ -377,8 +388,10 @@ def main():
     maxiter, atol, rtol = (20, 1e-14, 1e-6) if args.rhs == "lin" else (100, 1e-14, 1e-8)
 
     def leg(H, b, nlev, steps, warmup, options=None):
-        """numerical_setup + `steps` timed solves; HIP events around every 7th finest-level sweep launch (prof_stride: odd, so that
-        both alternating sweep variants are sampled in proportion)."""
+        """numerical_setup + `steps` timed solves; HIP events around every prof_stride-th finest-level sweep launch of the timed solves
+        (the roofline's per-launch time).  Every sampled launch costs the stream ~11 us (two event bubbles): at the library's default
+        stride of 7 that was 5 % of the 128^3 solve time this function reports, so the stride is the largest of 61 / 31 / 13 / 7 that
+        still leaves >= 8 samples (60 finest sweeps per solve; odd and coprime with 60: both alternating sweep forms, every position)."""
         solver = make_solver(H, nlev, maxiter, atol, rtol, options)
         t0 = time.perf_counter()
         ns = S.numerical_setup(S.symbolic_setup(solver, H["mats"][0]), H["mats"][0])
@@ -394,6 +407,8 @@ def main():
             S.solve_(xd, ns, bd)
         for _ in range(warmup):
             step()
+        stride = prof_stride_for(steps)
+        ns.P_ns.set_option("prof_stride", stride)
         ns.P_ns.profile(0, True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -402,6 +417,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         st = ns.P_ns.kernel_stats()
+        st["prof_stride"] = stride
         ns.P_ns.profile(0, False)
         fmt = ns.P_ns.level_format(0)
         fmt["sweep_signature"] = ns.P_ns.sweep_signature(0)
@@ -417,6 +433,7 @@ def main():
              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": (ach / HBM_PEAK_GBS) if ach else None,
              "bytes_per_launch": r["st"][bytes_key], "avg_launch_ms": r["avg_ms"], "launches_timed": r["st"]["launches"],
+             "event_stride": r["st"].get("prof_stride"),
              "rows": int(r["st"]["rows"]), "nnz": int(r["st"]["nnz"])}
         if label_extra:
             d["bytes_model"] = label_extra
@@ -528,6 +545,7 @@ def main():
     vbytes, cgbytes = R["model_bytes"]
     # the same sweep kernel on the coarser levels (report per level; these fit the Infinity Cache)
     per_level = []
+    ns.P_ns.set_option("prof_stride", 7)     # (untimed runs: dense sampling)
     for lv in range(1, nlev - 1):
         ns.P_ns.profile(lv, True)
         for _ in range(2):

@@ -5683,7 +5683,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_STRICT", false}, {"GMG_PAT_TILE", false}, {"GMG_PAT_TILE_LDS", false}, {"GMG_PAT_TILE_MIN", false}, {"GMG_PAT_TILE_ROWS", false},
   {"GMG_PAT_TILE_T", false}, {"GMG_PAT_UN", false}, {"GMG_PAT_WGS", false}, {"GMG_PAT_WIDE", false}, {"GMG_PAT_WIDE_LDS", false},
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
-  {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", false}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
+  {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", true}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
   {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PAT_ZWALK_WIDE_ROWS", false}, {"GMG_PERSIST_TAG", false}, {"GMG_PERSIST_TAG_MAX_SLICES", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
@@ -6356,6 +6356,8 @@ int gmg_profile_enable(gmg_handle_t h, int lev, int enable)
       for (auto &ev : h->prof_ev) HIP_CHECK(hipEventCreate(&ev));
     }
     h->prof_level = lev;
+    h->prof_stride = std::max(1, h->opt_int("GMG_PROF_STRIDE", 7));   // live: a caller picks the sampling density per measurement
+    h->prof_seq = 0;
     h->prof_used = 0;
     h->prof_ms = 0.0;
     h->prof_launches = 0; h->prof_fused = 0; h->prof_patch = false;

@@ -437,7 +437,9 @@ GMG_API int gmg_set_redistribution(gmg_handle_t h, int lev, int member, int64_t 
 /* Bracket launches of the fused Richardson-Jacobi sweep on `lev` with HIP events on the handle's
  * stream: every GMG_PROF_STRIDE-th launch (default 7 -- odd on purpose: sweeps alternate between the variant that leaves x
  * alone and the one that adds two increments to it, `x = (x + s_{k-1}) + s_k`, and an even stride would time one of them only;
- * an event pair costs ~4 us of stream time); enable=0 stops.  Read with gmg_get_kernel_stats (launch-weighted totals) and
+ * a sampled launch costs ~11 us of stream time -- two ~5.7 us bubbles, one per event (profiles/r05_tuning.md section 7: at stride 7 that
+ * was 5 % of a 128^3 solve) -- so a caller that times whole solves at the same time sets the option prof_stride (read at this call;
+ * odd and coprime with the number of sweeps per solve, e.g. 61) to keep the samples rare); enable=0 stops.  Read with gmg_get_kernel_stats (launch-weighted totals) and
  * gmg_get_kernel_stats_by_variant (index 0: sweeps that update x every time -- the generic layouts' first sweep, one-launch
  * passes, patch sweeps; 1: x untouched; 2: x updated with two increments). */
 GMG_API int gmg_profile_enable(gmg_handle_t h, int lev, int enable);
