@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One CG iteration of a bench.py run out of a rocprofv3 --kernel-trace database: python tools/iteration_timeline.py <dir> [which]
 The iterations are delimited by reduce_post_kernel (the norm of the residual posted to the host, CGSolvers.jl:111); `which` counts them
-from the end of the timed solves (default: the iteration before the last one of the last solve in front of the per-level profiling runs).
+from the end of the trace (default: the last iteration in which no launch is bracketed by the bench's own HIP events).
 Prints every kernel of the iteration (start offset us, duration, gap to the previous kernel's end, grid, name) and the sums by class."""
 import collections, glob, os, sqlite3, sys
 f = glob.glob(os.path.join(sys.argv[1], "**", "*.db"), recursive=True)
@@ -11,6 +11,16 @@ marks = [i for i, r in enumerate(rows) if "reduce_post_kernel" in r[3]]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 # segments between two norms that hold a whole V-cycle (>= 20 sweep launches), counted from the end
 segs = [(marks[i], marks[i + 1]) for i in range(len(marks) - 1) if sum("sweep_kernel" in r[3] for r in rows[marks[i] + 1:marks[i + 1] + 1]) >= 20]
+if len(sys.argv) <= 2:
+    # default: the last iteration whose launches are not bracketed by the bench's own HIP events (gmg_profile_enable: two bubbles of
+    # ~5.7 us per sampled launch -- bench.py's per-level profiling runs at the end of the trace, every prof_stride-th finest sweep
+    # of the timed solves): no idle gap above 2.5 us after the first launch
+    for w in range(8, len(segs)):
+        a_, b_ = segs[-w]
+        seq = rows[a_ + 1:b_ + 1]
+        if all(seq[i][0] - seq[i - 1][1] < 2500 for i in range(1, len(seq))):
+            which = w
+            break
 a, b = segs[-which]
 it = rows[a + 1:b + 1]
 t0 = it[0][0]
