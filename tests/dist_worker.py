@@ -640,7 +640,7 @@ def main():
         g = multigpu.DistributedGMG(cells, nlev, rank, world, device_id=dev, transport=transport, group=None, rep_from=rep_from,
                                     order=order, smoother=smoother, niter=(p_niter if smoother == "patch" else 10),
                                     omega=(p_omega if smoother == "patch" else 2.0 / 3.0), depth=depth, finest_depth=fdepth,
-                                    sub_from=sub_from, sub_ranks=sub_ranks,
+                                    sub_from=sub_from, sub_ranks=sub_ranks, cycle_type=os.environ.get("GMG_TEST_CYCLE", "v_cycle"),
                                     stream_rows=int(os.environ.get("GMG_TEST_STREAM_ROWS", "0")))
         verdict["streamed_levels"] = list(getattr(g, "streamed_levels", []))
         b = g.rhs_lin()
@@ -701,7 +701,8 @@ def main():
             sms = [orc.Smoother(orc.PATCH, p_niter, p_omega, *po.vertex_star_patches(c, order)) for c in H["ncells"][:-1]]
             go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=sms, maxiter=1)
         else:
-            go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1)
+            go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1,
+                         cycle={"v_cycle": orc.V_CYCLE, "w_cycle": orc.W_CYCLE, "f_cycle": orc.F_CYCLE}[os.environ.get("GMG_TEST_CYCLE", "v_cycle")])
         xo, nit_o, flag, hist_o = orc.cg_solve(H["mats"][0], bg, Pl=go, maxiter=maxiter, atol=atol, rtol=rtol)
         xg = np.zeros_like(xo)
         for gidq, xq, _, _ in parts:

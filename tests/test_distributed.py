@@ -674,3 +674,16 @@ def test_levels_on_a_rank_subset_on_gpu_host_transport(world, cells, nlev, rep, 
     _check(v0); _check(v)
     assert v["iters"] == v0["iters"] and v["fgmres_iters"] == v0["fgmres_iters"] and v["fgmres_vs_cg"] < 1e-6
     assert np.linalg.norm(v["x"] - v0["x"]) <= 1e-12 * np.linalg.norm(v0["x"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cycle", ["w_cycle", "f_cycle"])
+def test_rank_subset_levels_under_w_and_f_cycles(cycle, tmp_path):
+    """W and F cycles visit the subset levels and the replicated boundary below them more than once per cycle: the ranks outside the
+    subset must shadow exactly that recursion (`shadow_cycle`), or the all-reduces of the replicated boundary stop matching.  Two
+    subset levels (4 ranks -> 2), iteration counts of the serial oracle with the same cycle, the all-rank layout's solution."""
+    env = {"GMG_PERSIST_SHARED": "1", "GMG_TEST_CYCLE": cycle}
+    v0 = _launch("gpu", 4, (16, 16), 4, tmp_path, transport="host", rep_from=3, extra_env=env)
+    v = _launch("gpu", 4, (16, 16), 4, tmp_path, transport="host", rep_from=3, extra_env=dict(env, GMG_TEST_SUB_FROM="1", GMG_TEST_SUB_RANKS="2"))
+    _check(v0); _check(v)
+    assert v["iters"] == v0["iters"] and np.linalg.norm(v["x"] - v0["x"]) <= 1e-12 * np.linalg.norm(v0["x"])
