@@ -353,6 +353,10 @@ struct Level {
   // streamed matrix of an own | ghost level: the own x own part goes to the stream, the entries in ghost columns of the rows that
   // have any are kept as the small CSR the boundary fix-up applies (gmg_set_operator_rows splits every block)
   bool rs_forbid = false;           // several ranks: the r-gather sweep form is a joint decision (gmg_solver::setup)
+  // overlapping layout, gmg_set_partition_overlap_hints: the caller's geometry says that (a) after a smoothing pass the residual is still
+  // exact on every ghost entry the restriction reads, (b) P's rows are complete wherever r_own -= (A dxh)_own reads dxh -- the
+  // consistent!(r) before the restriction / the consistent!(dxh) before r -= A dxh are then skipped
+  bool ovl_skip_r = false, ovl_skip_dx = false;
   bool sA_split = false;
   std::vector<int32_t> g_rows, g_col;
   std::vector<int64_t> g_ptr;
@@ -3092,7 +3096,8 @@ struct gmg_solver {
     const int passes = (ctype == GMG_V_CYCLE) ? 1 : 2;
     for (int pass = 0; pass < passes; ++pass) {
       if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
-      exchange(l, r);
+      const bool ovl_l = comm.nranks > 1 && L.halo.present && L.halo.ovl;
+      if (!(ovl_l && L.ovl_skip_r)) exchange(l, r);
       if (redist.present && l + 1 == sub_from) {
         // level l+1 lives on a rank subset: restrict in the glued partition, redistribute! to the subset owners, recurse there (the
         // other ranks shadow the collectives), bring the correction back to the glued own and ghost entries, prolongate from those
@@ -3129,6 +3134,8 @@ struct gmg_solver {
         HIP_CHECK(hipGetLastError());
       } else
       { StepTimer tm(*this, "prolong", l); spmv_addto(L.P, C.x, L.dx, x); }                       // :491,494 dxh = P dxH ; xh += dxh
+      if (ovl_l && L.ovl_skip_dx && !L.has_pcorr) spmv_sub(L.A, L.dx, r);                            // (every local row; the pass that follows opens with consistent!(r))
+      else
       { StepTimer tm(*this, "r -= A dx", l); apply_A_sub(l, L.dx, r, &L.post); }                    // :495-496 rh -= Ah dxh (+ the post-smoother's first s)
     }
     { StepTimer tm(*this, "post-smooth", l); r = smooth(l, L.post, x, r, false); }                    // :499
@@ -6233,6 +6240,15 @@ int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, i
     REQUIRE(nnbr == 0 || (nbr_rank && snd_ptr && rcv_ptr), GMG_ERR_INVALID, "null neighbour arrays");
     fill_plan(h->lev[slot].halo, h->comm, n_own, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr);
     h->touch();
+  });
+}
+
+int gmg_set_partition_overlap_hints(gmg_handle_t h, int lev, int residual_exact_after_pass, int correction_exact_near_owned)
+{
+  return guarded(h, [&] {
+    check_level(h, lev, true);
+    h->lev[lev].ovl_skip_r = residual_exact_after_pass != 0;
+    h->lev[lev].ovl_skip_dx = correction_exact_near_owned != 0;
   });
 }
 

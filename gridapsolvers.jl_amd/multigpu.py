@@ -192,6 +192,12 @@ class DistributedGMG:
                         gp, gi = np.ascontiguousarray(G.ptr, dtype=np.int64), np.ascontiguousarray(G.idx, dtype=np.int64)
                         abi.check(h, lib.gmg_set_prolongation_patch_correction_rhs(h, l, G.shape[0], G.nnz, C.c_void_p(gp.ctypes.data),
                                                                                    C.c_void_p(gi.ctypes.data), C.c_void_p(G.val.ctypes.data), abi.CSR, 0, 8))
+        if world > 1 and local_hierarchy is None and "order" in self.local:
+            # transfer exchanges the halo geometry makes unnecessary (consistent!(r) before the restriction, consistent!(dxh) before r -= A dxh)
+            self.overlap_hints = pa.overlap_hints(self.local, niter, smoother)
+            for l, (sr, sd) in enumerate(self.overlap_hints):
+                if (sr or sd) and not int(os.environ.get("GMG_NO_OVERLAP_HINTS", "0")):
+                    abi.check(h, lib.gmg_set_partition_overlap_hints(h, l, int(sr), int(sd)))
         sub = self.local.get("sub") if world > 1 else None
         if sub is not None:
             tp, fp = abi.RedistPlan.from_dict(sub["to_sub"], self._keep), abi.RedistPlan.from_dict(sub["from_sub"], self._keep)
@@ -415,7 +421,7 @@ def _pass_us(n_own_cells, depth, niter, m=MODEL):
     return t_sweeps + nblk * (m["exchange_us"] + msg_us + 4.0)                      # + scaled-Jacobi launch per block
 
 
-def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, depth_choices=(0, 1, 2, 3, 5, 10)):
+def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, depth_choices=(0, 1, 2, 3, 5, 6, 10, 11)):
     """(rep_from, depths, table): replicate every level whose GLOBAL size is <= rep_rows dofs (latency-bound: redundant compute beats
     any exchange); give every other level the halo depth that minimises the modelled smoothing-pass time.  The finest level keeps the
     own | ghost layout while its own x own kernel hides the exchange (288^3 cells per GPU: 215 us per sweep against 60 us); below
@@ -434,7 +440,12 @@ def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, de
         if l >= rep_from or world == 1:
             table.append(dict(level=l, cells_per_rank=c, layout="replicated" if world > 1 else "single GPU"))
             continue
-        cand = {k: _pass_us(c, k, niter) for k in depth_choices if k == 0 or (k <= niter and c >= 2)}
+        cand = {k: _pass_us(c, k, niter) for k in depth_choices if k == 0 or (k <= niter + 1 and c >= 2)}
+        # consistent!(r) before the restriction (one per V-cycle = half of one per pass) is unnecessary when the LAST block of a pass is
+        # shorter than the halo is deep (partition.overlap_hints: depth 3 -> blocks 3,3,3,1; 6 -> 6,4; 11 -> one block of 10)
+        for k in cand:
+            if k > 0 and k - (niter - min(k, niter) * ((niter - 1) // min(k, niter))) < 1:
+                cand[k] += 0.5 * (MODEL["exchange_us"] + 4.0)
         if l == 0:
             # r scattered into / z gathered from the extended-box numbering: two launches of 16 B per owned row per V-cycle = per two passes
             idx_us = max(MODEL["launch_floor_us"], c ** 3 * 16.0 / 4.0e6)

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import poisson as po
 
-__all__ = ["rank_grid", "LocalLevel", "build_local_hierarchy", "global_cells", "local_vertex_star_patches"]
+__all__ = ["rank_grid", "LocalLevel", "build_local_hierarchy", "global_cells", "local_vertex_star_patches", "overlap_hints"]
 
 
 def rank_grid(nranks, dim=3):
@@ -609,3 +609,32 @@ def build_local_hierarchy(cells_global_fine, nlevels, grid, rank, order=1, lengt
                    n_sub_local=(int(levels[sub_from].n_own + levels[sub_from].n_ghost) if member else 0))
     return dict(levels=levels, rep_from=rep_from, rep_gid=np.ascontiguousarray(rep_gid, dtype=np.int64),
                 cells=[c[:d] for c in cells], grid=grid[:d], order=order, rank=rank, nranks=nranks, depths=depths, krylov=krylov, sub=sub)
+
+
+def overlap_hints(local, niter, smoother="jacobi"):
+    """Per level (skip_r, skip_dx) for gmg_set_partition_overlap_hints: which of the two transfer exchanges of an overlapping level the
+    geometry makes unnecessary.
+
+    skip_r : after the LAST block of a smoothing pass (blocks of `depth` sweeps; the last one has niter - depth * ((niter - 1) // depth))
+             the residual is still exact on `layers - last * reach` node layers around the owned box; the restriction of an owned coarse
+             row reads fine nodes up to 1 (Q1) / 3 (Q2) away -- no consistent!(r) before it when that many layers are left.
+    skip_dx: `r_own -= (A dxh)_own` reads dxh = P dxH up to `order` nodes outside the owned box; P's rows are complete there when the
+             coarse level is replicated (global columns) or overlapping with >= `order` node layers -- and not the glued side of a
+             redistribution (own | ghost numbering, filled by the redistribution itself)."""
+    order = int(local["order"])
+    reach = order if smoother == "jacobi" else 3 * order - 2
+    rnodes = 1 if order == 1 else 3
+    levels = local["levels"]
+    sub = local.get("sub")
+    out = []
+    for l, L in enumerate(levels):
+        if L is None or not getattr(L, "overlap", False) or l >= len(levels) - 1:
+            out.append((False, False)); continue
+        k = max(1, min(int(L.depth), int(niter)))
+        last = int(niter) - k * ((int(niter) - 1) // k)
+        skip_r = int(L.layers) - last * reach >= rnodes
+        nxt = levels[l + 1]
+        glued = sub is not None and sub["sub_from"] == l + 1
+        skip_dx = (not glued) and nxt is not None and (nxt.replicated or (getattr(nxt, "overlap", False) and int(nxt.layers) >= order))
+        out.append((bool(skip_r), bool(skip_dx)))
+    return out

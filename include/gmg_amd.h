@@ -383,6 +383,16 @@ GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_
 GMG_API int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, int64_t n_ghost, int depth, int nnbr,
                                       const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
                                       const int64_t *rcv_ptr, const int64_t *rcv_idx);
+/* Two of the exchanges a V-cycle makes on an overlapping level besides the smoothing blocks can be dropped when the caller's geometry
+ * allows (it knows the halo in node layers; the library only knows `depth`):
+ *   residual_exact_after_pass   -- after the LAST block of a smoothing pass the residual is still exact on every ghost entry the
+ *     restriction of an owned coarse row reads (node layers - sweeps of the last block x layers per sweep >= reach of R: 1 node for
+ *     Q1, 3 for Q2): consistent!(r) before `rH = R rh` (GMGLinearSolvers.jl:484) is skipped;
+ *   correction_exact_near_owned -- P's local rows are complete (the coarse level is replicated, or overlapping with >= 1 layer) on every
+ *     fine entry that `rh_own -= (A dxh)_own` reads: consistent!(dxh) before `rh -= A dxh` (:495) is skipped -- the ghost rows of r it
+ *     leaves inexact are refreshed by the consistent!(r) that opens the post-smoothing pass.
+ * partition.overlap_hints() is the structured-grid rule; results on owned rows are bit-identical with and without the hints. */
+GMG_API int gmg_set_partition_overlap_hints(gmg_handle_t h, int lev, int residual_exact_after_pass, int correction_exact_near_owned);
 /* FINEST level in the overlapping layout (round 5).  The Krylov solver's vectors are the caller's -- own | ghost numbering, its dot
  * products run over owned entries -- so the solver then holds TWO finest operators: the preconditioner's level 0 in the overlapping
  * layout (gmg_set_partition_overlap(h, 0, ...), gmg_set_matrix(h, 0, square local matrix), P_0 / R_0 in that numbering) and the

@@ -30,6 +30,9 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
     dinv = [None if levels[l] is None else 1.0 / A[l].diagonal() if levels[l].overlap else 1.0 / A[l].diagonal()[: levels[l].n_own]
             for l in range(nlev - 1)]   # own x own diagonal (overlapping layout: every local row)
     sub = local.get("sub")
+    from gridapsolvers_jl_amd import partition as _pa
+    hints = ([(False, False)] * nlev if os.environ.get("GMG_NO_OVERLAP_HINTS", "0") != "0" or "order" not in local
+             else _pa.overlap_hints(local, niter, "jacobi" if patches is None else "patch"))
     stats = {"exchanges": 0}
     rep_from, rep_gid = local["rep_from"], local["rep_gid"]
     Gc = A[nlev - 1].tocsc()                    # coarsest level is always replicated (global matrix)
@@ -176,7 +179,8 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
             x[:n] = spla.spsolve(Gc, r[:n])
             return
         smooth(l, x, r)
-        exchange(l, r)
+        if not (levels[l].overlap and hints[l][0]):
+            exchange(l, r)                       # (skipped when the last smoothing block left the layers R reads exact)
         if sub is not None and l + 1 == sub["sub_from"]:
             # level l+1 lives on a rank subset: restrict in the glued partition, redistribute, recurse on the members, bring the
             # correction back to the glued own AND ghost entries (P reads both)
@@ -217,7 +221,8 @@ def numpy_distributed_cg(local, rank, world, dist, torch, b_own, maxiter, atol, 
         if levels[l].overlap:                    # every local row (ghost rows are fixed by the exchange below)
             dx = P[l] @ dxH
             x += dx
-            exchange(l, dx)
+            if not hints[l][1]:
+                exchange(l, dx)                  # (skipped when P's rows are complete wherever r_own -= (A dx)_own reads dx)
             r -= A[l] @ dx
         else:
             dx = vec(l); dx[:n] = P[l] @ dxH
@@ -633,6 +638,8 @@ def main():
             verdict["exchanges"] = int(numpy_distributed_cg.last_exchanges)
             verdict["redistributions"] = int(numpy_distributed_cg.last_redistributions)
         gid = local["levels"][0].own_gid
+        verdict["hint_skips"] = (0 if os.environ.get("GMG_NO_OVERLAP_HINTS", "0") != "0" else
+                                 int(sum(int(a) + int(b) for a, b in pa.overlap_hints(local, p_niter if smoother == "patch" else 10, smoother))))
     else:
         ndev = torch.cuda.device_count()
         dev = rank % max(ndev, 1)
@@ -643,6 +650,8 @@ def main():
                                     sub_from=sub_from, sub_ranks=sub_ranks, cycle_type=os.environ.get("GMG_TEST_CYCLE", "v_cycle"),
                                     stream_rows=int(os.environ.get("GMG_TEST_STREAM_ROWS", "0")))
         verdict["streamed_levels"] = list(getattr(g, "streamed_levels", []))
+        verdict["hint_skips"] = (0 if os.environ.get("GMG_NO_OVERLAP_HINTS", "0") != "0" else
+                                 int(sum(int(a) + int(b) for a, b in getattr(g, "overlap_hints", []))))
         b = g.rhs_lin()
         x = np.zeros(g.n_own)
         # test hook: ONE rank behaves as if a one-launch smoothing pass had timed out in the first solve -- every rank must re-run it
