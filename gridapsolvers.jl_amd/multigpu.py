@@ -644,6 +644,7 @@ def run_bench(args, rank, world, local_rank):
             "dofs": n, "dofs_per_gpu": g.n_own, "levels": nlev, "cg_iterations": D["iters"],
             "transport": transport, "degraded": bool(degraded), "replicated_from_level": rep_lvl, "max_abs_error_vs_exact": D["err"],
             "halo_depths": depths, "partition_plan": plan_table, "communication_model": MODEL,
+            "transfer_exchanges_skipped": [[bool(a), bool(b)] for a, b in getattr(g, "overlap_hints", [])],   # per level: consistent!(r) before R, consistent!(dxh) before r -= A dxh
             "halo_exchanges_per_solve": D["exchanges_per_solve"], "allreduces_per_solve": D["allreduces_per_solve"],
             "setup_s": setup_s, "assembly_s": asm_s,
         },
