@@ -688,3 +688,27 @@ def test_rank_subset_levels_under_w_and_f_cycles(cycle, tmp_path):
     v = _launch("gpu", 4, (16, 16), 4, tmp_path, transport="host", rep_from=3, extra_env=dict(env, GMG_TEST_SUB_FROM="1", GMG_TEST_SUB_RANKS="2"))
     _check(v0); _check(v)
     assert v["iters"] == v0["iters"] and np.linalg.norm(v["x"] - v0["x"]) <= 1e-12 * np.linalg.norm(v0["x"])
+
+
+def test_planner_and_overlap_hints_rules(pkg):
+    """multigpu.plan_partition: at BASELINE config 4's size the finest level stays own | ghost (its kernel hides the exchange), levels 1 / 2
+    take the depths whose last smoothing block leaves the residual exact where the restriction reads it (6 -> blocks 6,4; 11 -> one
+    block of 10), small finest levels go into the overlapping layout, and no rank subset beats the all-rank layouts.
+    partition.overlap_hints: the rule behind gmg_set_partition_overlap_hints."""
+    import importlib
+    mg = importlib.import_module(pkg.__name__ + ".multigpu")
+    pa = importlib.import_module(pkg.__name__ + ".partition")
+    rep, depths, table = mg.plan_partition(288, 6, 8)
+    assert rep == 3 and depths == [0, 6, 11, 0, 0, 0]
+    for row in table[1:3]:
+        best = min(row["modelled_pass_us"].values())
+        assert all(v > best for v in row["modelled_pass_us_on_rank_subset"].values()), row
+    assert mg.plan_partition(128, 5, 8)[1][0] > 0 and mg.plan_partition(64, 4, 8)[1][0] > 0      # strong-scaling sizes: finest level overlaps
+    assert mg.plan_partition(288, 6, 1)[1] == [0] * 6                                              # one GPU: nothing to plan
+    g = pa.rank_grid(4, 2)
+    h = pa.build_local_hierarchy((32, 32), 4, g, 0, 1, None, 3, [0, 3, 5, 0], "jacobi")
+    assert pa.overlap_hints(h, 10) == [(False, False), (True, True), (False, True), (False, False)]   # 3 -> blocks 3,3,3,1 ; 5 -> 5,5
+    h = pa.build_local_hierarchy((32, 32), 4, g, 0, 1, None, 3, [0, 11, 6, 0], "jacobi", finest_depth=2)
+    assert pa.overlap_hints(h, 10) == [(False, True), (True, True), (True, True), (False, False)]
+    h = pa.build_local_hierarchy((32, 32), 4, g, 0, 1, None, 3, [0, 3, 3, 0], "jacobi", sub_from=2, sub_ranks=2)
+    assert pa.overlap_hints(h, 10)[1] == (True, False)            # P of level 1 reads the glued side of a redistribution: filled by it, no shortcut
