@@ -712,3 +712,29 @@ def test_planner_and_overlap_hints_rules(pkg):
     assert pa.overlap_hints(h, 10) == [(False, True), (True, True), (True, True), (False, False)]
     h = pa.build_local_hierarchy((32, 32), 4, g, 0, 1, None, 3, [0, 3, 3, 0], "jacobi", sub_from=2, sub_ranks=2)
     assert pa.overlap_hints(h, 10)[1] == (True, False)            # P of level 1 reads the glued side of a redistribution: filled by it, no shortcut
+
+
+@pytest.mark.gpu
+def test_config4_at_full_size_through_the_host_transport(tmp_path):
+    """BASELINE configs[3] as stated -- 3D Poisson Q1, 576^3 cells = 1.9e8 dofs on a 2 x 2 x 2 rank grid, 288^3 cells per rank, 6 levels --
+    through `bench.py --gpus 8` exactly as the driver launches it, with the eight ranks sharing the one GPU of the test box over the
+    host-staged transport (everything of the N = 8 run except RCCL's own transport and the timing; ~30 s, ~4 GB of device and ~8 GB of
+    host memory per rank): the planner's layout (finest level own | ghost, levels 1 / 2 overlapping with depths 6 / 11, levels 3-5
+    replicated), 3 CG iterations, the analytic solution to 1e-5, the exchange count of that plan."""
+    import subprocess
+    env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--cells", "288", "--levels", "6",
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-generic"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["dofs"] == 575 ** 3 == 190109375 and c["dofs_per_gpu"] > 2.3e7
+    assert c["halo_depths"] == [0, 6, 11, 0, 0, 0] and c["replicated_from_level"] == 3
+    assert c["transfer_exchanges_skipped"][1] == [True, True] and c["transfer_exchanges_skipped"][2] == [True, True]
+    assert c["cg_iterations"] == 3 and c["max_abs_error_vs_exact"] < 1e-5
+    # per CG iteration: 20 finest sweeps + r -= A dx + w = A p + the restriction's consistent!(r) on level 0; 2 x 2 + 1 on level 1 (depth 6:
+    # blocks 6,4; the coarse correction), 2 x 1 + 1 on level 2 (depth 11) -- plus the initial residual
+    assert c["halo_exchanges_per_solve"] == 3 * (23 + 5 + 3) + 1, c["halo_exchanges_per_solve"]
+    assert c["transport"] == "host" and c["degraded"] is True
