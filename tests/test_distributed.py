@@ -628,7 +628,7 @@ def test_overlap_space_of_the_vector_valued_stokes_velocity(po, pkg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,nlev,depth", [(4, 16, 3, 1), (2, 32, 4, 2)])      # ((8, 16, 3, 1) passes too: 49 s of process start-up, left out of the suite)
+@pytest.mark.parametrize("world,n,nlev,depth", [(4, 16, 3, 1), (2, 32, 4, 2), (4, 64, 4, 2)])      # ((8, 16, 3, 1) passes too: 49 s of process start-up, left out of the suite)
 def test_distributed_real_stokes_with_overlapping_velocity_levels(world, n, nlev, depth, tmp_path):
     """Round 5: the partitioned vector-valued velocity levels >= 1 of the distributed Stokes solve in the OVERLAPPING layout
     (dpartition.OverlapSpace; patch smoother AND patch-corrected prolongation with blocks from the local matrix, no assemble!):
