@@ -2,6 +2,7 @@
 // Sequence per round: A (256 threads x 1024 workgroups, short) ; B (bs threads x nb workgroups, spins ~us microseconds) ; A.
 // Prints the wall time per round for several shapes of B with the same number of waves; the differences are dispatch gaps.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,32 @@ int main()
       CK(hipStreamSynchronize(s));
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
       if (rep == 1) std::printf("B = %4d threads x %4d workgroups: %.2f us per round (A ; B(40 us spin) ; A)\n", sh[0], sh[1], us);
+    }
+  }
+  // what timing B costs: nothing / hipEventRecord before and after / hipExtLaunchKernel with start and stop events (the kernel's own
+  // dispatch timestamps, no marker packets)
+  {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int mode = 0; mode < 3; ++mode) {
+      double us = 0.0, ev_us = 0.0;
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipStreamSynchronize(s));
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rounds = 200;
+        ev_us = 0.0;
+        for (int r = 0; r < rounds; ++r) {
+          hipLaunchKernelGGL(short_kernel, dim3(1024), dim3(256), 0, s, p, n);
+          if (mode == 1) CK(hipEventRecord(e0, s));
+          if (mode == 2) { long long tk = ticks; void *args[2] = {&p, &tk}; CK(hipExtLaunchKernel((const void *)spin_kernel, dim3(253), dim3(1024), args, 0, s, e0, e1, 0)); }
+          else hipLaunchKernelGGL(spin_kernel, dim3(253), dim3(1024), 0, s, p, ticks);
+          if (mode == 1) CK(hipEventRecord(e1, s));
+          hipLaunchKernelGGL(short_kernel, dim3(1024), dim3(256), 0, s, p, n);
+          if (mode && (r % 50) == 49) { CK(hipStreamSynchronize(s)); float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); ev_us = ms * 1e3; }
+        }
+        CK(hipStreamSynchronize(s));
+        us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / rounds;
+      }
+      std::printf("timing mode %d (0 none, 1 hipEventRecord pair, 2 hipExtLaunchKernel events): %.2f us per round, events say %.2f us for the 40 us kernel\n", mode, us, ev_us);
     }
   }
   // the same with a B that touches memory like a one-launch smoothing pass: 4 vectors of 2.6e5 doubles (8 MB), 100 KB of dynamic LDS
