@@ -225,4 +225,64 @@ __global__ void ghost_fix_kernel(int64_t nb, const int32_t *__restrict__ rows, c
   }
 }
 
+// The same with the boundary rows' ghost entries in slices of 64 rows, column-major (SELL-64: entry e of the slice's lane l at
+// soff[slice] + 64 e + l, rows padded to the slice's longest with (column 0, value 0.0) that the row's own length keeps out of the sum):
+// a wave's loads of one entry are contiguous and the entries of a row are independent loads -- the CSR form above walks each row with one
+// thread, 12-byte loads at a stride of the row length, one dependent chain per row (measured on one rank of BASELINE config 4, alone on the
+// GPU: 25.5 us per sweep for 2.5e5 boundary rows, 0.5 ms of a 6.1 ms iteration; profiles/r05_tuning.md section 9).  Same products in the
+// same order: bit-identical.
+template <int MODE>
+__global__ __launch_bounds__(256) void ghost_fix_sell_kernel(int64_t nb, const int32_t *__restrict__ rows, const int32_t *__restrict__ glen,
+                                                             const int64_t *__restrict__ soff, const int32_t *__restrict__ scol,
+                                                             const double *__restrict__ sval, const double *__restrict__ v,
+                                                             double *__restrict__ y, const double *__restrict__ dinv, double omega,
+                                                             double *__restrict__ s_out, const int64_t *__restrict__ pk_ptr = nullptr,
+                                                             const int32_t *__restrict__ pk_slot = nullptr, double *__restrict__ sendbuf = nullptr,
+                                                             double du = 0.0)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  const int64_t slice = i >> 6;
+  const int64_t base = soff[slice] + (i & 63);
+  const int w = (int)((soff[slice + 1] - soff[slice]) >> 6);
+  const int len = glen[i];
+  const int32_t row = rows[i];
+  const double y0 = y[row];
+  auto f = [&](double x) -> double { return MODE == 3 ? omega * (du * x) : x; };
+  double g = 0.0;
+  int e = 0;
+  for (; e + 4 <= w; e += 4) {
+    const int64_t b = base + (int64_t)e * 64;
+    const int32_t c0 = scol[b], c1 = scol[b + 64], c2 = scol[b + 128], c3 = scol[b + 192];
+    const double a0 = sval[b], a1 = sval[b + 64], a2 = sval[b + 128], a3 = sval[b + 192];
+    const double x0 = v[c0], x1 = v[c1], x2 = v[c2], x3 = v[c3];
+    if (e < len) g += a0 * f(x0);
+    if (e + 1 < len) g += a1 * f(x1);
+    if (e + 2 < len) g += a2 * f(x2);
+    if (e + 3 < len) g += a3 * f(x3);
+  }
+  for (; e < w; ++e) {
+    const int64_t b = base + (int64_t)e * 64;
+    const int32_t c0 = scol[b];
+    const double a0 = sval[b];
+    const double x0 = v[c0];
+    if (e < len) g += a0 * f(x0);
+  }
+  if (MODE == 0) y[row] = y0 + g;
+  else if (MODE == 1) y[row] = y0 - g;
+  else if (MODE == 3) {
+    const double rn = y0 - g;
+    y[row] = rn;
+    if (pk_ptr)
+      for (int64_t k = pk_ptr[i]; k < pk_ptr[i + 1]; ++k) sendbuf[pk_slot[k]] = rn;
+  } else {
+    const double rn = y0 - g;
+    y[row] = rn;
+    const double sn = omega * (dinv[row] * rn);
+    s_out[row] = sn;
+    if (pk_ptr)
+      for (int64_t k = pk_ptr[i]; k < pk_ptr[i + 1]; ++k) sendbuf[pk_slot[k]] = sn;
+  }
+}
+
 } // namespace gmg

@@ -390,6 +390,10 @@ struct Level {
   int64_t *gh_ptr = nullptr;
   int32_t *gh_col = nullptr;
   double *gh_val = nullptr;
+  // the same entries in slices of 64 boundary rows, column-major (ghost_fix_sell_kernel); null: the CSR form is used
+  int32_t *gh_len = nullptr, *gh_scol = nullptr;
+  int64_t *gh_soff = nullptr;
+  double *gh_sval = nullptr;
   double *x = nullptr;            // correction at this level (levels > 0)
   double *rbuf[2] = {nullptr, nullptr};
   double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
@@ -748,6 +752,7 @@ struct gmg_solver {
       L.rbuf[0] = L.rbuf[1] = nullptr;
       L.ptmp = L.pcor = nullptr; L.pcorr.built = false;
       L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
+      L.gh_len = nullptr; L.gh_scol = nullptr; L.gh_soff = nullptr; L.gh_sval = nullptr;
       L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pflags = nullptr; L.pf_nwg = 0; L.pf_epoch = 1;
       L.tbuf[0] = L.tbuf[1] = L.tbuf[2] = nullptr; L.t_off = 0; L.t_sym = -1;
@@ -2264,6 +2269,11 @@ struct gmg_solver {
       if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
       if (L.split && L.nbnd > 0) {
         const bool pk = pack_next && L.halo.d_pk_ptr != nullptr;
+        if (L.gh_sval)
+          hipLaunchKernelGGL((ghost_fix_sell_kernel<3>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
+                             L.gh_len, L.gh_soff, L.gh_scol, L.gh_sval, r_cur, r_next, (const double *)nullptr, S.omega, (double *)nullptr,
+                             pk ? L.halo.d_pk_ptr : nullptr, pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr, L.A.pdinv_u);
+        else
         hipLaunchKernelGGL((ghost_fix_kernel<3>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
                            L.gh_ptr, L.gh_col, L.gh_val, r_cur, r_next, (const double *)nullptr, S.omega, (double *)nullptr,
                            pk ? L.halo.d_pk_ptr : nullptr, pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr, L.A.pdinv_u);
@@ -2532,6 +2542,11 @@ struct gmg_solver {
     if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
     if (!L.split || L.nbnd == 0) return;
     const bool pk = pack_next && MODE == 2 && L.halo.d_pk_ptr != nullptr;
+    if (L.gh_sval)
+      hipLaunchKernelGGL((ghost_fix_sell_kernel<MODE>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
+                         L.gh_len, L.gh_soff, L.gh_scol, L.gh_sval, src, y, L.dinv, omega, s_out, pk ? L.halo.d_pk_ptr : nullptr,
+                         pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr);
+    else
     hipLaunchKernelGGL((ghost_fix_kernel<MODE>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
                        L.gh_ptr, L.gh_col, L.gh_val, src, y, L.dinv, omega, s_out, pk ? L.halo.d_pk_ptr : nullptr,
                        pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr);
@@ -4843,6 +4858,28 @@ void gmg_solver::setup()
       L.split = true;
       L.nbnd = (int64_t)brows.size();
       L.gh_rows = upload(brows); L.gh_ptr = upload(bptr); L.gh_col = upload(bcol); L.gh_val = upload(bval);
+      if (opt_int("GMG_HALO_FIX_SELL", 1) && !brows.empty()) {
+        // slices of 64 boundary rows, column-major, padded with (column 0, value 0.0) behind every row's own length
+        const size_t nbr = brows.size(), nsl = (nbr + 63) / 64;
+        std::vector<int32_t> glen(nbr);
+        std::vector<int64_t> soff(nsl + 1, 0);
+        for (size_t sl = 0; sl < nsl; ++sl) {
+          int64_t w = 0;
+          for (size_t q = sl * 64; q < std::min(nbr, sl * 64 + 64); ++q) {
+            glen[q] = (int32_t)(bptr[q + 1] - bptr[q]);
+            w = std::max<int64_t>(w, glen[q]);
+          }
+          soff[sl + 1] = soff[sl] + 64 * w;
+        }
+        std::vector<int32_t> scol((size_t)soff[nsl], 0);
+        std::vector<double> sval((size_t)soff[nsl], 0.0);
+        for (size_t q = 0; q < nbr; ++q)
+          for (int64_t k = bptr[q]; k < bptr[q + 1]; ++k) {
+            const size_t at = (size_t)soff[q / 64] + (size_t)(k - bptr[q]) * 64 + (q & 63);
+            scol[at] = bcol[(size_t)k]; sval[at] = bval[(size_t)k];
+          }
+        L.gh_len = upload(glen); L.gh_soff = upload(soff); L.gh_scol = upload(scol); L.gh_sval = upload(sval);
+      }
       {   // send slots of every boundary row (fused pack): valid when every sent row is a boundary row
         HaloPlan &Hp = L.halo;
         std::vector<int32_t> bidx((size_t)L.n, -1);
@@ -5682,7 +5719,7 @@ struct OptionKey { const char *name; bool live; };
 const OptionKey kOptionKeys[] = {
   {"GMG_BIG_ROWS", false}, {"GMG_COARSE_HOST_FALLBACK_MAX", false}, {"GMG_COARSE_HOST_MAX", false}, {"GMG_COARSE_AUTO_CG_MIN", false},
   {"GMG_DBG_NOGATHER", false}, {"GMG_EAGER", true}, {"GMG_EAGER_MIN_ROWS", true}, {"GMG_FORCE_PTR64", false}, {"GMG_GJ_MFMA", false}, {"GMG_GJ_WIDE_MIN", false},
-  {"GMG_HALO_FUSE_PACK", false}, {"GMG_HOST_ASYNC", false}, {"GMG_IDX16", false}, {"GMG_LANES_LOG2", false}, {"GMG_NT", false},
+  {"GMG_HALO_FUSE_PACK", false}, {"GMG_HALO_FIX_SELL", false}, {"GMG_HOST_ASYNC", false}, {"GMG_IDX16", false}, {"GMG_LANES_LOG2", false}, {"GMG_NT", false},
   {"GMG_NT_ROWWISE", false}, {"GMG_ONE_GATHER", false}, {"GMG_OPATTERN", false}, {"GMG_OVERLAP", false}, {"GMG_PATCH_DEDUP", false},
   {"GMG_PATCH_OPERATOR", false}, {"GMG_PATCH_OP_DEVICE", false}, {"GMG_PATCH_SOURCE_DEDUP", false}, {"GMG_PATTERN", false}, {"GMG_PAT_BATCHED", false},
   {"GMG_PAT_CODED_MIN_ROWS", false}, {"GMG_PAT_DEFER", false}, {"GMG_PAT_DINV", false}, {"GMG_PAT_EMIT", false}, {"GMG_PAT_NB", false},

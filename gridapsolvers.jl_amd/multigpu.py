@@ -70,6 +70,26 @@ class _HostTransport:
         return self.dist.get_global_rank(self.group, q) if self.group is not None else q
 
 
+class _AloneTransport:
+    """Measurement only (tools/rank_alone.py): ONE rank of an N-rank partition runs by itself -- every halo it would receive is zero,
+    every scalar all-reduce returns N times its own contribution (so that joint decisions pass), vector all-reduces return the rank's
+    own part.  The numbers it computes mean nothing; the kernels it launches, their shapes and their order are exactly those of
+    that rank in the N-rank run, with the GPU to itself: the communication-free part of an iteration."""
+
+    def __init__(self, world):
+        def exchange(ctx, nnbr, nbr_rank, sendbuf, snd_ptr, recvbuf, rcv_ptr):
+            n = int(rcv_ptr[nnbr])
+            if n > 0:
+                np.ctypeslib.as_array(recvbuf, shape=(n,))[:] = 0.0
+
+        def allreduce(ctx, vals, n):
+            if n == 1:
+                vals[0] = vals[0] * world
+
+        self.exchange_cb = abi.HOST_EXCHANGE_FN(exchange)
+        self.allreduce_cb = abi.HOST_ALLREDUCE_FN(allreduce)
+
+
 class DistributedGMG:
     """Distributed numerical setup of CG/FGMRES + GMG on the structured Poisson hierarchy."""
 
@@ -132,12 +152,12 @@ class DistributedGMG:
                 blob = [bytes(uid.raw) if rank == 0 else None]
                 dist.broadcast_object_list(blob, src=0, group=group)
                 abi.check(h, lib.gmg_comm_init_rccl(h, path, blob[0], rank, world))
-            elif transport == "host":
-                self._host = _HostTransport(group)
+            elif transport in ("host", "alone"):
+                self._host = _HostTransport(group) if transport == "host" else _AloneTransport(world)
                 abi.check(h, lib.gmg_comm_init_host(h, rank, world, C.cast(self._host.exchange_cb, C.c_void_p),
                                                     C.cast(self._host.allreduce_cb, C.c_void_p), None))
             else:
-                raise ValueError("transport must be 'rccl' or 'host'")
+                raise ValueError("transport must be 'rccl', 'host' or 'alone'")
         levels = self.local["levels"]
         for l, L in enumerate(levels):
             if L is None:                                     # a level of a rank subset this rank is not part of
@@ -401,16 +421,21 @@ class DistributedGMG:
 # with a floor of 4.4 us + 1.5 us of dependent-launch gap per launch; a whole block of k
 # sweeps as ONE launch (<= 5.08e5 rows: sells_smooth_kernel): 2.8 us + 6.0e-6 us per row per sweep (profiles/r02_tuning.md section 6).
 MODEL = dict(exchange_us=40.0, exchange_overlapped_us=60.0, link_GBs=50.0, sweep_ns_per_krow=9.0, launch_floor_us=5.9,
-             one_launch_rows=507904, one_launch_base_us=2.8, one_launch_us_per_row=6.0e-6, allreduce_us=30.0, allreduce_GBs=50.0)
+             one_launch_rows=507904, one_launch_base_us=2.8, one_launch_us_per_row=6.0e-6, allreduce_us=30.0, allreduce_GBs=50.0,
+             # boundary fix-up of an own | ghost sweep (ghost_fix_sell_kernel): 17.8 us for the 2.5e5 boundary rows of a corner rank of
+             # 2 x 2 x 2 x 288^3, measured with that rank alone on the GPU (tools/rank_alone.sh; the CSR form took 25.3)
+             fixup_us_per_krow=0.072, fixup_floor_us=3.0)
 
 
-def _pass_us(n_own_cells, depth, niter, m=MODEL):
+def _pass_us(n_own_cells, depth, niter, m=MODEL, nfaces=3):
     """modelled time of one smoothing pass of `niter` sweeps on a level with n_own_cells^3 owned cells per rank and `depth` ghost
-    layers (0 = own | ghost layout with the exchange overlapped with the own x own kernel)"""
+    layers (0 = own | ghost layout with the exchange overlapped with the own x own kernel; nfaces = faces of the rank's box that
+    touch a neighbour: their rows are finished by the boundary fix-up after the halo has arrived)"""
     c = n_own_cells
     if depth == 0:
         t_sweep = max(m["launch_floor_us"], c ** 3 * m["sweep_ns_per_krow"] * 1e-6)
-        return niter * (max(t_sweep, m["exchange_overlapped_us"]) + 3.0)           # + boundary fix-up launch
+        fix = max(m["fixup_floor_us"], nfaces * c * c * 1e-3 * m["fixup_us_per_krow"])
+        return niter * (max(t_sweep, m["exchange_overlapped_us"]) + fix)          # + boundary fix-up launch
     rows = (c + 2 * depth) ** 3
     nblk = -(-niter // depth)
     msg_us = depth * c * c * 8.0 / (m["link_GBs"] * 1e3)                            # one face, `depth` layers
@@ -440,7 +465,8 @@ def plan_partition(cells_per_rank, nlevels, world, niter=10, rep_rows=400000, de
         if l >= rep_from or world == 1:
             table.append(dict(level=l, cells_per_rank=c, layout="replicated" if world > 1 else "single GPU"))
             continue
-        cand = {k: _pass_us(c, k, niter) for k in depth_choices if k == 0 or (k <= niter + 1 and c >= 2)}
+        nfaces = sum(1 for gk in grid if gk > 1)               # (2 ranks per partitioned direction: one neighbour face each)
+        cand = {k: _pass_us(c, k, niter, nfaces=nfaces) for k in depth_choices if k == 0 or (k <= niter + 1 and c >= 2)}
         # consistent!(r) before the restriction (one per V-cycle = half of one per pass) is unnecessary when the LAST block of a pass is
         # shorter than the halo is deep (partition.overlap_hints: depth 3 -> blocks 3,3,3,1; 6 -> 6,4; 11 -> one block of 10)
         for k in cand:

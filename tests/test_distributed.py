@@ -261,6 +261,12 @@ def test_partitioned_cg_gmg_on_gpu_host_transport(world, cells, nlev, rep, tmp_p
         _check(z)
         assert z["iters"] == v["iters"]
         np.testing.assert_array_equal(z["x"], v["x"])
+    # the boundary fix-up of the own | ghost levels in its two forms (slices of 64 boundary rows, column-major: the default; one thread
+    # walking a CSR row): same products in the same order
+    c = _launch("gpu", world, cells, nlev, tmp_path, transport="host", rep_from=rep, extra_env={"GMG_HALO_FIX_SELL": "0"})
+    _check(c)
+    assert c["iters"] == v["iters"] and c["x_sha"] == v["x_sha"]
+    np.testing.assert_array_equal(c["x"], v["x"])
 
 
 @pytest.mark.gpu
