@@ -231,15 +231,22 @@ __global__ void ghost_fix_kernel(int64_t nb, const int32_t *__restrict__ rows, c
 // thread, 12-byte loads at a stride of the row length, one dependent chain per row (measured on one rank of BASELINE config 4, alone on the
 // GPU: 25.5 us per sweep for 2.5e5 boundary rows, 0.5 ms of a 6.1 ms iteration; profiles/r05_tuning.md section 9).  Same products in the
 // same order: bit-identical.
-template <int MODE>
+// DICT: the values come from a dictionary of <= 256 distinct doubles (constant-coefficient operators have a handful), one byte per
+// entry instead of eight -- 12 -> 5 bytes per ghost entry; `sval` then points at the codes, `dict` at the values (staged in LDS).
+template <int MODE, bool DICT = false>
 __global__ __launch_bounds__(256) void ghost_fix_sell_kernel(int64_t nb, const int32_t *__restrict__ rows, const int32_t *__restrict__ glen,
                                                              const int64_t *__restrict__ soff, const int32_t *__restrict__ scol,
-                                                             const double *__restrict__ sval, const double *__restrict__ v,
+                                                             const void *__restrict__ sval_, const double *__restrict__ dict, const double *__restrict__ v,
                                                              double *__restrict__ y, const double *__restrict__ dinv, double omega,
                                                              double *__restrict__ s_out, const int64_t *__restrict__ pk_ptr = nullptr,
                                                              const int32_t *__restrict__ pk_slot = nullptr, double *__restrict__ sendbuf = nullptr,
                                                              double du = 0.0)
 {
+  __shared__ double sd[DICT ? 256 : 1];
+  if (DICT) { sd[threadIdx.x] = dict[threadIdx.x]; __syncthreads(); }
+  const double *__restrict__ sval = static_cast<const double *>(sval_);
+  const uint8_t *__restrict__ scode = static_cast<const uint8_t *>(sval_);
+  auto val = [&](int64_t at) -> double { return DICT ? sd[scode[at]] : sval[at]; };
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
   const int64_t slice = i >> 6;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void ghost_fix_sell_kernel(int64_t nb, const i
   for (; e + 4 <= w; e += 4) {
     const int64_t b = base + (int64_t)e * 64;
     const int32_t c0 = scol[b], c1 = scol[b + 64], c2 = scol[b + 128], c3 = scol[b + 192];
-    const double a0 = sval[b], a1 = sval[b + 64], a2 = sval[b + 128], a3 = sval[b + 192];
+    const double a0 = val(b), a1 = val(b + 64), a2 = val(b + 128), a3 = val(b + 192);
     const double x0 = v[c0], x1 = v[c1], x2 = v[c2], x3 = v[c3];
     if (e < len) g += a0 * f(x0);
     if (e + 1 < len) g += a1 * f(x1);
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256) void ghost_fix_sell_kernel(int64_t nb, const i
   for (; e < w; ++e) {
     const int64_t b = base + (int64_t)e * 64;
     const int32_t c0 = scol[b];
-    const double a0 = sval[b];
+    const double a0 = val(b);
     const double x0 = v[c0];
     if (e < len) g += a0 * f(x0);
   }

@@ -394,6 +394,8 @@ struct Level {
   int32_t *gh_len = nullptr, *gh_scol = nullptr;
   int64_t *gh_soff = nullptr;
   double *gh_sval = nullptr;
+  uint8_t *gh_scode = nullptr;      // one byte per entry into gh_dict (<= 256 distinct values) instead of gh_sval
+  double *gh_dict = nullptr;
   double *x = nullptr;            // correction at this level (levels > 0)
   double *rbuf[2] = {nullptr, nullptr};
   double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
@@ -752,7 +754,7 @@ struct gmg_solver {
       L.rbuf[0] = L.rbuf[1] = nullptr;
       L.ptmp = L.pcor = nullptr; L.pcorr.built = false;
       L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
-      L.gh_len = nullptr; L.gh_scol = nullptr; L.gh_soff = nullptr; L.gh_sval = nullptr;
+      L.gh_len = nullptr; L.gh_scol = nullptr; L.gh_soff = nullptr; L.gh_sval = nullptr; L.gh_scode = nullptr; L.gh_dict = nullptr;
       L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pflags = nullptr; L.pf_nwg = 0; L.pf_epoch = 1;
       L.tbuf[0] = L.tbuf[1] = L.tbuf[2] = nullptr; L.t_off = 0; L.t_sym = -1;
@@ -2269,9 +2271,13 @@ struct gmg_solver {
       if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
       if (L.split && L.nbnd > 0) {
         const bool pk = pack_next && L.halo.d_pk_ptr != nullptr;
-        if (L.gh_sval)
-          hipLaunchKernelGGL((ghost_fix_sell_kernel<3>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
-                             L.gh_len, L.gh_soff, L.gh_scol, L.gh_sval, r_cur, r_next, (const double *)nullptr, S.omega, (double *)nullptr,
+        if (L.gh_scode)
+          hipLaunchKernelGGL((ghost_fix_sell_kernel<3, true>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
+                             L.gh_len, L.gh_soff, L.gh_scol, (const void *)L.gh_scode, L.gh_dict, r_cur, r_next, (const double *)nullptr, S.omega, (double *)nullptr,
+                             pk ? L.halo.d_pk_ptr : nullptr, pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr, L.A.pdinv_u);
+        else if (L.gh_sval)
+          hipLaunchKernelGGL((ghost_fix_sell_kernel<3, false>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
+                             L.gh_len, L.gh_soff, L.gh_scol, (const void *)L.gh_sval, (const double *)nullptr, r_cur, r_next, (const double *)nullptr, S.omega, (double *)nullptr,
                              pk ? L.halo.d_pk_ptr : nullptr, pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr, L.A.pdinv_u);
         else
         hipLaunchKernelGGL((ghost_fix_kernel<3>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
@@ -2542,9 +2548,13 @@ struct gmg_solver {
     if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
     if (!L.split || L.nbnd == 0) return;
     const bool pk = pack_next && MODE == 2 && L.halo.d_pk_ptr != nullptr;
-    if (L.gh_sval)
-      hipLaunchKernelGGL((ghost_fix_sell_kernel<MODE>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
-                         L.gh_len, L.gh_soff, L.gh_scol, L.gh_sval, src, y, L.dinv, omega, s_out, pk ? L.halo.d_pk_ptr : nullptr,
+    if (L.gh_scode)
+      hipLaunchKernelGGL((ghost_fix_sell_kernel<MODE, true>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
+                         L.gh_len, L.gh_soff, L.gh_scol, (const void *)L.gh_scode, L.gh_dict, src, y, L.dinv, omega, s_out, pk ? L.halo.d_pk_ptr : nullptr,
+                         pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr);
+    else if (L.gh_sval)
+      hipLaunchKernelGGL((ghost_fix_sell_kernel<MODE, false>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
+                         L.gh_len, L.gh_soff, L.gh_scol, (const void *)L.gh_sval, (const double *)nullptr, src, y, L.dinv, omega, s_out, pk ? L.halo.d_pk_ptr : nullptr,
                          pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr);
     else
     hipLaunchKernelGGL((ghost_fix_kernel<MODE>), dim3((unsigned)((L.nbnd + 255) / 256)), dim3(256), 0, stream, L.nbnd, L.gh_rows,
@@ -4878,7 +4888,24 @@ void gmg_solver::setup()
             const size_t at = (size_t)soff[q / 64] + (size_t)(k - bptr[q]) * 64 + (q & 63);
             scol[at] = bcol[(size_t)k]; sval[at] = bval[(size_t)k];
           }
-        L.gh_len = upload(glen); L.gh_soff = upload(soff); L.gh_scol = upload(scol); L.gh_sval = upload(sval);
+        L.gh_len = upload(glen); L.gh_soff = upload(soff); L.gh_scol = upload(scol);
+        // <= 256 distinct values (constant coefficients: a handful): one byte per entry into a dictionary
+        std::map<uint64_t, int> seen;
+        std::vector<double> dict;
+        std::vector<uint8_t> code(sval.size(), 0);
+        bool small = opt_int("GMG_HALO_FIX_SELL", 1) >= 1 && opt_int("GMG_HALO_FIX_DICT", 1) != 0;
+        for (size_t q = 0; q < sval.size() && small; ++q) {
+          uint64_t bits; std::memcpy(&bits, &sval[q], 8);
+          auto it = seen.find(bits);
+          if (it == seen.end()) {
+            if (dict.size() == 256) { small = false; break; }
+            it = seen.emplace(bits, (int)dict.size()).first;
+            dict.push_back(sval[q]);
+          }
+          code[q] = (uint8_t)it->second;
+        }
+        if (small) { dict.resize(256, 0.0); L.gh_scode = upload(code); L.gh_dict = upload(dict); }
+        else L.gh_sval = upload(sval);
       }
       {   // send slots of every boundary row (fused pack): valid when every sent row is a boundary row
         HaloPlan &Hp = L.halo;
@@ -5719,7 +5746,7 @@ struct OptionKey { const char *name; bool live; };
 const OptionKey kOptionKeys[] = {
   {"GMG_BIG_ROWS", false}, {"GMG_COARSE_HOST_FALLBACK_MAX", false}, {"GMG_COARSE_HOST_MAX", false}, {"GMG_COARSE_AUTO_CG_MIN", false},
   {"GMG_DBG_NOGATHER", false}, {"GMG_EAGER", true}, {"GMG_EAGER_MIN_ROWS", true}, {"GMG_FORCE_PTR64", false}, {"GMG_GJ_MFMA", false}, {"GMG_GJ_WIDE_MIN", false},
-  {"GMG_HALO_FUSE_PACK", false}, {"GMG_HALO_FIX_SELL", false}, {"GMG_HOST_ASYNC", false}, {"GMG_IDX16", false}, {"GMG_LANES_LOG2", false}, {"GMG_NT", false},
+  {"GMG_HALO_FUSE_PACK", false}, {"GMG_HALO_FIX_SELL", false}, {"GMG_HALO_FIX_DICT", false}, {"GMG_HOST_ASYNC", false}, {"GMG_IDX16", false}, {"GMG_LANES_LOG2", false}, {"GMG_NT", false},
   {"GMG_NT_ROWWISE", false}, {"GMG_ONE_GATHER", false}, {"GMG_OPATTERN", false}, {"GMG_OVERLAP", false}, {"GMG_PATCH_DEDUP", false},
   {"GMG_PATCH_OPERATOR", false}, {"GMG_PATCH_OP_DEVICE", false}, {"GMG_PATCH_SOURCE_DEDUP", false}, {"GMG_PATTERN", false}, {"GMG_PAT_BATCHED", false},
   {"GMG_PAT_CODED_MIN_ROWS", false}, {"GMG_PAT_DEFER", false}, {"GMG_PAT_DINV", false}, {"GMG_PAT_EMIT", false}, {"GMG_PAT_NB", false},

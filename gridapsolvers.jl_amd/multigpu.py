@@ -422,9 +422,9 @@ class DistributedGMG:
 # sweeps as ONE launch (<= 5.08e5 rows: sells_smooth_kernel): 2.8 us + 6.0e-6 us per row per sweep (profiles/r02_tuning.md section 6).
 MODEL = dict(exchange_us=40.0, exchange_overlapped_us=60.0, link_GBs=50.0, sweep_ns_per_krow=9.0, launch_floor_us=5.9,
              one_launch_rows=507904, one_launch_base_us=2.8, one_launch_us_per_row=6.0e-6, allreduce_us=30.0, allreduce_GBs=50.0,
-             # boundary fix-up of an own | ghost sweep (ghost_fix_sell_kernel): 17.8 us for the 2.5e5 boundary rows of a corner rank of
-             # 2 x 2 x 2 x 288^3, measured with that rank alone on the GPU (tools/rank_alone.sh; the CSR form took 25.3)
-             fixup_us_per_krow=0.072, fixup_floor_us=3.0)
+             # boundary fix-up of an own | ghost sweep (ghost_fix_sell_kernel, dictionary-coded values): 15.4 us for the 2.5e5 boundary rows
+             # of a corner rank of 2 x 2 x 2 x 288^3, measured with that rank alone on the GPU (tools/rank_alone.sh; the CSR form took 25.3)
+             fixup_us_per_krow=0.062, fixup_floor_us=3.0)
 
 
 def _pass_us(n_own_cells, depth, niter, m=MODEL, nfaces=3):
