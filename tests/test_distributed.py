@@ -744,3 +744,25 @@ def test_config4_at_full_size_through_the_host_transport(tmp_path):
     # blocks 6,4; the coarse correction), 2 x 1 + 1 on level 2 (depth 11) -- plus the initial residual
     assert c["halo_exchanges_per_solve"] == 3 * (23 + 5 + 3) + 1, c["halo_exchanges_per_solve"]
     assert c["transport"] == "host" and c["degraded"] is True
+
+
+@pytest.mark.gpu
+def test_one_rank_of_a_partition_alone_on_the_gpu(pkg):
+    """multigpu._AloneTransport (tools/rank_alone.py): one rank of an 8-rank partition runs by itself -- zero halos, no peers -- so that
+    its kernels can be profiled undisturbed.  The numbers mean nothing; the run must launch the partitioned path (boundary fix-ups,
+    overlapping levels, replicated levels) and stay finite for a fixed number of iterations."""
+    import importlib
+    import torch
+    mg = importlib.import_module(pkg.__name__ + ".multigpu")
+    pa = importlib.import_module(pkg.__name__ + ".partition")
+    rep, depths, _ = mg.plan_partition(16, 4, 8)
+    g = mg.DistributedGMG((16, 16, 16), 4, 0, 8, device_id=0, transport="alone", lengths=tuple(float(v) for v in pa.rank_grid(8, 3)),
+                          rep_from=rep, depth=depths, finest_depth=0)
+    b = torch.from_numpy(g.rhs_lin()).cuda()
+    x = torch.zeros(g.n_own, dtype=torch.float64, device="cuda")
+    ex0 = g.comm_stats()[0]
+    log = g.cg_solve(b, x, maxiter=3, atol=0.0, rtol=0.0)
+    torch.cuda.synchronize()
+    assert log.num_iters == 3 and bool(torch.isfinite(x).all()) and g.comm_stats()[0] - ex0 > 20
+    assert g.comm_info()["transport"] == "host" and g.comm_info()["nranks"] == 8
+    g.close()
