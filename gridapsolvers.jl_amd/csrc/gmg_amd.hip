@@ -342,6 +342,16 @@ struct Smoother {
   }
 };
 
+// rows of an operator that reference ghost columns, in the form ghost_fix_sell_kernel reads (slices of 64 rows, column-major, values as
+// doubles or as one-byte codes into a dictionary)
+struct GhostFix {
+  int64_t nb = 0;
+  int32_t *rows = nullptr, *len = nullptr, *scol = nullptr;
+  int64_t *soff = nullptr;
+  double *sval = nullptr, *dict = nullptr;
+  uint8_t *scode = nullptr;
+};
+
 struct Level {
   // s = omega*(Dinv*r) already written into sbuf[0] by the kernel that produced r (restriction / r -= A dx)
   bool s0_ready = false;
@@ -396,6 +406,10 @@ struct Level {
   double *gh_sval = nullptr;
   uint8_t *gh_scode = nullptr;      // one byte per entry into gh_dict (<= 256 distinct values) instead of gh_sval
   double *gh_dict = nullptr;
+  // the restriction of an own | ghost level split the same way (round 5): R keeps the own columns -- and with them a row-pattern
+  // layout -- and runs while consistent!(r) is in flight, the ghost columns of the coarse rows next to the box faces are added afterwards
+  bool r_split = false;
+  GhostFix rfix;
   double *x = nullptr;            // correction at this level (levels > 0)
   double *rbuf[2] = {nullptr, nullptr};
   double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
@@ -755,6 +769,7 @@ struct gmg_solver {
       L.ptmp = L.pcor = nullptr; L.pcorr.built = false;
       L.split = false; L.nbnd = 0; L.gh_rows = nullptr; L.gh_ptr = nullptr; L.gh_col = nullptr; L.gh_val = nullptr;
       L.gh_len = nullptr; L.gh_scol = nullptr; L.gh_soff = nullptr; L.gh_sval = nullptr; L.gh_scode = nullptr; L.gh_dict = nullptr;
+      L.r_split = false; L.rfix = GhostFix();
       L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pflags = nullptr; L.pf_nwg = 0; L.pf_epoch = 1;
       L.tbuf[0] = L.tbuf[1] = L.tbuf[2] = nullptr; L.t_off = 0; L.t_sym = -1;
@@ -2562,6 +2577,67 @@ struct gmg_solver {
                        pk ? L.halo.d_pk_slot : nullptr, pk ? L.halo.d_sendbuf : nullptr);
     HIP_CHECK(hipGetLastError());
   }
+  // boundary rows (CSR over ghost columns) -> the sliced form; values become dictionary codes when there are <= 256 distinct ones
+  void build_ghost_fix(GhostFix &G, const std::vector<int32_t> &brows, const std::vector<int64_t> &bptr, const std::vector<int32_t> &bcol,
+                       const std::vector<double> &bval)
+  {
+    G = GhostFix();
+    const size_t nbr = brows.size(), nsl = (nbr + 63) / 64;
+    if (nbr == 0) return;
+    std::vector<int32_t> glen(nbr);
+    std::vector<int64_t> soff(nsl + 1, 0);
+    for (size_t sl = 0; sl < nsl; ++sl) {
+      int64_t w = 0;
+      for (size_t q = sl * 64; q < std::min(nbr, sl * 64 + 64); ++q) { glen[q] = (int32_t)(bptr[q + 1] - bptr[q]); w = std::max<int64_t>(w, glen[q]); }
+      soff[sl + 1] = soff[sl] + 64 * w;
+    }
+    std::vector<int32_t> scol((size_t)soff[nsl], 0);
+    std::vector<double> sval((size_t)soff[nsl], 0.0);
+    for (size_t q = 0; q < nbr; ++q)
+      for (int64_t k = bptr[q]; k < bptr[q + 1]; ++k) {
+        const size_t at = (size_t)soff[q / 64] + (size_t)(k - bptr[q]) * 64 + (q & 63);
+        scol[at] = bcol[(size_t)k]; sval[at] = bval[(size_t)k];
+      }
+    std::map<uint64_t, int> seen;
+    std::vector<double> dict;
+    std::vector<uint8_t> code(sval.size(), 0);
+    bool small = opt_int("GMG_HALO_FIX_DICT", 1) != 0;
+    for (size_t q = 0; q < sval.size() && small; ++q) {
+      uint64_t bits; std::memcpy(&bits, &sval[q], 8);
+      auto it = seen.find(bits);
+      if (it == seen.end()) {
+        if (dict.size() == 256) { small = false; break; }
+        it = seen.emplace(bits, (int)dict.size()).first;
+        dict.push_back(sval[q]);
+      }
+      code[q] = (uint8_t)it->second;
+    }
+    G.nb = (int64_t)nbr; G.rows = upload(brows); G.len = upload(glen); G.soff = upload(soff); G.scol = upload(scol);
+    if (small) { dict.resize(256, 0.0); G.scode = upload(code); G.dict = upload(dict); }
+    else G.sval = upload(sval);
+  }
+  // y[row] += sum over the row's ghost entries of val * v[col]
+  void add_ghost_part(const GhostFix &G, const double *v, double *y)
+  {
+    if (G.nb <= 0) return;
+    const dim3 g((unsigned)((G.nb + 255) / 256)), b(256);
+    if (G.scode) hipLaunchKernelGGL((ghost_fix_sell_kernel<0, true>), g, b, 0, stream, G.nb, G.rows, G.len, G.soff, G.scol, (const void *)G.scode, G.dict, v, y,
+                                    (const double *)nullptr, 0.0, (double *)nullptr);
+    else hipLaunchKernelGGL((ghost_fix_sell_kernel<0, false>), g, b, 0, stream, G.nb, G.rows, G.len, G.soff, G.scol, (const void *)G.sval, (const double *)nullptr, v, y,
+                            (const double *)nullptr, 0.0, (double *)nullptr);
+    HIP_CHECK(hipGetLastError());
+  }
+  // dst = R_l r on a level whose R is split (own | ghost layout, several ranks): consistent!(r) runs on the communication stream while
+  // the own columns are applied, the ghost columns follow -- the exchange is the caller's otherwise
+  void restrict_into(int l, double *r, double *dst)
+  {
+    Level &L = lev[l];
+    if (!L.r_split) { spmv_set(L.R, r, dst); return; }
+    begin_exchange(l, r);
+    spmv_set(L.R, r, dst);
+    if (overlapped()) HIP_CHECK(hipStreamWaitEvent(stream, ev_done, 0));
+    add_ghost_part(L.rfix, r, dst);
+  }
   bool can_fuse_pack(int l) const { return comm.nranks > 1 && lev[l].halo.present && lev[l].split && lev[l].nbnd > 0 && lev[l].halo.d_pk_ptr != nullptr; }
   // y = A_l x ; y -= A_l x ; y = b - A_l x   with the halo of x folded in
   void apply_A_set(int l, double *x, double *y)
@@ -3027,7 +3103,7 @@ struct gmg_solver {
   {
     Level &L = lev[l];
     const int64_t nrows = r ? L.R.nrows : 0, ng = lev[l + 1].n;   // (r == nullptr: a rank that holds no part of level l, shadow_cycle)
-    if (r) spmv_set(L.R, r, d_rep_tmp);
+    if (r) restrict_into(l, const_cast<double *>(r), d_rep_tmp);
     zero(rH_global, ng);
     if (nrows > 0) {
       hipLaunchKernelGGL(scatter_gid_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, stream, nrows, d_rep_gid, d_rep_tmp, rH_global);
@@ -3122,12 +3198,12 @@ struct gmg_solver {
     for (int pass = 0; pass < passes; ++pass) {
       if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
       const bool ovl_l = comm.nranks > 1 && L.halo.present && L.halo.ovl;
-      if (!(ovl_l && L.ovl_skip_r)) exchange(l, r);
+      if (!(ovl_l && L.ovl_skip_r) && !L.r_split) exchange(l, r);      // (a split R starts its own exchange and hides it: restrict_into)
       if (redist.present && l + 1 == sub_from) {
         // level l+1 lives on a rank subset: restrict in the glued partition, redistribute! to the subset owners, recurse there (the
         // other ranks shadow the collectives), bring the correction back to the glued own and ghost entries, prolongate from those
         const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
-        spmv_set(L.R, r, redist.glue_r);
+        restrict_into(l, r, redist.glue_r);
         redistribute(redist.to_sub, 0, redist.glue_r, C.rbuf[0]);
         if (redist.member) cycle(l + 1, C.x, C.rbuf[0], true, child);
         else shadow_cycle(l + 1, child);
@@ -3143,7 +3219,7 @@ struct gmg_solver {
         C.s0_ready = true; C.s0_src = C.rbuf[0]; C.s0_omega = C.pre.omega;
       } else {
       StepTimer tm(*this, "restrict", l);
-      spmv_set(L.R, r, C.rbuf[0]);                         // :484 rH = R rh
+      restrict_into(l, r, C.rbuf[0]);                      // :484 rH = R rh
       }
       // :487 fill!(dxH,0) is implicit: the first sweep below / the coarse solve write dxH
       const int child = (pass == 0) ? ctype : (ctype == GMG_W_CYCLE ? GMG_W_CYCLE : GMG_V_CYCLE);
@@ -4950,6 +5026,28 @@ void gmg_solver::setup()
       L.dx = dvec(L.nvec);
       if (one_gather()) { L.sbuf[0] = dvec(L.nvec); L.sbuf[1] = dvec(L.nvec); }                                     // :188 dxh (Adxh is fused away)
       L.P = L.sP ? finish_stream(*L.sP, "prolongation") : upload_csr(L.hP);
+      if (L.hasR && !L.sR && comm.nranks > 1 && L.halo.present && !L.halo.ovl && opt_int("GMG_HALO_SPLIT_R", 1)) {
+        // own | ghost level: R's own columns (all rows: row-pattern layouts apply) + the ghost columns of the rows that have any
+        HostCSR loc;
+        loc.nrows = L.hR.nrows; loc.ncols = L.hR.ncols;
+        loc.ptr.assign((size_t)L.hR.nrows + 1, 0);
+        std::vector<int32_t> brows, bcol;
+        std::vector<int64_t> bptr(1, 0);
+        std::vector<double> bval;
+        for (int64_t i = 0; i < L.hR.nrows; ++i) {
+          bool any = false;
+          for (int64_t k = L.hR.ptr[i]; k < L.hR.ptr[i + 1]; ++k) {
+            if (L.hR.col[k] < L.n) { loc.col.push_back(L.hR.col[k]); loc.val.push_back(L.hR.val[k]); }
+            else { bcol.push_back(L.hR.col[k]); bval.push_back(L.hR.val[k]); any = true; }
+          }
+          loc.ptr[i + 1] = (int64_t)loc.col.size();
+          if (any) { brows.push_back((int32_t)i); bptr.push_back((int64_t)bcol.size()); }
+        }
+        L.R = upload_csr(loc);
+        L.R.nnz_model = L.hR.nnz();
+        build_ghost_fix(L.rfix, brows, bptr, bcol, bval);
+        L.r_split = true;
+      } else
       if (L.hasR) L.R = L.sR ? finish_stream(*L.sR, "restriction") : upload_csr(L.hR);
       else {
         HostCSR Rt = L.sP ? transpose(expand_stream(*L.sP)) : transpose(L.hP);   // R = P^T, GridTransferOperators.jl:536-547
@@ -5746,7 +5844,7 @@ struct OptionKey { const char *name; bool live; };
 const OptionKey kOptionKeys[] = {
   {"GMG_BIG_ROWS", false}, {"GMG_COARSE_HOST_FALLBACK_MAX", false}, {"GMG_COARSE_HOST_MAX", false}, {"GMG_COARSE_AUTO_CG_MIN", false},
   {"GMG_DBG_NOGATHER", false}, {"GMG_EAGER", true}, {"GMG_EAGER_MIN_ROWS", true}, {"GMG_FORCE_PTR64", false}, {"GMG_GJ_MFMA", false}, {"GMG_GJ_WIDE_MIN", false},
-  {"GMG_HALO_FUSE_PACK", false}, {"GMG_HALO_FIX_SELL", false}, {"GMG_HALO_FIX_DICT", false}, {"GMG_HOST_ASYNC", false}, {"GMG_IDX16", false}, {"GMG_LANES_LOG2", false}, {"GMG_NT", false},
+  {"GMG_HALO_FUSE_PACK", false}, {"GMG_HALO_FIX_SELL", false}, {"GMG_HALO_FIX_DICT", false}, {"GMG_HALO_SPLIT_R", false}, {"GMG_HOST_ASYNC", false}, {"GMG_IDX16", false}, {"GMG_LANES_LOG2", false}, {"GMG_NT", false},
   {"GMG_NT_ROWWISE", false}, {"GMG_ONE_GATHER", false}, {"GMG_OPATTERN", false}, {"GMG_OVERLAP", false}, {"GMG_PATCH_DEDUP", false},
   {"GMG_PATCH_OPERATOR", false}, {"GMG_PATCH_OP_DEVICE", false}, {"GMG_PATCH_SOURCE_DEDUP", false}, {"GMG_PATTERN", false}, {"GMG_PAT_BATCHED", false},
   {"GMG_PAT_CODED_MIN_ROWS", false}, {"GMG_PAT_DEFER", false}, {"GMG_PAT_DINV", false}, {"GMG_PAT_EMIT", false}, {"GMG_PAT_NB", false},
@@ -6044,7 +6142,11 @@ int gmg_op_apply(gmg_handle_t h, int lev, int op, const double *x, double *y, in
                                memspace == GMG_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
       double *dy = memspace == GMG_MEM_DEVICE ? y : h->scratch_vec(1, h->lev[0].nvec);
       if (op == GMG_OP_A) h->apply_A_set(lev, sx, dy);      // own x own kernel overlapping the halo + boundary rows
-      else { h->exchange(src, sx); h->spmv_set(*M, sx, dy); }
+      else {
+        h->exchange(src, sx);
+        h->spmv_set(*M, sx, dy);
+        if (op == GMG_OP_R && L.r_split) h->add_ghost_part(L.rfix, sx, dy);     // (R of an own | ghost level: the ghost columns separately)
+      }
       h->out_vec(y, dy, M->nrows, memspace);
       return;
     } else {
