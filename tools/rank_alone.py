@@ -30,4 +30,5 @@ for k in range(nsolve + 1):
 print(f"rank {rank} of {world} alone: {cells}^3 cells per rank, {nlev} levels, depths {depths}, replicated from level {rep_from}: "
       f"{log.num_iters} iterations in {dt * 1e3:.3f} ms = {dt * 1e3 / max(log.num_iters, 1):.3f} ms per iteration (wall, host callbacks included); "
       f"halo exchanges per solve {g.comm_stats()[0] // (nsolve + 1)}")
+print("finest sweep:", g.sweep_signature(0))
 g.close()
