@@ -114,11 +114,11 @@ SYMBOLS = {
     "gmg_get_comm_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "gmg_set_replication": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64],
     "gmg_set_krylov_map": [C.c_void_p, C.c_void_p, C.c_int64],
-    "gmg_set_partition_overlap_hints": [C.c_void_p, C.c_int, C.c_int, C.c_int],
+    "gmg_set_partition_overlap_hints": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "gmg_set_redistribution": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(RedistPlan), C.POINTER(RedistPlan)],
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],
     "gmg_get_kernel_stats": [C.c_void_p, C.POINTER(KernelStats)],
-    "gmg_get_kernel_stats_by_variant": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "gmg_get_kernel_stats_by_variant": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)],
     "gmg_model_bytes": [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gmg_sweep_signature": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "gmg_level_format": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),

@@ -363,10 +363,14 @@ struct Level {
   // streamed matrix of an own | ghost level: the own x own part goes to the stream, the entries in ghost columns of the rows that
   // have any are kept as the small CSR the boundary fix-up applies (gmg_set_operator_rows splits every block)
   bool rs_forbid = false;           // several ranks: the r-gather sweep form is a joint decision (gmg_solver::setup)
-  // overlapping layout, gmg_set_partition_overlap_hints: the caller's geometry says that (a) after a smoothing pass the residual is still
-  // exact on every ghost entry the restriction reads, (b) P's rows are complete wherever r_own -= (A dxh)_own reads dxh -- the
-  // consistent!(r) before the restriction / the consistent!(dxh) before r -= A dxh are then skipped
-  bool ovl_skip_r = false, ovl_skip_dx = false;
+  // overlapping layout, gmg_set_partition_overlap_hints: the caller states GEOMETRY only -- how many exact node layers the halo holds,
+  // how many of them one sweep of this level's smoother consumes, how far the restriction of an owned coarse row reads -- and (b) that P's
+  // rows are complete wherever r_own -= (A dxh)_own reads dxh.  Whether the consistent!(r) before the restriction can be skipped is
+  // derived per smoothing pass from the depth and the niter of the smoother that just ran (skip_r_after); cleared by
+  // gmg_set_partition_overlap and gmg_set_smoother_* of the level.
+  int ovl_layers = 0, ovl_sweep_reach = 0, ovl_r_reach = 0;
+  bool ovl_skip_dx = false;
+  void clear_overlap_hints() { ovl_layers = ovl_sweep_reach = ovl_r_reach = 0; ovl_skip_dx = false; }
   bool sA_split = false;
   std::vector<int32_t> g_rows, g_col;
   std::vector<int64_t> g_ptr;
@@ -3181,6 +3185,16 @@ struct gmg_solver {
     for (size_t i = first; i < host_steps.size(); ++i)
       std::fprintf(stderr, "[gmg host] %10.1f us  +%7.1f  lev %d  %s\n", host_steps[i].t0 - host_steps[first].t0, host_steps[i].t1 - host_steps[i].t0, host_steps[i].lev, host_steps[i].what);
   }
+  // Overlapping level: is the residual the pass of smoother S left behind still exact on every ghost entry the restriction of an owned
+  // coarse row reads?  smooth() runs S.niter sweeps in blocks of `depth` (one exchange per block); the LAST block has
+  // niter - depth * ((niter - 1) / depth) sweeps, each of which makes `ovl_sweep_reach` more node layers inexact.
+  static bool skip_r_after(const Level &L, const Smoother &S)
+  {
+    if (L.ovl_layers <= 0 || L.ovl_sweep_reach <= 0 || L.ovl_r_reach <= 0 || S.niter <= 0) return false;
+    const int k = std::max(1, std::min(L.halo.depth, S.niter));
+    const int last = S.niter - k * ((S.niter - 1) / k);
+    return L.ovl_layers - last * L.ovl_sweep_reach >= L.ovl_r_reach;
+  }
   // gmg_v_cycle! / gmg_w_cycle! / gmg_f_cycle!, GMGLinearSolvers.jl:468-610
   void cycle(int l, double *x, const double *r_in, bool x_zero, int ctype)
   {
@@ -3198,7 +3212,7 @@ struct gmg_solver {
     for (int pass = 0; pass < passes; ++pass) {
       if (pass == 1) r = smooth(l, L.post, x, r, false);   // W :531 / F :584 re-smooth
       const bool ovl_l = comm.nranks > 1 && L.halo.present && L.halo.ovl;
-      if (!(ovl_l && L.ovl_skip_r) && !L.r_split) exchange(l, r);      // (a split R starts its own exchange and hides it: restrict_into)
+      if (!(ovl_l && skip_r_after(L, pass == 0 ? L.pre : L.post)) && !L.r_split) exchange(l, r);      // (a split R starts its own exchange and hides it: restrict_into)
       if (redist.present && l + 1 == sub_from) {
         // level l+1 lives on a rank subset: restrict in the glued partition, redistribute! to the subset owners, recurse there (the
         // other ranks shadow the collectives), bring the correction back to the glued own and ghost entries, prolongate from those
@@ -3565,6 +3579,22 @@ struct gmg_solver {
     else if (A.sell) { mat = 12.0 * (double)A.zpad + 4.0 * N + 8.0 * (double)A.nslices; if (sell_defer && sell_un >= 6 && sell_un < 9) vec -= 4.0 * N; }
     else mat = 12.0 * (double)A.nnz + (A.ptr64 ? 8.0 : 4.0) * N;
     return mat + vec;
+  }
+  // The same count for ONE form of the sweep (xmode 0: x updated every sweep, 1: x untouched, 2: x updated with both
+  // pending increments).  On the layouts whose sweeps alternate between forms 1 and 2, sweep_layout_bytes() is their
+  // launch-weighted mean: it carries 12 B/row for x (x in + x out + the previous increment on every second sweep).
+  double sweep_layout_bytes_variant(int l, int xmode) const
+  {
+    const Level &L = lev[l];
+    const DevCSR &A = L.A;
+    const double N = (double)L.n, mean = sweep_layout_bytes(l);
+    const bool defer = (A.pat && A.pat_shared) ? pat_defer != 0
+                     : (A.pat) ? false
+                     : (A.sell && A.opat) ? (sell_defer && sell_un < 27)
+                     : (A.sell && (A.comp_idx || A.vdict)) ? false
+                     : (A.sell) ? (sell_defer && sell_un >= 6 && sell_un < 9) : false;
+    if (!defer) return mean;
+    return mean - 12.0 * N + (xmode == 1 ? 0.0 : xmode == 2 ? 24.0 * N : 16.0 * N);
   }
   KrylovOps level0_ops(int use_precond);
   bool can_refresh() const;
@@ -5696,6 +5726,7 @@ static void assign_smoother(gmg_handle_t h, int lev, int which, const Smoother &
   if (which == GMG_PRE_AND_POST) { L.pre = S; L.post_shares_pre = true; }
   else if (which == GMG_PRE) { L.pre = S; if (L.post_shares_pre) { L.post_shares_pre = false; } }
   else { L.post = S; L.post_shares_pre = false; }
+  L.clear_overlap_hints();          // layers-per-sweep was stated for the smoother that was here before: state it again after this call
   h->touch();
 }
 
@@ -6409,12 +6440,17 @@ int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_ghost, i
   });
 }
 
-int gmg_set_partition_overlap_hints(gmg_handle_t h, int lev, int residual_exact_after_pass, int correction_exact_near_owned)
+int gmg_set_partition_overlap_hints(gmg_handle_t h, int lev, int exact_node_layers, int layers_per_sweep, int restriction_reach,
+                                    int correction_exact_near_owned)
 {
   return guarded(h, [&] {
     check_level(h, lev, true);
-    h->lev[lev].ovl_skip_r = residual_exact_after_pass != 0;
-    h->lev[lev].ovl_skip_dx = correction_exact_near_owned != 0;
+    REQUIRE(exact_node_layers >= 0 && layers_per_sweep >= 0 && restriction_reach >= 0, GMG_ERR_INVALID, "negative layer counts");
+    Level &L = h->lev[lev];
+    REQUIRE(L.halo.present && L.halo.ovl, GMG_ERR_INVALID, "overlap hints need gmg_set_partition_overlap on this level first");
+    L.ovl_layers = exact_node_layers; L.ovl_sweep_reach = layers_per_sweep; L.ovl_r_reach = restriction_reach;
+    L.ovl_skip_dx = correction_exact_near_owned != 0;
+    h->touch();
   });
 }
 
@@ -6438,6 +6474,8 @@ int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, int64_t 
     REQUIRE(n_ghost == 0 || rcv_idx, GMG_ERR_INVALID, "null rcv_idx");
     static const int64_t none = 0;
     fill_plan(h->lev[lev].halo, h->comm, n_local - n_ghost, n_ghost, nnbr, nbr_rank, snd_ptr, snd_idx, rcv_ptr, rcv_idx ? rcv_idx : &none, depth);
+    h->lev[lev].clear_overlap_hints();                       // stated for the halo that was here before
+    if (lev > 0) h->lev[lev - 1].ovl_skip_dx = false;        // "P's rows are complete" was a statement about THIS level's layout too
     h->touch();
   });
 }
@@ -6584,15 +6622,19 @@ int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
   });
 }
 
-int gmg_get_kernel_stats_by_variant(gmg_handle_t h, double total_ms[3], int64_t launches[3])
+int gmg_get_kernel_stats_by_variant(gmg_handle_t h, double total_ms[3], int64_t launches[3], double layout_bytes[3])
 {
   return guarded(h, [&] {
     check_ready(h);
-    REQUIRE(total_ms && launches, GMG_ERR_INVALID, "null output");
+    REQUIRE(total_ms && launches && layout_bytes, GMG_ERR_INVALID, "null output");
     gmg_kernel_stats tmp;
     const int st = gmg_get_kernel_stats(h, &tmp);            // folds the pending event pairs into the accumulators
     REQUIRE(st == GMG_OK, st, "gmg_get_kernel_stats failed");
-    for (int v = 0; v < 3; ++v) { total_ms[v] = h->prof_ms_v[v]; launches[v] = h->prof_n_v[v]; }
+    const int l = h->prof_level >= 0 ? h->prof_level : 0;
+    for (int v = 0; v < 3; ++v) {
+      total_ms[v] = h->prof_ms_v[v]; launches[v] = h->prof_n_v[v];
+      layout_bytes[v] = h->prof_patch ? tmp.layout_bytes : h->sweep_layout_bytes_variant(l, v);
+    }
   });
 }
 

@@ -214,10 +214,12 @@ class DistributedGMG:
                                                                                    C.c_void_p(gi.ctypes.data), C.c_void_p(G.val.ctypes.data), abi.CSR, 0, 8))
         if world > 1 and local_hierarchy is None and "order" in self.local:
             # transfer exchanges the halo geometry makes unnecessary (consistent!(r) before the restriction, consistent!(dxh) before r -= A dxh)
+            # (the library is told the geometry -- layers, layers per sweep, reach of R -- and derives the first skip per pass itself;
+            # overlap_hints() is the same rule evaluated here for this niter: what the bench line reports)
             self.overlap_hints = pa.overlap_hints(self.local, niter, smoother)
-            for l, (sr, sd) in enumerate(self.overlap_hints):
-                if (sr or sd) and not int(os.environ.get("GMG_NO_OVERLAP_HINTS", "0")):
-                    abi.check(h, lib.gmg_set_partition_overlap_hints(h, l, int(sr), int(sd)))
+            for l, (lay, per, rr, sd) in enumerate(pa.overlap_geometry(self.local, smoother)):
+                if lay > 0 and not int(os.environ.get("GMG_NO_OVERLAP_HINTS", "0")):
+                    abi.check(h, lib.gmg_set_partition_overlap_hints(h, l, lay, per, rr, int(sd)))
         sub = self.local.get("sub") if world > 1 else None
         if sub is not None:
             tp, fp = abi.RedistPlan.from_dict(sub["to_sub"], self._keep), abi.RedistPlan.from_dict(sub["from_sub"], self._keep)
@@ -614,7 +616,7 @@ def run_bench(args, rank, world, local_rank):
             lg = step()
         # HIP events on every stride-th finest sweep of the timed solves: each sample costs the stream ~11 us, so keep them rare
         # (largest of 61 / 31 / 13 / 7 that leaves >= 8 samples; GMG_PROF_STRIDE overrides)
-        stride = next((s for s in (61, 31, 13, 7) if steps * 60 // s >= 8), 7)
+        stride = int(os.environ["GMG_PROF_STRIDE"]) if os.environ.get("GMG_PROF_STRIDE") else next((s for s in (61, 31, 13, 7) if steps * 60 // s >= 8), 7)
         abi.check(gh.h, gh._lib.gmg_set_option(gh.h, b"prof_stride", float(stride)))
         gh.profile(0, True)
         ex0, ar0 = gh.comm_stats()

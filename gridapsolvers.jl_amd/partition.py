@@ -638,3 +638,15 @@ def overlap_hints(local, niter, smoother="jacobi"):
         skip_dx = (not glued) and nxt is not None and (nxt.replicated or (getattr(nxt, "overlap", False) and int(nxt.layers) >= order))
         out.append((bool(skip_r), bool(skip_dx)))
     return out
+
+
+def overlap_geometry(local, smoother="jacobi"):
+    """Per level the geometric facts gmg_set_partition_overlap_hints takes -- (exact node layers, layers one sweep consumes, reach of R,
+    P's rows complete near the owned box) -- from which the library derives what overlap_hints() predicts for a given niter."""
+    order = int(local["order"])
+    reach = order if smoother == "jacobi" else 3 * order - 2
+    rnodes = 1 if order == 1 else 3
+    levels = local["levels"]
+    hints = overlap_hints(local, 1, smoother)
+    return [(int(L.layers), reach, rnodes, bool(hints[l][1])) if (L is not None and getattr(L, "overlap", False) and l < len(levels) - 1)
+            else (0, 0, 0, False) for l, L in enumerate(levels)]

@@ -628,10 +628,11 @@ class GMGNumericalSetup:
     def kernel_stats(self):
         st = abi.KernelStats()
         abi.check(self.h, self._lib.gmg_get_kernel_stats(self.h, C.byref(st)))
-        ms, nl = (C.c_double * 3)(), (C.c_int64 * 3)()
-        abi.check(self.h, self._lib.gmg_get_kernel_stats_by_variant(self.h, ms, nl))
+        ms, nl, lb = (C.c_double * 3)(), (C.c_int64 * 3)(), (C.c_double * 3)()
+        abi.check(self.h, self._lib.gmg_get_kernel_stats_by_variant(self.h, ms, nl, lb))
         names = ("x_every_sweep", "x_untouched", "x_two_increments")
-        by_variant = {names[v]: dict(launches=int(nl[v]), total_ms=float(ms[v]), avg_ms=float(ms[v]) / nl[v]) for v in range(3) if nl[v]}
+        by_variant = {names[v]: dict(launches=int(nl[v]), total_ms=float(ms[v]), avg_ms=float(ms[v]) / nl[v], layout_bytes=float(lb[v]))
+                      for v in range(3) if nl[v]}
         return dict(launches=st.launches, total_ms=st.total_ms, alg_bytes=st.alg_bytes, rows=st.rows, nnz=st.nnz,
                     layout_bytes=st.layout_bytes, fused_passes=st.fused_passes, by_variant=by_variant)
 

@@ -383,16 +383,23 @@ GMG_API int gmg_set_partition(gmg_handle_t h, int lev, int64_t n_own, int64_t n_
 GMG_API int gmg_set_partition_overlap(gmg_handle_t h, int lev, int64_t n_local, int64_t n_ghost, int depth, int nnbr,
                                       const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
                                       const int64_t *rcv_ptr, const int64_t *rcv_idx);
-/* Two of the exchanges a V-cycle makes on an overlapping level besides the smoothing blocks can be dropped when the caller's geometry
- * allows (it knows the halo in node layers; the library only knows `depth`):
- *   residual_exact_after_pass   -- after the LAST block of a smoothing pass the residual is still exact on every ghost entry the
- *     restriction of an owned coarse row reads (node layers - sweeps of the last block x layers per sweep >= reach of R: 1 node for
- *     Q1, 3 for Q2): consistent!(r) before `rH = R rh` (GMGLinearSolvers.jl:484) is skipped;
+/* Two of the exchanges a V-cycle makes on an overlapping level besides the smoothing blocks can be dropped when the halo geometry allows.
+ * The caller states the GEOMETRY (it knows the halo in node layers; the library only knows `depth` in sweeps), the library decides:
+ *   exact_node_layers, layers_per_sweep, restriction_reach -- the halo holds `exact_node_layers` node layers around the owned box, one
+ *     sweep of this level's smoother makes `layers_per_sweep` more of them inexact (Richardson-Jacobi: `order`; vertex-star patches:
+ *     3 order - 2), and the restriction of an owned coarse row reads fine nodes up to `restriction_reach` away (1 for Q1, 3 for Q2).
+ *     After a smoothing pass of niter sweeps in blocks of `depth` the last block has niter - depth * ((niter - 1) / depth) sweeps;
+ *     when exact_node_layers - that * layers_per_sweep >= restriction_reach, consistent!(r) before `rH = R rh`
+ *     (GMGLinearSolvers.jl:484) is skipped -- evaluated per pass with the niter of the smoother that just ran (pre-smoother; the
+ *     post-smoother on the second leg of a W / F cycle), so pre != post niter and later gmg_set_smoother_* calls cannot make it stale;
  *   correction_exact_near_owned -- P's local rows are complete (the coarse level is replicated, or overlapping with >= 1 layer) on every
  *     fine entry that `rh_own -= (A dxh)_own` reads: consistent!(dxh) before `rh -= A dxh` (:495) is skipped -- the ghost rows of r it
  *     leaves inexact are refreshed by the consistent!(r) that opens the post-smoothing pass.
- * partition.overlap_hints() is the structured-grid rule; results on owned rows are bit-identical with and without the hints. */
-GMG_API int gmg_set_partition_overlap_hints(gmg_handle_t h, int lev, int residual_exact_after_pass, int correction_exact_near_owned);
+ * Call AFTER gmg_set_partition_overlap and gmg_set_smoother_* of the level: both clear the hints (they were stated for the halo / the
+ * smoother that was there before); zeros = no shortcut.  partition.overlap_hints() is the structured-grid rule; results on owned rows
+ * are bit-identical with and without the hints. */
+GMG_API int gmg_set_partition_overlap_hints(gmg_handle_t h, int lev, int exact_node_layers, int layers_per_sweep, int restriction_reach,
+                                            int correction_exact_near_owned);
 /* FINEST level in the overlapping layout (round 5).  The Krylov solver's vectors are the caller's -- own | ghost numbering, its dot
  * products run over owned entries -- so the solver then holds TWO finest operators: the preconditioner's level 0 in the overlapping
  * layout (gmg_set_partition_overlap(h, 0, ...), gmg_set_matrix(h, 0, square local matrix), P_0 / R_0 in that numbering) and the
@@ -451,10 +458,11 @@ GMG_API int gmg_set_redistribution(gmg_handle_t h, int lev, int member, int64_t 
  * was 5 % of a 128^3 solve) -- so a caller that times whole solves at the same time sets the option prof_stride (read at this call;
  * odd and coprime with the number of sweeps per solve, e.g. 61) to keep the samples rare); enable=0 stops.  Read with gmg_get_kernel_stats (launch-weighted totals) and
  * gmg_get_kernel_stats_by_variant (index 0: sweeps that update x every time -- the generic layouts' first sweep, one-launch
- * passes, patch sweeps; 1: x untouched; 2: x updated with two increments). */
+ * passes, patch sweeps; 1: x untouched; 2: x updated with two increments; layout_bytes[v] = the bytes ONE launch of form v moves with the
+ * stored layout, every operand once -- gmg_kernel_stats.layout_bytes is their launch-weighted mean). */
 GMG_API int gmg_profile_enable(gmg_handle_t h, int lev, int enable);
 GMG_API int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out);
-GMG_API int gmg_get_kernel_stats_by_variant(gmg_handle_t h, double total_ms[3], int64_t launches[3]);
+GMG_API int gmg_get_kernel_stats_by_variant(gmg_handle_t h, double total_ms[3], int64_t launches[3], double layout_bytes[3]);
 /* Algorithmic bytes (SURVEY 8d byte model) of one V-cycle / one CG iteration. */
 GMG_API int gmg_model_bytes(gmg_handle_t h, double *vcycle_bytes, double *cg_iter_bytes);
 /* Storage chosen for A_lev at setup: *sell = 0 CSR-stream, 1 SELL-64 / SELL-C, 2 SELL-P (row-pattern

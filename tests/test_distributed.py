@@ -747,6 +747,7 @@ def test_config4_at_full_size_through_the_host_transport(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.child_process
 def test_one_rank_of_a_partition_alone_on_the_gpu(pkg):
     """multigpu._AloneTransport (tools/rank_alone.py): one rank of an 8-rank partition runs by itself -- zero halos, no peers -- so that
     its kernels can be profiled undisturbed.  The numbers mean nothing; the run must launch the partitioned path (boundary fix-ups,

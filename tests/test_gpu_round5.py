@@ -184,6 +184,7 @@ def test_big_level_matvecs_are_bitwise_the_single_row_kernels_and_the_oracle(S, 
 
 
 # ---------------------------------------------------------------- the per-GPU problem of BASELINE configs[3] on its own workload
+@pytest.mark.child_process
 def test_weak_anchor_288cubed_properties(S, po):
     """288^3 cells Q1, 6 levels (2.37e7 dofs): what every GPU of BASELINE configs[3] (576^3 on 2x2x2) holds and what bench.py reports as
     `weak_anchor_value`.  Beyond the oracle's reach in test time, so: the finest level runs the OCC=2 kernels the tests above pin;
@@ -231,6 +232,7 @@ def test_weak_anchor_288cubed_properties(S, po):
 
 
 # ---------------------------------------------------------------- BASELINE configs[2] at its stated size
+@pytest.mark.child_process
 def test_config3_q2_256cubed_properties(S, po):
     """BASELINE configs[2] as stated: 3-D Poisson Q2 on 256^3 cells (1.33e8 dofs, 8.5e9 stored nonzeros, 1.7e7 vertex-star patches on
     the finest level), 5-level GMG, Richardson(PatchSolver,10,0.2) pre = post, FGMRES(5), rtol 1e-6
