@@ -377,12 +377,15 @@ def emit(out):
     head = rc if (compressed or not (isinstance(rg, dict) and rg.get("achieved"))) else rg     # no structure found: the default leg IS the generic stream
     full["roofline"], full["roofline_generic"] = head, rg
     paths = []
-    for d in ("profiles", "gpurun_out"):
+    # GMG_BENCH_DETAILS=<file>: the details go there and nowhere else (tests: keeps the tracked profiles/ copy out of their way)
+    targets = [os.environ["GMG_BENCH_DETAILS"]] if os.environ.get("GMG_BENCH_DETAILS") else \
+        [os.path.join(ROOT, d, "bench_legs_latest.json") for d in ("profiles", "gpurun_out")]
+    for t in targets:
         try:
-            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-            with open(os.path.join(ROOT, d, "bench_legs_latest.json"), "w") as f:
+            os.makedirs(os.path.dirname(t) or ".", exist_ok=True)
+            with open(t, "w") as f:
                 json.dump(full, f, indent=1, default=float)
-            paths.append(d + "/bench_legs_latest.json")
+            paths.append(os.path.relpath(t, ROOT) if t.startswith(ROOT) else t)
         except OSError:
             pass
     line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",

@@ -114,6 +114,7 @@ SYMBOLS = {
     "gmg_get_comm_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "gmg_set_replication": [C.c_void_p, C.c_int, C.c_void_p, C.c_int64],
     "gmg_set_krylov_map": [C.c_void_p, C.c_void_p, C.c_int64],
+    "gmg_comm_set_loopback": [C.c_void_p, C.c_int],
     "gmg_set_partition_overlap_hints": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int],
     "gmg_set_redistribution": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(RedistPlan), C.POINTER(RedistPlan)],
     "gmg_profile_enable": [C.c_void_p, C.c_int, C.c_int],

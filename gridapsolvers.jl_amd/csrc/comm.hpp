@@ -89,6 +89,12 @@ struct Comm {
   HostExchangeFn xfn = nullptr;
   HostAllreduceFn rfn = nullptr;
   void *ctx = nullptr;
+  // gmg_comm_set_loopback: the communicator has ONE real rank, the partition it serves was written for `nranks` of them and folded
+  // onto this one (every neighbour is this rank itself).  Every message is then a self send / receive -- the whole exchange path
+  // (pack, grouped ncclSend/ncclRecv on the communication stream, events, boundary fix-up, ncclAllReduce) runs on one GPU.
+  bool loopback = false;
+  int peer(int r) const { return loopback ? 0 : r; }
+  int real_ranks() const { return loopback ? 1 : nranks; }
 };
 
 // Per-level exchange plan (PartitionedArrays: assembly_neighbors + local indices)

@@ -28,6 +28,8 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <exception>
 #include <string>
 #include <thread>
 #include <atomic>
@@ -74,32 +76,55 @@ int64_t read_index(const void *p, int64_t i, int bytes)
   return bytes == 8 ? reinterpret_cast<const int64_t *>(p)[i] : (int64_t) reinterpret_cast<const int32_t *>(p)[i];
 }
 
-// setup-time host loops over independent chunks (slices, columns): plain std::thread fan-out
+// setup-time host loops over independent chunks (slices, columns): plain std::thread fan-out.
+// run_threads(nt, body): body(0) .. body(nt-1), body(0) on the calling thread.  Exception-safe on both sides -- an exception in a
+// worker (a REQUIRE, std::bad_alloc on a box with little host memory) is carried to the caller and rethrown after every thread
+// has been joined, and a thread that cannot be created (EAGAIN under a container's pid limit) has its share run by the caller:
+// either of the two used to end the whole process through std::terminate (an uncaught exception in a std::thread body; a
+// joinable std::thread destroyed while the vector unwinds) -- SIGABRT with no message, which no ABI-level try/catch can intercept.
+template <typename F>
+void run_threads(int nt, F &&body)
+{
+  if (nt <= 1) { body(0); return; }
+  std::vector<std::thread> th;
+  std::exception_ptr first;
+  std::mutex mu;
+  auto guarded_body = [&](int t) {
+    try { body(t); }
+    catch (...) { std::lock_guard<std::mutex> lk(mu); if (!first) first = std::current_exception(); }
+  };
+  int started = 1;                                    // index 0 is the caller's
+  try {
+    th.reserve((size_t)nt - 1);
+    for (; started < nt; ++started) th.emplace_back(guarded_body, started);
+  } catch (...) { /* thread creation failed: the caller runs the indices that have no thread */ }
+  guarded_body(0);
+  for (int t = started; t < nt; ++t) guarded_body(t);
+  for (auto &x : th) x.join();
+  if (first) std::rethrow_exception(first);
+}
+inline int host_threads(int64_t cap)
+{
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(hw, 32u), cap));
+}
 template <typename F>
 void parallel_for(int64_t n, F &&fn)
 {
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 32u), std::max<int64_t>(1, n / 256));
+  const int nt = host_threads(n / 256);
   if (nt <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
-  std::vector<std::thread> th;
   const int64_t chunk = (n + nt - 1) / nt;
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&, t] { for (int64_t i = t * chunk; i < std::min(n, (t + 1) * chunk); ++i) fn(i); });
-  for (auto &x : th) x.join();
+  run_threads(nt, [&](int t) { for (int64_t i = t * chunk; i < std::min(n, (t + 1) * chunk); ++i) fn(i); });
 }
 
 // the same for a handful of BIG work items (one chunk of rows each): one thread per item, at most 32
 template <typename F>
 void parallel_chunks(int64_t n, F &&fn)
 {
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const int nt = (int)std::min<int64_t>(std::min<unsigned>(hw, 32u), n);
+  const int nt = host_threads(n);
   if (nt <= 1) { for (int64_t i = 0; i < n; ++i) fn(i); return; }
-  std::vector<std::thread> th;
   std::atomic<int64_t> next(0);
-  for (int t = 0; t < nt; ++t)
-    th.emplace_back([&] { for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
-  for (auto &x : th) x.join();
+  run_threads(nt, [&](int) { for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
 }
 
 // Accepts {CSR|CSC} x {0|1}-based x {int32|int64} (SparseMatrixCSC{Float64,Int}: CSC,1,8;
@@ -867,7 +892,7 @@ struct gmg_solver {
       std::vector<uint64_t> hash;
       std::unordered_map<uint64_t, std::vector<int32_t>> index;
     };
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), (n + 4095) / 4096));
+    const int T = host_threads((n + 4095) / 4096);
     std::vector<Local> loc((size_t)T);
     std::vector<int32_t> lid((size_t)n);
     std::atomic<bool> fail(false);
@@ -2428,8 +2453,8 @@ struct gmg_solver {
       int rc = comm.api.GroupStart();
       for (size_t k = 0; k < H.nbr.size() && rc == 0; ++k) {
         const int64_t sc = H.snd_ptr[k + 1] - H.snd_ptr[k], rcn = H.rcv_ptr[k + 1] - H.rcv_ptr[k];
-        if (sc > 0) rc = comm.api.Send(H.d_sendbuf + H.snd_ptr[k], (size_t)sc, kNcclDouble, H.nbr[k], comm.comm, stream);
-        if (rc == 0 && rcn > 0) rc = comm.api.Recv(ghost + H.rcv_ptr[k], (size_t)rcn, kNcclDouble, H.nbr[k], comm.comm, stream);
+        if (sc > 0) rc = comm.api.Send(H.d_sendbuf + H.snd_ptr[k], (size_t)sc, kNcclDouble, comm.peer(H.nbr[k]), comm.comm, stream);
+        if (rc == 0 && rcn > 0) rc = comm.api.Recv(ghost + H.rcv_ptr[k], (size_t)rcn, kNcclDouble, comm.peer(H.nbr[k]), comm.comm, stream);
       }
       const int rc2 = comm.api.GroupEnd();
       REQUIRE(rc == 0 && rc2 == 0, GMG_ERR_COMM, std::string("RCCL halo exchange: ") + comm.api.GetErrorString(rc ? rc : rc2));
@@ -2495,8 +2520,8 @@ struct gmg_solver {
       int rc = comm.api.GroupStart();
       for (size_t k = 0; k < H.nbr.size() && rc == 0; ++k) {
         const int64_t sc = H.snd_ptr[k + 1] - H.snd_ptr[k], rcn = H.rcv_ptr[k + 1] - H.rcv_ptr[k];
-        if (rcn > 0) rc = comm.api.Send(ghost + H.rcv_ptr[k], (size_t)rcn, kNcclDouble, H.nbr[k], comm.comm, stream);
-        if (rc == 0 && sc > 0) rc = comm.api.Recv(H.d_recvbuf + H.snd_ptr[k], (size_t)sc, kNcclDouble, H.nbr[k], comm.comm, stream);
+        if (rcn > 0) rc = comm.api.Send(ghost + H.rcv_ptr[k], (size_t)rcn, kNcclDouble, comm.peer(H.nbr[k]), comm.comm, stream);
+        if (rc == 0 && sc > 0) rc = comm.api.Recv(H.d_recvbuf + H.snd_ptr[k], (size_t)sc, kNcclDouble, comm.peer(H.nbr[k]), comm.comm, stream);
       }
       const int rc2 = comm.api.GroupEnd();
       REQUIRE(rc == 0 && rc2 == 0, GMG_ERR_COMM, std::string("RCCL reverse halo: ") + comm.api.GetErrorString(rc ? rc : rc2));
@@ -4718,8 +4743,7 @@ double *gmg_solver::build_dense_inverse(const HostCSR &A, const std::string &wha
   BandLU lu;
   REQUIRE(lu.factor(A), GMG_ERR_SINGULAR, what + " is singular");
   std::vector<double> inv((size_t)n * n);
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const int nthreads = (int)std::min<unsigned>(hw, (unsigned)std::max(1, n / 16));
+  const int nthreads = host_threads(std::max(1, n / 16));
   auto work = [&](int t) {
     std::vector<double> e(n);
     for (int c = t; c < n; c += nthreads) {
@@ -4729,10 +4753,7 @@ double *gmg_solver::build_dense_inverse(const HostCSR &A, const std::string &wha
       for (int i = 0; i < n; ++i) inv[(size_t)i * n + c] = e[i]; // row-major inverse
     }
   };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
-  work(0);
-  for (auto &t : th) t.join();
+  run_threads(nthreads, work);
   double *d = upload(inv);
   HIP_CHECK(hipStreamSynchronize(stream));
   return d;
@@ -5161,7 +5182,7 @@ void gmg_solver::setup()
       if (own_ghost) L.rs_forbid = false;
       double ok = (!own_ghost || rsweep_level(L)) ? 1.0 : 0.0;
       host_allreduce_sum(&ok);
-      if (own_ghost) L.rs_forbid = ok < (double)comm.nranks - 0.5;
+      if (own_ghost) L.rs_forbid = ok < (double)comm.real_ranks() - 0.5;
     }
   }
   HIP_CHECK(hipStreamSynchronize(stream));
@@ -5281,6 +5302,10 @@ int guarded(gmg_handle_t h, F &&f)
   } catch (const std::exception &e) {
     if (h) h->err = e.what();
     g_last_error = e.what();
+    return GMG_ERR_INVALID;
+  } catch (...) {                                            // nothing may cross the C ABI
+    if (h) h->err = "unknown exception";
+    g_last_error = "unknown exception";
     return GMG_ERR_INVALID;
   }
 }
@@ -6424,6 +6449,18 @@ int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_f
       if (!h->ev_ready) HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
       if (!h->ev_done) HIP_CHECK(hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming));
     }
+    h->touch();
+  });
+}
+
+int gmg_comm_set_loopback(gmg_handle_t h, int virtual_nranks)
+{
+  return guarded(h, [&] {
+    REQUIRE(h, GMG_ERR_INVALID, "null handle");
+    REQUIRE(h->comm.kind != COMM_NONE, GMG_ERR_STATE, "gmg_comm_init_rccl / gmg_comm_init_host first");
+    REQUIRE(h->comm.nranks == 1 && !h->comm.loopback, GMG_ERR_STATE, "loopback needs a communicator of exactly one rank");
+    REQUIRE(virtual_nranks >= 2, GMG_ERR_INVALID, "virtual_nranks must be >= 2");
+    h->comm.loopback = true; h->comm.rank = 0; h->comm.nranks = virtual_nranks;
     h->touch();
   });
 }

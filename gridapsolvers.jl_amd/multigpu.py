@@ -90,6 +90,28 @@ class _AloneTransport:
         self.allreduce_cb = abi.HOST_ALLREDUCE_FN(allreduce)
 
 
+class _LoopbackTransport:
+    """Host-staged counterpart of gmg_comm_set_loopback: message k of a plan goes from send segment k to receive segment k of the
+    same rank; all-reduces over the one real rank are the identity.  The bit-for-bit reference of the RCCL loopback run."""
+
+    def __init__(self):
+        def exchange(ctx, nnbr, nbr_rank, sendbuf, snd_ptr, recvbuf, rcv_ptr):
+            ns, nr = int(snd_ptr[nnbr]), int(rcv_ptr[nnbr])
+            if nr == 0:
+                return
+            s, r = np.ctypeslib.as_array(sendbuf, shape=(ns,)), np.ctypeslib.as_array(recvbuf, shape=(nr,))
+            for k in range(nnbr):
+                s0, s1, r0, r1 = int(snd_ptr[k]), int(snd_ptr[k + 1]), int(rcv_ptr[k]), int(rcv_ptr[k + 1])
+                assert s1 - s0 == r1 - r0, "loopback: message k must have the same length on both sides"
+                r[r0:r1] = s[s0:s1]
+
+        def allreduce(ctx, vals, n):
+            pass
+
+        self.exchange_cb = abi.HOST_EXCHANGE_FN(exchange)
+        self.allreduce_cb = abi.HOST_ALLREDUCE_FN(allreduce)
+
+
 class DistributedGMG:
     """Distributed numerical setup of CG/FGMRES + GMG on the structured Poisson hierarchy."""
 
@@ -152,12 +174,24 @@ class DistributedGMG:
                 blob = [bytes(uid.raw) if rank == 0 else None]
                 dist.broadcast_object_list(blob, src=0, group=group)
                 abi.check(h, lib.gmg_comm_init_rccl(h, path, blob[0], rank, world))
+            elif transport == "rccl_loopback":
+                # ONE real rank, a partition folded onto it (partition.fold_ranks): RCCL's own unique id, a communicator of one rank
+                path = rccl_path().encode()
+                uid = C.create_string_buffer(128)
+                abi.check(None, lib.gmg_comm_unique_id(path, uid))
+                abi.check(h, lib.gmg_comm_init_rccl(h, path, bytes(uid.raw), 0, 1))
+                abi.check(h, lib.gmg_comm_set_loopback(h, world))
+            elif transport == "host_loopback":
+                self._host = _LoopbackTransport()
+                abi.check(h, lib.gmg_comm_init_host(h, 0, 1, C.cast(self._host.exchange_cb, C.c_void_p),
+                                                    C.cast(self._host.allreduce_cb, C.c_void_p), None))
+                abi.check(h, lib.gmg_comm_set_loopback(h, world))
             elif transport in ("host", "alone"):
                 self._host = _HostTransport(group) if transport == "host" else _AloneTransport(world)
                 abi.check(h, lib.gmg_comm_init_host(h, rank, world, C.cast(self._host.exchange_cb, C.c_void_p),
                                                     C.cast(self._host.allreduce_cb, C.c_void_p), None))
             else:
-                raise ValueError("transport must be 'rccl', 'host' or 'alone'")
+                raise ValueError("transport must be 'rccl', 'host', 'alone', 'rccl_loopback' or 'host_loopback'")
         levels = self.local["levels"]
         for l, L in enumerate(levels):
             if L is None:                                     # a level of a rank subset this rank is not part of
@@ -212,7 +246,7 @@ class DistributedGMG:
                         gp, gi = np.ascontiguousarray(G.ptr, dtype=np.int64), np.ascontiguousarray(G.idx, dtype=np.int64)
                         abi.check(h, lib.gmg_set_prolongation_patch_correction_rhs(h, l, G.shape[0], G.nnz, C.c_void_p(gp.ctypes.data),
                                                                                    C.c_void_p(gi.ctypes.data), C.c_void_p(G.val.ctypes.data), abi.CSR, 0, 8))
-        if world > 1 and local_hierarchy is None and "order" in self.local:
+        if world > 1 and (local_hierarchy is None or self.local.get("structured")) and "order" in self.local:
             # transfer exchanges the halo geometry makes unnecessary (consistent!(r) before the restriction, consistent!(dxh) before r -= A dxh)
             # (the library is told the geometry -- layers, layers per sweep, reach of R -- and derives the first skip per pass itself;
             # overlap_hints() is the same rule evaluated here for this niter: what the bench line reports)
@@ -246,7 +280,7 @@ class DistributedGMG:
         abi.check(h, lib.gmg_setup(h))
         self.t_setup = time.perf_counter() - t0
         self.n_own = levels[0].n_own
-        self.n_global = po.level_sizes(self.cells_global, order) if local_hierarchy is None else None
+        self.n_global = po.level_sizes(self.cells_global, order) if (local_hierarchy is None or self.local.get("structured")) else None
         self.nnz_local = levels[0].A.nnz
 
     def _set_patch_smoother(self, l, L, niter, omega):

@@ -650,3 +650,100 @@ def overlap_geometry(local, smoother="jacobi"):
     hints = overlap_hints(local, 1, smoother)
     return [(int(L.layers), reach, rnodes, bool(hints[l][1])) if (L is not None and getattr(L, "overlap", False) and l < len(levels) - 1)
             else (0, 0, 0, False) for l, L in enumerate(levels)]
+
+
+def fold_ranks(locals_):
+    """Fold the local hierarchies of ALL ranks of a partition (build_local_hierarchy for rank 0 .. W-1) onto ONE rank whose every
+    neighbour is itself -- the partition gmg_comm_set_loopback is made for.
+
+    Per partitioned level: the ranks' owned rows stacked in rank order, the ranks' ghosts stacked behind them (own | ghost layout) or the
+    ranks' extended boxes stacked (overlapping layout: block-diagonal local matrix); the exchange plan has one message per
+    (receiving rank a, neighbour q of a) pair, in the order the folded ghosts are stored, its send list = what q sends to a with q's
+    offset -- so message k's send segment lands exactly in receive segment k, which is how a self send / receive pairs up.  Every
+    neighbour is named rank 1 (any rank other than 0 means "this rank" under loopback).  Replicated levels are taken as they are;
+    rep_gid = the ranks' lists stacked (together: every row of level rep_from once).
+    Mathematically the folded operators ARE the global ones (a ghost column is a copy of an owned entry the exchange keeps current),
+    so the serial oracle on the global hierarchy is the reference; the sums are split own | ghost exactly as on W GPUs.
+    No rank-subset levels, no separate Krylov operator (finest_depth = 0)."""
+    W = len(locals_)
+    assert W >= 2 and all(h["nranks"] == W for h in locals_) and all(h.get("sub") is None and h.get("krylov") is None for h in locals_)
+    nlev = len(locals_[0]["levels"])
+    rep_from = locals_[0]["rep_from"]
+    lv = [[h["levels"][l] for h in locals_] for l in range(nlev)]
+
+    def offsets(sizes):
+        o = np.zeros(len(sizes) + 1, dtype=np.int64)
+        np.cumsum(sizes, out=o[1:])
+        return o
+
+    kind, cmap, ncols = [], [], []        # per level: "rep" / "og" / "ovl"; per rank the local-column -> folded-column map
+    for l in range(nlev):
+        Ls = lv[l]
+        if Ls[0].replicated:
+            kind.append("rep"); cmap.append([None] * W); ncols.append(Ls[0].A.shape[0])
+        elif Ls[0].overlap:
+            off = offsets([L.n_local for L in Ls])
+            kind.append("ovl"); cmap.append([off[a] + np.arange(Ls[a].n_local, dtype=np.int64) for a in range(W)]); ncols.append(int(off[-1]))
+        else:
+            off, goff = offsets([L.n_own for L in Ls]), offsets([L.n_ghost for L in Ls])
+            kind.append("og")
+            cmap.append([np.concatenate([off[a] + np.arange(Ls[a].n_own, dtype=np.int64),
+                                         off[-1] + goff[a] + np.arange(Ls[a].n_ghost, dtype=np.int64)]) for a in range(W)])
+            ncols.append(int(off[-1] + goff[-1]))
+
+    def stack(mats, maps, nc):
+        """rows of the ranks' matrices stacked, columns through the rank's map (None: unchanged)"""
+        ptr = [np.zeros(1, dtype=np.int64)]
+        idx, val, base = [], [], 0
+        for M, m in zip(mats, maps):
+            ptr.append(M.ptr[1:] + base)
+            base += M.nnz
+            idx.append(M.idx.astype(np.int64) if m is None else m[M.idx])
+            val.append(M.val)
+        return po.CSR((sum(M.shape[0] for M in mats), nc), np.concatenate(ptr), np.concatenate(idx), np.concatenate(val))
+
+    levels = []
+    for l in range(nlev):
+        Ls = lv[l]
+        F = LocalLevel()
+        if kind[l] == "rep":
+            F.A, F.n_own, F.n_ghost, F.replicated = Ls[0].A, Ls[0].n_own, 0, True
+            F.own_gid, F.ghost_gid = Ls[0].own_gid, Ls[0].ghost_gid
+        else:
+            F.A = stack([L.A for L in Ls], cmap[l], ncols[l])
+            F.n_own, F.n_ghost = sum(L.n_own for L in Ls), sum(L.n_ghost for L in Ls)
+            F.own_gid, F.ghost_gid = np.concatenate([L.own_gid for L in Ls]), np.concatenate([L.ghost_gid for L in Ls])
+            ovl = kind[l] == "ovl"
+            loc_off = offsets([L.n_local for L in Ls]) if ovl else offsets([L.n_own for L in Ls])
+            snd, rcv, sp, rp = [], [], [0], [0]
+            for a in range(W):
+                La = Ls[a]
+                for k, q in enumerate(La.nbr_rank):
+                    Lq = Ls[int(q)]
+                    kq = int(np.nonzero(Lq.nbr_rank == a)[0][0])
+                    s = loc_off[int(q)] + Lq.snd_idx[Lq.snd_ptr[kq]:Lq.snd_ptr[kq + 1]]
+                    nr = int(La.rcv_ptr[k + 1] - La.rcv_ptr[k])
+                    assert s.size == nr, "what q sends to a is what a receives from q"
+                    snd.append(s); sp.append(sp[-1] + s.size); rp.append(rp[-1] + nr)
+                    if ovl:
+                        rcv.append(loc_off[a] + La.rcv_idx[La.rcv_ptr[k]:La.rcv_ptr[k + 1]])
+            F.nbr_rank = np.ones(len(snd), dtype=np.int32)
+            F.snd_ptr, F.rcv_ptr = np.asarray(sp, dtype=np.int64), np.asarray(rp, dtype=np.int64)
+            F.snd_idx = np.concatenate(snd).astype(np.int64) if snd else np.zeros(0, np.int64)
+            if ovl:
+                F.overlap, F.depth, F.layers = True, Ls[0].depth, Ls[0].layers
+                F.n_local = int(loc_off[-1])
+                F.rcv_idx = np.concatenate(rcv).astype(np.int64) if rcv else np.zeros(0, np.int64)
+                F.own_idx = np.concatenate([loc_off[a] + Ls[a].own_idx for a in range(W)])
+                F.local_gid = np.concatenate([L.local_gid for L in Ls])
+        if l < nlev - 1:
+            if kind[l] == "rep":
+                F.P, F.R = Ls[0].P, Ls[0].R
+            else:
+                F.P = stack([L.P for L in Ls], cmap[l + 1], ncols[l + 1])      # fine rows x coarse columns
+                F.R = stack([L.R for L in Ls], cmap[l], ncols[l])              # coarse rows x fine columns
+        levels.append(F)
+    h0 = locals_[0]
+    return dict(levels=levels, rep_from=rep_from, rep_gid=np.ascontiguousarray(np.concatenate([h["rep_gid"] for h in locals_]), dtype=np.int64),
+                cells=h0["cells"], grid=h0["grid"], order=h0["order"], rank=0, nranks=2, depths=h0["depths"], krylov=None, sub=None,
+                folded_from=W, structured=True)

@@ -357,6 +357,14 @@ GMG_API int gmg_comm_selftest(gmg_handle_t h, double *out2);
  * out6[1] host time to enqueue it, out6[2] / out6[3] the same for a 1-double ncclAllReduce + square root, out6[4] the
  * exchange issued in-stream, out6[5] an empty kernel.  Peers are the ring neighbours (the rank itself on one rank). */
 GMG_API int gmg_comm_latency_probe(gmg_handle_t h, int nmsg, int64_t count, int reps, double *out6);
+/* Loopback (testing / bring-up on one GPU; no reference counterpart -- the reference's analogue is running its MPI tests with one
+ * process, test/LinearSolvers/mpi/GMGTests.jl:5-8): after gmg_comm_init_rccl(.., rank 0, nranks 1) or gmg_comm_init_host(.., 0, 1, ..)
+ * declare that the partition handed over next was written for `virtual_nranks` ranks and FOLDED onto this one: every rank's owned rows
+ * stacked, every rank's ghosts stacked behind them, every neighbour entry naming a rank other than 0 -- which then means "this rank".
+ * Message k of a level's plan is sent to and received from this rank itself (RCCL matches the k-th send of a group with the k-th
+ * receive), so pack -> ncclGroupStart/Send/Recv/GroupEnd on the communication stream -> event -> boundary fix-up -> ncclAllReduce
+ * run exactly as on `virtual_nranks` GPUs, on the one that exists.  partition.fold_ranks() builds such a partition. */
+GMG_API int gmg_comm_set_loopback(gmg_handle_t h, int virtual_nranks);
 /* Host-staged transport through callbacks of the host language (MPI in Julia, gloo in the
  * Python tests); lets several ranks share one GPU.  Functional, not fast. */
 GMG_API int gmg_comm_init_host(gmg_handle_t h, int rank, int nranks, gmg_host_exchange_fn exchange,

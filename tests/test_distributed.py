@@ -405,14 +405,17 @@ def test_bench_multi_rank_path_with_overlapping_levels(finest, tmp_path):
     keeps it own | ghost as at BASELINE config 4's size."""
     import subprocess
     env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1",
+               GMG_BENCH_DETAILS=str(tmp_path / "legs.json"),
                GMG_REP_ROWS="3000", GMG_HALO_DEPTH="5", **({} if finest is None else {"GMG_FINEST_DEPTH": str(finest)}))
     root = os.path.dirname(HERE)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "32", "--levels", "4",
                           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["n_gpus"] == 2 and d["headline_leg"] == "default" and d["roofline_compressed"]["leg"] == "default" and d["roofline"]["leg"] == "generic"
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][0]
+    assert len(line) <= 4096 and json.loads(line)["details"] == str(tmp_path / "legs.json")
+    d = json.load(open(tmp_path / "legs.json"))           # everything the run measured; the printed line is its <= 4 KB extract
+    assert d["n_gpus"] == 2 and d["headline_leg"] == "default" and d["roofline"]["leg"] == "default" and d["roofline_generic"]["leg"] == "generic"
     assert d["config"]["halo_depths"][:3] == [11 if finest is None else finest, 5, 0] and d["config"]["replicated_from_level"] == 2
     assert d["config"]["cg_iterations"] == d["config"]["cg_iterations_generic"] <= 4 and d["config"]["max_abs_error_vs_exact"] < 1e-4
     assert d["value_generic"] > 0 and d["config"]["halo_exchanges_per_solve"] > 0
@@ -423,7 +426,8 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(tmp_path):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), both ranks sharing the single
     GPU of the test box over the host-staged transport: the JSON contract of the multi-rank line and the joint self-check."""
     import subprocess
-    env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1",
+               GMG_BENCH_DETAILS=str(tmp_path / "legs.json"))
     root = os.path.dirname(HERE)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--cells", "32", "--levels", "3",
@@ -431,13 +435,19 @@ def test_bench_multi_rank_path_runs_end_to_end_on_one_gpu(tmp_path):
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-1500:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["unit"] == "DoFs/s" and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["transport"] == "host" and d["config"]["degraded"] is True
+    # the printed line: <= 4 KB, ONE leg (value, ms_per_step and roofline all describe the default leg), the driver's contract keys
+    assert len(lines[0]) <= 4096
+    ln = json.loads(lines[0])
+    assert set(ln) >= {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data", "config", "roofline"} and ln["roofline"]["leg"].startswith("default")
+    assert ln["n_gpus"] == 2 and ln["steps"] == 2 and ln["unit"] == "DoFs/s" and ln["scaling"] == "weak" and ln["value"] > 0
+    assert ln["config"]["transport"] == "host" and ln["config"]["degraded"] is True and "workload" in ln["config"]
+    assert ln["roofline"]["frac"] is None or ln["roofline"]["frac"] <= 1.0
+    d = json.load(open(tmp_path / "legs.json"))           # everything else: the details file the line names
+    assert ln["details"] == str(tmp_path / "legs.json") and d["value"] == ln["value"] and d["ms_per_step"] == ln["ms_per_step"]
     assert d["config"]["cg_iterations"] <= 4 and d["config"]["max_abs_error_vs_exact"] < 1e-4
-    assert d["roofline"]["frac"] is None or d["roofline"]["frac"] <= 1.0
-    # the same shape as the N = 1 line: generic leg = `roofline`, default leg = `roofline_compressed`; who took part; the anchor
-    assert d["roofline"]["leg"] == "generic" and d["roofline_compressed"]["leg"] == "default"
+    # the same shape as the N = 1 record: default leg = `roofline`, generic leg = `roofline_generic`; who took part; the anchor
+    assert d["roofline_generic"]["leg"] == "generic" and d["roofline"]["leg"] == "default"
     assert d["rccl_ranks"] == 0 and len(d["devices"]) == 2 and {x["rank"] for x in d["devices"]} == {0, 1}
     assert d["weak_anchor_value"] > 0 and d["weak_scaling_ref"]["cg_iterations"] == d["config"]["cg_iterations"]
 
@@ -728,13 +738,15 @@ def test_config4_at_full_size_through_the_host_transport(tmp_path):
     host memory per rank): the planner's layout (finest level own | ghost, levels 1 / 2 overlapping with depths 6 / 11, levels 3-5
     replicated), 3 CG iterations, the analytic solution to 1e-5, the exchange count of that plan."""
     import subprocess
-    env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    env = dict(os.environ, GMG_SHARE_GPU="1", GMG_TRANSPORT="host", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4",
+               GMG_BENCH_DETAILS=str(tmp_path / "legs.json"))
     root = os.path.dirname(HERE)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--cells", "288", "--levels", "6",
                           "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-generic"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]) <= 4096
+    d = json.load(open(tmp_path / "legs.json"))
     c = d["config"]
     assert d["n_gpus"] == 8 and c["dofs"] == 575 ** 3 == 190109375 and c["dofs_per_gpu"] > 2.3e7
     assert c["halo_depths"] == [0, 6, 11, 0, 0, 0] and c["replicated_from_level"] == 3
