@@ -27,10 +27,14 @@ N = 1  BASELINE configs[1]: 128^3 cells, Q1, 4 levels, Richardson(Jacobi,10,2/3)
 N > 1  BASELINE configs[3]: 288^3 cells per GPU (576^3 on 2x2x2), 6 levels, box row partition, halo exchange and
        scalar all-reduces over RCCL; launched by torch.distributed.run, or by bench.py itself when WORLD_SIZE is unset.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--legs default,generic,varcoef,weak_ref,host_io,config3,config5,cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--legs default,generic,varcoef,weak_ref,host_io,config3,config5,rccl_loopback,cpu]
                     [--allow-degraded]   (N > 1 only: without it a run whose transport is not RCCL on all N ranks exits non-zero)
 
-Prints ONE JSON line (rank 0)."""
+         rccl_loopback          functional: the 2x2x2 partition of a Q1 problem folded onto this GPU, solved through the product's halo
+                                exchange and all-reduces over RCCL (one real rank, self messages); bitwise against the host transport
+
+Prints ONE JSON line (rank 0) of <= 4 KB -- value, ms_per_step and roofline all describe the default leg -- and writes everything
+else the run measured to profiles/bench_legs_latest.json (GMG_BENCH_DETAILS=<file> redirects it)."""
 from __future__ import annotations
 
 import argparse
@@ -63,7 +67,7 @@ def prof_stride_for(steps, sweeps_per_solve=60):
         if steps * sweeps_per_solve // s >= 8:
             return s
     return 7
-ALL_LEGS = ("default", "generic", "varcoef", "weak_ref", "host_io", "config3", "config5", "cpu")
+ALL_LEGS = ("default", "generic", "varcoef", "weak_ref", "host_io", "config3", "config5", "rccl_loopback", "cpu")
 LEGS_NOTE = ("same key <-> leg mapping at every --gpus N: default leg (the product as shipped: gmg_setup picks the storage layout) = `value`, "
              "`ms_per_step`, `roofline_compressed`; generic leg (every structure-exploiting layout off: the 12 B/nnz (col,val) stream SURVEY 8(d)'s "
              "byte model describes) = `value_generic`, `ms_per_step_generic`, `roofline`.  N = 1 runs BASELINE configs[1] (128^3) and carries the "
@@ -91,6 +95,8 @@ def parse():
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (Stokes Q2/P1disc, block-triangular FGMRES)")
     ap.add_argument("--config5-cells", type=int, default=512, help="cells per direction of the 2-D Stokes leg (2 (2n-1)^2 velocity dofs)")
     ap.add_argument("--config5-levels", type=int, default=6)
+    ap.add_argument("--loopback-cells", type=int, default=48, help="cells per direction per (virtual) rank of the rccl_loopback leg")
+    ap.add_argument("--loopback-levels", type=int, default=4)
     ap.add_argument("--allow-degraded", action="store_true",
                     help="N > 1: accept the host-staged transport / in-stream exchanges when RCCL is unavailable (the line then says degraded: true)")
     ap.add_argument("--rhs", choices=["lin", "rand"], default="lin")
@@ -407,6 +413,10 @@ def emit(out):
         line["generic_leg"] = dict(value=full.get("value_generic"), ms_per_step=full.get("ms_per_step_generic"),
                                    what="same problem, every structure-exploiting layout off: the 12 B/nnz (col,val) stream of SURVEY 8(d)",
                                    roofline=_pick(rg, ("bytes_per_launch", "avg_launch_ms", "launches_timed", "achieved", "frac", "traffic", "traffic_GBs")))
+    lb = full.get("rccl_loopback")
+    if isinstance(lb, dict):
+        line["rccl_loopback"] = _pick(lb, ("rccl_ranks", "virtual_ranks", "exchanges_per_solve", "allreduces_per_solve", "bitwise_equal_host_transport",
+                                           "ms_per_step_overlapped", "ms_per_step_unpartitioned", "error"))
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         c = _pick(cb, ("value", "unit", "cores", "kind", "seconds", "single_thread_value", "error"))
@@ -415,7 +425,7 @@ def emit(out):
     line["details"] = paths[0] if paths else None
     txt = json.dumps(line, default=float)
     if len(txt) > LINE_LIMIT:                    # never again a line the driver cannot take: drop the optional parts first
-        for k in ("generic_leg", "details"):
+        for k in ("generic_leg", "rccl_loopback", "details"):
             line.pop(k, None)
         line["config"]["workload"] = _short(line["config"]["workload"], 160)
         txt = json.dumps(line, default=float)
@@ -786,6 +796,13 @@ def main():
         except Exception as e:
             out["config5"] = {"error": str(e)[-400:]}
 
+    # ---------------- the product's exchange path over RCCL on this one GPU (a folded 8-rank partition, self messages) ----------
+    if "rccl_loopback" in legs:
+        try:
+            out["rccl_loopback"] = rccl_loopback_leg(torch, pkg, args)
+        except Exception as e:
+            out["rccl_loopback"] = {"error": str(e)[-400:]}
+
     if "cpu" in legs:
         cb, xo, nit_o, hist_o = cpu_baseline(args.cells, nlev, args.rhs)
         out["cpu_baseline"] = cb
@@ -905,6 +922,88 @@ def config3_leg(torch, pkg, args):
                             gpu_hist=[float(v) for v in solver2.log.residuals[: solver2.log.num_iters + 1]], gpu_x=x2)
     ns2.P_ns.close()
     return out
+
+
+def rccl_loopback_leg(torch, pkg, args):
+    """FUNCTIONAL record (no scaling claim: one GPU): the 2x2x2 partition of a 3-D Q1 Poisson problem folded onto this GPU
+    (partition.fold_ranks) and solved with CG + GMG through the product's own exchange path over RCCL -- pack kernel / fused pack in the
+    boundary fix-up -> ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the communication stream -> event -> boundary fix-up,
+    ncclAllReduce for every dot / norm and for the replicated coarse levels' residual (gmg_comm_set_loopback: a communicator of ONE rank,
+    every neighbour is this rank itself).  Overlapped with the own x own kernels and in-stream; checked bit for bit against the same
+    folded partition through the host-staged loopback.  Its times next to the unpartitioned solve of the same problem show what the
+    partitioned path costs on one GPU (split kernels + exchanges + all-reduces), kernels and transport together."""
+    import importlib
+    pa, mg, po, S = (importlib.import_module(pkg.__name__ + "." + m) for m in ("partition", "multigpu", "poisson", "solvers"))
+    per, nlev, W = args.loopback_cells, args.loopback_levels, 8
+    cells = (2 * per,) * 3
+    grid = pa.rank_grid(W, 3)
+    rep_from, depths, _plan = mg.plan_partition(per, nlev, W)
+    depths = [0] + list(depths[1:])          # finest level own | ghost (as at BASELINE config 4's size): its exchanges overlap the own x own kernel
+    t0 = time.perf_counter()
+    F = pa.fold_ranks([pa.build_local_hierarchy(cells, nlev, grid, r, 1, None, rep_from, depths, "jacobi") for r in range(W)])
+    t_fold = time.perf_counter() - t0
+    steps = max(3, args.steps // 2)
+
+    def run(transport, overlap):
+        old = os.environ.get("GMG_OVERLAP")
+        os.environ["GMG_OVERLAP"] = "1" if overlap else "0"
+        try:
+            g = mg.DistributedGMG(cells, nlev, 0, 2, device_id=torch.cuda.current_device(), transport=transport, local_hierarchy=F, cells_global=cells)
+        finally:
+            os.environ.pop("GMG_OVERLAP", None) if old is None else os.environ.__setitem__("GMG_OVERLAP", old)
+        b = torch.from_numpy(g.rhs_lin()).cuda()
+        x = torch.zeros(g.n_own, dtype=torch.float64, device="cuda")
+
+        def step():
+            x.zero_(); torch.cuda.synchronize()
+            return g.cg_solve(b, x, maxiter=20, atol=1e-14, rtol=1e-6)
+        step()
+        ex0, ar0 = g.comm_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lg = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ex1, ar1 = g.comm_stats()
+        rec = dict(ms_per_step=dt * 1e3, iters=int(lg.num_iters), exchanges_per_solve=(ex1 - ex0) / steps, allreduces_per_solve=(ar1 - ar0) / steps,
+                   info=g.comm_info(), x=x.cpu().numpy(), err=float(np.max(np.abs(x.cpu().numpy() - g.exact_own()))), n=int(g.n_own),
+                   sweep_signature=g.sweep_signature(0))
+        g.close()
+        return rec
+    host = run("host_loopback", False)
+    ovl = run("rccl_loopback", True)
+    ins = run("rccl_loopback", False)
+    # the same global problem unpartitioned on this GPU
+    H = po.build_hierarchy(cells, nlev, 1)
+    sm = [S.RichardsonSmoother(S.JacobiLinearSolver(), 10, 2.0 / 3.0)] * (nlev - 1)
+    gm = S.GMGLinearSolver(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=sm, post_smoothers=sm, coarsest_solver=S.LUSolver(), maxiter=1,
+                           mode="preconditioner", cycle_type="v_cycle")
+    sol = S.CGSolver(gm, maxiter=20, atol=1e-14, rtol=1e-6)
+    ns = S.numerical_setup(S.symbolic_setup(sol, H["mats"][0]), H["mats"][0])
+    bd = torch.from_numpy(po.dirichlet_lift_rhs(cells, 1)).cuda()
+    xd = torch.zeros_like(bd)
+    S.solve_(xd, ns, bd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        xd.zero_(); torch.cuda.synchronize(); S.solve_(xd, ns, bd)
+    torch.cuda.synchronize()
+    t_one = (time.perf_counter() - t0) / steps
+    xs = xd.cpu().numpy()
+    ns.P_ns.close()
+    gid = F["levels"][0].own_gid
+    return dict(workload=f"3D Poisson Q1 {cells[0]}^3 cells ({ovl['n']} dofs), {nlev}-level GMG V-cycle, Richardson(Jacobi,10,2/3), CG rtol=1e-6: the 2x2x2 partition "
+                         f"({per}^3 cells per rank; planner: replicated from level {rep_from}, halo depths {depths}) folded onto ONE GPU, every neighbour = this rank",
+                rccl_ranks=int(ovl["info"]["rccl_comm_count"]), virtual_ranks=W, transport=ovl["info"]["transport"], steps=steps,
+                cg_iterations=ovl["iters"], exchanges_per_solve=ovl["exchanges_per_solve"], allreduces_per_solve=ovl["allreduces_per_solve"],
+                ms_per_step_overlapped=ovl["ms_per_step"], ms_per_step_in_stream=ins["ms_per_step"], ms_per_step_host_staged=host["ms_per_step"],
+                ms_per_step_unpartitioned=t_one * 1e3,
+                bitwise_equal_host_transport=bool(np.array_equal(ovl["x"], host["x"]) and np.array_equal(ins["x"], host["x"])),
+                same_counts_as_host_transport=bool(ovl["exchanges_per_solve"] == host["exchanges_per_solve"] and ovl["allreduces_per_solve"] == host["allreduces_per_solve"]),
+                iterations_match_unpartitioned=bool(ovl["iters"] == int(sol.log.num_iters)),
+                rel_diff_vs_unpartitioned_solution=float(np.linalg.norm(ovl["x"] - xs[gid]) / np.linalg.norm(xs)),
+                max_abs_error_vs_exact=ovl["err"], sweep_signature=ovl["sweep_signature"], fold_s=t_fold)
 
 
 def config5_leg(torch, pkg, args, want_cpu):

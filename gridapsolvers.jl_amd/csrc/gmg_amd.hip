@@ -229,6 +229,8 @@ struct PatStream {
 // device containers
 // ----------------------------------------------------------------------------
 struct DevCSR {
+  Z2Geo z2;                         // fused pair of sweeps (sells_z2sweep_kernel): geometry, valid when z2_ok > 0
+  mutable int z2_ok = -1;           // -1 not examined yet, 0 no, 1 yes
   int64_t nrows = 0, ncols = 0, nnz = 0;
   bool ptr64 = false;
   void *rowptr = nullptr;
@@ -443,9 +445,6 @@ struct Level {
   double *rbuf[2] = {nullptr, nullptr};
   double *sbuf[2] = {nullptr, nullptr}; // s = omega*(dinv.*r) ping-pong (one-gather sweep)
   uint32_t *pflags = nullptr;     // persistent smoothing pass (sells_smooth_kernel): one progress word per workgroup, 64 B apart
-  double *tbuf[3] = {nullptr, nullptr, nullptr};   // data-tagged pass (sells_smooth_tag_kernel): three s buffers, sentinel where not yet written
-  int t_off = 0;                  // rotation offset of the next tagged pass
-  int t_sym = -1;                 // run offsets symmetric (every reader of a row is gathered from)? -1 not checked yet
   int pf_nwg = 0;
   uint32_t pf_epoch = 1;
   double *dx = nullptr;
@@ -681,11 +680,6 @@ struct gmg_solver {
   int pat_wide = 1;     // GMG_PAT_WIDE: coded (wide-row) operators decode the patterns of each workgroup's chunk into a plain LDS value table
   int pat_strict = 1;   // GMG_PAT_STRICT: fused sweeps keep the per-entry mask (exact zero products even for non-finite vectors); 0 = 8-byte table entries, 2-3 % faster
   int persist_wpb_min = 1;   // GMG_PERSIST_WPB: smallest workgroup (in waves) of a one-launch pass
-  int persist_tag = 0;  // GMG_PERSIST_TAG (opt-in): the one-launch passes of SMALL levels hand s over through data-tagged buffers (sells_smooth_tag_kernel) instead of
-                        // progress words.  -7 us per pass on 31^3 rows and bit-identical over 4 500 soaked V-cycles, but forced onto a level of 4 034 slices
-                        // it timed out intermittently (cause not found: profiles/r05_tuning.md section 5) -- a time-out costs the handle its one-launch passes
-  int persist_tag_max_slices = 1024;   // GMG_PERSIST_TAG_MAX_SLICES: ... of levels up to this many 62-row slices (31^3 rows: 30.5 -> 23.3 us per pass of 10; 63^3 rows, 4 034 slices
-                                       // on 253 workgroups of 16 waves: 43.2 -> 78.7 us -- 4 048 polling waves and two 8-byte write-through stores per row and sweep)
   int persist = 1;      // GMG_PERSIST: small levels run a whole smoothing pass in one launch (sells_smooth_kernel)
   int persist_fenced = 0; // GMG_PERSIST_FENCED: progress words published with release / polled with acquire semantics (agent scope)
   int persist_max_slices = 0;  // GMG_PERSIST_MAX_SLICES (0: what one workgroup per CU holds)
@@ -699,6 +693,15 @@ struct gmg_solver {
                                            // not bytes): Q2 64^3 (2.05e6 rows) 18.6 -> 16.0 ms per solve, 96^3 (7.0e6) 40.3 -> 30.0, 128^3 89 -> 70
   int pat_zwalk_wide = 1; // GMG_PAT_ZWALK_WIDE: the wide-row (Q2) operator applications of those levels (sellw_zwalk_kernel)
   int pat_zwalk_mv = 1; // GMG_PAT_ZWALK_MV: also the operator mat-vecs of those levels
+  // GMG_PAT_FUSE2 (opt-in): two sweeps per pass over the data (kernels.hpp: sells_z2sweep_kernel) on grid levels of one GPU: 1 = levels of >=
+  // pat_fuse2_rows rows, 2 = every level that qualifies, 0 = off (default).  Bit-identical to the single sweeps and 32 instead of 56 bytes
+  // per row and pair -- but measured SLOWER on MI355X (profiles/r06_ab_fuse2.txt): 128^3 21.9 against 18.5 us per sweep, 288^3 185 against
+  // 156: the rim rows (W / (W - 2) x (T + 2) / T more sweep-k rows), 77 % lane use on 287-row lines and one workgroup barrier per plane
+  // cost more issue slots than the saved bytes buy; the single sweeps already run at their memory bound at 288^3.
+  // pat_fuse2_w = waves (grid lines) per workgroup, pat_fuse2_t = planes per block (0: chosen from the level's size); pat_fuse2_box = 0
+  // keeps the per-row patterns in LDS even on constant-coefficient boxes (the BC form reads one coefficient set per wave from the arguments)
+  int pat_fuse2 = 0, pat_fuse2_w = 0, pat_fuse2_t = 0;
+  int64_t pat_fuse2_rows = 1000000;
   int pat_zwalk_T = 12; // GMG_PAT_ZWALK_T: planes per chain (288^3: 8 / 12 / 16 / 24 / 32 -> 149 / 114 / 120 / 118 / 155 us for the x-untouched form)
   int64_t pat_zwalk_rows = 9000000;   // the walk pays once r, r', x and the pattern ids (26 B per row) no longer fit the 256 MB Infinity Cache: 224^3 (1.09e7 rows) 8.13 -> 7.59 ms per solve,
                                       // 192^3 (7.0e6) 4.89 -> 5.23-5.50 with every chain length (profiles/r05_sizes.txt)
@@ -801,7 +804,6 @@ struct gmg_solver {
       L.r_split = false; L.rfix = GhostFix();
       L.sbuf[0] = L.sbuf[1] = nullptr;
       L.pflags = nullptr; L.pf_nwg = 0; L.pf_epoch = 1;
-      L.tbuf[0] = L.tbuf[1] = L.tbuf[2] = nullptr; L.t_off = 0; L.t_sym = -1;
       for (Smoother *sp : {&L.pre, &L.post, &L.pcorr}) sp->reset_device();
       L.s0_ready = false;
     }
@@ -2197,6 +2199,116 @@ struct gmg_solver {
     g.nchains = (int)nch;
     return true;
   }
+  // geometry of the fused pair of sweeps (kernels.hpp: sells_z2sweep_kernel): the nine runs are the 3 x 3 neighbours (dz, dy) of a grid
+  // whose rows are numbered z P + y L + x, every plane has whole lines and the level whole planes
+  bool z2_geo(const DevCSR &M, Z2Geo &g)
+  {
+    if (M.pat_nruns != 9 || M.pat_k != 3 || !M.ptab) return false;
+    const std::vector<int32_t> &off = host_run_off(M);
+    const int64_t P = (int64_t)off[3] - off[0], L = (int64_t)off[1] - off[0];
+    if (L < 8 || P < 2 * L || P % L != 0 || M.nrows % P != 0 || M.nrows != M.ncols) return false;
+    for (int q = 0; q < 9; ++q) if ((int64_t)off[(size_t)q] != (int64_t)(q / 3 - 1) * P + (int64_t)(q % 3 - 1) * L - 1) return false;
+    g.P = (int)P; g.L = (int)L; g.ny = (int)(P / L); g.nz = (int)(M.nrows / P);
+    if (g.nz < 3 || g.ny < 3) return false;
+    g.whole = L <= 127 ? 1 : 0;
+    g.nxs = g.whole ? 1 : (int)((L + 123) / 124);
+    g.xlen = g.whole ? (int)L : (int)((L + g.nxs - 1) / g.nxs);
+    // W lines per workgroup (two of them rim lines), T planes per block: enough workgroups for two rounds of the chip, as little redundancy as that allows
+    int W = pat_fuse2_w > 0 ? pat_fuse2_w : (M.nrows >= 8000000 ? 16 : 8);
+    W = std::max(3, std::min(16, std::min(W, g.ny + 2)));
+    g.W = W;
+    g.nyt = (g.ny + W - 3) / (W - 2);
+    int T = pat_fuse2_t;
+    if (T <= 0) {
+      const int64_t per_plane_block = (int64_t)g.nyt * g.nxs;
+      const int64_t want = 2 * (int64_t)n_cus;
+      T = (int)std::max<int64_t>(4, std::min<int64_t>(16, (int64_t)g.nz * per_plane_block / std::max<int64_t>(1, want)));
+    }
+    g.T = std::max(1, std::min(T, g.nz));
+    g.nzb = (g.nz + g.T - 1) / g.T;
+    if ((((size_t)M.pat_np * 28 + 1) & ~(size_t)1) * 8 + (size_t)4 * g.W * kZ2Slot * 8 > (size_t)150 * 1024) return false;   // table + ring in one CU's LDS
+    if ((int64_t)g.nzb * g.nyt * g.nxs >= (int64_t)(1 << 30)) return false;
+    // constant-coefficient box?  The nine (plane class, line class) patterns from nine rows in the middle of their lines, then every
+    // row checked against them on the device (kernels.hpp: z2_box_check_kernel)
+    g.box = 0;
+    std::memset(g.coef, 0, sizeof(g.coef)); std::memset(g.cmask, 0, sizeof(g.cmask));
+    if (opt_int("GMG_PAT_FUSE2_BOX", 1) && g.L >= 3) {
+      std::vector<PatEntry> tab((size_t)M.pat_np * 27);
+      HIP_CHECK(hipMemcpyAsync(tab.data(), M.ptab, tab.size() * sizeof(PatEntry), hipMemcpyDeviceToHost, stream));
+      uint16_t pid[9];
+      const int zc[3] = {0, g.nz / 2, g.nz - 1}, yc[3] = {0, g.ny / 2, g.ny - 1};
+      for (int c = 0; c < 9; ++c) {
+        const int64_t row = (int64_t)zc[c / 3] * g.P + (int64_t)yc[c % 3] * g.L + g.L / 2;
+        HIP_CHECK(hipMemcpyAsync(&pid[c], M.rowpid + row, sizeof(uint16_t), hipMemcpyDeviceToHost, stream));
+      }
+      HIP_CHECK(hipStreamSynchronize(stream));
+      std::vector<double> hc(9 * 27);
+      std::vector<uint32_t> hm(9 * 27);
+      for (int c = 0; c < 9; ++c)
+        for (int j = 0; j < 27; ++j) {
+          const PatEntry &e = tab[(size_t)pid[c] * 27 + j];
+          g.coef[c][j] = e.v; g.cmask[c][j] = e.m; hc[(size_t)c * 27 + j] = e.v; hm[(size_t)c * 27 + j] = e.m;
+        }
+      double *d_c = nullptr; uint32_t *d_m = nullptr; int *d_bad = nullptr;
+      HIP_CHECK(hipMalloc((void **)&d_c, hc.size() * sizeof(double)));
+      HIP_CHECK(hipMalloc((void **)&d_m, hm.size() * sizeof(uint32_t)));
+      HIP_CHECK(hipMalloc((void **)&d_bad, sizeof(int)));
+      int bad = 0;
+      hipError_t e1 = hipMemcpyAsync(d_c, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, stream);
+      hipError_t e2 = hipMemcpyAsync(d_m, hm.data(), hm.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+      hipError_t e3 = hipMemsetAsync(d_bad, 0, sizeof(int), stream);
+      if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) {
+        hipLaunchKernelGGL(z2_box_check_kernel, dim3((unsigned)std::min<int64_t>(4096, (M.nrows + 255) / 256)), dim3(256), 0, stream, M.nrows, g.L, g.ny, g.nz, g.P,
+                           M.rowpid, M.ptab, d_c, d_m, d_bad);
+        e1 = hipGetLastError();
+        if (e1 == hipSuccess) e1 = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(stream);
+      }
+      (void)hipFree(d_c); (void)hipFree(d_m); (void)hipFree(d_bad);
+      HIP_CHECK(e1); HIP_CHECK(e2); HIP_CHECK(e3);
+      g.box = bad == 0 ? 1 : 0;
+    }
+    return true;
+  }
+  bool fuse2_level(const Level &L) const
+  {
+    return pat_fuse2 && pat_defer && comm.nranks == 1 && rsweep_level(L) && (pat_fuse2 >= 2 || L.A.nrows >= pat_fuse2_rows) && L.A.z2_ok > 0;
+  }
+  // sweeps k and k + 1 of a pass in one launch: r_k -> r_{k+2}, x += s_k + s_{k+1}
+  void launch_z2sweep(const DevCSR &M, const double *r_cur, double *r_next, double *x, bool x_zero, double omega)
+  {
+    SellSArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.rowpid = M.rowpid; a.tab = M.ptab; a.tab8 = M.ptab8; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
+    a.minoff = M.pat_minoff; a.maxoff = M.pat_maxoff; a.xmode = 2; a.pdinv = M.pdinv;
+    a.nrows = M.nrows; a.ncols = M.ncols; a.xcd_remap = xcd_remap;
+    a.x_zero = x_zero ? 1 : 0; a.x = r_cur; a.omega = omega; a.y = r_next; a.b = r_cur; a.x2 = x;
+    const Z2Geo &g = M.z2;
+    const bool mk = pat_strict || !M.ptab8;
+    const bool bc = g.box != 0;
+    const size_t lds = (bc ? 0 : (((size_t)M.pat_np * 28 + 1) & ~(size_t)1) * 8) + (size_t)4 * g.W * kZ2Slot * 8;
+    const dim3 gr((unsigned)(g.nzb * g.nyt * g.nxs)), b(64 * g.W);
+    M.note_sweep("sells_z2sweep_kernel<MK=%d,FM=%d,BC=%d> (two sweeps per launch) wgs=%u W=%d T=%d tiles=%dx%dx%d L=%d", mk ? 1 : 0, pat_fma ? 1 : 0, bc ? 1 : 0, gr.x, g.W, g.T, g.nxs, g.nyt, g.nzb, g.L);
+    REQUIRE(lds <= (size_t)150 * 1024, GMG_ERR_UNSUPPORTED, "sells_z2sweep_kernel: pattern table + ring exceed the LDS of a CU");
+    static bool attr[64] = {false};
+    if (!attr[device & 63]) {
+#define GMG_Z2_ATTR(MKV, FMV, BCV) HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sells_z2sweep_kernel<MKV, FMV, BCV>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+      GMG_Z2_ATTR(true, true, true); GMG_Z2_ATTR(true, false, true); GMG_Z2_ATTR(false, true, true); GMG_Z2_ATTR(false, false, true);
+      GMG_Z2_ATTR(true, true, false); GMG_Z2_ATTR(true, false, false); GMG_Z2_ATTR(false, true, false); GMG_Z2_ATTR(false, false, false);
+#undef GMG_Z2_ATTR
+      attr[device & 63] = true;
+    }
+#define GMG_Z2_LAUNCH(BCV)                                                                                                   \
+    do {                                                                                                                     \
+      if (mk) { if (pat_fma) hipLaunchKernelGGL((sells_z2sweep_kernel<true, true, BCV>), gr, b, lds, stream, a, g);          \
+                else hipLaunchKernelGGL((sells_z2sweep_kernel<true, false, BCV>), gr, b, lds, stream, a, g); }               \
+      else { if (pat_fma) hipLaunchKernelGGL((sells_z2sweep_kernel<false, true, BCV>), gr, b, lds, stream, a, g);            \
+             else hipLaunchKernelGGL((sells_z2sweep_kernel<false, false, BCV>), gr, b, lds, stream, a, g); }                 \
+    } while (0)
+    if (bc) GMG_Z2_LAUNCH(true); else GMG_Z2_LAUNCH(false);
+#undef GMG_Z2_LAUNCH
+    HIP_CHECK(hipGetLastError());
+  }
   void launch_rsweep(const DevCSR &M, const double *r_cur, double *r_next, const double *r_prev, double *x, bool x_zero, double omega, int xmode)
   {
     SellSArgs a;
@@ -2810,63 +2922,6 @@ struct gmg_solver {
       d_perr_dev = dalloc<uint32_t>(16);
       HIP_CHECK(hipMemsetAsync(d_perr_dev, 0, 64, stream));
     }
-    // data-tagged hand-offs (kernels.hpp: sells_smooth_tag_kernel): 27-point operators whose run offsets are symmetric about the
-    // window centre -- every wave that reads a row is a wave the row's owner gathers from
-    if (persist_tag && M.pat_nruns == 9 && nsl <= persist_tag_max_slices) {
-      if (L.t_sym < 0) {
-        const std::vector<int32_t> &off = host_run_off(M);
-        bool sym = true;
-        for (int q = 0; q < 9 && sym; ++q) {
-          bool found = false;
-          for (int p = 0; p < 9; ++p) found = found || ((int64_t)off[(size_t)p] == -(int64_t)off[(size_t)q] - (M.pat_k - 1));
-          sym = found;
-        }
-        L.t_sym = sym ? 1 : 0;
-      }
-      if (L.t_sym == 1) {
-        if (!L.tbuf[0]) {
-          for (int j = 0; j < 3; ++j) {
-            L.tbuf[j] = dvec(L.nvec);
-            hipLaunchKernelGGL(fill_sentinel_kernel, dim3((unsigned)std::min<int64_t>(1024, (L.nvec + 255) / 256)), dim3(256), 0, stream, L.nvec, L.tbuf[j]);
-            HIP_CHECK(hipGetLastError());
-          }
-          L.t_off = 0;
-        }
-        SellSmoothTagArgs ta;
-        std::memset(&ta, 0, sizeof(ta));
-        SellSmoothArgs &a = ta.b;
-        a.rowpid = M.rowpid; a.tab = M.ptab; a.tab8 = M.ptab8; a.run_off = M.prun; a.np = M.pat_np; a.nruns = M.pat_nruns;
-        a.nrows = M.nrows; a.ncols = M.ncols; a.nslices = nsl;
-        a.pdinv = pat_dinv ? M.pdinv : nullptr; a.dinv = L.dinv; a.omega = S.omega;
-        a.niter = niter; a.x_zero = x_zero ? 1 : 0;
-        a.r_in = r_in; a.r_out = r_out; a.x = x; a.s_a = L.sbuf[0]; a.s_b = L.sbuf[1];
-        a.err = d_perr; a.err_dev = d_perr_dev;
-        for (int j = 0; j < 3; ++j) ta.t[j] = L.tbuf[j];
-        ta.off = L.t_off;
-        L.t_off = (L.t_off + niter - 1) % 3;
-        const dim3 g(nwg), b(64 * wpb);
-        const bool td = a.pdinv != nullptr;
-        const bool mk = pat_strict || !M.ptab8;
-        const bool prof = (l == prof_level) && prof_used + 2 <= prof_ev.size();
-        if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
-#define GMG_SMOOTH_TAG_LAUNCH(NSV, TDV)                                                                        \
-        do {                                                                                                     \
-          if (mk) hipLaunchKernelGGL((sells_smooth_tag_kernel<NSV, TDV, true>), g, b, lds, stream, ta);          \
-          else hipLaunchKernelGGL((sells_smooth_tag_kernel<NSV, TDV, false>), g, b, lds, stream, ta);            \
-        } while (0)
-        if (ns == 2) { if (td) GMG_SMOOTH_TAG_LAUNCH(2, true); else GMG_SMOOTH_TAG_LAUNCH(2, false); }
-        else { if (td) GMG_SMOOTH_TAG_LAUNCH(1, true); else GMG_SMOOTH_TAG_LAUNCH(1, false); }
-#undef GMG_SMOOTH_TAG_LAUNCH
-        HIP_CHECK(hipGetLastError());
-        if (prof) {
-          HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
-          prof_w[prof_used / 2] = niter;
-          prof_xm[prof_used / 2] = 0;
-          prof_used += 2;
-        }
-        return true;
-      }
-    }
     if (!L.pflags || L.pf_nwg < nwg) {
       if (L.pflags) { HIP_CHECK(hipStreamSynchronize(stream)); release(L.pflags, (size_t)L.pf_nwg * 16); }
       L.pflags = dalloc<uint32_t>((size_t)nwg * 16);
@@ -3051,12 +3106,30 @@ struct gmg_solver {
             copy(L.rbuf[0], cur, n);                           // the exchange writes the ghost entries of r_k: never into a caller's vector
             cur = L.rbuf[0];
           }
+          if (L.A.z2_ok < 0) L.A.z2_ok = z2_geo(L.A, L.A.z2) ? 1 : 0;
+          const bool fuse2 = fuse2_level(L);
           for (int it = 0; it < nb; ++it) {
+            double *next = (cur == L.rbuf[0]) ? L.rbuf[1] : L.rbuf[0];
+            if (fuse2 && (it & 1) == 0 && it + 1 < nb) {
+              // sweeps it (x untouched) and it + 1 (x += both increments) in ONE launch: r_k -> r_{k+2}, r_{k+1} never leaves the CUs
+              const bool prof = (l == prof_level) && (prof_seq++ % (uint64_t)prof_stride == 0) && prof_used + 2 <= prof_ev.size();
+              if (prof) HIP_CHECK(hipEventRecord(prof_ev[prof_used], stream));
+              launch_z2sweep(L.A, cur, next, x, xz0 && it == 0, S.omega);
+              if (prof) {
+                HIP_CHECK(hipEventRecord(prof_ev[prof_used + 1], stream));
+                prof_w[prof_used / 2] = 2;
+                prof_xm[prof_used / 2] = 2;
+                prof_used += 2;
+              }
+              prev = nullptr;
+              cur = next;
+              ++it;
+              continue;
+            }
             int xmode = 0;
             bool xz = xz0 && it == 0;
             if ((it & 1) == 0 && it + 1 < nb) xmode = 1;
             else if (it & 1) { xmode = 2; xz = xz0 && it == 1; }
-            double *next = (cur == L.rbuf[0]) ? L.rbuf[1] : L.rbuf[0];
             const bool fp = can_fuse_pack(l);
             rsweep(l, S, x, cur, next, prev, xz, xmode, fp && it > 0, fp && it + 1 < nb);
             prev = cur;
@@ -3513,6 +3586,10 @@ struct gmg_solver {
     pat_zwalk_wide = opt_int("GMG_PAT_ZWALK_WIDE", 1);
     pat_zwalk_wide_rows = opt_int("GMG_PAT_ZWALK_WIDE_ROWS", 1000000);
     pat_zwalk_rows = opt_int("GMG_PAT_ZWALK_ROWS", 9000000);
+    pat_fuse2 = opt_int("GMG_PAT_FUSE2", 0);
+    pat_fuse2_w = opt_int("GMG_PAT_FUSE2_W", 0);
+    pat_fuse2_t = opt_int("GMG_PAT_FUSE2_T", 0);
+    pat_fuse2_rows = opt_int("GMG_PAT_FUSE2_ROWS", 1000000);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
     pat_pair_p = opt_int("GMG_PAT_PAIR_P", 1);
@@ -3520,8 +3597,6 @@ struct gmg_solver {
     pat_r2mv_min = opt_int("GMG_PAT_R2MV_MIN", 100000);
     pat_fma = opt_int("GMG_PAT_FMA", 0);
     persist = opt_int("GMG_PERSIST", 1);
-    persist_tag = opt_int("GMG_PERSIST_TAG", 0);
-    persist_tag_max_slices = opt_int("GMG_PERSIST_TAG_MAX_SLICES", 1024);
     // several ranks on ONE device (host-staged transport: the test / debugging set-up): the one-launch passes of different processes
     // could keep each other from becoming fully resident, so they are off unless asked for
     if (comm.kind == COMM_HOST && !opt_int("GMG_PERSIST_SHARED", 0)) persist = 0;
@@ -3598,6 +3673,7 @@ struct gmg_solver {
       if (pat_dinv && A.pdinv) vec -= 8.0 * N;             // 1/diag from the pattern table
       if (pat_defer) vec -= 4.0 * N;                       // x touched every second sweep: (8+8+8)/2 instead of 8+8
       if (pat_defer && rsweep_level(L)) vec = 28.0 * N;    // sells_rsweep_kernel: r in + r out, (x in + x out + r_prev) every second sweep; no s, no 1/diag
+      if (fuse2_level(L)) vec = 16.0 * N;                  // sells_z2sweep_kernel, per sweep of the pair: (r_k in + r_{k+2} out + x in + x out) / 2
     } else if (A.pat) mat = (A.rowbase ? 6.0 : 2.0) * N;
     else if (A.sell && A.opat) { mat = 8.0 * (double)A.zpad + (A.orowbase ? 6.0 : 2.0) * N + 4.0 * N + 8.0 * (double)A.nslices; if (sell_defer && sell_un < 27) vec -= 4.0 * N; }
     else if (A.sell && (A.comp_idx || A.vdict)) mat = A.stream_bytes_per_nnz * (double)A.zpack + 4.0 * N + 4.0 * (double)(A.zpack / 64);
@@ -3618,7 +3694,7 @@ struct gmg_solver {
                      : (A.sell && A.opat) ? (sell_defer && sell_un < 27)
                      : (A.sell && (A.comp_idx || A.vdict)) ? false
                      : (A.sell) ? (sell_defer && sell_un >= 6 && sell_un < 9) : false;
-    if (!defer) return mean;
+    if (!defer || fuse2_level(L)) return mean;              // (a fused pair is one form: half of the pair's bytes per sweep)
     return mean - 12.0 * N + (xmode == 1 ? 0.0 : xmode == 2 ? 24.0 * N : 16.0 * N);
   }
   KrylovOps level0_ops(int use_precond);
@@ -5910,7 +5986,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", true}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PAT_ZWALK_WIDE_ROWS", false}, {"GMG_PERSIST_TAG", false}, {"GMG_PERSIST_TAG_MAX_SLICES", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PAT_ZWALK_WIDE_ROWS", false}, {"GMG_PAT_FUSE2", false}, {"GMG_PAT_FUSE2_W", false}, {"GMG_PAT_FUSE2_T", false}, {"GMG_PAT_FUSE2_ROWS", false}, {"GMG_PAT_FUSE2_BOX", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option
@@ -6633,7 +6709,7 @@ int gmg_get_kernel_stats(gmg_handle_t h, gmg_kernel_stats *out)
       HIP_CHECK(hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
       h->prof_ms += ms;
       h->prof_launches += h->prof_w[i / 2];
-      if (h->prof_w[i / 2] > 1) h->prof_fused += 1;
+      if (h->prof_w[i / 2] > 2) h->prof_fused += 1;          // (a weight of 2 is a fused PAIR of sweeps, sells_z2sweep_kernel: not a one-launch pass)
       const int v = std::min(2, std::max(0, (int)h->prof_xm[i / 2]));
       h->prof_ms_v[v] += ms; h->prof_n_v[v] += h->prof_w[i / 2];
     }

@@ -2270,6 +2270,258 @@ __global__ __launch_bounds__(kBlock, 4) void sells_zsweep_kernel(SellSArgs a, ZW
 }
 
 // ---------------------------------------------------------------------------
+// TWO sweeps per pass over the data (round 6).  RichardsonSmoothers.jl:90-97 is ten sweeps in a row over the same vectors; launched one
+// by one, every sweep reads r_k and writes r_{k+1} through memory (and every second one x).  On a level whose rows are the nodes of a
+// grid (row = z P + y L + x: the 3 x 3 grid of run offsets says so) sweep k + 1 of a tile needs r_{k+1} only one node further out
+// than the tile, so a workgroup can run BOTH sweeps on a tile with r_{k+1} never leaving the CU:
+//   workgroup = W consecutive grid lines (one per wave) x one segment of x x a block of T planes, walked upwards plane by plane;
+//   step z:  phase 1  every wave computes sweep k (the x-untouched form, XM = 1) for its line of plane z from r_k in memory and puts the
+//                     line of r_{k+1} into a ring of four planes in LDS (zeros where the grid has no node: absent taps need finite values)
+//            barrier
+//            phase 2  the W - 2 inner waves compute sweep k + 1 (the form that updates x with both increments, XM = 2) for their line of
+//                     plane z - 1 from the three planes z - 2, z - 1, z of the ring and store r_{k+2} and x.
+// The rim lines (first / last wave), the planes below / above the block and one node left / right of an x segment are computed
+// redundantly by the neighbouring workgroups -- W / (W - 2) x (T + 2) / T more arithmetic on sweep k, none on sweep k + 1 -- and per pair
+// of sweeps memory sees r_k in, r_{k+2} out, x in / out: 32 bytes per row instead of 16 + 40.
+// A ring of FOUR planes needs one barrier per step: phase 1 of step z + 1 writes the slot phase 2 of step z does not read.
+// Every row is summed exactly as sells_r2sweep_kernel / sells_zsweep_kernel sum it (same taps, same order, same strict-mask rule; the
+// rim rows are recomputed from the same inputs), so the pair is bit-identical to the two single sweeps -- except that a tap the row does
+// not store may meet 0.0 instead of a neighbouring line's value: its product is an exact zero either way.
+//   a.x = r_k ; a.y = r_{k+2} ; a.x2 = x (in / out) ; a.pdinv[0] = d ; a.x_zero: x is zero on entry
+// whole != 0 (L <= 127): one wave holds a whole grid line, lane l rows 2 l, 2 l + 1 in both sweeps.  Otherwise a segment of xlen <= 124
+// rows: sweep k on the segment and one node either side (lane l rows x0 - 1 + 2 l, x0 + 2 l; lane 63 only supplies windows), sweep k + 1
+// on rows x0 + 2 l, x0 + 2 l + 1.  The ring stores position p of a line at p - (first row of sweep k + 1) + 1.
+// ---------------------------------------------------------------------------
+// BC ("box, constant"): on a constant-coefficient operator every row of a grid line stores the SAME 27 numbers -- those of the line's
+// class (first / inner / last line of a plane) x (first / inner / last plane) -- except that the first / last row of the line does not
+// store the taps that would leave the line.  With exact zeros at those positions (the ring's pads in phase 2, a select on the window
+// values in phase 1) one set of coefficients serves the whole wave, and it comes out of the KERNEL ARGUMENTS through scalar loads
+// instead of 27 LDS reads per row: the sweeps of a row-pattern level are bound by LDS bandwidth (54 x 8 B per lane and step against
+// ~150 vector instructions), not by memory.  gmg_solver::z2_geo verifies the property row by row on the device (z2_box_check_kernel)
+// before it sets `box`; the sums are those of the general form except for the sign of an exact zero product.
+struct Z2Geo {
+  int P, L, ny, nz;       // rows per plane, per line ; lines per plane ; planes
+  int W, T;               // waves per workgroup (lines incl. the two rim lines) ; planes per block
+  int nyt, nzb, nxs;      // tiles in y, blocks in z, segments in x
+  int xlen, whole;
+  int box;                // 1: coef / cmask below describe every row (BC kernels)
+  double coef[9][27];     // class c = 3 * (plane class) + (line class), class 0 first / 1 inner / 2 last ; entry j = 3 * run + tap
+  uint32_t cmask[9][27];  // 0xffffffff stored, 0 absent
+};
+constexpr int kZ2Slot = 130;     // doubles per line slot of the ring (128 rows + one either side)
+
+// bad[0] != 0 afterwards: some row's pattern is not the class pattern with the taps that leave the line removed
+__global__ void z2_box_check_kernel(int64_t nrows, int L, int ny, int nz, int P, const uint16_t *__restrict__ rowpid, const PatEntry *__restrict__ tab,
+                                    const double *__restrict__ coef, const uint32_t *__restrict__ cmask, int *__restrict__ bad)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % L), y = (int)((i / L) % ny), z = (int)(i / P);
+    const int c = 3 * (z == 0 ? 0 : z == nz - 1 ? 2 : 1) + (y == 0 ? 0 : y == ny - 1 ? 2 : 1);
+    const PatEntry *te = tab + (size_t)rowpid[i] * 27;
+    bool ok = true;
+    for (int j = 0; j < 27; ++j) {
+      const int dx = j % 3 - 1;
+      const bool inside = x + dx >= 0 && x + dx < L;
+      const unsigned long long want = inside ? (unsigned long long)__double_as_longlong(coef[c * 27 + j]) : 0ull;   // absent entries hold +0.0
+      const uint32_t wm = inside ? cmask[c * 27 + j] : 0u;
+      ok = ok && (unsigned long long)__double_as_longlong(te[j].v) == want && te[j].m == wm;
+    }
+    if (!ok) atomicOr(bad, 1);
+  }
+}
+
+template <bool MK, bool FM, bool BC = false>
+__global__ __launch_bounds__(1024) void sells_z2sweep_kernel(SellSArgs a, Z2Geo g)
+{
+  constexpr int K = 3, NR = 9, nu = K * NR, NUP = 28, SL = kZ2Slot;
+  extern __shared__ double sp_smem[];
+  const int tot = BC ? 0 : a.np * NUP;
+  double *s_tab8 = sp_smem;                                   // [np*NUP] coefficients (absent entries 0.0); the masks stay in global memory
+  double *ring = sp_smem + ((tot + 1) & ~1);                  // [4][W][SL] r_{k+1}
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int W = g.W;
+  const int blk = remap_block(blockIdx.x, gridDim.x, a.xcd_remap);
+  const int xs = blk % g.nxs, t2 = blk / g.nxs, yt = t2 % g.nyt, zb = t2 / g.nyt;
+  const int y = yt * (W - 2) - 1 + wave;
+  const bool vline = y >= 0 && y < g.ny;
+  const bool inner = wave >= 1 && wave <= W - 2 && vline;
+  const int x0 = g.whole ? 0 : xs * g.xlen;
+  const int len = g.whole ? g.L : min(g.xlen, g.L - x0);      // rows of sweep k + 1 in this segment
+  const int ka = g.whole ? 0 : x0 - 1;                        // x of lane 0's first row in sweep k
+  const int klo = g.whole ? 0 : max(0, x0 - 1), khi = g.whole ? g.L : min(g.L, x0 + len + 1);
+  const int xk = ka + 2 * lane;
+  const bool kvA = xk >= klo && xk < khi, kvB = xk + 1 >= klo && xk + 1 < khi;
+  const int xb = x0 + 2 * lane;
+  const bool nvA = xb < x0 + len, nvB = xb + 1 < x0 + len;
+  const int sidx = g.whole ? 2 * lane + 1 : 2 * lane;         // where the lane's two rows of sweep k sit in a line slot
+  const double *__restrict__ rg = a.x;
+  const double omega = a.omega, du = a.pdinv[0];
+  const int last = (int)a.ncols - 1, lastrow = (int)a.nrows - 1;
+  const bool xz = a.x_zero != 0;
+  int roff[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  auto conv = [&](gmg_d2 v) -> gmg_d2 { return gmg_d2{omega * (du * v.x), omega * (du * v.y)}; };   // s = omega * (Dinv * r)
+  // the 27 taps of the lane's two rows from nine converted windows: w0, w1 its own pair, w2, w3 = lane l + 1's (lane 63: 0.0)
+  // (BC: cls = the class of the wave's line and the step's plane, wave-uniform -- the coefficients are scalar loads from the arguments)
+  auto taps = [&](const gmg_d2 *C, const double *tvA, const double *tvB, int cls, double &sA, double &sB) {
+    sA = 0.0; sB = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const double w0 = C[q].x, w1 = C[q].y;
+      const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+      const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        const double ca = BC ? g.coef[cls][q * K + t] : tvA[q * K + t], cb = BC ? ca : tvB[q * K + t];
+        sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
+        sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+      }
+    }
+  };
+  // strict form: a sum that is not finite is redone with the masks (a vector that already holds Inf / NaN: rare).  The windows are
+  // fetched again, run by run (getw(q): from memory in phase 1, from the ring in phase 2) -- indexing the register array of the fast
+  // path with a loop counter would move it into scratch memory for the whole kernel
+  auto taps_masked = [&](auto getw, int pidA, int pidB, int cls, double &sA, double &sB) {
+    sA = 0.0; sB = 0.0;
+    const double *tvA = s_tab8 + pidA * NUP, *tvB = s_tab8 + pidB * NUP;
+#pragma unroll 1
+    for (int q = 0; q < NR; ++q) {
+      const gmg_d2 c = conv(getw(q));
+      const double w0 = c.x, w1 = c.y;
+      const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+      const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        const int j = q * K + t;
+        const int ma = BC ? (int)g.cmask[cls][j] : (int)a.tab[pidA * nu + j].m, mb = BC ? ma : (int)a.tab[pidB * nu + j].m;
+        const double ca = BC ? g.coef[cls][j] : tvA[j], cb = BC ? ca : tvB[j];
+        const double ga = __hiloint2double(__double2hiint(wa[t]) & ma, __double2loint(wa[t]));
+        const double gb = __hiloint2double(__double2hiint(wb[t]) & mb, __double2loint(wb[t]));
+        sA = FM ? __builtin_fma(ca, ga, sA) : sA + ca * ga;
+        sB = FM ? __builtin_fma(cb, gb, sB) : sB + cb * gb;
+      }
+    }
+  };
+  // BC, phase 1: window positions that leave the grid line read as exact zeros (lane l holds positions ka - 1 + 2 l and ka + 2 l)
+  const bool zx0 = BC && (ka - 1 + 2 * lane < 0 || ka - 1 + 2 * lane >= g.L), zx1 = BC && (ka + 2 * lane < 0 || ka + 2 * lane >= g.L);
+  const bool zx_any = BC && __any(zx0 || zx1);
+  const int cy = y <= 0 ? 0 : (y >= g.ny - 1 ? 2 : 1);
+  if (!BC)
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+      const int pq = i / NUP, j = i - pq * NUP;
+      s_tab8[i] = j < nu ? (a.tab8 ? a.tab8[pq * nu + j] : a.tab[pq * nu + j].v) : 0.0;
+    }
+  for (int i = threadIdx.x; i < 4 * W * SL; i += blockDim.x) ring[i] = 0.0;
+  __syncthreads();
+  const int zb0 = zb * g.T, zb1 = min(g.nz, zb0 + g.T);
+  typedef double d2a __attribute__((ext_vector_type(2), aligned(16)));
+  // Requests run ahead of the arithmetic (as in sells_zsweep_kernel): the nine windows of sweep k live in registers, converted, and walk
+  // up the planes with the wave -- a step fetches only the three windows of the plane above, and it asks for them, for the rows' own
+  // r_k and for the operands of phase 2 (x, r_k of plane z - 1) BEFORE the arithmetic of the step, so that a workgroup whose waves
+  // all sit in the same phase (one barrier per step) still has its memory requests in flight behind ~300 vector instructions.
+  // Every address is clamped into the vectors: one control path, the same number of requests in the first and last planes.
+  auto loadw = [&](int plane, int q) -> gmg_d2 {                // window q of the lane's rows taken at `plane` (any integer: clamped)
+    const int c = plane * g.P + y * g.L + ka + roff[q] + 2 * lane;
+    const gmg_d2 v = gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
+    return zx_any ? gmg_d2{zx0 ? 0.0 : v.x, zx1 ? 0.0 : v.y} : v;
+  };
+  struct Own { gmg_d2 e0; int pidA, pidB; };
+  auto load_own = [&](int plane) -> Own {                       // sweep k: the rows' own r_k (and pattern ids)
+    Own o;
+    const int row = plane * g.P + y * g.L + ka + 2 * lane;
+    const int ra = min(max(row, 0), lastrow), rb = min(max(row + 1, 0), lastrow);
+    o.e0 = gmg_d2{rg[ra], rg[rb]};
+    o.pidA = BC ? 0 : (int)a.rowpid[ra]; o.pidB = BC ? 0 : (int)a.rowpid[rb];
+    return o;
+  };
+  struct Ops2 { gmg_d2 rp, e2; int pidA, pidB; };
+  auto load_ops2 = [&](int plane) -> Ops2 {                     // sweep k + 1: r_k and x of the rows, pattern ids
+    Ops2 o;
+    const int row = plane * g.P + y * g.L + x0 + 2 * lane;
+    const int ra = min(max(row, 0), lastrow), rb = min(max(row + 1, 0), lastrow);
+    o.rp = gmg_d2{rg[ra], rg[rb]};
+    o.e2 = gmg_d2{a.x2[ra], a.x2[rb]};
+    o.pidA = BC ? 0 : (int)a.rowpid[ra]; o.pidB = BC ? 0 : (int)a.rowpid[rb];
+    return o;
+  };
+  gmg_d2 C[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) C[q] = conv(loadw(zb0 - 1, q));
+  Own cur = load_own(zb0 - 1);
+#pragma unroll 1
+  for (int z = zb0 - 1; z <= zb1; ++z) {
+    // requests of this step: the three windows of plane z + 2 (run 6..8 of step z + 1), the rows' own r_k of plane z + 1, phase 2's operands
+    gmg_d2 N[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) N[q] = loadw(z + 1, 6 + q);
+    const Own nxt = load_own(z + 1);
+    const int zz = z - 1;
+    const Ops2 o2 = load_ops2(zz);
+    // ---- phase 1: sweep k, plane z, this wave's line -> ring slot z & 3
+    gmg_d2 rk1 = gmg_d2{0.0, 0.0};
+    if (vline && z >= 0 && z < g.nz) {                        // (wave-uniform)
+      const int cls1 = 3 * (z == 0 ? 0 : (z == g.nz - 1 ? 2 : 1)) + cy;
+      double sA, sB;
+      taps(C, s_tab8 + cur.pidA * NUP, s_tab8 + cur.pidB * NUP, cls1, sA, sB);
+      if (MK && !__all(__builtin_isfinite(sA) && __builtin_isfinite(sB)))
+        taps_masked([&](int q) -> gmg_d2 { const int c = z * g.P + y * g.L + ka + a.run_off[q] + 2 * lane;
+                                           const gmg_d2 v = gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
+                                           return gmg_d2{zx0 ? 0.0 : v.x, zx1 ? 0.0 : v.y}; },
+                    cur.pidA, cur.pidB, cls1, sA, sB);
+      rk1 = gmg_d2{kvA ? cur.e0.x - sA : 0.0, kvB ? cur.e0.y - sB : 0.0};
+    }
+    {
+      double *slot = ring + ((z & 3) * W + wave) * SL;
+      slot[sidx] = rk1.x; slot[sidx + 1] = rk1.y;
+    }
+    __syncthreads();
+    // ---- phase 2: sweep k + 1, plane z - 1, inner lines, from the ring
+    if (inner && zz >= zb0 && zz < zb1) {                     // (wave-uniform)
+      const int cls2 = 3 * (zz == 0 ? 0 : (zz == g.nz - 1 ? 2 : 1)) + cy;
+      const double *tvA = s_tab8 + o2.pidA * NUP, *tvB = s_tab8 + o2.pidB * NUP;
+      double sA = 0.0, sB = 0.0;
+      gmg_d2 raw4 = gmg_d2{0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int dz = q / 3 - 1, dy = q % 3 - 1;
+        const double *sl = ring + (((zz + dz) & 3) * W + wave + dy) * SL;
+        const gmg_d2 v = *reinterpret_cast<const d2a *>(sl + 2 * lane);
+        if (q == 4) raw4 = v;
+        const gmg_d2 c = conv(v);
+        const double w0 = c.x, w1 = c.y;
+        const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+        const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const double ca = BC ? g.coef[cls2][q * K + t] : tvA[q * K + t], cb = BC ? ca : tvB[q * K + t];
+          sA = FM ? __builtin_fma(ca, wa[t], sA) : sA + ca * wa[t];
+          sB = FM ? __builtin_fma(cb, wb[t], sB) : sB + cb * wb[t];
+        }
+      }
+      if (MK && !__all(__builtin_isfinite(sA) && __builtin_isfinite(sB)))
+        taps_masked([&](int q) -> gmg_d2 { const double *sl = ring + (((zz + q / 3 - 1) & 3) * W + wave + q % 3 - 1) * SL;
+                                           return *reinterpret_cast<const d2a *>(sl + 2 * lane); }, o2.pidA, o2.pidB, cls2, sA, sB);
+      const gmg_d2 e0 = gmg_d2{raw4.y, wave_shl1(raw4.x)};     // the rows' own r_{k+1}: positions x, x + 1 of the centre window
+      const gmg_d2 e2 = xz ? gmg_d2{0.0, 0.0} : o2.e2;
+      const gmg_d2 rn = gmg_d2{e0.x - sA, e0.y - sB};
+      const gmg_d2 sk = gmg_d2{omega * (du * e0.x), omega * (du * e0.y)};
+      const gmg_d2 xn = gmg_d2{(e2.x + omega * (du * o2.rp.x)) + sk.x, (e2.y + omega * (du * o2.rp.y)) + sk.y};
+      const int row = zz * g.P + y * g.L + x0 + 2 * lane;
+      if (nvA) { a.x2[row] = xn.x; a.y[row] = rn.x; }
+      if (nvB) { a.x2[row + 1] = xn.y; a.y[row + 1] = rn.y; }
+    }
+    // the walk: plane z's windows 3..8 are plane z + 1's windows 0..5
+#pragma unroll
+    for (int q = 0; q < 6; ++q) C[q] = C[q + 3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) C[6 + q] = conv(N[q]);
+    cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Wide rows (Q2: 25 runs of 5 consecutive offsets, 125 entries per row) in the z-walk form (round 5).  The runs are a 5 x 5 grid,
 // run q = 5 (dz + 2) + (dy + 2) at dz P + dy L - 2, so 20 of the 25 windows of the slice at r0 + P are windows of the slice at r0:
 // a wave keeps an interval of <= 60 rows of a grid plane, walks T planes upwards and gathers FIVE new windows per step instead of
@@ -3029,176 +3281,6 @@ __global__ __launch_bounds__(1024) void sells_smooth_kernel(SellSmoothArgs a)
   // a wait timed out somewhere (as far as this workgroup can see): the pass is void -- leave x and r as they were, the host
   // re-runs the solve sweep by sweep (with_persist_retry)
   if (a.err_dev && __hip_atomic_load(a.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    if (own[i]) { a.x[row[i]] = xr[i]; a.r_out[row[i]] = r[i]; }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// The one-launch pass with DATA-TAGGED hand-offs (round 5).  sells_smooth_kernel pays per sweep: the neighbours' progress words polled
-// by one lane per neighbour, a workgroup barrier, the gathers, the store drain (s_waitcnt vmcnt(0)), another barrier, the flag store --
-// a flag hand-off, 1.7-1.9 x the price of a data-tagged one (MI355X_MICROARCH.md, price list: handoff-flag vs handoff-1to1), 3.1 us
-// per sweep on 31^3 rows for 0.3 us of work.  Here the VALUE is the flag: s moves through three buffers T[0..2] that hold a sentinel
-// (a signalling NaN -- no arithmetic result is one, and s = omega (d r) is always an arithmetic result) wherever the value of the
-// coming sweep has not been written yet; a lane gathers with agent-scope loads and simply repeats a load that returned the sentinel.
-// No progress words, no barrier, no store drain in front of a publish: every wave runs on as soon as ITS windows are there.
-//   sweep k reads   k = 0: a.s_a (s_0, written by the previous kernel)      k >= 1: T[(off + k) % 3]
-//   sweep k         resets its own rows of T[(off + k + 2) % 3] to the sentinel (after its gathers: every reader of those rows --
-//                   the waves it has just gathered from: the run offsets are symmetric, checked by the launcher -- finished the
-//                   sweep that read them before publishing what this wave has just seen), drains THOSE stores behind the taps,
-//   then publishes  s_{k+1} into T[(off + k + 1) % 3] (reset two sweeps ago, or sentinel since the previous pass).
-// After a pass of n sweeps T[(off + n) % 3] and T[(off + n + 1) % 3] are all sentinel and the third holds stale values: the next pass
-// starts with off' = off + n - 1, so that its first publish goes to a sentinel buffer and the stale one is reset in its sweep 1
-// before anybody polls it (gmg_solver keeps off per level; a timed-out pass leaves the handle on per-sweep launches for good).
-// Same arithmetic, operand order and roundings as sells_smooth_kernel / sells_sweep_kernel: bit-identical.
-// ---------------------------------------------------------------------------
-constexpr unsigned long long kSmoothSentinel = 0x7FF4A5C3D2E1F00Full;   // signalling NaN (quiet bit clear, payload non-zero)
-__device__ __forceinline__ bool is_sentinel(double v) { return (unsigned long long)__double_as_longlong(v) == kSmoothSentinel; }
-__global__ void fill_sentinel_kernel(int64_t n, double *p)
-{
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    reinterpret_cast<unsigned long long *>(p)[i] = kSmoothSentinel;
-}
-
-struct SellSmoothTagArgs {
-  SellSmoothArgs b;         // flags / epoch / halo_wg / fenced unused
-  double *t[3];             // tagged s buffers
-  int off;                  // rotation offset of this pass
-};
-
-template <int NS, bool TD, bool MK>
-__global__ __launch_bounds__(1024) void sells_smooth_tag_kernel(SellSmoothTagArgs ta)
-{
-  const SellSmoothArgs &a = ta.b;
-  constexpr int K = 3, ROWS = 65 - K, NR = 9;
-  extern __shared__ double sp_smem[];
-  constexpr int nu = K * NR;
-  const int tot = a.np * nu;
-  double *s_tab8 = sp_smem;
-  uint32_t *s_msk = reinterpret_cast<uint32_t *>(sp_smem + tot);
-  double *s_dinv = sp_smem + (MK ? 2 : 1) * (size_t)tot;
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
-  const int w = blockIdx.x;
-  const int last = (int)a.ncols - 1;
-  const int lastrow = (int)a.nrows - 1;
-  const double omega = a.omega;
-  int pid[NS], row[NS];
-  bool own[NS];
-  bool need[NS];                                            // the lane's window values are used by some existing row of the slice (see the gathers)
-  double r[NS], xr[NS], so[NS], dv[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const int slice = w * (wpb * NS) + i * wpb + wave;
-    row[i] = min(slice, a.nslices - 1) * ROWS + lane;       // slices past the end recompute the last one, store nothing
-    own[i] = slice < a.nslices && lane < ROWS && row[i] <= lastrow;
-    need[i] = slice < a.nslices && lane <= min(ROWS - 1, lastrow - slice * ROWS) + (K - 1);   // (a slice past the end owns nothing and nobody gathers from it: it must not wait)
-    const int rc = min(row[i], lastrow);
-    pid[i] = (int)a.rowpid[rc];
-    r[i] = a.r_in[rc];
-    { const double xl = a.x[rc]; xr[i] = a.x_zero ? 0.0 : xl; }
-    so[i] = a.s_a[rc];
-    dv[i] = TD ? 0.0 : a.dinv[rc];
-  }
-  if (MK) { for (int i = threadIdx.x; i < tot; i += blockDim.x) { const PatEntry en = a.tab[i]; s_tab8[i] = en.v; s_msk[i] = en.m; } }
-  else { for (int i = threadIdx.x; i < tot; i += blockDim.x) s_tab8[i] = a.tab8[i]; }
-  if (TD)
-    for (int i = threadIdx.x; i < a.np; i += blockDim.x) s_dinv[i] = a.pdinv[i];
-  __syncthreads();
-  if (TD) {
-#pragma unroll
-    for (int i = 0; i < NS; ++i) dv[i] = s_dinv[pid[i]];
-  }
-  int roff[NR];
-#pragma unroll
-  for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
-  bool dead = false;                                         // a wait timed out: the pass is void (see the end)
-  for (int k = 0; k < a.niter; ++k) {
-    const double *sin = k == 0 ? a.s_a : ta.t[(ta.off + k) % 3];
-    double *sout = ta.t[(ta.off + k + 1) % 3];
-    double *srst = ta.t[(ta.off + k + 2) % 3];
-    const bool publish = k + 1 < a.niter;                    // the s of the last sweep has no reader
-    double acc[NS];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      // the nine windows of the slice: a load that returns the sentinel is repeated (bounded)
-      double A[NR];
-      unsigned spins = 0;
-      for (;;) {
-        bool wait = false;
-#pragma unroll
-        for (int q = 0; q < NR; ++q) {
-          // Only positions some existing row of the slice has a tap on are waited for: positions outside the vector (the other kernels
-          // read a clamped element there) and the lanes past the last row of a ragged slice take 0.0 -- their coefficients are absent,
-          // the products exact zeros either way.  A wave that polled such a position would read rows of a wave that does NOT gather
-          // from it, which may reset them under it: with this rule "w' reads rows of w" <=> "w gathers from w'" (symmetric run offsets)
-          const int c = row[i] + roff[q];
-          const double v = ld_agent(sin + min(max(c, 0), last));
-          A[q] = (need[i] && c >= 0 && c <= last) ? v : 0.0;
-          wait = wait || is_sentinel(A[q]);
-        }
-        if (k == 0 || !wait || dead) break;
-        if (++spins > (1u << 17)) {
-          __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (a.err_dev) __hip_atomic_store(a.err_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          dead = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (i == NS - 1) {
-        // ALL gathers of the wave are in: the readers of this wave's rows in srst are done with it (they published what was gathered
-        // above after reading it) -- reset, the stores drain behind the taps of the last slice
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-          if (own[j]) __hip_atomic_store(reinterpret_cast<unsigned long long *>(srst + row[j]), kSmoothSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const uint32_t *tm = s_msk + pid[i] * nu;
-      const double *tv = s_tab8 + pid[i] * nu;
-      double s = 0.0;
-#pragma unroll
-      for (int q = 0; q < NR; ++q) {
-        double c = A[q];
-#pragma unroll
-        for (int t = 0; t < K; ++t) {
-          if (t > 0) c = wave_shl1(c);
-          s = s + tv[q * K + t] * c;
-        }
-      }
-      if (MK && !__all(__builtin_isfinite(s))) {             // rare: a vector that already holds Inf / NaN -- redo the slice with the masks
-        s = 0.0;
-#pragma unroll 1
-        for (int q = 0; q < NR; ++q) {
-          const int cc = row[i] + roff[q];
-          double c = ld_agent(sin + min(max(cc, 0), last));
-          if (!(need[i] && cc >= 0 && cc <= last)) c = 0.0;
-#pragma unroll
-          for (int t = 0; t < K; ++t) {
-            if (t > 0) c = wave_shl1(c);
-            const int j = q * K + t;
-            const double g = __hiloint2double(__double2hiint(c) & (int)tm[j], __double2loint(c));
-            s = s + tv[j] * g;
-          }
-        }
-      }
-      acc[i] = s;
-    }
-    // the resets have left the CU (agent-scope stores, write-through) before anything of sweep k + 1 is published: a neighbour that
-    // sees s_{k+1} of this wave and runs on to poll srst two sweeps later finds the sentinel or the new value there, never the old one
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      xr[i] = xr[i] + so[i];                                 // x += s_k
-      const double rn = r[i] - acc[i];                       // r -= A s_k
-      r[i] = rn;
-      so[i] = omega * (dv[i] * rn);                          // s_{k+1} = omega * Dinv r
-      if (publish && own[i]) st_agent(sout + row[i], so[i]);
-    }
-  }
-  // a wait timed out somewhere (as far as this workgroup can see): the pass is void -- leave x and r as they were, the host
-  // re-runs the solve sweep by sweep (with_persist_retry)
-  if (dead || (a.err_dev && __hip_atomic_load(a.err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) return;
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     if (own[i]) { a.x[row[i]] = xr[i]; a.r_out[row[i]] = r[i]; }

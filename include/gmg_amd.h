@@ -228,11 +228,14 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  *                    pat_zwalk (1: levels of >= pat_zwalk_rows (9000000: where the vectors of a sweep outgrow the 256 MB Infinity Cache) rows sweep as a walk up the grid planes -- an interval of a plane
  *                    per wave, three new windows per step, pat_zwalk_t (12) planes per chain; 2: every level; 0: off) pat_zwalk_mv (1: their
  *                    mat-vecs too) pat_zwalk_wide (1: the wide-row (Q2) operator applications of levels of >= pat_zwalk_wide_rows (1000000) rows in the same form, 25 windows in registers)
+ *                    pat_fuse2 (0: opt-in.  1: on grid levels of >= pat_fuse2_rows (1000000) rows of one GPU a smoothing pass runs TWO sweeps per launch -- r_k in,
+ *                    r_{k+2} out, r_{k+1} in LDS only, sells_z2sweep_kernel; 2: every level that qualifies.  Bit-identical to the single sweeps; measured slower
+ *                    than them on MI355X, see profiles/r06_ab_fuse2.txt) pat_fuse2_w / pat_fuse2_t (0 = chosen from the size: grid lines per workgroup, planes
+ *                    per block) pat_fuse2_box (1: constant-coefficient boxes read one coefficient set per wave from the kernel arguments)
  *   reductions       red_fused (1: inside CG the second stage of every dot is done by the kernel that consumes the scalar and the
  *                    norm is reduced + posted to the host by one launch; 0: one reduce launch per dot.  Same bits either way)
  *   one-launch pass  persist (1) persist_fenced (0) persist_max_slices (0 = one workgroup per CU) persist_shared (0)
  *                    persist_wpb (1: smallest workgroup, in waves)
- *                    persist_tag (0: opt-in -- data-tagged hand-offs instead of progress words on levels of <= persist_tag_max_slices (1024) slices)
  *   coarsest level   coarse_host_max (1500) coarse_host_fallback_max (6000) coarse_auto_cg_min (20000: a dense-inverse request on a
  *                    coarsest level of at least this many dofs is served by the device CG-Jacobi solver instead) gj_mfma (1) gj_wide_min (4096)
  *   patch smoother   patch_dedup (1) patch_source_dedup (1) patch_operator (1)

@@ -45,9 +45,21 @@ BIG_FORMS = {"occ2": ({"pat_tile_rows": 0, "pat_zwalk": 0, "persist": 0}, ("sell
              "zwalk_T1": ({"pat_zwalk": 2, "pat_zwalk_T": 1, "persist": 0}, ("sells_zsweep_kernel", "T=1"))}
 
 
-@pytest.mark.parametrize("form", list(BIG_FORMS))
-@pytest.mark.parametrize("nc,nlev,niter", BIG_LEVEL_CASES)
-def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(S, po, orc, nc, nlev, niter, form):
+# round 6: two sweeps per launch (sells_z2sweep_kernel; default on grid levels of >= pat_fuse2_rows = 1e6 rows of one GPU), forced onto the
+# small levels: tile shapes from the default to the smallest legal one (three lines per workgroup, one plane per block: every row of
+# sweep k is somebody's rim), and two levels whose grid lines are longer than a wave holds (135 and 259 nodes: two / three x segments
+# with one node of sweep k either side).  fuse2 = the form a constant-coefficient box operator gets (BC: one set of coefficients per wave from the
+# kernel arguments, verified row by row at setup), fuse2_general = per-row patterns from LDS (what any other grid operator gets)
+BIG_FORMS.update({"fuse2": ({"pat_fuse2": 2, "persist": 0}, ("sells_z2sweep_kernel", "BC=1")),
+                  "fuse2_general": ({"pat_fuse2": 2, "pat_fuse2_box": 0, "persist": 0}, ("sells_z2sweep_kernel", "BC=0")),
+                  "fuse2_W16_T3": ({"pat_fuse2": 2, "pat_fuse2_w": 16, "pat_fuse2_t": 3, "persist": 0}, ("sells_z2sweep_kernel", "T=3")),
+                  "fuse2_W3_T1": ({"pat_fuse2": 2, "pat_fuse2_w": 3, "pat_fuse2_t": 1, "persist": 0}, ("sells_z2sweep_kernel", "W=3", "T=1"))})
+LONG_LINE_CASES = [((136, 8, 8), 2, 4), ((260, 8, 16), 2, 10)]
+SWEEP_CASES = [(c, f) for f in BIG_FORMS for c in BIG_LEVEL_CASES] + [(c, f) for f in ("fuse2", "fuse2_general", "fuse2_W3_T1") for c in LONG_LINE_CASES]
+
+
+@pytest.mark.parametrize("case,form", SWEEP_CASES, ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v[0])) + f"-{v[1]}-{v[2]}")
+def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(S, po, orc, case, form):
     """sells_r2sweep_kernel<XM, MK, FM, 9, OCC=2> -- the form every Q1 level of >= pat_tile_rows (3.5e6) rows takes: 288^3, 256^3,
     the finest level of BASELINE configs[3] -- forced onto small levels with pat_tile_rows = 0 and compared (i) bit for bit with
     sells_rsweep_kernel (pat_r2 = 0, one row per lane, masks in LDS) and (ii) with the oracle's literal
@@ -57,8 +69,13 @@ def test_big_level_sweep_is_bitwise_the_single_row_sweep_and_matches_the_oracle(
     form = zwalk*: the same for sells_zsweep_kernel (round 5: the pair sweep as a walk along the slowest grid direction -- an interval
     of <= 126 rows of a grid plane per wave, three new windows per step, six carried in registers; default on levels of >=
     pat_zwalk_rows = 9e6 rows), forced onto the small levels with pat_zwalk = 2, with chains of 12, 3 and 1 planes (chain starts
-    and ends in the middle of the level, planes whose row count is not a multiple of the interval, the clamped first / last planes)."""
+    and ends in the middle of the level, planes whose row count is not a multiple of the interval, the clamped first / last planes).
+    form = fuse2*: sells_z2sweep_kernel (round 6), sweeps k and k + 1 of a pass in one launch with r_{k+1} in LDS only: the same bits as
+    the single sweeps for every tile shape, from x given / x = 0, odd sweep counts (the last sweep runs alone), Inf / NaN in r."""
+    (nc, nlev, niter) = case
     big_opts, big_sig = BIG_FORMS[form]
+    if form.startswith("fuse2") and niter % 2:
+        big_sig = ()                                      # (odd pass: the last sweep -- and with it the signature -- is a single one)
     H = po.build_hierarchy(nc, nlev, 1)
     n = H["mats"][0].shape[0]
     b = po.dirichlet_lift_rhs(nc, 1)
@@ -445,48 +462,3 @@ def test_wide_row_zwalk_is_bitwise_the_wide_row_kernel_and_the_oracle(S, po, orc
     assert sols["zwalk"][1] == nit
     np.testing.assert_allclose(sols["zwalk"][2], hist, rtol=1e-7)
     assert rel_err(sols["zwalk"][0], xo) <= 1e-9
-
-
-# ---------------------------------------------------------------- one-launch passes with data-tagged hand-offs
-@pytest.mark.parametrize("nc,nlev,niter", [((64, 64, 64), 4, 10), ((32, 32, 32), 3, 10), ((40, 36, 28), 3, 7), ((64, 64, 64), 4, 5)])
-def test_data_tagged_one_launch_pass_is_bitwise_the_flag_pass_and_the_sweep_loop(S, po, orc, nc, nlev, niter):
-    """sells_smooth_tag_kernel (round 5; option persist_tag = 1, levels of <= persist_tag_max_slices = 1024 slices): the s of a sweep moves through
-    three buffers that hold a signalling-NaN sentinel wherever the coming sweep's value is not written yet; a lane repeats a load that
-    returned the sentinel -- no progress words, no barriers.  Against sells_smooth_kernel (persist_tag = 0: progress words) and the
-    per-sweep launches (persist = 0) on every level >= 1: chained passes (the buffer rotation carries over from pass to pass), odd and
-    even sweep counts, levels with a ragged last slice and with MORE waves than slices (the waves past the end must not wait: nobody
-    gathers from them -- the deadlock of the first version); bit-identical, and the passes match the oracle's
-    RichardsonSmoothers.jl:84-98 loop.  (Opt-in: forced onto a level of 4 034 slices on 253 workgroups the tagged pass timed out
-    intermittently -- the handle then falls back to per-sweep launches, results stay correct -- so the progress-word pass stays the default.)"""
-    H = po.build_hierarchy(nc, nlev, 1)
-    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=[orc.Smoother(orc.JACOBI, niter, 2.0 / 3.0)] * (nlev - 1), maxiter=1)
-    res = {}
-    for key, opts in (("tag", {"persist_tag": 1}), ("flag", {"persist_tag": 0}), ("sweeps", {"persist": 0})):
-        gmg = make_gmg(S, H, pre_smoothers=jac(S, nlev, niter), options=opts)
-        ns = setup(S, gmg, H["mats"][0])
-        out = []
-        for lev in range(1, nlev - 1):
-            n = H["mats"][lev].shape[0]
-            x, r = np.random.default_rng(10 + lev).uniform(-1, 1, n), np.random.default_rng(20 + lev).uniform(-1, 1, n)
-            for rep in range(4):                                        # chained: pass k + 1 starts from the buffers pass k left
-                ns.smooth(lev, x, r)
-                out += [x.copy(), r.copy()]
-            xz, rz = np.zeros(n), np.random.default_rng(30 + lev).uniform(-1, 1, n)
-            rz[n // 2] = np.inf
-            ns.smooth(lev, xz, rz)
-            out += [np.isfinite(xz), np.where(np.isfinite(xz), xz, 0.0), np.isfinite(rz), np.where(np.isfinite(rz), rz, 0.0)]
-        b = np.random.default_rng(5).uniform(-1, 1, H["mats"][0].shape[0])
-        z = np.zeros_like(b)
-        for _ in range(3):
-            S.solve_(z, ns, b)                                          # whole V-cycles (pre and post passes on every level)
-        out.append(z.copy())
-        if key != "tag":
-            assert ns.persist_retries() == dict(retries=0, persist_active=(key != "sweeps")), (key, ns.persist_retries())
-        res[key] = out
-        ns.close()
-    for key in ("flag", "sweeps"):
-        for a, c in zip(res["tag"], res[key]):
-            np.testing.assert_array_equal(a, c)
-    n1 = H["mats"][1].shape[0]
-    xo, ro = go.smooth(1, np.random.default_rng(11).uniform(-1, 1, n1), np.random.default_rng(21).uniform(-1, 1, n1))
-    assert max_rel(res["tag"][0], xo) <= TOL_KERNEL and max_rel(res["tag"][1], ro) <= TOL_KERNEL
