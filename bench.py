@@ -93,8 +93,11 @@ def parse():
     ap.add_argument("--config3-cells", type=int, default=256, help="cells per direction of the config-3 leg (BASELINE configs[2]: 256; 5 levels)")
     ap.add_argument("--config3-levels", type=int, default=5)
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 leg (Stokes Q2/P1disc, block-triangular FGMRES)")
-    ap.add_argument("--config5-cells", type=int, default=512, help="cells per direction of the 2-D Stokes leg (2 (2n-1)^2 velocity dofs)")
-    ap.add_argument("--config5-levels", type=int, default=6)
+    ap.add_argument("--config5-cells", type=int, default=1024, help="cells per direction of the 2-D Stokes leg (2 (2n-1)^2 velocity dofs; 1024: 8.4e6 -- one "
+                                                                     "vector of the finest velocity level is 67 MB, a sweep's operands outgrow the 256 MB Infinity Cache)")
+    ap.add_argument("--config5-levels", type=int, default=7)
+    ap.add_argument("--config5-cpu-cells", type=int, default=256, help="size of the config-5 oracle check / CPU baseline (the oracle's patch solves are sequential)")
+    ap.add_argument("--config5-cpu-levels", type=int, default=5)
     ap.add_argument("--loopback-cells", type=int, default=48, help="cells per direction per (virtual) rank of the rccl_loopback leg")
     ap.add_argument("--loopback-levels", type=int, default=4)
     ap.add_argument("--allow-degraded", action="store_true",
@@ -1019,10 +1022,12 @@ def config5_leg(torch, pkg, args, want_cpu):
     st = importlib.import_module(pkg.__name__ + ".stokes")
     alpha = 1.0e3
 
-    def make(n, nlev):
+    def make(n, nlev, with_K=False):
         t0 = time.perf_counter()
-        sysd = st.stokes_system(n, alpha)
-        Hv = st.velocity_hierarchy(n, nlev, alpha)
+        # (inputs by stencil replication, stokes.stokes_system_fast: bitwise the scipy assembly, seconds instead of minutes)
+        fast = n >= 8 and not (n & (n - 1))
+        sysd = st.stokes_system_fast(n, alpha, with_K=with_K) if fast else st.stokes_system(n, alpha)
+        Hv = st.velocity_hierarchy_fast(n, nlev, alpha) if fast else st.velocity_hierarchy(n, nlev, alpha)
         t_asm = time.perf_counter() - t0
         sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 10, 0.2) for pp, pd in Hv["star_patches"]]
         interp = [S.PatchProlongationOperator(Hv["prolongations"][l], *Hv["interior_patches"][l], pivoting=True, rhs=Hv["graddiv"][l])
@@ -1061,19 +1066,34 @@ def config5_leg(torch, pkg, args, want_cpu):
     kst = gv.kernel_stats()
     gv.profile(0, False)
     x = xd.cpu().numpy()
-    res = float(np.linalg.norm(sysd["K"] @ x - b))
     nu, npp = sysd["sizes"]
+    # norm(K x - b) block by block on the host (scipy): K = [A_uu A_up ; A_pu 0]
+    Ab = sysd["A"]
+    ru = Ab[0][0].matvec(x[:nu]) + Ab[0][1].matvec(x[nu:]) - b[:nu]
+    rp = Ab[1][0].matvec(x[:nu]) - b[nu:]
+    res = float(np.sqrt(ru @ ru + rp @ rp))
     fmt = gv.level_format(0)
     avg_ms = kst["total_ms"] / max(kst["launches"], 1)
     rl = None
     if kst["launches"]:
         ach = kst["alg_bytes"] / (avg_ms * 1e-3) / 1e9
         lay = kst["layout_bytes"] / (avg_ms * 1e-3) / 1e9
-        rl = {"leg": "config5", "bound": "hbm", "kernel": "r -= A dx of the velocity block's finest patch sweep (vector Q2 + grad-div: up to 50 entries per row)",
-              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "bytes_model": "SURVEY 8(d): 12 Z + 28 N",
-              "bytes_per_launch": kst["alg_bytes"], "layout_bytes_per_launch": kst["layout_bytes"], "layout_GBs": lay,
-              "avg_launch_ms": avg_ms, "launches_timed": kst["launches"], "rows": int(kst["rows"]), "nnz": int(kst["nnz"]), "traffic": None,
-              "note": "a 2-D level of 2e6 rows: it sits in the 256 MB Infinity Cache / L2s, the HBM roofline is an upper bound only"}
+        # priced with the bytes the stored layout moves (the row-pattern form has no 12 B/nnz stream: that model would give frac > 1) next to
+        # the PMC-measured HBM traffic of the same kernel at this size (profiles/traffic_latest.json, run_profile.sh --order 3)
+        tr, src = committed_traffic("sells_kernel_wide", n, nlev, int(kst["rows"]), None, order=3)
+        vec_MB = 8.0 * kst["rows"] / 1e6
+        rl = {"leg": "config5", "bound": "hbm", "kernel": "r -= A dx of the velocity block's finest patch sweep (vector Q2 + grad-div: up to 50 entries per row), "
+                                                           "sells_kernel<EPI_SUB, K=5, coded patterns decoded per workgroup into LDS>",
+              "achieved": lay, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lay / HBM_PEAK_GBS,
+              "bytes_model": "bytes the stored layout moves per launch (pattern id + dx in + r in / out per row: gmg_kernel_stats.layout_bytes)",
+              "bytes_per_launch": kst["layout_bytes"], "model_12B_per_nnz_bytes": kst["alg_bytes"], "model_12B_per_nnz_GBs": ach,
+              "avg_launch_ms": avg_ms, "launches_timed": kst["launches"], "rows": int(kst["rows"]), "nnz": int(kst["nnz"]),
+              "traffic": tr, "traffic_source": src,
+              "note": f"one vector of this level is {vec_MB:.0f} MB: " + ("the sweep's operands (r, dx, x, patch tables) outgrow the 256 MB Infinity Cache" if vec_MB >= 60
+                                                                            else "the level sits in the 256 MB Infinity Cache / L2s, the HBM roofline is an upper bound only")}
+        if tr:
+            rl["traffic_GBs"] = tr / (avg_ms * 1e-3) / 1e9
+            rl["traffic_frac"] = rl["traffic_GBs"] / HBM_PEAK_GBS
     out = dict(workload=f"BASELINE configs[4] on one GPU: 2-D Stokes lid-driven cavity, Q2 / P1disc on {n}x{n} cells, alpha = {alpha:g}; FGMRES(20, atol 1e-10, "
                         f"rtol 1e-12) + upper block-triangular preconditioner; velocity: {nlev}-level GMG(maxiter 4, Richardson(PatchSolver,10,0.2) pre = post, "
                         f"patch-corrected prolongation (grad-div rhs), LU coarsest); pressure: CG-Jacobi(20, rtol 1e-6) on -1/alpha M_p",
@@ -1089,8 +1109,8 @@ def config5_leg(torch, pkg, args, want_cpu):
     if want_cpu:
         # the same configuration at the size the sequential oracle affords: iterations, history, solution and time against it
         orc = entry.import_oracle()
-        cn, cl = 256, 5                              # ~10 s of single-thread oracle work
-        sysd, Hv, solver, gmg, solver_p, ns, _a, _s = make(cn, cl)
+        cn, cl = args.config5_cpu_cells, args.config5_cpu_levels     # 256 / 5: ~10 s of single-thread oracle work
+        sysd, Hv, solver, gmg, solver_p, ns, _a, _s = make(cn, cl, with_K=True)
         b = sysd["b"]
         x = np.zeros(b.size)
         S.solve_(x, ns, b)

@@ -43,7 +43,8 @@ def main():
     ap.add_argument("--cmd", default="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
     ap.add_argument("--no-latest", action="store_true")
     ap.add_argument("--merge-latest", action="store_true", help="add this run's records to profiles/traffic_latest.json (same kernels.hpp sha) instead of replacing it")
-    ap.add_argument("--order", type=int, default=1, help="2: the config-3 leg (Q2): the record is the wide-row operator mat-vec r -= A dx of the patch sweep")
+    ap.add_argument("--order", type=int, default=1, help="2: the config-3 leg (Q2): the record is the wide-row operator mat-vec r -= A dx of the patch sweep; "
+                                                         "3: the config-5 leg (2-D Stokes velocity block, --cells = cells per direction): the same kernel family on 2 (2 cells - 1)^2 rows")
     ap.add_argument("--bench-log", default=None, help="stdout of the profiled bench.py run (default: <src>/trace.log): its JSON line supplies the sweep signatures")
     a = ap.parse_args()
     src, out = a.src, a.out
@@ -98,10 +99,10 @@ def main():
                      "group by name, grid_x order by grid_x desc").fetchall()
     recs = []
     nrows = (a.cells - 1) ** 3
-    if a.order == 2:
+    if a.order in (2, 3):
         # config-3 leg: the timed kernel is the operator mat-vec of the patch sweep, sells_kernel<EPI_SUB = 1, ..., K = 5, VD, ..., WL> on the
         # finest Q2 level ((2 cells - 1)^3 rows); the additive-Schwarz mat-vec (EPI_ADDTO = 4) runs on the same grid and is listed beside it
-        nrows = (2 * a.cells - 1) ** 3
+        nrows = (2 * a.cells - 1) ** 3 if a.order == 2 else 2 * (2 * a.cells - 1) ** 2
         # (coarser levels launch the same kernels on the same capped grid: only the dispatches of the finest level -- at least 0.75 of the
         # longest -- enter the record)
         sw = []
@@ -127,7 +128,7 @@ def main():
     fams = {}
     for name, grid, avg_us, cnt in sw:
         fam = family(name)
-        if a.order == 2:
+        if a.order in (2, 3):
             fam = "sells_kernel_wide" if ("sells_kernel<1," in name or "sellw_zwalk_kernel<1," in name) else "sells_kernel_wide_schwarz"
         if fam is None:
             continue
@@ -165,11 +166,16 @@ def main():
     # the kernel source: bench.py attaches these measurements only to runs of the same kernels
     sigs = {}
     try:
-        blog = a.bench_log or os.path.join(src, "trace.log")
-        line = [ln for ln in open(blog).read().splitlines() if ln.startswith("{") and '"roofline"' in ln][-1]
-        bj = json.loads(line)
-        for fam_leg, blk in (("generic", bj.get("roofline")), ("default", bj.get("roofline_compressed")),
-                             ("varcoef", (bj.get("variable_coefficient") or {}).get("roofline"))):
+        det = os.path.join(src, "legs_trace.json")
+        if os.path.exists(det):                                     # round 6: everything the run measured (bench.py's details file)
+            bj = json.load(open(det))
+            legs = (("generic", bj.get("roofline_generic")), ("default", bj.get("roofline")), ("varcoef", (bj.get("variable_coefficient") or {}).get("roofline")))
+        else:
+            blog = a.bench_log or os.path.join(src, "trace.log")
+            line = [ln for ln in open(blog).read().splitlines() if ln.startswith("{") and '"roofline"' in ln][-1]
+            bj = json.loads(line)
+            legs = (("generic", bj.get("roofline")), ("default", bj.get("roofline_compressed")), ("varcoef", (bj.get("variable_coefficient") or {}).get("roofline")))
+        for fam_leg, blk in legs:
             if blk and blk.get("sweep_signature"):
                 sigs[blk["sweep_signature"].split("<")[0].replace("sells_sweep_kernel", "sells_kernel").replace("sells_rsweep_kernel", "sells_kernel").replace("sells_r2sweep_kernel", "sells_kernel").replace("sells_tsweep_kernel", "sells_kernel").replace("sells_zsweep_kernel", "sells_kernel")] = blk["sweep_signature"]
     except Exception as e:

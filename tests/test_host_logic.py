@@ -84,3 +84,24 @@ def test_overlap_geometry_counts(pkg):
         if prev is not None:
             assert g.n_local >= prev
         prev = g.n_local
+
+
+def test_stokes_inputs_by_stencil_replication_equal_the_assembly(pkg):
+    """stokes.stokes_system_fast / velocity_hierarchy_fast (what bench.py's config-5 leg feeds the library at sizes the scipy assembly
+    needs minutes for) against the assembly they replace: every block, the right-hand side and every level, bit for bit."""
+    import importlib
+    st = importlib.import_module(pkg.__name__ + ".stokes")
+    for n, nlev in ((8, 2), (16, 3)):
+        a, b = st.stokes_system(n, 1.0e3), st.stokes_system_fast(n, 1.0e3, with_K=True)
+        assert a["sizes"] == b["sizes"] and np.array_equal(a["b"], b["b"])
+        assert abs(a["K"] - b["K"]).max() == 0.0 and abs(a["Mp_scaled"].to_scipy() - b["Mp_scaled"].to_scipy()).max() == 0.0
+        for i, j in ((0, 0), (0, 1), (1, 0)):
+            assert np.array_equal(a["A"][i][j].ptr, b["A"][i][j].ptr) and np.array_equal(a["A"][i][j].idx, b["A"][i][j].idx) \
+                and np.array_equal(a["A"][i][j].val, b["A"][i][j].val)
+        H1, H2 = st.velocity_hierarchy(n, nlev, 1.0e3), st.velocity_hierarchy_fast(n, nlev, 1.0e3)
+        for key in ("mats", "graddiv", "prolongations", "restrictions"):
+            for x, y in zip(H1[key], H2[key]):
+                assert np.array_equal(x.ptr, y.ptr) and np.array_equal(x.idx, y.idx) and np.array_equal(x.val, y.val), key
+        for key in ("star_patches", "interior_patches"):
+            for (p1, d1), (p2, d2) in zip(H1[key], H2[key]):
+                assert np.array_equal(p1, p2) and np.array_equal(d1, d2)
