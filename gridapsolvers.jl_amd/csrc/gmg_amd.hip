@@ -229,7 +229,8 @@ struct PatStream {
 // device containers
 // ----------------------------------------------------------------------------
 struct DevCSR {
-  Z2Geo z2;                         // fused pair of sweeps (sells_z2sweep_kernel): geometry, valid when z2_ok > 0
+  mutable Z2Geo z2;                 // fused pair of sweeps (sells_z2sweep_kernel): geometry, valid when z2_ok > 0
+  mutable Z2Geo zbx;                // single sweep of a constant-coefficient box (sells_boxsweep_kernel): the same grid, its own chains
   mutable int z2_ok = -1;           // -1 not examined yet, 0 no, 1 yes
   int64_t nrows = 0, ncols = 0, nnz = 0;
   bool ptr64 = false;
@@ -701,6 +702,13 @@ struct gmg_solver {
   // pat_fuse2_w = waves (grid lines) per workgroup, pat_fuse2_t = planes per block (0: chosen from the level's size); pat_fuse2_box = 0
   // keeps the per-row patterns in LDS even on constant-coefficient boxes (the BC form reads one coefficient set per wave from the arguments)
   int pat_fuse2 = 0, pat_fuse2_w = 0, pat_fuse2_t = 0;
+  // GMG_PAT_BOX (opt-in): constant-coefficient box levels (verified row by row at setup) sweep with one coefficient set per wave from the kernel
+  // arguments -- no pattern ids, no LDS (kernels.hpp: sells_boxsweep_kernel): 1 = levels of pat_box_min_rows .. pat_box_max_rows rows, 2 = every
+  // level that qualifies, 0 = off (default).  Measured on MI355X (profiles/r06_ab_box.txt): 128^3 20.1-21.0 us per sweep against 18.8 for
+  // sells_r2sweep_kernel, 288^3 208 against 165 for sells_zsweep_kernel -- the per-row LDS coefficient reads it removes are not what bounds the
+  // single sweeps.  pat_box_t = planes per chain (0: from the level's size)
+  int pat_box = 0, pat_box_t = 0;
+  int64_t pat_box_min_rows = 1000000, pat_box_max_rows = 9000000;
   int64_t pat_fuse2_rows = 1000000;
   int pat_zwalk_T = 12; // GMG_PAT_ZWALK_T: planes per chain (288^3: 8 / 12 / 16 / 24 / 32 -> 149 / 114 / 120 / 118 / 155 us for the x-untouched form)
   int64_t pat_zwalk_rows = 9000000;   // the walk pays once r, r', x and the pattern ids (26 B per row) no longer fit the 256 MB Infinity Cache: 224^3 (1.09e7 rows) 8.13 -> 7.59 ms per solve,
@@ -2309,6 +2317,34 @@ struct gmg_solver {
 #undef GMG_Z2_LAUNCH
     HIP_CHECK(hipGetLastError());
   }
+  void ensure_z2(const DevCSR &M)
+  {
+    if (M.z2_ok >= 0) return;
+    M.z2_ok = z2_geo(M, M.z2) ? 1 : 0;
+    if (M.z2_ok > 0) {
+      // the single box sweep walks the same grid with chains of its own: segments of <= 126 rows, enough chains for ~4 waves per SIMD
+      Z2Geo &b = M.zbx;
+      b = M.z2;
+      b.nxs = b.whole ? 1 : (b.L + 125) / 126;
+      b.xlen = b.whole ? b.L : (b.L + b.nxs - 1) / b.nxs;
+      int T = pat_box_t;
+      if (T <= 0) T = (int)std::max<int64_t>(2, std::min<int64_t>(12, (int64_t)b.nz * b.ny * b.nxs / std::max(1, 16 * n_cus)));
+      b.T = std::max(1, std::min(T, b.nz));
+      b.nzb = (b.nz + b.T - 1) / b.T;
+    }
+  }
+  // (what box_level decided, for the byte counts: valid once a sweep of the level has been launched)
+  bool box_active(const DevCSR &M) const
+  {
+    return pat_box && pat_r2 && (pat_box >= 2 || (M.nrows >= pat_box_min_rows && M.nrows <= pat_box_max_rows)) && M.z2_ok > 0 && M.z2.box != 0;
+  }
+  bool box_level(const DevCSR &M)
+  {
+    if (!pat_box || !pat_r2) return false;
+    if (pat_box < 2 && (M.nrows < pat_box_min_rows || M.nrows > pat_box_max_rows)) return false;
+    ensure_z2(M);
+    return M.z2_ok > 0 && M.z2.box != 0;
+  }
   void launch_rsweep(const DevCSR &M, const double *r_cur, double *r_next, const double *r_prev, double *x, bool x_zero, double omega, int xmode)
   {
     SellSArgs a;
@@ -2327,6 +2363,24 @@ struct gmg_solver {
     const dim3 g2(wg2), b(64 * wpb);
     const size_t lds2 = (size_t)M.pat_np * nu * 16 + 16;
     const bool mk = pat_strict || !M.ptab8;
+    // constant-coefficient box: one coefficient set per wave from the kernel arguments, no pattern ids, no LDS
+    if (box_level(M)) {
+      const Z2Geo &gb = M.zbx;
+      const int nch = gb.nzb * gb.ny * gb.nxs;
+      const dim3 gx((unsigned)((nch + 3) / 4)), bx(256);
+      M.note_sweep("sells_boxsweep_kernel<XM=*,MK=%d,FM=%d> chains=%d T=%d segs=%d L=%d", mk ? 1 : 0, pat_fma ? 1 : 0, nch, gb.T, gb.nxs, gb.L);
+#define GMG_BOX_LAUNCH(XMV)                                                                                      \
+      do {                                                                                                       \
+        if (mk) { if (pat_fma) hipLaunchKernelGGL((sells_boxsweep_kernel<XMV, true, true>), gx, bx, 0, stream, a, gb);      \
+                  else hipLaunchKernelGGL((sells_boxsweep_kernel<XMV, true, false>), gx, bx, 0, stream, a, gb); }           \
+        else { if (pat_fma) hipLaunchKernelGGL((sells_boxsweep_kernel<XMV, false, true>), gx, bx, 0, stream, a, gb);        \
+               else hipLaunchKernelGGL((sells_boxsweep_kernel<XMV, false, false>), gx, bx, 0, stream, a, gb); }             \
+      } while (0)
+      if (xmode == 0) GMG_BOX_LAUNCH(0); else if (xmode == 1) GMG_BOX_LAUNCH(1); else GMG_BOX_LAUNCH(2);
+#undef GMG_BOX_LAUNCH
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
     // the pair sweep as a walk along the slowest grid direction: three new windows per step instead of nine, one step of requests in flight
     ZWalkGeo zg;
     if (pat_r2 && pat_zwalk && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_rows) && zwalk_geo(M, zg)) {
@@ -3106,7 +3160,7 @@ struct gmg_solver {
             copy(L.rbuf[0], cur, n);                           // the exchange writes the ghost entries of r_k: never into a caller's vector
             cur = L.rbuf[0];
           }
-          if (L.A.z2_ok < 0) L.A.z2_ok = z2_geo(L.A, L.A.z2) ? 1 : 0;
+          if (pat_fuse2) ensure_z2(L.A);
           const bool fuse2 = fuse2_level(L);
           for (int it = 0; it < nb; ++it) {
             double *next = (cur == L.rbuf[0]) ? L.rbuf[1] : L.rbuf[0];
@@ -3590,6 +3644,10 @@ struct gmg_solver {
     pat_fuse2_w = opt_int("GMG_PAT_FUSE2_W", 0);
     pat_fuse2_t = opt_int("GMG_PAT_FUSE2_T", 0);
     pat_fuse2_rows = opt_int("GMG_PAT_FUSE2_ROWS", 1000000);
+    pat_box = opt_int("GMG_PAT_BOX", 0);
+    pat_box_t = opt_int("GMG_PAT_BOX_T", 0);
+    pat_box_min_rows = opt_int("GMG_PAT_BOX_MIN_ROWS", 1000000);
+    pat_box_max_rows = opt_int("GMG_PAT_BOX_MAX_ROWS", 9000000);
     persist_wpb_min = opt_int("GMG_PERSIST_WPB", 1);
     pat_r2mv = opt_int("GMG_PAT_R2MV", 1);
     pat_pair_p = opt_int("GMG_PAT_PAIR_P", 1);
@@ -3674,6 +3732,7 @@ struct gmg_solver {
       if (pat_defer) vec -= 4.0 * N;                       // x touched every second sweep: (8+8+8)/2 instead of 8+8
       if (pat_defer && rsweep_level(L)) vec = 28.0 * N;    // sells_rsweep_kernel: r in + r out, (x in + x out + r_prev) every second sweep; no s, no 1/diag
       if (fuse2_level(L)) vec = 16.0 * N;                  // sells_z2sweep_kernel, per sweep of the pair: (r_k in + r_{k+2} out + x in + x out) / 2
+      if (box_active(A)) mat = 0.0;                        // sells_boxsweep_kernel: no pattern ids either -- the coefficients are kernel arguments
     } else if (A.pat) mat = (A.rowbase ? 6.0 : 2.0) * N;
     else if (A.sell && A.opat) { mat = 8.0 * (double)A.zpad + (A.orowbase ? 6.0 : 2.0) * N + 4.0 * N + 8.0 * (double)A.nslices; if (sell_defer && sell_un < 27) vec -= 4.0 * N; }
     else if (A.sell && (A.comp_idx || A.vdict)) mat = A.stream_bytes_per_nnz * (double)A.zpack + 4.0 * N + 4.0 * (double)(A.zpack / 64);
@@ -5986,7 +6045,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", true}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PAT_ZWALK_WIDE_ROWS", false}, {"GMG_PAT_FUSE2", false}, {"GMG_PAT_FUSE2_W", false}, {"GMG_PAT_FUSE2_T", false}, {"GMG_PAT_FUSE2_ROWS", false}, {"GMG_PAT_FUSE2_BOX", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PAT_ZWALK_WIDE_ROWS", false}, {"GMG_PAT_FUSE2", false}, {"GMG_PAT_FUSE2_W", false}, {"GMG_PAT_FUSE2_T", false}, {"GMG_PAT_FUSE2_ROWS", false}, {"GMG_PAT_FUSE2_BOX", false}, {"GMG_PAT_BOX", false}, {"GMG_PAT_BOX_T", false}, {"GMG_PAT_BOX_MIN_ROWS", false}, {"GMG_PAT_BOX_MAX_ROWS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

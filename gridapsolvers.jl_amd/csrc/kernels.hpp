@@ -2522,6 +2522,124 @@ __global__ __launch_bounds__(1024) void sells_z2sweep_kernel(SellSArgs a, Z2Geo 
 }
 
 // ---------------------------------------------------------------------------
+// The single sweep of a constant-coefficient box (round 6): what phase 1 of sells_z2sweep_kernel<.., BC> does, without the ring, the
+// barrier and the rim rows.  One wave = one grid line (a segment of <= 126 rows of it) walked up T planes: nine converted windows in
+// registers, three new ones per step requested a step ahead, the 27 coefficients of the line's class from the KERNEL ARGUMENTS (scalar
+// loads) -- no pattern ids, no coefficient table in LDS, no LDS at all.  Window positions that leave the line read as exact zeros, so
+// the line's first and last rows use the same coefficients as the rest.  Sums as in sells_r2sweep_kernel / sells_zsweep_kernel (same
+// taps, same order) up to the sign of an exact zero product; strict form: cmask of the class.
+//   a.x = r_k ; a.y = r_{k+1} ; a.x2 = x ; a.s_out = r_{k-1} (XM = 2) ; a.pdinv[0] = d ; g.T = planes per chain, g.W unused
+// ---------------------------------------------------------------------------
+template <int XM, bool MK, bool FM>
+__global__ __launch_bounds__(kBlock, 4) void sells_boxsweep_kernel(SellSArgs a, Z2Geo g)
+{
+  constexpr int K = 3, NR = 9;
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int blk = remap_block(blockIdx.x, gridDim.x, a.xcd_remap);
+  const int chain = blk * wpb + wave;                         // (zb, y, xs), xs fastest: neighbouring waves hold neighbouring lines of the same planes
+  const int per_zb = g.ny * g.nxs;
+  if (chain >= g.nzb * per_zb) return;
+  const int zb = chain / per_zb, c2 = chain - zb * per_zb, y = c2 / g.nxs, xs = c2 - y * g.nxs;
+  const int x0 = g.whole ? 0 : xs * g.xlen;
+  const int len = g.whole ? g.L : min(g.xlen, g.L - x0);
+  const double *__restrict__ rg = a.x;
+  const double omega = a.omega, du = a.pdinv[0];
+  const int last = (int)a.ncols - 1, lastrow = (int)a.nrows - 1;
+  const bool xz = a.x_zero != 0;
+  int roff[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) roff[q] = __builtin_amdgcn_readfirstlane(a.run_off[q]);
+  auto conv = [&](gmg_d2 v) -> gmg_d2 { return gmg_d2{omega * (du * v.x), omega * (du * v.y)}; };
+  // lane l: rows x0 + 2 l, x0 + 2 l + 1 ; window positions x0 - 1 + 2 l, x0 + 2 l (lane 63 of a segment only supplies windows)
+  const int xr = x0 + 2 * lane;
+  const bool vA = xr < x0 + len, vB = xr + 1 < x0 + len;
+  const bool zx0 = x0 - 1 + 2 * lane < 0 || x0 - 1 + 2 * lane >= g.L, zx1 = x0 + 2 * lane >= g.L;
+  const bool zx_any = __any(zx0 || zx1);
+  const int cy = y <= 0 ? 0 : (y >= g.ny - 1 ? 2 : 1);
+  const int z0 = zb * g.T, z1 = min(g.nz, z0 + g.T);
+  const int lbase = y * g.L + x0;
+  auto loadw = [&](int plane, int q) -> gmg_d2 {
+    const int c = plane * g.P + lbase + roff[q] + 2 * lane;
+    const gmg_d2 v = gmg_d2{rg[min(max(c, 0), last)], rg[min(max(c + 1, 0), last)]};
+    return zx_any ? gmg_d2{zx0 ? 0.0 : v.x, zx1 ? 0.0 : v.y} : v;
+  };
+  struct Own { gmg_d2 e0, e2, rp; };
+  auto load_own = [&](int plane) -> Own {
+    Own o;
+    const int row = plane * g.P + lbase + 2 * lane;
+    const int ra = min(max(row, 0), lastrow), rb = min(max(row + 1, 0), lastrow);
+    o.e0 = gmg_d2{rg[ra], rg[rb]};
+    o.e2 = gmg_d2{0.0, 0.0}; o.rp = gmg_d2{0.0, 0.0};
+    if (XM != 1) o.e2 = gmg_d2{a.x2[ra], a.x2[rb]};
+    if (XM == 2) o.rp = gmg_d2{a.s_out[ra], a.s_out[rb]};
+    return o;
+  };
+  gmg_d2 C[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) C[q] = conv(loadw(z0, q));
+  Own cur = load_own(z0);
+#pragma unroll 1
+  for (int z = z0; z < z1; ++z) {
+    gmg_d2 N[3];
+    const int zn = min(z + 1, z1 - 1);                        // (past the end of the chain: the last step again, unused)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) N[q] = loadw(zn, 6 + q);
+    const Own nxt = load_own(zn);
+    const int cls = 3 * (z == 0 ? 0 : (z == g.nz - 1 ? 2 : 1)) + cy;
+    double sA = 0.0, sB = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const double w0 = C[q].x, w1 = C[q].y;
+      const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+      const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        const double c = g.coef[cls][q * K + t];
+        sA = FM ? __builtin_fma(c, wa[t], sA) : sA + c * wa[t];
+        sB = FM ? __builtin_fma(c, wb[t], sB) : sB + c * wb[t];
+      }
+    }
+    if (MK && !__all(__builtin_isfinite(sA) && __builtin_isfinite(sB))) {
+      sA = 0.0; sB = 0.0;
+#pragma unroll 1
+      for (int q = 0; q < NR; ++q) {
+        const int cc = z * g.P + lbase + a.run_off[q] + 2 * lane;
+        gmg_d2 v = gmg_d2{rg[min(max(cc, 0), last)], rg[min(max(cc + 1, 0), last)]};
+        v = conv(gmg_d2{zx0 ? 0.0 : v.x, zx1 ? 0.0 : v.y});
+        const double w0 = v.x, w1 = v.y;
+        const double w2 = wave_shl1(w0), w3 = wave_shl1(w1);
+        const double wa[3] = {w0, w1, w2}, wb[3] = {w1, w2, w3};
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const int j = q * K + t;
+          const int m = (int)g.cmask[cls][j];
+          const double c = g.coef[cls][j];
+          const double ga = __hiloint2double(__double2hiint(wa[t]) & m, __double2loint(wa[t]));
+          const double gb = __hiloint2double(__double2hiint(wb[t]) & m, __double2loint(wb[t]));
+          sA = FM ? __builtin_fma(c, ga, sA) : sA + c * ga;
+          sB = FM ? __builtin_fma(c, gb, sB) : sB + c * gb;
+        }
+      }
+    }
+    const gmg_d2 rn = gmg_d2{cur.e0.x - sA, cur.e0.y - sB};
+    const gmg_d2 sk = gmg_d2{omega * (du * cur.e0.x), omega * (du * cur.e0.y)};
+    const gmg_d2 e2 = xz ? gmg_d2{0.0, 0.0} : cur.e2;
+    gmg_d2 xn = gmg_d2{0.0, 0.0};
+    if (XM == 0) xn = gmg_d2{e2.x + sk.x, e2.y + sk.y};
+    else if (XM == 2) xn = gmg_d2{(e2.x + omega * (du * cur.rp.x)) + sk.x, (e2.y + omega * (du * cur.rp.y)) + sk.y};
+    const int row = z * g.P + lbase + 2 * lane;
+    if (vA) { if (XM != 1) a.x2[row] = xn.x; a.y[row] = rn.x; }
+    if (vB) { if (XM != 1) a.x2[row + 1] = xn.y; a.y[row + 1] = rn.y; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) C[q] = C[q + 3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) C[6 + q] = conv(N[q]);
+    cur = nxt;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Wide rows (Q2: 25 runs of 5 consecutive offsets, 125 entries per row) in the z-walk form (round 5).  The runs are a 5 x 5 grid,
 // run q = 5 (dz + 2) + (dy + 2) at dz P + dy L - 2, so 20 of the 25 windows of the slice at r0 + P are windows of the slice at r0:
 // a wave keeps an interval of <= 60 rows of a grid plane, walks T planes upwards and gathers FIVE new windows per step instead of

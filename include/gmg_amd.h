@@ -232,6 +232,9 @@ GMG_API int gmg_set_options(gmg_handle_t h, int mode, int cycle, int maxiter, do
  *                    r_{k+2} out, r_{k+1} in LDS only, sells_z2sweep_kernel; 2: every level that qualifies.  Bit-identical to the single sweeps; measured slower
  *                    than them on MI355X, see profiles/r06_ab_fuse2.txt) pat_fuse2_w / pat_fuse2_t (0 = chosen from the size: grid lines per workgroup, planes
  *                    per block) pat_fuse2_box (1: constant-coefficient boxes read one coefficient set per wave from the kernel arguments)
+ *                    pat_box (0: opt-in, measured slower -- profiles/r06_ab_box.txt.  1: levels of pat_box_min_rows (1000000) .. pat_box_max_rows (9000000) rows whose operator is a constant-coefficient stencil on a box --
+ *                    verified row by row at setup -- sweep with one coefficient set per wave read from the kernel arguments: no pattern ids, no LDS,
+ *                    sells_boxsweep_kernel; 2: every level that qualifies; 0: off) pat_box_t (0: planes per chain from the level's size)
  *   reductions       red_fused (1: inside CG the second stage of every dot is done by the kernel that consumes the scalar and the
  *                    norm is reduced + posted to the host by one launch; 0: one reduce launch per dot.  Same bits either way)
  *   one-launch pass  persist (1) persist_fenced (0) persist_max_slices (0 = one workgroup per CU) persist_shared (0)

@@ -49,13 +49,18 @@ BIG_FORMS = {"occ2": ({"pat_tile_rows": 0, "pat_zwalk": 0, "persist": 0}, ("sell
 # small levels: tile shapes from the default to the smallest legal one (three lines per workgroup, one plane per block: every row of
 # sweep k is somebody's rim), and two levels whose grid lines are longer than a wave holds (135 and 259 nodes: two / three x segments
 # with one node of sweep k either side).  fuse2 = the form a constant-coefficient box operator gets (BC: one set of coefficients per wave from the
-# kernel arguments, verified row by row at setup), fuse2_general = per-row patterns from LDS (what any other grid operator gets)
+# kernel arguments, verified row by row at setup), fuse2_general = per-row patterns from LDS (what any other grid operator gets).
+# box* = sells_boxsweep_kernel (round 6): the SINGLE sweep of a constant-coefficient box with the coefficients from the kernel arguments (default on
+# levels of 1e6 .. 9e6 rows), forced onto the small levels with chains of the default length, of one plane and of five
 BIG_FORMS.update({"fuse2": ({"pat_fuse2": 2, "persist": 0}, ("sells_z2sweep_kernel", "BC=1")),
                   "fuse2_general": ({"pat_fuse2": 2, "pat_fuse2_box": 0, "persist": 0}, ("sells_z2sweep_kernel", "BC=0")),
                   "fuse2_W16_T3": ({"pat_fuse2": 2, "pat_fuse2_w": 16, "pat_fuse2_t": 3, "persist": 0}, ("sells_z2sweep_kernel", "T=3")),
                   "fuse2_W3_T1": ({"pat_fuse2": 2, "pat_fuse2_w": 3, "pat_fuse2_t": 1, "persist": 0}, ("sells_z2sweep_kernel", "W=3", "T=1"))})
+BIG_FORMS.update({"box": ({"pat_box": 2, "persist": 0}, ("sells_boxsweep_kernel",)),
+                  "box_T1": ({"pat_box": 2, "pat_box_t": 1, "persist": 0}, ("sells_boxsweep_kernel", "T=1")),
+                  "box_T5": ({"pat_box": 2, "pat_box_t": 5, "persist": 0}, ("sells_boxsweep_kernel", "T=5"))})
 LONG_LINE_CASES = [((136, 8, 8), 2, 4), ((260, 8, 16), 2, 10)]
-SWEEP_CASES = [(c, f) for f in BIG_FORMS for c in BIG_LEVEL_CASES] + [(c, f) for f in ("fuse2", "fuse2_general", "fuse2_W3_T1") for c in LONG_LINE_CASES]
+SWEEP_CASES = [(c, f) for f in BIG_FORMS for c in BIG_LEVEL_CASES] + [(c, f) for f in ("fuse2", "fuse2_general", "fuse2_W3_T1", "box", "box_T5") for c in LONG_LINE_CASES]
 
 
 @pytest.mark.parametrize("case,form", SWEEP_CASES, ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v[0])) + f"-{v[1]}-{v[2]}")
