@@ -1360,8 +1360,29 @@ struct gmg_solver {
         runs.push_back(o);
         while (i < U.size() && U[i] <= o + c.k - 1) ++i;
       }
+      // Round 6: a coded table whose offsets fall into FIVE equally spaced groups of <= 15 consecutive offsets each -- a 2-D operator of
+      // reach +-2 lines on interleaved vector dofs (Stokes velocity, Q2: 5 lines x offsets -5 .. +5) -- is laid out as the 5 x 5 grid of
+      // runs the z-walk form of the wide-row kernels takes (sellw_zwalk_kernel: "planes" = grid lines): per group the runs
+      // first - 5 + 5 j, j = 0 .. 4, so that the entries sit in the middle three (the kernel cuts a group to those when the outer two are
+      // absent for the wave).  The greedy cover above gives 3 runs per group, which only the per-slice kernel can use (16 gathers per
+      // slice: 251 us per application on 8.4e6 rows against ~1/4 of that in the walk).
+      if (c.k == 5 && c.coded && runs.size() != 25 && opt_int("GMG_PAT_WIDE_GRID", 1)) {
+        std::vector<int32_t> first, lastv;
+        for (int32_t o : U) {
+          if (first.empty() || o > first.back() + 24) { first.push_back(o); lastv.push_back(o); }
+          else lastv.back() = o;
+        }
+        bool grid = first.size() == 5 && first[1] - first[0] >= 64;
+        for (size_t gq = 0; gq < first.size() && grid; ++gq)
+          grid = lastv[gq] - first[gq] <= 14 && (gq == 0 || first[gq] - first[gq - 1] == first[1] - first[0]);
+        if (grid) {
+          runs.clear();
+          for (size_t gq = 0; gq < 5; ++gq)
+            for (int j = 0; j < 5; ++j) runs.push_back(first[gq] - 5 + 5 * j);
+        }
+      }
       // more loads than the generic kernel would issue: not worth it (when the generic kernel is an option)
-      if (generic_fits && 2 * runs.size() > maxlen + 2) continue;
+      if (generic_fits && 2 * runs.size() > maxlen + 2 && runs.size() != 25) continue;
       const size_t nreal = runs.size();                     // sorted ascending
       while (runs.size() % (size_t)c.rb) runs.push_back(0); // dummy runs: zero coefficients on x[row..row+k-1]
       const int nruns = (int)runs.size(), nu = c.k * nruns;
@@ -6045,7 +6066,7 @@ const OptionKey kOptionKeys[] = {
   {"GMG_PAT_WIDE_ROUNDS", false}, {"GMG_PERSIST", false}, {"GMG_PERSIST_FENCED", false}, {"GMG_PERSIST_MAX_SLICES", false},
   {"GMG_PERSIST_SHARED", false}, {"GMG_PROF_STRIDE", true}, {"GMG_REFRESH", true}, {"GMG_SELL", false}, {"GMG_SELL_BLOCK", false},
   {"GMG_SELL_DEFER", false}, {"GMG_SELL_MAXPAD", false}, {"GMG_SELL_UN", false}, {"GMG_SETUP_TIMING", true}, {"GMG_VDICT", false},
-  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PAT_ZWALK_WIDE_ROWS", false}, {"GMG_PAT_FUSE2", false}, {"GMG_PAT_FUSE2_W", false}, {"GMG_PAT_FUSE2_T", false}, {"GMG_PAT_FUSE2_ROWS", false}, {"GMG_PAT_FUSE2_BOX", false}, {"GMG_PAT_BOX", false}, {"GMG_PAT_BOX_T", false}, {"GMG_PAT_BOX_MIN_ROWS", false}, {"GMG_PAT_BOX_MAX_ROWS", false},
+  {"GMG_XCD_REMAP", false}, {"GMG_XCD_REMAP_BIG", false}, {"GMG_X0_ZERO", true}, {"GMG_HOST_POLL", true}, {"GMG_HOST_CHUNK_BYTES", true}, {"GMG_PAT_FMA", false}, {"GMG_PAT_R2", false}, {"GMG_RED_FUSED", false}, {"GMG_PAT_R2MV", false}, {"GMG_PAT_R2_OCC", false}, {"GMG_PAT_PAIR_P", false}, {"GMG_PAT_R2MV_DOT", false}, {"GMG_PERSIST_WPB", false}, {"GMG_HOST_TIMELINE", true}, {"GMG_PAT_R2MV_MIN", false}, {"GMG_PAT_BCAST", false}, {"GMG_PAT_R2_WGS", false}, {"GMG_PAT_ZWALK", false}, {"GMG_PAT_ZWALK_T", false}, {"GMG_PAT_ZWALK_ROWS", false}, {"GMG_PAT_ZWALK_MV", false}, {"GMG_PAT_ZWALK_WIDE", false}, {"GMG_PAT_ZWALK_WIDE_ROWS", false}, {"GMG_PAT_FUSE2", false}, {"GMG_PAT_FUSE2_W", false}, {"GMG_PAT_FUSE2_T", false}, {"GMG_PAT_FUSE2_ROWS", false}, {"GMG_PAT_FUSE2_BOX", false}, {"GMG_PAT_BOX", false}, {"GMG_PAT_WIDE_GRID", false}, {"GMG_PAT_BOX_T", false}, {"GMG_PAT_BOX_MIN_ROWS", false}, {"GMG_PAT_BOX_MAX_ROWS", false},
   {"GMG_PERSIST_FORCE_TIMEOUT", true},
 };
 // "pat_tile", "PAT_TILE" and "GMG_PAT_TILE" name the same option

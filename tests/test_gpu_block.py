@@ -264,3 +264,49 @@ def test_real_stokes_q2_p1disc_block_triangular_fgmres(S, po, orc, n, nlev):
     assert np.linalg.norm(sysd["A"][1][0].to_scipy() @ x[:nu] - b[nu:]) < 1e-7
     assert x[:nu].max() > 0.3
     ns.P_ns.close()
+
+
+@pytest.mark.parametrize("n,T", [(32, 12), (24, 3), (40, 1)])
+def test_vector_q2_velocity_operator_in_the_line_walk_form(S, po, orc, monkeypatch, capfd, n, T):
+    """Round 6: the Stokes velocity operator (2-D, vector Q2 + grad-div: 5 grid lines x offsets -5 .. +5 on interleaved dofs) laid out as the
+    5 x 5 grid of runs the walk form of the wide-row kernels takes (sellw_zwalk_kernel with "planes" = grid lines; option pat_wide_grid,
+    default on) -- what the config-5 leg's dominant kernel (r -= A dx of the patch sweep) runs at 1024^2 cells.  Forced onto small levels
+    (pat_zwalk = 2; chains of 12 / 3 / 1 lines): mul!(y, A, x) equals the oracle's row sums bit for bit, also against the per-slice kernel
+    on the greedy run cover (pat_wide_grid = 0), with Inf / NaN in x; the patch-smoothed velocity GMG gives the same bits in both forms."""
+    import importlib
+    from gridapsolvers_jl_amd import abi
+    st = importlib.import_module(po.__name__.rsplit(".", 1)[0] + ".stokes")
+    monkeypatch.setenv("GMG_PAT_CODED_MIN_ROWS", "0")               # the coded shared-offset table on these small levels
+    monkeypatch.setenv("GMG_SETUP_TIMING", "1")
+    nlev = 2
+    Hv = st.velocity_hierarchy(n, nlev, 1.0e3)
+    A = Hv["mats"][0]
+    nu = A.shape[0]
+    x = np.random.default_rng(21).uniform(-1, 1, nu)
+    xi = x.copy(); xi[nu // 2 + 1] = np.inf; xi[5] = np.nan
+    r = np.random.default_rng(22).uniform(-1, 1, nu)
+    res = {}
+    for mode, opts in (("walk", {"pat_zwalk": 2, "pat_zwalk_T": T}), ("slice_grid", {"pat_zwalk": 0}), ("slice_greedy", {"pat_zwalk": 0, "pat_wide_grid": 0})):
+        sm = [S.RichardsonSmoother(S.PatchSolver(pp, pd), 3, 0.2) for pp, pd in Hv["star_patches"]]
+        gmg = S.GMGLinearSolver(Hv["mats"], Hv["prolongations"], Hv["restrictions"], pre_smoothers=sm, post_smoothers=sm,
+                                coarsest_solver=S.LUSolver(), maxiter=2, mode="solver", options=opts)
+        capfd.readouterr()
+        ns = setup(S, gmg, A)
+        y, yi, z = np.zeros(nu), np.zeros(nu), np.zeros(nu)
+        ns.op_apply(0, abi.OP_A, x, y)
+        ns.op_apply(0, abi.OP_A, xi, yi)
+        S.solve_(z, ns, r)
+        err = capfd.readouterr().err
+        assert ("wide-row z-walk" in err) == (mode == "walk"), (mode, err[-600:])
+        res[mode] = (y, np.isfinite(yi), np.where(np.isfinite(yi), yi, 0.0), z, gmg.log.num_iters)
+        ns.close()
+    yo = orc.spmv(A, x)
+    for mode in res:
+        assert np.array_equal(res[mode][0], yo), mode
+        for a_, b_ in zip(res[mode], res["slice_greedy"]):
+            assert np.array_equal(a_, b_), mode
+    As = A.to_scipy().tocsc()
+    touched = np.zeros(nu, dtype=bool)
+    for k in (nu // 2 + 1, 5):
+        touched[As.indices[As.indptr[k]:As.indptr[k + 1]]] = True
+    assert np.array_equal(~res["walk"][1], touched)
