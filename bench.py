@@ -363,6 +363,19 @@ def host_io_leg(torch, S, ns, b, dev_ms, steps, label):
 
 
 LINE_LIMIT = 4096          # bytes: round 5's 22.7 KB line was more than the driver's parser takes
+_REAL_STDOUT = None        # the process's original stdout, see claim_stdout()
+
+
+def claim_stdout():
+    """From here on ONLY the JSON line reaches the process's real stdout: file descriptor 1 is pointed at stderr and the line is written
+    to a duplicate of the original.  RCCL prints a version banner to stdout when NCCL_DEBUG=VERSION is set (it is, on the GPU boxes) --
+    through C stdio, i.e. at process EXIT when stdout is a pipe or a file: five lines BEHIND the JSON line of any run that initialises a
+    communicator (every N > 1 run; the rccl_loopback leg at N = 1)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
 
 
 def _pick(d, keys):
@@ -434,13 +447,15 @@ def emit(out):
         txt = json.dumps(line, default=float)
     assert len(txt) <= LINE_LIMIT, len(txt)
     json.loads(txt)
-    print(txt, flush=True)
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (txt + "\n").encode())
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    claim_stdout()
     import torch
     import torch.distributed as dist
 

@@ -137,3 +137,25 @@ def test_generic_layout_over_rccl_loopback(pkg, po, orc):
     r = _solve(mg, F, cells, nlev, "rccl_loopback", W, options=opts)
     assert r["iters"] == host["iters"] == nit and np.array_equal(r["x"], host["x"]) and r["exchanges"] == host["exchanges"]
     assert rel_err(r["x"], xo[r["gid"]]) < 1e-10 and "sell" in r["sig"]
+
+
+@pytest.mark.gpu
+def test_bench_prints_exactly_one_line_on_stdout_even_when_rccl_prints_its_banner(tmp_path):
+    """NCCL_DEBUG=VERSION (set on the GPU boxes) makes RCCL print a five-line version banner to stdout through C stdio -- at process
+    exit when stdout is a pipe, i.e. BEHIND the JSON line of any bench run that creates a communicator.  bench.py points file
+    descriptor 1 at stderr and writes its one line to a duplicate of the original stdout (claim_stdout): the driver's parser sees one line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NCCL_DEBUG="VERSION", GMG_BENCH_DETAILS=str(tmp_path / "legs.json"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--legs", "default,rccl_loopback", "--cells", "32", "--levels", "3",
+                          "--loopback-cells", "16", "--loopback-levels", "3", "--steps", "2", "--warmup", "1"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and len(lines[0]) <= 4096, out.stdout[-800:]
+    d = json.loads(lines[0])
+    lb = d["rccl_loopback"]
+    assert lb["rccl_ranks"] == 1 and lb["virtual_ranks"] == 8 and lb["bitwise_equal_host_transport"] is True and lb["exchanges_per_solve"] > 20
+    assert "RCCL version" in out.stderr          # (the banner exists -- and went to stderr)

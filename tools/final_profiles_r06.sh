@@ -9,6 +9,6 @@ bash profiles/run_profile.sh r06_config3_256 --merge-latest --order 2 --cells 25
 bash profiles/run_profile.sh r06_config5_1024 --merge-latest --order 3 --cells 1024 --levels 7 -- --legs default,config5
 R=$(pwd)
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tl && timeout -k 5 600 rocprofv3 --kernel-trace -d /tmp/tl -o p -- python3 $R/bench.py --legs default --steps 20 > /tmp/tl.log 2>&1 < /dev/null; python3 $R/tools/iteration_timeline.py /tmp/tl > $R/gpurun_out/r06_timeline_128.txt 2>&1 )
-cp profiles/traffic_latest.json gpurun_out/traffic_latest.json
+cp gpurun_out/traffic_latest.json profiles/traffic_latest.json     # (summarize.py keeps it next to its outputs; bench.py reads profiles/)
 python3 bench.py > gpurun_out/r06_bench_line.json 2> gpurun_out/r06_bench.err
 echo "bench rc=$?"; wc -c gpurun_out/r06_bench_line.json
