@@ -294,6 +294,15 @@ struct DevCSR {
   mutable uint16_t *wz_pids = nullptr;
   mutable int32_t *wz_cnt = nullptr;
   mutable ZWalkGeo wz_geo = {0, 0, 0, 0, 0};
+  // auxiliary walk table (round 6): a plain (K = 3) table whose offsets form the 5 x 5 run grid but whose values are too many for 8-bit
+  // codes also carries 16-bit codes over those 25 runs of five -- sellw_zwalk_kernel decodes per workgroup, so the dictionary never has to
+  // fit LDS; the per-slice kernels keep using the plain table
+  bool aux_ok = false;
+  int32_t *aux_run = nullptr;        // [25] run offsets
+  uint16_t *aux_codes16 = nullptr;   // [np * 125]
+  double *aux_dict = nullptr;        // [65536], [65535] = 0.0
+  uint32_t *aux_rmask = nullptr;     // [np]
+  std::vector<int32_t> h_aux_run;
   mutable int32_t *wl_cnt = nullptr;
   // offset-pattern layout (SELL-O): SELL-64 value stream + a 16-bit offset-pattern id per row, no column stream
   bool opat = false;
@@ -1317,6 +1326,48 @@ struct gmg_solver {
     upload_pattern(D, P.nrows, P.rowpid, P.rowbase, plen, poff, pval, W, generic, true);
     return D;                                                // P keeps its per-row ids (2-6 B/row): gmg_setup may run again
   }
+  // 16-bit coded table over the 5 x 5 run grid for the walk form of the wide-row kernels (DevCSR::aux_*): offsets in five equally
+  // spaced groups of <= 15, at most 65 535 distinct values
+  void build_aux_walk_table(DevCSR &D, const std::vector<int32_t> &plen, const std::vector<int32_t> &poff8, const std::vector<double> &pval, int W,
+                            const std::vector<int32_t> &U)
+  {
+    const int np = (int)plen.size();
+    std::vector<int32_t> first, lastv;
+    for (int32_t o : U) {
+      if (first.empty() || o > first.back() + 24) { first.push_back(o); lastv.push_back(o); }
+      else lastv.back() = o;
+    }
+    if (first.size() != 5 || first[1] - first[0] < 64) return;
+    for (size_t gq = 0; gq < 5; ++gq)
+      if (lastv[gq] - first[gq] > 14 || (gq > 0 && first[gq] - first[gq - 1] != first[1] - first[0])) return;
+    std::vector<int32_t> runs;
+    for (size_t gq = 0; gq < 5; ++gq)
+      for (int j = 0; j < 5; ++j) runs.push_back(first[gq] - 5 + 5 * j);
+    std::vector<uint64_t> keys;
+    for (int p = 0; p < np; ++p)
+      for (int j = 0; j < plen[p]; ++j) { uint64_t bits; std::memcpy(&bits, &pval[(size_t)p * W + j], 8); keys.push_back(bits); }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    if (keys.size() > 65535) return;
+    const int nu = 125;
+    std::vector<uint16_t> codes((size_t)np * nu, (uint16_t)65535);
+    std::vector<uint32_t> rmask((size_t)np, 0u);
+    for (int p = 0; p < np; ++p)
+      for (int j = 0; j < plen[p]; ++j) {
+        const int32_t o = poff8[(size_t)p * W + j] / 8;
+        const size_t r = (size_t)(std::upper_bound(runs.begin(), runs.end(), o) - runs.begin()) - 1;
+        uint64_t bits;
+        std::memcpy(&bits, &pval[(size_t)p * W + j], 8);
+        codes[(size_t)p * nu + r * 5 + (size_t)(o - runs[r])] = (uint16_t)(std::lower_bound(keys.begin(), keys.end(), bits) - keys.begin());
+        rmask[p] |= 1u << r;
+      }
+    std::vector<double> dict(65536, 0.0);
+    for (size_t q = 0; q < keys.size(); ++q) std::memcpy(&dict[q], &keys[q], 8);
+    codes.resize(((codes.size() + 63) / 64) * 64, (uint16_t)65535);
+    D.aux_codes16 = upload(codes); D.aux_dict = upload(dict); D.aux_rmask = upload(rmask); D.aux_run = upload(runs);
+    D.h_aux_run = runs;
+    D.aux_ok = true;
+  }
   // Shared-offset form of a row-relative pattern table (sells_kernel): the union of all offsets, covered
   // greedily by runs of three consecutive offsets; every pattern becomes a dense coefficient vector over it.
   void build_shared_offsets(DevCSR &D, const std::vector<int32_t> &plen, const std::vector<int32_t> &poff8,
@@ -1439,6 +1490,8 @@ struct gmg_solver {
         for (size_t q = 0; q < tab.size(); ++q) tab8[q] = tab[q].v;
         D.ptab8 = upload(tab8);
       }
+      if (!c.coded && opt_int("GMG_PAT_WIDE_GRID", 1) && pat_zwalk && pat_zwalk_wide && (pat_zwalk >= 2 || D.nrows >= pat_zwalk_wide_rows) && np <= 4096)
+        build_aux_walk_table(D, plen, poff8, pval, W, U);
       D.prun = upload(runs);
       D.pat_nruns = nruns;
       D.pat_k = c.k;
@@ -1503,9 +1556,10 @@ struct gmg_solver {
     if (M.wz_state != 0 && M.wz_T == pat_zwalk_T) return M.wz_state == 1 ? M.wz_nwg : 0;
     if (M.wz_state == 1) { HIP_CHECK(hipStreamSynchronize(stream)); release(M.wz_pids, (size_t)M.wz_nwg * kWideStride); release(M.wz_cnt, (size_t)M.wz_nwg); }
     M.wz_state = 2; M.wz_T = pat_zwalk_T; M.wz_nwg = 0; M.wz_max = 0;
-    if (!pat_wide || !M.pat_coded || M.pat_k != 5 || M.pat_nruns != 25 || M.pat_np > 4096 || M.pat_np < 2 || !M.rowpid || !M.pcodes || !M.pdict || !M.prunmask) return 0;
-    if (M.ncols >= (int64_t)(1 << 28) || M.nrows + 64 + std::max<int64_t>(M.pat_maxoff, -(int64_t)M.pat_minoff) >= (int64_t)(1 << 28)) return 0;
-    const std::vector<int32_t> &off = host_run_off(M);
+    const bool main_tab = M.pat_coded && M.pat_k == 5 && M.pat_nruns == 25 && M.pcodes && M.pdict && M.prunmask;
+    if (!pat_wide || !(main_tab || M.aux_ok) || M.pat_np > 4096 || M.pat_np < 2 || !M.rowpid) return 0;
+    if (M.ncols >= (int64_t)(1 << 28) || M.nrows + 64 + std::max<int64_t>(M.pat_maxoff, -(int64_t)M.pat_minoff) + 16 >= (int64_t)(1 << 28)) return 0;
+    const std::vector<int32_t> &off = main_tab ? host_run_off(M) : M.h_aux_run;
     const int64_t P = (int64_t)off[5] - off[0];
     if (P < 64 || P > (int64_t)(1 << 24)) return 0;
     for (int q = 0; q < 20; ++q) if ((int64_t)off[(size_t)q + 5] - off[(size_t)q] != P) return 0;
@@ -1664,9 +1718,12 @@ struct gmg_solver {
     if (EPI == EPI_SWEEP) M.note_sweep("sells_kernel<EPI_SWEEP,%s,RB=%d,K=%d,VD=%d> wgs=%d wpb=%d", ONEG ? "ONEG" : "2G", M.pat_coded ? M.pat_k : pat_rb, M.pat_k, M.pat_coded ? 1 : 0, nwg, wpb);
     if constexpr ((EPI == EPI_SET || EPI == EPI_SUB || EPI == EPI_RESID || EPI == EPI_ADDTO) && !ONEG) {
       // big wide-row levels: the z-walk form (five new windows per step instead of up to 25 gathers per slice)
-      if (M.pat_coded && M.pat_k == 5 && pat_zwalk && pat_zwalk_wide && !a.s_out && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_wide_rows)) {
+      if (((M.pat_coded && M.pat_k == 5) || M.aux_ok) && pat_zwalk && pat_zwalk_wide && !a.s_out && (pat_zwalk >= 2 || M.nrows >= pat_zwalk_wide_rows)) {
         const int nwz = prepare_wide_z(M);
         if (nwz > 0) {
+          if (!(M.pat_coded && M.pat_k == 5)) {               // the auxiliary 16-bit coded table over the 5 x 5 run grid
+            a.codes = nullptr; a.codes16 = M.aux_codes16; a.dict = M.aux_dict; a.runmask = M.aux_rmask; a.run_off = M.aux_run; a.nruns = 25;
+          }
           a.wl_pids = M.wz_pids; a.wl_cnt = M.wz_cnt; a.wl_stride = kWideStride; a.wl_max = M.wz_max;
           const size_t ldsz = wide_z_lds(M, M.wz_max);
           static bool attr_z[64] = {false};

@@ -1150,6 +1150,7 @@ struct SellSArgs {
   const PatEntry *tab;      // [np * nu], nu = K * nruns ; the last pattern is empty
   const double *tab8;       // the coefficients alone (unmasked sweep kernels)
   const uint8_t *codes;     // coded form (VD): [np * nu] index into dict, 255 = entry absent
+  const uint16_t *codes16;  // walk form of a table with more than 255 distinct values (sellw_zwalk_kernel only): 16-bit codes, 65535 = absent; dict then holds 65536 doubles
   const double *dict;       // coded form: [256] distinct values, dict[255] = 0.0
   const uint32_t *runmask;  // coded form: [np] bit r set when the pattern has an entry in run r (nruns <= 32)
   const int32_t *run_off;   // [nruns] first offset of each run (elements)
@@ -2680,7 +2681,7 @@ __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWa
     }
     for (int i = threadIdx.x; i < lnp * NUT; i += blockDim.x) {
       const int l = i / NUT, e = i - l * NUT;
-      sp_smem[i] = e < nu ? a.dict[a.codes[(size_t)mine[l] * nu + e]] : 0.0;
+      sp_smem[i] = e < nu ? a.dict[a.codes16 ? (int)a.codes16[(size_t)mine[l] * nu + e] : (int)a.codes[(size_t)mine[l] * nu + e]] : 0.0;
     }
   }
   __syncthreads();
@@ -2796,7 +2797,7 @@ __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWa
     // that already holds Inf / NaN -- the step is redone from memory with the masks of the coded table
     if (!__all(__builtin_isfinite(sum))) {
       sum = 0.0;
-      const uint8_t *gc = a.codes + (size_t)gpid * nu;
+      const size_t gb = (size_t)gpid * nu;
 #pragma unroll 1
       for (int q = 0; q < NR; ++q) {
         if (!((M >> q) & 1u)) continue;
@@ -2804,8 +2805,8 @@ __global__ __launch_bounds__(kBlock, 4) void sellw_zwalk_kernel(SellSArgs a, ZWa
 #pragma unroll 1
         for (int t = 0; t < K; ++t) {
           if (t > 0) v = wave_shl1(v);
-          const int code = gc[q * K + t];
-          const double gv = __hiloint2double(__double2hiint(v) & ((code == 255) ? 0 : -1), __double2loint(v));
+          const bool absent = a.codes16 ? a.codes16[gb + q * K + t] == 65535 : a.codes[gb + q * K + t] == 255;
+          const double gv = __hiloint2double(__double2hiint(v) & (absent ? 0 : -1), __double2loint(v));
           sum = FM ? __builtin_fma(tv[q * K + t], gv, sum) : sum + tv[q * K + t] * gv;
         }
       }

@@ -298,6 +298,10 @@ def test_vector_q2_velocity_operator_in_the_line_walk_form(S, po, orc, monkeypat
         S.solve_(z, ns, r)
         err = capfd.readouterr().err
         assert ("wide-row z-walk" in err) == (mode == "walk"), (mode, err[-600:])
+        if mode == "walk":
+            # both operators of the patch sweep walk: A (8-bit codes) and the additive-Schwarz operator (too many distinct values for
+            # those: the auxiliary 16-bit coded table next to its plain one)
+            assert err.count("wide-row z-walk") >= 2, err[-1200:]
         res[mode] = (y, np.isfinite(yi), np.where(np.isfinite(yi), yi, 0.0), z, gmg.log.num_iters)
         ns.close()
     yo = orc.spmv(A, x)
