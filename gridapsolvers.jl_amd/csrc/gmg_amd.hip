@@ -6231,7 +6231,20 @@ int gmg_set_stream(gmg_handle_t h, void *stream)
     REQUIRE(!h->attached_to, GMG_ERR_STATE, "this handle is a diagonal block of a block preconditioner, which issues its work on the block handle's stream");
     HIP_CHECK(hipSetDevice(h->device));
     HIP_CHECK(hipStreamSynchronize(h->stream));             // nothing of ours is left on the stream we leave
-    h->stream = stream ? static_cast<hipStream_t>(stream) : h->own_stream;
+    // the two sentinels of the header are mapped by NAME (not by casting 1 / 2 to a handle: that would rest on the numeric values of
+    // hipStreamLegacy / hipStreamPerThread in this runtime), and whatever comes out is checked before it is accepted
+    hipStream_t s = h->own_stream;
+    if (stream == GMG_STREAM_LEGACY) s = hipStreamLegacy;
+    else if (stream == GMG_STREAM_PER_THREAD) s = hipStreamPerThread;
+    else if (stream) s = static_cast<hipStream_t>(stream);
+    if (s != h->own_stream) {
+      const hipError_t q = hipStreamQuery(s);
+      if (q != hipSuccess && q != hipErrorNotReady) {
+        (void)hipGetLastError();
+        throw GmgError{GMG_ERR_INVALID, std::string("gmg_set_stream: not a usable HIP stream (") + hipGetErrorString(q) + ")"};
+      }
+    }
+    h->stream = s;
   });
 }
 
