@@ -746,4 +746,34 @@ def fold_ranks(locals_):
     h0 = locals_[0]
     return dict(levels=levels, rep_from=rep_from, rep_gid=np.ascontiguousarray(np.concatenate([h["rep_gid"] for h in locals_]), dtype=np.int64),
                 cells=h0["cells"], grid=h0["grid"], order=h0["order"], rank=0, nranks=2, depths=h0["depths"], krylov=None, sub=None,
-                folded_from=W, structured=True)
+                folded_from=W, structured=True, cmap=cmap)
+
+
+def fold_patch_tables(folded, lengths=None):
+    """Vertex-star patch tables of a folded hierarchy (fold_ranks) for DistributedGMG(patch_tables=...): per partitioned own | ghost level the
+    patches every rank OWNS (local_vertex_star_patches) stacked in rank order, their dofs taken through the rank's column map into the folded
+    [own | ghost] numbering, and their matrices assembled by the driver from the global operator (a rank's local matrix lacks the rows of
+    ghost dofs: PatchSolvers.jl:137-150) -- exactly what DistributedGMG builds for one rank; replicated levels get the global table.
+    The patch smoother of such a level needs consistent!(r) before the local solves AND assemble!(dx) after them (PatchSolvers.jl:227-258):
+    over the loopback communicator both directions of the halo run as self-messages."""
+    W, order, grid = folded["folded_from"], folded["order"], folded["grid"]
+    levels = folded["levels"]
+    out = []
+    for l, L in enumerate(levels[:-1]):
+        cells_l = folded["cells"][l]
+        if L.replicated:
+            pp, pd = po.vertex_star_patches(cells_l, order)
+            out.append((pp, pd.astype(np.int64), None))
+            continue
+        assert not getattr(L, "overlap", False), "overlapping levels take their patches from the extended box (DistributedGMG does that itself)"
+        Ag = po.poisson_matrix(cells_l, order, lengths).to_scipy().tocsr()
+        ptr, dofs, blocks = [np.zeros(1, dtype=np.int64)], [], []
+        for a in range(W):
+            pp, pl, pg = local_vertex_star_patches(cells_l, order, grid, a)
+            ptr.append(pp[1:] + ptr[-1][-1])
+            dofs.append(folded["cmap"][l][a][pl.astype(np.int64)])
+            for p_ in range(pp.size - 1):
+                g_ = pg[pp[p_]:pp[p_ + 1]]
+                blocks.append(Ag[g_][:, g_].toarray().reshape(-1, order="F"))
+        out.append((np.concatenate(ptr), np.concatenate(dofs).astype(np.int64), np.ascontiguousarray(np.concatenate(blocks)) if blocks else np.zeros(0)))
+    return out

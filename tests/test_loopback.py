@@ -159,3 +159,40 @@ def test_bench_prints_exactly_one_line_on_stdout_even_when_rccl_prints_its_banne
     lb = d["rccl_loopback"]
     assert lb["rccl_ranks"] == 1 and lb["virtual_ranks"] == 8 and lb["bitwise_equal_host_transport"] is True and lb["exchanges_per_solve"] > 20
     assert "RCCL version" in out.stderr          # (the banner exists -- and went to stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.child_process
+@pytest.mark.parametrize("cells,W", [((8, 8, 8), 8), ((12, 8, 8), 2)])
+def test_patch_smoother_consistent_and_assemble_over_rccl_loopback(pkg, po, orc, cells, W):
+    """The distributed patch smoother (PatchSolvers.jl:227-258: consistent!(r) -> local patch solves -> assemble!(dx) -> consistent!(dx) inside
+    r -= A dx) with BOTH directions of the halo over RCCL: Q2, vertex-star patches owned per rank with driver-assembled matrices, FGMRES(5)
+    outside, 2 x 2 x 2 and 2 x 1 x 1 partitions folded onto the GPU.  Bit-identical to the host-staged loopback; iteration count and solution
+    of the serial oracle."""
+    pa, mg = _mods(pkg)
+    import torch
+    nlev, order = 2, 2
+    F = _folded(pa, cells, nlev, W, order=order)
+    tabs = pa.fold_patch_tables(F)
+    H = po.build_hierarchy(cells, nlev, order)
+    b = po.dirichlet_lift_rhs(cells, order)
+    osm = [orc.Smoother(orc.PATCH, 5, 0.2, *po.vertex_star_patches(H["ncells"][l], order)) for l in range(nlev - 1)]
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], pre_smoothers=osm, maxiter=1)
+    xo, nit, flag, hist = orc.fgmres_solve(H["mats"][0], b, Pr=go, m=5, maxiter=30, atol=1e-14, rtol=1e-8)
+    res = {}
+    for tr in ("host_loopback", "rccl_loopback"):
+        g = mg.DistributedGMG(cells, nlev, 0, 2, device_id=0, transport=tr, local_hierarchy=F, cells_global=cells, order=order, smoother="patch",
+                              niter=5, omega=0.2, patch_tables=tabs)
+        bb = torch.from_numpy(g.rhs_lin()).cuda()
+        x = torch.zeros(g.n_own, dtype=torch.float64, device="cuda")
+        ex0 = g.comm_stats()[0]
+        log = g.fgmres_solve(bb, x, m=5, maxiter=30, atol=1e-14, rtol=1e-8)
+        torch.cuda.synchronize()
+        res[tr] = (x.cpu().numpy(), log.num_iters, np.array(log.residuals[: log.num_iters + 1]), g.comm_stats()[0] - ex0, g.comm_info())
+        g.close()
+    h, r = res["host_loopback"], res["rccl_loopback"]
+    assert r[4]["transport"] == "rccl" and r[4]["rccl_comm_count"] == 1
+    assert r[1] == h[1] == nit and r[3] == h[3] > 10 * nit
+    assert np.array_equal(r[0], h[0]) and np.array_equal(r[2], h[2])
+    gid = F["levels"][0].own_gid
+    assert np.max(np.abs(r[2] - hist) / hist) < 1e-8 and rel_err(r[0], xo[gid]) < 1e-9
