@@ -132,6 +132,7 @@ SYMBOLS = {
     "gmg_block_last_error": [C.c_void_p],
     "gmg_block_comm_init_rccl": [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int],
     "gmg_block_comm_init_host": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "gmg_block_comm_set_loopback": [C.c_void_p, C.c_int],
     "gmg_block_set_partition": [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "gmg_block_set_system_block": [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_int, C.c_int],

@@ -391,6 +391,14 @@ int gmg_block_comm_init_host(gmg_block_handle_t h, int rank, int nranks, gmg_hos
   h->setup_done = false;
   return st;
 }
+int gmg_block_comm_set_loopback(gmg_block_handle_t h, int virtual_nranks)
+{
+  if (!h) return GMG_ERR_INVALID;
+  const int st = gmg_comm_set_loopback(&h->eng, virtual_nranks);
+  if (st != GMG_OK) h->err = h->eng.err;
+  h->setup_done = false;
+  return st;
+}
 int gmg_block_set_partition(gmg_block_handle_t h, int j, int64_t n_own, int64_t n_ghost, int nnbr, const int32_t *nbr_rank,
                             const int64_t *snd_ptr, const int64_t *snd_idx, const int64_t *rcv_ptr)
 {

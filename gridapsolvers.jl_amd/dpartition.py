@@ -19,7 +19,7 @@ import scipy.sparse as sp
 
 from . import poisson as po
 
-__all__ = ["Space", "partition_spaces", "local_operator", "local_patches", "OverlapSpace"]
+__all__ = ["Space", "partition_spaces", "local_operator", "local_patches", "OverlapSpace", "FoldedSpace", "stack_rows"]
 
 
 class Space:
@@ -221,3 +221,52 @@ def sliced_operator(M, rows, colmap=None, keep_row=None, ncols=None, strict_rows
     L = sp.csr_matrix((v[keep], (r[keep], c[keep])), shape=(len(rows), nc))
     L.sort_indices()
     return po.CSR(L.shape, L.indptr.astype(np.int64), L.indices.astype(np.int32), L.data)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# folding a partition onto ONE rank (gmg_comm_set_loopback; partition.fold_ranks is the structured-grid twin)
+# ----------------------------------------------------------------------------------------------------------------------
+def stack_rows(mats, maps, ncols):
+    """rows of the ranks' matrices stacked in rank order, columns through the rank's local -> folded map (None: unchanged)"""
+    ptr, idx, val, base = [np.zeros(1, dtype=np.int64)], [], [], 0
+    for M, m in zip(mats, maps):
+        ptr.append(M.ptr[1:] + base)
+        base += M.nnz
+        idx.append(M.idx.astype(np.int64) if m is None else m[M.idx])
+        val.append(M.val)
+    return po.CSR((sum(M.shape[0] for M in mats), ncols), np.concatenate(ptr), np.concatenate(idx), np.concatenate(val))
+
+
+class FoldedSpace:
+    """A partitioned Space seen from ONE rank whose every neighbour is itself: the ranks' owned dofs stacked in rank order, their ghosts
+    stacked behind them; one message per (receiving rank, neighbour) pair in the order the folded ghosts are stored, its send list = what
+    the neighbour sends, with the neighbour's offset -- so message k's send segment lands in receive segment k (how a self send / receive
+    pairs up).  cmap[r] maps rank r's [own | ghost] numbering into the folded one; every neighbour is named rank 1."""
+
+    def __init__(self, S):
+        W = S.nranks
+        no = np.array([S.n_own(r) for r in range(W)], dtype=np.int64)
+        ng = np.array([S.n_ghost(r) for r in range(W)], dtype=np.int64)
+        off, goff = np.concatenate([[0], np.cumsum(no)]), np.concatenate([[0], np.cumsum(ng)])
+        self.n_own, self.n_ghost = int(off[-1]), int(goff[-1])
+        self.cmap = [np.concatenate([off[r] + np.arange(no[r], dtype=np.int64), off[-1] + goff[r] + np.arange(ng[r], dtype=np.int64)]) for r in range(W)]
+        self.own_gid = np.concatenate([S.own[r] for r in range(W)])
+        snd, sp, rp = [], [0], [0]
+        for a in range(W):
+            pa_ = S.plan[a]
+            for k, q in enumerate(pa_["nbr_rank"]):
+                pq = S.plan[int(q)]
+                kq = int(np.nonzero(pq["nbr_rank"] == a)[0][0])
+                sseg = off[int(q)] + pq["snd_idx"][pq["snd_ptr"][kq]:pq["snd_ptr"][kq + 1]]
+                nr = int(pa_["rcv_ptr"][k + 1] - pa_["rcv_ptr"][k])
+                assert sseg.size == nr
+                snd.append(sseg); sp.append(sp[-1] + sseg.size); rp.append(rp[-1] + nr)
+        self.nbr_rank = np.ones(len(snd), dtype=np.int32)
+        self.snd_ptr, self.rcv_ptr = np.asarray(sp, dtype=np.int64), np.asarray(rp, dtype=np.int64)
+        self.snd_idx = np.concatenate(snd).astype(np.int64) if snd else np.zeros(0, np.int64)
+        assert self.rcv_ptr[-1] == self.n_ghost
+
+    def plan_into(self, obj):
+        obj.n_own, obj.n_ghost = self.n_own, self.n_ghost
+        obj.nbr_rank, obj.snd_ptr, obj.snd_idx, obj.rcv_ptr = self.nbr_rank, self.snd_ptr, self.snd_idx, self.rcv_ptr
+        return obj

@@ -788,7 +788,17 @@ class DistributedBlockSolver:
         self.h = h
         self._keep = []
         if gmg.world > 1:
-            if gmg.transport == "rccl":
+            if gmg.transport == "rccl_loopback":
+                path = rccl_path().encode()
+                uid = C.create_string_buffer(128)
+                abi.check(None, lib.gmg_comm_unique_id(path, uid))
+                abi.check_block(h, lib.gmg_block_comm_init_rccl(h, path, bytes(uid.raw), 0, 1))
+                abi.check_block(h, lib.gmg_block_comm_set_loopback(h, gmg.world))
+            elif gmg.transport == "host_loopback":
+                hb = gmg._host
+                abi.check_block(h, lib.gmg_block_comm_init_host(h, 0, 1, C.cast(hb.exchange_cb, C.c_void_p), C.cast(hb.allreduce_cb, C.c_void_p), None))
+                abi.check_block(h, lib.gmg_block_comm_set_loopback(h, gmg.world))
+            elif gmg.transport == "rccl":
                 import torch.distributed as dist
                 path = rccl_path().encode()
                 uid = C.create_string_buffer(128)

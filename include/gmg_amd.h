@@ -525,6 +525,8 @@ GMG_API const char *gmg_block_last_error(gmg_block_handle_t h);
 GMG_API int gmg_block_comm_init_rccl(gmg_block_handle_t h, const char *rccl_path, const char *unique_id128, int rank, int nranks);
 GMG_API int gmg_block_comm_init_host(gmg_block_handle_t h, int rank, int nranks, gmg_host_exchange_fn exchange,
                                      gmg_host_allreduce_fn allreduce, void *ctx);
+/* gmg_comm_set_loopback for a block handle: its own communicator of one rank serves a folded partition (see there). */
+GMG_API int gmg_block_comm_set_loopback(gmg_block_handle_t h, int virtual_nranks);
 GMG_API int gmg_block_set_partition(gmg_block_handle_t h, int j, int64_t n_own, int64_t n_ghost, int nnbr,
                                     const int32_t *nbr_rank, const int64_t *snd_ptr, const int64_t *snd_idx,
                                     const int64_t *rcv_ptr);

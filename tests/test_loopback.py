@@ -196,3 +196,122 @@ def test_patch_smoother_consistent_and_assemble_over_rccl_loopback(pkg, po, orc,
     assert np.array_equal(r[0], h[0]) and np.array_equal(r[2], h[2])
     gid = F["levels"][0].own_gid
     assert np.max(np.abs(r[2] - hist) / hist) < 1e-8 and rel_err(r[0], xo[gid]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.child_process
+@pytest.mark.parametrize("n,nlev,W", [(16, 3, 4), (8, 2, 2)])
+def test_distributed_stokes_block_solver_over_rccl_loopback(pkg, po, orc, n, nlev, W):
+    """BASELINE configs[4] in its multi-rank form (test/Applications/mpi/StokesGMG.jl:5-12) with every exchange over RCCL, on one GPU: the
+    lid-driven-cavity Q2 / P1disc system partitioned by cell boxes over W ranks (dpartition.py) and folded onto one (FoldedSpace) --
+    vector-valued velocity GMG(maxiter 4) with owned vertex-star patch smoothers (driver-assembled matrices, consistent! + assemble!), the
+    DISTRIBUTED patch-corrected prolongation with the grad-div rhs form, CG-Jacobi pressure block, upper block-triangular preconditioner
+    (BlockTriangularSolvers.jl:216-242 on block vectors), FGMRES(20); the block handle's own communicator is a loopback one too
+    (gmg_block_comm_set_loopback).  Bit-identical to the host-staged loopback; iteration count, history and solution of the serial oracle."""
+    import importlib
+    import torch
+    pa, mg = _mods(pkg)
+    st, dp = (importlib.import_module(pkg.__name__ + "." + m) for m in ("stokes", "dpartition"))
+    alpha = 1.0e3
+    grid = pa.rank_grid(W, 2)
+    sysd, Hv = st.stokes_system(n, alpha), st.velocity_hierarchy(n, nlev, alpha)
+    cells, npart = Hv["ncells"], nlev - 1
+    V = [dp.Space(f"v{l}", st.velocity_owner(cells[l], grid), W) for l in range(nlev)]
+    Pq = dp.Space("p", st.pressure_owner(n, grid), W)
+    A = sysd["A"]
+    sc = lambda M: M.to_scipy()
+    ops = [(sc(A[0][0]), V[0], V[0]), (sc(A[0][1]), V[0], Pq), (sc(A[1][0]), Pq, V[0]), (sc(sysd["Mp_scaled"]), Pq, Pq)]
+    pats, star_own, int_own = [], [], []
+    for l in range(npart):
+        ops += [(sc(Hv["mats"][l]), V[l], V[l]), (sc(Hv["graddiv"][l]), V[l], V[l]), (sc(Hv["restrictions"][l]), V[l + 1], V[l])]
+        if l + 1 < npart:
+            ops.append((sc(Hv["prolongations"][l]), V[l], V[l + 1]))
+        star_own.append(st.patch_owner(*Hv["star_patches"][l], V[l].owner))
+        int_own.append(st.patch_owner(*Hv["interior_patches"][l], V[l].owner))
+        pats += [(*Hv["star_patches"][l], V[l], star_own[l]), (*Hv["interior_patches"][l], V[l], int_own[l])]
+    dp.partition_spaces(V + [Pq], ops, pats)
+    FV, FP = [dp.FoldedSpace(V[l]) for l in range(npart)], dp.FoldedSpace(Pq)
+    R_ = range(W)
+
+    class LL:
+        overlap = False
+
+    def fold_patches(tabs, space, F, owners, Ag=None):
+        ptr, loc, blocks = [np.zeros(1, dtype=np.int64)], [], []
+        for r in R_:
+            p_, l_, _g, b_ = dp.local_patches(*tabs, space, owners, r, Ag)
+            ptr.append(p_[1:] + ptr[-1][-1]); loc.append(F.cmap[r][l_])
+            if b_ is not None:
+                blocks.append(b_)
+        return np.concatenate(ptr), np.concatenate(loc).astype(np.int64), (np.ascontiguousarray(np.concatenate(blocks)) if blocks else None)
+    levels, ptabs, ctabs = [], [], []
+    rep_gid = np.zeros(0, dtype=np.int64)
+    for l in range(nlev):
+        L = LL()
+        if l < npart:
+            F = FV[l]
+            F.plan_into(L)
+            nc = F.n_own + F.n_ghost
+            L.replicated = False
+            L.own_gid = F.own_gid
+            L.A = dp.stack_rows([dp.local_operator(sc(Hv["mats"][l]), V[l], V[l], r) for r in R_], F.cmap, nc)
+            if l + 1 < npart:
+                Fc = FV[l + 1]
+                L.P = dp.stack_rows([dp.local_operator(sc(Hv["prolongations"][l]), V[l], V[l + 1], r) for r in R_], Fc.cmap, Fc.n_own + Fc.n_ghost)
+                L.R = dp.stack_rows([dp.local_operator(sc(Hv["restrictions"][l]), V[l + 1], V[l], r) for r in R_], F.cmap, nc)
+            else:                                               # boundary to the replicated level: global coarse columns, the ranks' coarse rows stacked
+                Pg = sc(Hv["prolongations"][l]).tocsr()[F.own_gid]
+                Pg.sort_indices()
+                L.P = po.CSR(Pg.shape, Pg.indptr.astype(np.int64), Pg.indices.astype(np.int32), Pg.data)
+                L.R = dp.stack_rows([dp.local_operator(sc(Hv["restrictions"][l]), V[l + 1], V[l], r) for r in R_], F.cmap, nc)
+                rep_gid = np.concatenate([V[l + 1].own[r] for r in R_])
+            ptabs.append(fold_patches(Hv["star_patches"][l], V[l], F, star_own[l], sc(Hv["mats"][l])))
+            cptr, cloc, _ = fold_patches(Hv["interior_patches"][l], V[l], F, int_own[l])
+            ctabs.append((cptr, cloc, dp.stack_rows([dp.local_operator(sc(Hv["graddiv"][l]), V[l], V[l], r) for r in R_], F.cmap, nc)))
+        else:
+            L.replicated = True
+            L.A = Hv["mats"][l]
+            L.n_own, L.n_ghost = L.A.shape[0], 0
+            ptabs.append(None); ctabs.append(None)
+        levels.append(L)
+    local = dict(levels=levels, rep_from=npart, rep_gid=np.ascontiguousarray(rep_gid, dtype=np.int64), cells=[(c, c) for c in cells],
+                 grid=grid, order=2, rank=0, nranks=2)
+    lev1 = FP.plan_into(LL())
+    A01 = dp.stack_rows([dp.local_operator(sc(A[0][1]), V[0], Pq, r) for r in R_], FP.cmap, FP.n_own + FP.n_ghost)
+    A10 = dp.stack_rows([dp.local_operator(sc(A[1][0]), Pq, V[0], r) for r in R_], FV[0].cmap, FV[0].n_own + FV[0].n_ghost)
+    M11 = dp.stack_rows([dp.local_operator(sc(sysd["Mp_scaled"]), Pq, Pq, r) for r in R_], FP.cmap, FP.n_own + FP.n_ghost)
+    nu, npp = sysd["sizes"]
+    bg = sysd["b"]
+    b = np.concatenate([bg[:nu][FV[0].own_gid], bg[nu:][FP.own_gid]])
+    rg = np.random.default_rng(2).uniform(-1, 1, nu)
+    res = {}
+    for tr in ("host_loopback", "rccl_loopback"):
+        g = mg.DistributedGMG((n // grid[0], n // grid[1]), nlev, 0, 2, device_id=0, transport=tr, order=2, niter=10, omega=0.2, gmg_maxiter=4,
+                              gmg_rtol=1e-8, local_hierarchy=local, smoother="patch", patch_tables=ptabs, pcorr_tables=ctabs, cells_global=(n, n))
+        z = np.zeros(FV[0].n_own)
+        glog = g.apply(np.ascontiguousarray(rg[FV[0].own_gid]), z, maxiter=4)
+        blk = mg.DistributedBlockSolver(g, A01, A10, M11, levels[0], lev1, A11=None, coeffs=((1.0, 1.0), (0.0, 1.0)), half="upper", cg=(20, 1e-14, 1e-6))
+        x = np.zeros_like(b)
+        ex0 = g.comm_stats()[0]
+        log = blk.fgmres_solve(b, x, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+        res[tr] = (x, z, int(log.num_iters), np.array(log.residuals[: log.num_iters + 1]), int(glog.num_iters), g.comm_stats()[0] - ex0, g.comm_info())
+        blk.close(); g.close()
+    h, r = res["host_loopback"], res["rccl_loopback"]
+    assert r[6]["transport"] == "rccl" and r[6]["rccl_comm_count"] == 1
+    assert np.array_equal(r[0], h[0]) and np.array_equal(r[1], h[1]) and np.array_equal(r[3], h[3]) and r[2] == h[2] and r[5] == h[5] > 100
+    osm = [orc.Smoother(orc.PATCH, 10, 0.2, pp, pd) for pp, pd in Hv["star_patches"]]
+
+    def make_go():
+        return orc.GMG(Hv["mats"], Hv["prolongations"], Hv["restrictions"], pre_smoothers=osm, maxiter=4, rtol=1e-8,
+                       prolongation_patches=[(orc.PATCH, *Hv["interior_patches"][l], Hv["graddiv"][l]) for l in range(nlev - 1)])
+    zo, nit_g, _, _ = make_go().solve(rg)
+    Po = orc.BlockPreconditioner([nu, npp], [make_go(), (orc.BD_CG_JACOBI, sysd["Mp_scaled"], 20, 1e-14, 1e-6)],
+                                 {(0, 1): (A[0][1], 1.0), (1, 0): (A[1][0], 0.0)}, orc.UPPER)
+    K = sysd["K"]
+    xo, nit, flag, hist = orc.fgmres_solve(po.CSR(K.shape, K.indptr, K.indices, K.data), bg, Pr=Po, m=20, maxiter=100, atol=1e-10, rtol=1e-12)
+    xg, zg = np.zeros(nu + npp), np.zeros(nu)
+    xg[FV[0].own_gid] = r[0][: nu]; xg[nu + FP.own_gid] = r[0][nu:]
+    zg[FV[0].own_gid] = r[1]
+    assert r[4] == nit_g and rel_err(zg, zo) < 1e-8
+    assert r[2] == nit and rel_err(xg, xo) < 1e-6 and np.max(np.abs(r[3] - hist) / hist[0]) < 1e-6
+    assert np.linalg.norm(K @ xg - bg) < 1e-7
