@@ -71,12 +71,13 @@ def test_folded_partition_is_the_global_hierarchy(pkg, po, cells, nlev, W, depth
                 assert np.max(np.abs(_own(C, r) - want[C.own_gid])) < 1e-12
 
 
-def _solve(mg, F, cells, nlev, transport, W, env=None, options=None):
+def _solve(mg, F, cells, nlev, transport, W, env=None, options=None, cycle_type="v_cycle"):
     import torch
     old = {k: os.environ.get(k) for k in (env or {})}
     os.environ.update(env or {})
     try:
-        g = mg.DistributedGMG(cells, nlev, 0, 2, device_id=0, transport=transport, local_hierarchy=F, cells_global=cells, options=options)
+        g = mg.DistributedGMG(cells, nlev, 0, 2, device_id=0, transport=transport, local_hierarchy=F, cells_global=cells, options=options,
+                              cycle_type=cycle_type)
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
@@ -315,3 +316,24 @@ def test_distributed_stokes_block_solver_over_rccl_loopback(pkg, po, orc, n, nle
     assert r[4] == nit_g and rel_err(zg, zo) < 1e-8
     assert r[2] == nit and rel_err(xg, xo) < 1e-6 and np.max(np.abs(r[3] - hist) / hist[0]) < 1e-6
     assert np.linalg.norm(K @ xg - bg) < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.child_process
+@pytest.mark.parametrize("cycle", ["w_cycle", "f_cycle"])
+def test_w_and_f_cycles_over_rccl_loopback(pkg, po, orc, cycle):
+    """gmg_w_cycle! / gmg_f_cycle! (GMGLinearSolvers.jl:504-610) on a partitioned hierarchy -- two partitioned levels, the second leg of every
+    level re-smoothing and restricting again -- with every exchange and all-reduce over RCCL: the same bits as the host-staged loopback, the
+    oracle's iteration count and solution."""
+    pa, mg = _mods(pkg)
+    cells, nlev, W = (32, 32, 32), 4, 8
+    F = _folded(pa, cells, nlev, W, None, 2)                      # levels 0 and 1 partitioned, 2 and 3 replicated
+    H = po.build_hierarchy(cells, nlev, 1)
+    b = po.dirichlet_lift_rhs(cells, 1)
+    go = orc.GMG(H["mats"], H["prolongations"], H["restrictions"], maxiter=1, cycle={"w_cycle": orc.W_CYCLE, "f_cycle": orc.F_CYCLE}[cycle])
+    xo, nit, flag, hist = orc.cg_solve(H["mats"][0], b, Pl=go, maxiter=20, atol=1e-14, rtol=1e-6)
+    host = _solve(mg, F, cells, nlev, "host_loopback", W, cycle_type=cycle)
+    r = _solve(mg, F, cells, nlev, "rccl_loopback", W, cycle_type=cycle)
+    assert r["iters"] == host["iters"] == nit and r["exchanges"] == host["exchanges"] and r["allreduces"] == host["allreduces"]
+    assert np.array_equal(r["x"], host["x"]) and np.array_equal(r["hist"], host["hist"])
+    assert np.max(np.abs(r["hist"] - hist) / hist) < 1e-10 and rel_err(r["x"], xo[r["gid"]]) < 1e-10
