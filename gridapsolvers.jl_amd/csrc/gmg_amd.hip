@@ -5209,43 +5209,11 @@ void gmg_solver::setup()
       L.nbnd = (int64_t)brows.size();
       L.gh_rows = upload(brows); L.gh_ptr = upload(bptr); L.gh_col = upload(bcol); L.gh_val = upload(bval);
       if (opt_int("GMG_HALO_FIX_SELL", 1) && !brows.empty()) {
-        // slices of 64 boundary rows, column-major, padded with (column 0, value 0.0) behind every row's own length
-        const size_t nbr = brows.size(), nsl = (nbr + 63) / 64;
-        std::vector<int32_t> glen(nbr);
-        std::vector<int64_t> soff(nsl + 1, 0);
-        for (size_t sl = 0; sl < nsl; ++sl) {
-          int64_t w = 0;
-          for (size_t q = sl * 64; q < std::min(nbr, sl * 64 + 64); ++q) {
-            glen[q] = (int32_t)(bptr[q + 1] - bptr[q]);
-            w = std::max<int64_t>(w, glen[q]);
-          }
-          soff[sl + 1] = soff[sl] + 64 * w;
-        }
-        std::vector<int32_t> scol((size_t)soff[nsl], 0);
-        std::vector<double> sval((size_t)soff[nsl], 0.0);
-        for (size_t q = 0; q < nbr; ++q)
-          for (int64_t k = bptr[q]; k < bptr[q + 1]; ++k) {
-            const size_t at = (size_t)soff[q / 64] + (size_t)(k - bptr[q]) * 64 + (q & 63);
-            scol[at] = bcol[(size_t)k]; sval[at] = bval[(size_t)k];
-          }
-        L.gh_len = upload(glen); L.gh_soff = upload(soff); L.gh_scol = upload(scol);
-        // <= 256 distinct values (constant coefficients: a handful): one byte per entry into a dictionary
-        std::map<uint64_t, int> seen;
-        std::vector<double> dict;
-        std::vector<uint8_t> code(sval.size(), 0);
-        bool small = opt_int("GMG_HALO_FIX_SELL", 1) >= 1 && opt_int("GMG_HALO_FIX_DICT", 1) != 0;
-        for (size_t q = 0; q < sval.size() && small; ++q) {
-          uint64_t bits; std::memcpy(&bits, &sval[q], 8);
-          auto it = seen.find(bits);
-          if (it == seen.end()) {
-            if (dict.size() == 256) { small = false; break; }
-            it = seen.emplace(bits, (int)dict.size()).first;
-            dict.push_back(sval[q]);
-          }
-          code[q] = (uint8_t)it->second;
-        }
-        if (small) { dict.resize(256, 0.0); L.gh_scode = upload(code); L.gh_dict = upload(dict); }
-        else L.gh_sval = upload(sval);
+        // slices of 64 boundary rows, column-major, one byte per entry into a dictionary when the values allow: ONE builder for this
+        // level's fix-up and the split restriction's (build_ghost_fix) -- ghost_fix_sell_kernel reads both
+        GhostFix gf;
+        build_ghost_fix(gf, brows, bptr, bcol, bval);
+        L.gh_len = gf.len; L.gh_soff = gf.soff; L.gh_scol = gf.scol; L.gh_scode = gf.scode; L.gh_dict = gf.dict; L.gh_sval = gf.sval;
       }
       {   // send slots of every boundary row (fused pack): valid when every sent row is a boundary row
         HaloPlan &Hp = L.halo;
@@ -5298,6 +5266,7 @@ void gmg_solver::setup()
         std::vector<int32_t> brows, bcol;
         std::vector<int64_t> bptr(1, 0);
         std::vector<double> bval;
+        loc.col.reserve((size_t)L.hR.nnz()); loc.val.reserve((size_t)L.hR.nnz());   // (the ghost part is a boundary layer: it grows on demand)
         for (int64_t i = 0; i < L.hR.nrows; ++i) {
           bool any = false;
           for (int64_t k = L.hR.ptr[i]; k < L.hR.ptr[i + 1]; ++k) {
